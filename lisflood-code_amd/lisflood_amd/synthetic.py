@@ -1,0 +1,188 @@
+"""Seeded synthetic catchments for parity tests and bench.py.
+
+LDD families (all acyclic by construction -- every cell drains to a strictly lower neighbour of a
+potential phi, or is a pit):
+  shallow : phi = U(0,1)                                   -> ~11 % pits, NL ~ 7-8 ("random LDD")
+  deep    : phi = row-from-bottom + 0.25*col/W + 0.6*U(0,1) -> NL = H+2, ~W cells per level (sheet flow)
+Codes follow the LISFLOOD/PCRaster keypad convention of the reference
+(kinematic_wave_parallel.py:49-51): index 0..7 <-> codes [2,3,6,9,8,7,4,1], 5 = pit, and the
+(row, col) shifts IX_ADDS.  Ties are resolved to the first minimum in IX_ADDS order.
+
+The noise of row r depends only on (seed, r // ROWS_PER_CHUNK), so a rank of a row-block partition can
+generate exactly its own rows (plus halo rows) of the global raster without generating the rest.
+"""
+import numpy as np
+
+IX_ADDS = ((1, 0), (1, 1), (0, 1), (-1, 1), (-1, 0), (-1, -1), (0, -1), (1, -1))
+FLOW_CODE = (2, 3, 6, 9, 8, 7, 4, 1, 5)
+ROWS_PER_CHUNK = 256
+FAMILIES = ("shallow", "deep")
+
+
+def _noise_rows(seed, r0, r1, W):
+    """U(0,1) noise for global rows [r0, r1) -- chunk-seeded so any row range is reproducible."""
+    out = np.empty((r1 - r0, W))
+    c0 = r0 // ROWS_PER_CHUNK
+    c1 = (r1 - 1) // ROWS_PER_CHUNK
+    for c in range(c0, c1 + 1):
+        rng = np.random.default_rng([int(seed), int(c)])
+        blk = rng.random((ROWS_PER_CHUNK, W))
+        a = max(r0, c * ROWS_PER_CHUNK)
+        b = min(r1, (c + 1) * ROWS_PER_CHUNK)
+        out[a - r0:b - r0] = blk[a - c * ROWS_PER_CHUNK:b - c * ROWS_PER_CHUNK]
+    return out
+
+
+def potential_rows(family, H, W, seed, r0, r1):
+    """phi for global rows [r0, r1) of an H x W raster."""
+    u = _noise_rows(seed, r0, r1, W)
+    if family == "shallow":
+        return u
+    rows_from_bottom = (H - 1 - np.arange(r0, r1, dtype=np.float64))[:, None]
+    cols = np.arange(W, dtype=np.float64)[None, :]
+    if family == "deep":
+        return rows_from_bottom + 0.25 * cols / W + 0.6 * u
+    raise ValueError("unknown LDD family %r" % (family,))
+
+
+def make_ldd(family, H, W, seed, r0=0, r1=None, land_mask=None):
+    """uint8 LDD codes for global rows [r0, r1) of the H x W synthetic raster (all land unless
+    land_mask[H, W] is given: non-land cells get code 0 and never receive flow)."""
+    if r1 is None:
+        r1 = H
+    out = np.empty((r1 - r0, W), np.uint8)
+    step = 1024
+    for a in range(r0, r1, step):
+        b = min(r1, a + step)
+        ga, gb = max(0, a - 1), min(H, b + 1)
+        phi = potential_rows(family, H, W, seed, ga, gb)
+        if land_mask is not None:
+            phi = np.where(land_mask[ga:gb], phi, np.inf)
+        pad = np.full((gb - ga + 2, W + 2), np.inf)
+        pad[1:-1, 1:-1] = phi
+        # rows of `pad` that correspond to global rows [a, b)
+        o = a - ga + 1
+        n = b - a
+        centre = pad[o:o + n, 1:-1]
+        best = centre.copy()
+        code = np.full((n, W), FLOW_CODE[8], np.uint8)
+        for k, (dr, dc) in enumerate(IX_ADDS):
+            nb = pad[o + dr:o + dr + n, 1 + dc:1 + dc + W]
+            better = nb < best          # strict: first minimum in IX_ADDS order wins ties
+            best = np.where(better, nb, best)
+            code[better] = FLOW_CODE[k]
+        if land_mask is not None:
+            code[~land_mask[a:b]] = 0
+        out[a - r0:b - r0] = code
+    return out
+
+
+def router_params(N, seed=3, beta=0.6, dt=3600.0):
+    """alpha ~ logU(0.4,16), dx ~ U(500,15000), Q0 = (A0/alpha)^(1/beta) with A0 ~ logU(0.05,500)."""
+    rng = np.random.default_rng(seed)
+    alpha = np.exp(rng.uniform(np.log(0.4), np.log(16.0), N))
+    dx = rng.uniform(500.0, 15000.0, N)
+    a0 = np.exp(rng.uniform(np.log(0.05), np.log(500.0), N))
+    q0 = (a0 / alpha) ** (1.0 / beta)
+    return dict(alpha=alpha, dx=dx, Q0=q0, beta=beta, dt=dt)
+
+
+def lateral_inflow(N, step, seed=4, hi=2e-4):
+    """specific lateral inflow q ~ U(0, 2e-4) [m3 s-1 m-1], redrawn each step (seed 4 + step)."""
+    return np.random.default_rng(seed + step).uniform(0.0, hi, N)
+
+
+def soil_params(N, V=3, L=3, seed=11, frozen_frac=0.1, zero_pore_frac=0.02):
+    """Synthetic soil-column inputs in the layout of soilColumnsWaterBalance (soilloop.py:79-99).
+
+    Returns a dict whose keys are exactly the reference's argument names.  Ranges follow SURVEY.md
+    section 8(d): theta_s 0.35-0.5, theta_r 0.02-0.08, lambda 0.1-0.4, KSat 5-500 mm/d, depths
+    50 / 100-600 / 300-1500 mm, b 0.1-0.8, Rain 0-30 mm, 10 % frozen.
+    """
+    rng = np.random.default_rng(seed)
+    d = {}
+    depth1a = np.full((L, N), 50.0)
+    depth1b = rng.uniform(100.0, 600.0, (L, N))
+    depth2 = rng.uniform(300.0, 1500.0, (L, N))
+    zero = rng.random((L, N)) < zero_pore_frac
+    depth1b = np.where(zero, 0.0, depth1b)
+    for name, depth in (("1a", depth1a), ("1b", depth1b), ("2", depth2)):
+        ths = rng.uniform(0.35, 0.5, (L, N))
+        thr = rng.uniform(0.02, 0.08, (L, N))
+        lam = rng.uniform(0.1, 0.4, (L, N))
+        m = lam / (lam + 1.0)
+        d["SoilDepth" + name] = depth
+        d["WS" + name] = ths * depth
+        d["WRes" + name] = thr * depth
+        fc = thr + (ths - thr) * rng.uniform(0.45, 0.7, (L, N))
+        wp = thr + (ths - thr) * rng.uniform(0.1, 0.3, (L, N))
+        d["WFC" + name] = fc * depth
+        d["WWP" + name] = wp * depth
+        d["KSat" + name] = np.exp(rng.uniform(np.log(5.0), np.log(500.0), (L, N)))
+        d["GenuM" + name] = m
+        d["GenuInvM" + name] = 1.0 / m
+        d["PoreSpaceNotZero" + name] = (ths * depth) != 0
+    for k in ("WS", "WRes", "WFC", "WWP"):
+        d[k + "1"] = d[k + "1a"] + d[k + "1b"]
+    d["StoreMaxPervious"] = d["WS1"] / rng.uniform(0.2, 1.0, (L, N)) * 0.5
+    sat = rng.uniform(0.05, 1.0, (3, V, N))
+    lu = np.arange(V) % L
+    d["index_landuse_all"] = lu.astype(np.int64)
+    d["is_irrigated"] = np.array([(v % L) == 2 for v in range(V)], bool)
+    d["is_paddy_irrig"] = np.zeros(V, bool)
+    d["paddy_inactive"] = np.zeros((1, N), bool)
+    for i, name in enumerate(("1a", "1b", "2")):
+        d["W" + name] = d["WRes" + name][lu] + sat[i] * (d["WS" + name][lu] - d["WRes" + name][lu])
+    d["W1"] = d["W1a"] + d["W1b"]
+    d["DSLR"] = 1.0 + np.floor(rng.uniform(0.0, 6.0, (V, N)))
+    d["UZ"] = rng.uniform(0.0, 20.0, (V, N))
+    d["LeafDrainage"] = rng.uniform(0.0, 2.0, (V, N))
+    d["Interception"] = rng.uniform(0.0, 1.0, (V, N))
+    d["ESMax"] = rng.uniform(0.0, 4.0, (V, N))
+    rain = rng.uniform(0.0, 30.0, N)
+    rain[rng.random(N) < 0.4] = 0.0
+    d["Rain"] = rain
+    d["SnowMelt"] = np.where(rng.random(N) < 0.1, rng.uniform(0.0, 5.0, N), 0.0)
+    d["isFrozenSoil"] = rng.random(N) < frozen_frac
+    d["b_Xinanjiang"] = rng.uniform(0.1, 0.8, N)
+    d["PowerInfPot"] = rng.uniform(1.0, 3.0, N)
+    d["PowerPrefFlow"] = rng.uniform(1.0, 6.0, N)
+    d["UpperZoneK"] = rng.uniform(0.01, 0.3, N)
+    d["GwPercStep"] = rng.uniform(0.1, 1.5, N)
+    d["DtDay"] = 1.0
+    d["AvWaterThreshold"] = 1.0
+    d["CourantCrit"] = 0.4
+    d["DrainedFraction"] = 0.1
+    for k in ("AvailableWaterForInfiltration", "ESAct", "PrefFlow", "Infiltration", "Theta1a", "Theta1b",
+              "Theta2", "Sat1a", "Sat1b", "Sat1", "Sat2", "SeepTopToSubA", "SeepTopToSubB", "SeepSubToGW",
+              "UZOutflow", "GwPercUZLZ"):
+        d[k] = np.zeros((V, N))
+    return d
+
+
+# positional order of soilColumnsWaterBalance (soilloop.py:79-99)
+SOIL_ARG_ORDER = (
+    "index_landuse_all is_irrigated is_paddy_irrig paddy_inactive DtDay AvailableWaterForInfiltration Rain "
+    "SnowMelt LeafDrainage Interception DSLR AvWaterThreshold ESAct ESMax isFrozenSoil b_Xinanjiang "
+    "StoreMaxPervious PowerInfPot PrefFlow PowerPrefFlow Infiltration CourantCrit PoreSpaceNotZero1a "
+    "PoreSpaceNotZero1b PoreSpaceNotZero2 KSat1a KSat1b KSat2 GenuInvM1a GenuInvM1b GenuInvM2 GenuM1a GenuM1b "
+    "GenuM2 W1a W1b W1 W2 Theta1a Theta1b Theta2 Sat1a Sat1b Sat1 Sat2 SeepTopToSubA SeepTopToSubB SeepSubToGW "
+    "WRes1a WRes1b WRes1 WRes2 WWP1a WWP1b WWP1 WWP2 WFC1a WFC1b WFC1 WFC2 SoilDepth1a SoilDepth1b SoilDepth2 "
+    "WS1a WS1b WS1 WS2 UpperZoneK DrainedFraction GwPercStep UZOutflow UZ GwPercUZLZ").split()
+
+SOIL_WRITTEN = (
+    "AvailableWaterForInfiltration DSLR ESAct PrefFlow Infiltration W1a W1b W1 W2 Theta1a Theta1b Theta2 Sat1a "
+    "Sat1b Sat1 Sat2 SeepTopToSubA SeepTopToSubB SeepSubToGW UZOutflow UZ GwPercUZLZ").split()
+
+
+def interception_params(N, V=3, seed=21):
+    rng = np.random.default_rng(seed)
+    lai = rng.uniform(0.0, 8.0, (V, N))
+    lai[:, : N // 20] = rng.uniform(0.0, 0.1, (V, N // 20))          # SMax = 0 branch
+    lai[:, N // 20: N // 10] = rng.uniform(43.3, 50.0, (V, N // 10 - N // 20))  # saturated branch
+    rain = rng.uniform(0.0, 30.0, N)
+    rain[rng.random(N) < 0.4] = 0.0
+    return dict(
+        Interception=np.zeros((V, N)), TaInterception=np.zeros((V, N)), LeafDrainage=np.zeros((V, N)),
+        CumInterception=rng.uniform(0.0, 3.0, (V, N)) * (rng.random((V, N)) < 0.7),
+        LAI=lai, Rain=rain, TaInterceptionMax=rng.uniform(0.0, 3.0, (V, N)), drainageK=0.25)

@@ -1,0 +1,223 @@
+"""ctypes front-end of the CPU oracle (oracle/lf_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module -- as the
+checker / the reported CPU baseline, never as the path that is measured or shipped.  The product
+(lisflood-code_amd/) never imports it.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "liblf_oracle.so")
+
+_lib = None
+f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
+i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+
+
+def build(force=False):
+    src = os.path.join(HERE, "lf_oracle.c")
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", HERE, "-B", "liblf_oracle.so"], stdout=subprocess.DEVNULL)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            build()
+        _lib = C.CDLL(LIB)
+        _lib.lfo_lookups.restype = C.c_int
+        _lib.lfo_orders.restype = C.c_int64
+    return _lib
+
+
+def _f(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _u8(a):
+    return np.ascontiguousarray(np.asarray(a).astype(np.uint8))
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def lookups(codes, mask):
+    """-> downstream_lookup[N] float64, upstream_lookup[N,K] int64 (kinematic_wave_parallel.py:73-90)."""
+    mask = np.asarray(mask, bool)
+    H, W = mask.shape
+    N = int(mask.sum())
+    codes = _f(codes)
+    m8 = _u8(mask)
+    down = np.empty(N, np.int64)
+    ups = np.empty((N, 8), np.int64)
+    nups = np.empty(N, np.int64)
+    K = lib().lfo_lookups(_ptr(codes), _ptr(m8), C.c_int(H), C.c_int(W), _ptr(down), _ptr(ups), _ptr(nups))
+    return down.astype(np.float64), np.ascontiguousarray(ups[:, :K]), nups
+
+
+def orders(downstream_lookup, upstream_lookup8, num_ups):
+    N = downstream_lookup.size
+    down = np.ascontiguousarray(downstream_lookup, dtype=np.int64)
+    ups = np.full((N, 8), -1, np.int64)
+    ups[:, :upstream_lookup8.shape[1]] = upstream_lookup8
+    po = np.empty(N, np.int64)
+    ss = np.empty(2 * max(N, 1), np.int64)
+    NL = lib().lfo_orders(_ptr(down), _ptr(ups), _ptr(np.ascontiguousarray(num_ups, dtype=np.int64)),
+                          C.c_int64(N), _ptr(po), _ptr(ss))
+    if NL < 0:
+        raise ValueError("cyclic LDD")
+    return po, ss[:2 * NL].reshape(NL, 2).copy()
+
+
+class kinematicWave:
+    """CPU oracle with the reference's interface (kinematic_wave_parallel.py:114-184)."""
+
+    def __init__(self, compressed_encoded_ldd, land_mask, alpha_channel, beta, space_delta, time_delta,
+                 alpha_floodplains=None, flagnancheck=False):
+        self.space_delta = space_delta
+        self.beta = beta
+        self.a_dx_div_dt_channel = _f(alpha_channel * space_delta / time_delta)
+        self.b_a_dx_div_dt_channel = _f(beta * self.a_dx_div_dt_channel)
+        if alpha_floodplains is not None:
+            self.a_dx_div_dt_floodplains = _f(alpha_floodplains * space_delta / time_delta)
+            self.b_a_dx_div_dt_floodplains = _f(beta * self.a_dx_div_dt_floodplains)
+        self.downstream_lookup, self.upstream_lookup, self.num_upstream_pixels = lookups(compressed_encoded_ldd,
+                                                                                         land_mask)
+        ups8 = np.full((self.num_upstream_pixels.size, 8), -1, np.int64)
+        ups8[:, :self.upstream_lookup.shape[1]] = self.upstream_lookup
+        self.pixels_ordered, self.order_start_stop = orders(self.downstream_lookup, ups8, self.num_upstream_pixels)
+        self._scratch = np.empty(self.num_upstream_pixels.size)
+        self.last_iters = (0, 0)
+
+    def kinematicWaveRouting(self, discharge, specific_lateral_inflow, section="main_channel"):
+        if section == "main_channel":
+            a, ba = self.a_dx_div_dt_channel, self.b_a_dx_div_dt_channel
+        elif section == "floodplains":
+            a, ba = self.a_dx_div_dt_floodplains, self.b_a_dx_div_dt_floodplains
+        else:
+            raise Exception("The section parameter must be either 'main_channel' or 'floodplain'!")
+        assert discharge.dtype == np.float64 and discharge.flags.c_contiguous
+        q = _f(specific_lateral_inflow)
+        N = discharge.size
+        if np.ndim(self.space_delta) == 0:
+            dxp, dxs = None, float(self.space_delta)
+        else:
+            dxa = _f(self.space_delta)
+            dxp, dxs = _ptr(dxa), 0.0
+        it = np.zeros(2, np.int64)
+        K = self.upstream_lookup.shape[1]
+        lib().lfo_route(_ptr(discharge), _ptr(q), dxp, C.c_double(dxs), _ptr(a), _ptr(ba), C.c_double(self.beta),
+                        _ptr(self.upstream_lookup), C.c_int(K), _ptr(self.num_upstream_pixels),
+                        _ptr(self.pixels_ordered), _ptr(self.order_start_stop), C.c_int64(self.order_start_stop.shape[0]),
+                        C.c_int64(N), _ptr(self._scratch), _ptr(it))
+        self.last_iters = (int(it[0]), int(it[1]))
+
+
+def interception(Interception, TaInterception, LeafDrainage, CumInterception, LAI, Rain, TaInterceptionMax, drainageK):
+    V, N = Interception.shape
+    lib().lfo_interception(_ptr(Interception), _ptr(TaInterception), _ptr(LeafDrainage), _ptr(CumInterception),
+                           _ptr(_f(LAI)), _ptr(_f(Rain)), _ptr(_f(TaInterceptionMax)), C.c_double(drainageK),
+                           C.c_int64(V), C.c_int64(N))
+
+
+_SOIL_FIELDS = (
+    # order of lfo_soil_args in lf_oracle.c
+    "PoreSpaceNotZero1a PoreSpaceNotZero1b PoreSpaceNotZero2 "
+    "KSat1a KSat1b KSat2 GenuInvM1a GenuInvM1b GenuInvM2 GenuM1a GenuM1b GenuM2 "
+    "WRes1a WRes1b WRes1 WRes2 WWP1a WWP1b WWP1 WWP2 WFC1a WFC1b WFC1 WFC2 "
+    "SoilDepth1a SoilDepth1b SoilDepth2 WS1a WS1b WS1 WS2 StoreMaxPervious "
+    "Rain SnowMelt b_Xinanjiang PowerInfPot PowerPrefFlow UpperZoneK GwPercStep isFrozenSoil "
+    "LeafDrainage Interception ESMax "
+    "AvailableWaterForInfiltration DSLR ESAct PrefFlow Infiltration W1a W1b W1 W2 "
+    "Theta1a Theta1b Theta2 Sat1a Sat1b Sat1 Sat2 SeepTopToSubA SeepTopToSubB SeepSubToGW "
+    "UZOutflow UZ GwPercUZLZ "
+    "index_landuse_all is_irrigated is_paddy_irrig paddy_inactive").split()
+_SOIL_WRITTEN = set(
+    "AvailableWaterForInfiltration DSLR ESAct PrefFlow Infiltration W1a W1b W1 W2 Theta1a Theta1b Theta2 Sat1a "
+    "Sat1b Sat1 Sat2 SeepTopToSubA SeepTopToSubB SeepSubToGW UZOutflow UZ GwPercUZLZ".split())
+
+
+class _SoilArgs(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in _SOIL_FIELDS] + [
+        ("DtDay", C.c_double), ("AvWaterThreshold", C.c_double), ("CourantCrit", C.c_double),
+        ("DrainedFraction", C.c_double), ("V", C.c_int64), ("L", C.c_int64), ("N", C.c_int64)]
+
+
+def soil_columns(d):
+    """d: dict keyed by the reference's argument names (soilloop.py:79-99); written arrays updated in place."""
+    a = _SoilArgs()
+    keep = []
+    for k in _SOIL_FIELDS:
+        v = d[k]
+        if k in _SOIL_WRITTEN:
+            assert v.dtype == np.float64 and v.flags.c_contiguous, k
+            arr = v
+        elif k == "index_landuse_all":
+            arr = np.ascontiguousarray(v, dtype=np.int64)
+        elif np.asarray(v).dtype == np.bool_ or np.asarray(v).dtype == np.uint8:
+            arr = _u8(v)
+        else:
+            arr = _f(v)
+        keep.append(arr)
+        setattr(a, k, arr.ctypes.data)
+    a.DtDay, a.AvWaterThreshold = float(d["DtDay"]), float(d["AvWaterThreshold"])
+    a.CourantCrit, a.DrainedFraction = float(d["CourantCrit"]), float(d["DrainedFraction"])
+    a.V, a.N = d["W1a"].shape
+    a.L = d["WS1a"].shape[0]
+    lib().lfo_soil_columns(C.byref(a))
+
+
+def upstream_sum(downstruct, w):
+    out = np.empty(w.size)
+    lib().lfo_upstream_sum(_ptr(np.ascontiguousarray(downstruct, dtype=np.int32)), _ptr(_f(w)), C.c_int64(w.size),
+                           _ptr(out))
+    return out
+
+
+class RoutingSubstep:
+    """Element-wise arithmetic of routing.dynamic (routing.py:512-603, 693-703) around an oracle router."""
+
+    def __init__(self, router, v):
+        self.r, self.v = router, v   # v: namespace with the reference's var names
+
+    def dynamic(self, split):
+        v, L = self.v, lib()
+        N = v.ChanQKin.size
+        n = C.c_int64(N)
+        side = np.empty(N)
+        L.lfo_sideflow(_ptr(_f(v.ToChanM3RunoffDt)), _ptr(_u8(v.IsChannelKinematic)), _ptr(_f(v.InvChanLength)),
+                       C.c_double(v.InvDtRouting), C.c_int(0 if split else 1), n, _ptr(side))
+        fix = lambda: L.lfo_main_fixup(_ptr(v.ChanQKin), _ptr(v.ChanM3Kin), _ptr(_f(v.ChanLength)),
+                                       _ptr(_f(v.ChannelAlpha)), _ptr(_f(v.InvChanLength)),
+                                       _ptr(_f(v.InvChannelAlpha)), C.c_double(v.Beta), C.c_double(v.InvBeta), n)
+        if not split:
+            self.r.kinematicWaveRouting(v.ChanQKin, side, "main_channel")
+            fix()
+            v.ChanQ = v.ChanQKin.copy()
+            v.sumDisDay += v.ChanQ
+        else:
+            s1, s2 = np.empty(N), np.empty(N)
+            L.lfo_split_sideflow(_ptr(side), _ptr(v.ChanM3Kin), _ptr(v.Chan2M3Kin), _ptr(_f(v.Chan2M3Start)),
+                                 _ptr(_f(v.M3Limit)), _ptr(_f(v.Chan2QStart)), _ptr(_f(v.InvChanLength)), n,
+                                 _ptr(s1), _ptr(s2))
+            v.Sideflow1Chan = s1
+            self.r.kinematicWaveRouting(v.ChanQKin, s1, "main_channel")
+            fix()
+            self.r.kinematicWaveRouting(v.Chan2QKin, s2, "floodplains")
+            v.ChanQ = np.empty(N)
+            L.lfo_floodplain_fixup(_ptr(v.Chan2QKin), _ptr(v.Chan2M3Kin), _ptr(v.CrossSection2Area), _ptr(v.ChanQ),
+                                   _ptr(v.ChanQKin), _ptr(_f(v.ChanLength)), _ptr(_f(v.ChannelAlpha2)),
+                                   _ptr(_f(v.InvChanLength)), _ptr(_f(v.InvChannelAlpha2)), _ptr(_f(v.Chan2M3Start)),
+                                   _ptr(_f(v.QLimit)), C.c_double(v.Beta), C.c_double(v.InvBeta), n)
+            v.sumDisDay += v.ChanQ
+        v.FlowVelocity, v.TravelDistance = np.empty(N), np.empty(N)
+        L.lfo_velocity(_ptr(v.ChanM3Kin), _ptr(v.ChanQKin), _ptr(_f(v.InvChanLength)), _ptr(_f(v.PixelArea)),
+                       C.c_double(v.DtSec), n, _ptr(v.FlowVelocity), _ptr(v.TravelDistance))

@@ -1,0 +1,45 @@
+"""Extract the LF_ETRS89_UseCase static maps the routing hot path needs into one small .npz.
+
+THIS CONTAINER ONLY. Run with the conda interpreter (the only one that has h5py):
+    /opt/conda/bin/python3.9 tests/golden/extract_etrs89.py
+Reads netCDF-4/HDF5 test maps from /root/reference/tests/data/LF_ETRS89_UseCase/maps (data files held
+by the reference's own tests -- fixtures, not source) and writes tests/golden/etrs89_static.npz.
+"""
+import os
+import numpy as np
+import h5py
+
+SRC = "/root/reference/tests/data/LF_ETRS89_UseCase/maps"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "etrs89_static.npz")
+
+FILES = {
+    "ldd": "ec_ldd.nc", "chan": "chan.nc", "chanlength": "chanlength.nc", "changrad": "changrad.nc",
+    "chanman": "ec_chanman.nc", "chanbw": "ec_chanbw.nc", "chanbnkf": "ec_chanbnkf.nc", "chans": "chans.nc",
+    "pixarea": "pixarea.nc", "pixleng": "pixleng.nc", "gradient": "gradient.nc",
+    "lakes": "ec_lakes.nc", "res": "ec_res.nc", "outlets": "ec_outlets.nc", "uparea": "ec_upArea.nc",
+    "calchanman1": "parameters/params_CalChanMan1.nc", "calchanman2": "parameters/params_CalChanMan2.nc",
+}
+
+def main_var(f):
+    best = None
+    for k, v in f.items():
+        if isinstance(v, h5py.Dataset) and v.ndim == 2:
+            best = k
+    return best
+
+out = {}
+for key, fn in FILES.items():
+    p = os.path.join(SRC, fn)
+    if not os.path.exists(p):
+        print("missing", p); continue
+    with h5py.File(p, "r") as f:
+        name = main_var(f)
+        ds = f[name]
+        arr = ds[...]
+        fill = ds.attrs.get("_FillValue", None)
+        print(key, fn, name, arr.dtype, arr.shape, "fill", fill)
+        out[key] = arr
+        if fill is not None:
+            out[key + "_fill"] = np.asarray(fill).reshape(-1)[:1]
+np.savez_compressed(OUT, **out)
+print("wrote", OUT, os.path.getsize(OUT))
