@@ -1,0 +1,227 @@
+#!/usr/bin/env python
+"""bench.py -- kinematic-wave routing throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W           # single GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   # row-block split
+
+A "step" is one kinematicWaveRouting call (one pass of the hot path over the whole raster): every land
+cell goes through one implicit Newton-Raphson solve = one cell-step.  Inputs (discharge, lateral
+inflow, parameters, graph) are resident in HBM when the timed region starts.  One JSON line is printed
+by rank 0.
+
+Workload at N=1: the 10000 x 10000 fp64 synthetic raster BASELINE.json quotes the metric on
+("random LDD" = `shallow` family, seed 1).  `--family deep` gives the level-sequential worst case
+(NL = H+2); a short run of it is reported under "other_workloads".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "lisflood-code_amd"))
+
+B_ALG = 48.0          # algorithmic bytes per cell-step
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=10000, help="raster is size x size cells")
+    ap.add_argument("--family", default="shallow", choices=["shallow", "deep"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads / soil kernel")
+    ap.add_argument("--cpu-sample", type=int, default=2000, help="CPU baseline raster is sample x sample")
+    return ap.parse_args()
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build_case(family, H, W):
+    from lisflood_amd import synthetic as syn
+    from lisflood_amd.kinematic_wave_parallel import Graph, kinematicWave
+    t = time.time()
+    seed = {"shallow": 1, "deep": 2}[family]
+    codes = syn.make_ldd(family, H, W, seed)
+    N = H * W
+    p = syn.router_params(N)
+    g = Graph(ldd_raster=codes)
+    kw = kinematicWave(None, None, p["alpha"], p["beta"], p["dx"], p["dt"], graph=g)
+    log("[bench] %s %dx%d: N=%d NL=%d K=%d built in %.1f s" % (family, H, W, N, g.num_levels, g.max_upstream,
+                                                               time.time() - t))
+    return kw, p, g
+
+
+def run_routing(kw, p, steps, warmup, nq=3, profile_steps=2):
+    """-> dict(ms_per_step, event_ms_per_step, prof) with inputs resident in HBM."""
+    from lisflood_amd import _lib
+    from lisflood_amd import synthetic as syn
+    N = kw.num_pixels
+    Q = _lib.DeviceArray.from_host(p["Q0"])
+    qs = [_lib.DeviceArray.from_host(syn.lateral_inflow(N, s)) for s in range(nq)]
+    for s in range(warmup):
+        kw.route_device(Q, qs[s % nq])
+    _lib.synchronize()
+    t0 = time.perf_counter()
+    _lib.timer_start()
+    for s in range(steps):
+        kw.route_device(Q, qs[s % nq])
+    ev_ms = _lib.timer_stop()
+    _lib.synchronize()
+    t1 = time.perf_counter()
+    stats = kw.last_launches()
+    # per-kernel durations with hipEvents on the launch stream (separate short pass: the event pairs
+    # add host work per launch, so they are kept out of the timed region)
+    kw.profile(True)
+    kw.profile_read(reset=True)
+    for s in range(profile_steps):
+        kw.route_device(Q, qs[s % nq])
+    _lib.synchronize()
+    prof = kw.profile_read(reset=True)
+    kw.profile(False)
+    Qh = Q.download()
+    ok = bool(np.isfinite(Qh).all() and (Qh >= 0).all())
+    for d in qs + [Q]:
+        d.free()
+    return dict(ms_per_step=(t1 - t0) * 1e3 / steps, event_ms_per_step=ev_ms / steps, prof=prof, stats=stats,
+                finite=ok)
+
+
+def roofline_of(res):
+    """Dominant sweep kernel: achieved algorithmic GB/s = 48 B x cells per launch / mean launch duration."""
+    prof = res["prof"]
+    wide, narrow = prof["wide_level"], prof["narrow_run"]
+    dom = wide if wide["ms"] >= narrow["ms"] else narrow
+    name = "k_level" if dom is wide else "k_levels_narrow"
+    if dom["launches"] == 0 or dom["ms"] == 0:
+        return None
+    cells_per_launch = dom["cells"] / dom["launches"]
+    ms_per_launch = dom["ms"] / dom["launches"]
+    achieved = B_ALG * cells_per_launch / (ms_per_launch * 1e-3) / 1e9
+    return dict(bound="hbm", kernel=name, achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit="GB/s",
+                frac=round(achieved / HBM_PEAK_GBS, 6), traffic=None,
+                launches_per_step=dom["launches"] and int(round(dom["launches"] / 2)),
+                mean_launch_us=round(ms_per_launch * 1e3, 3), cells_per_launch=round(cells_per_launch, 1),
+                alg_bytes_per_cell_step=B_ALG,
+                prep_ms_per_step=round(prof["prep"]["ms"] / max(prof["prep"]["launches"], 1), 4))
+
+
+def cpu_baseline(family, sample, steps=2):
+    """The oracle (C restatement of the reference algorithm, OpenMP level-parallel like numba prange)
+    timed on this host on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle
+    from lisflood_amd import synthetic as syn
+    oracle.build()
+    H = W = sample
+    seed = {"shallow": 1, "deep": 2}[family]
+    codes = syn.make_ldd(family, H, W, seed)
+    mask = np.ones((H, W), bool)
+    N = H * W
+    p = syn.router_params(N)
+    kw = oracle.kinematicWave(codes.reshape(-1).astype(np.float64), mask, p["alpha"], p["beta"], p["dx"], p["dt"])
+    Q = p["Q0"].copy()
+    q = syn.lateral_inflow(N, 0)
+    cores = os.cpu_count() or 1
+    kw.kinematicWaveRouting(Q, q)    # warm
+    t0 = time.perf_counter()
+    for s in range(steps):
+        kw.kinematicWaveRouting(Q, q)
+    dt_all = (time.perf_counter() - t0) / steps
+    os.environ["OMP_NUM_THREADS"] = "1"
+    import ctypes
+    try:
+        omp = ctypes.CDLL("libgomp.so.1")
+        omp.omp_set_num_threads(1)
+        t0 = time.perf_counter()
+        kw.kinematicWaveRouting(Q, q)
+        dt_one = time.perf_counter() - t0
+        omp.omp_set_num_threads(cores)
+    except OSError:
+        dt_one = float("nan")
+    return dict(value=round(N / dt_all / 1e6, 3), unit="Mcell-steps/s", cores=cores, kind="port",
+                sample="%dx%d %s raster, %d calls, OpenMP %d threads (1 thread: %.3f Mcell-steps/s); "
+                       "C restatement of the reference algorithm (oracle/lf_oracle.c), not numba"
+                       % (H, W, family, steps, cores, N / dt_one / 1e6),
+                newton_iters_mean=round(kw.last_iters[0] / N, 3), newton_iters_max=kw.last_iters[1])
+
+
+def soil_bench(N=4_000_000, steps=10):
+    """Secondary metric: soil column-steps/s (lf_soil.hip), 504 B algorithmic per (veg,pixel)-step."""
+    from lisflood_amd import _lib
+    from lisflood_amd import synthetic as syn
+    from lisflood_amd.soilloop import SoilColumnsDevice
+    d = syn.soil_params(N, seed=3)
+    dev = SoilColumnsDevice(d)
+    for _ in range(2):
+        dev.step()
+    _lib.synchronize()
+    _lib.timer_start()
+    for _ in range(steps):
+        dev.step()
+    ms = _lib.timer_stop() / steps
+    cols = 3 * N
+    gbs = 504.0 * cols / (ms * 1e-3) / 1e9
+    return dict(metric="soil Mcolumn-steps/s", value=round(cols / ms / 1e3, 2), ms_per_step=round(ms, 4),
+                columns=cols, alg_bytes_per_column_step=504, achieved_GBs=round(gbs, 1),
+                frac_hbm=round(gbs / HBM_PEAK_GBS, 4))
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus > 1 or world > 1:
+        from lisflood_amd import dist_bench
+        return dist_bench.main(a)
+    H = W = a.size
+    kw, p, g = build_case(a.family, H, W)
+    res = run_routing(kw, p, a.steps, a.warmup)
+    N = kw.num_pixels
+    value = N / res["ms_per_step"] / 1e3          # Mcell-steps/s
+    out = {
+        "metric": "Mcell-steps/s kinematic routing", "value": round(value, 2), "unit": "Mcell-steps/s",
+        "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(res["ms_per_step"], 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "%dx%d fp64 raster, %s LDD (seed %d), all land, beta=0.6, 1 router call per step"
+                               % (H, W, "random ('shallow')" if a.family == "shallow" else "sheet-flow ('deep')",
+                                  1 if a.family == "shallow" else 2),
+                   "cells": N, "levels": g.num_levels, "launches_per_step": res["stats"]["launches"],
+                   "parallelism": "1 GPU"},
+        "event_ms_per_step": round(res["event_ms_per_step"], 4),
+        "hbm_frac_whole_step": round(B_ALG * N / (res["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+        "finite": res["finite"],
+    }
+    out["roofline"] = roofline_of(res)
+    kw.close()
+    if not a.no_extra:
+        extra = {}
+        try:
+            other = "deep" if a.family == "shallow" else "shallow"
+            kw2, p2, g2 = build_case(other, H, W)
+            r2 = run_routing(kw2, p2, max(2, a.steps // 5), 1, nq=1, profile_steps=1)
+            extra[other] = dict(value=round(kw2.num_pixels / r2["ms_per_step"] / 1e3, 2), unit="Mcell-steps/s",
+                                ms_per_step=round(r2["ms_per_step"], 3), levels=g2.num_levels,
+                                launches_per_step=r2["stats"]["launches"], roofline=roofline_of(r2))
+            kw2.close()
+        except Exception as e:  # secondary numbers must never break the headline line
+            extra["error"] = repr(e)
+        try:
+            extra["soil"] = soil_bench()
+        except Exception as e:
+            extra["soil_error"] = repr(e)
+        out["other_workloads"] = extra
+    if not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(a.family, a.cpu_sample)
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

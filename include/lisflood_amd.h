@@ -1,0 +1,204 @@
+/*
+ * lisflood_amd.h -- C ABI of the MI355X (gfx950) engine for the LISFLOOD per-timestep hot path:
+ * kinematic-wave routing, soil-column water balance and LDD-directed reductions.
+ *
+ * The reference (ec-jrc/lisflood-code v4.3.1) is pure Python and has no FFI of its own; the seams this
+ * library sits behind are (paths relative to src/lisflood/hydrological_modules/):
+ *   - class kinematicWave                      kinematic_wave_parallel.py:114-184
+ *   - numba kernels kinematicRouting/solve1Pixel  kinematic_wave_parallel_tools.py:34-92
+ *   - interception_water_balance / soilColumnsWaterBalance   soilloop.py:27-70 / 78-355
+ *   - routing.dynamic sub-step arithmetic      routing.py:512-603, 693-703
+ *   - np.bincount one-hop upstream sum         routing.py:159-164, lakes.py:215
+ * Host code (Python, lisflood-code_amd/lisflood_amd/) binds these entry points with ctypes; the binding
+ * a maintainer of the reference would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C: opaque handles, raw pointers and sizes, no exceptions across the boundary;
+ *   - every function returns LF_OK (0) or a negative LF_E_* code; lf_last_error() gives the message
+ *     (thread-local);
+ *   - "pixel order" = the reference's compressed 1-D land-pixel vector, row-major over the land mask
+ *     (global_modules/add1.py:268-305); all reals are IEEE fp64;
+ *   - pointers named *_host are caller-owned host memory, *_dev are device memory obtained from
+ *     lf_device_alloc (or any hipMalloc'ed pointer of the same device);
+ *   - there is NO CPU fallback: every compute entry point fails with LF_E_NO_DEVICE when no gfx950
+ *     device is usable.
+ */
+#ifndef LISFLOOD_AMD_H
+#define LISFLOOD_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LF_OK 0
+#define LF_E_INVALID (-1)   /* bad argument */
+#define LF_E_CYCLE (-2)     /* LDD has a cycle (the reference loops forever: kinematic_wave_parallel.py:99) */
+#define LF_E_NO_DEVICE (-3) /* no usable HIP device */
+#define LF_E_HIP (-4)       /* HIP runtime error, see lf_last_error() */
+#define LF_E_SECTION (-5)   /* section not in {main_channel, floodplains} / floodplains not configured
+                               (kinematic_wave_parallel.py:172) */
+#define LF_E_COMM (-6)      /* RCCL error */
+
+#define LF_SECTION_MAIN 0        /* "main_channel" */
+#define LF_SECTION_FLOODPLAINS 1 /* "floodplains"  */
+
+typedef struct lf_graph lf_graph;   /* host: LDD -> adjacency -> routing orders            */
+typedef struct lf_router lf_router; /* device: one kinematicWave instance                   */
+
+const char *lf_last_error(void);
+int lf_version(void);
+/* sizeof(lf_substep_args), sizeof(lf_interception_args), sizeof(lf_soil_args): lets a binding verify
+ * its struct mirrors. */
+int lf_struct_sizes(int64_t out[3]);
+
+/* ---------------------------------------------------------------------------------------------
+ * device plumbing
+ * ------------------------------------------------------------------------------------------- */
+int lf_device_count(int *count);
+int lf_device_name(int device, char *buf, size_t buflen); /* gcnArchName, e.g. "gfx950:sramecc+:xnack-" */
+int lf_device_alloc(int device, size_t bytes, void **ptr_dev);
+int lf_device_free(int device, void *ptr_dev);
+int lf_memcpy_h2d(int device, void *dst_dev, const void *src_host, size_t bytes);
+int lf_memcpy_d2h(int device, void *dst_host, const void *src_dev, size_t bytes);
+int lf_memcpy_d2d(int device, void *dst_dev, const void *src_dev, size_t bytes);
+int lf_memset(int device, void *dst_dev, int value, size_t bytes);
+int lf_device_synchronize(int device);
+/* hipEvent stopwatch on the library's compute stream of `device` (the stream every kernel of this
+ * library is launched on): start records an event, stop records another, synchronises and returns the
+ * elapsed milliseconds. */
+int lf_timer_start(int device);
+int lf_timer_stop(int device, double *elapsed_ms);
+
+/* ---------------------------------------------------------------------------------------------
+ * graph: replaces rebuildFlowMatrix/decodeFlowMatrix/streamLookups/topoDistFromSea/_setRoutingOrders
+ * (kinematic_wave_parallel.py:59-106, 140-158; kinematic_wave_parallel_tools.py:111-130)
+ * ------------------------------------------------------------------------------------------- */
+/* ldd_codes: N compressed LISFLOOD keypad codes (doubles, as the reference passes them; 0 = sea,
+ * 5 = pit; any value outside {1,2,3,4,6,7,8,9} is "no flow").  land_mask: H*W bytes, non-zero = land. */
+int lf_graph_create(const double *ldd_codes, const uint8_t *land_mask, int H, int W, lf_graph **out);
+/* raster form for large domains: H*W uint8 codes; land_mask may be NULL (= all land). */
+int lf_graph_create_raster(const uint8_t *ldd_raster, const uint8_t *land_mask, int H, int W, lf_graph **out);
+void lf_graph_destroy(lf_graph *g);
+int64_t lf_graph_num_pixels(const lf_graph *g);   /* N  */
+int64_t lf_graph_num_levels(const lf_graph *g);   /* NL = order_start_stop.shape[0] */
+int lf_graph_max_upstream(const lf_graph *g);     /* K  = upstream_lookup.shape[1]  */
+/* the reference's attributes, for parity tests: downstream_lookup[N] (float64, -1 = none),
+ * upstream_lookup[N*K] (int64, -1 filled, ascending source id), num_upstream_pixels[N] */
+int lf_graph_get_lookups(const lf_graph *g, double *downstream, int64_t *upstream, int64_t *num_upstream);
+/* pixels_ordered[N], order_start_stop[NL*2] (kinematic_wave_parallel.py:150-158) */
+int lf_graph_get_orders(const lf_graph *g, int64_t *pixels_ordered, int64_t *order_start_stop);
+/* engine layout: perm[N] = pixel at sweep position p (levels ascending; inside a level, breadth-first
+ * from the outlets so that the upstream cells of position p are the contiguous positions
+ * [ups_ptr[p], ups_ptr[p+1])); level_start[NL+1]. */
+int lf_graph_get_layout(const lf_graph *g, int32_t *perm, int32_t *ups_ptr, int64_t *level_start);
+
+/* ---------------------------------------------------------------------------------------------
+ * router: replaces class kinematicWave (kinematic_wave_parallel.py:114-184)
+ * ------------------------------------------------------------------------------------------- */
+/* alpha[N]; dx[N] or NULL + dx_scalar; alpha_floodplains[N] or NULL (no split routing). */
+int lf_router_create(const lf_graph *g, const double *alpha, double beta, const double *dx, double dx_scalar,
+                     double dt, const double *alpha_floodplains, int device, lf_router **out);
+void lf_router_destroy(lf_router *r);
+/* kinematicWaveRouting(discharge, specific_lateral_inflow, section): discharge[N] is updated in place.
+ * Host-buffer form (PCIe-inclusive): H2D, route, D2H. */
+int lf_router_route_host(lf_router *r, double *discharge_host, const double *lateral_host, int section);
+/* Device-resident form: discharge_dev[N] (in/out) and lateral_dev[N] in pixel order, asynchronous on the
+ * library stream. */
+int lf_router_route_device(lf_router *r, double *discharge_dev, const double *lateral_dev, int section);
+/* nancheck (kinematic_wave_parallel.py:180-184): number of non-finite entries of a device vector. */
+int lf_count_nonfinite(int device, const double *x_dev, int64_t n, int64_t *count);
+/* launch statistics of the last route call: [0] kernel launches, [1] wide-level launches,
+ * [2] narrow-run launches, [3] levels */
+int lf_router_last_launches(const lf_router *r, int64_t stats[4]);
+/* per-kernel hipEvent profiling: when enabled every sweep launch is bracketed by an event pair.
+ * lf_router_profile_read returns accumulated {launches, milliseconds, cells} per kernel class
+ * (0 = prep, 1 = wide level, 2 = narrow run) since the last reset. */
+int lf_router_profile_enable(lf_router *r, int on);
+int lf_router_profile_read(lf_router *r, double out[9], int reset);
+
+/* ---------------------------------------------------------------------------------------------
+ * routing sub-step arithmetic (routing.py:512-603, 693-703), device vectors in pixel order
+ * ------------------------------------------------------------------------------------------- */
+typedef struct lf_substep_args {
+    /* static [N] */
+    const double *ChanLength, *InvChanLength, *ChannelAlpha, *InvChannelAlpha, *ChannelAlpha2, *InvChannelAlpha2;
+    const double *Chan2M3Start, *Chan2QStart, *M3Limit, *QLimit, *PixelArea;
+    const uint8_t *IsChannelKinematic;
+    /* per sub-step input [N] */
+    const double *SideflowChanM3;
+    /* state [N], updated in place */
+    double *ChanQKin, *ChanM3Kin, *Chan2QKin, *Chan2M3Kin, *CrossSection2Area, *Sideflow1Chan, *ChanQ, *sumDisDay;
+    /* outputs [N] */
+    double *FlowVelocity, *TravelDistance;
+    /* scratch [N] x 2 */
+    double *scratch0, *scratch1;
+    double Beta, InvBeta, InvDtRouting, DtSec;
+    int32_t split; /* 0: single routing branch (routing.py:518-538), 1: split routing (543-604) */
+} lf_substep_args;
+/* One routing.dynamic() sub-step: sideflow assembly, 1 or 2 router calls, volume/discharge fix-ups,
+ * sumDisDay, FlowVelocity/TravelDistance.  All pointers are device memory, pixel order. */
+int lf_routing_substep(lf_router *r, const lf_substep_args *a);
+
+/* ---------------------------------------------------------------------------------------------
+ * LDD one-hop upstream reduction == np.bincount(downstruct, weights)[:N] (routing.py:159-164,
+ * lakes.py:215, reservoir.py:190) and upstream(ldd, x) (routing.py:387)
+ * ------------------------------------------------------------------------------------------- */
+int lf_upstream_sum_device(lf_router *r, const double *w_dev, double *out_dev);
+int lf_upstream_sum_host(lf_router *r, const double *w_host, double *out_host);
+/* accuflux(ldd, x): sum of x over all upstream cells including the cell itself (routing.py:98) */
+int lf_accuflux_host(lf_router *r, const double *x_host, double *out_host);
+
+/* ---------------------------------------------------------------------------------------------
+ * soil: replaces interception_water_balance (soilloop.py:27-70) and soilColumnsWaterBalance
+ * (soilloop.py:78-355).  Layouts as in the reference: [V,N] / [L,N] C-order fp64, bool arrays 1 byte.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct lf_interception_args {
+    double *Interception, *TaInterception, *LeafDrainage, *CumInterception; /* [V,N] in/out */
+    const double *LAI;               /* [V,N] */
+    const double *Rain;              /* [N]   */
+    const double *TaInterceptionMax; /* [V,N] */
+    double drainageK;
+    int64_t V, N;
+} lf_interception_args;
+
+typedef struct lf_soil_args {
+    /* [L,N] statics */
+    const uint8_t *PoreSpaceNotZero1a, *PoreSpaceNotZero1b, *PoreSpaceNotZero2;
+    const double *KSat1a, *KSat1b, *KSat2, *GenuInvM1a, *GenuInvM1b, *GenuInvM2, *GenuM1a, *GenuM1b, *GenuM2;
+    const double *WRes1a, *WRes1b, *WRes1, *WRes2, *WWP1a, *WWP1b, *WWP1, *WWP2, *WFC1a, *WFC1b, *WFC1, *WFC2;
+    const double *SoilDepth1a, *SoilDepth1b, *SoilDepth2, *WS1a, *WS1b, *WS1, *WS2, *StoreMaxPervious;
+    /* [N] */
+    const double *Rain, *SnowMelt, *b_Xinanjiang, *PowerInfPot, *PowerPrefFlow, *UpperZoneK, *GwPercStep;
+    const uint8_t *isFrozenSoil;
+    /* [V,N] in */
+    const double *LeafDrainage, *Interception, *ESMax;
+    /* [V,N] in/out and out */
+    double *AvailableWaterForInfiltration, *DSLR, *ESAct, *PrefFlow, *Infiltration, *W1a, *W1b, *W1, *W2;
+    double *Theta1a, *Theta1b, *Theta2, *Sat1a, *Sat1b, *Sat1, *Sat2, *SeepTopToSubA, *SeepTopToSubB, *SeepSubToGW;
+    double *UZOutflow, *UZ, *GwPercUZLZ;
+    /* small, ALWAYS host memory */
+    const int64_t *index_landuse_all; /* [V] */
+    const uint8_t *is_irrigated;      /* [V] */
+    const uint8_t *is_paddy_irrig;    /* [V] */
+    /* [n_paddy, N]; host memory in lf_soil_columns_host, device memory in lf_soil_columns_device;
+     * paddy_any[n_paddy] (host) tells the device form which rows have any inactive pixel */
+    const uint8_t *paddy_inactive;
+    const uint8_t *paddy_any;
+    double DtDay, AvWaterThreshold, CourantCrit, DrainedFraction;
+    int64_t V, L, N;
+} lf_soil_args;
+
+/* host-buffer forms (drop-in for the numba kernels; PCIe-inclusive) */
+int lf_interception_host(int device, const lf_interception_args *a);
+int lf_soil_columns_host(int device, const lf_soil_args *a);
+/* device-resident forms: every array pointer is device memory (except the small per-vegetation ones) */
+int lf_interception_device(int device, const lf_interception_args *a);
+int lf_soil_columns_device(int device, const lf_soil_args *a);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LISFLOOD_AMD_H */

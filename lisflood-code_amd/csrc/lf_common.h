@@ -1,0 +1,86 @@
+// lf_common.h -- internal declarations shared by the translation units of liblisflood_amd.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/lisflood_amd.h"
+
+#define LF_NEWTON_TOL 1e-12 /* kinematic_wave_parallel_tools.py:26 */
+#define LF_MAX_ITERS 3000   /* kinematic_wave_parallel_tools.py:27 */
+
+int lf_set_error(int code, const char *fmt, ...);
+
+#define LF_HIP(call)                                                                                      \
+    do {                                                                                                  \
+        hipError_t e_ = (call);                                                                           \
+        if (e_ != hipSuccess)                                                                             \
+            return lf_set_error(LF_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
+                                __LINE__);                                                                \
+    } while (0)
+
+#define LF_TRY(call)          \
+    do {                      \
+        int rc_ = (call);     \
+        if (rc_ != LF_OK) return rc_; \
+    } while (0)
+
+// Per-device context: one compute stream, a stopwatch event pair.
+struct lf_device_ctx {
+    bool ready = false;
+    hipStream_t stream = nullptr;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+};
+int lf_ctx(int device, lf_device_ctx **out); // makes `device` current, creates the context on first use
+
+// Host-side graph.  Positions ("sweep order") are the engine's internal cell numbering: levels
+// ascending (level = max distance to outlet - distance, as kinematic_wave_parallel.py:148-149),
+// breadth-first from the outlets inside a level, which makes the upstream cells of position p the
+// contiguous positions [ups_ptr[p], ups_ptr[p+1]) in ascending pixel id.
+struct lf_graph {
+    int H = 0, W = 0;
+    int64_t N = 0, NL = 0;
+    int K = 1;
+    std::vector<int32_t> down;        // [N] downstream pixel id, -1 = none
+    std::vector<int32_t> perm;        // [N] position -> pixel
+    std::vector<int32_t> ups_ptr;     // [N+1]
+    std::vector<int64_t> level_start; // [NL+1]
+};
+
+template <typename T>
+struct lf_dbuf { // owning device buffer
+    T *p = nullptr;
+    size_t n = 0;
+    int alloc(size_t count)
+    {
+        release();
+        n = count;
+        if (count == 0) return LF_OK;
+        hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+        if (e != hipSuccess) {
+            p = nullptr;
+            return lf_set_error(LF_E_HIP, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+        }
+        return LF_OK;
+    }
+    int upload(const T *src, size_t count)
+    {
+        LF_TRY(alloc(count));
+        if (count) LF_HIP(hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice));
+        return LF_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    ~lf_dbuf() { release(); }
+    lf_dbuf() = default;
+    lf_dbuf(const lf_dbuf &) = delete;
+    lf_dbuf &operator=(const lf_dbuf &) = delete;
+};

@@ -1,0 +1,161 @@
+// lf_device.cpp -- error reporting, per-device context (stream + stopwatch), memory plumbing.
+#include <cstring>
+#include <mutex>
+
+#include "lf_common.h"
+
+namespace {
+thread_local char g_err[512] = "";
+std::mutex g_ctx_mutex;
+lf_device_ctx g_ctx[64];
+} // namespace
+
+int lf_set_error(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int lf_ctx(int device, lf_device_ctx **out)
+{
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return lf_set_error(LF_E_NO_DEVICE, "no HIP device available (%s); this library has no CPU fallback",
+                            e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device < 0 || device >= count || device >= 64)
+        return lf_set_error(LF_E_INVALID, "device %d out of range (0..%d)", device, count - 1);
+    LF_HIP(hipSetDevice(device));
+    std::lock_guard<std::mutex> lock(g_ctx_mutex);
+    lf_device_ctx &c = g_ctx[device];
+    if (!c.ready) {
+        LF_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+        LF_HIP(hipEventCreate(&c.t0));
+        LF_HIP(hipEventCreate(&c.t1));
+        c.ready = true;
+    }
+    if (out) *out = &c;
+    return LF_OK;
+}
+
+extern "C" {
+
+const char *lf_last_error(void) { return g_err; }
+int lf_version(void) { return 100; }
+
+int lf_struct_sizes(int64_t out[3])
+{
+    if (!out) return lf_set_error(LF_E_INVALID, "null argument");
+    out[0] = (int64_t)sizeof(lf_substep_args);
+    out[1] = (int64_t)sizeof(lf_interception_args);
+    out[2] = (int64_t)sizeof(lf_soil_args);
+    return LF_OK;
+}
+
+int lf_device_count(int *count)
+{
+    if (!count) return lf_set_error(LF_E_INVALID, "null argument");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    *count = (e == hipSuccess) ? n : 0;
+    return LF_OK;
+}
+
+int lf_device_name(int device, char *buf, size_t buflen)
+{
+    if (!buf || buflen == 0) return lf_set_error(LF_E_INVALID, "null argument");
+    LF_TRY(lf_ctx(device, nullptr));
+    hipDeviceProp_t prop;
+    LF_HIP(hipGetDeviceProperties(&prop, device));
+    snprintf(buf, buflen, "%s", prop.gcnArchName);
+    return LF_OK;
+}
+
+int lf_device_alloc(int device, size_t bytes, void **ptr_dev)
+{
+    if (!ptr_dev) return lf_set_error(LF_E_INVALID, "null argument");
+    LF_TRY(lf_ctx(device, nullptr));
+    *ptr_dev = nullptr;
+    if (bytes == 0) return LF_OK;
+    LF_HIP(hipMalloc(ptr_dev, bytes));
+    return LF_OK;
+}
+
+int lf_device_free(int device, void *ptr_dev)
+{
+    LF_TRY(lf_ctx(device, nullptr));
+    if (ptr_dev) LF_HIP(hipFree(ptr_dev));
+    return LF_OK;
+}
+
+int lf_memcpy_h2d(int device, void *dst_dev, const void *src_host, size_t bytes)
+{
+    lf_device_ctx *c;
+    LF_TRY(lf_ctx(device, &c));
+    if (bytes) {
+        LF_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, c->stream));
+        LF_HIP(hipStreamSynchronize(c->stream));
+    }
+    return LF_OK;
+}
+
+int lf_memcpy_d2h(int device, void *dst_host, const void *src_dev, size_t bytes)
+{
+    lf_device_ctx *c;
+    LF_TRY(lf_ctx(device, &c));
+    if (bytes) {
+        LF_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+        LF_HIP(hipStreamSynchronize(c->stream));
+    }
+    return LF_OK;
+}
+
+int lf_memcpy_d2d(int device, void *dst_dev, const void *src_dev, size_t bytes)
+{
+    lf_device_ctx *c;
+    LF_TRY(lf_ctx(device, &c));
+    if (bytes) LF_HIP(hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, c->stream));
+    return LF_OK;
+}
+
+int lf_memset(int device, void *dst_dev, int value, size_t bytes)
+{
+    lf_device_ctx *c;
+    LF_TRY(lf_ctx(device, &c));
+    if (bytes) LF_HIP(hipMemsetAsync(dst_dev, value, bytes, c->stream));
+    return LF_OK;
+}
+
+int lf_device_synchronize(int device)
+{
+    lf_device_ctx *c;
+    LF_TRY(lf_ctx(device, &c));
+    LF_HIP(hipStreamSynchronize(c->stream));
+    LF_HIP(hipDeviceSynchronize());
+    return LF_OK;
+}
+
+int lf_timer_start(int device)
+{
+    lf_device_ctx *c;
+    LF_TRY(lf_ctx(device, &c));
+    LF_HIP(hipEventRecord(c->t0, c->stream));
+    return LF_OK;
+}
+
+int lf_timer_stop(int device, double *elapsed_ms)
+{
+    lf_device_ctx *c;
+    LF_TRY(lf_ctx(device, &c));
+    LF_HIP(hipEventRecord(c->t1, c->stream));
+    LF_HIP(hipEventSynchronize(c->t1));
+    float ms = 0.f;
+    LF_HIP(hipEventElapsedTime(&ms, c->t0, c->t1));
+    if (elapsed_ms) *elapsed_ms = (double)ms;
+    return LF_OK;
+}
+
+} // extern "C"

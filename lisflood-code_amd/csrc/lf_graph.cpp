@@ -1,0 +1,235 @@
+// lf_graph.cpp -- LDD raster -> adjacency -> routing orders -> engine layout (host side, O(N)).
+//
+// Replaces rebuildFlowMatrix / decodeFlowMatrix / streamLookups / upDownLookups / topoDistFromSea /
+// _setRoutingOrders of the reference (kinematic_wave_parallel.py:59-106, 140-158;
+// kinematic_wave_parallel_tools.py:111-130).  The reference builds the level sets with one np.unique
+// per level (O(N*NL)); here a single breadth-first pass from the outlets yields the distances, the
+// level sets and the engine's sweep layout at once.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+
+#include "lf_common.h"
+
+namespace {
+
+// keypad code -> direction index 0..7 (IX_ADDS row, kinematic_wave_parallel.py:49-51), 8 = no flow
+const int kRowAdd[8] = {1, 1, 0, -1, -1, -1, 0, 1};
+const int kColAdd[8] = {0, 1, 1, 1, 0, -1, -1, -1};
+
+inline int decode(int code)
+{
+    switch (code) {
+    case 2: return 0;
+    case 3: return 1;
+    case 6: return 2;
+    case 9: return 3;
+    case 8: return 4;
+    case 7: return 5;
+    case 4: return 6;
+    case 1: return 7;
+    default: return 8; // 5 = pit, 0 = sea; anything else is undefined in the reference -> no flow
+    }
+}
+
+// codes_at(i): LDD code of raster cell i (row-major); is_land(i): land mask.
+template <typename CodeAt, typename IsLand>
+int build(int H, int W, CodeAt codes_at, IsLand is_land, bool all_land, lf_graph **out)
+{
+    if (H <= 0 || W <= 0) return lf_set_error(LF_E_INVALID, "bad raster shape %d x %d", H, W);
+    const int64_t HW = (int64_t)H * W;
+    lf_graph *g = new (std::nothrow) lf_graph();
+    if (!g) return lf_set_error(LF_E_INVALID, "out of memory");
+    g->H = H;
+    g->W = W;
+    try {
+        // 1. pixel ids (row-major over the land mask, add1.py:268-282)
+        std::vector<int32_t> land_points;
+        int64_t n = HW;
+        if (!all_land) {
+            land_points.assign(HW, -1);
+            n = 0;
+            for (int64_t i = 0; i < HW; ++i)
+                if (is_land(i)) land_points[i] = (int32_t)n++;
+        }
+        if (n >= (int64_t)1 << 31) {
+            delete g;
+            return lf_set_error(LF_E_INVALID, "too many land pixels (%lld >= 2^31)", (long long)n);
+        }
+        g->N = n;
+        // 2. downstream pixel of every pixel (kwpt.py:119-126): none if the target is off-grid or not land
+        g->down.assign(n, -1);
+        std::vector<int32_t> nups(n + 1, 0);
+        {
+            int64_t p = 0;
+            for (int r = 0; r < H; ++r)
+                for (int c = 0; c < W; ++c) {
+                    const int64_t i = (int64_t)r * W + c;
+                    if (!all_land && land_points[i] < 0) continue;
+                    const int d = decode(codes_at(i, p));
+                    if (d < 8) {
+                        const int rr = r + kRowAdd[d], cc = c + kColAdd[d];
+                        if (rr >= 0 && cc >= 0 && rr < H && cc < W) {
+                            const int64_t j = (int64_t)rr * W + cc;
+                            const int32_t dn = all_land ? (int32_t)j : land_points[j];
+                            if (dn >= 0) {
+                                g->down[p] = dn;
+                                nups[dn]++;
+                            }
+                        }
+                    }
+                    ++p;
+                }
+        }
+        std::vector<int32_t>().swap(land_points);
+        int K = 0;
+        for (int64_t p = 0; p < n; ++p) K = std::max(K, (int)nups[p]);
+        g->K = std::max(1, K);
+        // 3. upstream adjacency in pixel space (CSR, ascending source id as kwpt.py:127-128)
+        std::vector<int32_t> uptr(n + 1);
+        {
+            int64_t acc = 0;
+            for (int64_t p = 0; p < n; ++p) {
+                uptr[p] = (int32_t)acc;
+                acc += nups[p];
+            }
+            uptr[n] = (int32_t)acc;
+        }
+        std::vector<int32_t> uidx(uptr[n]);
+        {
+            std::vector<int32_t> fill(uptr.begin(), uptr.end() - 1);
+            for (int64_t p = 0; p < n; ++p)
+                if (g->down[p] >= 0) uidx[fill[g->down[p]]++] = (int32_t)p;
+        }
+        // 4. breadth-first search from the outlets (topoDistFromSea, kinematic_wave_parallel.py:92-106):
+        //    generation k holds the pixels at distance k+1 from their outlet.
+        std::vector<int32_t> queue(n);
+        std::vector<int64_t> gen_start;
+        int64_t tail = 0;
+        for (int64_t p = 0; p < n; ++p)
+            if (g->down[p] < 0) queue[tail++] = (int32_t)p;
+        int64_t head = 0;
+        gen_start.push_back(0);
+        while (head < tail) {
+            const int64_t gen_end = tail;
+            for (; head < gen_end; ++head) {
+                const int32_t p = queue[head];
+                for (int32_t e = uptr[p]; e < uptr[p + 1]; ++e) queue[tail++] = uidx[e];
+            }
+            gen_start.push_back(gen_end);
+        }
+        if (tail != n) {
+            delete g;
+            return lf_set_error(LF_E_CYCLE, "LDD has a cycle: %lld of %lld pixels never reach an outlet",
+                                (long long)(n - tail), (long long)n);
+        }
+        // gen_start = [0, |gen0|, |gen0|+|gen1|, ..., n]; drop a possible duplicated tail entry
+        while (gen_start.size() >= 2 && gen_start[gen_start.size() - 1] == gen_start[gen_start.size() - 2])
+            gen_start.pop_back();
+        if (gen_start.back() != n) gen_start.push_back(n);
+        const int64_t NL = (int64_t)gen_start.size() - 1;
+        g->NL = NL;
+        // 5. sweep layout: order k = generation NL-1-k (routing_order = max - distance, :149)
+        g->level_start.assign(NL + 1, 0);
+        for (int64_t k = 0; k < NL; ++k) {
+            const int64_t gen = NL - 1 - k;
+            g->level_start[k + 1] = g->level_start[k] + (gen_start[gen + 1] - gen_start[gen]);
+        }
+        g->perm.resize(n);
+        for (int64_t k = 0; k < NL; ++k) {
+            const int64_t gen = NL - 1 - k;
+            std::memcpy(g->perm.data() + g->level_start[k], queue.data() + gen_start[gen],
+                        sizeof(int32_t) * (size_t)(gen_start[gen + 1] - gen_start[gen]));
+        }
+        // 6. contiguous upstream ranges: the children of the i-th cell of generation g are consecutive
+        //    in generation g+1, in ascending pixel id.
+        g->ups_ptr.resize(n + 1);
+        for (int64_t k = 0; k < NL; ++k) {
+            int64_t acc = (k == 0) ? 0 : g->level_start[k - 1];
+            for (int64_t p = g->level_start[k]; p < g->level_start[k + 1]; ++p) {
+                g->ups_ptr[p] = (int32_t)acc;
+                acc += nups[g->perm[p]];
+            }
+        }
+        g->ups_ptr[n] = (int32_t)(NL >= 1 ? g->level_start[NL - 1] : 0);
+    } catch (const std::bad_alloc &) {
+        delete g;
+        return lf_set_error(LF_E_INVALID, "out of host memory while building the graph");
+    }
+    *out = g;
+    return LF_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int lf_graph_create(const double *ldd_codes, const uint8_t *land_mask, int H, int W, lf_graph **out)
+{
+    if (!ldd_codes || !land_mask || !out) return lf_set_error(LF_E_INVALID, "null argument");
+    auto code = [&](int64_t, int64_t p) {
+        const double c = ldd_codes[p];
+        return (c >= 0.0 && c <= 9.0 && c == std::floor(c)) ? (int)c : 0;
+    };
+    auto land = [&](int64_t i) { return land_mask[i] != 0; };
+    return build(H, W, code, land, false, out);
+}
+
+int lf_graph_create_raster(const uint8_t *ldd_raster, const uint8_t *land_mask, int H, int W, lf_graph **out)
+{
+    if (!ldd_raster || !out) return lf_set_error(LF_E_INVALID, "null argument");
+    auto code = [&](int64_t i, int64_t) { return (int)ldd_raster[i]; };
+    if (land_mask) {
+        auto land = [&](int64_t i) { return land_mask[i] != 0; };
+        return build(H, W, code, land, false, out);
+    }
+    auto land = [](int64_t) { return true; };
+    return build(H, W, code, land, true, out);
+}
+
+void lf_graph_destroy(lf_graph *g) { delete g; }
+int64_t lf_graph_num_pixels(const lf_graph *g) { return g ? g->N : -1; }
+int64_t lf_graph_num_levels(const lf_graph *g) { return g ? g->NL : -1; }
+int lf_graph_max_upstream(const lf_graph *g) { return g ? g->K : -1; }
+
+int lf_graph_get_lookups(const lf_graph *g, double *downstream, int64_t *upstream, int64_t *num_upstream)
+{
+    if (!g || !downstream || !upstream || !num_upstream) return lf_set_error(LF_E_INVALID, "null argument");
+    const int64_t n = g->N;
+    const int K = g->K;
+    for (int64_t p = 0; p < n; ++p) {
+        downstream[p] = (double)g->down[p];
+        num_upstream[p] = 0;
+        for (int k = 0; k < K; ++k) upstream[p * K + k] = -1;
+    }
+    for (int64_t p = 0; p < n; ++p) { // ascending source id
+        const int32_t d = g->down[p];
+        if (d >= 0) upstream[(int64_t)d * K + num_upstream[d]++] = p;
+    }
+    return LF_OK;
+}
+
+int lf_graph_get_orders(const lf_graph *g, int64_t *pixels_ordered, int64_t *order_start_stop)
+{
+    if (!g || !pixels_ordered || !order_start_stop) return lf_set_error(LF_E_INVALID, "null argument");
+    for (int64_t k = 0; k < g->NL; ++k) {
+        const int64_t a = g->level_start[k], b = g->level_start[k + 1];
+        order_start_stop[2 * k] = a;
+        order_start_stop[2 * k + 1] = b;
+        for (int64_t p = a; p < b; ++p) pixels_ordered[p] = g->perm[p];
+        std::sort(pixels_ordered + a, pixels_ordered + b); // (order, pixel id), kinematic_wave_parallel.py:152
+    }
+    return LF_OK;
+}
+
+int lf_graph_get_layout(const lf_graph *g, int32_t *perm, int32_t *ups_ptr, int64_t *level_start)
+{
+    if (!g) return lf_set_error(LF_E_INVALID, "null argument");
+    if (perm) std::memcpy(perm, g->perm.data(), sizeof(int32_t) * g->perm.size());
+    if (ups_ptr) std::memcpy(ups_ptr, g->ups_ptr.data(), sizeof(int32_t) * g->ups_ptr.size());
+    if (level_start) std::memcpy(level_start, g->level_start.data(), sizeof(int64_t) * g->level_start.size());
+    return LF_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,618 @@
+// lf_router.hip -- kinematic-wave routing on gfx950: level-ordered implicit sweep with a per-cell
+// Newton-Raphson solve.  Replaces kinematicWave.kinematicWaveRouting + kinematicRouting + solve1Pixel
+// (kinematic_wave_parallel.py:160-184, kinematic_wave_parallel_tools.py:34-92).
+//
+// Data layout (HBM, all fp64 unless noted), N = land pixels, positions = sweep order (lf_graph):
+//   perm[N]      int32  position -> pixel (gather/scatter to the caller's pixel-order vectors)
+//   ups_ptr[N+1] int32  upstream cells of position p are the CONTIGUOUS positions [ups_ptr[p], ups_ptr[p+1])
+//   a1[N], a2[N]        alpha*dx/dt for main channel / floodplains, sweep order
+//   dx[N]               space delta (only when it is per-pixel), sweep order
+//   constant[N]         a*Qold^beta + q*dx, sweep order (written by the prep kernel)
+//   qord[N]             new discharge, sweep order (read by the downstream level)
+// Because a level is a contiguous range of positions and the upstream cells of consecutive positions
+// are consecutive too, every global access of the sweep except the perm-indexed gather/scatter of the
+// caller's vectors is a coalesced stream.
+//
+// Launch structure per call: 1 prep launch over all cells, then one launch per "wide" level
+// (> kNarrowMax cells, one cell per lane) and one single-workgroup launch per run of consecutive
+// "narrow" levels (the workgroup walks the levels with a barrier between them).  A dependent kernel
+// boundary costs ~1.5 us on MI355X, less than any software grid barrier (4-7 us), so wide levels
+// are separated by launches, not by in-kernel synchronisation.
+#include <cmath>
+
+#include "lf_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kNarrowBlock = 1024;
+constexpr int kNarrowMax = 1024; // levels up to this many cells are swept by the single-workgroup kernel
+
+// solve1Pixel, kinematic_wave_parallel_tools.py:59-82 (c = const_plus_ups_infl)
+__device__ __forceinline__ double lf_solve_cell(double c, double a, double ba, double beta, double inv_beta,
+                                                double b_minus_1)
+{
+    if (c <= LF_NEWTON_TOL) return 0.0;
+    const double t = ba * pow(c, b_minus_1);
+    double secant;
+    if (t <= 1.0)
+        secant = c / (1.0 + t);
+    else
+        secant = c / (1.0 + pow(t, inv_beta));
+    const double other = pow((c - secant) / a, inv_beta);
+    double q = (secant + other) / 2.0;
+    double err = q + a * pow(q, beta) - c; // closureError, :89-92
+    double prev = -1.0;
+    int count = 0;
+    while (fabs(err) > LF_NEWTON_TOL && q != prev && count < LF_MAX_ITERS) {
+        prev = q;
+        q -= err / (1.0 + ba * pow(q, b_minus_1));
+        q = (LF_NEWTON_TOL > q) ? LF_NEWTON_TOL : q; // builtins.max(q, NEWTON_TOL)
+        err = q + a * pow(q, beta) - c;
+        ++count;
+    }
+    if (q == LF_NEWTON_TOL) q = 0.0;
+    return q;
+}
+
+// constant = a*Qold^beta + q*dx (kinematic_wave_parallel.py:163,175), gathered into sweep order
+__global__ void __launch_bounds__(kBlock) k_prep(int n, const int *__restrict__ perm, const double *__restrict__ q_pix,
+                                                 const double *__restrict__ lat_pix, const double *__restrict__ a,
+                                                 const double *__restrict__ dx, double dx_scalar, double beta,
+                                                 double *__restrict__ constant)
+{
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= n) return;
+    const int pix = perm[p];
+    const double lateral = lat_pix[pix] * (dx ? dx[p] : dx_scalar);
+    constant[p] = a[p] * pow(q_pix[pix], beta) + lateral;
+}
+
+__device__ __forceinline__ void sweep_cell(int p, const int *__restrict__ ups_ptr, const int *__restrict__ perm,
+                                           const double *__restrict__ constant, const double *__restrict__ a,
+                                           double beta, double inv_beta, double b_minus_1, double *qord,
+                                           double *__restrict__ q_pix)
+{
+    const int u0 = ups_ptr[p], u1 = ups_ptr[p + 1];
+    double ups = 0.0;
+    for (int e = u0; e < u1; ++e) ups += qord[e]; // ascending pixel id, kinematic_wave_parallel_tools.py:57-58
+    const double c = ups + constant[p];
+    const double ap = a[p];
+    const double q = lf_solve_cell(c, ap, beta * ap, beta, inv_beta, b_minus_1);
+    qord[p] = q;
+    q_pix[perm[p]] = q;
+}
+
+// one wide level: one cell per lane
+__global__ void __launch_bounds__(kBlock) k_level(int first, int count, const int *__restrict__ ups_ptr,
+                                                  const int *__restrict__ perm, const double *__restrict__ constant,
+                                                  const double *__restrict__ a, double beta, double inv_beta,
+                                                  double b_minus_1, double *qord, double *__restrict__ q_pix)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= count) return;
+    sweep_cell(first + i, ups_ptr, perm, constant, a, beta, inv_beta, b_minus_1, qord, q_pix);
+}
+
+// a run of narrow levels [k0, k1): one workgroup, barrier between levels
+__global__ void __launch_bounds__(kNarrowBlock) k_levels_narrow(int k0, int k1, const long long *__restrict__ level_start,
+                                                                const int *__restrict__ ups_ptr,
+                                                                const int *__restrict__ perm,
+                                                                const double *__restrict__ constant,
+                                                                const double *__restrict__ a, double beta,
+                                                                double inv_beta, double b_minus_1, double *qord,
+                                                                double *__restrict__ q_pix)
+{
+    for (int k = k0; k < k1; ++k) {
+        const int first = (int)level_start[k], last = (int)level_start[k + 1];
+        for (int p = first + (int)threadIdx.x; p < last; p += kNarrowBlock)
+            sweep_cell(p, ups_ptr, perm, constant, a, beta, inv_beta, b_minus_1, qord, q_pix);
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_gather(int n, const int *__restrict__ perm, const double *__restrict__ src_pix,
+                                                   double *__restrict__ dst_ord)
+{
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p < n) dst_ord[p] = src_pix[perm[p]];
+}
+
+// out[pixel(p)] = sum of w over the upstream cells of p, ascending pixel id (np.bincount order)
+__global__ void __launch_bounds__(kBlock) k_upstream_sum(int n, const int *__restrict__ perm,
+                                                         const int *__restrict__ ups_ptr, const double *__restrict__ w_pix,
+                                                         double *__restrict__ out_pix)
+{
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= n) return;
+    double s = 0.0;
+    for (int e = ups_ptr[p]; e < ups_ptr[p + 1]; ++e) s += w_pix[perm[e]];
+    out_pix[perm[p]] = s;
+}
+
+// accuflux: acc[p] = x[p] + sum over upstream acc (upstream first, ascending pixel id, then the cell itself)
+__global__ void __launch_bounds__(kBlock) k_accu_level(int first, int count, const int *__restrict__ ups_ptr,
+                                                       const double *__restrict__ x_ord, double *acc)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= count) return;
+    const int p = first + i;
+    double s = 0.0;
+    for (int e = ups_ptr[p]; e < ups_ptr[p + 1]; ++e) s += acc[e];
+    acc[p] = s + x_ord[p];
+}
+
+__global__ void __launch_bounds__(kNarrowBlock) k_accu_narrow(int k0, int k1, const long long *__restrict__ level_start,
+                                                              const int *__restrict__ ups_ptr,
+                                                              const double *__restrict__ x_ord, double *acc)
+{
+    for (int k = k0; k < k1; ++k) {
+        const int first = (int)level_start[k], last = (int)level_start[k + 1];
+        for (int p = first + (int)threadIdx.x; p < last; p += kNarrowBlock) {
+            double s = 0.0;
+            for (int e = ups_ptr[p]; e < ups_ptr[p + 1]; ++e) s += acc[e];
+            acc[p] = s + x_ord[p];
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_scatter(int n, const int *__restrict__ perm, const double *__restrict__ src_ord,
+                                                    double *__restrict__ dst_pix)
+{
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p < n) dst_pix[perm[p]] = src_ord[p];
+}
+
+__global__ void __launch_bounds__(kBlock) k_count_nonfinite(long long n, const double *__restrict__ x,
+                                                            unsigned long long *count)
+{
+    long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    unsigned long long local = 0;
+    for (; i < n; i += (long long)gridDim.x * kBlock) local += !isfinite(x[i]);
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(count, local);
+}
+
+struct segment {
+    int k0, k1; // levels [k0, k1); wide segments have k1 == k0 + 1
+    bool wide;
+};
+
+} // namespace
+
+struct lf_router {
+    int device = 0;
+    lf_device_ctx *ctx = nullptr;
+    int64_t N = 0, NL = 0;
+    double beta = 0, inv_beta = 0, b_minus_1 = 0, dx_scalar = 0;
+    bool has_floodplains = false, dx_per_pixel = false;
+    lf_dbuf<int32_t> perm, ups_ptr;
+    lf_dbuf<long long> level_start;
+    lf_dbuf<double> a1, a2, dx, constant, qord, io_q, io_lat, tmp_ord;
+    lf_dbuf<unsigned long long> counter;
+    std::vector<int64_t> h_level_start;
+    std::vector<segment> schedule;
+    int64_t last_stats[4] = {0, 0, 0, 0};
+    // profiling
+    bool profile = false;
+    std::vector<hipEvent_t> ev_pool;
+    struct rec {
+        int cls;
+        size_t e0, e1;
+        int64_t cells;
+    };
+    std::vector<rec> recs;
+    size_t ev_used = 0;
+    double prof_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+    ~lf_router()
+    {
+        for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
+    }
+    int ev_get(size_t *idx)
+    {
+        if (ev_used == ev_pool.size()) {
+            hipEvent_t e;
+            LF_HIP(hipEventCreate(&e));
+            ev_pool.push_back(e);
+        }
+        *idx = ev_used++;
+        return LF_OK;
+    }
+    int prof_begin(int cls, int64_t cells)
+    {
+        if (!profile) return LF_OK;
+        rec r{cls, 0, 0, cells};
+        LF_TRY(ev_get(&r.e0));
+        LF_TRY(ev_get(&r.e1));
+        LF_HIP(hipEventRecord(ev_pool[r.e0], ctx->stream));
+        recs.push_back(r);
+        return LF_OK;
+    }
+    int prof_end()
+    {
+        if (!profile) return LF_OK;
+        LF_HIP(hipEventRecord(ev_pool[recs.back().e1], ctx->stream));
+        return LF_OK;
+    }
+    int prof_collect()
+    {
+        if (recs.empty()) return LF_OK;
+        LF_HIP(hipStreamSynchronize(ctx->stream));
+        for (const rec &r : recs) {
+            float ms = 0.f;
+            LF_HIP(hipEventElapsedTime(&ms, ev_pool[r.e0], ev_pool[r.e1]));
+            prof_acc[3 * r.cls + 0] += 1.0;
+            prof_acc[3 * r.cls + 1] += (double)ms;
+            prof_acc[3 * r.cls + 2] += (double)r.cells;
+        }
+        recs.clear();
+        ev_used = 0;
+        return LF_OK;
+    }
+};
+
+namespace {
+
+inline int blocks_for(int64_t n) { return (int)((n + kBlock - 1) / kBlock); }
+
+int route_device(lf_router *r, double *q_dev, const double *lat_dev, int section)
+{
+    if (section != LF_SECTION_MAIN && section != LF_SECTION_FLOODPLAINS)
+        return lf_set_error(LF_E_SECTION, "The section parameter must be either 'main_channel' or 'floodplain'!");
+    if (section == LF_SECTION_FLOODPLAINS && !r->has_floodplains)
+        return lf_set_error(LF_E_SECTION, "floodplains routing requested but alpha_floodplains was not given");
+    LF_HIP(hipSetDevice(r->device));
+    hipStream_t s = r->ctx->stream;
+    const double *a = (section == LF_SECTION_MAIN) ? r->a1.p : r->a2.p;
+    const int n = (int)r->N;
+    int64_t launches = 0, wide = 0, narrow = 0;
+    if (n > 0) {
+        LF_TRY(r->prof_begin(0, n));
+        hipLaunchKernelGGL(k_prep, dim3(blocks_for(n)), dim3(kBlock), 0, s, n, r->perm.p, q_dev, lat_dev, a,
+                           r->dx_per_pixel ? r->dx.p : nullptr, r->dx_scalar, r->beta, r->constant.p);
+        LF_TRY(r->prof_end());
+        ++launches;
+    }
+    for (const segment &g : r->schedule) {
+        if (g.wide) {
+            const int first = (int)r->h_level_start[g.k0];
+            const int count = (int)(r->h_level_start[g.k1] - r->h_level_start[g.k0]);
+            LF_TRY(r->prof_begin(1, count));
+            hipLaunchKernelGGL(k_level, dim3(blocks_for(count)), dim3(kBlock), 0, s, first, count, r->ups_ptr.p,
+                               r->perm.p, r->constant.p, a, r->beta, r->inv_beta, r->b_minus_1, r->qord.p, q_dev);
+            LF_TRY(r->prof_end());
+            ++wide;
+        } else {
+            LF_TRY(r->prof_begin(2, r->h_level_start[g.k1] - r->h_level_start[g.k0]));
+            hipLaunchKernelGGL(k_levels_narrow, dim3(1), dim3(kNarrowBlock), 0, s, g.k0, g.k1, r->level_start.p,
+                               r->ups_ptr.p, r->perm.p, r->constant.p, a, r->beta, r->inv_beta, r->b_minus_1,
+                               r->qord.p, q_dev);
+            LF_TRY(r->prof_end());
+            ++narrow;
+        }
+        ++launches;
+    }
+    LF_HIP(hipGetLastError());
+    r->last_stats[0] = launches;
+    r->last_stats[1] = wide;
+    r->last_stats[2] = narrow;
+    r->last_stats[3] = r->NL;
+    if (r->profile) LF_TRY(r->prof_collect());
+    return LF_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int lf_router_create(const lf_graph *g, const double *alpha, double beta, const double *dx, double dx_scalar, double dt,
+                     const double *alpha_floodplains, int device, lf_router **out)
+{
+    if (!g || !alpha || !out) return lf_set_error(LF_E_INVALID, "null argument");
+    lf_device_ctx *ctx;
+    LF_TRY(lf_ctx(device, &ctx));
+    lf_router *r = new lf_router();
+    r->device = device;
+    r->ctx = ctx;
+    r->N = g->N;
+    r->NL = g->NL;
+    r->beta = beta;
+    r->inv_beta = 1 / beta;      // kinematic_wave_parallel.py:125
+    r->b_minus_1 = beta - 1;     // :126
+    r->dx_scalar = dx_scalar;
+    r->dx_per_pixel = dx != nullptr;
+    r->has_floodplains = alpha_floodplains != nullptr;
+    const int64_t n = g->N;
+    int rc = LF_OK;
+    {
+        // a_dx_div_dt = alpha * dx / dt, evaluated left to right (:127), permuted into sweep order
+        std::vector<double> h(n);
+        auto fill = [&](const double *al) {
+            for (int64_t p = 0; p < n; ++p) {
+                const int32_t pix = g->perm[p];
+                h[p] = al[pix] * (dx ? dx[pix] : dx_scalar) / dt;
+            }
+        };
+        fill(alpha);
+        rc = r->a1.upload(h.data(), n);
+        if (rc == LF_OK && alpha_floodplains) {
+            fill(alpha_floodplains);
+            rc = r->a2.upload(h.data(), n);
+        }
+        if (rc == LF_OK && dx) {
+            for (int64_t p = 0; p < n; ++p) h[p] = dx[g->perm[p]];
+            rc = r->dx.upload(h.data(), n);
+        }
+    }
+    if (rc == LF_OK) rc = r->perm.upload(g->perm.data(), n);
+    if (rc == LF_OK) rc = r->ups_ptr.upload(g->ups_ptr.data(), n + 1);
+    if (rc == LF_OK) {
+        std::vector<long long> ls(g->level_start.begin(), g->level_start.end());
+        rc = r->level_start.upload(ls.data(), ls.size());
+    }
+    if (rc == LF_OK) rc = r->constant.alloc(n);
+    if (rc == LF_OK) rc = r->qord.alloc(n);
+    if (rc == LF_OK) rc = r->counter.alloc(1);
+    if (rc != LF_OK) {
+        delete r;
+        return rc;
+    }
+    r->h_level_start = g->level_start;
+    // launch schedule
+    for (int64_t k = 0; k < g->NL;) {
+        const int64_t size = g->level_start[k + 1] - g->level_start[k];
+        if (size > kNarrowMax) {
+            r->schedule.push_back({(int)k, (int)k + 1, true});
+            ++k;
+        } else {
+            int64_t e = k + 1;
+            while (e < g->NL && g->level_start[e + 1] - g->level_start[e] <= kNarrowMax) ++e;
+            r->schedule.push_back({(int)k, (int)e, false});
+            k = e;
+        }
+    }
+    *out = r;
+    return LF_OK;
+}
+
+void lf_router_destroy(lf_router *r)
+{
+    if (!r) return;
+    (void)hipSetDevice(r->device);
+    (void)hipStreamSynchronize(r->ctx->stream);
+    delete r;
+}
+
+int lf_router_route_device(lf_router *r, double *discharge_dev, const double *lateral_dev, int section)
+{
+    if (!r || !discharge_dev || !lateral_dev) return lf_set_error(LF_E_INVALID, "null argument");
+    return route_device(r, discharge_dev, lateral_dev, section);
+}
+
+int lf_router_route_host(lf_router *r, double *discharge_host, const double *lateral_host, int section)
+{
+    if (!r || !discharge_host || !lateral_host) return lf_set_error(LF_E_INVALID, "null argument");
+    if (section != LF_SECTION_MAIN && section != LF_SECTION_FLOODPLAINS)
+        return lf_set_error(LF_E_SECTION, "The section parameter must be either 'main_channel' or 'floodplain'!");
+    LF_HIP(hipSetDevice(r->device));
+    const size_t bytes = sizeof(double) * (size_t)r->N;
+    if (!r->io_q.p) LF_TRY(r->io_q.alloc(r->N));
+    if (!r->io_lat.p) LF_TRY(r->io_lat.alloc(r->N));
+    hipStream_t s = r->ctx->stream;
+    if (bytes) {
+        LF_HIP(hipMemcpyAsync(r->io_q.p, discharge_host, bytes, hipMemcpyHostToDevice, s));
+        LF_HIP(hipMemcpyAsync(r->io_lat.p, lateral_host, bytes, hipMemcpyHostToDevice, s));
+    }
+    LF_TRY(route_device(r, r->io_q.p, r->io_lat.p, section));
+    if (bytes) LF_HIP(hipMemcpyAsync(discharge_host, r->io_q.p, bytes, hipMemcpyDeviceToHost, s));
+    LF_HIP(hipStreamSynchronize(s));
+    return LF_OK;
+}
+
+int lf_count_nonfinite(int device, const double *x_dev, int64_t n, int64_t *count)
+{
+    if (!x_dev || !count) return lf_set_error(LF_E_INVALID, "null argument");
+    lf_device_ctx *c;
+    LF_TRY(lf_ctx(device, &c));
+    lf_dbuf<unsigned long long> ctr;
+    LF_TRY(ctr.alloc(1));
+    LF_HIP(hipMemsetAsync(ctr.p, 0, sizeof(unsigned long long), c->stream));
+    if (n > 0) {
+        const int grid = (int)std::min<int64_t>((n + kBlock - 1) / kBlock, 2048);
+        hipLaunchKernelGGL(k_count_nonfinite, dim3(grid), dim3(kBlock), 0, c->stream, (long long)n, x_dev, ctr.p);
+    }
+    unsigned long long h = 0;
+    LF_HIP(hipMemcpyAsync(&h, ctr.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    LF_HIP(hipStreamSynchronize(c->stream));
+    *count = (int64_t)h;
+    return LF_OK;
+}
+
+int lf_router_last_launches(const lf_router *r, int64_t stats[4])
+{
+    if (!r || !stats) return lf_set_error(LF_E_INVALID, "null argument");
+    for (int i = 0; i < 4; ++i) stats[i] = r->last_stats[i];
+    return LF_OK;
+}
+
+int lf_router_profile_enable(lf_router *r, int on)
+{
+    if (!r) return lf_set_error(LF_E_INVALID, "null argument");
+    r->profile = on != 0;
+    return LF_OK;
+}
+
+int lf_router_profile_read(lf_router *r, double out[9], int reset)
+{
+    if (!r || !out) return lf_set_error(LF_E_INVALID, "null argument");
+    for (int i = 0; i < 9; ++i) out[i] = r->prof_acc[i];
+    if (reset)
+        for (int i = 0; i < 9; ++i) r->prof_acc[i] = 0;
+    return LF_OK;
+}
+
+int lf_upstream_sum_device(lf_router *r, const double *w_dev, double *out_dev)
+{
+    if (!r || !w_dev || !out_dev) return lf_set_error(LF_E_INVALID, "null argument");
+    LF_HIP(hipSetDevice(r->device));
+    const int n = (int)r->N;
+    if (n > 0)
+        hipLaunchKernelGGL(k_upstream_sum, dim3(blocks_for(n)), dim3(kBlock), 0, r->ctx->stream, n, r->perm.p,
+                           r->ups_ptr.p, w_dev, out_dev);
+    LF_HIP(hipGetLastError());
+    return LF_OK;
+}
+
+int lf_upstream_sum_host(lf_router *r, const double *w_host, double *out_host)
+{
+    if (!r || !w_host || !out_host) return lf_set_error(LF_E_INVALID, "null argument");
+    LF_HIP(hipSetDevice(r->device));
+    const size_t bytes = sizeof(double) * (size_t)r->N;
+    if (!r->io_q.p) LF_TRY(r->io_q.alloc(r->N));
+    if (!r->io_lat.p) LF_TRY(r->io_lat.alloc(r->N));
+    hipStream_t s = r->ctx->stream;
+    if (bytes) LF_HIP(hipMemcpyAsync(r->io_lat.p, w_host, bytes, hipMemcpyHostToDevice, s));
+    LF_TRY(lf_upstream_sum_device(r, r->io_lat.p, r->io_q.p));
+    if (bytes) LF_HIP(hipMemcpyAsync(out_host, r->io_q.p, bytes, hipMemcpyDeviceToHost, s));
+    LF_HIP(hipStreamSynchronize(s));
+    return LF_OK;
+}
+
+int lf_accuflux_host(lf_router *r, const double *x_host, double *out_host)
+{
+    if (!r || !x_host || !out_host) return lf_set_error(LF_E_INVALID, "null argument");
+    LF_HIP(hipSetDevice(r->device));
+    const int n = (int)r->N;
+    const size_t bytes = sizeof(double) * (size_t)r->N;
+    if (!r->io_q.p) LF_TRY(r->io_q.alloc(r->N));
+    if (!r->io_lat.p) LF_TRY(r->io_lat.alloc(r->N));
+    if (!r->tmp_ord.p) LF_TRY(r->tmp_ord.alloc(r->N));
+    hipStream_t s = r->ctx->stream;
+    if (n == 0) return LF_OK;
+    LF_HIP(hipMemcpyAsync(r->io_lat.p, x_host, bytes, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_gather, dim3(blocks_for(n)), dim3(kBlock), 0, s, n, r->perm.p, r->io_lat.p, r->tmp_ord.p);
+    for (const segment &g : r->schedule) {
+        if (g.wide) {
+            const int first = (int)r->h_level_start[g.k0];
+            const int count = (int)(r->h_level_start[g.k1] - r->h_level_start[g.k0]);
+            hipLaunchKernelGGL(k_accu_level, dim3(blocks_for(count)), dim3(kBlock), 0, s, first, count, r->ups_ptr.p,
+                               r->tmp_ord.p, r->qord.p);
+        } else {
+            hipLaunchKernelGGL(k_accu_narrow, dim3(1), dim3(kNarrowBlock), 0, s, g.k0, g.k1, r->level_start.p,
+                               r->ups_ptr.p, r->tmp_ord.p, r->qord.p);
+        }
+    }
+    hipLaunchKernelGGL(k_scatter, dim3(blocks_for(n)), dim3(kBlock), 0, s, n, r->perm.p, r->qord.p, r->io_q.p);
+    LF_HIP(hipGetLastError());
+    LF_HIP(hipMemcpyAsync(out_host, r->io_q.p, bytes, hipMemcpyDeviceToHost, s));
+    LF_HIP(hipStreamSynchronize(s));
+    return LF_OK;
+}
+
+} // extern "C"
+
+// ================================================================================================
+// routing.dynamic() sub-step: element-wise arithmetic around the router calls (routing.py:512-603,
+// 693-703), fused into three kernels so that a model step's NoRoutSteps x (1..2) router calls never
+// leave the device.
+// ================================================================================================
+namespace {
+
+// routing.py:512 (+524 in the single branch) and, for split routing, 549-567
+__global__ void __launch_bounds__(kBlock) k_substep_sideflow(int n, lf_substep_args A)
+{
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= n) return;
+    double side = A.IsChannelKinematic[p] ? A.SideflowChanM3[p] * A.InvChanLength[p] * A.InvDtRouting : 0.0;
+    if (!A.split) {
+        if (isnan(side)) side = 0.0; // :524
+        A.scratch0[p] = side;
+        return;
+    }
+    const double m3 = A.ChanM3Kin[p], m3_2 = A.Chan2M3Kin[p];
+    const double tot = m3 + m3_2;
+    const double ratio = (tot > 0) ? m3 / tot : 0.0;                                  // :549
+    double s1 = ((tot - A.Chan2M3Start[p]) > A.M3Limit[p]) ? ratio * side : side;     // :557-558
+    if (fabs(side) < 1e-7) s1 = side;                                                 // :563
+    A.Sideflow1Chan[p] = s1;
+    A.scratch0[p] = s1;
+    A.scratch1[p] = (side - s1) + A.Chan2QStart[p] * A.InvChanLength[p];              // :565-567
+}
+
+__device__ __forceinline__ void velocity(const lf_substep_args &A, int p, double m3, double q)
+{
+    double area = m3 * A.InvChanLength[p]; // :693
+    if (area < 0.01) area = 0.01;
+    const double v1 = q / area, v2 = 0.36 * pow(q, 0.24);
+    double v = (v2 < v1) ? v2 : v1; // np.minimum, NaN propagates
+    if (isnan(v2)) v = v2;
+    double sinu = sqrt(A.PixelArea[p]) * A.InvChanLength[p];
+    if (sinu > 1) sinu = 1;
+    v *= sinu;
+    A.FlowVelocity[p] = v;
+    A.TravelDistance[p] = v * A.DtSec;
+}
+
+// routing.py:527-538 (single) / 574-578 (split, main channel)
+__global__ void __launch_bounds__(kBlock) k_substep_main(int n, lf_substep_args A)
+{
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= n) return;
+    double v = A.ChanLength[p] * A.ChannelAlpha[p] * pow(A.ChanQKin[p], A.Beta);
+    if (v < 0.0) v = 0.0;
+    const double q = pow(v * A.InvChanLength[p] * A.InvChannelAlpha[p], A.InvBeta);
+    A.ChanM3Kin[p] = v;
+    A.ChanQKin[p] = q;
+    if (!A.split) {
+        A.ChanQ[p] = q;
+        A.sumDisDay[p] += q;
+        velocity(A, p, v, q);
+    }
+}
+
+// routing.py:584-603 + 693-703
+__global__ void __launch_bounds__(kBlock) k_substep_floodplain(int n, lf_substep_args A)
+{
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= n) return;
+    const double start = A.Chan2M3Start[p];
+    double v = A.ChanLength[p] * A.ChannelAlpha2[p] * pow(A.Chan2QKin[p], A.Beta);
+    if ((v - start) < 0.0) v = start;
+    A.Chan2M3Kin[p] = v;
+    A.CrossSection2Area[p] = (v - start) * A.InvChanLength[p];
+    const double q2 = pow(v * A.InvChanLength[p] * A.InvChannelAlpha2[p], A.InvBeta);
+    A.Chan2QKin[p] = q2;
+    const double q1 = A.ChanQKin[p];
+    double q = q1 + q2 - A.QLimit[p];
+    if (q < 0.0) q = 0.0; // np.maximum(q, 0.0), NaN propagates
+    A.ChanQ[p] = q;
+    A.sumDisDay[p] += q;
+    velocity(A, p, A.ChanM3Kin[p], q1);
+}
+
+} // namespace
+
+extern "C" int lf_routing_substep(lf_router *r, const lf_substep_args *a)
+{
+    if (!r || !a) return lf_set_error(LF_E_INVALID, "null argument");
+    if (a->split && !r->has_floodplains)
+        return lf_set_error(LF_E_SECTION, "split routing requested but the router has no floodplain alpha");
+    LF_HIP(hipSetDevice(r->device));
+    hipStream_t s = r->ctx->stream;
+    const int n = (int)r->N;
+    if (n == 0) return LF_OK;
+    const dim3 grid(blocks_for(n)), block(kBlock);
+    hipLaunchKernelGGL(k_substep_sideflow, grid, block, 0, s, n, *a);
+    LF_TRY(route_device(r, a->ChanQKin, a->scratch0, LF_SECTION_MAIN));
+    hipLaunchKernelGGL(k_substep_main, grid, block, 0, s, n, *a);
+    if (a->split) {
+        LF_TRY(route_device(r, a->Chan2QKin, a->scratch1, LF_SECTION_FLOODPLAINS));
+        hipLaunchKernelGGL(k_substep_floodplain, grid, block, 0, s, n, *a);
+    }
+    LF_HIP(hipGetLastError());
+    return LF_OK;
+}

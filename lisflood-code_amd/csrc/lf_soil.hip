@@ -1,0 +1,403 @@
+// lf_soil.hip -- soil / vegetation column water balance on gfx950.
+// Replaces the numba kernels interception_water_balance (soilloop.py:27-70) and
+// soilColumnsWaterBalance (soilloop.py:78-355, helpers 360-396).
+//
+// Columns (vegetation fraction x pixel) are independent: one lane per pixel, the lane walks the V
+// vegetation fractions so that the per-pixel inputs (Rain, SnowMelt, isFrozenSoil, b_Xinanjiang, ...)
+// are fetched once.  Every array keeps the reference's [V,N] / [L,N] C-order layout, so lanes of a
+// wavefront read/write consecutive fp64 of one row: all ~95 streams are coalesced.  The kernel is
+// HBM-bound (~500 B per column-step) unless many Courant sub-steps are needed.
+#include <cmath>
+
+#include "lf_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kMaxVeg = 16;
+
+__device__ __forceinline__ double dmin(double a, double b) { return (b < a) ? b : a; } // builtins.min(a, b)
+__device__ __forceinline__ double dmax(double a, double b) { return (b > a) ? b : a; } // builtins.max(a, b)
+
+// interception_water_balance, soilloop.py:27-70
+__global__ void __launch_bounds__(kBlock) k_interception(lf_interception_args A)
+{
+    const long long pix = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (pix >= A.N) return;
+    const double rain = A.Rain[pix];
+    for (long long veg = 0; veg < A.V; ++veg) {
+        const long long i = veg * A.N + pix;
+        const double lai = A.LAI[i];
+        double smax;
+        if (lai <= .1)
+            smax = 0.;
+        else if (lai <= 43.3)
+            smax = 0.935 + 0.498 * lai - 0.00575 * (lai * lai);
+        else
+            smax = 11.718;
+        double cum = A.CumInterception[i], inter;
+        if (smax > 0) {
+            double v = smax - cum;
+            v = dmin(v, smax * (1. - exp(-0.046 * lai * rain / smax)));
+            v = dmin(v, rain);
+            inter = v;
+            cum += inter;
+        } else
+            inter = 0.;
+        double ta, drain;
+        if (cum > 0.) {
+            ta = dmax(dmin(cum, A.TaInterceptionMax[i]), 0.);
+            cum = dmax(cum - ta, 0.);
+            drain = A.drainageK * cum;
+            cum = dmax(cum - drain, 0.);
+        } else {
+            ta = 0.;
+            drain = 0.;
+        }
+        A.Interception[i] = inter;
+        A.TaInterception[i] = ta;
+        A.LeafDrainage[i] = drain;
+        A.CumInterception[i] = cum;
+    }
+}
+
+// saturationDegree (soilloop.py:378-383) + unsaturatedConductivity (360-367)
+__device__ __forceinline__ double unsat_k(double w, bool pore, double wres, double ws, double ksat, double inv_m,
+                                          double m)
+{
+    double s = 0.;
+    if (pore) s = dmax(dmin((w - wres) / (ws - wres), 1.), 0.);
+    const double t = 1. - pow(1. - pow(s, inv_m), m);
+    return ksat * sqrt(s) * (t * t);
+}
+
+struct veg_plan {
+    int mode[kMaxVeg];       // 0 skip, 1 all pixels, 2 only pixels with paddy_inactive[row] set
+    int landuse[kMaxVeg];    // index_landuse_all
+    int drained[kMaxVeg];    // is_drained_irrigation
+    int paddy_row[kMaxVeg];
+};
+
+// soilColumnsWaterBalance, soilloop.py:78-355
+__global__ void __launch_bounds__(kBlock) k_soil_columns(lf_soil_args A, veg_plan P)
+{
+    const long long pix = (long long)blockIdx.x * kBlock + threadIdx.x;
+    const long long N = A.N;
+    if (pix >= N) return;
+    const double DtDay = A.DtDay;
+    const double rain_plus_snow = A.Rain[pix] + A.SnowMelt[pix]; // :100
+    const bool frozen = A.isFrozenSoil[pix] != 0;
+    const double bx = A.b_Xinanjiang[pix], pinf = A.PowerInfPot[pix], ppref = A.PowerPrefFlow[pix];
+    const double uzk = A.UpperZoneK[pix], gwperc = A.GwPercStep[pix];
+    for (int veg = 0; veg < (int)A.V; ++veg) {
+        const int mode = P.mode[veg];
+        if (mode == 0) continue;
+        if (mode == 2 && !A.paddy_inactive[(long long)P.paddy_row[veg] * N + pix]) continue;
+        const long long i = (long long)veg * N + pix, j = (long long)P.landuse[veg] * N + pix;
+        const double wres1a = A.WRes1a[j], wres1b = A.WRes1b[j], wres2 = A.WRes2[j];
+        const double ws1a = A.WS1a[j], ws1b = A.WS1b[j], ws2 = A.WS2[j];
+        const bool pore1a = A.PoreSpaceNotZero1a[j] != 0, pore1b = A.PoreSpaceNotZero1b[j] != 0,
+                   pore2 = A.PoreSpaceNotZero2[j] != 0;
+        // available water for infiltration, :131
+        double awi = dmax(rain_plus_snow + A.LeafDrainage[i] - A.Interception[i], 0.);
+        // days since last rain, :137-140
+        double dslr = A.DSLR[i];
+        if (awi > A.AvWaterThreshold)
+            dslr = 1;
+        else
+            dslr += DtDay;
+        A.DSLR[i] = dslr;
+        // bare soil evaporation, :148-163
+        double w1a = A.W1a[i], w1b = A.W1b[i], esact;
+        if (frozen)
+            esact = 0.;
+        else {
+            esact = A.ESMax[i] * (sqrt(dslr) - sqrt(dslr - 1));
+            esact = dmax(dmin(esact, A.W1[i] - A.WRes1[j]), 0.);
+            const double supply1a = w1a - wres1a;
+            const double es1a = dmin(esact, supply1a);
+            const double es1b = dmax(esact - supply1a, 0.);
+            w1a = dmax(w1a - es1a, wres1a);
+            w1b = dmax(w1b - es1b, wres1b);
+        }
+        A.ESAct[i] = esact;
+        double w1 = w1a + w1b;
+        // Xinanjiang infiltration capacity, :168-179
+        const double relsat1 = pore1a ? dmin(w1 / A.WS1[j], 1.0) : 0.0;
+        const double satfrac = 1.0 - pow(1.0 - relsat1, bx);
+        const double infpot = frozen ? 0.0 : A.StoreMaxPervious[j] * pow(1. - satfrac, pinf) * DtDay;
+        // preferential flow, :190-194
+        const double pref = pow(relsat1, ppref) * awi;
+        A.PrefFlow[i] = pref;
+        awi -= pref;
+        A.AvailableWaterForInfiltration[i] = awi;
+        // infiltration, :201-211
+        double inf = dmax(dmin(awi, infpot), 0.);
+        const double test1a = w1a + inf;
+        w1a = dmin(ws1a, test1a);
+        w1b += dmax(test1a - ws1a, 0.);
+        double w2 = A.W2[i];
+        // Van Genuchten conductivities and Courant numbers, :223-249
+        const double ks1a = A.KSat1a[j], ks1b = A.KSat1b[j], ks2 = A.KSat2[j];
+        const double im1a = A.GenuInvM1a[j], im1b = A.GenuInvM1b[j], im2 = A.GenuInvM2[j];
+        const double m1a = A.GenuM1a[j], m1b = A.GenuM1b[j], m2 = A.GenuM2[j];
+        double k1a = unsat_k(w1a, pore1a, wres1a, ws1a, ks1a, im1a, m1a);
+        double k1b = unsat_k(w1b, pore1b, wres1b, ws1b, ks1b, im1b, m1b);
+        double k2 = unsat_k(w2, pore2, wres2, ws2, ks2, im2, m2);
+        double av1a = w1a - wres1a, av1b = w1b - wres1b, av2 = w2 - wres2;
+        double cap1 = ws1b - w1b, cap2 = ws2 - w2;
+        const double ca = (av1a == 0) ? 0. : k1a * DtDay / av1a;
+        const double cb = (av1b == 0) ? 0. : k1b * DtDay / av1b;
+        const double cg = (av2 == 0) ? 0. : k2 * DtDay / av2;
+        const double courant = dmax(dmax(ca, cb), cg);
+        const double nsub_f = dmax(1., ceil(courant / A.CourantCrit));
+        const long long nsub = (long long)nsub_f;
+        // sub-step loop, :266-312
+        double wt1a = w1a, wt1b = w1b, wt2 = w2;
+        double sa = 0., sb = 0., sg = 0.;
+        const double dtsub = DtDay / (double)nsub;
+        for (long long s = 0; s < nsub; ++s) {
+            if (s > 0) {
+                k1a = unsat_k(wt1a, pore1a, wres1a, ws1a, ks1a, im1a, m1a);
+                k1b = unsat_k(wt1b, pore1b, wres1b, ws1b, ks1b, im1b, m1b);
+                k2 = unsat_k(wt2, pore2, wres2, ws2, ks2, im2, m2);
+            }
+            const double fa = dmin(k1a * dtsub, cap1);
+            const double fb = dmin(k1b * dtsub, cap2);
+            const double fg = dmin(k2 * dtsub, av2);
+            av1a -= fa;
+            av1b += fa - fb;
+            av2 += fb - fg;
+            wt1a = av1a + wres1a;
+            wt1b = av1b + wres1b;
+            wt2 = av2 + wres2;
+            cap1 = ws1b - wt1b;
+            cap2 = ws2 - wt2;
+            sa += fa;
+            sb += fb;
+            sg += fg;
+        }
+        if (frozen) sa = sb = sg = 0.; // :313-316
+        A.SeepTopToSubA[i] = sa;
+        A.SeepTopToSubB[i] = sb;
+        A.SeepSubToGW[i] = sg;
+        // state update, :319-325 (W1 is taken BEFORE the 1a overflow correction, as the reference does)
+        w1a -= sa;
+        w1b = w1b + sa - sb;
+        w2 = w2 + sb - sg;
+        w1 = w1a + w1b;
+        inf -= dmax(w1a - ws1a, 0.);
+        w1a = dmin(w1a, ws1a);
+        A.Infiltration[i] = inf;
+        A.W1a[i] = w1a;
+        A.W1b[i] = w1b;
+        A.W1[i] = w1;
+        A.W2[i] = w2;
+        // diagnostics, :330-336
+        A.Theta1a[i] = pore1a ? w1a / A.SoilDepth1a[j] : 0.;
+        A.Theta1b[i] = pore1b ? w1b / A.SoilDepth1b[j] : 0.;
+        A.Theta2[i] = pore2 ? w2 / A.SoilDepth2[j] : 0.;
+        const double wwp1a = A.WWP1a[j], wwp1b = A.WWP1b[j], wwp1 = A.WWP1[j], wwp2 = A.WWP2[j];
+        A.Sat1a[i] = (w1a - wwp1a) / (A.WFC1a[j] - wwp1a);
+        A.Sat1b[i] = (w1b - wwp1b) / (A.WFC1b[j] - wwp1b);
+        A.Sat1[i] = (w1 - wwp1) / (A.WFC1[j] - wwp1);
+        A.Sat2[i] = (w2 - wwp2) / (A.WFC2[j] - wwp2);
+        // upper zone, :340-354
+        double uz = A.UZ[i];
+        double uzout = dmin(uzk * uz, uz);
+        uz = dmax(uz - uzout, 0.);
+        if (P.drained[veg]) {
+            uzout += A.DrainedFraction * sg;
+            uz += (1 - A.DrainedFraction) * sg + pref;
+        } else
+            uz += sg + pref;
+        const double perc = dmin(gwperc, uz);
+        uz = dmax(uz - perc, 0.);
+        A.UZOutflow[i] = uzout;
+        A.GwPercUZLZ[i] = perc;
+        A.UZ[i] = uz;
+    }
+}
+
+int make_plan(const lf_soil_args *a, const uint8_t *paddy_any, veg_plan *P)
+{
+    if (a->V > kMaxVeg) return lf_set_error(LF_E_INVALID, "V = %lld exceeds the supported maximum %d", (long long)a->V, kMaxVeg);
+    int count_paddy = 0;
+    for (int veg = 0; veg < (int)a->V; ++veg) {
+        P->landuse[veg] = (int)a->index_landuse_all[veg];
+        if (P->landuse[veg] < 0 || P->landuse[veg] >= a->L)
+            return lf_set_error(LF_E_INVALID, "index_landuse_all[%d] = %d out of range", veg, P->landuse[veg]);
+        P->paddy_row[veg] = 0;
+        if (a->is_paddy_irrig && a->is_paddy_irrig[veg]) { // soilloop.py:107-113
+            if (!paddy_any || !paddy_any[count_paddy]) {
+                P->mode[veg] = 0; // note: the reference does not advance count_paddy_crop here either
+                P->drained[veg] = 0;
+                continue;
+            }
+            P->mode[veg] = 2;
+            P->drained[veg] = 0;
+            P->paddy_row[veg] = count_paddy++;
+        } else {
+            P->mode[veg] = 1;
+            P->drained[veg] = (a->is_irrigated && a->is_irrigated[veg] && a->DrainedFraction > 0) ? 1 : 0;
+        }
+    }
+    return LF_OK;
+}
+
+inline int blocks_for(int64_t n) { return (int)((n + kBlock - 1) / kBlock); }
+
+} // namespace
+
+extern "C" {
+
+int lf_interception_device(int device, const lf_interception_args *a)
+{
+    if (!a) return lf_set_error(LF_E_INVALID, "null argument");
+    lf_device_ctx *c;
+    LF_TRY(lf_ctx(device, &c));
+    if (a->N > 0 && a->V > 0)
+        hipLaunchKernelGGL(k_interception, dim3(blocks_for(a->N)), dim3(kBlock), 0, c->stream, *a);
+    LF_HIP(hipGetLastError());
+    return LF_OK;
+}
+
+int lf_soil_columns_device(int device, const lf_soil_args *a)
+{
+    if (!a || !a->index_landuse_all) return lf_set_error(LF_E_INVALID, "null argument");
+    lf_device_ctx *c;
+    LF_TRY(lf_ctx(device, &c));
+    veg_plan P;
+    LF_TRY(make_plan(a, a->paddy_any, &P));
+    if (a->N > 0 && a->V > 0)
+        hipLaunchKernelGGL(k_soil_columns, dim3(blocks_for(a->N)), dim3(kBlock), 0, c->stream, *a, P);
+    LF_HIP(hipGetLastError());
+    return LF_OK;
+}
+
+} // extern "C"
+
+// ---- host-buffer forms: stage every array through device memory (PCIe-inclusive) -------------------
+
+namespace {
+struct stager {
+    hipStream_t s;
+    std::vector<void *> bufs;
+    struct wb {
+        void *host;
+        void *dev;
+        size_t bytes;
+    };
+    std::vector<wb> writeback;
+    ~stager()
+    {
+        for (void *p : bufs) (void)hipFree(p);
+    }
+    template <typename T>
+    int in(const T *&field, size_t count)
+    {
+        if (!field) return lf_set_error(LF_E_INVALID, "null array argument");
+        void *d = nullptr;
+        LF_HIP(hipMalloc(&d, count * sizeof(T) + 8));
+        bufs.push_back(d);
+        LF_HIP(hipMemcpyAsync(d, field, count * sizeof(T), hipMemcpyHostToDevice, s));
+        field = (const T *)d;
+        return LF_OK;
+    }
+    template <typename T>
+    int inout(T *&field, size_t count)
+    {
+        if (!field) return lf_set_error(LF_E_INVALID, "null array argument");
+        void *d = nullptr;
+        LF_HIP(hipMalloc(&d, count * sizeof(T) + 8));
+        bufs.push_back(d);
+        LF_HIP(hipMemcpyAsync(d, field, count * sizeof(T), hipMemcpyHostToDevice, s));
+        writeback.push_back({(void *)field, d, count * sizeof(T)});
+        field = (T *)d;
+        return LF_OK;
+    }
+    int finish()
+    {
+        for (const wb &w : writeback) LF_HIP(hipMemcpyAsync(w.host, w.dev, w.bytes, hipMemcpyDeviceToHost, s));
+        LF_HIP(hipStreamSynchronize(s));
+        return LF_OK;
+    }
+};
+} // namespace
+
+extern "C" {
+
+int lf_interception_host(int device, const lf_interception_args *a_in)
+{
+    if (!a_in) return lf_set_error(LF_E_INVALID, "null argument");
+    lf_device_ctx *c;
+    LF_TRY(lf_ctx(device, &c));
+    lf_interception_args a = *a_in;
+    stager st{c->stream, {}, {}};
+    const size_t vn = (size_t)(a.V * a.N), n = (size_t)a.N;
+    LF_TRY(st.inout(a.Interception, vn));
+    LF_TRY(st.inout(a.TaInterception, vn));
+    LF_TRY(st.inout(a.LeafDrainage, vn));
+    LF_TRY(st.inout(a.CumInterception, vn));
+    LF_TRY(st.in(a.LAI, vn));
+    LF_TRY(st.in(a.Rain, n));
+    LF_TRY(st.in(a.TaInterceptionMax, vn));
+    LF_TRY(lf_interception_device(device, &a));
+    return st.finish();
+}
+
+int lf_soil_columns_host(int device, const lf_soil_args *a_in)
+{
+    if (!a_in || !a_in->index_landuse_all) return lf_set_error(LF_E_INVALID, "null argument");
+    lf_device_ctx *c;
+    LF_TRY(lf_ctx(device, &c));
+    lf_soil_args a = *a_in;
+    stager st{c->stream, {}, {}};
+    const size_t vn = (size_t)(a.V * a.N), ln = (size_t)(a.L * a.N), n = (size_t)a.N;
+    // which paddy rows have any inactive pixel (soilloop.py:109)
+    std::vector<uint8_t> any;
+    int n_paddy = 0;
+    if (a.is_paddy_irrig)
+        for (int v = 0; v < (int)a.V; ++v) n_paddy += a.is_paddy_irrig[v] != 0;
+    if (n_paddy > 0) {
+        if (!a.paddy_inactive) return lf_set_error(LF_E_INVALID, "paddy_inactive is required when is_paddy_irrig is set");
+        any.assign(n_paddy, 0);
+        for (int r = 0; r < n_paddy; ++r)
+            for (size_t p = 0; p < n && !any[r]; ++p) any[r] = a.paddy_inactive[(size_t)r * n + p] != 0;
+        LF_TRY(st.in(a.paddy_inactive, (size_t)n_paddy * n));
+        a.paddy_any = any.data();
+    } else {
+        a.paddy_inactive = nullptr;
+        a.paddy_any = nullptr;
+    }
+#define LF_IN_L(f) LF_TRY(st.in(a.f, ln))
+#define LF_IN_N(f) LF_TRY(st.in(a.f, n))
+#define LF_IN_V(f) LF_TRY(st.in(a.f, vn))
+#define LF_IO_V(f) LF_TRY(st.inout(a.f, vn))
+    LF_IN_L(PoreSpaceNotZero1a); LF_IN_L(PoreSpaceNotZero1b); LF_IN_L(PoreSpaceNotZero2);
+    LF_IN_L(KSat1a); LF_IN_L(KSat1b); LF_IN_L(KSat2);
+    LF_IN_L(GenuInvM1a); LF_IN_L(GenuInvM1b); LF_IN_L(GenuInvM2);
+    LF_IN_L(GenuM1a); LF_IN_L(GenuM1b); LF_IN_L(GenuM2);
+    LF_IN_L(WRes1a); LF_IN_L(WRes1b); LF_IN_L(WRes1); LF_IN_L(WRes2);
+    LF_IN_L(WWP1a); LF_IN_L(WWP1b); LF_IN_L(WWP1); LF_IN_L(WWP2);
+    LF_IN_L(WFC1a); LF_IN_L(WFC1b); LF_IN_L(WFC1); LF_IN_L(WFC2);
+    LF_IN_L(SoilDepth1a); LF_IN_L(SoilDepth1b); LF_IN_L(SoilDepth2);
+    LF_IN_L(WS1a); LF_IN_L(WS1b); LF_IN_L(WS1); LF_IN_L(WS2); LF_IN_L(StoreMaxPervious);
+    LF_IN_N(Rain); LF_IN_N(SnowMelt); LF_IN_N(b_Xinanjiang); LF_IN_N(PowerInfPot); LF_IN_N(PowerPrefFlow);
+    LF_IN_N(UpperZoneK); LF_IN_N(GwPercStep); LF_IN_N(isFrozenSoil);
+    LF_IN_V(LeafDrainage); LF_IN_V(Interception); LF_IN_V(ESMax);
+    LF_IO_V(AvailableWaterForInfiltration); LF_IO_V(DSLR); LF_IO_V(ESAct); LF_IO_V(PrefFlow); LF_IO_V(Infiltration);
+    LF_IO_V(W1a); LF_IO_V(W1b); LF_IO_V(W1); LF_IO_V(W2);
+    LF_IO_V(Theta1a); LF_IO_V(Theta1b); LF_IO_V(Theta2);
+    LF_IO_V(Sat1a); LF_IO_V(Sat1b); LF_IO_V(Sat1); LF_IO_V(Sat2);
+    LF_IO_V(SeepTopToSubA); LF_IO_V(SeepTopToSubB); LF_IO_V(SeepSubToGW);
+    LF_IO_V(UZOutflow); LF_IO_V(UZ); LF_IO_V(GwPercUZLZ);
+#undef LF_IN_L
+#undef LF_IN_N
+#undef LF_IN_V
+#undef LF_IO_V
+    LF_TRY(lf_soil_columns_device(device, &a));
+    return st.finish();
+}
+
+} // extern "C"

@@ -1,0 +1,152 @@
+"""ctypes binding of liblisflood_amd.so (C ABI: include/lisflood_amd.h)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBNAME = "liblisflood_amd.so"
+_lib = None
+
+LF_OK = 0
+LF_E_INVALID, LF_E_CYCLE, LF_E_NO_DEVICE, LF_E_HIP, LF_E_SECTION, LF_E_COMM = -1, -2, -3, -4, -5, -6
+SECTION = {"main_channel": 0, "floodplains": 1}
+
+
+class LisfloodAmdError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("lisflood_amd error %d: %s" % (code, message))
+        self.code = code
+
+
+def library_path():
+    return os.path.join(_HERE, _LIBNAME)
+
+
+def lib():
+    """The loaded HIP library.  Fails loudly when it has not been built: there is no fallback path."""
+    global _lib
+    if _lib is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise LisfloodAmdError(LF_E_NO_DEVICE, "%s not found - build it with `make -C lisflood-code_amd` "
+                                   "(or __graft_entry__.build()); lisflood_amd has no CPU fallback" % path)
+        L = C.CDLL(path)
+        L.lf_last_error.restype = C.c_char_p
+        L.lf_graph_num_pixels.restype = C.c_int64
+        L.lf_graph_num_levels.restype = C.c_int64
+        L.lf_graph_num_pixels.argtypes = [C.c_void_p]
+        L.lf_graph_num_levels.argtypes = [C.c_void_p]
+        L.lf_graph_max_upstream.argtypes = [C.c_void_p]
+        L.lf_graph_destroy.argtypes = [C.c_void_p]
+        L.lf_graph_destroy.restype = None
+        L.lf_router_destroy.argtypes = [C.c_void_p]
+        L.lf_router_destroy.restype = None
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != LF_OK:
+        raise LisfloodAmdError(rc, lib().lf_last_error().decode("utf-8", "replace"))
+
+
+def ptr(a):
+    """void* of a numpy array (keeps the array alive through the returned object) or None."""
+    if a is None:
+        return None
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def u8(a):
+    a = np.asarray(a)
+    if a.dtype == np.bool_:
+        a = a.view(np.uint8) if a.flags.c_contiguous else a.astype(np.uint8)
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def device_count():
+    n = C.c_int(0)
+    check(lib().lf_device_count(C.byref(n)))
+    return n.value
+
+
+def device_name(device=0):
+    buf = C.create_string_buffer(256)
+    check(lib().lf_device_name(C.c_int(device), buf, C.c_size_t(256)))
+    return buf.value.decode()
+
+
+class DeviceArray:
+    """fp64 / uint8 vector resident in HBM (thin RAII wrapper over lf_device_alloc)."""
+
+    def __init__(self, shape, dtype=np.float64, device=0):
+        self.shape = tuple(np.atleast_1d(shape).tolist()) if not isinstance(shape, tuple) else shape
+        self.dtype = np.dtype(dtype)
+        self.device = device
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        p = C.c_void_p()
+        check(lib().lf_device_alloc(C.c_int(device), C.c_size_t(self.nbytes), C.byref(p)))
+        self.ptr = C.c_void_p(p.value)
+
+    @classmethod
+    def from_host(cls, a, device=0):
+        a = np.ascontiguousarray(a)
+        if a.dtype == np.bool_:
+            a = a.view(np.uint8)
+        d = cls(a.shape, a.dtype, device)
+        d.upload(a)
+        return d
+
+    def upload(self, a):
+        a = np.ascontiguousarray(a)
+        if a.dtype == np.bool_:
+            a = a.view(np.uint8)
+        assert a.nbytes == self.nbytes and a.dtype == self.dtype, (a.shape, a.dtype, self.shape, self.dtype)
+        check(lib().lf_memcpy_h2d(C.c_int(self.device), self.ptr, ptr(a), C.c_size_t(self.nbytes)))
+        return self
+
+    def download(self, out=None):
+        if out is None:
+            out = np.empty(self.shape, self.dtype)
+        assert out.nbytes == self.nbytes and out.flags.c_contiguous
+        check(lib().lf_memcpy_d2h(C.c_int(self.device), ptr(out), self.ptr, C.c_size_t(self.nbytes)))
+        return out
+
+    def copy_from(self, other):
+        assert other.nbytes == self.nbytes
+        check(lib().lf_memcpy_d2d(C.c_int(self.device), self.ptr, other.ptr, C.c_size_t(self.nbytes)))
+        return self
+
+    def zero(self):
+        check(lib().lf_memset(C.c_int(self.device), self.ptr, C.c_int(0), C.c_size_t(self.nbytes)))
+        return self
+
+    def free(self):
+        if getattr(self, "ptr", None) is not None and self.ptr.value:
+            lib().lf_device_free(C.c_int(self.device), self.ptr)
+            self.ptr = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def synchronize(device=0):
+    check(lib().lf_device_synchronize(C.c_int(device)))
+
+
+def timer_start(device=0):
+    check(lib().lf_timer_start(C.c_int(device)))
+
+
+def timer_stop(device=0):
+    ms = C.c_double(0.0)
+    check(lib().lf_timer_stop(C.c_int(device), C.byref(ms)))
+    return ms.value

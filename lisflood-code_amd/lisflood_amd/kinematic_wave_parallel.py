@@ -1,0 +1,213 @@
+"""kinematicWave -- drop-in for the reference class of the same name
+(src/lisflood/hydrological_modules/kinematic_wave_parallel.py:114-184), running on MI355X.
+
+Same constructor arguments, same `kinematicWaveRouting(discharge, specific_lateral_inflow, section)`
+contract (discharge is mutated in place, returns None, a bad section raises Exception, optional
+one-shot NaN/Inf warning), same public attributes (downstream_lookup, upstream_lookup,
+num_upstream_pixels, pixels_ordered, order_start_stop).  The solve itself is the hand-written HIP
+level sweep of csrc/lf_router.hip, called through the C ABI.
+"""
+import ctypes as C
+import warnings
+
+import numpy as np
+
+from . import _lib
+from ._lib import DeviceArray, check, f64, lib, ptr, u8
+
+try:  # inside the reference tree the warning class lives here (global_modules/errors.py:42-53)
+    from lisflood.global_modules.errors import LisfloodWarning  # type: ignore
+except Exception:  # stand-alone
+    class LisfloodWarning(Warning):
+        pass
+
+
+class Graph:
+    """LDD -> adjacency -> routing orders (lf_graph); host memory only."""
+
+    def __init__(self, compressed_encoded_ldd=None, land_mask=None, ldd_raster=None):
+        self._h = C.c_void_p()
+        if ldd_raster is not None:
+            r = np.ascontiguousarray(ldd_raster, dtype=np.uint8)
+            H, W = r.shape
+            m = None if land_mask is None else u8(land_mask)
+            check(lib().lf_graph_create_raster(ptr(r), ptr(m), C.c_int(H), C.c_int(W), C.byref(self._h)))
+        else:
+            land_mask = np.asarray(land_mask)
+            H, W = land_mask.shape
+            codes = f64(compressed_encoded_ldd)
+            m = u8(land_mask)
+            if codes.size != int(m.sum()):
+                raise ValueError("compressed LDD has %d values but the land mask has %d land cells"
+                                 % (codes.size, int(m.sum())))
+            check(lib().lf_graph_create(ptr(codes), ptr(m), C.c_int(H), C.c_int(W), C.byref(self._h)))
+        self.shape = (H, W)
+        self.num_pixels = int(lib().lf_graph_num_pixels(self._h))
+        self.num_levels = int(lib().lf_graph_num_levels(self._h))
+        self.max_upstream = int(lib().lf_graph_max_upstream(self._h))
+
+    def lookups(self):
+        N, K = self.num_pixels, self.max_upstream
+        down = np.empty(N, np.float64)
+        ups = np.empty((N, K), np.int64)
+        nups = np.empty(N, np.int64)
+        check(lib().lf_graph_get_lookups(self._h, ptr(down), ptr(ups), ptr(nups)))
+        return down, ups, nups
+
+    def orders(self):
+        po = np.empty(self.num_pixels, np.int64)
+        ss = np.empty((self.num_levels, 2), np.int64)
+        check(lib().lf_graph_get_orders(self._h, ptr(po), ptr(ss)))
+        return po, ss
+
+    def layout(self):
+        perm = np.empty(self.num_pixels, np.int32)
+        ups_ptr = np.empty(self.num_pixels + 1, np.int32)
+        level_start = np.empty(self.num_levels + 1, np.int64)
+        check(lib().lf_graph_get_layout(self._h, ptr(perm), ptr(ups_ptr), ptr(level_start)))
+        return perm, ups_ptr, level_start
+
+    def close(self):
+        if self._h:
+            lib().lf_graph_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class kinematicWave:
+    """See module docstring.  Extra keyword `device` selects the GPU (default 0)."""
+
+    def __init__(self, compressed_encoded_ldd, land_mask, alpha_channel, beta, space_delta, time_delta,
+                 alpha_floodplains=None, flagnancheck=False, device=0, graph=None):
+        self.kinematic_wave_warning_printed = False
+        self.flagnancheck = flagnancheck
+        self.device = device
+        self.space_delta = space_delta
+        self.beta = beta
+        self.inv_beta = 1 / beta
+        self.b_minus_1 = beta - 1
+        self.graph = graph if graph is not None else Graph(compressed_encoded_ldd, land_mask)
+        N = self.graph.num_pixels
+        self.num_pixels = N
+        alpha = f64(np.broadcast_to(alpha_channel, (N,)))
+        if np.ndim(space_delta) == 0:
+            dx, dxs = None, float(space_delta)
+        else:
+            dx, dxs = f64(space_delta), 0.0
+        a2 = None if alpha_floodplains is None else f64(np.broadcast_to(alpha_floodplains, (N,)))
+        self._h = C.c_void_p()
+        check(lib().lf_router_create(self.graph._h, ptr(alpha), C.c_double(beta), ptr(dx), C.c_double(dxs),
+                                     C.c_double(time_delta), ptr(a2), C.c_int(device), C.byref(self._h)))
+        self._lookups = None
+        self._orders = None
+
+    # --- the reference's public attributes, materialised lazily (init-time only data) ---------------
+    def _lk(self):
+        if self._lookups is None:
+            self._lookups = self.graph.lookups()
+        return self._lookups
+
+    @property
+    def downstream_lookup(self):
+        return self._lk()[0]
+
+    @property
+    def upstream_lookup(self):
+        return self._lk()[1]
+
+    @property
+    def num_upstream_pixels(self):
+        return self._lk()[2]
+
+    @property
+    def pixels_ordered(self):
+        if self._orders is None:
+            self._orders = self.graph.orders()
+        return self._orders[0]
+
+    @property
+    def order_start_stop(self):
+        if self._orders is None:
+            self._orders = self.graph.orders()
+        return self._orders[1]
+
+    # --- routing -----------------------------------------------------------------------------------
+    @staticmethod
+    def _section(section):
+        if section not in _lib.SECTION:
+            raise Exception("The section parameter must be either 'main_channel' or 'floodplain'!")
+        return _lib.SECTION[section]
+
+    def kinematicWaveRouting(self, discharge, specific_lateral_inflow, section="main_channel"):
+        """Host-vector form, exactly the reference call: `discharge` (fp64, C-contiguous) is updated in place."""
+        sec = self._section(section)
+        if not (isinstance(discharge, np.ndarray) and discharge.dtype == np.float64 and discharge.flags.c_contiguous
+                and discharge.size == self.num_pixels):
+            raise ValueError("discharge must be a C-contiguous float64 vector of %d land pixels" % self.num_pixels)
+        q = f64(np.broadcast_to(specific_lateral_inflow, (self.num_pixels,)))
+        check(lib().lf_router_route_host(self._h, ptr(discharge), ptr(q), C.c_int(sec)))
+        if self.flagnancheck and not self.kinematic_wave_warning_printed:
+            if not np.all(np.isfinite(discharge)):
+                self._warn()
+
+    def route_device(self, discharge_dev, lateral_dev, section="main_channel"):
+        """Device-resident form: DeviceArray vectors in pixel order; asynchronous."""
+        sec = self._section(section)
+        check(lib().lf_router_route_device(self._h, discharge_dev.ptr, lateral_dev.ptr, C.c_int(sec)))
+        if self.flagnancheck and not self.kinematic_wave_warning_printed:
+            n = C.c_int64(0)
+            check(lib().lf_count_nonfinite(C.c_int(self.device), discharge_dev.ptr, C.c_int64(self.num_pixels),
+                                           C.byref(n)))
+            if n.value:
+                self._warn()
+
+    def _warn(self):
+        self.kinematic_wave_warning_printed = True
+        warnings.warn(LisfloodWarning("Warning: NaN or Inf values after kinematicRouting module. Suggestion: please "
+                                      "check the input maps (e.g. channel geometry and ldd)"))
+
+    # --- LDD reductions on the same graph ------------------------------------------------------------
+    def upstream_sum(self, weights):
+        """np.bincount(downstruct, weights)[:N] / PCRaster upstream(ldd, x) (routing.py:159-164, 387)."""
+        w = f64(weights)
+        out = np.empty(self.num_pixels)
+        check(lib().lf_upstream_sum_host(self._h, ptr(w), ptr(out)))
+        return out
+
+    def accuflux(self, x):
+        """PCRaster accuflux(ldd, x): x accumulated over all upstream cells incl. the cell (routing.py:98)."""
+        xv = f64(np.broadcast_to(x, (self.num_pixels,)))
+        out = np.empty(self.num_pixels)
+        check(lib().lf_accuflux_host(self._h, ptr(xv), ptr(out)))
+        return out
+
+    # --- instrumentation -------------------------------------------------------------------------
+    def last_launches(self):
+        s = (C.c_int64 * 4)()
+        check(lib().lf_router_last_launches(self._h, s))
+        return dict(launches=s[0], wide=s[1], narrow=s[2], levels=s[3])
+
+    def profile(self, on):
+        check(lib().lf_router_profile_enable(self._h, C.c_int(1 if on else 0)))
+
+    def profile_read(self, reset=True):
+        o = (C.c_double * 9)()
+        check(lib().lf_router_profile_read(self._h, o, C.c_int(1 if reset else 0)))
+        names = ("prep", "wide_level", "narrow_run")
+        return {names[i]: dict(launches=o[3 * i], ms=o[3 * i + 1], cells=o[3 * i + 2]) for i in range(3)}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().lf_router_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,198 @@
+"""routing -- channel routing module in the reference's HydroModule shape
+(src/lisflood/hydrological_modules/routing.py), with the per-sub-step work of `dynamic()` executed on
+MI355X: sideflow assembly, 1 (single) or 2 (split) kinematic-wave router calls, the volume <-> discharge
+fix-ups, sumDisDay, FlowVelocity/TravelDistance (routing.py:435-706).
+
+All state lives on `var` under the reference's attribute names.  Two ways to run:
+  * drop-in (default): every `dynamic(s)` uploads the state vectors it reads from `var`, runs the fused
+    device sub-step and writes the results back into `var` -- other (CPU) modules may touch `var`
+    between sub-steps exactly as in the reference;
+  * resident: `begin_step()` uploads once, `dynamic(s)` only uploads the sideflow, `end_step()`
+    downloads -- the NoRoutSteps x (1..2) router calls of a model step never leave the GPU.
+
+What is NOT here (out of this round's scope): `initial()`'s PCRaster LDD preprocessing
+and map loading (routing.py:61-339), lakes/reservoirs/polder/inflow/transmission in-loop calls
+(routing.py:441-450) -- pass them as `inloop_modules` callables and they are invoked at the same place.
+"""
+import ctypes as C
+import types
+
+import numpy as np
+
+from ._lib import DeviceArray, check, f64, lib, u8
+from .hydro_module import HydroModule
+from .kinematic_wave_parallel import kinematicWave
+
+_STATIC = ("ChanLength InvChanLength ChannelAlpha InvChannelAlpha ChannelAlpha2 InvChannelAlpha2 Chan2M3Start "
+           "Chan2QStart M3Limit QLimit PixelArea IsChannelKinematic").split()
+_STATE = "ChanQKin ChanM3Kin Chan2QKin Chan2M3Kin CrossSection2Area Sideflow1Chan ChanQ sumDisDay".split()
+_OUT = "FlowVelocity TravelDistance".split()
+
+
+class _SubstepArgs(C.Structure):  # lf_substep_args, include/lisflood_amd.h
+    _fields_ = ([(k, C.c_void_p) for k in _STATIC] + [("SideflowChanM3", C.c_void_p)] +
+                [(k, C.c_void_p) for k in _STATE + _OUT] + [("scratch0", C.c_void_p), ("scratch1", C.c_void_p)] +
+                [("Beta", C.c_double), ("InvBeta", C.c_double), ("InvDtRouting", C.c_double), ("DtSec", C.c_double),
+                 ("split", C.c_int32)])
+
+
+class routing(HydroModule):
+    input_files_keys = {'all': ['beta', 'ChanLength', 'Ldd', 'Channels', 'ChanGrad', 'ChanGradMin', 'CalChanMan',
+                                'ChanMan', 'ChanBottomWidth', 'ChanDepthThreshold', 'ChanSdXdY',
+                                'TotalCrossSectionAreaInitValue', 'PrevDischarge'],
+                        'SplitRouting': ['CrossSection2AreaInitValue', 'PrevSideflowInitValue', 'CalChanMan2'],
+                        'dynamicWave': ['ChannelsDynamic']}   # routing.py:44-50
+    module_name = 'Routing'
+
+    def __init__(self, routing_variable, split_routing=False, init_lisflood=False, options=None, device=0,
+                 inloop_modules=()):
+        self.var = routing_variable
+        self.options = dict(options or {})
+        self.options.setdefault("SplitRouting", split_routing)
+        self.options.setdefault("InitLisflood", init_lisflood)
+        self.device = device
+        self.inloop_modules = tuple(inloop_modules)
+        self.river_router = None
+        self._dev = {}
+        self._resident = False
+
+    # ------------------------------------------------------------------------------------------
+    def attach_router(self, compressed_ldd_kinematic, land_mask, flagnancheck=False):
+        """The router construction of initialSecond (routing.py:401-403)."""
+        v = self.var
+        self.river_router = kinematicWave(compressed_ldd_kinematic, land_mask, v.ChannelAlpha, v.Beta, v.ChanLength,
+                                          v.DtRouting, alpha_floodplains=getattr(v, "ChannelAlpha2", None),
+                                          flagnancheck=flagnancheck, device=self.device)
+        return self.river_router
+
+    def initialSecond(self, compressed_ldd_kinematic=None, land_mask=None, flagnancheck=False):
+        """Split-routing start values (routing.py:355-397) + router (401-403).  The one-hop upstream sum of
+        QLimit (PCRaster `upstream`, routing.py:387) runs on the device graph."""
+        v = self.var
+        split = self.options["SplitRouting"]
+        if split:
+            if not hasattr(v, "ChannelAlpha2") or v.ChannelAlpha2 is None:
+                raise ValueError("SplitRouting needs var.ChannelAlpha2 (routing.py:355-358)")
+            v.InvChannelAlpha2 = 1 / v.ChannelAlpha2
+        self.attach_router(compressed_ldd_kinematic, land_mask, flagnancheck)
+        if split and not self.options["InitLisflood"]:
+            v.M3Limit = v.ChannelAlpha * v.ChanLength * (v.QLimit ** v.Beta)                       # :371
+            v.Chan2M3Start = v.ChannelAlpha2 * v.ChanLength * (v.QLimit ** v.Beta)                 # :384
+            v.Chan2QStart = v.QLimit - self.river_router.upstream_sum(v.QLimit)                    # :387
+            v.Chan2M3Kin = v.CrossSection2Area * v.ChanLength + v.Chan2M3Start                     # :391
+            v.ChanM3Kin = v.ChanM3 - v.Chan2M3Kin + v.Chan2M3Start                                 # :392
+            v.ChanM3Kin = np.where((v.ChanM3Kin < 0.0) & (v.ChanM3Kin > -0.0000001), 0.0, v.ChanM3Kin)  # :394
+            v.Chan2QKin = (v.Chan2M3Kin * v.InvChanLength * v.InvChannelAlpha2) ** v.InvBeta      # :396
+            v.ChanQKin = (v.ChanM3Kin * v.InvChanLength * v.InvChannelAlpha) ** v.InvBeta          # :397
+
+    # ------------------------------------------------------------------------------------------
+    def _split(self):
+        return bool(self.options["SplitRouting"]) and not self.options["InitLisflood"]   # routing.py:518
+
+    def _ensure_device(self):
+        v = self.var
+        N = self.river_router.num_pixels
+        if "scratch0" in self._dev:
+            return
+        zeros = np.zeros(N)
+        for k in _STATIC:
+            a = getattr(v, k, None)
+            if a is None:
+                a = np.ones(N, bool) if k == "IsChannelKinematic" else zeros
+            a = u8(np.broadcast_to(a, (N,))) if k == "IsChannelKinematic" else f64(np.broadcast_to(a, (N,)))
+            self._dev[k] = DeviceArray.from_host(a, self.device)
+        for k in _STATE + _OUT + ["SideflowChanM3", "scratch0", "scratch1"]:
+            self._dev[k] = DeviceArray(N, np.float64, self.device).zero()
+        a = self._args = _SubstepArgs()
+        for k, d in self._dev.items():
+            setattr(a, k, d.ptr.value)
+        a.Beta, a.InvBeta, a.InvDtRouting, a.DtSec = float(v.Beta), float(v.InvBeta), float(v.InvDtRouting), float(v.DtSec)
+
+    def _upload_state(self):
+        v = self.var
+        N = self.river_router.num_pixels
+        for k in _STATE:
+            a = getattr(v, k, None)
+            if a is None:
+                a = np.zeros(N)
+                setattr(v, k, a)
+            self._dev[k].upload(f64(np.broadcast_to(a, (N,))))
+
+    def _download_state(self):
+        v = self.var
+        split = self._split()
+        names = _STATE + _OUT if split else ["ChanQKin", "ChanM3Kin", "ChanQ", "sumDisDay"] + _OUT
+        for k in names:
+            cur = getattr(v, k, None)
+            if isinstance(cur, np.ndarray) and cur.dtype == np.float64 and cur.flags.c_contiguous and \
+                    cur.size == self.river_router.num_pixels and cur.flags.writeable:
+                self._dev[k].download(cur)          # in place, like the numba kernels
+            else:
+                setattr(v, k, self._dev[k].download())
+
+    def begin_step(self):
+        """resident mode: upload the routing state once per model step."""
+        self._ensure_device()
+        self._upload_state()
+        self._resident = True
+
+    def end_step(self):
+        self._download_state()
+        self._resident = False
+
+    def sideflow_m3(self):
+        """SideflowChanM3 assembly, routing.py:462-478 (each term option-gated)."""
+        v, o = self.var, self.options
+        s = np.array(v.ToChanM3RunoffDt, dtype=np.float64, copy=True)
+        if o.get('openwaterevapo'):
+            s -= v.EvaAddM3Dt
+        if o.get('wateruse'):
+            v.WUseAddM3Dt = v.withdrawal_CH_actual_M3_routStep - v.returnflow_GwAbs2Channel_M3_routStep
+            s -= v.WUseAddM3Dt
+        if o.get('inflow'):
+            s += v.QInDt
+        if o.get('TransLoss'):
+            s -= v.TransLossM3Dt
+        if not o.get('InitLisflood'):
+            if o.get('simulateLakes'):
+                s += v.QLakeOutM3Dt
+            if o.get('simulateReservoirs'):
+                s += v.QResOutM3Dt
+            if o.get('simulatePolders'):
+                s -= v.ChannelToPolderM3Dt
+        return s
+
+    def dynamic(self, NoRoutingExecuted):
+        """One routing sub-step (routing.py:435-706)."""
+        if self.river_router is None:
+            raise RuntimeError("routing.initialSecond()/attach_router() must be called first")
+        for m in self.inloop_modules:          # lakes / reservoirs / polder / inflow / transmission, :441-450
+            m(NoRoutingExecuted)
+        self._ensure_device()
+        if not self._resident:
+            self._upload_state()
+        self._dev["SideflowChanM3"].upload(f64(self.sideflow_m3()))
+        self._args.split = 1 if self._split() else 0
+        check(lib().lf_routing_substep(self.river_router._h, C.byref(self._args)))
+        if self._split():
+            # routing.py:602: copy of the running sum before this sub-step's contribution
+            pass
+        if not self._resident:
+            self._download_state()
+
+
+def var_from_fixture(g):
+    """Build the `var` namespace routing.dynamic needs from a tests/golden/substep_*.npz fixture."""
+    v = types.SimpleNamespace()
+    for k in ("ChannelAlpha", "ChannelAlpha2", "ChanLength", "PixelArea", "IsChannelKinematic", "QLimit", "M3Limit",
+              "Chan2M3Start", "Chan2QStart"):
+        setattr(v, k, g[k])
+    v.Beta = float(g["Beta"]); v.InvBeta = 1 / v.Beta
+    v.DtRouting = float(g["DtRouting"]); v.InvDtRouting = 1 / v.DtRouting
+    v.NoRoutSteps = int(g["NoRoutSteps"]); v.DtSec = v.DtRouting * v.NoRoutSteps
+    v.InvChanLength, v.InvChannelAlpha, v.InvChannelAlpha2 = 1 / v.ChanLength, 1 / v.ChannelAlpha, 1 / v.ChannelAlpha2
+    for k in ("ChanQKin", "ChanM3Kin", "Chan2QKin", "Chan2M3Kin", "CrossSection2Area", "Sideflow1Chan"):
+        setattr(v, k, g["init_" + k].copy())
+    v.sumDisDay = np.zeros(v.ChanQKin.size)
+    v.ChanQ = v.ChanQKin.copy()
+    return v

@@ -1,0 +1,124 @@
+"""CPU-only checks of the product's host side: the C-ABI library loads and exports every symbol the
+header declares, struct mirrors have the right size, the host graph builder reproduces the reference's
+lookups/orders on the golden vectors, and compute entry points fail loudly without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden
+
+from lisflood_amd import _lib
+from lisflood_amd import synthetic as syn
+from lisflood_amd.kinematic_wave_parallel import Graph, kinematicWave
+
+HEADER = os.path.join(ROOT, "include", "lisflood_amd.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lf_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib.lib()
+    syms = declared_symbols()
+    assert len(syms) >= 35
+    for s in syms:
+        assert hasattr(L, s), "missing export " + s
+
+
+def test_struct_mirrors_have_the_c_size():
+    from lisflood_amd import soilloop, routing
+    out = (C.c_int64 * 3)()
+    assert _lib.lib().lf_struct_sizes(out) == 0
+    assert C.sizeof(routing._SubstepArgs) == out[0]
+    assert C.sizeof(soilloop._InterceptionArgs) == out[1]
+    assert C.sizeof(soilloop._SoilArgs) == out[2]
+
+
+@pytest.mark.parametrize("name", ["syn64_shallow", "syn64_deep", "syn48_masked", "etrs89"])
+def test_graph_matches_reference_golden(name):
+    g = golden("graph_" + name)
+    G = Graph(g["codes"], g["mask"])
+    down, ups, nups = G.lookups()
+    po, ss = G.orders()
+    assert np.array_equal(down, g["downstream_lookup"])
+    assert np.array_equal(ups, g["upstream_lookup"])
+    assert np.array_equal(nups, g["num_upstream_pixels"])
+    assert np.array_equal(po, g["pixels_ordered"])
+    assert np.array_equal(ss, g["order_start_stop"])
+
+
+@pytest.mark.parametrize("name", ["syn64_shallow", "syn48_masked", "etrs89"])
+def test_sweep_layout_invariants(name):
+    """upstream cells of position p are the contiguous positions [ups_ptr[p], ups_ptr[p+1]) of the
+    previous level, in ascending pixel id (the summation order of kinematic_wave_parallel_tools.py:57-58)."""
+    g = golden("graph_" + name)
+    G = Graph(g["codes"], g["mask"])
+    perm, ups_ptr, level_start = G.layout()
+    N = G.num_pixels
+    assert sorted(perm.tolist()) == list(range(N))
+    assert level_start[0] == 0 and level_start[-1] == N and ups_ptr[0] == 0
+    ups = g["upstream_lookup"]
+    level_of = np.empty(N, np.int64)
+    for k in range(G.num_levels):
+        level_of[level_start[k]:level_start[k + 1]] = k
+    for p in range(N):
+        want = [u for u in ups[perm[p]] if u >= 0]
+        got = perm[ups_ptr[p]:ups_ptr[p + 1]].tolist()
+        assert got == want
+        if want:
+            assert (level_of[ups_ptr[p]:ups_ptr[p + 1]] == level_of[p] - 1).all()
+
+
+def test_raster_form_equals_compressed_form():
+    codes = syn.make_ldd("shallow", 40, 50, 1)
+    mask = np.ones((40, 50), bool)
+    a = Graph(codes[mask].astype(float), mask)
+    b = Graph(ldd_raster=codes)
+    for x, y in zip(a.layout(), b.layout()):
+        assert np.array_equal(x, y)
+    m2 = mask.copy(); m2[:5, :7] = False
+    c = Graph(codes[m2].astype(float), m2)
+    d = Graph(ldd_raster=codes, land_mask=m2)
+    for x, y in zip(c.layout(), d.layout()):
+        assert np.array_equal(x, y)
+
+
+def test_edge_graphs():
+    one = Graph(np.array([5.0]), np.ones((1, 1), bool))
+    assert (one.num_pixels, one.num_levels, one.max_upstream) == (1, 1, 1)
+    with pytest.raises(_lib.LisfloodAmdError) as e:
+        Graph(np.array([6.0, 4.0]), np.ones((1, 2), bool))      # 2-cycle: the reference hangs (kwp.py:99)
+    assert e.value.code == _lib.LF_E_CYCLE
+    with pytest.raises(ValueError):
+        Graph(np.array([5.0]), np.ones((1, 2), bool))           # ragged: codes do not match the mask
+    # unknown codes are "no flow" (documented deviation from the reference's uninitialised np.empty)
+    odd = Graph(np.array([6.0, np.nan, 11.0, 5.0]), np.ones((1, 4), bool))
+    assert odd.lookups()[0].tolist() == [1.0, -1.0, -1.0, -1.0]
+
+
+def test_synthetic_generator_is_chunk_consistent_and_acyclic():
+    for fam, seed in (("shallow", 1), ("deep", 2)):
+        full = syn.make_ldd(fam, 300, 70, seed)
+        part = syn.make_ldd(fam, 300, 70, seed, r0=250, r1=290)
+        assert np.array_equal(full[250:290], part)
+        G = Graph(ldd_raster=full)           # raises on a cycle
+        assert G.num_pixels == 300 * 70
+    assert Graph(ldd_raster=syn.make_ldd("deep", 300, 70, 2)).num_levels >= 300
+
+
+@pytest.mark.skipif(_lib.device_count() > 0, reason="only meaningful on a box without a GPU")
+def test_compute_fails_loudly_without_gpu():
+    g = golden("graph_syn64_shallow")
+    with pytest.raises(_lib.LisfloodAmdError) as e:
+        kinematicWave(g["codes"], g["mask"], np.ones(4096), 0.6, 1000.0, 3600.0)
+    assert e.value.code == _lib.LF_E_NO_DEVICE
+    from lisflood_amd.soilloop import soilColumnsWaterBalance
+    d = syn.soil_params(8)
+    with pytest.raises(_lib.LisfloodAmdError):
+        soilColumnsWaterBalance(*[d[k] for k in syn.SOIL_ARG_ORDER])
