@@ -31,10 +31,20 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB):
             build()
+        # GPU boxes expose hundreds of hardware threads but only a cgroup share of them: an unbounded
+        # OpenMP team is slower than one thread there.  Default to a small team unless the caller chose.
+        os.environ.setdefault("OMP_NUM_THREADS", str(min(8, os.cpu_count() or 1)))
         _lib = C.CDLL(LIB)
         _lib.lfo_lookups.restype = C.c_int
         _lib.lfo_orders.restype = C.c_int64
     return _lib
+
+
+def set_threads(n):
+    """OpenMP team size of the oracle's parallel loops (numba's set_num_threads, Lisflood_initial.py:101-104)."""
+    lib()
+    import ctypes.util
+    C.CDLL(ctypes.util.find_library("gomp") or "libgomp.so.1").omp_set_num_threads(int(n))
 
 
 def _f(a):

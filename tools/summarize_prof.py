@@ -1,0 +1,92 @@
+"""Condenses the rocprofv3 outputs of tools/gpu_profile.sh into one text summary (per kernel: calls,
+mean duration, and -- from the PMC passes -- FETCH_SIZE / WRITE_SIZE per launch in bytes).
+
+FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB.  On gfx950 the read counter under-reports wide
+coalesced streams (MI355X_MICROARCH.md, HBM section), so the prep kernel -- whose HBM traffic is known
+exactly (36 B read + 8 B written per cell, no reuse, working set >> 256 MiB L3) -- is used to calibrate a
+correction factor for this engine's 8-byte-per-lane access pattern; corrected numbers are printed next to
+the raw ones.
+"""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+
+
+def find(d, pat):
+    r = glob.glob(os.path.join(out, d, "**", pat), recursive=True)
+    return r[0] if r else None
+
+
+def short(name):
+    for k in ("k_prep", "k_levels_narrow", "k_level", "k_soil_columns", "k_interception", "k_substep",
+              "k_halo", "k_gather", "k_scatter"):
+        if k in name:
+            return k
+    return name[:40]
+
+
+stats = find("prof_%s_kt" % tag, "*kernel_stats.csv")
+print("# rocprofv3 --kernel-trace --stats (%s)" % (stats or "missing"))
+if stats:
+    rows = list(csv.DictReader(open(stats)))
+    print("%-22s %8s %14s %14s %8s" % ("kernel", "calls", "total_ms", "mean_us", "pct"))
+    for r in rows:
+        print("%-22s %8s %14.3f %14.3f %8s" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
+                                               float(r["AverageNs"]) / 1e3, r.get("Percentage", "")))
+
+trace = find("prof_%s_kt" % tag, "*kernel_trace.csv")
+cells = {}
+if trace:
+    per = defaultdict(list)
+    for r in csv.DictReader(open(trace)):
+        per[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"]),
+                                             int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0)))
+    print("\n# per kernel from the trace: launches, mean us, mean grid (threads)")
+    for k, v in per.items():
+        print("%-22s %8d %12.3f %14.1f" % (k, len(v), sum(d for d, _ in v) / len(v) / 1e3,
+                                           sum(g for _, g in v) / len(v)))
+        cells[k] = sum(g for _, g in v) / len(v)
+
+
+def pmc(d, counter):
+    f = find("prof_%s_%s" % (tag, d), "*counter_collection.csv")
+    if not f:
+        return {}
+    acc = defaultdict(lambda: [0, 0.0, 0.0])
+    for r in csv.DictReader(open(f)):
+        if r.get("Counter_Name") != counter:
+            continue
+        k = short(r["Kernel_Name"])
+        acc[k][0] += 1
+        acc[k][1] += float(r["Counter_Value"])
+        acc[k][2] += float(r.get("Grid_Size", 0) or 0)
+    return acc
+
+
+fetch, write = pmc("fetch", "FETCH_SIZE"), pmc("write", "WRITE_SIZE")
+if fetch or write:
+    print("\n# PMC (separate passes), per launch: KiB -> bytes; grid = threads per launch")
+    print("%-22s %8s %16s %16s %14s %12s %12s" % ("kernel", "launches", "FETCH_B/launch", "WRITE_B/launch",
+                                                   "grid", "fetch_B/thr", "write_B/thr"))
+    for k in sorted(set(fetch) | set(write)):
+        n = fetch.get(k, write.get(k))[0]
+        fb = fetch[k][1] * 1024 / fetch[k][0] if k in fetch else float("nan")
+        wb = write[k][1] * 1024 / write[k][0] if k in write else float("nan")
+        g = (fetch.get(k) or write.get(k))[2] / n
+        print("%-22s %8d %16.0f %16.0f %14.0f %12.2f %12.2f" % (k, n, fb, wb, g, fb / max(g, 1), wb / max(g, 1)))
+    if "k_prep" in fetch and "k_prep" in write:
+        g = fetch["k_prep"][2] / fetch["k_prep"][0]
+        cf = 36.0 / (fetch["k_prep"][1] * 1024 / fetch["k_prep"][0] / g)
+        cw = 8.0 / (write["k_prep"][1] * 1024 / write["k_prep"][0] / g)
+        print("\n# calibration on k_prep (36 B read + 8 B written per cell, exact): read x%.3f, write x%.3f" % (cf, cw))
+        for k in sorted(set(fetch) & set(write)):
+            fb = fetch[k][1] * 1024 / fetch[k][0] * cf
+            wb = write[k][1] * 1024 / write[k][0] * cw
+            g = fetch[k][2] / fetch[k][0]
+            print("%-22s corrected HBM bytes/launch: read %.4g + write %.4g = %.4g  (%.1f B per thread)"
+                  % (k, fb, wb, fb + wb, (fb + wb) / max(g, 1)))
