@@ -20,7 +20,10 @@
 // are separated by launches, not by in-kernel synchronisation.
 #include <cmath>
 
+#include <cstdlib>
+
 #include "lf_common.h"
+#include "lf_math.h"
 
 namespace {
 
@@ -68,45 +71,66 @@ __global__ void __launch_bounds__(kBlock) k_prep(int n, const int *__restrict__ 
     constant[p] = a[p] * pow(q_pix[pix], beta) + lateral;
 }
 
-__device__ __forceinline__ void sweep_cell(int p, const int *__restrict__ ups_ptr, const int *__restrict__ perm,
-                                           const double *__restrict__ constant, const double *__restrict__ a,
-                                           double beta, double inv_beta, double b_minus_1, double *qord,
-                                           double *__restrict__ q_pix)
+// everything one sweep launch needs (passed by value: 112 B of kernarg)
+struct sweep_args {
+    const int *__restrict__ ups_ptr;
+    const int *__restrict__ perm;
+    const double *__restrict__ a;        // alpha*dx/dt, sweep order
+    const double *__restrict__ constant; // general path: written by k_prep
+    const double *__restrict__ lat_pix;  // fused path: specific lateral inflow, pixel order
+    const double *__restrict__ dx;       // fused path: per-pixel dx (sweep order) or nullptr
+    double dx_scalar;
+    double beta, inv_beta, b_minus_1;
+    double *qord;              // new discharge, sweep order (read by the next level)
+    double *__restrict__ q_pix; // caller's discharge vector, pixel order (old value in, new value out)
+};
+
+// One cell of the implicit sweep.  FUSED (beta == 3/5): the old-discharge term is computed here
+// (kinematic_wave_parallel.py:163,175 folded into the sweep) and the closure is solved as a quintic in
+// Q^(1/5) (lf_math.h); otherwise `constant` comes from k_prep and the reference's own Newton iteration runs.
+template <bool FUSED>
+__device__ __forceinline__ void sweep_cell(int p, const sweep_args &A)
 {
-    const int u0 = ups_ptr[p], u1 = ups_ptr[p + 1];
+    const int u0 = A.ups_ptr[p], u1 = A.ups_ptr[p + 1];
+    const int pix = A.perm[p];
+    const double ap = A.a[p];
+    double cst;
+    if (FUSED) {
+        const double lateral = A.lat_pix[pix] * (A.dx ? A.dx[p] : A.dx_scalar);
+        cst = ap * lf_pow_3_5(A.q_pix[pix]) + lateral;
+    } else {
+        cst = A.constant[p];
+    }
     double ups = 0.0;
-    for (int e = u0; e < u1; ++e) ups += qord[e]; // ascending pixel id, kinematic_wave_parallel_tools.py:57-58
-    const double c = ups + constant[p];
-    const double ap = a[p];
-    const double q = lf_solve_cell(c, ap, beta * ap, beta, inv_beta, b_minus_1);
-    qord[p] = q;
-    q_pix[perm[p]] = q;
+    for (int e = u0; e < u1; ++e) ups += A.qord[e]; // ascending pixel id, kinematic_wave_parallel_tools.py:57-58
+    const double c = ups + cst;
+    double q;
+    if (FUSED && lf_fast_range(c) && lf_fast_range(ap)) {
+        q = (c <= LF_NEWTON_TOL) ? 0.0 : lf_solve_3_5(c, ap);
+    } else {
+        q = lf_solve_cell(c, ap, A.beta * ap, A.beta, A.inv_beta, A.b_minus_1); // incl. alpha == 0 / NaN semantics
+    }
+    A.qord[p] = q;
+    A.q_pix[pix] = q;
 }
 
 // one wide level: one cell per lane
-__global__ void __launch_bounds__(kBlock) k_level(int first, int count, const int *__restrict__ ups_ptr,
-                                                  const int *__restrict__ perm, const double *__restrict__ constant,
-                                                  const double *__restrict__ a, double beta, double inv_beta,
-                                                  double b_minus_1, double *qord, double *__restrict__ q_pix)
+template <bool FUSED>
+__global__ void __launch_bounds__(kBlock) k_level(int first, int count, sweep_args A)
 {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= count) return;
-    sweep_cell(first + i, ups_ptr, perm, constant, a, beta, inv_beta, b_minus_1, qord, q_pix);
+    sweep_cell<FUSED>(first + i, A);
 }
 
 // a run of narrow levels [k0, k1): one workgroup, barrier between levels
+template <bool FUSED>
 __global__ void __launch_bounds__(kNarrowBlock) k_levels_narrow(int k0, int k1, const long long *__restrict__ level_start,
-                                                                const int *__restrict__ ups_ptr,
-                                                                const int *__restrict__ perm,
-                                                                const double *__restrict__ constant,
-                                                                const double *__restrict__ a, double beta,
-                                                                double inv_beta, double b_minus_1, double *qord,
-                                                                double *__restrict__ q_pix)
+                                                                sweep_args A)
 {
     for (int k = k0; k < k1; ++k) {
         const int first = (int)level_start[k], last = (int)level_start[k + 1];
-        for (int p = first + (int)threadIdx.x; p < last; p += kNarrowBlock)
-            sweep_cell(p, ups_ptr, perm, constant, a, beta, inv_beta, b_minus_1, qord, q_pix);
+        for (int p = first + (int)threadIdx.x; p < last; p += kNarrowBlock) sweep_cell<FUSED>(p, A);
         __threadfence_block();
         __syncthreads();
     }
@@ -189,6 +213,7 @@ struct lf_router {
     int64_t N = 0, NL = 0;
     double beta = 0, inv_beta = 0, b_minus_1 = 0, dx_scalar = 0;
     bool has_floodplains = false, dx_per_pixel = false;
+    bool fused = false; // beta == 3/5: prep fused into the sweep, polynomial closure solve (lf_math.h)
     lf_dbuf<int32_t> perm, ups_ptr;
     lf_dbuf<long long> level_start;
     lf_dbuf<double> a1, a2, dx, constant, qord, io_q, io_lat, tmp_ord;
@@ -270,10 +295,23 @@ int route_device(lf_router *r, double *q_dev, const double *lat_dev, int section
     const double *a = (section == LF_SECTION_MAIN) ? r->a1.p : r->a2.p;
     const int n = (int)r->N;
     int64_t launches = 0, wide = 0, narrow = 0;
-    if (n > 0) {
+    sweep_args A;
+    A.ups_ptr = r->ups_ptr.p;
+    A.perm = r->perm.p;
+    A.a = a;
+    A.constant = r->constant.p;
+    A.lat_pix = lat_dev;
+    A.dx = r->dx_per_pixel ? r->dx.p : nullptr;
+    A.dx_scalar = r->dx_scalar;
+    A.beta = r->beta;
+    A.inv_beta = r->inv_beta;
+    A.b_minus_1 = r->b_minus_1;
+    A.qord = r->qord.p;
+    A.q_pix = q_dev;
+    if (n > 0 && !r->fused) {
         LF_TRY(r->prof_begin(0, n));
-        hipLaunchKernelGGL(k_prep, dim3(blocks_for(n)), dim3(kBlock), 0, s, n, r->perm.p, q_dev, lat_dev, a,
-                           r->dx_per_pixel ? r->dx.p : nullptr, r->dx_scalar, r->beta, r->constant.p);
+        hipLaunchKernelGGL(k_prep, dim3(blocks_for(n)), dim3(kBlock), 0, s, n, r->perm.p, q_dev, lat_dev, a, A.dx,
+                           r->dx_scalar, r->beta, r->constant.p);
         LF_TRY(r->prof_end());
         ++launches;
     }
@@ -282,15 +320,20 @@ int route_device(lf_router *r, double *q_dev, const double *lat_dev, int section
             const int first = (int)r->h_level_start[g.k0];
             const int count = (int)(r->h_level_start[g.k1] - r->h_level_start[g.k0]);
             LF_TRY(r->prof_begin(1, count));
-            hipLaunchKernelGGL(k_level, dim3(blocks_for(count)), dim3(kBlock), 0, s, first, count, r->ups_ptr.p,
-                               r->perm.p, r->constant.p, a, r->beta, r->inv_beta, r->b_minus_1, r->qord.p, q_dev);
+            if (r->fused)
+                hipLaunchKernelGGL(k_level<true>, dim3(blocks_for(count)), dim3(kBlock), 0, s, first, count, A);
+            else
+                hipLaunchKernelGGL(k_level<false>, dim3(blocks_for(count)), dim3(kBlock), 0, s, first, count, A);
             LF_TRY(r->prof_end());
             ++wide;
         } else {
             LF_TRY(r->prof_begin(2, r->h_level_start[g.k1] - r->h_level_start[g.k0]));
-            hipLaunchKernelGGL(k_levels_narrow, dim3(1), dim3(kNarrowBlock), 0, s, g.k0, g.k1, r->level_start.p,
-                               r->ups_ptr.p, r->perm.p, r->constant.p, a, r->beta, r->inv_beta, r->b_minus_1,
-                               r->qord.p, q_dev);
+            if (r->fused)
+                hipLaunchKernelGGL(k_levels_narrow<true>, dim3(1), dim3(kNarrowBlock), 0, s, g.k0, g.k1,
+                                   r->level_start.p, A);
+            else
+                hipLaunchKernelGGL(k_levels_narrow<false>, dim3(1), dim3(kNarrowBlock), 0, s, g.k0, g.k1,
+                                   r->level_start.p, A);
             LF_TRY(r->prof_end());
             ++narrow;
         }
@@ -326,6 +369,10 @@ int lf_router_create(const lf_graph *g, const double *alpha, double beta, const 
     r->dx_scalar = dx_scalar;
     r->dx_per_pixel = dx != nullptr;
     r->has_floodplains = alpha_floodplains != nullptr;
+    // beta == 3/5 (every LISFLOOD setting): fused prep + polynomial solve.  LF_GENERAL_POW=1 forces the
+    // general path (the reference's own Newton iteration with pow) for A/B parity and timing.
+    const char *force_general = std::getenv("LF_GENERAL_POW");
+    r->fused = (beta == 0.6) && !(force_general && force_general[0] == '1');
     const int64_t n = g->N;
     int rc = LF_OK;
     {
@@ -354,7 +401,7 @@ int lf_router_create(const lf_graph *g, const double *alpha, double beta, const 
         std::vector<long long> ls(g->level_start.begin(), g->level_start.end());
         rc = r->level_start.upload(ls.data(), ls.size());
     }
-    if (rc == LF_OK) rc = r->constant.alloc(n);
+    if (rc == LF_OK && !r->fused) rc = r->constant.alloc(n);
     if (rc == LF_OK) rc = r->qord.alloc(n);
     if (rc == LF_OK) rc = r->counter.alloc(1);
     if (rc != LF_OK) {
@@ -562,9 +609,11 @@ __global__ void __launch_bounds__(kBlock) k_substep_main(int n, lf_substep_args 
 {
     const int p = blockIdx.x * kBlock + threadIdx.x;
     if (p >= n) return;
-    double v = A.ChanLength[p] * A.ChannelAlpha[p] * pow(A.ChanQKin[p], A.Beta);
+    const bool b35 = A.Beta == 0.6;
+    double v = A.ChanLength[p] * A.ChannelAlpha[p] * (b35 ? lf_pow_3_5(A.ChanQKin[p]) : pow(A.ChanQKin[p], A.Beta));
     if (v < 0.0) v = 0.0;
-    const double q = pow(v * A.InvChanLength[p] * A.InvChannelAlpha[p], A.InvBeta);
+    const double x = v * A.InvChanLength[p] * A.InvChannelAlpha[p];
+    const double q = b35 ? lf_pow_5_3(x) : pow(x, A.InvBeta);
     A.ChanM3Kin[p] = v;
     A.ChanQKin[p] = q;
     if (!A.split) {
@@ -580,11 +629,13 @@ __global__ void __launch_bounds__(kBlock) k_substep_floodplain(int n, lf_substep
     const int p = blockIdx.x * kBlock + threadIdx.x;
     if (p >= n) return;
     const double start = A.Chan2M3Start[p];
-    double v = A.ChanLength[p] * A.ChannelAlpha2[p] * pow(A.Chan2QKin[p], A.Beta);
+    const bool b35 = A.Beta == 0.6;
+    double v = A.ChanLength[p] * A.ChannelAlpha2[p] * (b35 ? lf_pow_3_5(A.Chan2QKin[p]) : pow(A.Chan2QKin[p], A.Beta));
     if ((v - start) < 0.0) v = start;
     A.Chan2M3Kin[p] = v;
     A.CrossSection2Area[p] = (v - start) * A.InvChanLength[p];
-    const double q2 = pow(v * A.InvChanLength[p] * A.InvChannelAlpha2[p], A.InvBeta);
+    const double x2 = v * A.InvChanLength[p] * A.InvChannelAlpha2[p];
+    const double q2 = b35 ? lf_pow_5_3(x2) : pow(x2, A.InvBeta);
     A.Chan2QKin[p] = q2;
     const double q1 = A.ChanQKin[p];
     double q = q1 + q2 - A.QLimit[p];

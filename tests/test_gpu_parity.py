@@ -27,8 +27,19 @@ def amd():
     return types.SimpleNamespace(kw=kinematic_wave_parallel, soil=soilloop, routing=routing, lib=_lib)
 
 
+@pytest.fixture(params=["fused_beta_3_5", "general_pow"])
+def solver(request, monkeypatch):
+    """Both solve paths of csrc/lf_router.hip: the fused beta = 3/5 polynomial solve (default) and the
+    general path that follows the reference's own Newton iteration with pow (LF_GENERAL_POW=1)."""
+    if request.param == "general_pow":
+        monkeypatch.setenv("LF_GENERAL_POW", "1")
+    else:
+        monkeypatch.delenv("LF_GENERAL_POW", raising=False)
+    return request.param
+
+
 @pytest.mark.parametrize("name", ["syn64_shallow", "syn64_deep", "syn48_masked"])
-def test_route_golden(amd, name):
+def test_route_golden(amd, solver, name):
     g = golden("route_" + name)
     kw = amd.kw.kinematicWave(g["codes"], g["mask"], g["alpha"], float(g["beta"]), g["dx"], float(g["dt"]))
     Q = g["Q0"].copy()
@@ -37,7 +48,7 @@ def test_route_golden(amd, name):
         close(Q, g["Q"][s], (name, s))
 
 
-def test_route_etrs89_two_sections_golden(amd):
+def test_route_etrs89_two_sections_golden(amd, solver):
     g = golden("route_etrs89")
     kw = amd.kw.kinematicWave(g["codes"], g["mask"], g["alpha"], float(g["beta"]), g["dx"], float(g["dt"]),
                               alpha_floodplains=g["alpha2"])
@@ -54,7 +65,7 @@ def test_route_etrs89_two_sections_golden(amd):
         single.kinematicWaveRouting(Q1, g["q"][0], "floodplains")
 
 
-def test_route_edge_cases_golden(amd):
+def test_route_edge_cases_golden(amd, solver):
     g = golden("route_edge")
     kw = amd.kw.kinematicWave(g["codes"], g["mask"], g["alpha"], float(g["beta"]), g["dx"], float(g["dt"]))
     for k in ("zero", "tiny", "branches", "negative"):
@@ -97,7 +108,7 @@ def test_route_scalar_dx_and_device_form_vs_oracle(amd, oracle):
 
 
 @pytest.mark.parametrize("family,seed", [("shallow", 1), ("deep", 2)])
-def test_route_mid_size_vs_oracle(amd, oracle, family, seed):
+def test_route_mid_size_vs_oracle(amd, oracle, solver, family, seed):
     """1200 x 1000 cells: exercises wide-level launches (levels > 1024 cells) next to narrow runs."""
     from lisflood_amd import synthetic as syn
     H, W = 1200, 1000
@@ -146,6 +157,25 @@ def test_route_full_size_closure_property(amd):
     assert abs(lhs.sum() - rhs.sum()) <= 1e-9 * rhs.sum()
 
 
+def test_route_other_beta_vs_oracle(amd, oracle):
+    """beta != 3/5 always takes the general path."""
+    from lisflood_amd import synthetic as syn
+    H, W = 100, 130
+    codes = syn.make_ldd("deep", H, W, 4)
+    mask = np.ones((H, W), bool)
+    c = codes.reshape(-1).astype(np.float64)
+    N = H * W
+    p = syn.router_params(N, seed=12, beta=0.7)
+    gpu = amd.kw.kinematicWave(c, mask, p["alpha"], 0.7, p["dx"], p["dt"])
+    cpu = oracle.kinematicWave(c, mask, p["alpha"], 0.7, p["dx"], p["dt"])
+    Qg, Qc = p["Q0"].copy(), p["Q0"].copy()
+    for s in range(4):
+        q = syn.lateral_inflow(N, s)
+        gpu.kinematicWaveRouting(Qg, q)
+        cpu.kinematicWaveRouting(Qc, q)
+        close(Qg, Qc, s)
+
+
 @pytest.mark.parametrize("name", ["syn48_masked", "etrs89"])
 def test_upstream_sum_golden(amd, name):
     g = golden("upstream_sum")
@@ -179,7 +209,7 @@ def test_accuflux_matches_reference_uparea(amd):
 
 
 @pytest.mark.parametrize("mode", ["split", "single"])
-def test_routing_substeps_golden(amd, mode):
+def test_routing_substeps_golden(amd, solver, mode):
     """routing.dynamic() sub-steps (routing.py:435-706) through the HydroModule-shaped wrapper."""
     g = golden("substep_" + mode)
     v = amd.routing.var_from_fixture(g)
