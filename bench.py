@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads / soil kernel")
     ap.add_argument("--cpu-sample", type=int, default=2000, help="CPU baseline raster is sample x sample")
+    ap.add_argument("--calibrate", action="store_true",
+                    help="run the known-traffic stream copies first (PMC calibration under rocprofv3)")
     return ap.parse_args()
 
 
@@ -184,6 +186,17 @@ def main():
         from lisflood_amd import dist_bench
         return dist_bench.main(a)
     H = W = a.size
+    if a.calibrate:
+        import ctypes as C
+        from lisflood_amd import _lib
+        n = 100_000_000
+        src = _lib.DeviceArray(n).zero()
+        dst = _lib.DeviceArray(n).zero()
+        for width in (8, 16):
+            for _ in range(3):
+                _lib.check(_lib.lib().lf_calibration_copy(C.c_int(0), src.ptr, dst.ptr, C.c_int64(n), C.c_int(width)))
+        _lib.synchronize()
+        src.free(); dst.free()
     kw, p, g = build_case(a.family, H, W)
     res = run_routing(kw, p, a.steps, a.warmup)
     N = kw.num_pixels

@@ -72,6 +72,10 @@ int lf_device_synchronize(int device);
 int lf_timer_start(int device);
 int lf_timer_stop(int device, double *elapsed_ms);
 
+/* profiling aid: stream copy of n doubles with bytes_per_lane in {8, 16}; its HBM traffic is exactly
+ * n*8 B read + n*8 B written, which calibrates rocprofv3's FETCH_SIZE / WRITE_SIZE on gfx950. */
+int lf_calibration_copy(int device, const double *src_dev, double *dst_dev, int64_t n, int bytes_per_lane);
+
 /* ---------------------------------------------------------------------------------------------
  * graph: replaces rebuildFlowMatrix/decodeFlowMatrix/streamLookups/topoDistFromSea/_setRoutingOrders
  * (kinematic_wave_parallel.py:59-106, 140-158; kinematic_wave_parallel_tools.py:111-130)

@@ -81,6 +81,7 @@ struct sweep_args {
     const double *__restrict__ dx;       // fused path: per-pixel dx (sweep order) or nullptr
     double dx_scalar;
     double beta, inv_beta, b_minus_1;
+    int kmax;                  // max in-degree of the graph (<= 8)
     double *qord;              // new discharge, sweep order (read by the next level)
     double *__restrict__ q_pix; // caller's discharge vector, pixel order (old value in, new value out)
 };
@@ -101,8 +102,15 @@ __device__ __forceinline__ void sweep_cell(int p, const sweep_args &A)
     } else {
         cst = A.constant[p];
     }
+    // Upstream inflow, summed in ascending pixel id (kinematic_wave_parallel_tools.py:57-58).  A D8 cell has
+    // at most 8 upstream neighbours: all candidate loads are issued at once (predicated) instead of a
+    // dependent load per loop trip; missing ones contribute +0.0, which leaves the sum bit-identical.
+    double v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = (k < A.kmax && u0 + k < u1) ? A.qord[u0 + k] : 0.0;
     double ups = 0.0;
-    for (int e = u0; e < u1; ++e) ups += A.qord[e]; // ascending pixel id, kinematic_wave_parallel_tools.py:57-58
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ups += v[k];
     const double c = ups + cst;
     double q;
     if (FUSED && lf_fast_range(c) && lf_fast_range(ap)) {
@@ -213,6 +221,7 @@ struct lf_router {
     int64_t N = 0, NL = 0;
     double beta = 0, inv_beta = 0, b_minus_1 = 0, dx_scalar = 0;
     bool has_floodplains = false, dx_per_pixel = false;
+    int kmax = 8;
     bool fused = false; // beta == 3/5: prep fused into the sweep, polynomial closure solve (lf_math.h)
     lf_dbuf<int32_t> perm, ups_ptr;
     lf_dbuf<long long> level_start;
@@ -306,6 +315,7 @@ int route_device(lf_router *r, double *q_dev, const double *lat_dev, int section
     A.beta = r->beta;
     A.inv_beta = r->inv_beta;
     A.b_minus_1 = r->b_minus_1;
+    A.kmax = r->kmax;
     A.qord = r->qord.p;
     A.q_pix = q_dev;
     if (n > 0 && !r->fused) {
@@ -363,6 +373,7 @@ int lf_router_create(const lf_graph *g, const double *alpha, double beta, const 
     r->ctx = ctx;
     r->N = g->N;
     r->NL = g->NL;
+    r->kmax = g->K;
     r->beta = beta;
     r->inv_beta = 1 / beta;      // kinematic_wave_parallel.py:125
     r->b_minus_1 = beta - 1;     // :126
@@ -663,6 +674,42 @@ extern "C" int lf_routing_substep(lf_router *r, const lf_substep_args *a)
     if (a->split) {
         LF_TRY(route_device(r, a->Chan2QKin, a->scratch1, LF_SECTION_FLOODPLAINS));
         hipLaunchKernelGGL(k_substep_floodplain, grid, block, 0, s, n, *a);
+    }
+    LF_HIP(hipGetLastError());
+    return LF_OK;
+}
+
+// ================================================================================================
+// PMC calibration: a stream copy with exactly known HBM traffic (n*8 B read + n*8 B written) in this
+// engine's access widths, so that rocprofv3's FETCH_SIZE / WRITE_SIZE can be calibrated on gfx950
+// (MI355X_MICROARCH.md, HBM section) before they are compared with byte counts.
+// ================================================================================================
+namespace {
+__global__ void __launch_bounds__(kBlock) k_calib_copy8(long long n, const double *__restrict__ src, double *__restrict__ dst)
+{
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+__global__ void __launch_bounds__(kBlock) k_calib_copy16(long long n2, const double2 *__restrict__ src,
+                                                         double2 *__restrict__ dst)
+{
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n2) dst[i] = src[i];
+}
+} // namespace
+
+extern "C" int lf_calibration_copy(int device, const double *src_dev, double *dst_dev, int64_t n, int bytes_per_lane)
+{
+    lf_device_ctx *c;
+    LF_TRY(lf_ctx(device, &c));
+    if (!src_dev || !dst_dev || n <= 0) return lf_set_error(LF_E_INVALID, "bad argument");
+    if (bytes_per_lane == 16) {
+        const long long n2 = n / 2;
+        hipLaunchKernelGGL(k_calib_copy16, dim3((unsigned)((n2 + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, n2,
+                           (const double2 *)src_dev, (double2 *)dst_dev);
+    } else {
+        hipLaunchKernelGGL(k_calib_copy8, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream,
+                           (long long)n, src_dev, dst_dev);
     }
     LF_HIP(hipGetLastError());
     return LF_OK;

@@ -104,7 +104,7 @@ def test_route_scalar_dx_and_device_form_vs_oracle(amd, oracle):
         gpu.route_device(Qd, qd)
         close(Qd.download(), Qc, s)
     st = gpu.last_launches()
-    assert st["levels"] == cpu.order_start_stop.shape[0] and st["launches"] >= 2
+    assert st["levels"] == cpu.order_start_stop.shape[0] and st["launches"] >= 1
 
 
 @pytest.mark.parametrize("family,seed", [("shallow", 1), ("deep", 2)])

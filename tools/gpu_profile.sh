@@ -3,7 +3,7 @@
 # Usage: tools/gpu_profile.sh <tag> [bench args...]      outputs -> gpurun_out/prof_<tag>_{kt,fetch,write}
 set -u
 TAG=${1:-r01}; shift || true
-ARGS=${@:-"--size 10000 --steps 5 --warmup 1 --no-extra --no-cpu-baseline"}
+ARGS=${@:-"--size 10000 --steps 5 --warmup 1 --no-extra --no-cpu-baseline --calibrate"}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT

@@ -23,7 +23,7 @@ def find(d, pat):
 
 
 def short(name):
-    for k in ("k_prep", "k_levels_narrow", "k_level", "k_soil_columns", "k_interception", "k_substep",
+    for k in ("k_calib_copy8", "k_calib_copy16", "k_prep", "k_levels_narrow", "k_level", "k_soil_columns", "k_interception", "k_substep",
               "k_halo", "k_gather", "k_scatter"):
         if k in name:
             return k
@@ -79,14 +79,17 @@ if fetch or write:
         wb = write[k][1] * 1024 / write[k][0] if k in write else float("nan")
         g = (fetch.get(k) or write.get(k))[2] / n
         print("%-22s %8d %16.0f %16.0f %14.0f %12.2f %12.2f" % (k, n, fb, wb, g, fb / max(g, 1), wb / max(g, 1)))
-    if "k_prep" in fetch and "k_prep" in write:
-        g = fetch["k_prep"][2] / fetch["k_prep"][0]
-        cf = 36.0 / (fetch["k_prep"][1] * 1024 / fetch["k_prep"][0] / g)
-        cw = 8.0 / (write["k_prep"][1] * 1024 / write["k_prep"][0] / g)
-        print("\n# calibration on k_prep (36 B read + 8 B written per cell, exact): read x%.3f, write x%.3f" % (cf, cw))
-        for k in sorted(set(fetch) & set(write)):
-            fb = fetch[k][1] * 1024 / fetch[k][0] * cf
-            wb = write[k][1] * 1024 / write[k][0] * cw
-            g = fetch[k][2] / fetch[k][0]
-            print("%-22s corrected HBM bytes/launch: read %.4g + write %.4g = %.4g  (%.1f B per thread)"
-                  % (k, fb, wb, fb + wb, (fb + wb) / max(g, 1)))
+    for cal in ("k_calib_copy8", "k_calib_copy16"):
+        if cal in fetch and cal in write:
+            g = fetch[cal][2] / fetch[cal][0]
+            per_thr = 8.0 if cal.endswith("8") else 16.0
+            cf = per_thr / (fetch[cal][1] * 1024 / fetch[cal][0] / g)
+            cw = per_thr / (write[cal][1] * 1024 / write[cal][0] / g)
+            print("\n# calibration on %s (exactly %g B read + %g B written per thread): read x%.3f, write x%.3f"
+                  % (cal, per_thr, per_thr, cf, cw))
+            for k in sorted(set(fetch) & set(write)):
+                fb = fetch[k][1] * 1024 / fetch[k][0] * cf
+                wb = write[k][1] * 1024 / write[k][0] * cw
+                g2 = fetch[k][2] / fetch[k][0]
+                print("%-22s corrected HBM bytes/launch: read %.4g + write %.4g = %.4g  (%.1f B per thread)"
+                      % (k, fb, wb, fb + wb, (fb + wb) / max(g2, 1)))
