@@ -62,20 +62,34 @@ def build_case(family, H, W):
     return kw, p, g
 
 
-def run_routing(kw, p, steps, warmup, nq=3, profile_steps=2):
-    """-> dict(ms_per_step, event_ms_per_step, prof) with inputs resident in HBM."""
+def run_routing(kw, p, steps, warmup, nq=3, profile_steps=2, ordered=True):
+    """-> dict(ms_per_step, event_ms_per_step, prof) with inputs resident in HBM.
+
+    ordered=True : discharge / lateral inflow resident in the engine's sweep-order layout (lf_router_route_ordered)
+    ordered=False: resident in the reference's pixel order, gathered/scattered inside the sweep (lf_router_route_device)
+    """
     from lisflood_amd import _lib
     from lisflood_amd import synthetic as syn
     N = kw.num_pixels
     Q = _lib.DeviceArray.from_host(p["Q0"])
     qs = [_lib.DeviceArray.from_host(syn.lateral_inflow(N, s)) for s in range(nq)]
+    if ordered:
+        tmp = _lib.DeviceArray(N)
+        for d in [Q] + qs:
+            kw.to_engine_order(d, tmp)
+            d.copy_from(tmp)
+        _lib.synchronize()
+        tmp.free()
+        route = kw.route_ordered
+    else:
+        route = kw.route_device
     for s in range(warmup):
-        kw.route_device(Q, qs[s % nq])
+        route(Q, qs[s % nq])
     _lib.synchronize()
     t0 = time.perf_counter()
     _lib.timer_start()
     for s in range(steps):
-        kw.route_device(Q, qs[s % nq])
+        route(Q, qs[s % nq])
     ev_ms = _lib.timer_stop()
     _lib.synchronize()
     t1 = time.perf_counter()
@@ -85,7 +99,7 @@ def run_routing(kw, p, steps, warmup, nq=3, profile_steps=2):
     kw.profile(True)
     kw.profile_read(reset=True)
     for s in range(profile_steps):
-        kw.route_device(Q, qs[s % nq])
+        route(Q, qs[s % nq])
     _lib.synchronize()
     prof = kw.profile_read(reset=True)
     kw.profile(False)
@@ -94,7 +108,7 @@ def run_routing(kw, p, steps, warmup, nq=3, profile_steps=2):
     for d in qs + [Q]:
         d.free()
     return dict(ms_per_step=(t1 - t0) * 1e3 / steps, event_ms_per_step=ev_ms / steps, prof=prof, stats=stats,
-                finite=ok)
+                finite=ok, profile_steps=profile_steps)
 
 
 def roofline_of(res):
@@ -110,7 +124,7 @@ def roofline_of(res):
     achieved = B_ALG * cells_per_launch / (ms_per_launch * 1e-3) / 1e9
     return dict(bound="hbm", kernel=name, achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit="GB/s",
                 frac=round(achieved / HBM_PEAK_GBS, 6), traffic=None,
-                launches_per_step=dom["launches"] and int(round(dom["launches"] / 2)),
+                launches_per_step=int(round(dom["launches"] / max(res.get("profile_steps", 1), 1))),
                 mean_launch_us=round(ms_per_launch * 1e3, 3), cells_per_launch=round(cells_per_launch, 1),
                 alg_bytes_per_cell_step=B_ALG,
                 prep_ms_per_step=round(prof["prep"]["ms"] / max(prof["prep"]["launches"], 1), 4))
@@ -209,12 +223,22 @@ def main():
                                % (H, W, "random ('shallow')" if a.family == "shallow" else "sheet-flow ('deep')",
                                   1 if a.family == "shallow" else 2),
                    "cells": N, "levels": g.num_levels, "launches_per_step": res["stats"]["launches"],
+                   "layout": "discharge and lateral inflow resident in HBM in the engine's sweep order "
+                             "(lf_router_route_ordered); see pixel_order_call for the reference-order device call",
                    "parallelism": "1 GPU"},
         "event_ms_per_step": round(res["event_ms_per_step"], 4),
         "hbm_frac_whole_step": round(B_ALG * N / (res["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
         "finite": res["finite"],
     }
     out["roofline"] = roofline_of(res)
+    try:
+        rp = run_routing(kw, p, max(3, a.steps // 3), 1, nq=2, profile_steps=1, ordered=False)
+        out["pixel_order_call"] = dict(value=round(N / rp["ms_per_step"] / 1e3, 2), unit="Mcell-steps/s",
+                                       ms_per_step=round(rp["ms_per_step"], 4),
+                                       note="same call with vectors resident in the reference's pixel order "
+                                            "(lf_router_route_device: gather/scatter through perm inside the sweep)")
+    except Exception as e:
+        out["pixel_order_call"] = {"error": repr(e)}
     kw.close()
     if not a.no_extra:
         extra = {}

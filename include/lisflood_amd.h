@@ -112,6 +112,14 @@ int lf_router_route_host(lf_router *r, double *discharge_host, const double *lat
 /* Device-resident form: discharge_dev[N] (in/out) and lateral_dev[N] in pixel order, asynchronous on the
  * library stream. */
 int lf_router_route_device(lf_router *r, double *discharge_dev, const double *lateral_dev, int section);
+/* Engine-order form.  The engine's HBM layout of a per-pixel vector is "sweep order" (levels ascending,
+ * breadth-first inside a level; lf_graph_get_layout's perm): in that layout every access of the sweep is
+ * a coalesced stream and discharge is updated in place.  Element-wise work (routing.dynamic's fix-ups,
+ * sideflow assembly) is order-agnostic, so a model step can keep all its vectors in engine order and
+ * convert only at its boundary with these two permutations (dst[p] = src[perm[p]] and its inverse). */
+int lf_router_to_engine_order(lf_router *r, const double *src_pix_dev, double *dst_ord_dev);
+int lf_router_from_engine_order(lf_router *r, const double *src_ord_dev, double *dst_pix_dev);
+int lf_router_route_ordered(lf_router *r, double *discharge_ord_dev, const double *lateral_ord_dev, int section);
 /* nancheck (kinematic_wave_parallel.py:180-184): number of non-finite entries of a device vector. */
 int lf_count_nonfinite(int device, const double *x_dev, int64_t n, int64_t *count);
 /* launch statistics of the last route call: [0] kernel launches, [1] wide-level launches,
@@ -140,10 +148,12 @@ typedef struct lf_substep_args {
     /* scratch [N] x 2 */
     double *scratch0, *scratch1;
     double Beta, InvBeta, InvDtRouting, DtSec;
-    int32_t split; /* 0: single routing branch (routing.py:518-538), 1: split routing (543-604) */
+    int32_t split;        /* 0: single routing branch (routing.py:518-538), 1: split routing (543-604) */
+    int32_t engine_order; /* 0: all vectors in pixel order, 1: all vectors in engine (sweep) order */
 } lf_substep_args;
 /* One routing.dynamic() sub-step: sideflow assembly, 1 or 2 router calls, volume/discharge fix-ups,
- * sumDisDay, FlowVelocity/TravelDistance.  All pointers are device memory, pixel order. */
+ * sumDisDay, FlowVelocity/TravelDistance.  All pointers are device memory, all in the same order
+ * (pixel order, or engine order when engine_order = 1). */
 int lf_routing_substep(lf_router *r, const lf_substep_args *a);
 
 /* ---------------------------------------------------------------------------------------------

@@ -66,39 +66,44 @@ __global__ void __launch_bounds__(kBlock) k_prep(int n, const int *__restrict__ 
 {
     const int p = blockIdx.x * kBlock + threadIdx.x;
     if (p >= n) return;
-    const int pix = perm[p];
+    const int pix = perm ? perm[p] : p; // perm == nullptr: vectors already in sweep order
     const double lateral = lat_pix[pix] * (dx ? dx[p] : dx_scalar);
     constant[p] = a[p] * pow(q_pix[pix], beta) + lateral;
 }
 
-// everything one sweep launch needs (passed by value: 112 B of kernarg)
+// everything one sweep launch needs (passed by value)
 struct sweep_args {
     const int *__restrict__ ups_ptr;
-    const int *__restrict__ perm;
+    const int *__restrict__ perm;        // pixel-order I/O only
     const double *__restrict__ a;        // alpha*dx/dt, sweep order
     const double *__restrict__ constant; // general path: written by k_prep
-    const double *__restrict__ lat_pix;  // fused path: specific lateral inflow, pixel order
+    const double *__restrict__ lat;      // fused path: specific lateral inflow (pixel order, or sweep order if ORDERED)
     const double *__restrict__ dx;       // fused path: per-pixel dx (sweep order) or nullptr
     double dx_scalar;
     double beta, inv_beta, b_minus_1;
-    int kmax;                  // max in-degree of the graph (<= 8)
-    double *qord;              // new discharge, sweep order (read by the next level)
-    double *__restrict__ q_pix; // caller's discharge vector, pixel order (old value in, new value out)
+    int kmax;     // max in-degree of the graph (<= 8)
+    double *qord; // discharge in sweep order: upstream values are read from it, the new value is written to it
+    double *q_pix; // pixel-order I/O: caller's discharge vector (old value in, new value out); unused if ORDERED
 };
 
-// One cell of the implicit sweep.  FUSED (beta == 3/5): the old-discharge term is computed here
-// (kinematic_wave_parallel.py:163,175 folded into the sweep) and the closure is solved as a quintic in
-// Q^(1/5) (lf_math.h); otherwise `constant` comes from k_prep and the reference's own Newton iteration runs.
-template <bool FUSED>
+// One cell of the implicit sweep.
+//   FUSED (beta == 3/5): the old-discharge term is computed here (kinematic_wave_parallel.py:163,175 folded
+//     into the sweep) and the closure is solved as a quintic in Q^(1/5) (lf_math.h); otherwise `constant`
+//     comes from k_prep and the reference's own Newton iteration runs.
+//   ORDERED: discharge and lateral inflow are resident in sweep order (engine layout): qord[p] holds the old
+//     discharge on entry and the new one on exit, every access is a coalesced stream.  Otherwise they are
+//     gathered from / scattered to the caller's pixel-order vectors through perm.
+template <bool FUSED, bool ORDERED>
 __device__ __forceinline__ void sweep_cell(int p, const sweep_args &A)
 {
     const int u0 = A.ups_ptr[p], u1 = A.ups_ptr[p + 1];
-    const int pix = A.perm[p];
+    const int pix = ORDERED ? p : A.perm[p];
     const double ap = A.a[p];
     double cst;
     if (FUSED) {
-        const double lateral = A.lat_pix[pix] * (A.dx ? A.dx[p] : A.dx_scalar);
-        cst = ap * lf_pow_3_5(A.q_pix[pix]) + lateral;
+        const double lateral = A.lat[pix] * (A.dx ? A.dx[p] : A.dx_scalar);
+        const double qold = ORDERED ? A.qord[p] : A.q_pix[pix];
+        cst = ap * lf_pow_3_5(qold) + lateral;
     } else {
         cst = A.constant[p];
     }
@@ -119,26 +124,26 @@ __device__ __forceinline__ void sweep_cell(int p, const sweep_args &A)
         q = lf_solve_cell(c, ap, A.beta * ap, A.beta, A.inv_beta, A.b_minus_1); // incl. alpha == 0 / NaN semantics
     }
     A.qord[p] = q;
-    A.q_pix[pix] = q;
+    if (!ORDERED) A.q_pix[pix] = q;
 }
 
 // one wide level: one cell per lane
-template <bool FUSED>
+template <bool FUSED, bool ORDERED>
 __global__ void __launch_bounds__(kBlock) k_level(int first, int count, sweep_args A)
 {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= count) return;
-    sweep_cell<FUSED>(first + i, A);
+    sweep_cell<FUSED, ORDERED>(first + i, A);
 }
 
 // a run of narrow levels [k0, k1): one workgroup, barrier between levels
-template <bool FUSED>
+template <bool FUSED, bool ORDERED>
 __global__ void __launch_bounds__(kNarrowBlock) k_levels_narrow(int k0, int k1, const long long *__restrict__ level_start,
                                                                 sweep_args A)
 {
     for (int k = k0; k < k1; ++k) {
         const int first = (int)level_start[k], last = (int)level_start[k + 1];
-        for (int p = first + (int)threadIdx.x; p < last; p += kNarrowBlock) sweep_cell<FUSED>(p, A);
+        for (int p = first + (int)threadIdx.x; p < last; p += kNarrowBlock) sweep_cell<FUSED, ORDERED>(p, A);
         __threadfence_block();
         __syncthreads();
     }
@@ -293,7 +298,7 @@ namespace {
 
 inline int blocks_for(int64_t n) { return (int)((n + kBlock - 1) / kBlock); }
 
-int route_device(lf_router *r, double *q_dev, const double *lat_dev, int section)
+int route_device(lf_router *r, double *q_dev, const double *lat_dev, int section, bool ordered = false)
 {
     if (section != LF_SECTION_MAIN && section != LF_SECTION_FLOODPLAINS)
         return lf_set_error(LF_E_SECTION, "The section parameter must be either 'main_channel' or 'floodplain'!");
@@ -309,19 +314,19 @@ int route_device(lf_router *r, double *q_dev, const double *lat_dev, int section
     A.perm = r->perm.p;
     A.a = a;
     A.constant = r->constant.p;
-    A.lat_pix = lat_dev;
+    A.lat = lat_dev;
     A.dx = r->dx_per_pixel ? r->dx.p : nullptr;
     A.dx_scalar = r->dx_scalar;
     A.beta = r->beta;
     A.inv_beta = r->inv_beta;
     A.b_minus_1 = r->b_minus_1;
     A.kmax = r->kmax;
-    A.qord = r->qord.p;
-    A.q_pix = q_dev;
+    A.qord = ordered ? q_dev : r->qord.p;
+    A.q_pix = ordered ? nullptr : q_dev;
     if (n > 0 && !r->fused) {
         LF_TRY(r->prof_begin(0, n));
-        hipLaunchKernelGGL(k_prep, dim3(blocks_for(n)), dim3(kBlock), 0, s, n, r->perm.p, q_dev, lat_dev, a, A.dx,
-                           r->dx_scalar, r->beta, r->constant.p);
+        hipLaunchKernelGGL(k_prep, dim3(blocks_for(n)), dim3(kBlock), 0, s, n, ordered ? nullptr : r->perm.p, q_dev,
+                           lat_dev, a, A.dx, r->dx_scalar, r->beta, r->constant.p);
         LF_TRY(r->prof_end());
         ++launches;
     }
@@ -330,20 +335,29 @@ int route_device(lf_router *r, double *q_dev, const double *lat_dev, int section
             const int first = (int)r->h_level_start[g.k0];
             const int count = (int)(r->h_level_start[g.k1] - r->h_level_start[g.k0]);
             LF_TRY(r->prof_begin(1, count));
-            if (r->fused)
-                hipLaunchKernelGGL(k_level<true>, dim3(blocks_for(count)), dim3(kBlock), 0, s, first, count, A);
+            const dim3 grid(blocks_for(count)), block(kBlock);
+            if (r->fused && ordered)
+                hipLaunchKernelGGL((k_level<true, true>), grid, block, 0, s, first, count, A);
+            else if (r->fused)
+                hipLaunchKernelGGL((k_level<true, false>), grid, block, 0, s, first, count, A);
+            else if (ordered)
+                hipLaunchKernelGGL((k_level<false, true>), grid, block, 0, s, first, count, A);
             else
-                hipLaunchKernelGGL(k_level<false>, dim3(blocks_for(count)), dim3(kBlock), 0, s, first, count, A);
+                hipLaunchKernelGGL((k_level<false, false>), grid, block, 0, s, first, count, A);
             LF_TRY(r->prof_end());
             ++wide;
         } else {
             LF_TRY(r->prof_begin(2, r->h_level_start[g.k1] - r->h_level_start[g.k0]));
-            if (r->fused)
-                hipLaunchKernelGGL(k_levels_narrow<true>, dim3(1), dim3(kNarrowBlock), 0, s, g.k0, g.k1,
-                                   r->level_start.p, A);
+            const dim3 grid(1), block(kNarrowBlock);
+            if (r->fused && ordered)
+                hipLaunchKernelGGL((k_levels_narrow<true, true>), grid, block, 0, s, g.k0, g.k1, r->level_start.p, A);
+            else if (r->fused)
+                hipLaunchKernelGGL((k_levels_narrow<true, false>), grid, block, 0, s, g.k0, g.k1, r->level_start.p, A);
+            else if (ordered)
+                hipLaunchKernelGGL((k_levels_narrow<false, true>), grid, block, 0, s, g.k0, g.k1, r->level_start.p, A);
             else
-                hipLaunchKernelGGL(k_levels_narrow<false>, dim3(1), dim3(kNarrowBlock), 0, s, g.k0, g.k1,
-                                   r->level_start.p, A);
+                hipLaunchKernelGGL((k_levels_narrow<false, false>), grid, block, 0, s, g.k0, g.k1, r->level_start.p,
+                                   A);
             LF_TRY(r->prof_end());
             ++narrow;
         }
@@ -449,6 +463,36 @@ int lf_router_route_device(lf_router *r, double *discharge_dev, const double *la
 {
     if (!r || !discharge_dev || !lateral_dev) return lf_set_error(LF_E_INVALID, "null argument");
     return route_device(r, discharge_dev, lateral_dev, section);
+}
+
+int lf_router_route_ordered(lf_router *r, double *discharge_ord_dev, const double *lateral_ord_dev, int section)
+{
+    if (!r || !discharge_ord_dev || !lateral_ord_dev) return lf_set_error(LF_E_INVALID, "null argument");
+    return route_device(r, discharge_ord_dev, lateral_ord_dev, section, true);
+}
+
+int lf_router_to_engine_order(lf_router *r, const double *src_pix_dev, double *dst_ord_dev)
+{
+    if (!r || !src_pix_dev || !dst_ord_dev) return lf_set_error(LF_E_INVALID, "null argument");
+    LF_HIP(hipSetDevice(r->device));
+    const int n = (int)r->N;
+    if (n > 0)
+        hipLaunchKernelGGL(k_gather, dim3(blocks_for(n)), dim3(kBlock), 0, r->ctx->stream, n, r->perm.p, src_pix_dev,
+                           dst_ord_dev);
+    LF_HIP(hipGetLastError());
+    return LF_OK;
+}
+
+int lf_router_from_engine_order(lf_router *r, const double *src_ord_dev, double *dst_pix_dev)
+{
+    if (!r || !src_ord_dev || !dst_pix_dev) return lf_set_error(LF_E_INVALID, "null argument");
+    LF_HIP(hipSetDevice(r->device));
+    const int n = (int)r->N;
+    if (n > 0)
+        hipLaunchKernelGGL(k_scatter, dim3(blocks_for(n)), dim3(kBlock), 0, r->ctx->stream, n, r->perm.p, src_ord_dev,
+                           dst_pix_dev);
+    LF_HIP(hipGetLastError());
+    return LF_OK;
 }
 
 int lf_router_route_host(lf_router *r, double *discharge_host, const double *lateral_host, int section)
@@ -669,10 +713,11 @@ extern "C" int lf_routing_substep(lf_router *r, const lf_substep_args *a)
     if (n == 0) return LF_OK;
     const dim3 grid(blocks_for(n)), block(kBlock);
     hipLaunchKernelGGL(k_substep_sideflow, grid, block, 0, s, n, *a);
-    LF_TRY(route_device(r, a->ChanQKin, a->scratch0, LF_SECTION_MAIN));
+    const bool ordered = a->engine_order != 0;
+    LF_TRY(route_device(r, a->ChanQKin, a->scratch0, LF_SECTION_MAIN, ordered));
     hipLaunchKernelGGL(k_substep_main, grid, block, 0, s, n, *a);
     if (a->split) {
-        LF_TRY(route_device(r, a->Chan2QKin, a->scratch1, LF_SECTION_FLOODPLAINS));
+        LF_TRY(route_device(r, a->Chan2QKin, a->scratch1, LF_SECTION_FLOODPLAINS, ordered));
         hipLaunchKernelGGL(k_substep_floodplain, grid, block, 0, s, n, *a);
     }
     LF_HIP(hipGetLastError());

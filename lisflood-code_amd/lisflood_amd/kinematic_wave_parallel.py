@@ -166,6 +166,24 @@ class kinematicWave:
             if n.value:
                 self._warn()
 
+    def to_engine_order(self, src_pix_dev, dst_ord_dev=None):
+        """pixel order -> engine (sweep) order on the device; returns the DeviceArray in engine order."""
+        if dst_ord_dev is None:
+            dst_ord_dev = DeviceArray(self.num_pixels, np.float64, self.device)
+        check(lib().lf_router_to_engine_order(self._h, src_pix_dev.ptr, dst_ord_dev.ptr))
+        return dst_ord_dev
+
+    def from_engine_order(self, src_ord_dev, dst_pix_dev=None):
+        if dst_pix_dev is None:
+            dst_pix_dev = DeviceArray(self.num_pixels, np.float64, self.device)
+        check(lib().lf_router_from_engine_order(self._h, src_ord_dev.ptr, dst_pix_dev.ptr))
+        return dst_pix_dev
+
+    def route_ordered(self, discharge_ord_dev, lateral_ord_dev, section="main_channel"):
+        """Engine-order resident form: both DeviceArrays are in sweep order, discharge is updated in place."""
+        sec = self._section(section)
+        check(lib().lf_router_route_ordered(self._h, discharge_ord_dev.ptr, lateral_ord_dev.ptr, C.c_int(sec)))
+
     def _warn(self):
         self.kinematic_wave_warning_printed = True
         warnings.warn(LisfloodWarning("Warning: NaN or Inf values after kinematicRouting module. Suggestion: please "

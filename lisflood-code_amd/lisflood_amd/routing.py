@@ -33,7 +33,7 @@ class _SubstepArgs(C.Structure):  # lf_substep_args, include/lisflood_amd.h
     _fields_ = ([(k, C.c_void_p) for k in _STATIC] + [("SideflowChanM3", C.c_void_p)] +
                 [(k, C.c_void_p) for k in _STATE + _OUT] + [("scratch0", C.c_void_p), ("scratch1", C.c_void_p)] +
                 [("Beta", C.c_double), ("InvBeta", C.c_double), ("InvDtRouting", C.c_double), ("DtSec", C.c_double),
-                 ("split", C.c_int32)])
+                 ("split", C.c_int32), ("engine_order", C.c_int32)])
 
 
 class routing(HydroModule):
