@@ -47,6 +47,9 @@ extern "C" {
 
 typedef struct lf_graph lf_graph;   /* host: LDD -> adjacency -> routing orders            */
 typedef struct lf_router lf_router; /* device: one kinematicWave instance                   */
+typedef struct lf_dist_graph lf_dist_graph;   /* host: one rank's row block of the raster, with halos */
+typedef struct lf_dist_router lf_dist_router; /* device: one rank's share of a partitioned kinematicWave */
+typedef struct lf_comm lf_comm;               /* RCCL communicator (one rank per GPU)            */
 
 const char *lf_last_error(void);
 int lf_version(void);
@@ -211,6 +214,62 @@ int lf_soil_columns_host(int device, const lf_soil_args *a);
 /* device-resident forms: every array pointer is device memory (except the small per-vegetation ones) */
 int lf_interception_device(int device, const lf_interception_args *a);
 int lf_soil_columns_device(int device, const lf_soil_args *a);
+
+/* ---------------------------------------------------------------------------------------------
+ * multi-GPU: the raster is split into contiguous row blocks, one rank (process, GPU) per block; boundary
+ * discharge is exchanged with RCCL Send/Recv between vertical neighbours.  The reference has no
+ * distributed code; the result is bit-identical to the single-domain call (see csrc/lf_dist.hip).
+ * Setup protocol (host side, any transport for the tiny phase vectors):
+ *   1. lf_dist_graph_create with the rank's own rows and the one halo row above / below (NULL at the
+ *      raster's edge);
+ *   2. repeat { get_export_phases -> swap with the neighbours -> set_ghost_phases } until no rank changes;
+ *   3. lf_dist_graph_finalize(max over ranks of lf_dist_graph_local_num_phases).
+ * ------------------------------------------------------------------------------------------- */
+int lf_dist_graph_create(const uint8_t *ldd_local, const uint8_t *mask_local, int H_local, int W,
+                         const uint8_t *ldd_top, const uint8_t *mask_top, const uint8_t *ldd_bottom,
+                         const uint8_t *mask_bottom, lf_dist_graph **out);
+void lf_dist_graph_destroy(lf_dist_graph *g);
+int64_t lf_dist_graph_num_pixels(const lf_dist_graph *g);
+int lf_dist_graph_counts(const lf_dist_graph *g, int64_t out[4]); /* exports top,bottom; ghosts top,bottom */
+int lf_dist_graph_get_export_phases(const lf_dist_graph *g, int32_t *top, int32_t *bottom);
+int lf_dist_graph_set_ghost_phases(lf_dist_graph *g, const int32_t *top, const int32_t *bottom, int *changed);
+int lf_dist_graph_local_num_phases(const lf_dist_graph *g);
+int lf_dist_graph_finalize(lf_dist_graph *g, int nphases);
+int64_t lf_dist_graph_state_size(const lf_dist_graph *g); /* N local cells + ghost slots */
+int lf_dist_graph_num_phases(const lf_dist_graph *g);
+int64_t lf_dist_graph_num_launch_units(const lf_dist_graph *g);
+int lf_dist_graph_get_layout(const lf_dist_graph *g, int32_t *perm, int32_t *phase_of_position);
+int lf_dist_graph_get_csr(const lf_dist_graph *g, int32_t *ups_ptr, int32_t *ups_idx, int64_t *n_edges);
+int lf_dist_graph_phase_range(const lf_dist_graph *g, int phase, int64_t out[2]);
+int lf_dist_graph_round_counts(const lf_dist_graph *g, int round, int64_t out[4]); /* send t,b; recv t,b */
+int lf_dist_graph_round_send_positions(const lf_dist_graph *g, int round, int side, int32_t *positions);
+int64_t lf_dist_graph_round_recv_slot(const lf_dist_graph *g, int round, int side);
+
+int lf_comm_unique_id(char id[128]);                 /* rank 0; broadcast the 128 bytes to the other ranks */
+int lf_comm_create(const char id[128], int nranks, int rank, int device, lf_comm **out);
+void lf_comm_destroy(lf_comm *c);
+
+/* alpha / dx / alpha_floodplains: per LOCAL pixel (row-major over the rank's own rows) */
+int lf_dist_router_create(const lf_dist_graph *g, const double *alpha, double beta, const double *dx,
+                          double dx_scalar, double dt, const double *alpha_floodplains, int device,
+                          lf_dist_router **out);
+void lf_dist_router_destroy(lf_dist_router *r);
+int64_t lf_dist_router_state_size(const lf_dist_router *r);
+int64_t lf_dist_router_last_launches(const lf_dist_router *r);
+int lf_dist_router_to_engine_order(lf_dist_router *r, const double *src_pix_dev, double *dst_ord_dev);
+int lf_dist_router_from_engine_order(lf_dist_router *r, const double *src_ord_dev, double *dst_pix_dev);
+/* one kinematicWaveRouting call; q_ord_dev has lf_dist_router_state_size entries (local cells in engine
+ * order followed by the ghost slots), lat_ord_dev the N local cells in engine order.  rank_top /
+ * rank_bottom = -1 at the raster's edge.  Asynchronous on the library stream. */
+int lf_dist_router_route(lf_dist_router *r, lf_comm *comm, double *q_ord_dev, const double *lat_ord_dev, int section,
+                         int rank_top, int rank_bottom);
+/* the pieces of a call, for transports other than RCCL and for tests */
+int lf_dist_router_compute_phase(lf_dist_router *r, double *q_ord_dev, const double *lat_ord_dev, int section,
+                                 int phase);
+int lf_dist_router_pack(lf_dist_router *r, const double *q_ord_dev, int round, void *send_ptr[2], int64_t send_count[2]);
+int lf_dist_router_recv_slots(const lf_dist_router *r, int round, int64_t slot[2], int64_t count[2]);
+int lf_dist_router_exchange(lf_dist_router *r, lf_comm *comm, double *q_ord_dev, int round, int rank_top,
+                            int rank_bottom);
 
 #ifdef __cplusplus
 }

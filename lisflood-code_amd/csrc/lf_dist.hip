@@ -1,0 +1,829 @@
+// lf_dist.hip -- row-block partitioned kinematic-wave routing across the GPUs of one node.
+//
+// The catchment raster is split into contiguous row blocks, one per rank (one process per GPU).  D8 edges
+// span at most one row, so a rank only ever needs discharge values of the row just above and just below
+// its block ("ghosts").  A cell's upstream neighbour may live on the other rank at ANY depth of the flow
+// path, so one halo exchange per call would lag cross-boundary inflow by a call and change the numerical
+// scheme.  Instead every local cell gets a PHASE = the largest number of rank-boundary crossings on any
+// flow path into it:
+//     phase(c) = max( phase(local upstream u), phase_on_its_rank(ghost upstream g) + 1 )
+// and a call is   for j in 0..nphases-1:  sweep the local cells of phase j;  exchange the boundary cells of
+// phase j (RCCL Send/Recv with the rank above / below, empty messages skipped).
+// The result is bit-identical to the single-domain sweep: same per-cell arithmetic, same upstream
+// summation order (ghosts of the row above first, then local cells in ascending id, then the row below =
+// ascending global pixel id, kinematic_wave_parallel_tools.py:57-58,119-129).
+//
+// Local sweep order: cells sorted by (phase, height above the local sources, local pixel id); upstream
+// positions come from an index list (lf_sweep.h INDEXED) because they may sit in earlier phases or in the
+// ghost slots appended after the N local cells of the discharge vector.  Ghost slots are ordered
+// (side, phase, column) so that the values received in round j land in one contiguous range.
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstring>
+
+#include "lf_sweep.h"
+
+// ------------------------------------------------------------------------------------------------
+// host: local graph with halos
+// ------------------------------------------------------------------------------------------------
+struct lf_dist_graph {
+    int H = 0, W = 0;
+    int64_t N = 0;        // local land cells
+    int K = 1;            // max in-degree incl. ghosts
+    bool finalized = false;
+    std::vector<int32_t> down;     // [N] local downstream id, -1 none (true outlet or export)
+    std::vector<int32_t> uptr, uidx; // local upstream CSR (pixel space, ascending id)
+    std::vector<int32_t> topo;     // local cells, upstream before downstream
+    // ghosts: cells of the halo rows that drain into a local cell; [0] = row above, [1] = row below
+    std::vector<int32_t> ghost_target[2]; // local id each ghost drains into (ascending column)
+    std::vector<int32_t> ghost_phase[2];  // phase of the ghost on its own rank
+    // exports: local cells draining into a land cell of a halo row
+    std::vector<int32_t> export_cell[2];  // local id (ascending column)
+    std::vector<int32_t> phase, height;   // [N]
+    int nphases = 1;                      // global number of phases (set by the host after the fixpoint)
+    // finalized layout
+    std::vector<int32_t> perm, pos;       // position <-> local id
+    std::vector<int32_t> ups_ptr, ups_idx;
+    std::vector<int64_t> level_start;     // launch units: runs of equal (phase, height)
+    std::vector<int32_t> phase_level;     // [nphases+1] first launch unit of each phase
+    std::vector<int32_t> export_pos[2];   // positions of exports sorted by (phase, column)
+    std::vector<int64_t> export_off[2];   // [nphases+1] offsets into export_pos per phase
+    std::vector<int64_t> ghost_off[2];    // [nphases+1] offsets (within the side) of ghosts per phase
+    int64_t ghost_base[2] = {0, 0};       // slot of the first ghost of each side (added to N)
+};
+
+namespace {
+
+const int kRowAdd[8] = {1, 1, 0, -1, -1, -1, 0, 1};
+const int kColAdd[8] = {0, 1, 1, 1, 0, -1, -1, -1};
+inline int decode(int code)
+{
+    switch (code) {
+    case 2: return 0;
+    case 3: return 1;
+    case 6: return 2;
+    case 9: return 3;
+    case 8: return 4;
+    case 7: return 5;
+    case 4: return 6;
+    case 1: return 7;
+    default: return 8;
+    }
+}
+
+void local_phases(lf_dist_graph *g)
+{
+    const int64_t n = g->N;
+    std::fill(g->phase.begin(), g->phase.end(), 0);
+    for (int side = 0; side < 2; ++side)
+        for (size_t i = 0; i < g->ghost_target[side].size(); ++i) {
+            int32_t &ph = g->phase[g->ghost_target[side][i]];
+            ph = std::max(ph, g->ghost_phase[side][i] + 1);
+        }
+    for (int64_t t = 0; t < n; ++t) { // upstream before downstream
+        const int32_t c = g->topo[t];
+        const int32_t d = g->down[c];
+        if (d >= 0) g->phase[d] = std::max(g->phase[d], g->phase[c]);
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+int lf_dist_graph_create(const uint8_t *ldd_local, const uint8_t *mask_local, int H, int W, const uint8_t *ldd_top,
+                         const uint8_t *mask_top, const uint8_t *ldd_bottom, const uint8_t *mask_bottom,
+                         lf_dist_graph **out)
+{
+    if (!ldd_local || !out || H <= 0 || W <= 0) return lf_set_error(LF_E_INVALID, "bad argument");
+    const int64_t HW = (int64_t)H * W;
+    lf_dist_graph *g = new lf_dist_graph();
+    g->H = H;
+    g->W = W;
+    std::vector<int32_t> lp(HW, -1);
+    int64_t n = 0;
+    for (int64_t i = 0; i < HW; ++i)
+        if (!mask_local || mask_local[i]) lp[i] = (int32_t)n++;
+    g->N = n;
+    g->down.assign(n, -1);
+    std::vector<int32_t> nups(n + 1, 0);
+    const bool has_side[2] = {ldd_top != nullptr, ldd_bottom != nullptr};
+    const uint8_t *halo_ldd[2] = {ldd_top, ldd_bottom};
+    const uint8_t *halo_mask[2] = {mask_top, mask_bottom};
+    // local edges and exports
+    for (int r = 0; r < H; ++r)
+        for (int c = 0; c < W; ++c) {
+            const int64_t i = (int64_t)r * W + c;
+            const int32_t p = lp[i];
+            if (p < 0) continue;
+            const int d = decode(ldd_local[i]);
+            if (d >= 8) continue;
+            const int rr = r + kRowAdd[d], cc = c + kColAdd[d];
+            if (cc < 0 || cc >= W) continue;
+            if (rr >= 0 && rr < H) {
+                const int32_t dn = lp[(int64_t)rr * W + cc];
+                if (dn >= 0) {
+                    g->down[p] = dn;
+                    nups[dn]++;
+                }
+            } else {
+                const int side = rr < 0 ? 0 : 1;
+                if (has_side[side] && (!halo_mask[side] || halo_mask[side][cc])) g->export_cell[side].push_back(p);
+            }
+        }
+    // ghosts: halo cells draining into a local land cell
+    std::vector<int32_t> nghost(n, 0);
+    for (int side = 0; side < 2; ++side) {
+        if (!has_side[side]) continue;
+        const int target_row = side == 0 ? 0 : H - 1;
+        const int want_dr = side == 0 ? 1 : -1;
+        for (int c = 0; c < W; ++c) {
+            if (halo_mask[side] && !halo_mask[side][c]) continue;
+            const int d = decode(halo_ldd[side][c]);
+            if (d >= 8 || kRowAdd[d] != want_dr) continue;
+            const int cc = c + kColAdd[d];
+            if (cc < 0 || cc >= W) continue;
+            const int32_t t = lp[(int64_t)target_row * W + cc];
+            if (t < 0) continue;
+            g->ghost_target[side].push_back(t);
+            g->ghost_phase[side].push_back(0);
+            nghost[t]++;
+        }
+    }
+    int K = 0;
+    for (int64_t p = 0; p < n; ++p) K = std::max(K, nups[p] + nghost[p]);
+    g->K = std::max(1, K);
+    // local upstream CSR
+    g->uptr.resize(n + 1);
+    int64_t acc = 0;
+    for (int64_t p = 0; p < n; ++p) {
+        g->uptr[p] = (int32_t)acc;
+        acc += nups[p];
+    }
+    g->uptr[n] = (int32_t)acc;
+    g->uidx.resize(acc);
+    {
+        std::vector<int32_t> fill(g->uptr.begin(), g->uptr.end() - 1);
+        for (int64_t p = 0; p < n; ++p)
+            if (g->down[p] >= 0) g->uidx[fill[g->down[p]]++] = (int32_t)p;
+    }
+    // topological order (upstream first) = reversed breadth-first order from the local outlets
+    std::vector<int32_t> queue(n);
+    int64_t head = 0, tail = 0;
+    for (int64_t p = 0; p < n; ++p)
+        if (g->down[p] < 0) queue[tail++] = (int32_t)p;
+    while (head < tail) {
+        const int32_t p = queue[head++];
+        for (int32_t e = g->uptr[p]; e < g->uptr[p + 1]; ++e) queue[tail++] = g->uidx[e];
+    }
+    if (tail != n) {
+        delete g;
+        return lf_set_error(LF_E_CYCLE, "LDD has a cycle inside the row block");
+    }
+    g->topo.assign(queue.rbegin(), queue.rend());
+    g->phase.assign(n, 0);
+    g->height.assign(n, 0);
+    for (int64_t t = 0; t < n; ++t) {
+        const int32_t c = g->topo[t], d = g->down[c];
+        if (d >= 0) g->height[d] = std::max(g->height[d], g->height[c] + 1);
+    }
+    local_phases(g);
+    *out = g;
+    return LF_OK;
+}
+
+void lf_dist_graph_destroy(lf_dist_graph *g) { delete g; }
+int64_t lf_dist_graph_num_pixels(const lf_dist_graph *g) { return g ? g->N : -1; }
+
+// out: n_export_top, n_export_bottom, n_ghost_top, n_ghost_bottom
+int lf_dist_graph_counts(const lf_dist_graph *g, int64_t out[4])
+{
+    if (!g || !out) return lf_set_error(LF_E_INVALID, "null argument");
+    out[0] = (int64_t)g->export_cell[0].size();
+    out[1] = (int64_t)g->export_cell[1].size();
+    out[2] = (int64_t)g->ghost_target[0].size();
+    out[3] = (int64_t)g->ghost_target[1].size();
+    return LF_OK;
+}
+
+int lf_dist_graph_get_export_phases(const lf_dist_graph *g, int32_t *top, int32_t *bottom)
+{
+    if (!g) return lf_set_error(LF_E_INVALID, "null argument");
+    int32_t *dst[2] = {top, bottom};
+    for (int side = 0; side < 2; ++side)
+        for (size_t i = 0; i < g->export_cell[side].size(); ++i) dst[side][i] = g->phase[g->export_cell[side][i]];
+    return LF_OK;
+}
+
+// ghost phases = the export phases of the neighbouring ranks (column order is identical on both sides).
+// Recomputes the local phases; *changed = 1 if any export phase changed (the fixpoint iteration continues).
+int lf_dist_graph_set_ghost_phases(lf_dist_graph *g, const int32_t *top, const int32_t *bottom, int *changed)
+{
+    if (!g || !changed) return lf_set_error(LF_E_INVALID, "null argument");
+    if (g->finalized) return lf_set_error(LF_E_INVALID, "graph already finalized");
+    const int32_t *src[2] = {top, bottom};
+    std::vector<int32_t> before[2];
+    for (int side = 0; side < 2; ++side) {
+        before[side].resize(g->export_cell[side].size());
+        for (size_t i = 0; i < before[side].size(); ++i) before[side][i] = g->phase[g->export_cell[side][i]];
+        for (size_t i = 0; i < g->ghost_phase[side].size(); ++i) g->ghost_phase[side][i] = src[side][i];
+    }
+    local_phases(g);
+    *changed = 0;
+    for (int side = 0; side < 2; ++side)
+        for (size_t i = 0; i < before[side].size(); ++i)
+            if (before[side][i] != g->phase[g->export_cell[side][i]]) *changed = 1;
+    return LF_OK;
+}
+
+int lf_dist_graph_local_num_phases(const lf_dist_graph *g)
+{
+    if (!g) return -1;
+    int m = 0;
+    for (int32_t p : g->phase) m = std::max(m, p);
+    for (int side = 0; side < 2; ++side)
+        for (int32_t p : g->ghost_phase[side]) m = std::max(m, p + 1);
+    return m + 1;
+}
+
+// nphases: the global maximum over ranks of lf_dist_graph_local_num_phases (all ranks run the same rounds)
+int lf_dist_graph_finalize(lf_dist_graph *g, int nphases)
+{
+    if (!g) return lf_set_error(LF_E_INVALID, "null argument");
+    if (nphases < lf_dist_graph_local_num_phases(g)) return lf_set_error(LF_E_INVALID, "nphases too small");
+    const int64_t n = g->N;
+    g->nphases = nphases;
+    // order by (phase, height, id): stable counting sorts, height first
+    int maxh = 0;
+    for (int32_t h : g->height) maxh = std::max(maxh, h);
+    std::vector<int32_t> tmp(n);
+    {
+        std::vector<int64_t> cnt(maxh + 2, 0);
+        for (int64_t p = 0; p < n; ++p) cnt[g->height[p] + 1]++;
+        for (int h = 0; h <= maxh; ++h) cnt[h + 1] += cnt[h];
+        for (int64_t p = 0; p < n; ++p) tmp[cnt[g->height[p]]++] = (int32_t)p;
+    }
+    g->perm.resize(n);
+    {
+        std::vector<int64_t> cnt(nphases + 1, 0);
+        for (int64_t p = 0; p < n; ++p) cnt[g->phase[p] + 1]++;
+        for (int j = 0; j < nphases; ++j) cnt[j + 1] += cnt[j];
+        for (int64_t i = 0; i < n; ++i) g->perm[cnt[g->phase[tmp[i]]]++] = tmp[i];
+    }
+    g->pos.resize(n);
+    for (int64_t p = 0; p < n; ++p) g->pos[g->perm[p]] = (int32_t)p;
+    // launch units and phase boundaries
+    g->level_start.clear();
+    g->phase_level.assign(nphases + 1, 0);
+    {
+        int cur_phase = -1, cur_h = -1;
+        for (int64_t p = 0; p < n; ++p) {
+            const int32_t c = g->perm[p];
+            if (g->phase[c] != cur_phase || g->height[c] != cur_h) {
+                for (int j = cur_phase + 1; j <= g->phase[c]; ++j) g->phase_level[j] = (int32_t)g->level_start.size();
+                g->level_start.push_back(p);
+                cur_phase = g->phase[c];
+                cur_h = g->height[c];
+            }
+        }
+        for (int j = cur_phase + 1; j <= nphases; ++j) g->phase_level[j] = (int32_t)g->level_start.size();
+        g->level_start.push_back(n);
+    }
+    // ghost slots ordered (side, phase, column); exports ordered (phase, column)
+    std::vector<int32_t> ghost_slot[2];
+    int64_t slot = 0;
+    for (int side = 0; side < 2; ++side) {
+        const size_t m = g->ghost_target[side].size();
+        g->ghost_base[side] = slot;
+        g->ghost_off[side].assign(nphases + 1, 0);
+        for (size_t i = 0; i < m; ++i) g->ghost_off[side][g->ghost_phase[side][i] + 1]++;
+        for (int j = 0; j < nphases; ++j) g->ghost_off[side][j + 1] += g->ghost_off[side][j];
+        ghost_slot[side].resize(m);
+        std::vector<int64_t> fill(g->ghost_off[side].begin(), g->ghost_off[side].end() - 1);
+        for (size_t i = 0; i < m; ++i) ghost_slot[side][i] = (int32_t)(slot + fill[g->ghost_phase[side][i]]++);
+        slot += (int64_t)m;
+        const size_t me = g->export_cell[side].size();
+        g->export_off[side].assign(nphases + 1, 0);
+        for (size_t i = 0; i < me; ++i) g->export_off[side][g->phase[g->export_cell[side][i]] + 1]++;
+        for (int j = 0; j < nphases; ++j) g->export_off[side][j + 1] += g->export_off[side][j];
+        g->export_pos[side].resize(me);
+        std::vector<int64_t> efill(g->export_off[side].begin(), g->export_off[side].end() - 1);
+        for (size_t i = 0; i < me; ++i) {
+            const int32_t c = g->export_cell[side][i];
+            g->export_pos[side][efill[g->phase[c]]++] = g->pos[c];
+        }
+    }
+    // upstream index lists in ascending global pixel id: row above, local (ascending id), row below
+    std::vector<std::vector<int32_t>> gl[2];
+    std::vector<int32_t> gcount[2];
+    for (int side = 0; side < 2; ++side) gcount[side].assign(n, 0);
+    for (int side = 0; side < 2; ++side)
+        for (int32_t t : g->ghost_target[side]) gcount[side][t]++;
+    g->ups_ptr.resize(n + 1);
+    int64_t e = 0;
+    for (int64_t p = 0; p < n; ++p) {
+        const int32_t c = g->perm[p];
+        g->ups_ptr[p] = (int32_t)e;
+        e += gcount[0][c] + (g->uptr[c + 1] - g->uptr[c]) + gcount[1][c];
+    }
+    g->ups_ptr[n] = (int32_t)e;
+    g->ups_idx.assign(e, -1);
+    {
+        std::vector<int32_t> cursor(n);
+        for (int64_t p = 0; p < n; ++p) cursor[g->perm[p]] = g->ups_ptr[p];
+        for (size_t i = 0; i < g->ghost_target[0].size(); ++i) // row above, ascending column
+            g->ups_idx[cursor[g->ghost_target[0][i]]++] = (int32_t)(n + ghost_slot[0][i]);
+        for (int64_t c = 0; c < n; ++c)
+            for (int32_t k = g->uptr[c]; k < g->uptr[c + 1]; ++k) g->ups_idx[cursor[c]++] = g->pos[g->uidx[k]];
+        for (size_t i = 0; i < g->ghost_target[1].size(); ++i) // row below, ascending column
+            g->ups_idx[cursor[g->ghost_target[1][i]]++] = (int32_t)(n + ghost_slot[1][i]);
+    }
+    g->finalized = true;
+    return LF_OK;
+}
+
+int64_t lf_dist_graph_state_size(const lf_dist_graph *g)
+{
+    return g ? g->N + (int64_t)(g->ghost_target[0].size() + g->ghost_target[1].size()) : -1;
+}
+int lf_dist_graph_num_phases(const lf_dist_graph *g) { return g ? g->nphases : -1; }
+int64_t lf_dist_graph_num_launch_units(const lf_dist_graph *g) { return g ? (int64_t)g->level_start.size() - 1 : -1; }
+
+int lf_dist_graph_get_layout(const lf_dist_graph *g, int32_t *perm, int32_t *phase_of_position)
+{
+    if (!g || !g->finalized) return lf_set_error(LF_E_INVALID, "graph not finalized");
+    if (perm) std::memcpy(perm, g->perm.data(), sizeof(int32_t) * g->perm.size());
+    if (phase_of_position)
+        for (int64_t p = 0; p < g->N; ++p) phase_of_position[p] = g->phase[g->perm[p]];
+    return LF_OK;
+}
+
+// plan getters for host-side executors / tests: CSR in position space
+int lf_dist_graph_get_csr(const lf_dist_graph *g, int32_t *ups_ptr, int32_t *ups_idx, int64_t *n_edges)
+{
+    if (!g || !g->finalized) return lf_set_error(LF_E_INVALID, "graph not finalized");
+    if (n_edges) *n_edges = (int64_t)g->ups_idx.size();
+    if (ups_ptr) std::memcpy(ups_ptr, g->ups_ptr.data(), sizeof(int32_t) * g->ups_ptr.size());
+    if (ups_idx) std::memcpy(ups_idx, g->ups_idx.data(), sizeof(int32_t) * g->ups_idx.size());
+    return LF_OK;
+}
+
+// position range [begin, end) of the cells of `phase`
+int lf_dist_graph_phase_range(const lf_dist_graph *g, int phase, int64_t out[2])
+{
+    if (!g || !g->finalized || phase < 0 || phase >= g->nphases) return lf_set_error(LF_E_INVALID, "bad argument");
+    out[0] = g->level_start[g->phase_level[phase]];
+    out[1] = g->level_start[g->phase_level[phase + 1]];
+    return LF_OK;
+}
+
+// round j: out = {send_top, send_bottom, recv_top, recv_bottom} element counts
+int lf_dist_graph_round_counts(const lf_dist_graph *g, int round, int64_t out[4])
+{
+    if (!g || !g->finalized || round < 0 || round >= g->nphases) return lf_set_error(LF_E_INVALID, "bad argument");
+    for (int side = 0; side < 2; ++side) {
+        out[side] = g->export_off[side][round + 1] - g->export_off[side][round];
+        out[2 + side] = g->ghost_off[side][round + 1] - g->ghost_off[side][round];
+    }
+    return LF_OK;
+}
+
+// positions (in the state vector) of the cells sent in `round` to `side`, and the first slot the values
+// received from `side` land in
+int lf_dist_graph_round_send_positions(const lf_dist_graph *g, int round, int side, int32_t *positions)
+{
+    if (!g || !g->finalized || round < 0 || round >= g->nphases || side < 0 || side > 1)
+        return lf_set_error(LF_E_INVALID, "bad argument");
+    const int64_t a = g->export_off[side][round], b = g->export_off[side][round + 1];
+    for (int64_t i = a; i < b; ++i) positions[i - a] = g->export_pos[side][i];
+    return LF_OK;
+}
+int64_t lf_dist_graph_round_recv_slot(const lf_dist_graph *g, int round, int side)
+{
+    if (!g || !g->finalized || round < 0 || round >= g->nphases || side < 0 || side > 1) return -1;
+    return g->N + g->ghost_base[side] + g->ghost_off[side][round];
+}
+
+} // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// RCCL communicator (librccl is loaded lazily so that single-GPU use never touches it)
+// ------------------------------------------------------------------------------------------------
+namespace {
+typedef struct { char internal[128]; } rccl_unique_id;
+typedef void *rccl_comm_t;
+struct rccl_api {
+    void *lib = nullptr;
+    int (*GetUniqueId)(rccl_unique_id *) = nullptr;
+    int (*CommInitRank)(rccl_comm_t *, int, rccl_unique_id, int) = nullptr;
+    int (*CommDestroy)(rccl_comm_t) = nullptr;
+    int (*Send)(const void *, size_t, int, int, rccl_comm_t, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, rccl_comm_t, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+rccl_api g_rccl;
+constexpr int kNcclFloat64 = 8; // ncclDouble (rccl.h ncclDataType_t)
+
+int load_rccl()
+{
+    if (g_rccl.lib) return LF_OK;
+    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return lf_set_error(LF_E_COMM, "cannot load librccl: %s", dlerror());
+#define LF_SYM(field, name)                                                              \
+    *(void **)(&g_rccl.field) = dlsym(h, name);                                          \
+    if (!g_rccl.field) return lf_set_error(LF_E_COMM, "librccl lacks symbol %s", name)
+    LF_SYM(GetUniqueId, "ncclGetUniqueId");
+    LF_SYM(CommInitRank, "ncclCommInitRank");
+    LF_SYM(CommDestroy, "ncclCommDestroy");
+    LF_SYM(Send, "ncclSend");
+    LF_SYM(Recv, "ncclRecv");
+    LF_SYM(GroupStart, "ncclGroupStart");
+    LF_SYM(GroupEnd, "ncclGroupEnd");
+    LF_SYM(GetErrorString, "ncclGetErrorString");
+#undef LF_SYM
+    g_rccl.lib = h;
+    return LF_OK;
+}
+#define LF_NCCL(call)                                                                                   \
+    do {                                                                                                \
+        int e_ = (call);                                                                                \
+        if (e_ != 0) return lf_set_error(LF_E_COMM, "%s failed: %s", #call, g_rccl.GetErrorString(e_)); \
+    } while (0)
+} // namespace
+
+struct lf_comm {
+    rccl_comm_t comm = nullptr;
+    int nranks = 1, rank = 0, device = 0;
+};
+
+extern "C" {
+
+int lf_comm_unique_id(char id[128])
+{
+    if (!id) return lf_set_error(LF_E_INVALID, "null argument");
+    LF_TRY(load_rccl());
+    rccl_unique_id u;
+    LF_NCCL(g_rccl.GetUniqueId(&u));
+    std::memcpy(id, u.internal, 128);
+    return LF_OK;
+}
+
+int lf_comm_create(const char id[128], int nranks, int rank, int device, lf_comm **out)
+{
+    if (!id || !out) return lf_set_error(LF_E_INVALID, "null argument");
+    LF_TRY(load_rccl());
+    LF_TRY(lf_ctx(device, nullptr));
+    rccl_unique_id u;
+    std::memcpy(u.internal, id, 128);
+    lf_comm *c = new lf_comm();
+    c->nranks = nranks;
+    c->rank = rank;
+    c->device = device;
+    int e = g_rccl.CommInitRank(&c->comm, nranks, u, rank);
+    if (e != 0) {
+        delete c;
+        return lf_set_error(LF_E_COMM, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(e));
+    }
+    *out = c;
+    return LF_OK;
+}
+
+void lf_comm_destroy(lf_comm *c)
+{
+    if (!c) return;
+    if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+    delete c;
+}
+
+} // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// device: distributed router
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct dsegment {
+    int k0, k1;
+    bool wide;
+};
+
+__global__ void __launch_bounds__(kBlock) k_pack(int n, const int *__restrict__ positions, const double *__restrict__ q,
+                                                 double *__restrict__ buf)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) buf[i] = q[positions[i]];
+}
+__global__ void __launch_bounds__(kBlock) k_dgather(int n, const int *__restrict__ perm, const double *__restrict__ src,
+                                                    double *__restrict__ dst)
+{
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p < n) dst[p] = src[perm[p]];
+}
+__global__ void __launch_bounds__(kBlock) k_dscatter(int n, const int *__restrict__ perm, const double *__restrict__ src,
+                                                     double *__restrict__ dst)
+{
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p < n) dst[perm[p]] = src[p];
+}
+} // namespace
+
+struct lf_dist_router {
+    int device = 0;
+    lf_device_ctx *ctx = nullptr;
+    int64_t N = 0, state_size = 0;
+    int nphases = 1, kmax = 8;
+    double beta = 0, inv_beta = 0, b_minus_1 = 0, dx_scalar = 0;
+    bool has_floodplains = false, dx_per_pixel = false, fused = false;
+    lf_dbuf<int32_t> perm, ups_ptr, ups_idx, export_pos[2];
+    lf_dbuf<long long> level_start;
+    lf_dbuf<double> a1, a2, dx, constant, sendbuf[2];
+    std::vector<int64_t> h_level_start;
+    std::vector<std::vector<dsegment>> schedule; // per phase
+    std::vector<int64_t> export_off[2], ghost_off[2];
+    int64_t ghost_base[2] = {0, 0};
+    int64_t last_launches = 0;
+};
+
+namespace {
+
+int dist_compute_phase(lf_dist_router *r, double *q, const double *lat, int section, int phase)
+{
+    if (section != LF_SECTION_MAIN && section != LF_SECTION_FLOODPLAINS)
+        return lf_set_error(LF_E_SECTION, "The section parameter must be either 'main_channel' or 'floodplain'!");
+    if (section == LF_SECTION_FLOODPLAINS && !r->has_floodplains)
+        return lf_set_error(LF_E_SECTION, "floodplains routing requested but alpha_floodplains was not given");
+    if (phase < 0 || phase >= r->nphases) return lf_set_error(LF_E_INVALID, "phase %d out of range", phase);
+    hipStream_t s = r->ctx->stream;
+    sweep_args A;
+    A.ups_ptr = r->ups_ptr.p;
+    A.ups_idx = r->ups_idx.p;
+    A.perm = nullptr;
+    A.a = section == LF_SECTION_MAIN ? r->a1.p : r->a2.p;
+    A.constant = r->constant.p;
+    A.lat = lat;
+    A.dx = r->dx_per_pixel ? r->dx.p : nullptr;
+    A.dx_scalar = r->dx_scalar;
+    A.beta = r->beta;
+    A.inv_beta = r->inv_beta;
+    A.b_minus_1 = r->b_minus_1;
+    A.kmax = r->kmax;
+    A.qord = q;
+    A.q_pix = nullptr;
+    if (!r->fused && phase == 0 && r->N > 0) { // general beta: constant for ALL local cells from the old discharge
+        const int n = (int)r->N;
+        hipLaunchKernelGGL(k_prep, dim3(blocks_for(n)), dim3(kBlock), 0, s, n, (const int *)nullptr, q, lat, A.a, A.dx,
+                           r->dx_scalar, r->beta, r->constant.p);
+        r->last_launches++;
+    }
+    for (const dsegment &g : r->schedule[phase]) {
+        if (g.wide) {
+            const int first = (int)r->h_level_start[g.k0];
+            const int count = (int)(r->h_level_start[g.k1] - r->h_level_start[g.k0]);
+            const dim3 grid(blocks_for(count)), block(kBlock);
+            if (r->fused)
+                hipLaunchKernelGGL((k_level<true, true, true>), grid, block, 0, s, first, count, A);
+            else
+                hipLaunchKernelGGL((k_level<false, true, true>), grid, block, 0, s, first, count, A);
+        } else {
+            const dim3 grid(1), block(kNarrowBlock);
+            if (r->fused)
+                hipLaunchKernelGGL((k_levels_narrow<true, true, true>), grid, block, 0, s, g.k0, g.k1, r->level_start.p,
+                                   A);
+            else
+                hipLaunchKernelGGL((k_levels_narrow<false, true, true>), grid, block, 0, s, g.k0, g.k1,
+                                   r->level_start.p, A);
+        }
+        r->last_launches++;
+    }
+    LF_HIP(hipGetLastError());
+    return LF_OK;
+}
+
+int dist_pack(lf_dist_router *r, const double *q, int round)
+{
+    hipStream_t s = r->ctx->stream;
+    for (int side = 0; side < 2; ++side) {
+        const int64_t a = r->export_off[side][round], b = r->export_off[side][round + 1];
+        if (b > a) {
+            hipLaunchKernelGGL(k_pack, dim3(blocks_for(b - a)), dim3(kBlock), 0, s, (int)(b - a),
+                               r->export_pos[side].p + a, q, r->sendbuf[side].p + a);
+            r->last_launches++;
+        }
+    }
+    LF_HIP(hipGetLastError());
+    return LF_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int lf_dist_router_create(const lf_dist_graph *g, const double *alpha, double beta, const double *dx, double dx_scalar,
+                          double dt, const double *alpha_floodplains, int device, lf_dist_router **out)
+{
+    if (!g || !alpha || !out) return lf_set_error(LF_E_INVALID, "null argument");
+    if (!g->finalized) return lf_set_error(LF_E_INVALID, "graph not finalized");
+    lf_device_ctx *ctx;
+    LF_TRY(lf_ctx(device, &ctx));
+    lf_dist_router *r = new lf_dist_router();
+    r->device = device;
+    r->ctx = ctx;
+    r->N = g->N;
+    r->state_size = lf_dist_graph_state_size(g);
+    r->nphases = g->nphases;
+    r->kmax = std::min(8, g->K);
+    r->beta = beta;
+    r->inv_beta = 1 / beta;
+    r->b_minus_1 = beta - 1;
+    r->dx_scalar = dx_scalar;
+    r->dx_per_pixel = dx != nullptr;
+    r->has_floodplains = alpha_floodplains != nullptr;
+    const char *force_general = std::getenv("LF_GENERAL_POW");
+    r->fused = (beta == 0.6) && !(force_general && force_general[0] == '1');
+    const int64_t n = g->N;
+    int rc = LF_OK;
+    {
+        std::vector<double> h(n);
+        auto fill = [&](const double *al) {
+            for (int64_t p = 0; p < n; ++p) {
+                const int32_t pix = g->perm[p];
+                h[p] = al[pix] * (dx ? dx[pix] : dx_scalar) / dt; // kinematic_wave_parallel.py:127
+            }
+        };
+        fill(alpha);
+        rc = r->a1.upload(h.data(), n);
+        if (rc == LF_OK && alpha_floodplains) {
+            fill(alpha_floodplains);
+            rc = r->a2.upload(h.data(), n);
+        }
+        if (rc == LF_OK && dx) {
+            for (int64_t p = 0; p < n; ++p) h[p] = dx[g->perm[p]];
+            rc = r->dx.upload(h.data(), n);
+        }
+    }
+    if (rc == LF_OK) rc = r->perm.upload(g->perm.data(), n);
+    if (rc == LF_OK) rc = r->ups_ptr.upload(g->ups_ptr.data(), n + 1);
+    if (rc == LF_OK) rc = r->ups_idx.upload(g->ups_idx.data(), g->ups_idx.size());
+    if (rc == LF_OK) {
+        std::vector<long long> ls(g->level_start.begin(), g->level_start.end());
+        rc = r->level_start.upload(ls.data(), ls.size());
+    }
+    if (rc == LF_OK && !r->fused) rc = r->constant.alloc(n);
+    for (int side = 0; side < 2 && rc == LF_OK; ++side) {
+        rc = r->export_pos[side].upload(g->export_pos[side].data(), g->export_pos[side].size());
+        if (rc == LF_OK) rc = r->sendbuf[side].alloc(g->export_pos[side].size());
+        r->export_off[side] = g->export_off[side];
+        r->ghost_off[side] = g->ghost_off[side];
+        r->ghost_base[side] = g->ghost_base[side];
+    }
+    if (rc != LF_OK) {
+        delete r;
+        return rc;
+    }
+    r->h_level_start = g->level_start;
+    r->schedule.resize(g->nphases);
+    for (int j = 0; j < g->nphases; ++j) {
+        const int64_t k_end = g->phase_level[j + 1];
+        for (int64_t k = g->phase_level[j]; k < k_end;) {
+            const int64_t size = g->level_start[k + 1] - g->level_start[k];
+            if (size > kNarrowMax) {
+                r->schedule[j].push_back({(int)k, (int)k + 1, true});
+                ++k;
+            } else {
+                int64_t e = k + 1;
+                while (e < k_end && g->level_start[e + 1] - g->level_start[e] <= kNarrowMax) ++e;
+                r->schedule[j].push_back({(int)k, (int)e, false});
+                k = e;
+            }
+        }
+    }
+    *out = r;
+    return LF_OK;
+}
+
+void lf_dist_router_destroy(lf_dist_router *r)
+{
+    if (!r) return;
+    (void)hipSetDevice(r->device);
+    (void)hipStreamSynchronize(r->ctx->stream);
+    delete r;
+}
+
+int64_t lf_dist_router_state_size(const lf_dist_router *r) { return r ? r->state_size : -1; }
+int64_t lf_dist_router_last_launches(const lf_dist_router *r) { return r ? r->last_launches : -1; }
+
+// local pixel order -> engine order (first N entries of the state vector; ghost slots untouched) and back
+int lf_dist_router_to_engine_order(lf_dist_router *r, const double *src_pix_dev, double *dst_ord_dev)
+{
+    if (!r || !src_pix_dev || !dst_ord_dev) return lf_set_error(LF_E_INVALID, "null argument");
+    LF_HIP(hipSetDevice(r->device));
+    const int n = (int)r->N;
+    if (n > 0)
+        hipLaunchKernelGGL(k_dgather, dim3(blocks_for(n)), dim3(kBlock), 0, r->ctx->stream, n, r->perm.p, src_pix_dev,
+                           dst_ord_dev);
+    LF_HIP(hipGetLastError());
+    return LF_OK;
+}
+int lf_dist_router_from_engine_order(lf_dist_router *r, const double *src_ord_dev, double *dst_pix_dev)
+{
+    if (!r || !src_ord_dev || !dst_pix_dev) return lf_set_error(LF_E_INVALID, "null argument");
+    LF_HIP(hipSetDevice(r->device));
+    const int n = (int)r->N;
+    if (n > 0)
+        hipLaunchKernelGGL(k_dscatter, dim3(blocks_for(n)), dim3(kBlock), 0, r->ctx->stream, n, r->perm.p, src_ord_dev,
+                           dst_pix_dev);
+    LF_HIP(hipGetLastError());
+    return LF_OK;
+}
+
+// sweep of the local cells of one phase (state vector q_ord_dev has lf_dist_router_state_size entries)
+int lf_dist_router_compute_phase(lf_dist_router *r, double *q_ord_dev, const double *lat_ord_dev, int section, int phase)
+{
+    if (!r || !q_ord_dev || !lat_ord_dev) return lf_set_error(LF_E_INVALID, "null argument");
+    LF_HIP(hipSetDevice(r->device));
+    return dist_compute_phase(r, q_ord_dev, lat_ord_dev, section, phase);
+}
+
+// gathers the boundary cells of `round` into the two send buffers; returns their device addresses / counts
+int lf_dist_router_pack(lf_dist_router *r, const double *q_ord_dev, int round, void *send_ptr[2], int64_t send_count[2])
+{
+    if (!r || !q_ord_dev || round < 0 || round >= r->nphases) return lf_set_error(LF_E_INVALID, "bad argument");
+    LF_HIP(hipSetDevice(r->device));
+    LF_TRY(dist_pack(r, q_ord_dev, round));
+    for (int side = 0; side < 2; ++side) {
+        if (send_ptr) send_ptr[side] = r->sendbuf[side].p + r->export_off[side][round];
+        if (send_count) send_count[side] = r->export_off[side][round + 1] - r->export_off[side][round];
+    }
+    return LF_OK;
+}
+
+// where the values received in `round` from each side land inside the state vector
+int lf_dist_router_recv_slots(const lf_dist_router *r, int round, int64_t slot[2], int64_t count[2])
+{
+    if (!r || round < 0 || round >= r->nphases) return lf_set_error(LF_E_INVALID, "bad argument");
+    for (int side = 0; side < 2; ++side) {
+        slot[side] = r->N + r->ghost_base[side] + r->ghost_off[side][round];
+        count[side] = r->ghost_off[side][round + 1] - r->ghost_off[side][round];
+    }
+    return LF_OK;
+}
+
+// pack + RCCL Send/Recv with the rank above (rank_top) and below (rank_bottom); -1 = no neighbour
+int lf_dist_router_exchange(lf_dist_router *r, lf_comm *comm, double *q_ord_dev, int round, int rank_top, int rank_bottom)
+{
+    if (!r || !comm || !q_ord_dev || round < 0 || round >= r->nphases) return lf_set_error(LF_E_INVALID, "bad argument");
+    LF_HIP(hipSetDevice(r->device));
+    LF_TRY(dist_pack(r, q_ord_dev, round));
+    const int peer[2] = {rank_top, rank_bottom};
+    bool any = false;
+    for (int side = 0; side < 2; ++side) {
+        const int64_t ns = r->export_off[side][round + 1] - r->export_off[side][round];
+        const int64_t nr = r->ghost_off[side][round + 1] - r->ghost_off[side][round];
+        if ((ns > 0 || nr > 0) && peer[side] < 0) return lf_set_error(LF_E_INVALID, "halo traffic without a neighbour rank");
+        any = any || ns > 0 || nr > 0;
+    }
+    if (!any) return LF_OK;
+    hipStream_t s = r->ctx->stream;
+    LF_NCCL(g_rccl.GroupStart());
+    for (int side = 0; side < 2; ++side) {
+        const int64_t ns = r->export_off[side][round + 1] - r->export_off[side][round];
+        const int64_t nr = r->ghost_off[side][round + 1] - r->ghost_off[side][round];
+        if (ns > 0)
+            LF_NCCL(g_rccl.Send(r->sendbuf[side].p + r->export_off[side][round], (size_t)ns, kNcclFloat64, peer[side],
+                                comm->comm, s));
+        if (nr > 0)
+            LF_NCCL(g_rccl.Recv(q_ord_dev + r->N + r->ghost_base[side] + r->ghost_off[side][round], (size_t)nr,
+                                kNcclFloat64, peer[side], comm->comm, s));
+    }
+    LF_NCCL(g_rccl.GroupEnd());
+    return LF_OK;
+}
+
+// one kinematicWaveRouting call on the partitioned raster (asynchronous on the library stream)
+int lf_dist_router_route(lf_dist_router *r, lf_comm *comm, double *q_ord_dev, const double *lat_ord_dev, int section,
+                         int rank_top, int rank_bottom)
+{
+    if (!r || !q_ord_dev || !lat_ord_dev) return lf_set_error(LF_E_INVALID, "null argument");
+    LF_HIP(hipSetDevice(r->device));
+    r->last_launches = 0;
+    for (int j = 0; j < r->nphases; ++j) {
+        LF_TRY(dist_compute_phase(r, q_ord_dev, lat_ord_dev, section, j));
+        if (j + 1 < r->nphases) {
+            if (!comm) {
+                bool any = false;
+                for (int side = 0; side < 2; ++side)
+                    any = any || r->export_off[side][j + 1] > r->export_off[side][j] ||
+                          r->ghost_off[side][j + 1] > r->ghost_off[side][j];
+                if (any) return lf_set_error(LF_E_COMM, "halo exchange needed but no communicator given");
+            } else {
+                LF_TRY(lf_dist_router_exchange(r, comm, q_ord_dev, j, rank_top, rank_bottom));
+            }
+        }
+    }
+    return LF_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,146 @@
+// lf_sweep.h -- device code of the level sweep, shared by the single-GPU router (lf_router.hip) and the
+// row-block distributed router (lf_dist.hip).  See lf_router.hip for the data layout.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "lf_common.h"
+#include "lf_math.h"
+
+namespace {
+
+
+constexpr int kBlock = 256;
+constexpr int kNarrowBlock = 1024;
+constexpr int kNarrowMax = 1024; // levels up to this many cells are swept by the single-workgroup kernel
+
+inline int blocks_for(int64_t n) { return (int)((n + kBlock - 1) / kBlock); }
+
+// solve1Pixel, kinematic_wave_parallel_tools.py:59-82 (c = const_plus_ups_infl)
+__device__ __forceinline__ double lf_solve_cell(double c, double a, double ba, double beta, double inv_beta,
+                                                double b_minus_1)
+{
+    if (c <= LF_NEWTON_TOL) return 0.0;
+    const double t = ba * pow(c, b_minus_1);
+    double secant;
+    if (t <= 1.0)
+        secant = c / (1.0 + t);
+    else
+        secant = c / (1.0 + pow(t, inv_beta));
+    const double other = pow((c - secant) / a, inv_beta);
+    double q = (secant + other) / 2.0;
+    double err = q + a * pow(q, beta) - c; // closureError, :89-92
+    double prev = -1.0;
+    int count = 0;
+    while (fabs(err) > LF_NEWTON_TOL && q != prev && count < LF_MAX_ITERS) {
+        prev = q;
+        q -= err / (1.0 + ba * pow(q, b_minus_1));
+        q = (LF_NEWTON_TOL > q) ? LF_NEWTON_TOL : q; // builtins.max(q, NEWTON_TOL)
+        err = q + a * pow(q, beta) - c;
+        ++count;
+    }
+    if (q == LF_NEWTON_TOL) q = 0.0;
+    return q;
+}
+
+// constant = a*Qold^beta + q*dx (kinematic_wave_parallel.py:163,175), gathered into sweep order
+__global__ void __launch_bounds__(kBlock) k_prep(int n, const int *__restrict__ perm, const double *__restrict__ q_pix,
+                                                 const double *__restrict__ lat_pix, const double *__restrict__ a,
+                                                 const double *__restrict__ dx, double dx_scalar, double beta,
+                                                 double *__restrict__ constant)
+{
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= n) return;
+    const int pix = perm ? perm[p] : p; // perm == nullptr: vectors already in sweep order
+    const double lateral = lat_pix[pix] * (dx ? dx[p] : dx_scalar);
+    constant[p] = a[p] * pow(q_pix[pix], beta) + lateral;
+}
+
+// everything one sweep launch needs (passed by value)
+struct sweep_args {
+    const int *__restrict__ ups_ptr;
+    const int *__restrict__ ups_idx;     // INDEXED only: upstream positions (may point into the ghost slots)
+    const int *__restrict__ perm;        // pixel-order I/O only
+    const double *__restrict__ a;        // alpha*dx/dt, sweep order
+    const double *__restrict__ constant; // general path: written by k_prep
+    const double *__restrict__ lat;      // fused path: specific lateral inflow (pixel order, or sweep order if ORDERED)
+    const double *__restrict__ dx;       // fused path: per-pixel dx (sweep order) or nullptr
+    double dx_scalar;
+    double beta, inv_beta, b_minus_1;
+    int kmax;     // max in-degree of the graph (<= 8)
+    double *qord; // discharge in sweep order: upstream values are read from it, the new value is written to it
+    double *q_pix; // pixel-order I/O: caller's discharge vector (old value in, new value out); unused if ORDERED
+};
+
+// One cell of the implicit sweep.
+//   FUSED (beta == 3/5): the old-discharge term is computed here (kinematic_wave_parallel.py:163,175 folded
+//     into the sweep) and the closure is solved as a quintic in Q^(1/5) (lf_math.h); otherwise `constant`
+//     comes from k_prep and the reference's own Newton iteration runs.
+//   ORDERED: discharge and lateral inflow are resident in sweep order (engine layout): qord[p] holds the old
+//     discharge on entry and the new one on exit, every access is a coalesced stream.  Otherwise they are
+//     gathered from / scattered to the caller's pixel-order vectors through perm.
+//   INDEXED: upstream positions come from the index list ups_idx[ups_ptr[p] .. ups_ptr[p+1]) instead of being the
+//     contiguous positions themselves (row-block partitions: upstream cells may sit in other phases or in the
+//     ghost slots filled by the halo exchange).
+template <bool FUSED, bool ORDERED, bool INDEXED = false>
+__device__ __forceinline__ void sweep_cell(int p, const sweep_args &A)
+{
+    const int u0 = A.ups_ptr[p], u1 = A.ups_ptr[p + 1];
+    const int pix = ORDERED ? p : A.perm[p];
+    const double ap = A.a[p];
+    double cst;
+    if (FUSED) {
+        const double lateral = A.lat[pix] * (A.dx ? A.dx[p] : A.dx_scalar);
+        const double qold = ORDERED ? A.qord[p] : A.q_pix[pix];
+        cst = ap * lf_pow_3_5(qold) + lateral;
+    } else {
+        cst = A.constant[p];
+    }
+    // Upstream inflow, summed in ascending pixel id (kinematic_wave_parallel_tools.py:57-58).  A D8 cell has
+    // at most 8 upstream neighbours: all candidate loads are issued at once (predicated) instead of a
+    // dependent load per loop trip; missing ones contribute +0.0, which leaves the sum bit-identical.
+    double v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const bool on = k < A.kmax && u0 + k < u1;
+        if (INDEXED)
+            v[k] = on ? A.qord[A.ups_idx[u0 + k]] : 0.0;
+        else
+            v[k] = on ? A.qord[u0 + k] : 0.0;
+    }
+    double ups = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ups += v[k];
+    const double c = ups + cst;
+    double q;
+    if (FUSED && lf_fast_range(c) && lf_fast_range(ap)) {
+        q = (c <= LF_NEWTON_TOL) ? 0.0 : lf_solve_3_5(c, ap);
+    } else {
+        q = lf_solve_cell(c, ap, A.beta * ap, A.beta, A.inv_beta, A.b_minus_1); // incl. alpha == 0 / NaN semantics
+    }
+    A.qord[p] = q;
+    if (!ORDERED) A.q_pix[pix] = q;
+}
+
+// one wide level: one cell per lane
+template <bool FUSED, bool ORDERED, bool INDEXED = false>
+__global__ void __launch_bounds__(kBlock) k_level(int first, int count, sweep_args A)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= count) return;
+    sweep_cell<FUSED, ORDERED, INDEXED>(first + i, A);
+}
+
+// a run of narrow levels [k0, k1): one workgroup, barrier between levels
+template <bool FUSED, bool ORDERED, bool INDEXED = false>
+__global__ void __launch_bounds__(kNarrowBlock) k_levels_narrow(int k0, int k1, const long long *__restrict__ level_start,
+                                                                sweep_args A)
+{
+    for (int k = k0; k < k1; ++k) {
+        const int first = (int)level_start[k], last = (int)level_start[k + 1];
+        for (int p = first + (int)threadIdx.x; p < last; p += kNarrowBlock) sweep_cell<FUSED, ORDERED, INDEXED>(p, A);
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+} // namespace

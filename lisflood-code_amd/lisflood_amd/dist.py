@@ -1,0 +1,311 @@
+"""Row-block partitioned kinematic-wave routing (one process per GPU, RCCL halo exchange over xGMI).
+
+The reference has no distributed code; this module is the host side of csrc/lf_dist.hip.  A transport is
+any object with `exchange_int32(top_send, bottom_send, n_top_recv, n_bottom_recv) -> (top_recv, bottom_recv)`
+and `allreduce_max(int) -> int`; `TorchTransport` implements it on torch.distributed (gloo is enough: only
+the tiny phase vectors travel through it at set-up); `settle_phases_local` / `loopback_route` connect
+several blocks living in one process (tests, single-GPU loopback).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import DeviceArray, check, f64, lib, ptr, u8
+
+
+def row_blocks(H, nranks):
+    """Contiguous row ranges [(r0, r1)] of an H-row raster, as even as possible."""
+    base, extra = divmod(H, nranks)
+    out, r = [], 0
+    for k in range(nranks):
+        n = base + (1 if k < extra else 0)
+        out.append((r, r + n))
+        r += n
+    return out
+
+
+class DistGraph:
+    """One rank's block.  ldd_local [Hl, W] uint8; top / bottom: the halo row (W uint8) or None."""
+
+    def __init__(self, ldd_local, mask_local=None, ldd_top=None, mask_top=None, ldd_bottom=None, mask_bottom=None):
+        ldd_local = np.ascontiguousarray(ldd_local, dtype=np.uint8)
+        Hl, W = ldd_local.shape
+        self.shape = (Hl, W)
+        conv = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.uint8)
+        keep = [ldd_local, None if mask_local is None else u8(mask_local), conv(ldd_top),
+                None if mask_top is None else u8(mask_top), conv(ldd_bottom),
+                None if mask_bottom is None else u8(mask_bottom)]
+        self._h = C.c_void_p()
+        check(lib().lf_dist_graph_create(ptr(keep[0]), ptr(keep[1]), C.c_int(Hl), C.c_int(W), ptr(keep[2]),
+                                         ptr(keep[3]), ptr(keep[4]), ptr(keep[5]), C.byref(self._h)))
+        L = lib()
+        L.lf_dist_graph_num_pixels.restype = C.c_int64
+        L.lf_dist_graph_state_size.restype = C.c_int64
+        L.lf_dist_graph_num_launch_units.restype = C.c_int64
+        L.lf_dist_graph_round_recv_slot.restype = C.c_int64
+        self.num_pixels = int(L.lf_dist_graph_num_pixels(self._h))
+        c = (C.c_int64 * 4)()
+        check(L.lf_dist_graph_counts(self._h, c))
+        self.n_export = (int(c[0]), int(c[1]))
+        self.n_ghost = (int(c[2]), int(c[3]))
+        self.finalized = False
+
+    # --- phase fixpoint ---------------------------------------------------------------------------
+    def export_phases(self):
+        t = np.zeros(self.n_export[0], np.int32)
+        b = np.zeros(self.n_export[1], np.int32)
+        check(lib().lf_dist_graph_get_export_phases(self._h, ptr(t), ptr(b)))
+        return t, b
+
+    def set_ghost_phases(self, top, bottom):
+        top = np.ascontiguousarray(top, dtype=np.int32)
+        bottom = np.ascontiguousarray(bottom, dtype=np.int32)
+        assert top.size == self.n_ghost[0] and bottom.size == self.n_ghost[1]
+        ch = C.c_int(0)
+        check(lib().lf_dist_graph_set_ghost_phases(self._h, ptr(top), ptr(bottom), C.byref(ch)))
+        return bool(ch.value)
+
+    def local_num_phases(self):
+        return int(lib().lf_dist_graph_local_num_phases(self._h))
+
+    def finalize(self, nphases):
+        check(lib().lf_dist_graph_finalize(self._h, C.c_int(nphases)))
+        self.finalized = True
+        self.num_phases = nphases
+        self.state_size = int(lib().lf_dist_graph_state_size(self._h))
+        self.num_launch_units = int(lib().lf_dist_graph_num_launch_units(self._h))
+
+    # --- plan getters -----------------------------------------------------------------------------
+    def layout(self):
+        perm = np.empty(self.num_pixels, np.int32)
+        ph = np.empty(self.num_pixels, np.int32)
+        check(lib().lf_dist_graph_get_layout(self._h, ptr(perm), ptr(ph)))
+        return perm, ph
+
+    def csr(self):
+        ne = C.c_int64(0)
+        check(lib().lf_dist_graph_get_csr(self._h, None, None, C.byref(ne)))
+        ups_ptr = np.empty(self.num_pixels + 1, np.int32)
+        ups_idx = np.empty(ne.value, np.int32)
+        check(lib().lf_dist_graph_get_csr(self._h, ptr(ups_ptr), ptr(ups_idx), C.byref(ne)))
+        return ups_ptr, ups_idx
+
+    def phase_range(self, phase):
+        o = (C.c_int64 * 2)()
+        check(lib().lf_dist_graph_phase_range(self._h, C.c_int(phase), o))
+        return int(o[0]), int(o[1])
+
+    def round_counts(self, rnd):
+        o = (C.c_int64 * 4)()
+        check(lib().lf_dist_graph_round_counts(self._h, C.c_int(rnd), o))
+        return dict(send=(int(o[0]), int(o[1])), recv=(int(o[2]), int(o[3])))
+
+    def round_send_positions(self, rnd, side):
+        n = self.round_counts(rnd)["send"][side]
+        pos = np.empty(n, np.int32)
+        check(lib().lf_dist_graph_round_send_positions(self._h, C.c_int(rnd), C.c_int(side), ptr(pos)))
+        return pos
+
+    def round_recv_slot(self, rnd, side):
+        return int(lib().lf_dist_graph_round_recv_slot(self._h, C.c_int(rnd), C.c_int(side)))
+
+    def close(self):
+        if self._h:
+            lib().lf_dist_graph_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def settle_phases(graph, transport):
+    """Distributed fixpoint of the phase numbers, then finalize with the global phase count."""
+    while True:
+        t, b = graph.export_phases()
+        gt, gb = transport.exchange_int32(t, b, graph.n_ghost[0], graph.n_ghost[1])
+        changed = graph.set_ghost_phases(gt, gb)
+        if not transport.allreduce_max(1 if changed else 0):
+            break
+    graph.finalize(transport.allreduce_max(graph.local_num_phases()))
+    return graph
+
+
+def settle_phases_local(graphs):
+    """Same fixpoint as settle_phases for blocks held in one process (rank k is graphs[k])."""
+    R = len(graphs)
+    while True:
+        exports = [g.export_phases() for g in graphs]
+        changed = False
+        for k, g in enumerate(graphs):
+            gt = exports[k - 1][1] if k > 0 else np.zeros(0, np.int32)       # my top ghosts = upper rank's bottom exports
+            gb = exports[k + 1][0] if k + 1 < R else np.zeros(0, np.int32)   # my bottom ghosts = lower rank's top exports
+            changed |= g.set_ghost_phases(gt, gb)
+        if not changed:
+            break
+    nph = max(g.local_num_phases() for g in graphs)
+    for g in graphs:
+        g.finalize(nph)
+    return nph
+
+
+class TorchTransport:
+    """torch.distributed transport for set-up (vertical neighbours = rank -/+ 1)."""
+
+    def __init__(self, dist):
+        self.dist = dist
+        self.rank, self.nranks = dist.get_rank(), dist.get_world_size()
+
+    def exchange_int32(self, top_send, bottom_send, n_top_recv, n_bottom_recv):
+        import torch
+        dist = self.dist
+        top_recv = torch.zeros(n_top_recv, dtype=torch.int32)
+        bot_recv = torch.zeros(n_bottom_recv, dtype=torch.int32)
+        ops = []
+        up, dn = self.rank - 1, self.rank + 1
+        # message sizes are known on both sides (export / ghost counts match by construction)
+        if up >= 0:
+            if len(top_send):
+                ops.append(dist.P2POp(dist.isend, torch.from_numpy(np.ascontiguousarray(top_send)), up))
+            if n_top_recv:
+                ops.append(dist.P2POp(dist.irecv, top_recv, up))
+        if dn < self.nranks:
+            if len(bottom_send):
+                ops.append(dist.P2POp(dist.isend, torch.from_numpy(np.ascontiguousarray(bottom_send)), dn))
+            if n_bottom_recv:
+                ops.append(dist.P2POp(dist.irecv, bot_recv, dn))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        return top_recv.numpy(), bot_recv.numpy()
+
+    def allreduce_max(self, value):
+        import torch
+        t = torch.tensor([int(value)], dtype=torch.int64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return int(t.item())
+
+
+class Comm:
+    """RCCL communicator; `unique_id()` on rank 0, broadcast the bytes, then Comm(id, nranks, rank, device)."""
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        check(lib().lf_comm_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, uid, nranks, rank, device):
+        self._h = C.c_void_p()
+        check(lib().lf_comm_create(C.c_char_p(uid), C.c_int(nranks), C.c_int(rank), C.c_int(device), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().lf_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+
+class DistRouter:
+    """One rank's share of a kinematicWave over the partitioned raster (device side)."""
+
+    def __init__(self, graph, alpha, beta, space_delta, time_delta, alpha_floodplains=None, device=0, comm=None,
+                 rank_top=-1, rank_bottom=-1):
+        assert graph.finalized
+        self.graph, self.device, self.comm = graph, device, comm
+        self.rank_top, self.rank_bottom = rank_top, rank_bottom
+        N = graph.num_pixels
+        self.num_pixels = N
+        alpha = f64(np.broadcast_to(alpha, (N,)))
+        if np.ndim(space_delta) == 0:
+            dx, dxs = None, float(space_delta)
+        else:
+            dx, dxs = f64(space_delta), 0.0
+        a2 = None if alpha_floodplains is None else f64(np.broadcast_to(alpha_floodplains, (N,)))
+        self._h = C.c_void_p()
+        check(lib().lf_dist_router_create(graph._h, ptr(alpha), C.c_double(beta), ptr(dx), C.c_double(dxs),
+                                          C.c_double(time_delta), ptr(a2), C.c_int(device), C.byref(self._h)))
+        lib().lf_dist_router_state_size.restype = C.c_int64
+        lib().lf_dist_router_last_launches.restype = C.c_int64
+        self.state_size = graph.state_size
+
+    def new_state(self, pix_values=None):
+        """Device state vector (local cells in engine order + ghost slots), optionally initialised from a
+        local-pixel-order host vector."""
+        st = DeviceArray(max(self.state_size, 1), np.float64, self.device).zero()
+        if pix_values is not None:
+            tmp = DeviceArray.from_host(f64(pix_values), self.device)
+            check(lib().lf_dist_router_to_engine_order(self._h, tmp.ptr, st.ptr))
+            _lib.synchronize(self.device)
+            tmp.free()
+        return st
+
+    def download_pix(self, state):
+        tmp = DeviceArray(max(self.num_pixels, 1), np.float64, self.device)
+        check(lib().lf_dist_router_from_engine_order(self._h, state.ptr, tmp.ptr))
+        out = tmp.download()[:self.num_pixels]
+        tmp.free()
+        return out
+
+    def route(self, q_state, lat_state, section="main_channel"):
+        sec = _lib.SECTION[section]
+        ch = self.comm._h if self.comm is not None else None
+        check(lib().lf_dist_router_route(self._h, ch, q_state.ptr, lat_state.ptr, C.c_int(sec), C.c_int(self.rank_top),
+                                         C.c_int(self.rank_bottom)))
+
+    # pieces, for the in-process loopback
+    def compute_phase(self, q_state, lat_state, phase, section="main_channel"):
+        check(lib().lf_dist_router_compute_phase(self._h, q_state.ptr, lat_state.ptr, C.c_int(_lib.SECTION[section]),
+                                                 C.c_int(phase)))
+
+    def pack(self, q_state, rnd):
+        ptrs = (C.c_void_p * 2)()
+        cnt = (C.c_int64 * 2)()
+        check(lib().lf_dist_router_pack(self._h, q_state.ptr, C.c_int(rnd), ptrs, cnt))
+        return [(ptrs[i], int(cnt[i])) for i in range(2)]
+
+    def recv_slots(self, rnd):
+        slot = (C.c_int64 * 2)()
+        cnt = (C.c_int64 * 2)()
+        check(lib().lf_dist_router_recv_slots(self._h, C.c_int(rnd), slot, cnt))
+        return [(int(slot[i]), int(cnt[i])) for i in range(2)]
+
+    def last_launches(self):
+        return int(lib().lf_dist_router_last_launches(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().lf_dist_router_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def loopback_route(routers, q_states, lat_states, section="main_channel"):
+    """One call over blocks that all live on ONE GPU in ONE process: the halo exchange is a device-to-device
+    copy instead of RCCL Send/Recv.  Exercises exactly the kernels and the plan of the multi-GPU path."""
+    R = len(routers)
+    nph = routers[0].graph.num_phases
+    dev = routers[0].device
+    for j in range(nph):
+        for k in range(R):
+            routers[k].compute_phase(q_states[k], lat_states[k], j, section)
+        if j + 1 < nph:
+            sends = [routers[k].pack(q_states[k], j) for k in range(R)]
+            for k in range(R):
+                slots = routers[k].recv_slots(j)
+                # side 0: from the rank above (its bottom send buffer); side 1: from the rank below (its top buffer)
+                for side, src_rank, src_side in ((0, k - 1, 1), (1, k + 1, 0)):
+                    slot, n = slots[side]
+                    if n == 0:
+                        continue
+                    sp, sn = sends[src_rank][src_side]
+                    assert sn == n, (k, j, side, sn, n)
+                    dst = C.c_void_p(q_states[k].ptr.value + 8 * slot)
+                    check(lib().lf_memcpy_d2d(C.c_int(dev), dst, C.c_void_p(sp), C.c_size_t(8 * n)))

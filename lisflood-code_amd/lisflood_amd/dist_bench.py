@@ -1,0 +1,100 @@
+"""bench.py's N > 1 leg: the raster is split into row blocks, one rank (process, GPU) per block, launched by
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+torch.distributed (gloo) is used for rendezvous, the set-up fixpoint, the barrier and the max-over-ranks
+time; the data path (halo exchange of boundary discharge every call) is RCCL Send/Recv over xGMI from
+csrc/lf_dist.hip.  Strong scaling: the raster (BASELINE.json: 10000 x 10000) is fixed, each rank owns H/N rows.
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+B_ALG = 48.0
+HBM_PEAK_GBS = 8000.0
+
+
+def log(rank, *a):
+    print("[bench rank %d]" % rank, *a, file=sys.stderr, flush=True)
+
+
+def main(a):
+    import torch
+    import torch.distributed as dist
+    from . import _lib
+    from . import dist as D
+    from . import synthetic as syn
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", str(a.gpus)))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ndev = _lib.device_count()
+    device = local_rank % max(ndev, 1)
+    t_setup = time.time()
+    H = W = a.size
+    seed = {"shallow": 1, "deep": 2}[a.family]
+    r0, r1 = D.row_blocks(H, world)[rank]
+    g0, g1 = max(0, r0 - 1), min(H, r1 + 1)
+    codes = syn.make_ldd(a.family, H, W, seed, r0=g0, r1=g1)
+    top = codes[0] if r0 > 0 else None
+    bot = codes[-1] if r1 < H else None
+    local = codes[(r0 - g0):(r0 - g0) + (r1 - r0)]
+    graph = D.DistGraph(local, None, top, None, bot, None)
+    D.settle_phases(graph, D.TorchTransport(dist))
+    uid = [D.Comm.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(uid, src=0)
+    comm = D.Comm(uid[0], world, rank, device)
+    N = H * W
+    i0, i1 = r0 * W, r1 * W
+    p = syn.router_params_slice(N, i0, i1)
+    router = D.DistRouter(graph, p["alpha"], p["beta"], p["dx"], p["dt"], device=device, comm=comm,
+                          rank_top=rank - 1 if rank > 0 else -1, rank_bottom=rank + 1 if rank + 1 < world else -1)
+    Q = router.new_state(p["Q0"])
+    nq = 3
+    qs = [router.new_state(syn.lateral_inflow_slice(N, s, i0, i1)) for s in range(nq)]
+    _lib.synchronize(device)
+    log(rank, "rows [%d,%d) cells=%d phases=%d launch_units=%d ghosts=%s exports=%s setup %.1f s"
+        % (r0, r1, graph.num_pixels, graph.num_phases, graph.num_launch_units, graph.n_ghost, graph.n_export,
+           time.time() - t_setup))
+    for s in range(a.warmup):
+        router.route(Q, qs[s % nq])
+    _lib.synchronize(device)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for s in range(a.steps):
+        router.route(Q, qs[s % nq])
+    _lib.synchronize(device)
+    dt_local = time.perf_counter() - t0
+    dist.barrier()
+    t = torch.tensor([dt_local], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt_max = float(t.item())
+    Qh = router.download_pix(Q)
+    chk = torch.tensor([float(Qh.sum()), float(np.isfinite(Qh).all() and (Qh >= 0).all())], dtype=torch.float64)
+    dist.all_reduce(chk, op=dist.ReduceOp.SUM)
+    launches = torch.tensor([router.last_launches()], dtype=torch.int64)
+    dist.all_reduce(launches, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        ms = dt_max * 1e3 / a.steps
+        value = N / ms / 1e3
+        out = {
+            "metric": "Mcell-steps/s kinematic routing", "value": round(value, 2), "unit": "Mcell-steps/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%dx%d fp64 raster, %s LDD (seed %d), all land, beta=0.6, 1 router call per step"
+                                   % (H, W, "random ('shallow')" if a.family == "shallow" else "sheet-flow ('deep')",
+                                      seed),
+                       "cells": N, "phases": graph.num_phases, "max_launches_per_step": int(launches.item()),
+                       "layout": "engine sweep order per rank, ghost slots appended",
+                       "parallelism": "row-block x%d, RCCL Send/Recv halo per phase" % world},
+            "hbm_frac_whole_step": round(B_ALG * N / (ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), 6),
+            "checksum_sumQ": float(chk[0].item()), "finite": bool(chk[1].item() == world),
+        }
+        print(json.dumps(out), flush=True)
+    dist.barrier()
+    comm.close()
+    dist.destroy_process_group()

@@ -150,6 +150,8 @@ class kinematicWave:
                 and discharge.size == self.num_pixels):
             raise ValueError("discharge must be a C-contiguous float64 vector of %d land pixels" % self.num_pixels)
         q = f64(np.broadcast_to(specific_lateral_inflow, (self.num_pixels,)))
+        if self.num_pixels == 0:
+            return
         check(lib().lf_router_route_host(self._h, ptr(discharge), ptr(q), C.c_int(sec)))
         if self.flagnancheck and not self.kinematic_wave_warning_printed:
             if not np.all(np.isfinite(discharge)):
@@ -194,6 +196,8 @@ class kinematicWave:
         """np.bincount(downstruct, weights)[:N] / PCRaster upstream(ldd, x) (routing.py:159-164, 387)."""
         w = f64(weights)
         out = np.empty(self.num_pixels)
+        if self.num_pixels == 0:
+            return out
         check(lib().lf_upstream_sum_host(self._h, ptr(w), ptr(out)))
         return out
 
@@ -201,6 +205,8 @@ class kinematicWave:
         """PCRaster accuflux(ldd, x): x accumulated over all upstream cells incl. the cell (routing.py:98)."""
         xv = f64(np.broadcast_to(x, (self.num_pixels,)))
         out = np.empty(self.num_pixels)
+        if self.num_pixels == 0:
+            return out
         check(lib().lf_accuflux_host(self._h, ptr(xv), ptr(out)))
         return out
 

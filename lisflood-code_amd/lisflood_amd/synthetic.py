@@ -4,6 +4,7 @@ LDD families (all acyclic by construction -- every cell drains to a strictly low
 potential phi, or is a pit):
   shallow : phi = U(0,1)                                   -> ~11 % pits, NL ~ 7-8 ("random LDD")
   deep    : phi = row-from-bottom + 0.25*col/W + 0.6*U(0,1) -> NL = H+2, ~W cells per level (sheet flow)
+  saddle  : like deep, but the right half of the raster drains upward (tests: flow crosses a row cut both ways)
 Codes follow the LISFLOOD/PCRaster keypad convention of the reference
 (kinematic_wave_parallel.py:49-51): index 0..7 <-> codes [2,3,6,9,8,7,4,1], 5 = pit, and the
 (row, col) shifts IX_ADDS.  Ties are resolved to the first minimum in IX_ADDS order.
@@ -42,6 +43,9 @@ def potential_rows(family, H, W, seed, r0, r1):
     cols = np.arange(W, dtype=np.float64)[None, :]
     if family == "deep":
         return rows_from_bottom + 0.25 * cols / W + 0.6 * u
+    if family == "saddle":   # left half drains to the bottom row, right half to the top row
+        tilt = np.where(cols < W / 2, rows_from_bottom, (H - 1) - rows_from_bottom)
+        return tilt + 0.25 * cols / W + 0.6 * u
     raise ValueError("unknown LDD family %r" % (family,))
 
 
@@ -90,6 +94,31 @@ def router_params(N, seed=3, beta=0.6, dt=3600.0):
 def lateral_inflow(N, step, seed=4, hi=2e-4):
     """specific lateral inflow q ~ U(0, 2e-4) [m3 s-1 m-1], redrawn each step (seed 4 + step)."""
     return np.random.default_rng(seed + step).uniform(0.0, hi, N)
+
+
+def _stream_slice(seed, offset, count):
+    """`count` uniform(0,1) doubles starting at element `offset` of default_rng(seed)'s stream (PCG64 jump-ahead:
+    one 64-bit draw per double), so a rank can draw exactly its slice of a global vector."""
+    bg = np.random.PCG64(seed)
+    bg.advance(int(offset))
+    return np.random.Generator(bg).random(int(count))
+
+
+def router_params_slice(N, i0, i1, seed=3, beta=0.6, dt=3600.0):
+    """Elements [i0, i1) of router_params(N, seed) without generating the rest."""
+    n = i1 - i0
+    u1, u2, u3 = (_stream_slice(seed, k * N + i0, n) for k in range(3))
+    la, lb = np.log(0.4), np.log(16.0)
+    alpha = np.exp(la + (lb - la) * u1)
+    dx = 500.0 + (15000.0 - 500.0) * u2
+    la0, lb0 = np.log(0.05), np.log(500.0)
+    a0 = np.exp(la0 + (lb0 - la0) * u3)
+    q0 = (a0 / alpha) ** (1.0 / beta)
+    return dict(alpha=alpha, dx=dx, Q0=q0, beta=beta, dt=dt)
+
+
+def lateral_inflow_slice(N, step, i0, i1, seed=4, hi=2e-4):
+    return 0.0 + (hi - 0.0) * _stream_slice(seed + step, i0, i1 - i0)
 
 
 def soil_params(N, V=3, L=3, seed=11, frozen_frac=0.1, zero_pore_frac=0.02):

@@ -231,3 +231,11 @@ class RoutingSubstep:
         v.FlowVelocity, v.TravelDistance = np.empty(N), np.empty(N)
         L.lfo_velocity(_ptr(v.ChanM3Kin), _ptr(v.ChanQKin), _ptr(_f(v.InvChanLength)), _ptr(_f(v.PixelArea)),
                        C.c_double(v.DtSec), n, _ptr(v.FlowVelocity), _ptr(v.TravelDistance))
+
+
+def sweep_positions(state, constant, ups_ptr, ups_idx, a, ba, beta, begin, end):
+    """solve1Pixel over positions [begin, end) of an indexed state vector (row-block plan tests)."""
+    assert state.dtype == np.float64 and state.flags.c_contiguous
+    lib().lfo_sweep_positions(_ptr(state), _ptr(_f(constant)), _ptr(np.ascontiguousarray(ups_ptr, dtype=np.int32)),
+                              _ptr(np.ascontiguousarray(ups_idx, dtype=np.int32)), _ptr(_f(a)), _ptr(_f(ba)),
+                              C.c_double(beta), C.c_int64(begin), C.c_int64(end))

@@ -307,6 +307,36 @@ def test_soil_columns_device_resident_vs_oracle(amd, oracle):
     assert (d2["Theta1a"][1] == 0).all()
 
 
+@pytest.mark.parametrize("family,seed,nblocks", [("shallow", 1, 3), ("deep", 2, 4), ("saddle", 6, 2)])
+def test_row_block_partition_loopback(amd, oracle, solver, family, seed, nblocks):
+    """The multi-GPU path on ONE GPU: nblocks row-block routers in this process, halo exchange by device copy
+    instead of RCCL.  Same kernels (indexed sweep, pack), same plan; must match the single-domain oracle."""
+    from lisflood_amd import dist as D
+    from lisflood_amd import synthetic as syn
+    H, W = 300, 260
+    codes = syn.make_ldd(family, H, W, seed)
+    mask = np.ones((H, W), bool)
+    N = H * W
+    p = syn.router_params(N, seed=5)
+    cpu = oracle.kinematicWave(codes.reshape(-1).astype(np.float64), mask, p["alpha"], p["beta"], p["dx"], p["dt"])
+    blocks = D.row_blocks(H, nblocks)
+    graphs = [D.DistGraph(codes[r0:r1], None, codes[r0 - 1] if r0 > 0 else None, None,
+                          codes[r1] if r1 < H else None, None) for (r0, r1) in blocks]
+    nph = D.settle_phases_local(graphs)
+    sl = [slice(r0 * W, r1 * W) for (r0, r1) in blocks]
+    routers = [D.DistRouter(g, p["alpha"][s], p["beta"], p["dx"][s], p["dt"]) for g, s in zip(graphs, sl)]
+    Qs = [r.new_state(p["Q0"][s]) for r, s in zip(routers, sl)]
+    Qc = p["Q0"].copy()
+    for step in range(3):
+        q = syn.lateral_inflow(N, step)
+        cpu.kinematicWaveRouting(Qc, q)
+        lats = [r.new_state(q[s]) for r, s in zip(routers, sl)]
+        D.loopback_route(routers, Qs, lats)
+        got = np.concatenate([r.download_pix(Q) for r, Q in zip(routers, Qs)])
+        close(got, Qc, (family, step))
+    assert nph >= (nblocks if family == "deep" else 2)
+
+
 def test_empty_inputs(amd):
     mask = np.zeros((3, 4), bool)
     kw = amd.kw.kinematicWave(np.zeros(0), mask, np.zeros(0), 0.6, 1000.0, 3600.0)
