@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads / soil kernel")
     ap.add_argument("--cpu-sample", type=int, default=2000, help="CPU baseline raster is sample x sample")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the row-block/RCCL path even with a single rank (smoke test of that path)")
     ap.add_argument("--calibrate", action="store_true",
                     help="run the known-traffic stream copies first (PMC calibration under rocprofv3)")
     return ap.parse_args()
@@ -196,7 +198,7 @@ def soil_bench(N=4_000_000, steps=10):
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if a.gpus > 1 or world > 1:
+    if a.gpus > 1 or world > 1 or a.force_dist:
         from lisflood_amd import dist_bench
         return dist_bench.main(a)
     H = W = a.size
