@@ -113,7 +113,26 @@ def run_routing(kw, p, steps, warmup, nq=3, profile_steps=2, ordered=True):
                 finite=ok, profile_steps=profile_steps)
 
 
-def roofline_of(res):
+def pmc_traffic(kernel_key, cells_per_launch):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC digest (separate --pmc
+    passes of this same command, FETCH_SIZE x2 / WRITE_SIZE x1 after calibration on a known-traffic copy;
+    tools/gpu_profile.sh -> profiles/*_digest.json).  None when no digest matches this workload."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_digest.json"))):
+        try:
+            d = json.load(open(f))["kernels"].get(kernel_key)
+        except Exception:
+            continue
+        if d and "hbm_read_bytes_per_launch" in d and abs(d.get("threads_per_launch", 0) / cells_per_launch - 1) < 0.01:
+            best = (f, d)
+    if not best:
+        return None, None
+    f, d = best
+    return d["hbm_read_bytes_per_launch"] + d["hbm_write_bytes_per_launch"], os.path.relpath(f, ROOT)
+
+
+def roofline_of(res, kernel_key=None):
     """Dominant sweep kernel: achieved algorithmic GB/s = 48 B x cells per launch / mean launch duration."""
     prof = res["prof"]
     wide, narrow = prof["wide_level"], prof["narrow_run"]
@@ -124,8 +143,10 @@ def roofline_of(res):
     cells_per_launch = dom["cells"] / dom["launches"]
     ms_per_launch = dom["ms"] / dom["launches"]
     achieved = B_ALG * cells_per_launch / (ms_per_launch * 1e-3) / 1e9
+    traffic, src = pmc_traffic(kernel_key, cells_per_launch) if kernel_key else (None, None)
     return dict(bound="hbm", kernel=name, achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit="GB/s",
-                frac=round(achieved / HBM_PEAK_GBS, 6), traffic=None,
+                frac=round(achieved / HBM_PEAK_GBS, 6), traffic=traffic, traffic_unit="bytes per launch",
+                traffic_source=src, alg_bytes_per_launch=B_ALG * cells_per_launch,
                 launches_per_step=int(round(dom["launches"] / max(res.get("profile_steps", 1), 1))),
                 mean_launch_us=round(ms_per_launch * 1e3, 3), cells_per_launch=round(cells_per_launch, 1),
                 alg_bytes_per_cell_step=B_ALG,
@@ -232,7 +253,7 @@ def main():
         "hbm_frac_whole_step": round(B_ALG * N / (res["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
         "finite": res["finite"],
     }
-    out["roofline"] = roofline_of(res)
+    out["roofline"] = roofline_of(res, "k_level[fused+ordered]")
     try:
         rp = run_routing(kw, p, max(3, a.steps // 3), 1, nq=2, profile_steps=1, ordered=False)
         out["pixel_order_call"] = dict(value=round(N / rp["ms_per_step"] / 1e3, 2), unit="Mcell-steps/s",

@@ -23,6 +23,12 @@ def find(d, pat):
 
 
 def short(name):
+    import re
+    m = re.search(r"(k_level|k_levels_narrow)<([^>]*)>", name)
+    if m:   # template flags: FUSED (beta=3/5 quintic), ORDERED (engine-order vectors), INDEXED (row-block partition)
+        f = [x.strip() == "true" for x in m.group(2).split(",")] + [False, False, False]
+        tag = ("fused" if f[0] else "general") + ("+ordered" if f[1] else "+pixel") + ("+indexed" if f[2] else "")
+        return "%s[%s]" % (m.group(1), tag)
     for k in ("k_calib_copy8", "k_calib_copy16", "k_prep", "k_levels_narrow", "k_level", "k_soil_columns", "k_interception", "k_substep",
               "k_halo", "k_gather", "k_scatter"):
         if k in name:
@@ -34,9 +40,9 @@ stats = find("prof_%s_kt" % tag, "*kernel_stats.csv")
 print("# rocprofv3 --kernel-trace --stats (%s)" % (stats or "missing"))
 if stats:
     rows = list(csv.DictReader(open(stats)))
-    print("%-22s %8s %14s %14s %8s" % ("kernel", "calls", "total_ms", "mean_us", "pct"))
+    print("%-34s %8s %14s %14s %8s" % ("kernel", "calls", "total_ms", "mean_us", "pct"))
     for r in rows:
-        print("%-22s %8s %14.3f %14.3f %8s" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
+        print("%-34s %8s %14.3f %14.3f %8s" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
                                                float(r["AverageNs"]) / 1e3, r.get("Percentage", "")))
 
 trace = find("prof_%s_kt" % tag, "*kernel_trace.csv")
@@ -48,7 +54,7 @@ if trace:
                                              int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0)))
     print("\n# per kernel from the trace: launches, mean us, mean grid (threads)")
     for k, v in per.items():
-        print("%-22s %8d %12.3f %14.1f" % (k, len(v), sum(d for d, _ in v) / len(v) / 1e3,
+        print("%-34s %8d %12.3f %14.1f" % (k, len(v), sum(d for d, _ in v) / len(v) / 1e3,
                                            sum(g for _, g in v) / len(v)))
         cells[k] = sum(g for _, g in v) / len(v)
 
@@ -71,14 +77,14 @@ def pmc(d, counter):
 fetch, write = pmc("fetch", "FETCH_SIZE"), pmc("write", "WRITE_SIZE")
 if fetch or write:
     print("\n# PMC (separate passes), per launch: KiB -> bytes; grid = threads per launch")
-    print("%-22s %8s %16s %16s %14s %12s %12s" % ("kernel", "launches", "FETCH_B/launch", "WRITE_B/launch",
+    print("%-34s %8s %16s %16s %14s %12s %12s" % ("kernel", "launches", "FETCH_B/launch", "WRITE_B/launch",
                                                    "grid", "fetch_B/thr", "write_B/thr"))
     for k in sorted(set(fetch) | set(write)):
         n = fetch.get(k, write.get(k))[0]
         fb = fetch[k][1] * 1024 / fetch[k][0] if k in fetch else float("nan")
         wb = write[k][1] * 1024 / write[k][0] if k in write else float("nan")
         g = (fetch.get(k) or write.get(k))[2] / n
-        print("%-22s %8d %16.0f %16.0f %14.0f %12.2f %12.2f" % (k, n, fb, wb, g, fb / max(g, 1), wb / max(g, 1)))
+        print("%-34s %8d %16.0f %16.0f %14.0f %12.2f %12.2f" % (k, n, fb, wb, g, fb / max(g, 1), wb / max(g, 1)))
     for cal in ("k_calib_copy8", "k_calib_copy16"):
         if cal in fetch and cal in write:
             g = fetch[cal][2] / fetch[cal][0]
@@ -91,5 +97,20 @@ if fetch or write:
                 fb = fetch[k][1] * 1024 / fetch[k][0] * cf
                 wb = write[k][1] * 1024 / write[k][0] * cw
                 g2 = fetch[k][2] / fetch[k][0]
-                print("%-22s corrected HBM bytes/launch: read %.4g + write %.4g = %.4g  (%.1f B per thread)"
+                print("%-34s corrected HBM bytes/launch: read %.4g + write %.4g = %.4g  (%.1f B per thread)"
                       % (k, fb, wb, fb + wb, (fb + wb) / max(g2, 1)))
+
+
+# machine-readable digest: per kernel, rocprof mean duration and PMC-corrected HBM bytes per launch
+import json
+digest = {"tag": tag, "fetch_correction": 2.0, "write_correction": 1.0, "kernels": {}}
+if stats:
+    for r in csv.DictReader(open(stats)):
+        digest["kernels"].setdefault(short(r["Name"]), {}).update(
+            calls=int(r["Calls"]), mean_us=float(r["AverageNs"]) / 1e3)
+for k in set(fetch) & set(write):
+    d = digest["kernels"].setdefault(k, {})
+    d["hbm_read_bytes_per_launch"] = fetch[k][1] * 1024 / fetch[k][0] * 2.0
+    d["hbm_write_bytes_per_launch"] = write[k][1] * 1024 / write[k][0] * 1.0
+    d["threads_per_launch"] = fetch[k][2] / fetch[k][0]
+json.dump(digest, open(os.path.join(out, "prof_%s_digest.json" % tag), "w"), indent=1, sort_keys=True)
