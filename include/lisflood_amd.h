@@ -53,9 +53,9 @@ typedef struct lf_comm lf_comm;               /* RCCL communicator (one rank per
 
 const char *lf_last_error(void);
 int lf_version(void);
-/* sizeof(lf_substep_args), sizeof(lf_interception_args), sizeof(lf_soil_args): lets a binding verify
- * its struct mirrors. */
-int lf_struct_sizes(int64_t out[3]);
+/* sizeof(lf_substep_args), sizeof(lf_interception_args), sizeof(lf_soil_args), sizeof(lf_canopy_args),
+ * sizeof(lf_surface_args): lets a binding verify its struct mirrors. */
+int lf_struct_sizes(int64_t out[5]);
 
 /* ---------------------------------------------------------------------------------------------
  * device plumbing
@@ -109,6 +109,8 @@ int lf_graph_get_layout(const lf_graph *g, int32_t *perm, int32_t *ups_ptr, int6
 int lf_router_create(const lf_graph *g, const double *alpha, double beta, const double *dx, double dx_scalar,
                      double dt, const double *alpha_floodplains, int device, lf_router **out);
 void lf_router_destroy(lf_router *r);
+int lf_router_device(const lf_router *r);
+int64_t lf_router_num_pixels(const lf_router *r);
 /* kinematicWaveRouting(discharge, specific_lateral_inflow, section): discharge[N] is updated in place.
  * Host-buffer form (PCIe-inclusive): H2D, route, D2H. */
 int lf_router_route_host(lf_router *r, double *discharge_host, const double *lateral_host, int section);
@@ -207,6 +209,51 @@ typedef struct lf_soil_args {
     double DtDay, AvWaterThreshold, CourantCrit, DrainedFraction;
     int64_t V, L, N;
 } lf_soil_args;
+
+/* dynamic_canopy (soilloop.py:519-627) for the three prescribed vegetation fractions: TaInterceptionMax,
+ * interception kernel, potential transpiration, water-stress reduction, abstraction of transpiration from
+ * layers 1a/1b.  [V,N] / [L,N] C-order; index_landuse[V] (host) maps each vegetation row to its land-use row
+ * (the reference indexes W1/W1a/W1b by the land-use row there, soilloop.py:592-627 -- reproduced). */
+typedef struct lf_canopy_args {
+    /* [V,N] in/out */
+    double *Interception, *TaInterception, *LeafDrainage, *CumInterception;
+    double *potential_transpiration, *RWS, *Ta;
+    double *W1a, *W1b, *W1;
+    /* [V,N] in */
+    const double *LAI, *LAITerm;
+    /* [L,N] in */
+    const double *CropCoef, *CropGroupNumber, *WFC1, *WFC1a, *WFC1b, *WWP1, *WWP1a, *WWP1b;
+    /* [N] in */
+    const double *Rain, *EWRef, *ETRef;
+    const uint8_t *isFrozenSoil;
+    const int64_t *index_landuse; /* [V], host */
+    double LeafDrainageK, DtDay, InvDtDay;
+    int64_t V, L, N;
+} lf_canopy_args;
+int lf_canopy_device(int device, const lf_canopy_args *a);
+/* out[v,p] = row[p] * m[v,p]  (ESMax = ESRef * LAITerm, soilloop.py:638) */
+int lf_scale_rows_device(int device, const double *row_dev, const double *m_dev, double *out_dev, int64_t V, int64_t N);
+
+/* surface_routing.dynamic (surface_routing.py:115-212), prescribed fractions (V = L = 3, rows Rainfed /
+ * Forest / Irrigated), all vectors device memory in pixel order.  Three routers share one graph. */
+typedef struct lf_surface_args {
+    /* [3,N] in */
+    const double *SoilFraction, *AvailableWaterForInfiltration, *Infiltration, *OFAlpha; /* OFAlpha rows: Other, Forest, Direct */
+    /* [N] in */
+    const double *DirectRunoff, *UZOutflowPixel, *LZOutflowToChannelPixel;
+    const uint8_t *IsChannel;
+    /* [N] state, in/out */
+    double *OFQDirect, *OFQOther, *OFQForest;
+    /* [N] out */
+    double *OFM3Direct, *OFM3Other, *OFM3Forest, *SurfaceRunoff, *TotalRunoff, *OFToChanM3, *WaterDepth, *ToChanM3Runoff,
+        *ToChanM3RunoffDt;
+    double *SurfaceRunSoil; /* [3,N] out */
+    double *scratch;        /* [3,N] */
+    double Beta, MMtoM3, M3toMM, PixelLength, InvPixelLength, DtSec, InvDtSec, InvNoRoutSteps;
+    int64_t N;
+} lf_surface_args;
+int lf_surface_step(lf_router *direct_router, lf_router *other_router, lf_router *forest_router,
+                    const lf_surface_args *a);
 
 /* host-buffer forms (drop-in for the numba kernels; PCIe-inclusive) */
 int lf_interception_host(int device, const lf_interception_args *a);

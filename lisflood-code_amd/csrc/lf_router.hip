@@ -410,6 +410,9 @@ int lf_count_nonfinite(int device, const double *x_dev, int64_t n, int64_t *coun
     return LF_OK;
 }
 
+int lf_router_device(const lf_router *r) { return r ? r->device : -1; }
+int64_t lf_router_num_pixels(const lf_router *r) { return r ? r->N : -1; }
+
 int lf_router_last_launches(const lf_router *r, int64_t stats[4])
 {
     if (!r || !stats) return lf_set_error(LF_E_INVALID, "null argument");

@@ -145,3 +145,108 @@ class SoilColumnsDevice:
 
     def set(self, name, value):
         self.dev[name].upload(u8(value) if name in _BOOL else f64(value))
+
+
+# =================================================================================================
+# Module class: soilloop(HydroModule) -- same shape as the reference class (soilloop.py:438-722)
+# =================================================================================================
+from .hydro_module import HydroModule  # noqa: E402
+
+_CANOPY_IO = "Interception TaInterception LeafDrainage CumInterception potential_transpiration RWS Ta W1a W1b W1".split()
+_CANOPY_V_IN = "LAI LAITerm".split()
+_CANOPY_L_IN = "CropCoef CropGroupNumber WFC1 WFC1a WFC1b WWP1 WWP1a WWP1b".split()
+_CANOPY_N_IN = "Rain EWRef ETRef isFrozenSoil".split()
+
+
+class _CanopyArgs(C.Structure):  # lf_canopy_args
+    _fields_ = ([(k, C.c_void_p) for k in _CANOPY_IO + _CANOPY_V_IN + _CANOPY_L_IN + _CANOPY_N_IN] +
+                [("index_landuse", C.c_void_p), ("LeafDrainageK", C.c_double), ("DtDay", C.c_double),
+                 ("InvDtDay", C.c_double), ("V", C.c_int64), ("L", C.c_int64), ("N", C.c_int64)])
+
+
+def _values(x):
+    """`.values` of the reference's NumpyModified / xarray containers, or the array itself."""
+    return np.asarray(getattr(x, "values", x))
+
+
+class soilloop(HydroModule):
+    """Soil/vegetation loop for the three prescribed fractions.  `dynamic_canopy()` and `dynamic_soil()` read and
+    write the same `var` attributes as the reference methods; each is one device pass.
+    Option-gated extras of the reference that need other modules are not produced here: `cropsEPIC` rows (the
+    EPIC module is not part of the reference checkout), `SoilMoistureStressDays` (repStressDays), `WFilla/WFillb`
+    (wateruse) and `pF*` (simulatePF)."""
+    input_files_keys = {'wateruse': []}
+    module_name = 'SoilLoop'
+
+    def __init__(self, soilloop_variable, device=0):
+        self.var = soilloop_variable
+        self.device = device
+
+    def initial(self):
+        v = self.var
+        # soilloop.py:462-472
+        self.index_landuse_all = np.array([v.SOIL_USES.index(v.VEGETATION_LANDUSE[x]) for x in v.vegetation], np.int64)
+        self.index_landuse_prescr = np.array([v.SOIL_USES.index(v.VEGETATION_LANDUSE[x])
+                                              for x in v.PRESCRIBED_VEGETATION], np.int64)
+        self.is_irrigated = np.array([v.VEGETATION_LANDUSE[x] == 'Irrigated' for x in v.vegetation])
+        self.is_paddy_irrig = np.zeros(len(v.vegetation), bool)
+        if list(v.vegetation) != list(v.prescribed_vegetation):
+            raise NotImplementedError("only the prescribed vegetation fractions are supported (no EPIC crops)")
+
+    def _inplace_rows(self, name):
+        a = _values(getattr(self.var, name))
+        return _inplace(a, name)
+
+    def dynamic_canopy(self):
+        v = self.var
+        a = _CanopyArgs()
+        dev, host = {}, {}
+        V, N = _values(v.Interception).shape
+        for k in _CANOPY_IO:
+            host[k] = self._inplace_rows(k)
+            dev[k] = DeviceArray.from_host(host[k], self.device)
+        for k in _CANOPY_V_IN + _CANOPY_L_IN:
+            dev[k] = DeviceArray.from_host(f64(_values(getattr(v, k))), self.device)
+        for k in _CANOPY_N_IN:
+            x = _values(getattr(v, k))
+            dev[k] = DeviceArray.from_host(u8(x) if k == "isFrozenSoil" else f64(np.broadcast_to(x, (N,))), self.device)
+        for k, d in dev.items():
+            setattr(a, k, d.ptr.value)
+        idx = np.ascontiguousarray(self.index_landuse_prescr, dtype=np.int64)
+        a.index_landuse = idx.ctypes.data
+        a.LeafDrainageK, a.DtDay, a.InvDtDay = float(v.LeafDrainageK), float(v.DtDay), float(v.InvDtDay)
+        a.V, a.L, a.N = V, _values(v.WFC1).shape[0], N
+        check(lib().lf_canopy_device(C.c_int(self.device), C.byref(a)))
+        for k in _CANOPY_IO:
+            dev[k].download(host[k])
+        for d in dev.values():
+            d.free()
+
+    def dynamic_soil(self):
+        v = self.var
+        N = _values(v.Interception).shape[1]
+        # ESMax = ESRef * LAITerm (soilloop.py:638)
+        es = DeviceArray.from_host(f64(np.broadcast_to(_values(v.ESRef), (N,))), self.device)
+        lt = DeviceArray.from_host(f64(_values(v.LAITerm)), self.device)
+        V = _values(v.LAITerm).shape[0]
+        out = DeviceArray((V, N), np.float64, self.device)
+        check(lib().lf_scale_rows_device(C.c_int(self.device), es.ptr, lt.ptr, out.ptr, C.c_int64(V), C.c_int64(N)))
+        ESMax = out.download()
+        for d in (es, lt, out):
+            d.free()
+        paddy_inactive = np.zeros(N, bool)[None]           # soilloop.py:644
+        g = lambda k: _values(getattr(v, k))
+        soilColumnsWaterBalance(
+            self.index_landuse_all, self.is_irrigated, self.is_paddy_irrig, paddy_inactive, v.DtDay,
+            g("AvailableWaterForInfiltration"), g("Rain"), g("SnowMelt"), g("LeafDrainage"), g("Interception"),
+            g("DSLR"), v.AvWaterThreshold, g("ESAct"), ESMax, g("isFrozenSoil"), g("b_Xinanjiang"),
+            g("StoreMaxPervious"), g("PowerInfPot"), g("PrefFlow"), g("PowerPrefFlow"), g("Infiltration"),
+            v.CourantCrit, g("PoreSpaceNotZero1a"), g("PoreSpaceNotZero1b"), g("PoreSpaceNotZero2"),
+            g("KSat1a"), g("KSat1b"), g("KSat2"), g("GenuInvM1a"), g("GenuInvM1b"), g("GenuInvM2"),
+            g("GenuM1a"), g("GenuM1b"), g("GenuM2"), g("W1a"), g("W1b"), g("W1"), g("W2"),
+            g("Theta1a"), g("Theta1b"), g("Theta2"), g("Sat1a"), g("Sat1b"), g("Sat1"), g("Sat2"),
+            g("SeepTopToSubA"), g("SeepTopToSubB"), g("SeepSubToGW"),
+            g("WRes1a"), g("WRes1b"), g("WRes1"), g("WRes2"), g("WWP1a"), g("WWP1b"), g("WWP1"), g("WWP2"),
+            g("WFC1a"), g("WFC1b"), g("WFC1"), g("WFC2"), g("SoilDepth1a"), g("SoilDepth1b"), g("SoilDepth2"),
+            g("WS1a"), g("WS1b"), g("WS1"), g("WS2"), g("UpperZoneK"), v.DrainedFraction, g("GwPercStep"),
+            g("UZOutflow"), g("UZ"), g("GwPercUZLZ"), device=self.device)

@@ -360,9 +360,185 @@ def gen_soil_columns():
     save("soil_columns", rains=np.array(rains), **{"in_" + k: v for k, v in before.items()}, **outs)
 
 
+# ------------------------------------------------------------------------------------------------
+# module level: surface_routing.dynamic (a13), soilloop.dynamic_canopy / dynamic_soil (a17, a18)
+# ------------------------------------------------------------------------------------------------
+class VA(np.ndarray):
+    """ndarray with the three things the modules use of NumpyModified / xarray (add1.py:48-61)."""
+    def __new__(cls, a, dims):
+        o = np.asarray(a).view(cls)
+        o.dims = list(dims)
+        return o
+
+    def __array_finalize__(self, obj):
+        self.dims = getattr(obj, "dims", None)
+
+    @property
+    def values(self):
+        return self.view(np.ndarray)
+
+    def sel(self, **kw):
+        return self
+
+
+SOIL_USES = ["Rainfed", "Forest", "Irrigated"]
+PRESCRIBED = [u + "_prescribed" for u in SOIL_USES]
+
+
+def model_var(N):
+    """The slice of LisfloodModel_ini (Lisflood_initial.py:108-113, 272-345) the module methods touch."""
+    from collections import OrderedDict
+    v = types.SimpleNamespace()
+    v.SOIL_USES = SOIL_USES[:]
+    v.PRESCRIBED_VEGETATION = PRESCRIBED[:]
+    v.vegetation = PRESCRIBED[:]
+    v.prescribed_vegetation = PRESCRIBED[:]
+    v.VEGETATION_LANDUSE = OrderedDict(zip(PRESCRIBED, SOIL_USES))
+    v.LANDUSE_VEGETATION = OrderedDict([(u, [p]) for p, u in zip(PRESCRIBED, SOIL_USES)])
+    v.epic_settings = types.SimpleNamespace(soil_uses=SOIL_USES[:], vegetation_landuse=dict(zip(PRESCRIBED, SOIL_USES)))
+    v.num_pixel = N
+    v.dim_pixel = ("pixel", np.arange(N))
+    v.dim_landuse = ("landuse", SOIL_USES[:])
+    v.dim_vegetation = ("vegetation", PRESCRIBED[:])
+    v.dim_runoff = ("runoff", ["Other", "Forest", "Direct"])
+
+    def allocateDataArray(dimensions, dtype=float):
+        coords = OrderedDict(dimensions)
+        return VA(np.zeros([len(c) for c in coords.values()], dtype), coords.keys())
+    v.allocateDataArray = allocateDataArray
+    v.get_landuse_and_indexes_from_vegetation_epic = lambda veg: (
+        v.vegetation.index(veg), SOIL_USES.index(v.epic_settings.vegetation_landuse[veg]),
+        v.epic_settings.vegetation_landuse[veg])
+
+    def idx(landuse, veg_list):
+        return ([v.vegetation.index(x) for x in veg_list], [PRESCRIBED.index(x) for x in veg_list],
+                SOIL_USES.index(landuse))
+    v.get_indexes_from_landuse_and_veg_list_GLOBAL = idx
+    return v
+
+
+def gen_surface_step():
+    surf = REF["surface"]
+    H, W = 18, 24
+    rng = np.random.default_rng(41)
+    mask = np.ones((H, W), bool); mask[:3, :4] = False
+    ldd = syn.make_ldd("deep", H, W, 13, land_mask=mask)
+    is_channel = (rng.random((H, W)) < 0.3) & mask
+    N = int(mask.sum())
+    # LddToChan = lddrepair(ifthenelse(IsChannel, 5, Ldd)) (routing.py:125): channel pixels become pits
+    ldd_to_chan = np.where(is_channel, 5, ldd).astype(np.uint8)
+    v = model_var(N)
+    beta = 0.6
+    v.Beta, v.InvBeta = beta, 1 / beta
+    v.PixelLength, v.DtSec = 5000.0, 86400.0
+    v.InvPixelLength, v.InvDtSec = 1 / v.PixelLength, 1 / v.DtSec
+    v.PixelArea = 2.5e7
+    v.MMtoM3, v.M3toMM = 0.001 * v.PixelArea, 1 / (0.001 * v.PixelArea)
+    v.NoRoutSteps = 24
+    v.InvNoRoutSteps = 1 / 24.0
+    v.IsChannel = is_channel[mask]
+    grad = rng.uniform(0.001, 0.2, N)
+    nman = np.stack([rng.uniform(0.05, 0.2, N), rng.uniform(0.2, 0.5, N), rng.uniform(0.01, 0.05, N)])
+    perim = v.PixelLength + 2 * 0.001 * 5.0
+    v.OFAlpha = VA(((nman / np.sqrt(grad)) ** beta) * (perim ** (2.0 / 3.0 * beta)), ["runoff", "pixel"])   # :77-83
+    frac = rng.dirichlet([3, 2, 1], N).T * rng.uniform(0.5, 1.0, N)
+    v.SoilFraction = VA(frac, ["vegetation", "pixel"])
+    v.OFQDirect = rng.uniform(0, 0.5, N); v.OFQOther = rng.uniform(0, 0.5, N); v.OFQForest = rng.uniform(0, 0.2, N)
+    m = surf.surface_routing(v)
+    codes = ldd_to_chan[mask].astype(np.float64)
+    mk = lambda i: kwp.kinematicWave(codes.copy(), mask.copy(), v.OFAlpha.values[i], beta, v.PixelLength, v.DtSec)
+    m.other_surface_router, m.forest_surface_router, m.direct_surface_router = mk(0), mk(1), mk(2)
+    init = dict(OFQDirect=v.OFQDirect.copy(), OFQOther=v.OFQOther.copy(), OFQForest=v.OFQForest.copy())
+    ins, outs = {}, {}
+    out_keys = ("OFQDirect", "OFQOther", "OFQForest", "OFM3Direct", "OFM3Other", "OFM3Forest", "SurfaceRunoff",
+                "TotalRunoff", "OFToChanM3", "WaterDepth", "ToChanM3Runoff", "ToChanM3RunoffDt")
+    for s in range(2):
+        step_in = dict(
+            AvailableWaterForInfiltration=rng.uniform(0, 20, (3, N)) * (rng.random((3, N)) < 0.7),
+            Infiltration=rng.uniform(0, 15, (3, N)), DirectRunoff=rng.uniform(0, 5, N) * (rng.random(N) < 0.5),
+            UZOutflowPixel=rng.uniform(0, 1, N), LZOutflowToChannelPixel=rng.uniform(0, 0.5, N))
+        for k, a in step_in.items():
+            setattr(v, k, VA(a, ["vegetation", "pixel"]) if a.ndim == 2 else a)
+            ins["in%d_%s" % (s, k)] = a
+        m.dynamic()
+        for k in out_keys:
+            outs["out%d_%s" % (s, k)] = np.array(getattr(v, k), dtype=np.float64)
+    save("surface_step", mask=mask, ldd_to_chan=codes, IsChannel=v.IsChannel, OFAlpha=v.OFAlpha.values,
+         SoilFraction=frac, Beta=beta, PixelLength=v.PixelLength, DtSec=v.DtSec, PixelArea=v.PixelArea,
+         NoRoutSteps=24, **{"init_" + k: a for k, a in init.items()}, **ins, **outs)
+
+
+def gen_canopy_soil_step():
+    soil = REF["soilloop"]
+    N = 600
+    rng = np.random.default_rng(51)
+    p = syn.soil_params(N, seed=52)
+    v = model_var(N)
+    REF["MaskInfo"].n = N
+    REF["LisSettings"].options.clear()
+    REF["LisSettings"].soil_uses = SOIL_USES[:]
+    REF["LisSettings"].vegetation_landuse = dict(zip(PRESCRIBED, SOIL_USES))
+    vn, ln = ["vegetation", "pixel"], ["landuse", "pixel"]
+    L_KEYS = [k for k in syn.SOIL_ARG_ORDER if np.ndim(p[k]) == 2 and k not in syn.SOIL_WRITTEN and
+              k not in ("LeafDrainage", "Interception", "ESMax", "paddy_inactive")]
+    for k in L_KEYS:
+        setattr(v, k, VA(p[k].copy(), ln))
+    for k in syn.SOIL_WRITTEN + ["LeafDrainage", "Interception"]:
+        setattr(v, k, VA(p[k].copy(), vn))
+    for k in ("Rain", "SnowMelt", "isFrozenSoil", "b_Xinanjiang", "PowerInfPot", "PowerPrefFlow", "UpperZoneK",
+              "GwPercStep"):
+        setattr(v, k, p[k].copy())
+    for k in ("DtDay", "AvWaterThreshold", "CourantCrit", "DrainedFraction"):
+        setattr(v, k, p[k])
+    v.InvDtDay = 1 / v.DtDay
+    ip = syn.interception_params(N, seed=53)
+    v.LAI = VA(ip["LAI"], vn)
+    v.CumInterception = VA(ip["CumInterception"], vn)
+    v.TaInterception = VA(np.zeros((3, N)), vn)
+    v.LAITerm = VA(np.exp(-0.5 * ip["LAI"]), vn)
+    v.LeafDrainageK = 0.25
+    v.EWRef, v.ETRef, v.ESRef = rng.uniform(0, 6, N), rng.uniform(0, 5, N), rng.uniform(0, 4, N)
+    v.CropCoef = VA(rng.uniform(0.6, 1.2, (3, N)), ln)
+    v.CropGroupNumber = VA(np.stack([rng.uniform(1, 5, N), rng.uniform(1, 5, N), np.full(N, 2.0)]), ln)
+    v.WPF3a = VA(p["WWP1a"] + 0.6 * (p["WFC1a"] - p["WWP1a"]), ln)
+    v.WPF3b = VA(p["WWP1b"] + 0.6 * (p["WFC1b"] - p["WWP1b"]), ln)
+    v.potential_transpiration = VA(np.zeros((3, N)), vn)
+    v.RWS = VA(np.zeros((3, N)), vn)
+    v.Ta = VA(np.zeros((3, N)), vn)
+    v.SoilMoistureStressDays = VA(np.zeros((3, N)), vn)
+    m = soil.soilloop(v)
+    m.initial()
+    state_keys = ["Interception", "TaInterception", "LeafDrainage", "CumInterception", "potential_transpiration",
+                  "RWS", "Ta"] + syn.SOIL_WRITTEN
+    before = {k: np.array(getattr(v, k)).copy() for k in state_keys}
+    static = {k: np.array(getattr(v, k)).copy() for k in L_KEYS + ["LAI", "LAITerm", "CropCoef", "CropGroupNumber",
+                                                                    "WPF3a", "WPF3b", "SnowMelt", "isFrozenSoil",
+                                                                    "b_Xinanjiang", "PowerInfPot", "PowerPrefFlow",
+                                                                    "UpperZoneK", "GwPercStep"]}
+    forc, outs = {}, {}
+    with np.errstate(all="ignore"):
+        for s in range(2):
+            v.Rain = rng.uniform(0, 25, N) * (rng.random(N) < 0.6)
+            v.EWRef, v.ETRef, v.ESRef = rng.uniform(0, 6, N), rng.uniform(0, 5, N), rng.uniform(0, 4, N)
+            for k in ("Rain", "EWRef", "ETRef", "ESRef"):
+                forc["forc%d_%s" % (s, k)] = getattr(v, k).copy()
+            m.dynamic_canopy()
+            for k in ("Interception", "TaInterception", "LeafDrainage", "CumInterception", "potential_transpiration",
+                      "RWS", "Ta", "W1a", "W1b", "W1"):
+                outs["canopy%d_%s" % (s, k)] = np.array(getattr(v, k)).copy()
+            m.dynamic_soil()
+            for k in syn.SOIL_WRITTEN:
+                outs["soil%d_%s" % (s, k)] = np.array(getattr(v, k)).copy()
+    save("canopy_soil_step", LeafDrainageK=v.LeafDrainageK, DtDay=v.DtDay, AvWaterThreshold=v.AvWaterThreshold,
+         CourantCrit=v.CourantCrit, DrainedFraction=v.DrainedFraction,
+         **{"init_" + k: a for k, a in before.items()}, **{"static_" + k: a for k, a in static.items()}, **forc, **outs)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["graphs", "routes", "edge", "substeps", "upsum", "interception", "soil"]
+    which = sys.argv[1:] or ["graphs", "routes", "edge", "substeps", "upsum", "interception", "soil", "surface",
+                             "canopy"]
     fns = dict(graphs=gen_graphs, routes=gen_routes, edge=gen_route_edge, substeps=gen_substeps,
-               upsum=gen_upstream_sum, interception=gen_interception, soil=gen_soil_columns)
+               upsum=gen_upstream_sum, interception=gen_interception, soil=gen_soil_columns,
+               surface=gen_surface_step, canopy=gen_canopy_soil_step)
     for w in which:
         fns[w]()

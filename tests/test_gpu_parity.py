@@ -337,6 +337,79 @@ def test_row_block_partition_loopback(amd, oracle, solver, family, seed, nblocks
     assert nph >= (nblocks if family == "deep" else 2)
 
 
+def _model_var(N):
+    """The slice of LisfloodModel_ini (Lisflood_initial.py:108-113, 272-345) the module classes read."""
+    from collections import OrderedDict
+    uses = ["Rainfed", "Forest", "Irrigated"]
+    pres = [u + "_prescribed" for u in uses]
+    v = types.SimpleNamespace()
+    v.SOIL_USES, v.PRESCRIBED_VEGETATION, v.vegetation, v.prescribed_vegetation = uses, pres, pres[:], pres[:]
+    v.VEGETATION_LANDUSE = OrderedDict(zip(pres, uses))
+    v.LANDUSE_VEGETATION = OrderedDict([(u, [p]) for p, u in zip(pres, uses)])
+    v.dim_pixel, v.dim_landuse = ("pixel", np.arange(N)), ("landuse", uses)
+    v.dim_runoff = ("runoff", ["Other", "Forest", "Direct"])
+    return v
+
+
+def test_surface_routing_module_golden(amd, solver):
+    """surface_routing.dynamic() (surface_routing.py:115-212) against vectors captured from the reference's own
+    module method on an 18 x 24 LDD with 30 % channel pixels (overland routing between cells is exercised)."""
+    from lisflood_amd.surface_routing import surface_routing
+    g = golden("surface_step")
+    N = int(g["mask"].sum())
+    v = _model_var(N)
+    v.Beta = float(g["Beta"]); v.InvBeta = 1 / v.Beta
+    v.PixelLength, v.DtSec = float(g["PixelLength"]), float(g["DtSec"])
+    v.InvPixelLength, v.InvDtSec = 1 / v.PixelLength, 1 / v.DtSec
+    v.MMtoM3 = 0.001 * float(g["PixelArea"]); v.M3toMM = 1 / v.MMtoM3
+    v.InvNoRoutSteps = 1 / float(g["NoRoutSteps"])
+    v.IsChannel, v.OFAlpha, v.SoilFraction = g["IsChannel"], g["OFAlpha"], g["SoilFraction"]
+    for k in ("OFQDirect", "OFQOther", "OFQForest"):
+        setattr(v, k, g["init_" + k].copy())
+    m = surface_routing(v)
+    m.initialSecond(g["ldd_to_chan"], g["mask"])
+    keys = ("OFQDirect", "OFQOther", "OFQForest", "OFM3Direct", "OFM3Other", "OFM3Forest", "SurfaceRunoff",
+            "TotalRunoff", "OFToChanM3", "WaterDepth", "ToChanM3Runoff", "ToChanM3RunoffDt")
+    for s in range(2):
+        for k in ("AvailableWaterForInfiltration", "Infiltration", "DirectRunoff", "UZOutflowPixel",
+                  "LZOutflowToChannelPixel"):
+            setattr(v, k, g["in%d_%s" % (s, k)])
+        m.dynamic()
+        for k in keys:
+            close(getattr(v, k), g["out%d_%s" % (s, k)], (s, k))
+
+
+def test_soilloop_module_golden(amd):
+    """soilloop.dynamic_canopy() + dynamic_soil() (soilloop.py:519-704) against vectors captured from the
+    reference's own class methods, two consecutive steps."""
+    from lisflood_amd import synthetic as syn
+    from lisflood_amd.soilloop import soilloop
+    g = golden("canopy_soil_step")
+    N = g["init_W1a"].shape[1]
+    v = _model_var(N)
+    for k in g.files:
+        if k.startswith("static_"):
+            setattr(v, k[7:], g[k].copy())
+        elif k.startswith("init_"):
+            setattr(v, k[5:], g[k].copy())
+    v.LeafDrainageK, v.DtDay = float(g["LeafDrainageK"]), float(g["DtDay"])
+    v.InvDtDay = 1 / v.DtDay
+    v.AvWaterThreshold, v.CourantCrit, v.DrainedFraction = (float(g["AvWaterThreshold"]), float(g["CourantCrit"]),
+                                                           float(g["DrainedFraction"]))
+    m = soilloop(v)
+    m.initial()
+    for s in range(2):
+        for k in ("Rain", "EWRef", "ETRef", "ESRef"):
+            setattr(v, k, g["forc%d_%s" % (s, k)])
+        m.dynamic_canopy()
+        for k in ("Interception", "TaInterception", "LeafDrainage", "CumInterception", "potential_transpiration",
+                  "RWS", "Ta", "W1a", "W1b", "W1"):
+            np.testing.assert_allclose(getattr(v, k), g["canopy%d_%s" % (s, k)], rtol=1e-9, atol=1e-11, err_msg=(s, k))
+        m.dynamic_soil()
+        for k in syn.SOIL_WRITTEN:
+            np.testing.assert_allclose(getattr(v, k), g["soil%d_%s" % (s, k)], rtol=1e-9, atol=1e-11, err_msg=(s, k))
+
+
 def test_empty_inputs(amd):
     mask = np.zeros((3, 4), bool)
     kw = amd.kw.kinematicWave(np.zeros(0), mask, np.zeros(0), 0.6, 1000.0, 3600.0)
