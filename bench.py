@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads / soil kernel")
     ap.add_argument("--cpu-sample", type=int, default=2000, help="CPU baseline raster is sample x sample")
+    ap.add_argument("--only", choices=["soil"], default=None, help="run only the named secondary benchmark")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the row-block/RCCL path even with a single rank (smoke test of that path)")
     ap.add_argument("--calibrate", action="store_true",
@@ -211,9 +212,12 @@ def soil_bench(N=4_000_000, steps=10):
     ms = _lib.timer_stop() / steps
     cols = 3 * N
     gbs = 504.0 * cols / (ms * 1e-3) / 1e9
+    import ctypes as C
+    nd = C.c_int64(0)
+    _lib.check(_lib.lib().lf_soil_last_deferred(C.c_int(0), C.byref(nd)))
     return dict(metric="soil Mcolumn-steps/s", value=round(cols / ms / 1e3, 2), ms_per_step=round(ms, 4),
                 columns=cols, alg_bytes_per_column_step=504, achieved_GBs=round(gbs, 1),
-                frac_hbm=round(gbs / HBM_PEAK_GBS, 4))
+                frac_hbm=round(gbs / HBM_PEAK_GBS, 4), multi_substep_columns_frac=round(nd.value / cols, 4))
 
 
 def main():
@@ -222,6 +226,9 @@ def main():
     if a.gpus > 1 or world > 1 or a.force_dist:
         from lisflood_amd import dist_bench
         return dist_bench.main(a)
+    if a.only == "soil":
+        print(json.dumps(soil_bench()), flush=True)
+        return
     H = W = a.size
     if a.calibrate:
         import ctypes as C

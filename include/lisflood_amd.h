@@ -261,6 +261,8 @@ int lf_soil_columns_host(int device, const lf_soil_args *a);
 /* device-resident forms: every array pointer is device memory (except the small per-vegetation ones) */
 int lf_interception_device(int device, const lf_interception_args *a);
 int lf_soil_columns_device(int device, const lf_soil_args *a);
+/* instrumentation: columns of the last lf_soil_columns_device call that needed > 1 Courant sub-step */
+int lf_soil_last_deferred(int device, int64_t *count);
 
 /* ---------------------------------------------------------------------------------------------
  * multi-GPU: the raster is split into contiguous row blocks, one rank (process, GPU) per block; boundary

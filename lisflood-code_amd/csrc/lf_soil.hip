@@ -78,144 +78,173 @@ struct veg_plan {
     int paddy_row[kMaxVeg];
 };
 
-// soilColumnsWaterBalance, soilloop.py:78-355
-__global__ void __launch_bounds__(kBlock) k_soil_columns(lf_soil_args A, veg_plan P)
+// One soil column (vegetation fraction `veg`, pixel `pix`) of soilColumnsWaterBalance, soilloop.py:123-354.
+// Nothing is stored before the end, so a column can be abandoned and recomputed later: with DEFER, a column
+// that needs more than one Courant sub-step returns false without writing anything.
+template <bool DEFER>
+__device__ __forceinline__ bool soil_column(const lf_soil_args &A, const veg_plan &P, int veg, long long pix)
+{
+    const long long N = A.N;
+    const double DtDay = A.DtDay;
+    const long long i = (long long)veg * N + pix, j = (long long)P.landuse[veg] * N + pix;
+    const bool frozen = A.isFrozenSoil[pix] != 0;
+    const double wres1a = A.WRes1a[j], wres1b = A.WRes1b[j], wres2 = A.WRes2[j];
+    const double ws1a = A.WS1a[j], ws1b = A.WS1b[j], ws2 = A.WS2[j];
+    const bool pore1a = A.PoreSpaceNotZero1a[j] != 0, pore1b = A.PoreSpaceNotZero1b[j] != 0,
+               pore2 = A.PoreSpaceNotZero2[j] != 0;
+    // available water for infiltration, :100,131
+    double awi = dmax((A.Rain[pix] + A.SnowMelt[pix]) + A.LeafDrainage[i] - A.Interception[i], 0.);
+    // days since last rain, :137-140
+    double dslr = A.DSLR[i];
+    if (awi > A.AvWaterThreshold)
+        dslr = 1;
+    else
+        dslr += DtDay;
+    // bare soil evaporation, :148-163
+    double w1a = A.W1a[i], w1b = A.W1b[i], esact;
+    if (frozen)
+        esact = 0.;
+    else {
+        esact = A.ESMax[i] * (sqrt(dslr) - sqrt(dslr - 1));
+        esact = dmax(dmin(esact, A.W1[i] - A.WRes1[j]), 0.);
+        const double supply1a = w1a - wres1a;
+        const double es1a = dmin(esact, supply1a);
+        const double es1b = dmax(esact - supply1a, 0.);
+        w1a = dmax(w1a - es1a, wres1a);
+        w1b = dmax(w1b - es1b, wres1b);
+    }
+    double w1 = w1a + w1b;
+    // Xinanjiang infiltration capacity, :168-179
+    const double relsat1 = pore1a ? dmin(w1 / A.WS1[j], 1.0) : 0.0;
+    const double satfrac = 1.0 - pow(1.0 - relsat1, A.b_Xinanjiang[pix]);
+    const double infpot = frozen ? 0.0 : A.StoreMaxPervious[j] * pow(1. - satfrac, A.PowerInfPot[pix]) * DtDay;
+    // preferential flow, :190-194
+    const double pref = pow(relsat1, A.PowerPrefFlow[pix]) * awi;
+    awi -= pref;
+    // infiltration, :201-211
+    double inf = dmax(dmin(awi, infpot), 0.);
+    const double test1a = w1a + inf;
+    w1a = dmin(ws1a, test1a);
+    w1b += dmax(test1a - ws1a, 0.);
+    double w2 = A.W2[i];
+    // Van Genuchten conductivities and Courant numbers, :223-249
+    const double ks1a = A.KSat1a[j], ks1b = A.KSat1b[j], ks2 = A.KSat2[j];
+    const double im1a = A.GenuInvM1a[j], im1b = A.GenuInvM1b[j], im2 = A.GenuInvM2[j];
+    const double m1a = A.GenuM1a[j], m1b = A.GenuM1b[j], m2 = A.GenuM2[j];
+    double k1a = unsat_k(w1a, pore1a, wres1a, ws1a, ks1a, im1a, m1a);
+    double k1b = unsat_k(w1b, pore1b, wres1b, ws1b, ks1b, im1b, m1b);
+    double k2 = unsat_k(w2, pore2, wres2, ws2, ks2, im2, m2);
+    double av1a = w1a - wres1a, av1b = w1b - wres1b, av2 = w2 - wres2;
+    double cap1 = ws1b - w1b, cap2 = ws2 - w2;
+    const double ca = (av1a == 0) ? 0. : k1a * DtDay / av1a;
+    const double cb = (av1b == 0) ? 0. : k1b * DtDay / av1b;
+    const double cg = (av2 == 0) ? 0. : k2 * DtDay / av2;
+    const double courant = dmax(dmax(ca, cb), cg);
+    const double nsub_f = dmax(1., ceil(courant / A.CourantCrit));
+    const long long nsub = (long long)nsub_f;
+    if (DEFER && nsub > 1) return false;
+    // sub-step loop, :266-312
+    double wt1a = w1a, wt1b = w1b, wt2 = w2;
+    double sa = 0., sb = 0., sg = 0.;
+    const double dtsub = DtDay / (double)nsub;
+    const long long trips = DEFER ? 1 : nsub; // DEFER: nsub == 1 here, the re-evaluation branch disappears
+    for (long long s = 0; s < trips; ++s) {
+        if (s > 0) {
+            k1a = unsat_k(wt1a, pore1a, wres1a, ws1a, ks1a, im1a, m1a);
+            k1b = unsat_k(wt1b, pore1b, wres1b, ws1b, ks1b, im1b, m1b);
+            k2 = unsat_k(wt2, pore2, wres2, ws2, ks2, im2, m2);
+        }
+        const double fa = dmin(k1a * dtsub, cap1);
+        const double fb = dmin(k1b * dtsub, cap2);
+        const double fg = dmin(k2 * dtsub, av2);
+        av1a -= fa;
+        av1b += fa - fb;
+        av2 += fb - fg;
+        wt1a = av1a + wres1a;
+        wt1b = av1b + wres1b;
+        wt2 = av2 + wres2;
+        cap1 = ws1b - wt1b;
+        cap2 = ws2 - wt2;
+        sa += fa;
+        sb += fb;
+        sg += fg;
+    }
+    if (frozen) sa = sb = sg = 0.; // :313-316
+    // state update, :319-325 (W1 is taken BEFORE the 1a overflow correction, as the reference does)
+    w1a -= sa;
+    w1b = w1b + sa - sb;
+    w2 = w2 + sb - sg;
+    w1 = w1a + w1b;
+    inf -= dmax(w1a - ws1a, 0.);
+    w1a = dmin(w1a, ws1a);
+    // upper zone, :340-354
+    double uz = A.UZ[i];
+    double uzout = dmin(A.UpperZoneK[pix] * uz, uz);
+    uz = dmax(uz - uzout, 0.);
+    if (P.drained[veg]) {
+        uzout += A.DrainedFraction * sg;
+        uz += (1 - A.DrainedFraction) * sg + pref;
+    } else
+        uz += sg + pref;
+    const double perc = dmin(A.GwPercStep[pix], uz);
+    uz = dmax(uz - perc, 0.);
+    // stores
+    A.DSLR[i] = dslr;
+    A.ESAct[i] = esact;
+    A.PrefFlow[i] = pref;
+    A.AvailableWaterForInfiltration[i] = awi;
+    A.SeepTopToSubA[i] = sa;
+    A.SeepTopToSubB[i] = sb;
+    A.SeepSubToGW[i] = sg;
+    A.Infiltration[i] = inf;
+    A.W1a[i] = w1a;
+    A.W1b[i] = w1b;
+    A.W1[i] = w1;
+    A.W2[i] = w2;
+    // diagnostics, :330-336
+    A.Theta1a[i] = pore1a ? w1a / A.SoilDepth1a[j] : 0.;
+    A.Theta1b[i] = pore1b ? w1b / A.SoilDepth1b[j] : 0.;
+    A.Theta2[i] = pore2 ? w2 / A.SoilDepth2[j] : 0.;
+    const double wwp1a = A.WWP1a[j], wwp1b = A.WWP1b[j], wwp1 = A.WWP1[j], wwp2 = A.WWP2[j];
+    A.Sat1a[i] = (w1a - wwp1a) / (A.WFC1a[j] - wwp1a);
+    A.Sat1b[i] = (w1b - wwp1b) / (A.WFC1b[j] - wwp1b);
+    A.Sat1[i] = (w1 - wwp1) / (A.WFC1[j] - wwp1);
+    A.Sat2[i] = (w2 - wwp2) / (A.WFC2[j] - wwp2);
+    A.UZOutflow[i] = uzout;
+    A.GwPercUZLZ[i] = perc;
+    A.UZ[i] = uz;
+    return true;
+}
+
+// Pass 1: one lane per (vegetation fraction, pixel) column (blockIdx.y = fraction).  Columns that need a
+// single Courant sub-step (the vast majority) are finished here; the others are appended to a work list
+// instead of making the whole wavefront wait for them.
+__global__ void __launch_bounds__(kBlock) k_soil_columns(lf_soil_args A, veg_plan P, unsigned int *__restrict__ worklist,
+                                                         unsigned int *__restrict__ counter)
 {
     const long long pix = (long long)blockIdx.x * kBlock + threadIdx.x;
-    const long long N = A.N;
-    if (pix >= N) return;
-    const double DtDay = A.DtDay;
-    const double rain_plus_snow = A.Rain[pix] + A.SnowMelt[pix]; // :100
-    const bool frozen = A.isFrozenSoil[pix] != 0;
-    const double bx = A.b_Xinanjiang[pix], pinf = A.PowerInfPot[pix], ppref = A.PowerPrefFlow[pix];
-    const double uzk = A.UpperZoneK[pix], gwperc = A.GwPercStep[pix];
-    for (int veg = 0; veg < (int)A.V; ++veg) {
-        const int mode = P.mode[veg];
-        if (mode == 0) continue;
-        if (mode == 2 && !A.paddy_inactive[(long long)P.paddy_row[veg] * N + pix]) continue;
-        const long long i = (long long)veg * N + pix, j = (long long)P.landuse[veg] * N + pix;
-        const double wres1a = A.WRes1a[j], wres1b = A.WRes1b[j], wres2 = A.WRes2[j];
-        const double ws1a = A.WS1a[j], ws1b = A.WS1b[j], ws2 = A.WS2[j];
-        const bool pore1a = A.PoreSpaceNotZero1a[j] != 0, pore1b = A.PoreSpaceNotZero1b[j] != 0,
-                   pore2 = A.PoreSpaceNotZero2[j] != 0;
-        // available water for infiltration, :131
-        double awi = dmax(rain_plus_snow + A.LeafDrainage[i] - A.Interception[i], 0.);
-        // days since last rain, :137-140
-        double dslr = A.DSLR[i];
-        if (awi > A.AvWaterThreshold)
-            dslr = 1;
-        else
-            dslr += DtDay;
-        A.DSLR[i] = dslr;
-        // bare soil evaporation, :148-163
-        double w1a = A.W1a[i], w1b = A.W1b[i], esact;
-        if (frozen)
-            esact = 0.;
-        else {
-            esact = A.ESMax[i] * (sqrt(dslr) - sqrt(dslr - 1));
-            esact = dmax(dmin(esact, A.W1[i] - A.WRes1[j]), 0.);
-            const double supply1a = w1a - wres1a;
-            const double es1a = dmin(esact, supply1a);
-            const double es1b = dmax(esact - supply1a, 0.);
-            w1a = dmax(w1a - es1a, wres1a);
-            w1b = dmax(w1b - es1b, wres1b);
-        }
-        A.ESAct[i] = esact;
-        double w1 = w1a + w1b;
-        // Xinanjiang infiltration capacity, :168-179
-        const double relsat1 = pore1a ? dmin(w1 / A.WS1[j], 1.0) : 0.0;
-        const double satfrac = 1.0 - pow(1.0 - relsat1, bx);
-        const double infpot = frozen ? 0.0 : A.StoreMaxPervious[j] * pow(1. - satfrac, pinf) * DtDay;
-        // preferential flow, :190-194
-        const double pref = pow(relsat1, ppref) * awi;
-        A.PrefFlow[i] = pref;
-        awi -= pref;
-        A.AvailableWaterForInfiltration[i] = awi;
-        // infiltration, :201-211
-        double inf = dmax(dmin(awi, infpot), 0.);
-        const double test1a = w1a + inf;
-        w1a = dmin(ws1a, test1a);
-        w1b += dmax(test1a - ws1a, 0.);
-        double w2 = A.W2[i];
-        // Van Genuchten conductivities and Courant numbers, :223-249
-        const double ks1a = A.KSat1a[j], ks1b = A.KSat1b[j], ks2 = A.KSat2[j];
-        const double im1a = A.GenuInvM1a[j], im1b = A.GenuInvM1b[j], im2 = A.GenuInvM2[j];
-        const double m1a = A.GenuM1a[j], m1b = A.GenuM1b[j], m2 = A.GenuM2[j];
-        double k1a = unsat_k(w1a, pore1a, wres1a, ws1a, ks1a, im1a, m1a);
-        double k1b = unsat_k(w1b, pore1b, wres1b, ws1b, ks1b, im1b, m1b);
-        double k2 = unsat_k(w2, pore2, wres2, ws2, ks2, im2, m2);
-        double av1a = w1a - wres1a, av1b = w1b - wres1b, av2 = w2 - wres2;
-        double cap1 = ws1b - w1b, cap2 = ws2 - w2;
-        const double ca = (av1a == 0) ? 0. : k1a * DtDay / av1a;
-        const double cb = (av1b == 0) ? 0. : k1b * DtDay / av1b;
-        const double cg = (av2 == 0) ? 0. : k2 * DtDay / av2;
-        const double courant = dmax(dmax(ca, cb), cg);
-        const double nsub_f = dmax(1., ceil(courant / A.CourantCrit));
-        const long long nsub = (long long)nsub_f;
-        // sub-step loop, :266-312
-        double wt1a = w1a, wt1b = w1b, wt2 = w2;
-        double sa = 0., sb = 0., sg = 0.;
-        const double dtsub = DtDay / (double)nsub;
-        for (long long s = 0; s < nsub; ++s) {
-            if (s > 0) {
-                k1a = unsat_k(wt1a, pore1a, wres1a, ws1a, ks1a, im1a, m1a);
-                k1b = unsat_k(wt1b, pore1b, wres1b, ws1b, ks1b, im1b, m1b);
-                k2 = unsat_k(wt2, pore2, wres2, ws2, ks2, im2, m2);
-            }
-            const double fa = dmin(k1a * dtsub, cap1);
-            const double fb = dmin(k1b * dtsub, cap2);
-            const double fg = dmin(k2 * dtsub, av2);
-            av1a -= fa;
-            av1b += fa - fb;
-            av2 += fb - fg;
-            wt1a = av1a + wres1a;
-            wt1b = av1b + wres1b;
-            wt2 = av2 + wres2;
-            cap1 = ws1b - wt1b;
-            cap2 = ws2 - wt2;
-            sa += fa;
-            sb += fb;
-            sg += fg;
-        }
-        if (frozen) sa = sb = sg = 0.; // :313-316
-        A.SeepTopToSubA[i] = sa;
-        A.SeepTopToSubB[i] = sb;
-        A.SeepSubToGW[i] = sg;
-        // state update, :319-325 (W1 is taken BEFORE the 1a overflow correction, as the reference does)
-        w1a -= sa;
-        w1b = w1b + sa - sb;
-        w2 = w2 + sb - sg;
-        w1 = w1a + w1b;
-        inf -= dmax(w1a - ws1a, 0.);
-        w1a = dmin(w1a, ws1a);
-        A.Infiltration[i] = inf;
-        A.W1a[i] = w1a;
-        A.W1b[i] = w1b;
-        A.W1[i] = w1;
-        A.W2[i] = w2;
-        // diagnostics, :330-336
-        A.Theta1a[i] = pore1a ? w1a / A.SoilDepth1a[j] : 0.;
-        A.Theta1b[i] = pore1b ? w1b / A.SoilDepth1b[j] : 0.;
-        A.Theta2[i] = pore2 ? w2 / A.SoilDepth2[j] : 0.;
-        const double wwp1a = A.WWP1a[j], wwp1b = A.WWP1b[j], wwp1 = A.WWP1[j], wwp2 = A.WWP2[j];
-        A.Sat1a[i] = (w1a - wwp1a) / (A.WFC1a[j] - wwp1a);
-        A.Sat1b[i] = (w1b - wwp1b) / (A.WFC1b[j] - wwp1b);
-        A.Sat1[i] = (w1 - wwp1) / (A.WFC1[j] - wwp1);
-        A.Sat2[i] = (w2 - wwp2) / (A.WFC2[j] - wwp2);
-        // upper zone, :340-354
-        double uz = A.UZ[i];
-        double uzout = dmin(uzk * uz, uz);
-        uz = dmax(uz - uzout, 0.);
-        if (P.drained[veg]) {
-            uzout += A.DrainedFraction * sg;
-            uz += (1 - A.DrainedFraction) * sg + pref;
-        } else
-            uz += sg + pref;
-        const double perc = dmin(gwperc, uz);
-        uz = dmax(uz - perc, 0.);
-        A.UZOutflow[i] = uzout;
-        A.GwPercUZLZ[i] = perc;
-        A.UZ[i] = uz;
+    const int veg = blockIdx.y;
+    if (pix >= A.N) return;
+    const int mode = P.mode[veg];
+    if (mode == 0) return;
+    if (mode == 2 && !A.paddy_inactive[(long long)P.paddy_row[veg] * A.N + pix]) return;
+    if (!soil_column<true>(A, P, veg, pix)) {
+        const unsigned int slot = atomicAdd(counter, 1u);
+        worklist[slot] = (unsigned int)(veg * A.N + pix);
+    }
+}
+
+// Pass 2: the deferred columns, one lane each, with their full sub-step loop.
+__global__ void __launch_bounds__(kBlock) k_soil_columns_deferred(lf_soil_args A, veg_plan P,
+                                                                  const unsigned int *__restrict__ worklist,
+                                                                  const unsigned int *__restrict__ counter)
+{
+    const unsigned int n = *counter;
+    for (unsigned int k = blockIdx.x * kBlock + threadIdx.x; k < n; k += gridDim.x * kBlock) {
+        const unsigned int id = worklist[k];
+        const int veg = (int)(id / (unsigned long long)A.N);
+        const long long pix = (long long)(id - (unsigned long long)veg * A.N);
+        soil_column<false>(A, P, veg, pix);
     }
 }
 
@@ -262,6 +291,21 @@ int lf_interception_device(int device, const lf_interception_args *a)
     return LF_OK;
 }
 
+// number of columns the last lf_soil_columns_device call on `device` deferred to the second pass
+int lf_soil_last_deferred(int device, int64_t *count)
+{
+    if (!count) return lf_set_error(LF_E_INVALID, "null argument");
+    lf_device_ctx *c;
+    LF_TRY(lf_ctx(device, &c));
+    *count = 0;
+    if (!c->soil_ws) return LF_OK;
+    unsigned int h = 0;
+    LF_HIP(hipMemcpyAsync(&h, c->soil_ws, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    LF_HIP(hipStreamSynchronize(c->stream));
+    *count = (int64_t)h;
+    return LF_OK;
+}
+
 int lf_soil_columns_device(int device, const lf_soil_args *a)
 {
     if (!a || !a->index_landuse_all) return lf_set_error(LF_E_INVALID, "null argument");
@@ -269,8 +313,25 @@ int lf_soil_columns_device(int device, const lf_soil_args *a)
     LF_TRY(lf_ctx(device, &c));
     veg_plan P;
     LF_TRY(make_plan(a, a->paddy_any, &P));
-    if (a->N > 0 && a->V > 0)
-        hipLaunchKernelGGL(k_soil_columns, dim3(blocks_for(a->N)), dim3(kBlock), 0, c->stream, *a, P);
+    if (a->N <= 0 || a->V <= 0) return LF_OK;
+    if ((unsigned long long)a->V * (unsigned long long)a->N >= 0xffffffffull)
+        return lf_set_error(LF_E_INVALID, "V*N exceeds the 32-bit column id range");
+    // work list of the columns that need more than one Courant sub-step (grow-only per-device workspace)
+    const size_t need = sizeof(unsigned int) * ((size_t)a->V * (size_t)a->N + 1);
+    if (c->soil_ws_bytes < need) {
+        if (c->soil_ws) LF_HIP(hipFree(c->soil_ws));
+        c->soil_ws = nullptr;
+        c->soil_ws_bytes = 0;
+        LF_HIP(hipMalloc(&c->soil_ws, need));
+        c->soil_ws_bytes = need;
+    }
+    unsigned int *counter = (unsigned int *)c->soil_ws;
+    unsigned int *worklist = counter + 1;
+    LF_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned int), c->stream));
+    hipLaunchKernelGGL(k_soil_columns, dim3(blocks_for(a->N), (unsigned)a->V), dim3(kBlock), 0, c->stream, *a, P, worklist,
+                       counter);
+    // the deferred count is only known on the device: a fixed grid walks the list with a grid-stride loop
+    hipLaunchKernelGGL(k_soil_columns_deferred, dim3(2048), dim3(kBlock), 0, c->stream, *a, P, worklist, counter);
     LF_HIP(hipGetLastError());
     return LF_OK;
 }
