@@ -80,9 +80,9 @@ struct veg_plan {
 
 // One soil column (vegetation fraction `veg`, pixel `pix`) of soilColumnsWaterBalance, soilloop.py:123-354.
 // Nothing is stored before the end, so a column can be abandoned and recomputed later: with DEFER, a column
-// that needs more than one Courant sub-step returns false without writing anything.
+// that needs more than one Courant sub-step returns that number without writing anything (0 = column done).
 template <bool DEFER>
-__device__ __forceinline__ bool soil_column(const lf_soil_args &A, const veg_plan &P, int veg, long long pix)
+__device__ __forceinline__ long long soil_column(const lf_soil_args &A, const veg_plan &P, int veg, long long pix)
 {
     const long long N = A.N;
     const double DtDay = A.DtDay;
@@ -142,7 +142,7 @@ __device__ __forceinline__ bool soil_column(const lf_soil_args &A, const veg_pla
     const double courant = dmax(dmax(ca, cb), cg);
     const double nsub_f = dmax(1., ceil(courant / A.CourantCrit));
     const long long nsub = (long long)nsub_f;
-    if (DEFER && nsub > 1) return false;
+    if (DEFER && nsub > 1) return nsub;
     // sub-step loop, :266-312
     double wt1a = w1a, wt1b = w1b, wt2 = w2;
     double sa = 0., sb = 0., sg = 0.;
@@ -213,14 +213,19 @@ __device__ __forceinline__ bool soil_column(const lf_soil_args &A, const veg_pla
     A.UZOutflow[i] = uzout;
     A.GwPercUZLZ[i] = perc;
     A.UZ[i] = uz;
-    return true;
+    return 0;
 }
+
+// Work-list header (unsigned ints at the start of the per-device workspace):
+//   [0] number of deferred columns, [1..kClasses] columns per sub-step class, [1+kClasses .. 2 kClasses] fill cursors
+constexpr int kClasses = 8; // class = floor(log2(nsub)) clamped to kClasses-1: trip counts inside a class differ < 2x
+constexpr int kHeader = 1 + 2 * kClasses;
 
 // Pass 1: one lane per (vegetation fraction, pixel) column (blockIdx.y = fraction).  Columns that need a
 // single Courant sub-step (the vast majority) are finished here; the others are appended to a work list
 // instead of making the whole wavefront wait for them.
-__global__ void __launch_bounds__(kBlock) k_soil_columns(lf_soil_args A, veg_plan P, unsigned int *__restrict__ worklist,
-                                                         unsigned int *__restrict__ counter)
+__global__ void __launch_bounds__(kBlock) k_soil_columns(lf_soil_args A, veg_plan P, unsigned int *__restrict__ header,
+                                                         unsigned int *__restrict__ raw, unsigned char *__restrict__ cls)
 {
     const long long pix = (long long)blockIdx.x * kBlock + threadIdx.x;
     const int veg = blockIdx.y;
@@ -228,20 +233,47 @@ __global__ void __launch_bounds__(kBlock) k_soil_columns(lf_soil_args A, veg_pla
     const int mode = P.mode[veg];
     if (mode == 0) return;
     if (mode == 2 && !A.paddy_inactive[(long long)P.paddy_row[veg] * A.N + pix]) return;
-    if (!soil_column<true>(A, P, veg, pix)) {
-        const unsigned int slot = atomicAdd(counter, 1u);
-        worklist[slot] = (unsigned int)(veg * A.N + pix);
+    const long long nsub = soil_column<true>(A, P, veg, pix);
+    if (nsub > 0) {
+        int c = 63 - __clzll((unsigned long long)nsub); // floor(log2(nsub)) >= 1
+        c = c < kClasses - 1 ? c : kClasses - 1;
+        const unsigned int slot = atomicAdd(&header[0], 1u);
+        atomicAdd(&header[1 + c], 1u);
+        raw[slot] = (unsigned int)(veg * A.N + pix);
+        cls[slot] = (unsigned char)c;
+    }
+}
+
+// Pass 1.5: order the work list by sub-step class so that the lanes of a wavefront run similar trip counts
+__global__ void __launch_bounds__(kBlock) k_soil_partition(unsigned int *__restrict__ header, const unsigned int *__restrict__ raw,
+                                                           const unsigned char *__restrict__ cls,
+                                                           unsigned int *__restrict__ sorted)
+{
+    const unsigned int n = header[0];
+    unsigned int offset[kClasses];
+    unsigned int acc = 0;
+#pragma unroll
+    for (int c = 0; c < kClasses; ++c) {
+        offset[c] = acc;
+        acc += header[1 + c];
+    }
+    for (unsigned int k = blockIdx.x * kBlock + threadIdx.x; k < n; k += gridDim.x * kBlock) {
+        const int c = cls[k];
+        unsigned int base = 0;
+#pragma unroll
+        for (int q = 0; q < kClasses; ++q) base = (q == c) ? offset[q] : base;
+        sorted[base + atomicAdd(&header[1 + kClasses + c], 1u)] = raw[k];
     }
 }
 
 // Pass 2: the deferred columns, one lane each, with their full sub-step loop.
 __global__ void __launch_bounds__(kBlock) k_soil_columns_deferred(lf_soil_args A, veg_plan P,
-                                                                  const unsigned int *__restrict__ worklist,
-                                                                  const unsigned int *__restrict__ counter)
+                                                                  const unsigned int *__restrict__ header,
+                                                                  const unsigned int *__restrict__ sorted)
 {
-    const unsigned int n = *counter;
+    const unsigned int n = header[0];
     for (unsigned int k = blockIdx.x * kBlock + threadIdx.x; k < n; k += gridDim.x * kBlock) {
-        const unsigned int id = worklist[k];
+        const unsigned int id = sorted[k];
         const int veg = (int)(id / (unsigned long long)A.N);
         const long long pix = (long long)(id - (unsigned long long)veg * A.N);
         soil_column<false>(A, P, veg, pix);
@@ -316,8 +348,10 @@ int lf_soil_columns_device(int device, const lf_soil_args *a)
     if (a->N <= 0 || a->V <= 0) return LF_OK;
     if ((unsigned long long)a->V * (unsigned long long)a->N >= 0xffffffffull)
         return lf_set_error(LF_E_INVALID, "V*N exceeds the 32-bit column id range");
-    // work list of the columns that need more than one Courant sub-step (grow-only per-device workspace)
-    const size_t need = sizeof(unsigned int) * ((size_t)a->V * (size_t)a->N + 1);
+    // work list of the columns that need more than one Courant sub-step (grow-only per-device workspace):
+    // header | raw ids | sorted ids | classes
+    const size_t cols = (size_t)a->V * (size_t)a->N;
+    const size_t need = sizeof(unsigned int) * (kHeader + 2 * cols) + cols;
     if (c->soil_ws_bytes < need) {
         if (c->soil_ws) LF_HIP(hipFree(c->soil_ws));
         c->soil_ws = nullptr;
@@ -325,13 +359,16 @@ int lf_soil_columns_device(int device, const lf_soil_args *a)
         LF_HIP(hipMalloc(&c->soil_ws, need));
         c->soil_ws_bytes = need;
     }
-    unsigned int *counter = (unsigned int *)c->soil_ws;
-    unsigned int *worklist = counter + 1;
-    LF_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned int), c->stream));
-    hipLaunchKernelGGL(k_soil_columns, dim3(blocks_for(a->N), (unsigned)a->V), dim3(kBlock), 0, c->stream, *a, P, worklist,
-                       counter);
-    // the deferred count is only known on the device: a fixed grid walks the list with a grid-stride loop
-    hipLaunchKernelGGL(k_soil_columns_deferred, dim3(2048), dim3(kBlock), 0, c->stream, *a, P, worklist, counter);
+    unsigned int *header = (unsigned int *)c->soil_ws;
+    unsigned int *raw = header + kHeader;
+    unsigned int *sorted = raw + cols;
+    unsigned char *cls = (unsigned char *)(sorted + cols);
+    LF_HIP(hipMemsetAsync(header, 0, sizeof(unsigned int) * kHeader, c->stream));
+    hipLaunchKernelGGL(k_soil_columns, dim3(blocks_for(a->N), (unsigned)a->V), dim3(kBlock), 0, c->stream, *a, P, header,
+                       raw, cls);
+    // the deferred count is only known on the device: fixed grids walk the list with grid-stride loops
+    hipLaunchKernelGGL(k_soil_partition, dim3(1024), dim3(kBlock), 0, c->stream, header, raw, cls, sorted);
+    hipLaunchKernelGGL(k_soil_columns_deferred, dim3(4096), dim3(kBlock), 0, c->stream, *a, P, header, sorted);
     LF_HIP(hipGetLastError());
     return LF_OK;
 }
