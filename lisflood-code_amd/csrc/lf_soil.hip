@@ -221,6 +221,24 @@ __device__ __forceinline__ long long soil_column(const lf_soil_args &A, const ve
 constexpr int kClasses = 8; // class = floor(log2(nsub)) clamped to kClasses-1: trip counts inside a class differ < 2x
 constexpr int kHeader = 1 + 2 * kClasses;
 
+// Wave-aggregated slot allocation: the lanes of a wavefront that want a slot of the same counter are served by
+// ONE atomicAdd (same-address atomics serialise at ~11 ns each; 64 lanes share one).  Returns the lane's slot.
+__device__ __forceinline__ unsigned int wave_alloc(unsigned int *counters, int which, bool want)
+{
+    const int lane = threadIdx.x & 63;
+    unsigned int slot = 0;
+    for (int c = 0; c < kClasses; ++c) {
+        const unsigned long long mask = __ballot(want && which == c);
+        if (mask == 0) continue;                      // wave-uniform
+        const int leader = __ffsll((long long)mask) - 1;
+        unsigned int base = 0;
+        if (lane == leader) base = atomicAdd(&counters[c], (unsigned int)__popcll(mask));
+        base = __shfl(base, leader, 64);
+        if (want && which == c) slot = base + (unsigned int)__popcll(mask & ((1ull << lane) - 1ull));
+    }
+    return slot;
+}
+
 // Pass 1: one lane per (vegetation fraction, pixel) column (blockIdx.y = fraction).  Columns that need a
 // single Courant sub-step (the vast majority) are finished here; the others are appended to a work list
 // instead of making the whole wavefront wait for them.
@@ -229,16 +247,18 @@ __global__ void __launch_bounds__(kBlock) k_soil_columns(lf_soil_args A, veg_pla
 {
     const long long pix = (long long)blockIdx.x * kBlock + threadIdx.x;
     const int veg = blockIdx.y;
-    if (pix >= A.N) return;
     const int mode = P.mode[veg];
-    if (mode == 0) return;
-    if (mode == 2 && !A.paddy_inactive[(long long)P.paddy_row[veg] * A.N + pix]) return;
-    const long long nsub = soil_column<true>(A, P, veg, pix);
-    if (nsub > 0) {
-        int c = 63 - __clzll((unsigned long long)nsub); // floor(log2(nsub)) >= 1
-        c = c < kClasses - 1 ? c : kClasses - 1;
-        const unsigned int slot = atomicAdd(&header[0], 1u);
-        atomicAdd(&header[1 + c], 1u);
+    bool active = pix < A.N && mode != 0;
+    if (active && mode == 2 && !A.paddy_inactive[(long long)P.paddy_row[veg] * A.N + pix]) active = false;
+    long long nsub = 0;
+    if (active) nsub = soil_column<true>(A, P, veg, pix);
+    // no early return above: every lane of the wavefront takes part in the ballots below
+    const bool defer = nsub > 0;
+    int c = defer ? 63 - __clzll((unsigned long long)nsub) : 0; // floor(log2(nsub)) >= 1
+    c = c < kClasses - 1 ? c : kClasses - 1;
+    const unsigned int slot = wave_alloc(&header[0], 0, defer);      // position in the raw list
+    (void)wave_alloc(&header[1], c, defer);                          // per-class population
+    if (defer) {
         raw[slot] = (unsigned int)(veg * A.N + pix);
         cls[slot] = (unsigned char)c;
     }
@@ -257,12 +277,17 @@ __global__ void __launch_bounds__(kBlock) k_soil_partition(unsigned int *__restr
         offset[c] = acc;
         acc += header[1 + c];
     }
-    for (unsigned int k = blockIdx.x * kBlock + threadIdx.x; k < n; k += gridDim.x * kBlock) {
-        const int c = cls[k];
+    const unsigned int stride = gridDim.x * kBlock;
+    const unsigned int rounds = (n + stride - 1) / stride; // same trip count for every lane (ballots inside)
+    for (unsigned int t = 0; t < rounds; ++t) {
+        const unsigned int k = t * stride + blockIdx.x * kBlock + threadIdx.x;
+        const bool on = k < n;
+        const int c = on ? cls[k] : 0;
         unsigned int base = 0;
 #pragma unroll
         for (int q = 0; q < kClasses; ++q) base = (q == c) ? offset[q] : base;
-        sorted[base + atomicAdd(&header[1 + kClasses + c], 1u)] = raw[k];
+        const unsigned int slot = wave_alloc(&header[1 + kClasses], c, on);
+        if (on) sorted[base + slot] = raw[k];
     }
 }
 
