@@ -221,24 +221,6 @@ __device__ __forceinline__ long long soil_column(const lf_soil_args &A, const ve
 constexpr int kClasses = 8; // class = floor(log2(nsub)) clamped to kClasses-1: trip counts inside a class differ < 2x
 constexpr int kHeader = 1 + 2 * kClasses;
 
-// Wave-aggregated slot allocation: the lanes of a wavefront that want a slot of the same counter are served by
-// ONE atomicAdd (same-address atomics serialise at ~11 ns each; 64 lanes share one).  Returns the lane's slot.
-__device__ __forceinline__ unsigned int wave_alloc(unsigned int *counters, int which, bool want)
-{
-    const int lane = threadIdx.x & 63;
-    unsigned int slot = 0;
-    for (int c = 0; c < kClasses; ++c) {
-        const unsigned long long mask = __ballot(want && which == c);
-        if (mask == 0) continue;                      // wave-uniform
-        const int leader = __ffsll((long long)mask) - 1;
-        unsigned int base = 0;
-        if (lane == leader) base = atomicAdd(&counters[c], (unsigned int)__popcll(mask));
-        base = __shfl(base, leader, 64);
-        if (want && which == c) slot = base + (unsigned int)__popcll(mask & ((1ull << lane) - 1ull));
-    }
-    return slot;
-}
-
 // Pass 1: one lane per (vegetation fraction, pixel) column (blockIdx.y = fraction).  Columns that need a
 // single Courant sub-step (the vast majority) are finished here; the others are appended to a work list
 // instead of making the whole wavefront wait for them.
@@ -247,47 +229,64 @@ __global__ void __launch_bounds__(kBlock) k_soil_columns(lf_soil_args A, veg_pla
 {
     const long long pix = (long long)blockIdx.x * kBlock + threadIdx.x;
     const int veg = blockIdx.y;
+    if (pix >= A.N) return;
     const int mode = P.mode[veg];
-    bool active = pix < A.N && mode != 0;
-    if (active && mode == 2 && !A.paddy_inactive[(long long)P.paddy_row[veg] * A.N + pix]) active = false;
-    long long nsub = 0;
-    if (active) nsub = soil_column<true>(A, P, veg, pix);
-    // no early return above: every lane of the wavefront takes part in the ballots below
-    const bool defer = nsub > 0;
-    int c = defer ? 63 - __clzll((unsigned long long)nsub) : 0; // floor(log2(nsub)) >= 1
-    c = c < kClasses - 1 ? c : kClasses - 1;
-    const unsigned int slot = wave_alloc(&header[0], 0, defer);      // position in the raw list
-    (void)wave_alloc(&header[1], c, defer);                          // per-class population
-    if (defer) {
+    if (mode == 0) return;
+    if (mode == 2 && !A.paddy_inactive[(long long)P.paddy_row[veg] * A.N + pix]) return;
+    const long long nsub = soil_column<true>(A, P, veg, pix);
+    if (nsub > 0) {
+        int c = 63 - __clzll((unsigned long long)nsub); // floor(log2(nsub)) >= 1
+        c = c < kClasses - 1 ? c : kClasses - 1;
+        const unsigned int slot = atomicAdd(&header[0], 1u); // hipcc folds this into one atomic per wavefront
         raw[slot] = (unsigned int)(veg * A.N + pix);
         cls[slot] = (unsigned char)c;
     }
 }
 
-// Pass 1.5: order the work list by sub-step class so that the lanes of a wavefront run similar trip counts
-__global__ void __launch_bounds__(kBlock) k_soil_partition(unsigned int *__restrict__ header, const unsigned int *__restrict__ raw,
-                                                           const unsigned char *__restrict__ cls,
-                                                           unsigned int *__restrict__ sorted)
+// Pass 1.5: counting sort of the work list by sub-step class (block-local histograms in LDS, a handful of
+// global atomics per block) so that the lanes of a wavefront of pass 2 run similar trip counts.
+__global__ void __launch_bounds__(kBlock) k_soil_hist(unsigned int *__restrict__ header, const unsigned char *__restrict__ cls)
 {
+    __shared__ unsigned int h[kClasses];
+    if (threadIdx.x < kClasses) h[threadIdx.x] = 0;
+    __syncthreads();
     const unsigned int n = header[0];
-    unsigned int offset[kClasses];
-    unsigned int acc = 0;
+    for (unsigned int k = blockIdx.x * kBlock + threadIdx.x; k < n; k += gridDim.x * kBlock) atomicAdd(&h[cls[k]], 1u);
+    __syncthreads();
+    if (threadIdx.x < kClasses && h[threadIdx.x]) atomicAdd(&header[1 + threadIdx.x], h[threadIdx.x]);
+}
+
+__global__ void __launch_bounds__(kBlock) k_soil_scatter(unsigned int *__restrict__ header, const unsigned int *__restrict__ raw,
+                                                         const unsigned char *__restrict__ cls,
+                                                         unsigned int *__restrict__ sorted)
+{
+    __shared__ unsigned int h[kClasses], base[kClasses];
+    const unsigned int n = header[0];
+    const unsigned int chunk = kBlock * 8;
+    for (unsigned int c0 = blockIdx.x * chunk; c0 < n; c0 += gridDim.x * chunk) {
+        if (threadIdx.x < kClasses) h[threadIdx.x] = 0;
+        __syncthreads();
+        unsigned int rank[8];
+        int myc[8];
 #pragma unroll
-    for (int c = 0; c < kClasses; ++c) {
-        offset[c] = acc;
-        acc += header[1 + c];
-    }
-    const unsigned int stride = gridDim.x * kBlock;
-    const unsigned int rounds = (n + stride - 1) / stride; // same trip count for every lane (ballots inside)
-    for (unsigned int t = 0; t < rounds; ++t) {
-        const unsigned int k = t * stride + blockIdx.x * kBlock + threadIdx.x;
-        const bool on = k < n;
-        const int c = on ? cls[k] : 0;
-        unsigned int base = 0;
+        for (int t = 0; t < 8; ++t) {
+            const unsigned int k = c0 + t * kBlock + threadIdx.x;
+            myc[t] = k < n ? (int)cls[k] : -1;
+            rank[t] = myc[t] >= 0 ? atomicAdd(&h[myc[t]], 1u) : 0;
+        }
+        __syncthreads();
+        if (threadIdx.x < kClasses) {
+            unsigned int off = 0; // start of this class in the sorted list
+            for (int q = 0; q < (int)threadIdx.x; ++q) off += header[1 + q];
+            base[threadIdx.x] = off + (h[threadIdx.x] ? atomicAdd(&header[1 + kClasses + threadIdx.x], h[threadIdx.x]) : 0);
+        }
+        __syncthreads();
 #pragma unroll
-        for (int q = 0; q < kClasses; ++q) base = (q == c) ? offset[q] : base;
-        const unsigned int slot = wave_alloc(&header[1 + kClasses], c, on);
-        if (on) sorted[base + slot] = raw[k];
+        for (int t = 0; t < 8; ++t) {
+            const unsigned int k = c0 + t * kBlock + threadIdx.x;
+            if (myc[t] >= 0) sorted[base[myc[t]] + rank[t]] = raw[k];
+        }
+        __syncthreads();
     }
 }
 
@@ -392,7 +391,8 @@ int lf_soil_columns_device(int device, const lf_soil_args *a)
     hipLaunchKernelGGL(k_soil_columns, dim3(blocks_for(a->N), (unsigned)a->V), dim3(kBlock), 0, c->stream, *a, P, header,
                        raw, cls);
     // the deferred count is only known on the device: fixed grids walk the list with grid-stride loops
-    hipLaunchKernelGGL(k_soil_partition, dim3(1024), dim3(kBlock), 0, c->stream, header, raw, cls, sorted);
+    hipLaunchKernelGGL(k_soil_hist, dim3(512), dim3(kBlock), 0, c->stream, header, cls);
+    hipLaunchKernelGGL(k_soil_scatter, dim3(512), dim3(kBlock), 0, c->stream, header, raw, cls, sorted);
     hipLaunchKernelGGL(k_soil_columns_deferred, dim3(4096), dim3(kBlock), 0, c->stream, *a, P, header, sorted);
     LF_HIP(hipGetLastError());
     return LF_OK;
