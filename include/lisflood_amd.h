@@ -160,6 +160,11 @@ typedef struct lf_substep_args {
  * sumDisDay, FlowVelocity/TravelDistance.  All pointers are device memory, all in the same order
  * (pixel order, or engine order when engine_order = 1). */
 int lf_routing_substep(lf_router *r, const lf_substep_args *a);
+/* nsteps consecutive sub-steps as one skewed wavefront over (level, sub-step): NL + nsteps - 1 launches
+ * instead of nsteps x (1..2) x NL.  Needs engine_order = 1.  a->SideflowChanM3 holds the sideflow of every
+ * sub-step: sideflow_stride = 0 (one vector used by all sub-steps) or N (nsteps vectors back to back).
+ * Bit-identical to nsteps calls of lf_routing_substep. */
+int lf_routing_substeps_fused(lf_router *r, const lf_substep_args *a, int nsteps, int64_t sideflow_stride);
 
 /* ---------------------------------------------------------------------------------------------
  * LDD one-hop upstream reduction == np.bincount(downstruct, weights)[:N] (routing.py:159-164,

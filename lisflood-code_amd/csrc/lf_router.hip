@@ -18,6 +18,7 @@
 // "narrow" levels (the workgroup walks the levels with a barrier between them).  A dependent kernel
 // boundary costs ~1.5 us on MI355X, less than any software grid barrier (4-7 us), so wide levels
 // are separated by launches, not by in-kernel synchronisation.
+#include <algorithm>
 #include <cmath>
 
 #include <cstdlib>
@@ -107,7 +108,7 @@ struct lf_router {
     bool fused = false; // beta == 3/5: prep fused into the sweep, polynomial closure solve (lf_math.h)
     lf_dbuf<int32_t> perm, ups_ptr;
     lf_dbuf<long long> level_start;
-    lf_dbuf<double> a1, a2, dx, constant, qord, io_q, io_lat, tmp_ord;
+    lf_dbuf<double> a1, a2, dx, constant, qord, io_q, io_lat, tmp_ord, fused_qr1, fused_qr2;
     lf_dbuf<unsigned long long> counter;
     std::vector<int64_t> h_level_start;
     std::vector<segment> schedule;
@@ -600,6 +601,175 @@ extern "C" int lf_routing_substep(lf_router *r, const lf_substep_args *a)
         hipLaunchKernelGGL(k_substep_floodplain, grid, block, 0, s, n, *a);
     }
     LF_HIP(hipGetLastError());
+    return LF_OK;
+}
+
+// ================================================================================================
+// Fused multi-sub-step routing: the NoRoutSteps sub-steps of a model step (Lisflood_dynamic.py:179-180) as ONE
+// skewed wavefront.  Sub-step s+1 of a cell needs only the cell's own state after sub-step s and the
+// sub-step-(s+1) router output of its upstream cells (one level up), so launch t processes every (level k,
+// sub-step s) with k + s = t: NL + S - 1 launches instead of S x (1..2) x NL, each S times wider.  Router
+// outputs live in two parity buffers per section (sub-step s writes buffer s&1, which sub-step s+2 may only
+// overwrite one launch after its last reader).  Arithmetic per cell is exactly that of lf_routing_substep, so
+// the result is bit-identical to S sequential sub-steps.  Valid when the sideflow of every sub-step is known
+// up front (stride 0: the same vector for all sub-steps, as in the model when no lake / reservoir sits in the
+// loop; stride N: one vector per sub-step).
+// ================================================================================================
+namespace {
+
+struct fused_args {
+    lf_substep_args S;
+    const int *__restrict__ ups_ptr;
+    const double *__restrict__ a1, *__restrict__ a2, *__restrict__ dx;
+    const long long *__restrict__ level_start;
+    double *qr1, *qr2; // [2][N] router outputs by sub-step parity (main channel / floodplains)
+    long long n, side_stride;
+    double dx_scalar, beta, inv_beta, b_minus_1;
+    int kmax, nlevels, nsteps, t;
+};
+
+__device__ __forceinline__ double solve_any(double c, double ap, bool b35, const fused_args &F)
+{
+    if (b35 && lf_fast_range(c) && lf_fast_range(ap)) return (c <= LF_NEWTON_TOL) ? 0.0 : lf_solve_3_5(c, ap);
+    return lf_solve_cell(c, ap, F.beta * ap, F.beta, F.inv_beta, F.b_minus_1);
+}
+
+__device__ __forceinline__ double upstream_sum8(const double *q, int u0, int u1, int kmax)
+{
+    double v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = (k < kmax && u0 + k < u1) ? q[u0 + k] : 0.0;
+    double ups = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ups += v[k];
+    return ups;
+}
+
+template <bool SPLIT>
+__global__ void __launch_bounds__(kBlock) k_fused_substeps(fused_args F)
+{
+    const int s = blockIdx.y;          // sub-step
+    const int k = F.t - s;             // level handled by this sub-step at wave time t
+    if (k < 0 || k >= F.nlevels) return;
+    const long long first = F.level_start[k];
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= F.level_start[k + 1] - first) return;
+    const long long p = first + i;
+    const lf_substep_args &A = F.S;
+    const bool b35 = F.beta == 0.6;
+    const long long par = (long long)(s & 1) * F.n;
+    const double dxp = F.dx ? F.dx[p] : F.dx_scalar;
+    const double inv_len = A.InvChanLength[p], len = A.ChanLength[p];
+    const int u0 = F.ups_ptr[p], u1 = F.ups_ptr[p + 1];
+    // sideflow (routing.py:512, 524 / 549-567)
+    double side = A.IsChannelKinematic[p] ? A.SideflowChanM3[(long long)s * F.side_stride + p] * inv_len * A.InvDtRouting : 0.0;
+    double s1 = side, s2 = 0.0;
+    if (!SPLIT) {
+        if (isnan(side)) s1 = 0.0;
+    } else {
+        const double m3 = A.ChanM3Kin[p], m3_2 = A.Chan2M3Kin[p];
+        const double tot = m3 + m3_2;
+        const double ratio = (tot > 0) ? m3 / tot : 0.0;
+        s1 = ((tot - A.Chan2M3Start[p]) > A.M3Limit[p]) ? ratio * side : side;
+        if (fabs(side) < 1e-7) s1 = side;
+        A.Sideflow1Chan[p] = s1;
+        s2 = (side - s1) + A.Chan2QStart[p] * inv_len;
+    }
+    // main channel: router call + fix-up (routing.py:526-532 / 573-578)
+    const double ap1 = F.a1[p];
+    const double qold = A.ChanQKin[p];
+    const double cst = ap1 * (b35 ? lf_pow_3_5(qold) : pow(qold, F.beta)) + s1 * dxp;
+    const double c = upstream_sum8(F.qr1 + par, u0, u1, F.kmax) + cst;
+    const double qr = solve_any(c, ap1, b35, F);
+    F.qr1[par + p] = qr;
+    double v = len * A.ChannelAlpha[p] * (b35 ? lf_pow_3_5(qr) : pow(qr, A.Beta));
+    if (v < 0.0) v = 0.0;
+    const double x = v * inv_len * A.InvChannelAlpha[p];
+    const double q = b35 ? lf_pow_5_3(x) : pow(x, A.InvBeta);
+    A.ChanM3Kin[p] = v;
+    A.ChanQKin[p] = q;
+    const bool last = s == F.nsteps - 1;
+    if (!SPLIT) {
+        A.ChanQ[p] = q;
+        A.sumDisDay[p] += q;
+        if (last) velocity(A, (int)p, v, q);
+        return;
+    }
+    // floodplains (routing.py:583-603)
+    const double ap2 = F.a2[p];
+    const double q2old = A.Chan2QKin[p];
+    const double cst2 = ap2 * (b35 ? lf_pow_3_5(q2old) : pow(q2old, F.beta)) + s2 * dxp;
+    const double c2 = upstream_sum8(F.qr2 + par, u0, u1, F.kmax) + cst2;
+    const double q2r = solve_any(c2, ap2, b35, F);
+    F.qr2[par + p] = q2r;
+    const double start = A.Chan2M3Start[p];
+    double v2 = len * A.ChannelAlpha2[p] * (b35 ? lf_pow_3_5(q2r) : pow(q2r, A.Beta));
+    if ((v2 - start) < 0.0) v2 = start;
+    A.Chan2M3Kin[p] = v2;
+    A.CrossSection2Area[p] = (v2 - start) * inv_len;
+    const double x2 = v2 * inv_len * A.InvChannelAlpha2[p];
+    const double q2 = b35 ? lf_pow_5_3(x2) : pow(x2, A.InvBeta);
+    A.Chan2QKin[p] = q2;
+    double qq = q + q2 - A.QLimit[p];
+    if (qq < 0.0) qq = 0.0;
+    A.ChanQ[p] = qq;
+    A.sumDisDay[p] += qq;
+    if (last) velocity(A, (int)p, v, q);
+}
+
+} // namespace
+
+extern "C" int lf_routing_substeps_fused(lf_router *r, const lf_substep_args *a, int nsteps, int64_t sideflow_stride)
+{
+    if (!r || !a || nsteps < 1) return lf_set_error(LF_E_INVALID, "bad argument");
+    if (!a->engine_order) return lf_set_error(LF_E_INVALID, "the fused sub-step wavefront needs engine-order vectors");
+    if (a->split && !r->has_floodplains)
+        return lf_set_error(LF_E_SECTION, "split routing requested but the router has no floodplain alpha");
+    if (sideflow_stride != 0 && sideflow_stride != r->N) return lf_set_error(LF_E_INVALID, "sideflow_stride must be 0 or N");
+    LF_HIP(hipSetDevice(r->device));
+    const int64_t n = r->N;
+    if (n == 0) return LF_OK;
+    if (!r->fused_qr1.p) LF_TRY(r->fused_qr1.alloc(2 * n));
+    if (a->split && !r->fused_qr2.p) LF_TRY(r->fused_qr2.alloc(2 * n));
+    fused_args F;
+    F.S = *a;
+    F.ups_ptr = r->ups_ptr.p;
+    F.a1 = r->a1.p;
+    F.a2 = r->a2.p;
+    F.dx = r->dx_per_pixel ? r->dx.p : nullptr;
+    F.level_start = r->level_start.p;
+    F.qr1 = r->fused_qr1.p;
+    F.qr2 = r->fused_qr2.p;
+    F.n = n;
+    F.side_stride = sideflow_stride;
+    F.dx_scalar = r->dx_scalar;
+    F.beta = r->beta;
+    F.inv_beta = r->inv_beta;
+    F.b_minus_1 = r->b_minus_1;
+    F.kmax = r->kmax;
+    F.nlevels = (int)r->NL;
+    F.nsteps = nsteps;
+    hipStream_t s = r->ctx->stream;
+    const int NL = (int)r->NL;
+    int64_t launches = 0;
+    for (int t = 0; t < NL + nsteps - 1; ++t) {
+        // widest level inside the window [t - nsteps + 1, t]
+        const int k_lo = std::max(0, t - nsteps + 1), k_hi = std::min(NL - 1, t);
+        int64_t widest = 0;
+        for (int k = k_lo; k <= k_hi; ++k) widest = std::max(widest, r->h_level_start[k + 1] - r->h_level_start[k]);
+        F.t = t;
+        const dim3 grid(blocks_for(widest), nsteps), block(kBlock);
+        if (a->split)
+            hipLaunchKernelGGL(k_fused_substeps<true>, grid, block, 0, s, F);
+        else
+            hipLaunchKernelGGL(k_fused_substeps<false>, grid, block, 0, s, F);
+        ++launches;
+    }
+    LF_HIP(hipGetLastError());
+    r->last_stats[0] = launches;
+    r->last_stats[1] = launches;
+    r->last_stats[2] = 0;
+    r->last_stats[3] = r->NL;
     return LF_OK;
 }
 

@@ -162,6 +162,19 @@ class routing(HydroModule):
                 s -= v.ChannelToPolderM3Dt
         return s
 
+    def dynamic_fused(self, sideflows=None):
+        """All NoRoutSteps sub-steps of a model step in one call (the loop of Lisflood_dynamic.py:179-180), run as a
+        skewed wavefront over (level, sub-step) on the device -- NL + NoRoutSteps - 1 launches instead of
+        NoRoutSteps x (1..2) x NL.  `sideflows`: SideflowChanM3 of the step -- one [N] vector (the model's case
+        when nothing in the loop changes it) or [NoRoutSteps, N]; default: assembled from `var` as in dynamic().
+        Bit-identical to calling dynamic(0..NoRoutSteps-1).  In-loop modules (lakes, reservoirs...) cannot run
+        inside the wavefront; use dynamic() when they are active."""
+        if self.river_router is None:
+            raise RuntimeError("routing.initialSecond()/attach_router() must be called first")
+        if self.inloop_modules:
+            raise RuntimeError("dynamic_fused cannot run in-loop modules; use dynamic()")
+        _fused(self, self.sideflow_m3() if sideflows is None else sideflows)
+
     def dynamic(self, NoRoutingExecuted):
         """One routing sub-step (routing.py:435-706)."""
         if self.river_router is None:
@@ -179,6 +192,47 @@ class routing(HydroModule):
             pass
         if not self._resident:
             self._download_state()
+
+
+def _fused(self, sideflows):
+    """See routing.dynamic_fused."""
+    v = self.var
+    r = self.river_router
+    N = r.num_pixels
+    perm = r.graph.layout()[0].astype(np.int64)
+    sideflows = np.ascontiguousarray(np.atleast_2d(np.asarray(sideflows, dtype=np.float64)))
+    nsteps_in, stride = (sideflows.shape[0], N) if sideflows.shape[0] > 1 else (1, 0)
+    nsteps = int(v.NoRoutSteps)
+    if stride and nsteps_in != nsteps:
+        raise ValueError("need one sideflow vector, or NoRoutSteps of them")
+    a = _SubstepArgs()
+    dev = {}
+    zeros = np.zeros(N)
+    for k in _STATIC:
+        x = getattr(v, k, None)
+        if x is None:
+            x = np.ones(N, bool) if k == "IsChannelKinematic" else zeros
+        x = np.broadcast_to(x, (N,))[perm]
+        dev[k] = DeviceArray.from_host(u8(x) if k == "IsChannelKinematic" else f64(x), self.device)
+    for k in _STATE:
+        x = getattr(v, k, None)
+        dev[k] = DeviceArray.from_host(f64(np.broadcast_to(zeros if x is None else x, (N,))[perm]), self.device)
+    for k in _OUT + ["scratch0", "scratch1"]:
+        dev[k] = DeviceArray(N, np.float64, self.device).zero()
+    dev["SideflowChanM3"] = DeviceArray.from_host(np.ascontiguousarray(sideflows[:, perm]), self.device)
+    for k, d in dev.items():
+        setattr(a, k, d.ptr.value)
+    a.Beta, a.InvBeta, a.InvDtRouting, a.DtSec = float(v.Beta), float(v.InvBeta), float(v.InvDtRouting), float(v.DtSec)
+    a.split = 1 if self._split() else 0
+    a.engine_order = 1
+    check(lib().lf_routing_substeps_fused(r._h, C.byref(a), C.c_int(nsteps), C.c_int64(stride)))
+    names = _STATE + _OUT if self._split() else ["ChanQKin", "ChanM3Kin", "ChanQ", "sumDisDay"] + _OUT
+    for k in names:
+        out = np.empty(N)
+        out[perm] = dev[k].download()
+        setattr(v, k, out)
+    for d in dev.values():
+        d.free()
 
 
 def var_from_fixture(g):

@@ -253,6 +253,50 @@ def test_routing_substeps_golden(amd, solver, mode):
                     close(getattr(v, k), g["out_" + k][i], (mode, s, k))
 
 
+@pytest.mark.parametrize("mode", ["split", "single"])
+def test_routing_substeps_fused_wavefront(amd, solver, mode):
+    """The 24 sub-steps of a model step as ONE skewed wavefront (lf_routing_substeps_fused): must reproduce the
+    reference-captured end state and be bit-identical to 24 sequential sub-steps of the same engine."""
+    g = golden("substep_" + mode)
+    n = int(g["NoRoutSteps"])
+    split = mode == "split"
+    # sequential
+    v1 = amd.routing.var_from_fixture(g)
+    m1 = amd.routing.routing(v1, split_routing=split)
+    m1.attach_router(g["codes"], g["mask"])
+    for s in range(n):
+        v1.ToChanM3RunoffDt = g["ToChanM3RunoffDt"][s]
+        m1.dynamic(s)
+    # fused, one sideflow vector per sub-step
+    v2 = amd.routing.var_from_fixture(g)
+    m2 = amd.routing.routing(v2, split_routing=split)
+    m2.attach_router(g["codes"], g["mask"])
+    m2.dynamic_fused(g["ToChanM3RunoffDt"])
+    st = m2.river_router.last_launches()
+    assert st["launches"] == st["levels"] + n - 1
+    keys = ["ChanQKin", "ChanM3Kin", "ChanQ", "sumDisDay", "FlowVelocity", "TravelDistance"]
+    if split:
+        keys += ["Chan2QKin", "Chan2M3Kin", "CrossSection2Area", "Sideflow1Chan"]
+    last = g["sampled"].tolist().index(n - 1)
+    for k in keys:
+        assert np.array_equal(getattr(v1, k), getattr(v2, k), equal_nan=True), k
+        if k == "CrossSection2Area":
+            scale = float(np.max(np.abs(g["Chan2M3Start"] / g["ChanLength"])))
+            np.testing.assert_allclose(getattr(v2, k), g["out_" + k][last], rtol=RTOL, atol=RTOL * scale)
+        else:
+            close(getattr(v2, k), g["out_" + k][last], (mode, k))
+    # one sideflow vector shared by all sub-steps (the model's case) == sequential with that vector
+    v3 = amd.routing.var_from_fixture(g); v4 = amd.routing.var_from_fixture(g)
+    m3 = amd.routing.routing(v3, split_routing=split); m3.attach_router(g["codes"], g["mask"])
+    m4 = amd.routing.routing(v4, split_routing=split); m4.attach_router(g["codes"], g["mask"])
+    v3.ToChanM3RunoffDt = v4.ToChanM3RunoffDt = g["ToChanM3RunoffDt"][3]
+    for s in range(n):
+        m3.dynamic(s)
+    m4.dynamic_fused()
+    for k in keys:
+        assert np.array_equal(getattr(v3, k), getattr(v4, k), equal_nan=True), k
+
+
 def test_interception_golden(amd):
     g = golden("interception")
     st = {k: g["in_" + k].copy() for k in ("Interception", "TaInterception", "LeafDrainage", "CumInterception")}
