@@ -626,6 +626,7 @@ struct fused_args {
     long long n, side_stride;
     double dx_scalar, beta, inv_beta, b_minus_1;
     int kmax, nlevels, nsteps, t;
+    int solve35; // router runs the beta = 3/5 quintic solve (false: general path, e.g. LF_GENERAL_POW=1)
 };
 
 __device__ __forceinline__ double solve_any(double c, double ap, bool b35, const fused_args &F)
@@ -656,7 +657,8 @@ __global__ void __launch_bounds__(kBlock) k_fused_substeps(fused_args F)
     if (i >= F.level_start[k + 1] - first) return;
     const long long p = first + i;
     const lf_substep_args &A = F.S;
-    const bool b35 = F.beta == 0.6;
+    const bool b35 = A.Beta == 0.6;     // fix-up round trips, as k_substep_main / k_substep_floodplain
+    const bool s35 = F.solve35 != 0;    // router solve + old-discharge term, as the router itself
     const long long par = (long long)(s & 1) * F.n;
     const double dxp = F.dx ? F.dx[p] : F.dx_scalar;
     const double inv_len = A.InvChanLength[p], len = A.ChanLength[p];
@@ -678,9 +680,9 @@ __global__ void __launch_bounds__(kBlock) k_fused_substeps(fused_args F)
     // main channel: router call + fix-up (routing.py:526-532 / 573-578)
     const double ap1 = F.a1[p];
     const double qold = A.ChanQKin[p];
-    const double cst = ap1 * (b35 ? lf_pow_3_5(qold) : pow(qold, F.beta)) + s1 * dxp;
+    const double cst = ap1 * (s35 ? lf_pow_3_5(qold) : pow(qold, F.beta)) + s1 * dxp;
     const double c = upstream_sum8(F.qr1 + par, u0, u1, F.kmax) + cst;
-    const double qr = solve_any(c, ap1, b35, F);
+    const double qr = solve_any(c, ap1, s35, F);
     F.qr1[par + p] = qr;
     double v = len * A.ChannelAlpha[p] * (b35 ? lf_pow_3_5(qr) : pow(qr, A.Beta));
     if (v < 0.0) v = 0.0;
@@ -698,9 +700,9 @@ __global__ void __launch_bounds__(kBlock) k_fused_substeps(fused_args F)
     // floodplains (routing.py:583-603)
     const double ap2 = F.a2[p];
     const double q2old = A.Chan2QKin[p];
-    const double cst2 = ap2 * (b35 ? lf_pow_3_5(q2old) : pow(q2old, F.beta)) + s2 * dxp;
+    const double cst2 = ap2 * (s35 ? lf_pow_3_5(q2old) : pow(q2old, F.beta)) + s2 * dxp;
     const double c2 = upstream_sum8(F.qr2 + par, u0, u1, F.kmax) + cst2;
-    const double q2r = solve_any(c2, ap2, b35, F);
+    const double q2r = solve_any(c2, ap2, s35, F);
     F.qr2[par + p] = q2r;
     const double start = A.Chan2M3Start[p];
     double v2 = len * A.ChannelAlpha2[p] * (b35 ? lf_pow_3_5(q2r) : pow(q2r, A.Beta));
@@ -749,6 +751,7 @@ extern "C" int lf_routing_substeps_fused(lf_router *r, const lf_substep_args *a,
     F.kmax = r->kmax;
     F.nlevels = (int)r->NL;
     F.nsteps = nsteps;
+    F.solve35 = r->fused ? 1 : 0;
     hipStream_t s = r->ctx->stream;
     const int NL = (int)r->NL;
     int64_t launches = 0;
