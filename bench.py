@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads / soil kernel")
     ap.add_argument("--cpu-sample", type=int, default=2000, help="CPU baseline raster is sample x sample")
-    ap.add_argument("--only", choices=["soil"], default=None, help="run only the named secondary benchmark")
+    ap.add_argument("--only", choices=["soil", "model_step"], default=None, help="run only the named secondary benchmark")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the row-block/RCCL path even with a single rank (smoke test of that path)")
     ap.add_argument("--calibrate", action="store_true",
@@ -220,6 +220,59 @@ def soil_bench(N=4_000_000, steps=10):
                 frac_hbm=round(gbs / HBM_PEAK_GBS, 4), multi_substep_columns_frac=round(nd.value / cols, 4))
 
 
+def model_step_bench(size=5000, nsteps=24):
+    """One LISFLOOD model step of channel routing on the `deep` raster: NoRoutSteps = 24 sub-steps, split routing
+    (2 router calls per sub-step) = 48 cell-steps per cell, all vectors resident in engine order.
+    `fused` = lf_routing_substeps_fused (one skewed wavefront), `sequential` = 24 x lf_routing_substep."""
+    from lisflood_amd import _lib
+    from lisflood_amd import synthetic as syn
+    from lisflood_amd.kinematic_wave_parallel import Graph, kinematicWave
+    from lisflood_amd.routing_device import RoutingStepDevice
+    H = W = size
+    N = H * W
+    codes = syn.make_ldd("deep", H, W, 2)
+    p = syn.router_params(N)
+    rng = np.random.default_rng(17)
+    beta, dt = p["beta"], 3600.0
+    alpha, length = p["alpha"], p["dx"]
+    alpha2 = alpha * rng.uniform(1.2, 2.0, N)
+    g = Graph(ldd_raster=codes)
+    kw = kinematicWave(None, None, alpha, beta, length, dt, alpha_floodplains=alpha2, graph=g)
+    qlimit = 2.0 * p["Q0"] * rng.uniform(0.3, 1.2, N)
+    vals = dict(ChanLength=length, InvChanLength=1 / length, ChannelAlpha=alpha, InvChannelAlpha=1 / alpha,
+                ChannelAlpha2=alpha2, InvChannelAlpha2=1 / alpha2, QLimit=qlimit,
+                M3Limit=alpha * length * qlimit ** beta, Chan2M3Start=alpha2 * length * qlimit ** beta,
+                Chan2QStart=qlimit * 0.1, PixelArea=np.full(N, 2.5e7), IsChannelKinematic=np.ones(N, bool),
+                SideflowChanM3=syn.lateral_inflow(N, 0) * length * dt)
+    m3 = alpha * length * p["Q0"] ** beta
+    vals["Chan2M3Kin"] = vals["Chan2M3Start"].copy()
+    vals["ChanM3Kin"] = m3
+    vals["ChanQKin"] = p["Q0"].copy()
+    vals["Chan2QKin"] = (vals["Chan2M3Kin"] / length / alpha2) ** (1 / beta)
+    out = {}
+    ref = None
+    for mode in ("fused", "sequential"):
+        st = RoutingStepDevice(kw, vals, True, beta, 1.0 / dt, dt * nsteps)
+        run = st.run_fused if mode == "fused" else st.run_sequential
+        reps = 3 if mode == "fused" else 1
+        if mode == "fused":
+            run(nsteps)                  # warm-up
+        _lib.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            run(nsteps)
+        _lib.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3 / reps
+        out[mode] = dict(ms_per_model_step=round(ms, 3), value=round(2 * nsteps * N / ms / 1e3, 2),
+                         unit="Mcell-steps/s", launches_per_model_step=kw.last_launches()["launches"] *
+                         (1 if mode == "fused" else 2 * nsteps))
+        st.free()
+    out["config"] = "%dx%d deep LDD (NL=%d), NoRoutSteps=%d, split routing: %d cell-steps per cell per model step" % (
+        H, W, g.num_levels, nsteps, 2 * nsteps)
+    kw.close()
+    return out
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -228,6 +281,9 @@ def main():
         return dist_bench.main(a)
     if a.only == "soil":
         print(json.dumps(soil_bench()), flush=True)
+        return
+    if a.only == "model_step":
+        print(json.dumps(model_step_bench(min(a.size, 5000))), flush=True)
         return
     H = W = a.size
     if a.calibrate:
@@ -286,6 +342,10 @@ def main():
             extra["soil"] = soil_bench()
         except Exception as e:
             extra["soil_error"] = repr(e)
+        try:
+            extra["model_step_24_substeps_split"] = model_step_bench()
+        except Exception as e:
+            extra["model_step_error"] = repr(e)
         out["other_workloads"] = extra
     if not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.family, a.cpu_sample)
