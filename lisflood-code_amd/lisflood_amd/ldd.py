@@ -1,0 +1,101 @@
+"""PCRaster-free LDD operations on compressed vectors.
+
+The reference calls PCRaster 4.3.3 (un-vendored C++) for these at initialisation: `lddmask`, `lddrepair`, `pit`,
+`downstream`, `upstream`, `accuflux`, `catchment`, `uniqueid` (routing.py:90-171, 387; structures.py:51-59).
+They are restated here from PCRaster's documented semantics on the engine's own graph (host side: init-time
+work, exactly as in the reference).  No reference test pins them at unit level -- PARITY UNPINNED except
+`accuflux`, which reproduces the reference's `ec_upArea.nc` where the test mask is upstream-closed, and the
+one-hop `upstream`, pinned by the np.bincount fixture.
+
+All functions take / return 1-D vectors over the land pixels of `land_mask` (row-major, add1.py:268-305).
+"""
+import numpy as np
+
+from .kinematic_wave_parallel import Graph
+
+PIT = 5
+_ROW = {2: 1, 3: 1, 6: 0, 9: -1, 8: -1, 7: -1, 4: 0, 1: 1}
+_COL = {2: 0, 3: 1, 6: 1, 9: 1, 8: 0, 7: -1, 4: -1, 1: -1}
+
+
+def _raster(codes, land_mask, fill=0):
+    r = np.full(land_mask.shape, fill, dtype=np.asarray(codes).dtype)
+    r[land_mask] = codes
+    return r
+
+
+def downstream_index(codes, land_mask):
+    """pixel id of the downstream neighbour, -1 if the cell is a pit or drains off the map / out of the mask."""
+    return Graph(np.asarray(codes, np.float64), land_mask).lookups()[0].astype(np.int64)
+
+
+def lddmask(codes, land_mask, keep):
+    """PCRaster lddmask(ldd, mask): the LDD cut to `keep` (bool per land pixel).  Returns (codes, land_mask) of the
+    sub-domain; a cell whose downstream neighbour is outside `keep` becomes a pit (routing.py:90, 118)."""
+    keep = np.asarray(keep, bool)
+    down = downstream_index(codes, land_mask)
+    out = np.asarray(codes).copy()
+    lost = (down >= 0) & ~keep[np.maximum(down, 0)]
+    out[lost] = PIT
+    sub = land_mask.copy()
+    sub[land_mask] = keep
+    return out[keep], sub
+
+
+def lddrepair(codes, land_mask):
+    """PCRaster lddrepair: cells draining to a missing value or off the map become pits (routing.py:125)."""
+    c = np.asarray(codes).copy()
+    down = downstream_index(c, land_mask)
+    valid = np.isin(c, (1, 2, 3, 4, 6, 7, 8, 9))
+    c[(down < 0) | ~valid] = PIT
+    return c
+
+
+def pit(codes):
+    """PCRaster pit(ldd): unique id 1..n (row-major) at pit cells, 0 elsewhere (routing.py:127)."""
+    c = np.asarray(codes)
+    out = np.zeros(c.shape, np.int64)
+    is_pit = c == PIT
+    out[is_pit] = np.arange(1, int(is_pit.sum()) + 1)
+    return out
+
+
+def uniqueid(flags):
+    """PCRaster uniqueid: 1..n (row-major) where `flags` is true, 0 elsewhere (routing.py:166)."""
+    f = np.asarray(flags, bool)
+    out = np.zeros(f.shape, np.int64)
+    out[f] = np.arange(1, int(f.sum()) + 1)
+    return out
+
+
+def downstream(codes, land_mask, x):
+    """PCRaster downstream(ldd, x): value of x at the downstream neighbour; pits keep their own value
+    (routing.py:141, 162; structures.py:51)."""
+    x = np.asarray(x)
+    down = downstream_index(codes, land_mask)
+    return np.where(down >= 0, x[np.maximum(down, 0)], x)
+
+
+def downstruct(codes, land_mask):
+    """routing.py:159-164: id of the downstream pixel, pits get N (the "drop" bin of np.bincount)."""
+    down = downstream_index(codes, land_mask)
+    N = down.size
+    out = np.where(down >= 0, down, N).astype(np.int32)
+    out[np.asarray(codes) == PIT] = N
+    return out
+
+
+def catchment(codes, land_mask, points):
+    """PCRaster catchment(ldd, points): every cell gets the id of the first non-zero point met going downstream
+    (a point cell belongs to its own catchment); 0 if none (routing.py:168-171)."""
+    g = Graph(np.asarray(codes, np.float64), land_mask)
+    down = g.lookups()[0].astype(np.int64)
+    po, ss = g.orders()
+    pts = np.asarray(points).astype(np.int64)
+    lab = np.zeros(pts.shape, np.int64)
+    for k in range(ss.shape[0] - 1, -1, -1):            # outlets first, then upstream level by level
+        cells = po[ss[k, 0]:ss[k, 1]]
+        d = down[cells]
+        inherited = np.where(d >= 0, lab[np.maximum(d, 0)], 0)
+        lab[cells] = np.where(pts[cells] != 0, pts[cells], inherited)
+    return lab

@@ -57,6 +57,101 @@ class routing(HydroModule):
         self._resident = False
 
     # ------------------------------------------------------------------------------------------
+    def initial(self, maps, land_mask):
+        """routing.initial (routing.py:61-339) from arrays the caller has loaded (map / netCDF loading and the
+        settings layer are outside this engine).  `maps`: dict of compressed vectors / scalars keyed by the
+        reference's binding names: beta, ChanLength, Ldd, Channels, ChanGrad, ChanGradMin, CalChanMan, ChanMan,
+        ChanBottomWidth, ChanDepthThreshold, ChanSdXdY, PixelArea and optionally TotalCrossSectionAreaInitValue,
+        PrevDischarge, CrossSection2AreaInitValue, PrevSideflowInitValue (-9999 / missing = cold start).
+        PCRaster's LDD operations are replaced by lisflood_amd.ldd (parity unpinned at that level)."""
+        from . import ldd as L
+        v, o = self.var, self.options
+        g = lambda k, d=None: maps[k] if k in maps else d
+        N = int(np.asarray(land_mask, bool).sum())
+        zero = np.zeros(N)
+        v.avgdis = zero.copy()
+        v.Beta = float(g('beta'))                                               # :66
+        v.InvBeta = 1 / v.Beta
+        v.ChanLength = np.broadcast_to(np.asarray(g('ChanLength'), float), (N,)).copy()
+        v.InvChanLength = 1 / v.ChanLength
+        v.NoRoutSteps = int(np.maximum(1, round(v.DtSec / v.DtSecChannel, 0)))  # :73
+        if o.get('InitLisflood'):
+            v.NoRoutSteps = 1
+        v.DtRouting = v.DtSec / v.NoRoutSteps
+        v.InvDtRouting = 1 / v.DtRouting
+        v.InvNoRoutSteps = 1 / float(v.NoRoutSteps)
+        codes = np.asarray(g('Ldd'), float)
+        v.PixelArea = np.broadcast_to(np.asarray(g('PixelArea'), float), (N,)).copy()
+        v.Ldd = L.lddrepair(codes, land_mask)                                   # lddmask(Ldd, MaskMap), :90
+        kw_all = kinematicWave(v.Ldd, land_mask, np.ones(N), v.Beta, 1.0, 1.0, device=self.device)
+        v.UpArea = kw_all.accuflux(v.PixelArea)                                 # :98
+        v.InvUpArea = 1 / v.UpArea
+        v.IsChannel = np.asarray(g('Channels')).astype(bool)                    # :107-108
+        v.IsChannelKinematic = v.IsChannel.copy()
+        v.IsStructureKinematic = np.zeros(N, bool)
+        ldd_chan_codes, chan_mask = L.lddmask(v.Ldd, land_mask, v.IsChannel)    # :118
+        v.LddKinematic = np.zeros(N)                                            # non-channel cells: code 0 (no flow)
+        v.LddKinematic[v.IsChannel] = ldd_chan_codes
+        v.LddToChan = L.lddrepair(np.where(v.IsChannel, L.PIT, v.Ldd), land_mask)  # :125
+        v.AtLastPointC = v.Ldd == L.PIT                                         # boolean(pit(Ldd)), :127,155-156
+        v.downstruct = L.downstruct(v.LddKinematic, land_mask)                  # :159-164
+        v.Catchments = L.catchment(v.Ldd, land_mask, L.uniqueid(v.AtLastPointC)).astype(np.int32)   # :168-171
+        CatchArea = np.bincount(v.Catchments, weights=v.PixelArea)[v.Catchments]
+        v.InvCatchArea = 1 / CatchArea
+        # channel geometry, :184-199
+        v.ChanGrad = np.maximum(g('ChanGrad'), g('ChanGradMin'))
+        v.CalChanMan = np.asarray(g('CalChanMan'), float)
+        v.ChanMan = v.CalChanMan * g('ChanMan')
+        v.ChanBottomWidth = np.asarray(g('ChanBottomWidth'), float)
+        depth, sdxdy = np.asarray(g('ChanDepthThreshold'), float), np.asarray(g('ChanSdXdY'), float)
+        v.ChanUpperWidth = v.ChanBottomWidth + 2 * sdxdy * depth
+        v.TotalCrossSectionAreaBankFull = 0.5 * depth * (v.ChanUpperWidth + v.ChanBottomWidth)
+        half = 0.5 * v.TotalCrossSectionAreaBankFull
+        init = np.broadcast_to(np.asarray(g('TotalCrossSectionAreaInitValue', -9999.0), float), (N,))
+        v.TotalCrossSectionArea = np.where(init == -9999, half, init)           # :203-204
+        if o.get('SplitRouting'):
+            c2 = np.broadcast_to(np.asarray(g('CrossSection2AreaInitValue', -9999.0), float), (N,))
+            v.CrossSection2Area = np.where(c2 == -9999, zero, c2)               # :210-212
+            ps = np.broadcast_to(np.asarray(g('PrevSideflowInitValue', -9999.0), float), (N,))
+            v.Sideflow1Chan = np.where(ps == -9999, zero, ps)                   # :216-218
+        # channel alpha, :227-236
+        d_alpha = np.where(v.IsChannel, 0.5 * depth, 0.0)
+        v.ChanWettedPerimeterAlpha = v.ChanBottomWidth + 2 * np.sqrt(np.square(d_alpha) + np.square(d_alpha * sdxdy))
+        AlpTermChan = (v.ChanMan / (np.sqrt(v.ChanGrad))) ** v.Beta
+        v.AlpPow = 2.0 / 3.0 * v.Beta
+        v.ChannelAlpha = (AlpTermChan * (v.ChanWettedPerimeterAlpha ** v.AlpPow)).astype(float)
+        with np.errstate(divide="ignore"):
+            v.InvChannelAlpha = 1 / v.ChannelAlpha
+        # initial volume and discharge, :243-248, 326-327
+        v.ChanM3 = v.TotalCrossSectionArea * v.ChanLength
+        v.ChanIniM3 = v.ChanM3.copy()
+        v.ChanM3Kin = v.ChanIniM3.copy().astype(float)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            v.ChanQKin = np.where(v.ChannelAlpha > 0, (v.TotalCrossSectionArea / v.ChannelAlpha) ** v.InvBeta, 0).astype(float)
+        v.CumQ = zero.copy()
+        prev = np.broadcast_to(np.asarray(g('PrevDischarge', -9999.0), float), (N,))
+        v.ChanQ = np.where(prev == -9999, v.ChanQKin, prev)
+        v.DischargeM3Out, v.TotalQInM3, v.sumDis, v.sumInWB = zero.copy(), zero.copy(), zero.copy(), zero.copy()
+        self._land_mask = np.asarray(land_mask, bool)
+        kw_all.close()
+
+    def step_end(self, time_since_start=None):
+        """What Lisflood_dynamic.py:194-229 does after the sub-step loop: ChanM3, TotalCrossSectionArea, sumDis,
+        ChanQAvg (= `dis` of the reference's outputs), avgdis, DischargeM3Out."""
+        v, o = self.var, self.options
+        if o.get('InitLisflood') or not o.get('SplitRouting'):
+            v.ChanM3 = v.ChanM3Kin.copy()
+        else:
+            v.ChanM3 = v.ChanM3Kin + v.Chan2M3Kin - v.Chan2M3Start
+        v.TotalCrossSectionArea = v.ChanM3 * v.InvChanLength
+        v.sumDis = getattr(v, "sumDis", 0.0) + v.sumDisDay
+        v.ChanQAvg = v.sumDisDay / v.NoRoutSteps
+        if (o.get('InitLisflood') or o.get('repAverageDis')) and time_since_start:
+            v.CumQ = getattr(v, "CumQ", 0.0) + v.ChanQ
+            v.avgdis = v.CumQ / time_since_start
+        if hasattr(v, "AtLastPointC"):
+            v.DischargeM3Out = getattr(v, "DischargeM3Out", 0.0) + np.where(v.AtLastPointC, v.ChanQ * v.DtSec, 0)
+
     def attach_router(self, compressed_ldd_kinematic, land_mask, flagnancheck=False):
         """The router construction of initialSecond (routing.py:401-403)."""
         v = self.var
@@ -70,10 +165,16 @@ class routing(HydroModule):
         QLimit (PCRaster `upstream`, routing.py:387) runs on the device graph."""
         v = self.var
         split = self.options["SplitRouting"]
+        if compressed_ldd_kinematic is None:
+            compressed_ldd_kinematic, land_mask = v.LddKinematic, self._land_mask
         if split:
-            if not hasattr(v, "ChannelAlpha2") or v.ChannelAlpha2 is None:
-                raise ValueError("SplitRouting needs var.ChannelAlpha2 (routing.py:355-358)")
-            v.InvChannelAlpha2 = 1 / v.ChannelAlpha2
+            if getattr(v, "ChannelAlpha2", None) is None:
+                if not hasattr(v, "CalChanMan2"):
+                    raise ValueError("SplitRouting needs var.ChannelAlpha2 or var.CalChanMan2 (routing.py:355-358)")
+                ChanMan2 = (v.ChanMan / v.CalChanMan) * v.CalChanMan2                                   # :355
+                v.ChannelAlpha2 = ((ChanMan2 / np.sqrt(v.ChanGrad)) ** v.Beta) * (v.ChanWettedPerimeterAlpha ** v.AlpPow)
+            with np.errstate(divide="ignore"):
+                v.InvChannelAlpha2 = 1 / v.ChannelAlpha2
         self.attach_router(compressed_ldd_kinematic, land_mask, flagnancheck)
         if split and not self.options["InitLisflood"]:
             v.M3Limit = v.ChannelAlpha * v.ChanLength * (v.QLimit ** v.Beta)                       # :371

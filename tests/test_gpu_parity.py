@@ -297,6 +297,41 @@ def test_routing_substeps_fused_wavefront(amd, solver, mode):
         assert np.array_equal(getattr(v3, k), getattr(v4, k), equal_nan=True), k
 
 
+def test_routing_module_initial_to_step_end_on_etrs89(amd, oracle):
+    """routing.initial -> initialSecond -> 24 x dynamic -> step_end on the LF_ETRS89 static maps (the reference's
+    own test catchment), checked against the reference-formula parameters of the golden fixture and against the
+    oracle driven with the same parameters."""
+    z = golden("etrs89_static")
+    gold = golden("route_etrs89")
+    mask = z["ldd"] != -1
+    f = lambda k: z[k][mask].astype(np.float64)
+    v = types.SimpleNamespace(DtSec=86400.0, DtSecChannel=3600.0)
+    m = amd.routing.routing(v, split_routing=False)
+    m.initial(dict(beta=0.6, ChanLength=f("chanlength"), Ldd=f("ldd"), Channels=f("chan"), ChanGrad=f("changrad"),
+                   ChanGradMin=0.0001, CalChanMan=f("calchanman1"), ChanMan=f("chanman"), ChanBottomWidth=f("chanbw"),
+                   ChanDepthThreshold=f("chanbnkf"), ChanSdXdY=f("chans"), PixelArea=f("pixarea")), mask)
+    assert v.NoRoutSteps == 24 and v.DtRouting == 3600.0
+    np.testing.assert_allclose(v.ChannelAlpha, gold["alpha"], rtol=1e-12)
+    np.testing.assert_allclose(v.ChanQKin, gold["Q0"], rtol=1e-12)
+    assert v.IsChannel.all() and (v.LddToChan == 5).all()        # every land pixel of LF_ETRS89 is a channel pixel
+    assert np.isclose(v.UpArea, z["uparea"][mask], rtol=1e-6).mean() > 0.95
+    assert v.Catchments.max() == (f("ldd") == 5).sum()
+    m.initialSecond()
+    cpu = oracle.kinematicWave(f("ldd"), mask, v.ChannelAlpha, 0.6, v.ChanLength, v.DtRouting)
+    v.sumDisDay = np.zeros(v.ChanQKin.size)
+    v.ToChanM3RunoffDt = np.random.default_rng(3).uniform(0, 3000, v.ChanQKin.size)
+    sub = oracle.RoutingSubstep(cpu, types.SimpleNamespace(**{k: (a.copy() if isinstance(a, np.ndarray) else a)
+                                                                 for k, a in vars(v).items()}))
+    sub.v.InvChannelAlpha2 = sub.v.ChannelAlpha2 = None
+    for s in range(v.NoRoutSteps):
+        m.dynamic(s)
+        sub.dynamic(split=False)
+    m.step_end()
+    close(v.ChanQKin, sub.v.ChanQKin)
+    close(v.ChanQAvg, sub.v.sumDisDay / v.NoRoutSteps)
+    close(v.TotalCrossSectionArea, sub.v.ChanM3Kin * v.InvChanLength)
+
+
 def test_interception_golden(amd):
     g = golden("interception")
     st = {k: g["in_" + k].copy() for k in ("Interception", "TaInterception", "LeafDrainage", "CumInterception")}
