@@ -105,3 +105,58 @@ __device__ __forceinline__ double lf_solve_3_5(double c, double a)
     const double q = (r2 * r2) * r;
     return (q > 1e-12) ? q : 0.0;
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// x^y for x >= 0 and finite y > 0 with per-lane exponents (soil kernel: Xinanjiang, Van Genuchten).
+// OCML's pow costs ~220 VALU instructions on gfx950, most of them double-double bookkeeping and special-case
+// handling the soil kernel never needs (negative bases, integer-exponent tests, overflow).  This version is
+// exp2(y * log2(x)) with an fdlibm-style log (argument reduced to [sqrt(1/2), sqrt(2)), 7-term minimax in
+// s = f/(2+f)), the product y*e carried with its rounding error (fma), and a degree-13 polynomial for 2^r:
+// ~70 instructions, relative error ~1e-15 for |y log2 x| <= 50 (measured against OCML in the gpu tests).
+// x == 0 -> 0, x == 1 -> 1, NaN propagates, x == +inf -> +inf.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double lf_pow_pos(double x, double y)
+{
+    if (!(x > 0.0)) return (x == 0.0) ? 0.0 : (x + y); // 0 -> 0 ; negative / NaN -> NaN via the general pow below
+    int e = __builtin_amdgcn_frexp_exp(x);
+    double m = __builtin_amdgcn_frexp_mant(x); // [0.5, 1)
+    if (m < 0.70710678118654752440) {
+        m *= 2.0;
+        e -= 1;
+    }
+    const double f = m - 1.0;
+    const double s = f / (2.0 + f);
+    const double z = s * s, w = z * z;
+    const double t1 = w * (3.999999999940941908e-01 + w * (2.222219843214978396e-01 + w * 1.531383769920937332e-01));
+    const double t2 = z * (6.666666666666735130e-01 +
+                           w * (2.857142874366239149e-01 + w * (1.818357216161805012e-01 + w * 1.479819860511658591e-01)));
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double ln_m = f - (hfsq - s * (hfsq + R)); // log(m), |error| < 1 ulp
+    const double l2m = ln_m * 1.44269504088896340736;  // log2(m), |l2m| <= 0.5
+    const double ed = (double)e;
+    const double p = y * ed;
+    const double p_err = fma(y, ed, -p);
+    const double q = y * l2m;
+    const double n = rint(p + q);
+    const double r = ((p - n) + q) + p_err; // |r| <= ~0.5
+    const double u = r * 0.69314718055994530942;
+    // e^u, |u| <= 0.36
+    double ex = 1.6059043836821613e-10; // 1/13!
+    ex = fma(ex, u, 2.08767569878681e-09);
+    ex = fma(ex, u, 2.505210838544172e-08);
+    ex = fma(ex, u, 2.755731922398589e-07);
+    ex = fma(ex, u, 2.7557319223985893e-06);
+    ex = fma(ex, u, 2.48015873015873e-05);
+    ex = fma(ex, u, 1.984126984126984e-04);
+    ex = fma(ex, u, 1.388888888888889e-03);
+    ex = fma(ex, u, 8.333333333333333e-03);
+    ex = fma(ex, u, 4.1666666666666664e-02);
+    ex = fma(ex, u, 1.6666666666666666e-01);
+    ex = fma(ex, u, 0.5);
+    ex = fma(ex, u, 1.0);
+    ex = fma(ex, u, 1.0);
+    const double nn = fmin(fmax(n, -2000.0), 2000.0);
+    return ldexp(ex, (int)nn);
+}

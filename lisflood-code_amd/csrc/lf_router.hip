@@ -105,7 +105,8 @@ struct lf_router {
     double beta = 0, inv_beta = 0, b_minus_1 = 0, dx_scalar = 0;
     bool has_floodplains = false, dx_per_pixel = false;
     int kmax = 8;
-    bool pair_lanes = true; // engine-order sweep: two cells per lane (16-byte streams); LF_PAIR_LANES=0 disables
+    bool pair_lanes = false; // engine-order sweep with two cells per lane (16-byte streams): measured equal to the
+                             // one-cell kernel (132 vs 131 us per 12.5 M-cell level), kept behind LF_PAIR_LANES=1
     bool fused = false; // beta == 3/5: prep fused into the sweep, polynomial closure solve (lf_math.h)
     lf_dbuf<int32_t> perm, ups_ptr;
     lf_dbuf<long long> level_start;
@@ -279,7 +280,7 @@ int lf_router_create(const lf_graph *g, const double *alpha, double beta, const 
     const char *force_general = std::getenv("LF_GENERAL_POW");
     r->fused = (beta == 0.6) && !(force_general && force_general[0] == '1');
     const char *pair = std::getenv("LF_PAIR_LANES");
-    r->pair_lanes = !(pair && pair[0] == '0');
+    r->pair_lanes = pair && pair[0] == '1';
     const int64_t n = g->N;
     int rc = LF_OK;
     {

@@ -8,8 +8,10 @@
 // wavefront read/write consecutive fp64 of one row: all ~95 streams are coalesced.  The kernel is
 // HBM-bound (~500 B per column-step) unless many Courant sub-steps are needed.
 #include <cmath>
+#include <cstdlib>
 
 #include "lf_common.h"
+#include "lf_math.h"
 
 namespace {
 
@@ -62,12 +64,20 @@ __global__ void __launch_bounds__(kBlock) k_interception(lf_interception_args A)
 }
 
 // saturationDegree (soilloop.py:378-383) + unsaturatedConductivity (360-367)
+// x^y with x in [0, 1] and y > 0: lf_pow_pos (lf_math.h) or OCML pow (LF_GENERAL_POW=1)
+template <bool FASTPOW>
+__device__ __forceinline__ double powxy(double x, double y)
+{
+    return FASTPOW ? lf_pow_pos(x, y) : pow(x, y);
+}
+
+template <bool FASTPOW>
 __device__ __forceinline__ double unsat_k(double w, bool pore, double wres, double ws, double ksat, double inv_m,
                                           double m)
 {
     double s = 0.;
     if (pore) s = dmax(dmin((w - wres) / (ws - wres), 1.), 0.);
-    const double t = 1. - pow(1. - pow(s, inv_m), m);
+    const double t = 1. - powxy<FASTPOW>(1. - powxy<FASTPOW>(s, inv_m), m);
     return ksat * sqrt(s) * (t * t);
 }
 
@@ -81,7 +91,7 @@ struct veg_plan {
 // One soil column (vegetation fraction `veg`, pixel `pix`) of soilColumnsWaterBalance, soilloop.py:123-354.
 // Nothing is stored before the end, so a column can be abandoned and recomputed later: with DEFER, a column
 // that needs more than one Courant sub-step returns that number without writing anything (0 = column done).
-template <bool DEFER>
+template <bool DEFER, bool FASTPOW>
 __device__ __forceinline__ long long soil_column(const lf_soil_args &A, const veg_plan &P, int veg, long long pix)
 {
     const long long N = A.N;
@@ -116,10 +126,10 @@ __device__ __forceinline__ long long soil_column(const lf_soil_args &A, const ve
     double w1 = w1a + w1b;
     // Xinanjiang infiltration capacity, :168-179
     const double relsat1 = pore1a ? dmin(w1 / A.WS1[j], 1.0) : 0.0;
-    const double satfrac = 1.0 - pow(1.0 - relsat1, A.b_Xinanjiang[pix]);
-    const double infpot = frozen ? 0.0 : A.StoreMaxPervious[j] * pow(1. - satfrac, A.PowerInfPot[pix]) * DtDay;
+    const double satfrac = 1.0 - powxy<FASTPOW>(1.0 - relsat1, A.b_Xinanjiang[pix]);
+    const double infpot = frozen ? 0.0 : A.StoreMaxPervious[j] * powxy<FASTPOW>(1. - satfrac, A.PowerInfPot[pix]) * DtDay;
     // preferential flow, :190-194
-    const double pref = pow(relsat1, A.PowerPrefFlow[pix]) * awi;
+    const double pref = powxy<FASTPOW>(relsat1, A.PowerPrefFlow[pix]) * awi;
     awi -= pref;
     // infiltration, :201-211
     double inf = dmax(dmin(awi, infpot), 0.);
@@ -131,9 +141,9 @@ __device__ __forceinline__ long long soil_column(const lf_soil_args &A, const ve
     const double ks1a = A.KSat1a[j], ks1b = A.KSat1b[j], ks2 = A.KSat2[j];
     const double im1a = A.GenuInvM1a[j], im1b = A.GenuInvM1b[j], im2 = A.GenuInvM2[j];
     const double m1a = A.GenuM1a[j], m1b = A.GenuM1b[j], m2 = A.GenuM2[j];
-    double k1a = unsat_k(w1a, pore1a, wres1a, ws1a, ks1a, im1a, m1a);
-    double k1b = unsat_k(w1b, pore1b, wres1b, ws1b, ks1b, im1b, m1b);
-    double k2 = unsat_k(w2, pore2, wres2, ws2, ks2, im2, m2);
+    double k1a = unsat_k<FASTPOW>(w1a, pore1a, wres1a, ws1a, ks1a, im1a, m1a);
+    double k1b = unsat_k<FASTPOW>(w1b, pore1b, wres1b, ws1b, ks1b, im1b, m1b);
+    double k2 = unsat_k<FASTPOW>(w2, pore2, wres2, ws2, ks2, im2, m2);
     double av1a = w1a - wres1a, av1b = w1b - wres1b, av2 = w2 - wres2;
     double cap1 = ws1b - w1b, cap2 = ws2 - w2;
     const double ca = (av1a == 0) ? 0. : k1a * DtDay / av1a;
@@ -150,9 +160,9 @@ __device__ __forceinline__ long long soil_column(const lf_soil_args &A, const ve
     const long long trips = DEFER ? 1 : nsub; // DEFER: nsub == 1 here, the re-evaluation branch disappears
     for (long long s = 0; s < trips; ++s) {
         if (s > 0) {
-            k1a = unsat_k(wt1a, pore1a, wres1a, ws1a, ks1a, im1a, m1a);
-            k1b = unsat_k(wt1b, pore1b, wres1b, ws1b, ks1b, im1b, m1b);
-            k2 = unsat_k(wt2, pore2, wres2, ws2, ks2, im2, m2);
+            k1a = unsat_k<FASTPOW>(wt1a, pore1a, wres1a, ws1a, ks1a, im1a, m1a);
+            k1b = unsat_k<FASTPOW>(wt1b, pore1b, wres1b, ws1b, ks1b, im1b, m1b);
+            k2 = unsat_k<FASTPOW>(wt2, pore2, wres2, ws2, ks2, im2, m2);
         }
         const double fa = dmin(k1a * dtsub, cap1);
         const double fb = dmin(k1b * dtsub, cap2);
@@ -224,6 +234,7 @@ constexpr int kHeader = 1 + 2 * kClasses;
 // Pass 1: one lane per (vegetation fraction, pixel) column (blockIdx.y = fraction).  Columns that need a
 // single Courant sub-step (the vast majority) are finished here; the others are appended to a work list
 // instead of making the whole wavefront wait for them.
+template <bool FASTPOW>
 __global__ void __launch_bounds__(kBlock) k_soil_columns(lf_soil_args A, veg_plan P, unsigned int *__restrict__ header,
                                                          unsigned int *__restrict__ raw, unsigned char *__restrict__ cls)
 {
@@ -233,7 +244,7 @@ __global__ void __launch_bounds__(kBlock) k_soil_columns(lf_soil_args A, veg_pla
     const int mode = P.mode[veg];
     if (mode == 0) return;
     if (mode == 2 && !A.paddy_inactive[(long long)P.paddy_row[veg] * A.N + pix]) return;
-    const long long nsub = soil_column<true>(A, P, veg, pix);
+    const long long nsub = soil_column<true, FASTPOW>(A, P, veg, pix);
     if (nsub > 0) {
         int c = 63 - __clzll((unsigned long long)nsub); // floor(log2(nsub)) >= 1
         c = c < kClasses - 1 ? c : kClasses - 1;
@@ -291,6 +302,7 @@ __global__ void __launch_bounds__(kBlock) k_soil_scatter(unsigned int *__restric
 }
 
 // Pass 2: the deferred columns, one lane each, with their full sub-step loop.
+template <bool FASTPOW>
 __global__ void __launch_bounds__(kBlock) k_soil_columns_deferred(lf_soil_args A, veg_plan P,
                                                                   const unsigned int *__restrict__ header,
                                                                   const unsigned int *__restrict__ sorted)
@@ -300,7 +312,7 @@ __global__ void __launch_bounds__(kBlock) k_soil_columns_deferred(lf_soil_args A
         const unsigned int id = sorted[k];
         const int veg = (int)(id / (unsigned long long)A.N);
         const long long pix = (long long)(id - (unsigned long long)veg * A.N);
-        soil_column<false>(A, P, veg, pix);
+        soil_column<false, FASTPOW>(A, P, veg, pix);
     }
 }
 
@@ -388,12 +400,21 @@ int lf_soil_columns_device(int device, const lf_soil_args *a)
     unsigned int *sorted = raw + cols;
     unsigned char *cls = (unsigned char *)(sorted + cols);
     LF_HIP(hipMemsetAsync(header, 0, sizeof(unsigned int) * kHeader, c->stream));
-    hipLaunchKernelGGL(k_soil_columns, dim3(blocks_for(a->N), (unsigned)a->V), dim3(kBlock), 0, c->stream, *a, P, header,
-                       raw, cls);
+    // LF_GENERAL_POW=1: OCML pow instead of lf_pow_pos (A/B parity and timing)
+    const char *force_general = std::getenv("LF_GENERAL_POW");
+    const bool fastpow = !(force_general && force_general[0] == '1');
+    const dim3 grid1(blocks_for(a->N), (unsigned)a->V), block(kBlock);
+    if (fastpow)
+        hipLaunchKernelGGL(k_soil_columns<true>, grid1, block, 0, c->stream, *a, P, header, raw, cls);
+    else
+        hipLaunchKernelGGL(k_soil_columns<false>, grid1, block, 0, c->stream, *a, P, header, raw, cls);
     // the deferred count is only known on the device: fixed grids walk the list with grid-stride loops
     hipLaunchKernelGGL(k_soil_hist, dim3(512), dim3(kBlock), 0, c->stream, header, cls);
     hipLaunchKernelGGL(k_soil_scatter, dim3(512), dim3(kBlock), 0, c->stream, header, raw, cls, sorted);
-    hipLaunchKernelGGL(k_soil_columns_deferred, dim3(4096), dim3(kBlock), 0, c->stream, *a, P, header, sorted);
+    if (fastpow)
+        hipLaunchKernelGGL(k_soil_columns_deferred<true>, dim3(4096), block, 0, c->stream, *a, P, header, sorted);
+    else
+        hipLaunchKernelGGL(k_soil_columns_deferred<false>, dim3(4096), block, 0, c->stream, *a, P, header, sorted);
     LF_HIP(hipGetLastError());
     return LF_OK;
 }

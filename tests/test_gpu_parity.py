@@ -29,8 +29,9 @@ def amd():
 
 @pytest.fixture(params=["fused_beta_3_5", "general_pow"])
 def solver(request, monkeypatch):
-    """Both solve paths of csrc/lf_router.hip: the fused beta = 3/5 polynomial solve (default) and the
-    general path that follows the reference's own Newton iteration with pow (LF_GENERAL_POW=1)."""
+    """Both arithmetic paths of the engine: the default one (routing: fused beta = 3/5 polynomial solve,
+    csrc/lf_math.h; soil: lf_pow_pos) and the general one that follows the reference's own iteration with OCML
+    pow (LF_GENERAL_POW=1)."""
     if request.param == "general_pow":
         monkeypatch.setenv("LF_GENERAL_POW", "1")
     else:
@@ -344,7 +345,7 @@ def test_interception_golden(amd):
             np.testing.assert_allclose(st[k], g["out%d_%s" % (s, k)], rtol=1e-12, atol=1e-14, err_msg=k)
 
 
-def test_soil_columns_golden(amd):
+def test_soil_columns_golden(amd, solver):
     from lisflood_amd import synthetic as syn
     g = golden("soil_columns")
     d = {k: (g["in_" + k].copy() if g["in_" + k].ndim else g["in_" + k][()]) for k in syn.SOIL_ARG_ORDER}
@@ -355,7 +356,7 @@ def test_soil_columns_golden(amd):
             np.testing.assert_allclose(d[k], g["out%d_%s" % (s, k)], rtol=1e-9, atol=1e-11, err_msg=(s, k))
 
 
-def test_soil_columns_device_resident_vs_oracle(amd, oracle):
+def test_soil_columns_device_resident_vs_oracle(amd, oracle, solver):
     """Bigger ragged N (not a multiple of the block), paddy rows, 4 consecutive resident steps."""
     from lisflood_amd import synthetic as syn
     N = 100003
@@ -458,7 +459,7 @@ def test_surface_routing_module_golden(amd, solver):
             close(getattr(v, k), g["out%d_%s" % (s, k)], (s, k))
 
 
-def test_soilloop_module_golden(amd):
+def test_soilloop_module_golden(amd, solver):
     """soilloop.dynamic_canopy() + dynamic_soil() (soilloop.py:519-704) against vectors captured from the
     reference's own class methods, two consecutive steps."""
     from lisflood_amd import synthetic as syn
