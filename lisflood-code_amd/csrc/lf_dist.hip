@@ -13,9 +13,10 @@
 // summation order (ghosts of the row above first, then local cells in ascending id, then the row below =
 // ascending global pixel id, kinematic_wave_parallel_tools.py:57-58,119-129).
 //
-// Local sweep order: cells sorted by (phase, height above the local sources, local pixel id); upstream
-// positions come from an index list (lf_sweep.h INDEXED) because they may sit in earlier phases or in the
-// ghost slots appended after the N local cells of the discharge vector.  Ghost slots are ordered
+// Local sweep order: cells sorted by (phase, level, breadth-first rank) with level = max local distance-to-outlet -
+// distance as in the single-domain layout, so siblings stay adjacent and upstream gathers nearly contiguous;
+// upstream positions come from an index list (lf_sweep.h INDEXED) because they may sit in earlier phases or in
+// the ghost slots appended after the N local cells of the discharge vector.  Ghost slots are ordered
 // (side, phase, column) so that the values received in round j land in one contiguous range.
 #include <dlfcn.h>
 
@@ -40,7 +41,7 @@ struct lf_dist_graph {
     std::vector<int32_t> ghost_phase[2];  // phase of the ghost on its own rank
     // exports: local cells draining into a land cell of a halo row
     std::vector<int32_t> export_cell[2];  // local id (ascending column)
-    std::vector<int32_t> phase, height;   // [N]
+    std::vector<int32_t> phase, height;   // [N]; height = level (max local distance-to-outlet - distance)
     int nphases = 1;                      // global number of phases (set by the host after the fixpoint)
     // finalized layout
     std::vector<int32_t> perm, pos;       // position <-> local id
@@ -168,26 +169,31 @@ int lf_dist_graph_create(const uint8_t *ldd_local, const uint8_t *mask_local, in
         for (int64_t p = 0; p < n; ++p)
             if (g->down[p] >= 0) g->uidx[fill[g->down[p]]++] = (int32_t)p;
     }
-    // topological order (upstream first) = reversed breadth-first order from the local outlets
+    // breadth-first search from the local outlets (true outlets + exports): generation = distance to the local
+    // outlet.  Reversed, the queue is a topological order (upstream first) that is sorted by level
+    // (= max distance - distance, as in the single-domain layout) and keeps the children of a cell adjacent.
     std::vector<int32_t> queue(n);
+    g->height.assign(n, 0);
     int64_t head = 0, tail = 0;
     for (int64_t p = 0; p < n; ++p)
         if (g->down[p] < 0) queue[tail++] = (int32_t)p;
+    int32_t gen = 0;
     while (head < tail) {
-        const int32_t p = queue[head++];
-        for (int32_t e = g->uptr[p]; e < g->uptr[p + 1]; ++e) queue[tail++] = g->uidx[e];
+        const int64_t gen_end = tail;
+        for (; head < gen_end; ++head) {
+            const int32_t p = queue[head];
+            g->height[p] = gen;
+            for (int32_t e = g->uptr[p]; e < g->uptr[p + 1]; ++e) queue[tail++] = g->uidx[e];
+        }
+        ++gen;
     }
     if (tail != n) {
         delete g;
         return lf_set_error(LF_E_CYCLE, "LDD has a cycle inside the row block");
     }
+    for (int64_t p = 0; p < n; ++p) g->height[p] = (gen - 1) - g->height[p]; // level: every local upstream cell is one lower
     g->topo.assign(queue.rbegin(), queue.rend());
     g->phase.assign(n, 0);
-    g->height.assign(n, 0);
-    for (int64_t t = 0; t < n; ++t) {
-        const int32_t c = g->topo[t], d = g->down[c];
-        if (d >= 0) g->height[d] = std::max(g->height[d], g->height[c] + 1);
-    }
     local_phases(g);
     *out = g;
     return LF_OK;
@@ -254,16 +260,9 @@ int lf_dist_graph_finalize(lf_dist_graph *g, int nphases)
     if (nphases < lf_dist_graph_local_num_phases(g)) return lf_set_error(LF_E_INVALID, "nphases too small");
     const int64_t n = g->N;
     g->nphases = nphases;
-    // order by (phase, height, id): stable counting sorts, height first
-    int maxh = 0;
-    for (int32_t h : g->height) maxh = std::max(maxh, h);
-    std::vector<int32_t> tmp(n);
-    {
-        std::vector<int64_t> cnt(maxh + 2, 0);
-        for (int64_t p = 0; p < n; ++p) cnt[g->height[p] + 1]++;
-        for (int h = 0; h <= maxh; ++h) cnt[h + 1] += cnt[h];
-        for (int64_t p = 0; p < n; ++p) tmp[cnt[g->height[p]]++] = (int32_t)p;
-    }
+    // order by (phase, level, breadth-first rank): `topo` is already sorted by level with siblings adjacent, a stable
+    // counting sort by phase on top of it keeps that inside every phase (upstream gathers stay nearly contiguous)
+    const std::vector<int32_t> &tmp = g->topo;
     g->perm.resize(n);
     {
         std::vector<int64_t> cnt(nphases + 1, 0);
