@@ -1,6 +1,8 @@
 // lf_device.cpp -- error reporting, per-device context (stream + stopwatch), memory plumbing.
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <unordered_map>
 
 #include "lf_common.h"
 
@@ -8,6 +10,12 @@ namespace {
 thread_local char g_err[512] = "";
 std::mutex g_ctx_mutex;
 lf_device_ctx g_ctx[64];
+// lf_device_alloc skews the start of successive allocations by a few KiB: kernels that stream dozens of equally
+// sized vectors in lock-step (the soil kernel reads ~67) would otherwise present every stream at the same offset
+// of a 2 MiB-aligned buffer, i.e. on the same HBM channel at the same time.  user pointer -> hipMalloc base.
+std::unordered_map<void *, void *> g_alloc_base;
+size_t g_alloc_counter = 0;
+constexpr size_t kSkewStep = 4096 + 256, kSkewSlots = 61;
 } // namespace
 
 int lf_set_error(int code, const char *fmt, ...)
@@ -82,14 +90,33 @@ int lf_device_alloc(int device, size_t bytes, void **ptr_dev)
     LF_TRY(lf_ctx(device, nullptr));
     *ptr_dev = nullptr;
     if (bytes == 0) return LF_OK;
-    LF_HIP(hipMalloc(ptr_dev, bytes));
+    static const bool skew_on = [] {
+        const char *e = std::getenv("LF_ALLOC_SKEW");
+        return !(e && e[0] == '0');
+    }();
+    std::lock_guard<std::mutex> lock(g_ctx_mutex);
+    const size_t skew = skew_on ? (g_alloc_counter++ % kSkewSlots) * kSkewStep : 0;
+    void *base = nullptr;
+    LF_HIP(hipMalloc(&base, bytes + skew));
+    *ptr_dev = (char *)base + skew;
+    g_alloc_base[*ptr_dev] = base;
     return LF_OK;
 }
 
 int lf_device_free(int device, void *ptr_dev)
 {
     LF_TRY(lf_ctx(device, nullptr));
-    if (ptr_dev) LF_HIP(hipFree(ptr_dev));
+    if (!ptr_dev) return LF_OK;
+    void *base = ptr_dev;
+    {
+        std::lock_guard<std::mutex> lock(g_ctx_mutex);
+        auto it = g_alloc_base.find(ptr_dev);
+        if (it != g_alloc_base.end()) {
+            base = it->second;
+            g_alloc_base.erase(it);
+        }
+    }
+    LF_HIP(hipFree(base));
     return LF_OK;
 }
 

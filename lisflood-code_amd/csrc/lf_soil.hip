@@ -97,26 +97,40 @@ __device__ __forceinline__ long long soil_column(const lf_soil_args &A, const ve
     const long long N = A.N;
     const double DtDay = A.DtDay;
     const long long i = (long long)veg * N + pix, j = (long long)P.landuse[veg] * N + pix;
+    // Every input of the column is fetched here, before any arithmetic: ~50 independent loads in flight per lane
+    // instead of the handful the compiler keeps when loads sit next to their first use (the kernel is a stream
+    // of ~90 vectors; memory-level parallelism, not ALU, sets its speed).
+    const double in_rain = A.Rain[pix], in_snow = A.SnowMelt[pix], in_leaf = A.LeafDrainage[i], in_int = A.Interception[i];
+    const double in_dslr = A.DSLR[i], in_w1a = A.W1a[i], in_w1b = A.W1b[i], in_w1 = A.W1[i], in_w2 = A.W2[i], in_uz = A.UZ[i];
+    const double in_esmax = A.ESMax[i], in_wres1 = A.WRes1[j], in_ws1 = A.WS1[j], in_store = A.StoreMaxPervious[j];
+    const double in_bx = A.b_Xinanjiang[pix], in_pinf = A.PowerInfPot[pix], in_ppref = A.PowerPrefFlow[pix];
+    const double in_uzk = A.UpperZoneK[pix], in_gwp = A.GwPercStep[pix];
+    const double in_sd1a = A.SoilDepth1a[j], in_sd1b = A.SoilDepth1b[j], in_sd2 = A.SoilDepth2[j];
+    const double wwp1a = A.WWP1a[j], wwp1b = A.WWP1b[j], wwp1 = A.WWP1[j], wwp2 = A.WWP2[j];
+    const double in_wfc1a = A.WFC1a[j], in_wfc1b = A.WFC1b[j], in_wfc1 = A.WFC1[j], in_wfc2 = A.WFC2[j];
+    const double ks1a = A.KSat1a[j], ks1b = A.KSat1b[j], ks2 = A.KSat2[j];
+    const double im1a = A.GenuInvM1a[j], im1b = A.GenuInvM1b[j], im2 = A.GenuInvM2[j];
+    const double m1a = A.GenuM1a[j], m1b = A.GenuM1b[j], m2 = A.GenuM2[j];
     const bool frozen = A.isFrozenSoil[pix] != 0;
     const double wres1a = A.WRes1a[j], wres1b = A.WRes1b[j], wres2 = A.WRes2[j];
     const double ws1a = A.WS1a[j], ws1b = A.WS1b[j], ws2 = A.WS2[j];
     const bool pore1a = A.PoreSpaceNotZero1a[j] != 0, pore1b = A.PoreSpaceNotZero1b[j] != 0,
                pore2 = A.PoreSpaceNotZero2[j] != 0;
     // available water for infiltration, :100,131
-    double awi = dmax((A.Rain[pix] + A.SnowMelt[pix]) + A.LeafDrainage[i] - A.Interception[i], 0.);
+    double awi = dmax((in_rain + in_snow) + in_leaf - in_int, 0.);
     // days since last rain, :137-140
-    double dslr = A.DSLR[i];
+    double dslr = in_dslr;
     if (awi > A.AvWaterThreshold)
         dslr = 1;
     else
         dslr += DtDay;
     // bare soil evaporation, :148-163
-    double w1a = A.W1a[i], w1b = A.W1b[i], esact;
+    double w1a = in_w1a, w1b = in_w1b, esact;
     if (frozen)
         esact = 0.;
     else {
-        esact = A.ESMax[i] * (sqrt(dslr) - sqrt(dslr - 1));
-        esact = dmax(dmin(esact, A.W1[i] - A.WRes1[j]), 0.);
+        esact = in_esmax * (sqrt(dslr) - sqrt(dslr - 1));
+        esact = dmax(dmin(esact, in_w1 - in_wres1), 0.);
         const double supply1a = w1a - wres1a;
         const double es1a = dmin(esact, supply1a);
         const double es1b = dmax(esact - supply1a, 0.);
@@ -125,22 +139,19 @@ __device__ __forceinline__ long long soil_column(const lf_soil_args &A, const ve
     }
     double w1 = w1a + w1b;
     // Xinanjiang infiltration capacity, :168-179
-    const double relsat1 = pore1a ? dmin(w1 / A.WS1[j], 1.0) : 0.0;
-    const double satfrac = 1.0 - powxy<FASTPOW>(1.0 - relsat1, A.b_Xinanjiang[pix]);
-    const double infpot = frozen ? 0.0 : A.StoreMaxPervious[j] * powxy<FASTPOW>(1. - satfrac, A.PowerInfPot[pix]) * DtDay;
+    const double relsat1 = pore1a ? dmin(w1 / in_ws1, 1.0) : 0.0;
+    const double satfrac = 1.0 - powxy<FASTPOW>(1.0 - relsat1, in_bx);
+    const double infpot = frozen ? 0.0 : in_store * powxy<FASTPOW>(1. - satfrac, in_pinf) * DtDay;
     // preferential flow, :190-194
-    const double pref = powxy<FASTPOW>(relsat1, A.PowerPrefFlow[pix]) * awi;
+    const double pref = powxy<FASTPOW>(relsat1, in_ppref) * awi;
     awi -= pref;
     // infiltration, :201-211
     double inf = dmax(dmin(awi, infpot), 0.);
     const double test1a = w1a + inf;
     w1a = dmin(ws1a, test1a);
     w1b += dmax(test1a - ws1a, 0.);
-    double w2 = A.W2[i];
+    double w2 = in_w2;
     // Van Genuchten conductivities and Courant numbers, :223-249
-    const double ks1a = A.KSat1a[j], ks1b = A.KSat1b[j], ks2 = A.KSat2[j];
-    const double im1a = A.GenuInvM1a[j], im1b = A.GenuInvM1b[j], im2 = A.GenuInvM2[j];
-    const double m1a = A.GenuM1a[j], m1b = A.GenuM1b[j], m2 = A.GenuM2[j];
     double k1a = unsat_k<FASTPOW>(w1a, pore1a, wres1a, ws1a, ks1a, im1a, m1a);
     double k1b = unsat_k<FASTPOW>(w1b, pore1b, wres1b, ws1b, ks1b, im1b, m1b);
     double k2 = unsat_k<FASTPOW>(w2, pore2, wres2, ws2, ks2, im2, m2);
@@ -188,15 +199,15 @@ __device__ __forceinline__ long long soil_column(const lf_soil_args &A, const ve
     inf -= dmax(w1a - ws1a, 0.);
     w1a = dmin(w1a, ws1a);
     // upper zone, :340-354
-    double uz = A.UZ[i];
-    double uzout = dmin(A.UpperZoneK[pix] * uz, uz);
+    double uz = in_uz;
+    double uzout = dmin(in_uzk * uz, uz);
     uz = dmax(uz - uzout, 0.);
     if (P.drained[veg]) {
         uzout += A.DrainedFraction * sg;
         uz += (1 - A.DrainedFraction) * sg + pref;
     } else
         uz += sg + pref;
-    const double perc = dmin(A.GwPercStep[pix], uz);
+    const double perc = dmin(in_gwp, uz);
     uz = dmax(uz - perc, 0.);
     // stores
     A.DSLR[i] = dslr;
@@ -212,14 +223,13 @@ __device__ __forceinline__ long long soil_column(const lf_soil_args &A, const ve
     A.W1[i] = w1;
     A.W2[i] = w2;
     // diagnostics, :330-336
-    A.Theta1a[i] = pore1a ? w1a / A.SoilDepth1a[j] : 0.;
-    A.Theta1b[i] = pore1b ? w1b / A.SoilDepth1b[j] : 0.;
-    A.Theta2[i] = pore2 ? w2 / A.SoilDepth2[j] : 0.;
-    const double wwp1a = A.WWP1a[j], wwp1b = A.WWP1b[j], wwp1 = A.WWP1[j], wwp2 = A.WWP2[j];
-    A.Sat1a[i] = (w1a - wwp1a) / (A.WFC1a[j] - wwp1a);
-    A.Sat1b[i] = (w1b - wwp1b) / (A.WFC1b[j] - wwp1b);
-    A.Sat1[i] = (w1 - wwp1) / (A.WFC1[j] - wwp1);
-    A.Sat2[i] = (w2 - wwp2) / (A.WFC2[j] - wwp2);
+    A.Theta1a[i] = pore1a ? w1a / in_sd1a : 0.;
+    A.Theta1b[i] = pore1b ? w1b / in_sd1b : 0.;
+    A.Theta2[i] = pore2 ? w2 / in_sd2 : 0.;
+    A.Sat1a[i] = (w1a - wwp1a) / (in_wfc1a - wwp1a);
+    A.Sat1b[i] = (w1b - wwp1b) / (in_wfc1b - wwp1b);
+    A.Sat1[i] = (w1 - wwp1) / (in_wfc1 - wwp1);
+    A.Sat2[i] = (w2 - wwp2) / (in_wfc2 - wwp2);
     A.UZOutflow[i] = uzout;
     A.GwPercUZLZ[i] = perc;
     A.UZ[i] = uz;

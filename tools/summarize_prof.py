@@ -29,7 +29,8 @@ def short(name):
         f = [x.strip() == "true" for x in m.group(2).split(",")] + [False, False, False]
         tag = ("fused" if f[0] else "general") + ("+ordered" if f[1] else "+pixel") + ("+indexed" if f[2] else "")
         return "%s[%s]" % (m.group(1), tag)
-    for k in ("k_calib_copy8", "k_calib_copy16", "k_prep", "k_levels_narrow", "k_level", "k_soil_columns", "k_interception", "k_substep",
+    for k in ("k_soil_columns_deferred", "k_soil_hist", "k_soil_scatter", "k_fused_substeps", "k_canopy", "k_surface_pre",
+              "k_surface_post", "k_calib_copy8", "k_calib_copy16", "k_prep", "k_levels_narrow", "k_level", "k_soil_columns", "k_interception", "k_substep",
               "k_halo", "k_gather", "k_scatter"):
         if k in name:
             return k
