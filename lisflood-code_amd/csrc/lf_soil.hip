@@ -240,13 +240,19 @@ __device__ __forceinline__ long long soil_column(const lf_soil_args &A, const ve
 //   [0] number of deferred columns, [1..kClasses] columns per sub-step class, [1+kClasses .. 2 kClasses] fill cursors
 constexpr int kClasses = 8; // class = floor(log2(nsub)) clamped to kClasses-1: trip counts inside a class differ < 2x
 constexpr int kHeader = 1 + 2 * kClasses;
+// Pass 1 appends to kShards separate lists (block b -> shard b % kShards), each with its counter on its own
+// 64-byte line: a single work-list counter saturates at ~88 atomics per microsecond, which alone cost 2.1 ms
+// for the 187 k wavefronts of a 12 M-column step.
+constexpr int kShards = 32;
+constexpr int kShardStride = 16; // unsigned ints between shard counters
 
 // Pass 1: one lane per (vegetation fraction, pixel) column (blockIdx.y = fraction).  Columns that need a
 // single Courant sub-step (the vast majority) are finished here; the others are appended to a work list
 // instead of making the whole wavefront wait for them.
 template <bool FASTPOW>
-__global__ void __launch_bounds__(kBlock) k_soil_columns(lf_soil_args A, veg_plan P, unsigned int *__restrict__ header,
-                                                         unsigned int *__restrict__ raw, unsigned char *__restrict__ cls)
+__global__ void __launch_bounds__(kBlock) k_soil_columns(lf_soil_args A, veg_plan P, unsigned int *__restrict__ shard_count,
+                                                         unsigned int *__restrict__ raw, unsigned char *__restrict__ cls,
+                                                         unsigned int shard_cap)
 {
     const long long pix = (long long)blockIdx.x * kBlock + threadIdx.x;
     const int veg = blockIdx.y;
@@ -258,9 +264,32 @@ __global__ void __launch_bounds__(kBlock) k_soil_columns(lf_soil_args A, veg_pla
     if (nsub > 0) {
         int c = 63 - __clzll((unsigned long long)nsub); // floor(log2(nsub)) >= 1
         c = c < kClasses - 1 ? c : kClasses - 1;
-        const unsigned int slot = atomicAdd(&header[0], 1u); // hipcc folds this into one atomic per wavefront
+        const unsigned int shard = (blockIdx.x + blockIdx.y * gridDim.x) % kShards;
+        // hipcc folds the lanes of a wavefront into one atomic
+        const unsigned int slot = shard * shard_cap + atomicAdd(&shard_count[shard * kShardStride], 1u);
         raw[slot] = (unsigned int)(veg * A.N + pix);
         cls[slot] = (unsigned char)c;
+    }
+}
+
+// Pass 1.25: concatenate the shard lists (header[0] = total number of deferred columns)
+__global__ void __launch_bounds__(kBlock) k_soil_concat(unsigned int *__restrict__ header, const unsigned int *__restrict__ shard_count,
+                                                        const unsigned int *__restrict__ raw, const unsigned char *__restrict__ cls,
+                                                        unsigned int shard_cap, unsigned int *__restrict__ raw2,
+                                                        unsigned char *__restrict__ cls2)
+{
+    const int shard = blockIdx.y;
+    unsigned int off = 0, total = 0;
+    for (int q = 0; q < kShards; ++q) {
+        const unsigned int c = shard_count[q * kShardStride];
+        if (q < shard) off += c;
+        total += c;
+    }
+    if (blockIdx.x == 0 && shard == 0 && threadIdx.x == 0) header[0] = total;
+    const unsigned int n = shard_count[shard * kShardStride];
+    for (unsigned int k = blockIdx.x * kBlock + threadIdx.x; k < n; k += gridDim.x * kBlock) {
+        raw2[off + k] = raw[(size_t)shard * shard_cap + k];
+        cls2[off + k] = cls[(size_t)shard * shard_cap + k];
     }
 }
 
@@ -394,10 +423,14 @@ int lf_soil_columns_device(int device, const lf_soil_args *a)
     if (a->N <= 0 || a->V <= 0) return LF_OK;
     if ((unsigned long long)a->V * (unsigned long long)a->N >= 0xffffffffull)
         return lf_set_error(LF_E_INVALID, "V*N exceeds the 32-bit column id range");
-    // work list of the columns that need more than one Courant sub-step (grow-only per-device workspace):
-    // header | raw ids | sorted ids | classes
+    // work lists of the columns that need more than one Courant sub-step (grow-only per-device workspace):
+    // header | shard counters | sharded ids | concatenated ids | sorted ids | sharded classes | concatenated classes
     const size_t cols = (size_t)a->V * (size_t)a->N;
-    const size_t need = sizeof(unsigned int) * (kHeader + 2 * cols) + cols;
+    const size_t nblocks = (size_t)blocks_for(a->N) * (size_t)a->V;
+    const size_t shard_cap = ((nblocks + kShards - 1) / kShards) * kBlock;
+    const size_t sharded = shard_cap * kShards;
+    const size_t nhead = kHeader + 15 + kShards * kShardStride;
+    const size_t need = sizeof(unsigned int) * (nhead + sharded + 2 * cols) + sharded + cols;
     if (c->soil_ws_bytes < need) {
         if (c->soil_ws) LF_HIP(hipFree(c->soil_ws));
         c->soil_ws = nullptr;
@@ -406,21 +439,28 @@ int lf_soil_columns_device(int device, const lf_soil_args *a)
         c->soil_ws_bytes = need;
     }
     unsigned int *header = (unsigned int *)c->soil_ws;
-    unsigned int *raw = header + kHeader;
-    unsigned int *sorted = raw + cols;
+    unsigned int *shard_count = header + ((kHeader + 15) / 16) * 16;
+    unsigned int *raw = header + nhead;
+    unsigned int *raw2 = raw + sharded;
+    unsigned int *sorted = raw2 + cols;
     unsigned char *cls = (unsigned char *)(sorted + cols);
-    LF_HIP(hipMemsetAsync(header, 0, sizeof(unsigned int) * kHeader, c->stream));
+    unsigned char *cls2 = cls + sharded;
+    LF_HIP(hipMemsetAsync(header, 0, sizeof(unsigned int) * nhead, c->stream));
     // LF_GENERAL_POW=1: OCML pow instead of lf_pow_pos (A/B parity and timing)
     const char *force_general = std::getenv("LF_GENERAL_POW");
     const bool fastpow = !(force_general && force_general[0] == '1');
     const dim3 grid1(blocks_for(a->N), (unsigned)a->V), block(kBlock);
     if (fastpow)
-        hipLaunchKernelGGL(k_soil_columns<true>, grid1, block, 0, c->stream, *a, P, header, raw, cls);
+        hipLaunchKernelGGL(k_soil_columns<true>, grid1, block, 0, c->stream, *a, P, shard_count, raw, cls,
+                           (unsigned int)shard_cap);
     else
-        hipLaunchKernelGGL(k_soil_columns<false>, grid1, block, 0, c->stream, *a, P, header, raw, cls);
-    // the deferred count is only known on the device: fixed grids walk the list with grid-stride loops
-    hipLaunchKernelGGL(k_soil_hist, dim3(512), dim3(kBlock), 0, c->stream, header, cls);
-    hipLaunchKernelGGL(k_soil_scatter, dim3(512), dim3(kBlock), 0, c->stream, header, raw, cls, sorted);
+        hipLaunchKernelGGL(k_soil_columns<false>, grid1, block, 0, c->stream, *a, P, shard_count, raw, cls,
+                           (unsigned int)shard_cap);
+    // the deferred count is only known on the device: fixed grids walk the lists with grid-stride loops
+    hipLaunchKernelGGL(k_soil_concat, dim3(64, kShards), block, 0, c->stream, header, shard_count, raw, cls,
+                       (unsigned int)shard_cap, raw2, cls2);
+    hipLaunchKernelGGL(k_soil_hist, dim3(512), block, 0, c->stream, header, cls2);
+    hipLaunchKernelGGL(k_soil_scatter, dim3(512), block, 0, c->stream, header, raw2, cls2, sorted);
     if (fastpow)
         hipLaunchKernelGGL(k_soil_columns_deferred<true>, dim3(4096), block, 0, c->stream, *a, P, header, sorted);
     else
