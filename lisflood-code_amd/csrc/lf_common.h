@@ -35,7 +35,7 @@ struct lf_device_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t t0 = nullptr, t1 = nullptr;
     void *soil_ws = nullptr; // work list of deferred soil columns (lf_soil.hip)
-    size_t soil_ws_bytes = 0;
+    size_t soil_ws_bytes = 0, soil_ntiles = 0;
 };
 int lf_ctx(int device, lf_device_ctx **out); // makes `device` current, creates the context on first use
 
