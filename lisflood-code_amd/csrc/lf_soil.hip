@@ -239,11 +239,12 @@ __device__ __forceinline__ long long soil_column(const lf_soil_args &A, const ve
 // Deferred columns are kept per TILE (= the 256 columns of one pass-1 block): pass 1 writes the tile's deferred
 // lanes (lane index + sub-step class) to a tile-local list with an LDS counter -- no global atomics -- and pass 2
 // gives each workgroup kGroup consecutive tiles, whose deferred columns it sorts by class in LDS (wavefronts then
-// run similar trip counts) and finishes.  Keeping pass 2 tile-local keeps its gathers inside a 1024-column window
+// run similar trip counts) and finishes.  Keeping pass 2 tile-local keeps its gathers inside a 4096-column window
 // of every stream instead of scattering 8-byte reads over the whole vectors (measured 14x over-fetch with a
 // global, class-sorted list).
 constexpr int kClasses = 8; // class = floor(log2(nsub)) clamped to kClasses-1: trip counts inside a class differ < 2x
-constexpr int kGroup = 4;   // tiles per pass-2 workgroup
+constexpr int kGroup = 16;  // tiles per pass-2 workgroup (a pool of 4096 columns: enough deferred columns to fill
+                            // wavefronts with similar trip counts even when the sub-step distribution has a long tail)
 
 template <bool FASTPOW>
 __global__ void __launch_bounds__(kBlock) k_soil_columns(lf_soil_args A, veg_plan P, unsigned short *__restrict__ tile_list,
@@ -284,7 +285,11 @@ __global__ void __launch_bounds__(kBlock) k_soil_columns_deferred(lf_soil_args A
     if (threadIdx.x < kGroup) cnt[threadIdx.x] = (t0 + threadIdx.x < ntiles) ? tile_count[t0 + threadIdx.x] : 0;
     if (threadIdx.x < kClasses) h[threadIdx.x] = 0;
     __syncthreads();
-    if (threadIdx.x == 0) total = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+    if (threadIdx.x == 0) {
+        unsigned int t = 0;
+        for (int g = 0; g < kGroup; ++g) t += cnt[g];
+        total = t;
+    }
     __syncthreads();
     if (total == 0) return;
     // class histogram, exclusive scan, scatter (all in LDS)

@@ -404,8 +404,13 @@ typedef struct {
     int64_t V, L, N;
 } lfo_soil_args;
 
+/* statistics of the last lfo_soil_columns call: columns, columns with > 1 sub-step, sum and max of nsub */
+static int64_t g_soil_stats[4];
+void lfo_soil_stats(int64_t out[4]) { memcpy(out, g_soil_stats, sizeof(g_soil_stats)); }
+
 void lfo_soil_columns(const lfo_soil_args *A)
 {
+    int64_t st_cols = 0, st_multi = 0, st_sum = 0, st_max = 0;
     const int64_t N = A->N;
     int64_t count_paddy = 0;
     for (int64_t veg = 0; veg < A->V; ++veg) {
@@ -421,7 +426,7 @@ void lfo_soil_columns(const lfo_soil_args *A)
         } else
             drained = A->is_irrigated[veg] && (A->DrainedFraction > 0);
         const int64_t lo = A->index_landuse_all[veg] * N, vo = veg * N;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) reduction(+ : st_cols, st_multi, st_sum) reduction(max : st_max)
         for (int64_t pix = 0; pix < N; ++pix) {
             if (inactive && !inactive[pix]) continue;
             const int64_t i = vo + pix, j = lo + pix;
@@ -479,6 +484,10 @@ void lfo_soil_columns(const lfo_soil_args *A)
             double courant = dmax(dmax(ca, cb), cg); /* max(a,b,c) sequential */
             double nsub_f = dmax(1, ceil(courant / A->CourantCrit));
             int64_t nsub = (int64_t)nsub_f;
+            st_cols += 1;
+            st_multi += nsub > 1;
+            st_sum += nsub;
+            if (nsub > st_max) st_max = nsub;
             /* sub-step loop, :266-312 */
             double wt1a = w1a, wt1b = w1b, wt2 = w2;
             double sa = 0., sb = 0., sg = 0.;
@@ -547,6 +556,10 @@ void lfo_soil_columns(const lfo_soil_args *A)
             A->UZ[i] = uz;
         }
     }
+    g_soil_stats[0] = st_cols;
+    g_soil_stats[1] = st_multi;
+    g_soil_stats[2] = st_sum;
+    g_soil_stats[3] = st_max;
 }
 
 /* ------------------------------------------------------------------------------------------------
