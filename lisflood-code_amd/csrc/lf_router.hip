@@ -105,8 +105,6 @@ struct lf_router {
     double beta = 0, inv_beta = 0, b_minus_1 = 0, dx_scalar = 0;
     bool has_floodplains = false, dx_per_pixel = false;
     int kmax = 8;
-    bool pair_lanes = false; // engine-order sweep with two cells per lane (16-byte streams): measured equal to the
-                             // one-cell kernel (132 vs 131 us per 12.5 M-cell level), kept behind LF_PAIR_LANES=1
     bool fused = false; // beta == 3/5: prep fused into the sweep, polynomial closure solve (lf_math.h)
     lf_dbuf<int32_t> perm, ups_ptr;
     lf_dbuf<long long> level_start;
@@ -215,9 +213,7 @@ int route_device(lf_router *r, double *q_dev, const double *lat_dev, int section
             const int count = (int)(r->h_level_start[g.k1] - r->h_level_start[g.k0]);
             LF_TRY(r->prof_begin(1, count));
             const dim3 grid(blocks_for(count)), block(kBlock);
-            if (r->fused && ordered && r->pair_lanes)
-                hipLaunchKernelGGL(k_level_pair, dim3(blocks_for((count + 3) / 2)), block, 0, s, first, count, A);
-            else if (r->fused && ordered)
+            if (r->fused && ordered)
                 hipLaunchKernelGGL((k_level<true, true>), grid, block, 0, s, first, count, A);
             else if (r->fused)
                 hipLaunchKernelGGL((k_level<true, false>), grid, block, 0, s, first, count, A);
@@ -279,8 +275,6 @@ int lf_router_create(const lf_graph *g, const double *alpha, double beta, const 
     // general path (the reference's own Newton iteration with pow) for A/B parity and timing.
     const char *force_general = std::getenv("LF_GENERAL_POW");
     r->fused = (beta == 0.6) && !(force_general && force_general[0] == '1');
-    const char *pair = std::getenv("LF_PAIR_LANES");
-    r->pair_lanes = pair && pair[0] == '1';
     const int64_t n = g->N;
     int rc = LF_OK;
     {

@@ -130,52 +130,6 @@ __global__ void __launch_bounds__(kBlock) k_level(int first, int count, sweep_ar
     sweep_cell<FUSED, ORDERED, INDEXED>(first + i, A);
 }
 
-// Engine-order, beta = 3/5, contiguous upstream ranges: TWO consecutive cells per lane so that every stream
-// (a, dx, lateral inflow, old / new discharge) moves as 16-byte accesses.  The pair starts at an even position
-// (16-byte aligned); positions outside [first, first + count) are masked.
-__global__ void __launch_bounds__(kBlock) k_level_pair(int first, int count, sweep_args A)
-{
-    const int base = first & ~1;
-    const int p0 = base + 2 * (blockIdx.x * kBlock + threadIdx.x);
-    const int last = first + count;
-    if (p0 >= last) return;
-    const bool on0 = p0 >= first, on1 = p0 + 1 < last;
-    if (on0 && on1) {
-        const double2 a2 = *reinterpret_cast<const double2 *>(A.a + p0);
-        const double2 l2 = *reinterpret_cast<const double2 *>(A.lat + p0);
-        const double2 q2 = *reinterpret_cast<const double2 *>(A.qord + p0);
-        double2 d2 = make_double2(A.dx_scalar, A.dx_scalar);
-        if (A.dx) d2 = *reinterpret_cast<const double2 *>(A.dx + p0);
-        const int u0 = A.ups_ptr[p0], u1 = A.ups_ptr[p0 + 1], u2 = A.ups_ptr[p0 + 2];
-        double v0[8], v1[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            v0[k] = (k < A.kmax && u0 + k < u1) ? A.qord[u0 + k] : 0.0;
-            v1[k] = (k < A.kmax && u1 + k < u2) ? A.qord[u1 + k] : 0.0;
-        }
-        double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            s0 += v0[k];
-            s1 += v1[k];
-        }
-        const double c0 = s0 + (a2.x * lf_pow_3_5(q2.x) + l2.x * d2.x);
-        const double c1 = s1 + (a2.y * lf_pow_3_5(q2.y) + l2.y * d2.y);
-        double r0, r1;
-        if (lf_fast_range(c0) && lf_fast_range(a2.x))
-            r0 = (c0 <= LF_NEWTON_TOL) ? 0.0 : lf_solve_3_5(c0, a2.x);
-        else
-            r0 = lf_solve_cell(c0, a2.x, A.beta * a2.x, A.beta, A.inv_beta, A.b_minus_1);
-        if (lf_fast_range(c1) && lf_fast_range(a2.y))
-            r1 = (c1 <= LF_NEWTON_TOL) ? 0.0 : lf_solve_3_5(c1, a2.y);
-        else
-            r1 = lf_solve_cell(c1, a2.y, A.beta * a2.y, A.beta, A.inv_beta, A.b_minus_1);
-        *reinterpret_cast<double2 *>(A.qord + p0) = make_double2(r0, r1);
-    } else {
-        sweep_cell<true, true, false>(on0 ? p0 : p0 + 1, A);
-    }
-}
-
 // a run of narrow levels [k0, k1): one workgroup, barrier between levels
 template <bool FUSED, bool ORDERED, bool INDEXED = false>
 __global__ void __launch_bounds__(kNarrowBlock) k_levels_narrow(int k0, int k1, const long long *__restrict__ level_start,
