@@ -54,8 +54,8 @@ typedef struct lf_comm lf_comm;               /* RCCL communicator (one rank per
 const char *lf_last_error(void);
 int lf_version(void);
 /* sizeof(lf_substep_args), sizeof(lf_interception_args), sizeof(lf_soil_args), sizeof(lf_canopy_args),
- * sizeof(lf_surface_args): lets a binding verify its struct mirrors. */
-int lf_struct_sizes(int64_t out[5]);
+ * sizeof(lf_surface_args), sizeof(lf_inloop_args): lets a binding verify its struct mirrors. */
+int lf_struct_sizes(int64_t out[6]);
 
 /* ---------------------------------------------------------------------------------------------
  * device plumbing
@@ -259,6 +259,45 @@ typedef struct lf_surface_args {
 } lf_surface_args;
 int lf_surface_step(lf_router *direct_router, lf_router *other_router, lf_router *forest_router,
                     const lf_surface_args *a);
+
+/* In-loop structures of routing.dynamic (routing.py:441-478): lakes (lakes.py:199-297, Modified Puls), reservoirs
+ * (reservoir.py:173-322), inflow hydrographs (inflow.py:129-147), transmission loss (transmission.py:67-89) and
+ * the SideflowChanM3 assembly (routing.py:462-478), all on device vectors in ONE order (pixel or engine).
+ * Sites are few (LF_ETRS89: 5 lakes, 64 reservoirs): one lane per site; per-site inflow = sum of ChanQ over
+ * site_ups_idx[site_ups_ptr[i] .. site_ups_ptr[i+1]) in ascending pixel id (np.bincount(downstruct, ChanQ)).
+ * Any pointer group may be NULL / its count 0 (option switched off). */
+typedef struct lf_inloop_args {
+    const double *ChanQ; /* [N] discharge at the start of the sub-step */
+    /* lakes [n_lakes] */
+    int64_t n_lakes;
+    const int32_t *lake_cell, *lake_ups_ptr, *lake_ups_idx;
+    const double *LakeFactor, *LakeFactorSqr, *LakeAreaCC;
+    double *LakeStorageM3CC, *LakeInflowOldCC, *LakeOutflowCC, *LakeStorageM3BalanceCC, *LakeLevelCC, *LakeInflowCC;
+    double *QLakeOutM3Dt; /* [N], written at the lake cells only */
+    /* reservoirs [n_res] */
+    int64_t n_res;
+    const int32_t *res_cell, *res_ups_ptr, *res_ups_idx;
+    const double *TotalReservoirStorageM3CC, *MinReservoirOutflowCC, *NormalReservoirOutflowCC,
+        *NonDamagingReservoirOutflowCC, *ConservativeStorageLimitCC, *NormalStorageLimitCC, *FloodStorageLimitCC,
+        *Normal_FloodStorageLimitCC, *DeltaO, *DeltaLN, *DeltaNFL;
+    double *ReservoirStorageM3CC, *ReservoirFillCC, *ReservoirInflowCC;
+    double *QResOutM3Dt; /* [N], written at the reservoir cells only */
+    /* inflow hydrographs [N] (NULL = option off) */
+    const double *QInM3Old, *QDelta;
+    double *QInDt, *QinADDEDM3;
+    /* transmission loss [N] (NULL = option off) */
+    const uint8_t *UpTrans;
+    double *TransLossM3Dt, *TransCum;
+    double TransPower1, TransPower2, TransSub;
+    /* sideflow assembly [N]: out = ToChanM3RunoffDt - EvaAddM3Dt - WUseAddM3Dt + QInDt - TransLossM3Dt
+     *                              + QLakeOutM3Dt + QResOutM3Dt - ChannelToPolderM3Dt   (NULL terms skipped) */
+    const double *ToChanM3RunoffDt, *EvaAddM3Dt, *WUseAddM3Dt, *ChannelToPolderM3Dt;
+    double *SideflowChanM3;
+    double DtRouting, InvNoRoutSteps;
+    int64_t N;
+    int32_t step; /* NoRoutingExecuted */
+} lf_inloop_args;
+int lf_inloop_structures(int device, const lf_inloop_args *a);
 
 /* host-buffer forms (drop-in for the numba kernels; PCIe-inclusive) */
 int lf_interception_host(int device, const lf_interception_args *a);

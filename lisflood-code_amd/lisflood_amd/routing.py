@@ -36,6 +36,31 @@ class _SubstepArgs(C.Structure):  # lf_substep_args, include/lisflood_amd.h
                  ("split", C.c_int32), ("engine_order", C.c_int32)])
 
 
+_INLOOP_PTRS = (
+    "ChanQ n_lakes lake_cell lake_ups_ptr lake_ups_idx LakeFactor LakeFactorSqr LakeAreaCC LakeStorageM3CC "
+    "LakeInflowOldCC LakeOutflowCC LakeStorageM3BalanceCC LakeLevelCC LakeInflowCC QLakeOutM3Dt n_res res_cell "
+    "res_ups_ptr res_ups_idx TotalReservoirStorageM3CC MinReservoirOutflowCC NormalReservoirOutflowCC "
+    "NonDamagingReservoirOutflowCC ConservativeStorageLimitCC NormalStorageLimitCC FloodStorageLimitCC "
+    "Normal_FloodStorageLimitCC DeltaO DeltaLN DeltaNFL ReservoirStorageM3CC ReservoirFillCC ReservoirInflowCC "
+    "QResOutM3Dt QInM3Old QDelta QInDt QinADDEDM3 UpTrans TransLossM3Dt TransCum").split()
+
+
+class _InloopArgs(C.Structure):  # lf_inloop_args, include/lisflood_amd.h
+    _fields_ = ([(k, C.c_int64 if k in ("n_lakes", "n_res") else C.c_void_p) for k in _INLOOP_PTRS] +
+                [("TransPower1", C.c_double), ("TransPower2", C.c_double), ("TransSub", C.c_double)] +
+                [(k, C.c_void_p) for k in ("ToChanM3RunoffDt", "EvaAddM3Dt", "WUseAddM3Dt", "ChannelToPolderM3Dt",
+                                           "SideflowChanM3")] +
+                [("DtRouting", C.c_double), ("InvNoRoutSteps", C.c_double), ("N", C.c_int64), ("step", C.c_int32)])
+
+
+_LAKE_PARAM = "LakeFactor LakeFactorSqr LakeAreaCC".split()
+_LAKE_STATE = "LakeStorageM3CC LakeInflowOldCC LakeOutflowCC LakeStorageM3BalanceCC LakeLevelCC LakeInflowCC".split()
+_RES_PARAM = ("TotalReservoirStorageM3CC MinReservoirOutflowCC NormalReservoirOutflowCC NonDamagingReservoirOutflowCC "
+              "ConservativeStorageLimitCC NormalStorageLimitCC FloodStorageLimitCC Normal_FloodStorageLimitCC DeltaO "
+              "DeltaLN DeltaNFL").split()
+_RES_STATE = "ReservoirStorageM3CC ReservoirFillCC ReservoirInflowCC".split()
+
+
 class routing(HydroModule):
     input_files_keys = {'all': ['beta', 'ChanLength', 'Ldd', 'Channels', 'ChanGrad', 'ChanGradMin', 'CalChanMan',
                                 'ChanMan', 'ChanBottomWidth', 'ChanDepthThreshold', 'ChanSdXdY',
@@ -263,6 +288,111 @@ class routing(HydroModule):
                 s -= v.ChannelToPolderM3Dt
         return s
 
+    # ------------------------------------------------------------------------------------------
+    def attach_structures(self):
+        """Lakes, reservoirs, inflow hydrographs and transmission loss inside the sub-step loop (routing.py:441-450),
+        on the device.  Reads the reference's attribute names from `var` according to the options
+        simulateLakes / simulateReservoirs / inflow / TransLoss: LakeIndex, LakeFactor, LakeFactorSqr, LakeAreaCC,
+        LakeStorageM3, LakeInflowOldCC, LakeOutflowCC, LakeStorageM3BalanceCC, LakeLevelCC (lakes.py);
+        ReservoirIndex, the eleven *CC parameter vectors, ReservoirStorageM3 (reservoir.py); QInM3Old, QDelta
+        (inflow.py); UpTrans, TransPower1/2, TransSub, TransCum (transmission.py); and `downstruct` of the UNCUT
+        kinematic LDD (routing.py:159-164) for the structures' inflow."""
+        v, o = self.var, self.options
+        N = self.river_router.num_pixels
+        self._ensure_device()
+        st = self._st = dict(dev={}, lakes=0, res=0)
+        a = self._inloop = _InloopArgs()
+        ds = np.asarray(v.downstruct).astype(np.int64)
+        order = np.argsort(ds, kind="stable")               # sources grouped by target, ascending source id
+        starts = np.searchsorted(ds[order], np.arange(N + 1))
+
+        def site_csr(cells):
+            ptr = np.zeros(len(cells) + 1, np.int32)
+            idx = []
+            for i, c in enumerate(cells):
+                u = order[starts[c]:starts[c + 1]]
+                idx.append(u)
+                ptr[i + 1] = ptr[i] + u.size
+            idx = np.concatenate(idx).astype(np.int32) if idx else np.zeros(0, np.int32)
+            return ptr, (idx if idx.size else np.zeros(1, np.int32))
+
+        def put(name, arr):
+            st["dev"][name] = DeviceArray.from_host(np.ascontiguousarray(arr), self.device)
+            setattr(a, name, st["dev"][name].ptr.value)
+
+        if o.get("simulateLakes") and not o.get("InitLisflood"):
+            cells = np.asarray(v.LakeIndex).astype(np.int32)
+            st["lakes"] = a.n_lakes = cells.size
+            ptr, idx = site_csr(cells)
+            put("lake_cell", cells); put("lake_ups_ptr", ptr); put("lake_ups_idx", idx)
+            for k in _LAKE_PARAM:
+                put(k, f64(np.broadcast_to(getattr(v, k), (cells.size,))))
+            for k in _LAKE_STATE:
+                put(k, f64(np.broadcast_to(getattr(v, k, 0.0), (cells.size,))))
+            put("QLakeOutM3Dt", np.zeros(N))
+        if o.get("simulateReservoirs") and not o.get("InitLisflood"):
+            cells = np.asarray(v.ReservoirIndex).astype(np.int32)
+            st["res"] = a.n_res = cells.size
+            ptr, idx = site_csr(cells)
+            put("res_cell", cells); put("res_ups_ptr", ptr); put("res_ups_idx", idx)
+            for k in _RES_PARAM:
+                put(k, f64(np.broadcast_to(getattr(v, k), (cells.size,))))
+            for k in _RES_STATE:
+                put(k, f64(np.broadcast_to(getattr(v, k, 0.0), (cells.size,))))
+            put("QResOutM3Dt", np.zeros(N))
+        if o.get("inflow"):
+            put("QInM3Old", f64(v.QInM3Old)); put("QDelta", f64(v.QDelta))
+            put("QInDt", np.zeros(N)); put("QinADDEDM3", np.zeros(N))
+        if o.get("TransLoss"):
+            put("UpTrans", u8(v.UpTrans)); put("TransLossM3Dt", np.zeros(N))
+            put("TransCum", f64(np.broadcast_to(getattr(v, "TransCum", 0.0), (N,))))
+            a.TransPower1, a.TransPower2, a.TransSub = float(v.TransPower1), float(v.TransPower2), float(v.TransSub)
+        for k in ("ToChanM3RunoffDt", "EvaAddM3Dt", "WUseAddM3Dt", "ChannelToPolderM3Dt"):
+            st["dev"][k] = DeviceArray(N, np.float64, self.device).zero()
+        a.ToChanM3RunoffDt = st["dev"]["ToChanM3RunoffDt"].ptr.value
+        a.ChanQ = self._dev["ChanQ"].ptr.value
+        a.SideflowChanM3 = self._dev["SideflowChanM3"].ptr.value
+        a.DtRouting, a.InvNoRoutSteps, a.N = float(v.DtRouting), float(v.InvNoRoutSteps), N
+
+    def _structures_substep(self, s):
+        v, o, st, a = self.var, self.options, self._st, self._inloop
+        N = self.river_router.num_pixels
+        if s == 0:      # lakes.py:211-212, reservoir.py:195-196: site state from the dense state maps
+            if st["lakes"]:
+                st["dev"]["LakeStorageM3CC"].upload(f64(np.asarray(v.LakeStorageM3)[np.asarray(v.LakeIndex)]))
+            if st["res"]:
+                st["dev"]["ReservoirStorageM3CC"].upload(f64(np.asarray(v.ReservoirStorageM3)[np.asarray(v.ReservoirIndex)]))
+        st["dev"]["ToChanM3RunoffDt"].upload(f64(np.broadcast_to(v.ToChanM3RunoffDt, (N,))))
+        for k, opt in (("EvaAddM3Dt", "openwaterevapo"), ("WUseAddM3Dt", "wateruse"), ("ChannelToPolderM3Dt", "simulatePolders")):
+            if o.get(opt):
+                if k == "WUseAddM3Dt":
+                    v.WUseAddM3Dt = v.withdrawal_CH_actual_M3_routStep - v.returnflow_GwAbs2Channel_M3_routStep
+                st["dev"][k].upload(f64(np.broadcast_to(getattr(v, k), (N,))))
+                setattr(a, k, st["dev"][k].ptr.value)
+        a.step = int(s)
+        check(lib().lf_inloop_structures(C.c_int(self.device), C.byref(a)))
+
+    def _structures_download(self, s):
+        v, st = self.var, self._st
+        names = []
+        if st["lakes"]:
+            names += _LAKE_STATE + ["QLakeOutM3Dt"]
+        if st["res"]:
+            names += _RES_STATE + ["QResOutM3Dt"]
+        names += [k for k in ("QInDt", "QinADDEDM3", "TransLossM3Dt", "TransCum") if k in st["dev"]]
+        for k in names:
+            setattr(v, k, st["dev"][k].download())
+        if s == v.NoRoutSteps - 1:      # lakes.py:283-292, reservoir.py:311-315: expand to the dense state maps
+            N = self.river_router.num_pixels
+            if st["lakes"]:
+                for dense, cc in (("LakeStorageM3", "LakeStorageM3CC"), ("LakeStorageM3Balance", "LakeStorageM3BalanceCC"),
+                                  ("LakeLevel", "LakeLevelCC"), ("LakeInflowOld", "LakeInflowOldCC"),
+                                  ("LakeOutflow", "LakeOutflowCC")):
+                    d = np.zeros(N); d[np.asarray(v.LakeIndex)] = getattr(v, cc); setattr(v, dense, d)
+            if st["res"]:
+                for dense, cc in (("ReservoirStorageM3", "ReservoirStorageM3CC"), ("ReservoirFill", "ReservoirFillCC")):
+                    d = np.zeros(N); d[np.asarray(v.ReservoirIndex)] = getattr(v, cc); setattr(v, dense, d)
+
     def dynamic_fused(self, sideflows=None):
         """All NoRoutSteps sub-steps of a model step in one call (the loop of Lisflood_dynamic.py:179-180), run as a
         skewed wavefront over (level, sub-step) on the device -- NL + NoRoutSteps - 1 launches instead of
@@ -285,14 +415,16 @@ class routing(HydroModule):
         self._ensure_device()
         if not self._resident:
             self._upload_state()
-        self._dev["SideflowChanM3"].upload(f64(self.sideflow_m3()))
+        if getattr(self, "_inloop", None) is not None:
+            self._structures_substep(NoRoutingExecuted)      # structures + sideflow assembly on the device
+        else:
+            self._dev["SideflowChanM3"].upload(f64(self.sideflow_m3()))
         self._args.split = 1 if self._split() else 0
         check(lib().lf_routing_substep(self.river_router._h, C.byref(self._args)))
-        if self._split():
-            # routing.py:602: copy of the running sum before this sub-step's contribution
-            pass
         if not self._resident:
             self._download_state()
+        if getattr(self, "_inloop", None) is not None:
+            self._structures_download(NoRoutingExecuted)
 
 
 def _fused(self, sideflows):

@@ -123,8 +123,11 @@ def load():
     soil = importlib.import_module("lisflood.hydrological_modules.soilloop")
     rout = importlib.import_module("lisflood.hydrological_modules.routing")
     surf = importlib.import_module("lisflood.hydrological_modules.surface_routing")
+    extra = {}
+    for name in ("lakes", "reservoir", "inflow", "transmission"):
+        extra[name] = importlib.import_module("lisflood.hydrological_modules." + name)
     _loaded.update(kwp=kwp, kwpt=kwp.kwpt, soilloop=soil, routing=rout, surface=surf,
-                   LisSettings=_Settings, MaskInfo=_MaskInfo)
+                   LisSettings=_Settings, MaskInfo=_MaskInfo, **extra)
     return _loaded
 
 

@@ -534,11 +534,123 @@ def gen_canopy_soil_step():
          **{"init_" + k: a for k, a in before.items()}, **{"static_" + k: a for k, a in static.items()}, **forc, **outs)
 
 
+def gen_inloop():
+    """routing.dynamic(s) WITH the reference's own lakes / reservoir / inflow / transmission modules in the loop
+    (routing.py:441-478) on LF_ETRS89: real lake and reservoir sites (ec_lakes.nc, ec_res.nc), the LDD cut just
+    upstream of every structure as structures.initial does (structures.py:51-59), synthetic structure parameters."""
+    z, ldd, mask = etrs89()
+    N = int(mask.sum())
+    cp = etrs89_channel_params(z, mask)
+    rng = np.random.default_rng(61)
+    opts = REF["LisSettings"].options
+    opts.clear()
+    opts.update(InitLisflood=False, SplitRouting=True, simulateLakes=True, simulateReservoirs=True, TransLoss=True,
+                inflow=True)
+    REF["MaskInfo"].n = N
+    nsteps = 24
+    v, _ = routing_var(ldd, mask, cp["alpha"], cp["alpha2"], cp["ChanLength"], 3600.0, nsteps, cp["Q0"], 62)
+    v.InvNoRoutSteps = 1 / nsteps
+    codes = ldd[mask].astype(np.float64)
+    full = build_router(ldd, mask, v.ChannelAlpha, v.Beta, v.ChanLength, v.DtRouting)     # uncut graph
+    down = full.downstream_lookup.astype(np.int64)
+    v.downstruct = np.where(down < 0, N, down).astype(np.int32)                            # routing.py:159-164
+    lake_sites = (z["lakes"][mask] > 0)
+    res_sites = (z["res"][mask] > 0) & ~lake_sites
+    is_struct = lake_sites | res_sites
+    ups_of_struct = (down >= 0) & is_struct[np.maximum(down, 0)]                           # structures.py:51-54
+    cut = np.where(ups_of_struct, 5.0, codes)                                              # structures.py:59
+    cut2d = np.zeros(mask.shape, ldd.dtype); cut2d[mask] = cut
+    kw = build_router(cut2d, mask, v.ChannelAlpha, v.Beta, v.ChanLength, v.DtRouting, alpha2=v.ChannelAlpha2)
+    ups = kwp.kwpt.immediateUpstreamInflow(v.QLimit, kw.upstream_lookup, kw.num_upstream_pixels)
+    v.Chan2QStart = v.QLimit - ups
+    v.CrossSection2Area = np.zeros(N)
+    ChanM3 = cp["area0"] * v.ChanLength * rng.uniform(0.5, 3.0, N)
+    v.Chan2M3Kin = v.CrossSection2Area * v.ChanLength + v.Chan2M3Start
+    v.ChanM3Kin = np.maximum(ChanM3 - v.Chan2M3Kin + v.Chan2M3Start, 0.0)
+    v.Chan2QKin = (v.Chan2M3Kin * v.InvChanLength * v.InvChannelAlpha2) ** v.InvBeta
+    v.ChanQKin = (v.ChanM3Kin * v.InvChanLength * v.InvChannelAlpha) ** v.InvBeta
+    v.ChanQ = np.maximum(v.ChanQKin + v.Chan2QKin - v.QLimit, 0.0)
+    v.sumDisDay = np.zeros(N); v.Sideflow1Chan = np.zeros(N)
+    # lakes (lakes.py:96-160)
+    v.LakeIndex = np.nonzero(lake_sites)[0]
+    nl = v.LakeIndex.size
+    v.LakeSitesC2 = lake_sites.astype(float)
+    v.LakeAreaCC = rng.uniform(2e6, 5e7, nl)
+    LakeACC = rng.uniform(5.0, 80.0, nl)
+    v.LakeFactor = v.LakeAreaCC / (v.DtRouting * np.sqrt(LakeACC))
+    v.LakeFactorSqr = np.square(v.LakeFactor)
+    v.LakeInflowOldCC = np.bincount(v.downstruct, weights=v.ChanQ)[v.LakeIndex]
+    v.LakeLevelCC = rng.uniform(0.5, 3.0, nl)
+    v.LakeStorageM3 = np.zeros(N); v.LakeStorageM3[v.LakeIndex] = v.LakeAreaCC * v.LakeLevelCC
+    v.LakeOutflowCC = LakeACC * v.LakeLevelCC ** 2 * 0 + np.square(v.LakeLevelCC) * LakeACC
+    v.LakeStorageM3BalanceCC = v.LakeStorageM3[v.LakeIndex].copy()
+    # reservoirs (reservoir.py:73-165)
+    v.ReservoirSitesC = res_sites.astype(float)
+    v.ReservoirIndex = np.nonzero(res_sites)[0]
+    nr = v.ReservoirIndex.size
+    v.TotalReservoirStorageM3CC = np.exp(rng.uniform(np.log(1e6), np.log(5e8), nr))
+    v.ConservativeStorageLimitCC = rng.uniform(0.05, 0.15, nr)
+    v.NormalStorageLimitCC = rng.uniform(0.4, 0.7, nr)
+    v.FloodStorageLimitCC = rng.uniform(0.8, 0.97, nr)
+    v.Normal_FloodStorageLimitCC = v.NormalStorageLimitCC + 0.5 * (v.FloodStorageLimitCC - v.NormalStorageLimitCC)
+    qin0 = np.bincount(v.downstruct, weights=v.ChanQ)[v.ReservoirIndex]
+    v.MinReservoirOutflowCC = 0.1 * qin0 + 0.01
+    v.NormalReservoirOutflowCC = 0.9 * qin0 + 0.05
+    v.NonDamagingReservoirOutflowCC = 4.0 * qin0 + 1.0
+    v.DeltaO = v.NormalReservoirOutflowCC - v.MinReservoirOutflowCC
+    v.DeltaLN = v.NormalStorageLimitCC - 2 * v.ConservativeStorageLimitCC
+    v.DeltaNFL = v.FloodStorageLimitCC - v.Normal_FloodStorageLimitCC
+    fill0 = rng.uniform(0.02, 1.0, nr)            # spans every branch of the outflow rule
+    v.ReservoirStorageM3 = np.zeros(N); v.ReservoirStorageM3[v.ReservoirIndex] = fill0 * v.TotalReservoirStorageM3CC
+    # inflow hydrographs and transmission loss
+    v.QInM3Old = np.zeros(N); v.QDelta = np.zeros(N)
+    pts = rng.choice(N, 6, replace=False)
+    v.QInM3Old[pts] = rng.uniform(1e4, 2e5, 6); v.QDelta[pts] = rng.uniform(-2e3, 2e3, 6)
+    v.UpTrans = (rng.random(N) < 0.3) & (v.ChanQ > 1.0)      # reaches that carry water: (Q^p2 - sub) stays positive
+    v.TransPower1, v.TransPower2, v.TransSub = 1 / 0.95, 0.95, 1e-5
+    v.TransCum = np.zeros(N)
+    m = REF["routing"].routing(v)
+    m.river_router = kw
+    m.lakes_module = REF["lakes"].lakes(v)
+    m.reservoir_module = REF["reservoir"].reservoir(v)
+    m.inflow_module = REF["inflow"].inflow(v)
+    m.transmission_module = REF["transmission"].transmission(v)
+    m.polder_module = types.SimpleNamespace(dynamic_inloop=lambda *a, **k: None)
+    init_keys = ("ChanQKin", "ChanM3Kin", "Chan2QKin", "Chan2M3Kin", "CrossSection2Area", "Sideflow1Chan", "ChanQ",
+                 "LakeStorageM3", "LakeInflowOldCC", "LakeOutflowCC", "LakeStorageM3BalanceCC", "LakeLevelCC",
+                 "ReservoirStorageM3", "TransCum")
+    init = {k: np.array(getattr(v, k), dtype=np.float64).copy() for k in init_keys}
+    out_keys = ("ChanQKin", "ChanM3Kin", "Chan2QKin", "Chan2M3Kin", "ChanQ", "sumDisDay", "QLakeOutM3Dt", "QResOutM3Dt",
+                "LakeStorageM3CC", "LakeOutflowCC", "LakeInflowOldCC", "LakeStorageM3BalanceCC", "LakeLevelCC",
+                "ReservoirStorageM3CC", "ReservoirFillCC", "QInDt", "QinADDEDM3", "TransLossM3Dt", "TransCum")
+    traj = {k: [] for k in out_keys}
+    side = []
+    with np.errstate(all="ignore"):
+        for s in range(nsteps):
+            v.ToChanM3RunoffDt = rng.uniform(0.0, 4000.0, N) * (rng.random(N) < 0.8)
+            side.append(v.ToChanM3RunoffDt.copy())
+            m.dynamic(s)
+            for k in out_keys:
+                traj[k].append(np.array(getattr(v, k), dtype=np.float64).copy())
+    sub = [0, 1, 5, 23]
+    static = {k: np.asarray(getattr(v, k)) for k in (
+        "ChannelAlpha", "ChannelAlpha2", "ChanLength", "PixelArea", "IsChannelKinematic", "QLimit", "M3Limit",
+        "Chan2M3Start", "Chan2QStart", "downstruct", "LakeIndex", "LakeAreaCC", "LakeFactor", "LakeFactorSqr",
+        "ReservoirIndex", "TotalReservoirStorageM3CC", "ConservativeStorageLimitCC", "NormalStorageLimitCC",
+        "FloodStorageLimitCC", "Normal_FloodStorageLimitCC", "MinReservoirOutflowCC", "NormalReservoirOutflowCC",
+        "NonDamagingReservoirOutflowCC", "DeltaO", "DeltaLN", "DeltaNFL", "QInM3Old", "QDelta", "UpTrans")}
+    save("inloop_structures", codes_cut=cut, mask=mask, Beta=v.Beta, DtRouting=v.DtRouting, NoRoutSteps=nsteps,
+         TransPower1=v.TransPower1, TransPower2=v.TransPower2, TransSub=v.TransSub, sampled=np.array(sub),
+         ToChanM3RunoffDt=np.array(side), **static, **{"init_" + k: a for k, a in init.items()},
+         **{"out_" + k: np.array(a)[sub] for k, a in traj.items()})
+    opts.clear()
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["graphs", "routes", "edge", "substeps", "upsum", "interception", "soil", "surface",
-                             "canopy"]
+                             "canopy", "inloop"]
     fns = dict(graphs=gen_graphs, routes=gen_routes, edge=gen_route_edge, substeps=gen_substeps,
                upsum=gen_upstream_sum, interception=gen_interception, soil=gen_soil_columns,
-               surface=gen_surface_step, canopy=gen_canopy_soil_step)
+               surface=gen_surface_step, canopy=gen_canopy_soil_step, inloop=gen_inloop)
     for w in which:
         fns[w]()

@@ -333,6 +333,43 @@ def test_routing_module_initial_to_step_end_on_etrs89(amd, oracle):
     close(v.TotalCrossSectionArea, sub.v.ChanM3Kin * v.InvChanLength)
 
 
+def test_routing_with_inloop_structures_golden(amd, solver):
+    """routing.dynamic with lakes, reservoirs, inflow hydrographs and transmission loss inside the loop
+    (routing.py:441-478), all on the device, against vectors captured from the reference's own modules
+    (lakes.py, reservoir.py, inflow.py, transmission.py driven by routing.dynamic) on LF_ETRS89's 5 lake and
+    64 reservoir sites."""
+    g = golden("inloop_structures")
+    v = amd.routing.var_from_fixture(g)
+    v.ChanQ = g["init_ChanQ"].copy()
+    v.InvNoRoutSteps = 1 / v.NoRoutSteps
+    for k in ("downstruct", "LakeIndex", "LakeAreaCC", "LakeFactor", "LakeFactorSqr", "ReservoirIndex", "QInM3Old",
+              "QDelta", "UpTrans", "TotalReservoirStorageM3CC", "ConservativeStorageLimitCC", "NormalStorageLimitCC",
+              "FloodStorageLimitCC", "Normal_FloodStorageLimitCC", "MinReservoirOutflowCC", "NormalReservoirOutflowCC",
+              "NonDamagingReservoirOutflowCC", "DeltaO", "DeltaLN", "DeltaNFL"):
+        setattr(v, k, g[k])
+    for k in ("LakeStorageM3", "LakeInflowOldCC", "LakeOutflowCC", "LakeStorageM3BalanceCC", "LakeLevelCC",
+              "ReservoirStorageM3", "TransCum"):
+        setattr(v, k, g["init_" + k].copy())
+    v.TransPower1, v.TransPower2, v.TransSub = float(g["TransPower1"]), float(g["TransPower2"]), float(g["TransSub"])
+    m = amd.routing.routing(v, options=dict(SplitRouting=True, InitLisflood=False, simulateLakes=True,
+                                            simulateReservoirs=True, inflow=True, TransLoss=True))
+    m.attach_router(g["codes_cut"], g["mask"])
+    m.attach_structures()
+    sampled = g["sampled"].tolist()
+    keys = ("ChanQKin", "ChanM3Kin", "Chan2QKin", "Chan2M3Kin", "ChanQ", "sumDisDay", "QLakeOutM3Dt", "QResOutM3Dt",
+            "LakeStorageM3CC", "LakeOutflowCC", "LakeInflowOldCC", "LakeStorageM3BalanceCC", "LakeLevelCC",
+            "ReservoirStorageM3CC", "ReservoirFillCC", "QInDt", "QinADDEDM3", "TransLossM3Dt", "TransCum")
+    for s in range(v.NoRoutSteps):
+        v.ToChanM3RunoffDt = g["ToChanM3RunoffDt"][s]
+        m.dynamic(s)
+        if s in sampled:
+            i = sampled.index(s)
+            for k in keys:
+                # volumes of 1e6..1e8 m3: the 1e-9 relative bar, with the Newton tolerance scaled by DtRouting as atol
+                np.testing.assert_allclose(getattr(v, k), g["out_" + k][i], rtol=RTOL, atol=1e-8, err_msg=str((s, k)))
+    assert (v.LakeStorageM3[g["LakeIndex"]] == v.LakeStorageM3CC).all()
+
+
 def test_interception_golden(amd):
     g = golden("interception")
     st = {k: g["in_" + k].copy() for k in ("Interception", "TaInterception", "LeafDrainage", "CumInterception")}
