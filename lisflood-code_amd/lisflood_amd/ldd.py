@@ -99,3 +99,15 @@ def catchment(codes, land_mask, points):
         inherited = np.where(d >= 0, lab[np.maximum(d, 0)], 0)
         lab[cells] = np.where(pts[cells] != 0, pts[cells], inherited)
     return lab
+
+
+def cut_at_structures(codes, land_mask, is_structure):
+    """structures.initial (structures.py:44-61): the cells just upstream of a lake / reservoir become pits of the
+    kinematic LDD (their outflow reaches the structure through its own inflow term instead).  Returns
+    (cut codes, IsUpsOfStructureKinematicC)."""
+    down = downstream_index(codes, land_mask)
+    st = np.asarray(is_structure, bool)
+    ups = (down >= 0) & st[np.maximum(down, 0)]          # downstream(LddKinematic, IsStructureKinematic)
+    out = np.asarray(codes).copy()
+    out[ups] = PIT
+    return lddrepair(out, land_mask), ups

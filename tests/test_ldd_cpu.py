@@ -63,3 +63,21 @@ def test_lddmask_and_repair_make_pits_at_the_cut():
     rep = L.lddrepair(bad, mask)
     assert rep[3] == L.PIT and rep[5] == L.PIT
     assert (L.pit(rep) > 0).sum() == (rep == L.PIT).sum() and L.pit(rep).max() == (rep == L.PIT).sum()
+
+
+def test_cut_at_structures_matches_the_reference_driven_fixture():
+    """The LDD cut of the in-loop fixture was produced by the generator with the reference's rule
+    (structures.py:51-59) on LF_ETRS89's real lake / reservoir sites."""
+    from conftest import golden
+    g = golden("inloop_structures")
+    z = golden("etrs89_static")
+    mask = g["mask"]
+    codes = z["ldd"][mask].astype(float)
+    is_struct = np.zeros(codes.size, bool)
+    is_struct[g["LakeIndex"]] = True
+    is_struct[g["ReservoirIndex"]] = True
+    cut, ups = L.cut_at_structures(codes, mask, is_struct)
+    want = g["codes_cut"].copy()
+    off_mask = (L.downstream_index(want, mask) < 0)            # lddrepair also pits cells leaving the mask
+    assert np.array_equal(cut[~off_mask], want[~off_mask]) and (cut[off_mask] == L.PIT).all()
+    assert ups.sum() > 0 and (cut[ups] == L.PIT).all()
