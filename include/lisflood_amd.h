@@ -54,8 +54,8 @@ typedef struct lf_comm lf_comm;               /* RCCL communicator (one rank per
 const char *lf_last_error(void);
 int lf_version(void);
 /* sizeof(lf_substep_args), sizeof(lf_interception_args), sizeof(lf_soil_args), sizeof(lf_canopy_args),
- * sizeof(lf_surface_args), sizeof(lf_inloop_args): lets a binding verify its struct mirrors. */
-int lf_struct_sizes(int64_t out[6]);
+ * sizeof(lf_surface_args), sizeof(lf_inloop_args), sizeof(lf_pixel_args): lets a binding verify its struct mirrors. */
+int lf_struct_sizes(int64_t out[7]);
 
 /* ---------------------------------------------------------------------------------------------
  * device plumbing
@@ -298,6 +298,30 @@ typedef struct lf_inloop_args {
     int32_t step; /* NoRoutingExecuted */
 } lf_inloop_args;
 int lf_inloop_structures(int device, const lf_inloop_args *a);
+
+/* The per-pixel aggregates between the soil columns and surface routing, one pass:
+ * opensealed.dynamic (opensealed.py:40-71), soil.dynamic_perpixel (soil.py:471-514; deffraction =
+ * sum over the fractions of SoilFraction * X, Lisflood_initial.py:69-71,393-396) and groundwater.dynamic
+ * (groundwater.py:134-180).  Prescribed fractions (V = L = 3, fraction v uses land-use row v). */
+typedef struct lf_pixel_args {
+    /* [3,N] in */
+    const double *SoilFraction, *TaInterception, *Ta, *ESAct, *PrefFlow, *Infiltration, *SeepTopToSubA, *SeepTopToSubB,
+        *SeepSubToGW, *Theta1a, *Theta1b, *Theta2, *W1a, *W1b, *W2, *UZOutflow, *GwPercUZLZ, *SoilDepthTotal;
+    /* [N] in */
+    const double *Rain, *SnowMelt, *EWRef, *SMaxSealed, *DirectRunoffFraction, *WaterFraction, *LowerZoneK, *LZThreshold,
+        *GwLossStep;
+    /* [N] state in/out */
+    double *CumInterSealed, *LZ, *LZInflowCUM, *TaInterceptionCUM, *TaCUM, *ESActCUM, *GwLossCUM;
+    /* [N] out */
+    double *RainSnowmelt, *EWaterAct, *InterSealed, *TASealed, *DirectRunoff, *TaInterceptionAll, *TaPixel, *ESActPixel,
+        *PrefFlowPixel, *InfiltrationPixel, *ThetaAll, *SeepTopToSubPixelA, *SeepTopToSubPixelB, *SeepSubToGWPixel,
+        *Theta1aPixel, *Theta1bPixel, *Theta2Pixel, *LZOutflow, *UZOutflowPixel, *GwPercUZLZPixel, *GwLossLZ, *LZAvInflow,
+        *LZOutflowToChannelPixel;
+    double *Theta; /* [3,N] out */
+    double InvDtDay, TimeSinceStart;
+    int64_t N;
+} lf_pixel_args;
+int lf_pixel_aggregates_device(int device, const lf_pixel_args *a);
 
 /* host-buffer forms (drop-in for the numba kernels; PCIe-inclusive) */
 int lf_interception_host(int device, const lf_interception_args *a);

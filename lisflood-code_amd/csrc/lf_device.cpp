@@ -54,7 +54,7 @@ extern "C" {
 const char *lf_last_error(void) { return g_err; }
 int lf_version(void) { return 100; }
 
-int lf_struct_sizes(int64_t out[6])
+int lf_struct_sizes(int64_t out[7])
 {
     if (!out) return lf_set_error(LF_E_INVALID, "null argument");
     out[0] = (int64_t)sizeof(lf_substep_args);
@@ -63,6 +63,7 @@ int lf_struct_sizes(int64_t out[6])
     out[3] = (int64_t)sizeof(lf_canopy_args);
     out[4] = (int64_t)sizeof(lf_surface_args);
     out[5] = (int64_t)sizeof(lf_inloop_args);
+    out[6] = (int64_t)sizeof(lf_pixel_args);
     return LF_OK;
 }
 

@@ -163,6 +163,82 @@ __global__ void __launch_bounds__(kBlock) k_surface_post(lf_surface_args A)
     A.ToChanM3Runoff[p] = run;
     A.ToChanM3RunoffDt[p] = run * A.InvNoRoutSteps;
 }
+// opensealed.dynamic + soil.dynamic_perpixel + groundwater.dynamic, one lane per pixel
+__global__ void __launch_bounds__(kBlock) k_pixel_aggregates(lf_pixel_args A)
+{
+    const long long p = (long long)blockIdx.x * kBlock + threadIdx.x;
+    const long long N = A.N;
+    if (p >= N) return;
+    // ---- opensealed.py:45-70 ----
+    const double ewref = A.EWRef[p], drf = A.DirectRunoffFraction[p], wf = A.WaterFraction[p];
+    const double rsm = npmax(A.Rain[p] + A.SnowMelt[p], 0.0);
+    double ewact = npmin(ewref, rsm);
+    ewact = npmax(ewact * 1.0, 0.0);
+    double cis = A.CumInterSealed[p];
+    double inter = npmax(A.SMaxSealed[p] - cis, 0.0);
+    inter = npmin(inter, rsm);
+    cis += inter;
+    const double tas = npmax(npmin(cis, ewref), 0.0);
+    cis = npmax(cis - tas, 0.0);
+    A.RainSnowmelt[p] = rsm;
+    A.EWaterAct[p] = ewact;
+    A.InterSealed[p] = inter;
+    A.TASealed[p] = tas;
+    A.CumInterSealed[p] = cis;
+    A.DirectRunoff[p] = drf * (rsm - inter) + wf * (rsm - ewact);
+    // ---- soil.py:475-513 : deffraction(X) = (SoilFraction * X).sum(vegetation) = ((f0 x0 + f1 x1) + f2 x2) ----
+    const double f0 = A.SoilFraction[p], f1 = A.SoilFraction[N + p], f2 = A.SoilFraction[2 * N + p];
+#define LF_DEF(X) ((f0 * A.X[p] + f1 * A.X[N + p]) + f2 * A.X[2 * N + p])
+    const double ta_int_all = LF_DEF(TaInterception) + drf * tas;
+    A.TaInterceptionAll[p] = ta_int_all;
+    A.TaInterceptionCUM[p] += ta_int_all;
+    const double ta_pix = LF_DEF(Ta);
+    A.TaPixel[p] = ta_pix;
+    A.TaCUM[p] += ta_pix;
+    const double es_pix = LF_DEF(ESAct) + wf * ewact;
+    A.ESActPixel[p] = es_pix;
+    A.ESActCUM[p] += es_pix;
+    A.PrefFlowPixel[p] = LF_DEF(PrefFlow);
+    A.InfiltrationPixel[p] = LF_DEF(Infiltration);
+    double th[3];
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+        const long long i = v * N + p;
+        const double tot_sm = A.W1a[i] + A.W1b[i] + A.W2[i];
+        th[v] = A.SoilFraction[i] * tot_sm / A.SoilDepthTotal[i];
+        A.Theta[i] = th[v];
+    }
+    const double fsum = (f0 + f1) + f2;
+    A.ThetaAll[p] = (fsum > 0) ? ((th[0] + th[1]) + th[2]) / fsum : 0.0;
+    A.SeepTopToSubPixelA[p] = LF_DEF(SeepTopToSubA);
+    A.SeepTopToSubPixelB[p] = LF_DEF(SeepTopToSubB);
+    A.SeepSubToGWPixel[p] = LF_DEF(SeepSubToGW);
+    A.Theta1aPixel[p] = LF_DEF(Theta1a);
+    A.Theta1bPixel[p] = LF_DEF(Theta1b);
+    A.Theta2Pixel[p] = LF_DEF(Theta2);
+    // ---- groundwater.py:137-180 ----
+    double lz = A.LZ[p];
+    double lzout = npmin(A.LowerZoneK[p] * lz, lz - A.LZThreshold[p]);
+    lzout = npmax(lzout, 0.0);
+    A.LZOutflow[p] = lzout;
+    lz -= lzout;
+    A.UZOutflowPixel[p] = LF_DEF(UZOutflow);
+    const double perc = LF_DEF(GwPercUZLZ);
+    A.GwPercUZLZPixel[p] = perc;
+    lz += perc;
+    const double loss = npmax(npmin(A.GwLossStep[p], lz), 0.0);
+    lz = lz - loss;
+    A.GwLossLZ[p] = loss;
+    A.LZ[p] = lz;
+    double cum = A.LZInflowCUM[p] + (perc - loss);
+    cum = npmax(cum, 0.0);
+    A.LZInflowCUM[p] = cum;
+    A.GwLossCUM[p] += loss;
+    A.LZAvInflow[p] = (cum * A.InvDtDay) / A.TimeSinceStart;
+    A.LZOutflowToChannelPixel[p] = lzout;
+#undef LF_DEF
+}
+
 // lakes.dynamic_inloop (lakes.py:215-258) and reservoir.dynamic_inloop (reservoir.py:190-296): one lane per site
 __global__ void __launch_bounds__(kBlock) k_inloop_sites(lf_inloop_args A)
 {
@@ -252,6 +328,16 @@ __global__ void __launch_bounds__(kBlock) k_inloop_dense(lf_inloop_args A)
 } // namespace
 
 extern "C" {
+
+int lf_pixel_aggregates_device(int device, const lf_pixel_args *a)
+{
+    if (!a) return lf_set_error(LF_E_INVALID, "null argument");
+    lf_device_ctx *c;
+    LF_TRY(lf_ctx(device, &c));
+    if (a->N > 0) hipLaunchKernelGGL(k_pixel_aggregates, dim3(blocks_for(a->N)), dim3(kBlock), 0, c->stream, *a);
+    LF_HIP(hipGetLastError());
+    return LF_OK;
+}
 
 int lf_inloop_structures(int device, const lf_inloop_args *a)
 {

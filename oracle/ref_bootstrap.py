@@ -124,7 +124,8 @@ def load():
     rout = importlib.import_module("lisflood.hydrological_modules.routing")
     surf = importlib.import_module("lisflood.hydrological_modules.surface_routing")
     extra = {}
-    for name in ("lakes", "reservoir", "inflow", "transmission"):
+    sys.modules.setdefault("xarray", types.ModuleType("xarray"))    # soil.py imports it, the methods used here do not
+    for name in ("lakes", "reservoir", "inflow", "transmission", "soil", "groundwater", "opensealed"):
         extra[name] = importlib.import_module("lisflood.hydrological_modules." + name)
     _loaded.update(kwp=kwp, kwpt=kwp.kwpt, soilloop=soil, routing=rout, surface=surf,
                    LisSettings=_Settings, MaskInfo=_MaskInfo, **extra)

@@ -534,6 +534,62 @@ def gen_canopy_soil_step():
          **{"init_" + k: a for k, a in before.items()}, **{"static_" + k: a for k, a in static.items()}, **forc, **outs)
 
 
+PIXEL_V_IN = ("SoilFraction TaInterception Ta ESAct PrefFlow Infiltration SeepTopToSubA SeepTopToSubB SeepSubToGW "
+              "Theta1a Theta1b Theta2 W1a W1b W2 UZOutflow GwPercUZLZ").split()
+PIXEL_N_IN = ("Rain SnowMelt EWRef SMaxSealed DirectRunoffFraction WaterFraction LowerZoneK LZThreshold "
+              "GwLossStep").split()
+PIXEL_STATE = "CumInterSealed LZ LZInflowCUM TaInterceptionCUM TaCUM ESActCUM GwLossCUM".split()
+PIXEL_OUT = ("RainSnowmelt EWaterAct InterSealed TASealed DirectRunoff TaInterceptionAll TaPixel ESActPixel "
+             "PrefFlowPixel InfiltrationPixel ThetaAll SeepTopToSubPixelA SeepTopToSubPixelB SeepSubToGWPixel "
+             "Theta1aPixel Theta1bPixel Theta2Pixel LZOutflow UZOutflowPixel GwPercUZLZPixel GwLossLZ LZAvInflow "
+             "LZOutflowToChannelPixel").split()
+
+
+def gen_pixel_aggregates():
+    """opensealed.dynamic (opensealed.py:40-71) -> soil.dynamic_perpixel (soil.py:471-514) -> groundwater.dynamic
+    (groundwater.py:134-180): the per-pixel aggregates between the soil columns and surface routing, driven
+    through the reference's own module methods for two steps."""
+    N = 700
+    rng = np.random.default_rng(71)
+    v = model_var(N)
+    REF["MaskInfo"].n = N
+    REF["LisSettings"].options.clear()
+    vn = ["vegetation", "pixel"]
+    frac = rng.dirichlet([3, 2, 1], N).T * rng.uniform(0.3, 1.0, N)
+    frac[:, :20] = 0.0                                       # pixels without any soil fraction (ThetaAll = 0 branch)
+    v.SoilFraction = VA(frac, vn)
+    v.SoilDepthTotal = VA(rng.uniform(400, 2000, (3, N)), ["landuse", "pixel"])
+    v.Theta = VA(np.zeros((3, N)), vn)
+    v.deffraction = lambda variable: (np.asarray(v.SoilFraction) * np.asarray(variable)).sum(0)   # Lisflood_initial.py:69-71, 393-396
+    for k in ("DirectRunoffFraction", "WaterFraction"):
+        setattr(v, k, rng.uniform(0, 0.2, N) * (rng.random(N) < 0.5))
+    v.SMaxSealed, v.LowerZoneK = 1.0, rng.uniform(0.001, 0.05, N)
+    v.LZThreshold = rng.uniform(0, 30, N) * (rng.random(N) < 0.3)
+    v.GwLossStep = rng.uniform(0, 0.5, N) * (rng.random(N) < 0.4)
+    v.InvDtDay = 1.0
+    for k in PIXEL_STATE:
+        setattr(v, k, rng.uniform(0, 5, N) if k != "LZ" else rng.uniform(0, 200, N))
+    init = {k: getattr(v, k).copy() for k in PIXEL_STATE}
+    static = {k: np.broadcast_to(np.asarray(getattr(v, k), float), (N,)).copy()
+              for k in ("SMaxSealed", "DirectRunoffFraction", "WaterFraction", "LowerZoneK", "LZThreshold", "GwLossStep")}
+    mo, ms, mg = REF["opensealed"].opensealed(v), REF["soil"].soil(v), REF["groundwater"].groundwater(v)
+    ins, outs = {}, {}
+    for s in range(2):
+        v.TimeSinceStart = float(s + 3)
+        step_in = dict(Rain=rng.uniform(0, 20, N) * (rng.random(N) < 0.6), SnowMelt=rng.uniform(0, 3, N) * (rng.random(N) < 0.2),
+                       EWRef=rng.uniform(0, 5, N))
+        for k in PIXEL_V_IN[1:]:
+            step_in[k] = rng.uniform(0, 30, (3, N)) if k in ("W1a", "W1b", "W2") else rng.uniform(0, 3, (3, N))
+        for k, a in step_in.items():
+            setattr(v, k, VA(a, vn) if a.ndim == 2 else a)
+            ins["in%d_%s" % (s, k)] = a
+        mo.dynamic(); ms.dynamic_perpixel(); mg.dynamic()
+        for k in PIXEL_OUT + PIXEL_STATE + ["Theta"]:
+            outs["out%d_%s" % (s, k)] = np.array(getattr(v, k), dtype=np.float64).copy()
+    save("pixel_aggregates", SoilFraction=frac, SoilDepthTotal=np.asarray(v.SoilDepthTotal), InvDtDay=v.InvDtDay,
+         **{"static_" + k: a for k, a in static.items()}, **{"init_" + k: a for k, a in init.items()}, **ins, **outs)
+
+
 def gen_inloop():
     """routing.dynamic(s) WITH the reference's own lakes / reservoir / inflow / transmission modules in the loop
     (routing.py:441-478) on LF_ETRS89: real lake and reservoir sites (ec_lakes.nc, ec_res.nc), the LDD cut just
@@ -648,9 +704,9 @@ def gen_inloop():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["graphs", "routes", "edge", "substeps", "upsum", "interception", "soil", "surface",
-                             "canopy", "inloop"]
+                             "canopy", "inloop", "pixel"]
     fns = dict(graphs=gen_graphs, routes=gen_routes, edge=gen_route_edge, substeps=gen_substeps,
                upsum=gen_upstream_sum, interception=gen_interception, soil=gen_soil_columns,
-               surface=gen_surface_step, canopy=gen_canopy_soil_step, inloop=gen_inloop)
+               surface=gen_surface_step, canopy=gen_canopy_soil_step, inloop=gen_inloop, pixel=gen_pixel_aggregates)
     for w in which:
         fns[w]()

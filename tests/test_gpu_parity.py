@@ -370,6 +370,29 @@ def test_routing_with_inloop_structures_golden(amd, solver):
     assert (v.LakeStorageM3[g["LakeIndex"]] == v.LakeStorageM3CC).all()
 
 
+def test_pixel_aggregates_golden(amd):
+    """opensealed.dynamic -> soil.dynamic_perpixel -> groundwater.dynamic as one device pass, against vectors
+    captured from the reference's own module methods (two consecutive steps)."""
+    from lisflood_amd import pixel_aggregates as PA
+    g = golden("pixel_aggregates")
+    v = types.SimpleNamespace(SoilFraction=g["SoilFraction"], SoilDepthTotal=g["SoilDepthTotal"],
+                              InvDtDay=float(g["InvDtDay"]))
+    for k in g.files:
+        if k.startswith("static_"):
+            setattr(v, k[7:], g[k])
+        elif k.startswith("init_"):
+            setattr(v, k[5:], g[k].copy())
+    for s in range(2):
+        v.TimeSinceStart = float(s + 3)
+        for k in g.files:
+            if k.startswith("in%d_" % s):
+                setattr(v, k[4:], g[k])
+        PA.dynamic(v)
+        for k in g.files:
+            if k.startswith("out%d_" % s):
+                np.testing.assert_allclose(getattr(v, k[5:]), g[k], rtol=1e-12, atol=1e-13, err_msg=k)
+
+
 def test_interception_golden(amd):
     g = golden("interception")
     st = {k: g["in_" + k].copy() for k in ("Interception", "TaInterception", "LeafDrainage", "CumInterception")}

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_mirrors_have_the_c_size():
     from lisflood_amd import soilloop, routing, surface_routing
-    out = (C.c_int64 * 6)()
+    out = (C.c_int64 * 7)()
     assert _lib.lib().lf_struct_sizes(out) == 0
     assert C.sizeof(routing._SubstepArgs) == out[0]
     assert C.sizeof(soilloop._InterceptionArgs) == out[1]
@@ -41,6 +41,8 @@ def test_struct_mirrors_have_the_c_size():
     assert C.sizeof(soilloop._CanopyArgs) == out[3]
     assert C.sizeof(surface_routing._SurfaceArgs) == out[4]
     assert C.sizeof(routing._InloopArgs) == out[5]
+    from lisflood_amd import pixel_aggregates
+    assert C.sizeof(pixel_aggregates._PixelArgs) == out[6]
 
 
 @pytest.mark.parametrize("name", ["syn64_shallow", "syn64_deep", "syn48_masked", "etrs89"])
