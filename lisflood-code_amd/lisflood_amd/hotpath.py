@@ -1,0 +1,138 @@
+"""Device-resident hot path of one LISFLOOD model step (Lisflood_dynamic.py:114-229, the stages SURVEY.md section 8
+covers), with every vector kept in HBM between steps:
+
+    soilloop.dynamic_canopy -> soilloop.dynamic_soil -> opensealed / soil.dynamic_perpixel / groundwater
+    -> surface_routing.dynamic (3 routers on LddToChan) -> NoRoutSteps x routing.dynamic (1-2 routers, fused
+    wavefront) -> ChanQAvg
+
+Per step only the meteorological forcing (Rain, SnowMelt, EWRef, ETRef, ESRef -- five [N] vectors) crosses PCIe.
+The stages are exactly the kernels the module classes (`soilloop`, `pixel_aggregates`, `surface_routing`,
+`routing`) call -- those stage their `var` arrays through the host on every call, this class wires the same
+device buffers from one stage to the next.  Channel vectors live in the channel router's engine order; the one
+vector that crosses from the surface graph to the channel graph (ToChanM3RunoffDt) is permuted on the device.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import pixel_aggregates as PA
+from . import routing as RT
+from . import soilloop as SL
+from . import surface_routing as SR
+from ._lib import DeviceArray, check, f64, lib, u8
+from .kinematic_wave_parallel import Graph, kinematicWave
+
+FORCING = ("Rain", "SnowMelt", "EWRef", "ETRef", "ESRef")
+
+
+class HotPathDevice:
+    def __init__(self, values, scalars, land_mask, ldd_to_chan, ldd_kinematic, split=True, device=0):
+        """values: name -> host array in pixel order ([N], [3,N]) for every vector of the stages (reference
+        attribute names); scalars: Beta, DtSec, DtRouting, NoRoutSteps, DtDay, PixelLength, MMtoM3, M3toMM,
+        LeafDrainageK, AvWaterThreshold, CourantCrit, DrainedFraction, InvDtDay.  ldd_to_chan / ldd_kinematic:
+        compressed LDD codes of the overland and the channel graph."""
+        self.device, self.split = device, bool(split)
+        self.sc = dict(scalars)
+        self.N = N = int(np.asarray(land_mask, bool).sum())
+        sc = self.sc
+        # ---- routers -------------------------------------------------------------------------------
+        g_surf = Graph(ldd_to_chan, land_mask)
+        alpha_of = np.asarray(values["OFAlpha"], float)
+        mk = lambda row: kinematicWave(None, None, alpha_of[row], sc["Beta"], sc["PixelLength"], sc["DtSec"],
+                                       device=device, graph=g_surf)
+        self.r_other, self.r_forest, self.r_direct = mk(0), mk(1), mk(2)
+        self.river = kinematicWave(ldd_kinematic, land_mask, values["ChannelAlpha"], sc["Beta"], values["ChanLength"],
+                                   sc["DtRouting"], alpha_floodplains=values["ChannelAlpha2"] if split else None,
+                                   device=device)
+        self.perm = self.river.graph.layout()[0].astype(np.int64)
+        # ---- device vectors ------------------------------------------------------------------------
+        self.d = {}
+        chan_names = set(RT._STATIC + RT._STATE)
+        bool_names = SL._BOOL | {"IsChannel", "IsChannelKinematic"}
+        for k, a in values.items():
+            a = np.asarray(a)
+            if k in chan_names:                       # channel vectors: engine order of the river router
+                a = np.broadcast_to(a, (N,))[self.perm]
+            self.d[k] = DeviceArray.from_host(u8(a) if k in bool_names else f64(a), device)
+
+        def zeros(name, shape):
+            if name not in self.d:
+                self.d[name] = DeviceArray(shape, np.float64, device).zero()
+            return self.d[name]
+        for k in FORCING:
+            zeros(k, N)
+        # ---- argument blocks (pointers into self.d) -----------------------------------------------------
+        def fill(args, names, shape_of):
+            for k in names:
+                setattr(args, k, zeros(k, shape_of(k)).ptr.value)
+        vn = lambda k: (3, N)
+        n1 = lambda k: N
+        a = self.canopy = SL._CanopyArgs()
+        fill(a, SL._CANOPY_IO + SL._CANOPY_V_IN + SL._CANOPY_L_IN, vn)
+        fill(a, SL._CANOPY_N_IN, n1)
+        self._idx = np.arange(3, dtype=np.int64)
+        a.index_landuse = self._idx.ctypes.data
+        a.LeafDrainageK, a.DtDay, a.InvDtDay = sc["LeafDrainageK"], sc["DtDay"], sc["InvDtDay"]
+        a.V, a.L, a.N = 3, 3, N
+        zeros("LAITerm", (3, N)); zeros("ESMax", (3, N))
+        s = self.soil = SL._SoilArgs()
+        fill(s, SL._L_FIELDS + SL._V_IN + SL._V_IO, vn)
+        fill(s, SL._N_FIELDS, n1)
+        self._irr = np.array([0, 0, 1], np.uint8)
+        self._pad = np.zeros(3, np.uint8)
+        s.index_landuse_all, s.is_irrigated, s.is_paddy_irrig = (self._idx.ctypes.data, self._irr.ctypes.data,
+                                                                 self._pad.ctypes.data)
+        s.DtDay, s.AvWaterThreshold, s.CourantCrit, s.DrainedFraction = (sc["DtDay"], sc["AvWaterThreshold"],
+                                                                         sc["CourantCrit"], sc["DrainedFraction"])
+        s.V, s.L, s.N = 3, 3, N
+        p = self.pixel = PA._PixelArgs()
+        fill(p, PA._V_IN + ["Theta"], vn)
+        fill(p, PA._N_IN + PA._STATE + PA._OUT, n1)
+        p.InvDtDay, p.N = sc["InvDtDay"], N
+        f = self.surface = SR._SurfaceArgs()
+        fill(f, SR._V_IN + ["SurfaceRunSoil", "scratch"], vn)
+        fill(f, SR._N_IN + SR._STATE + SR._OUT, n1)
+        f.Beta, f.MMtoM3, f.M3toMM = sc["Beta"], sc["MMtoM3"], sc["M3toMM"]
+        f.PixelLength, f.InvPixelLength = sc["PixelLength"], 1 / sc["PixelLength"]
+        f.DtSec, f.InvDtSec, f.InvNoRoutSteps, f.N = sc["DtSec"], 1 / sc["DtSec"], 1 / sc["NoRoutSteps"], N
+        r = self.rout = RT._SubstepArgs()
+        fill(r, RT._STATIC + ["SideflowChanM3"] + RT._STATE + RT._OUT + ["scratch0", "scratch1"], n1)
+        r.Beta, r.InvBeta, r.InvDtRouting, r.DtSec = sc["Beta"], 1 / sc["Beta"], 1 / sc["DtRouting"], sc["DtSec"]
+        r.split, r.engine_order = (1 if self.split else 0), 1
+        self.steps_done = 0
+
+    def step(self, forcing, time_since_start=None):
+        d, dev = self.d, self.device
+        for k in FORCING:
+            d[k].upload(f64(forcing[k]))
+        L = lib()
+        check(L.lf_canopy_device(C.c_int(dev), C.byref(self.canopy)))                                   # dyn.py:114
+        check(L.lf_scale_rows_device(C.c_int(dev), d["ESRef"].ptr, d["LAITerm"].ptr, d["ESMax"].ptr,
+                                     C.c_int64(3), C.c_int64(self.N)))                                 # soilloop.py:638
+        check(L.lf_soil_columns_device(C.c_int(dev), C.byref(self.soil)))                               # dyn.py:123
+        self.steps_done += 1
+        self.pixel.TimeSinceStart = float(time_since_start if time_since_start else self.steps_done)
+        check(L.lf_pixel_aggregates_device(C.c_int(dev), C.byref(self.pixel)))                          # dyn.py:129-149
+        check(L.lf_surface_step(self.r_direct._h, self.r_other._h, self.r_forest._h, C.byref(self.surface)))  # :165
+        d["sumDisDay"].zero()                                                                           # dyn.py:177
+        check(L.lf_router_to_engine_order(self.river._h, d["ToChanM3RunoffDt"].ptr, d["SideflowChanM3"].ptr))
+        check(L.lf_routing_substeps_fused(self.river._h, C.byref(self.rout), C.c_int(int(self.sc["NoRoutSteps"])),
+                                          C.c_int64(0)))                                                # dyn.py:179-180
+
+    def download(self, name):
+        a = self.d[name].download()
+        if name in set(RT._STATIC + RT._STATE + RT._OUT):
+            out = np.empty_like(a)
+            out[self.perm] = a
+            return out
+        return a
+
+    def chan_q_avg(self):
+        """ChanQAvg = sumDisDay / NoRoutSteps (Lisflood_dynamic.py:209): the `dis` output of the reference."""
+        return self.download("sumDisDay") / self.sc["NoRoutSteps"]
+
+    def free(self):
+        for a in self.d.values():
+            a.free()
+        for r in (self.r_other, self.r_forest, self.r_direct, self.river):
+            r.close()

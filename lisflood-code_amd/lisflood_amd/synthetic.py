@@ -215,3 +215,82 @@ def interception_params(N, V=3, seed=21):
         Interception=np.zeros((V, N)), TaInterception=np.zeros((V, N)), LeafDrainage=np.zeros((V, N)),
         CumInterception=rng.uniform(0.0, 3.0, (V, N)) * (rng.random((V, N)) < 0.7),
         LAI=lai, Rain=rain, TaInterceptionMax=rng.uniform(0.0, 3.0, (V, N)), drainageK=0.25)
+
+
+def hotpath_scenario(H, W, seed=101, channel_frac=0.3, nsteps=24, dt_sec=86400.0):
+    """A complete synthetic input set for the device-resident hot path (lisflood_amd.hotpath.HotPathDevice) and
+    for the module classes: -> (values, scalars, land_mask, ldd_to_chan, ldd_kinematic).  All-land H x W `deep`
+    raster, `channel_frac` of the cells are channel pixels (so overland routing between cells is exercised)."""
+    from . import ldd as L
+    rng = np.random.default_rng(seed)
+    N = H * W
+    mask = np.ones((H, W), bool)
+    codes = make_ldd("deep", H, W, seed)[mask].astype(np.float64)
+    is_chan = rng.random(N) < channel_frac
+    ldd_to_chan = np.where(is_chan, 5.0, codes)
+    kin_codes, _ = L.lddmask(codes, mask, is_chan)
+    ldd_kin = np.zeros(N)
+    ldd_kin[is_chan] = kin_codes
+    beta = 0.6
+    dt_routing = dt_sec / nsteps
+    v = {}
+    soil = soil_params(N, seed=seed + 1)
+    for k, a in soil.items():
+        if isinstance(a, np.ndarray) and a.ndim >= 1 and k not in ("index_landuse_all", "is_irrigated", "is_paddy_irrig",
+                                                                      "paddy_inactive"):
+            v[k] = a
+    ip = interception_params(N, seed=seed + 2)
+    v["LAI"] = ip["LAI"]
+    v["CumInterception"] = ip["CumInterception"]
+    v["TaInterception"] = np.zeros((3, N))
+    v["LAITerm"] = np.exp(-0.5 * ip["LAI"])
+    v["CropCoef"] = rng.uniform(0.6, 1.2, (3, N))
+    v["CropGroupNumber"] = np.stack([rng.uniform(1, 5, N), rng.uniform(1, 5, N), np.full(N, 2.0)])
+    for k in ("potential_transpiration", "RWS", "Ta"):
+        v[k] = np.zeros((3, N))
+    frac = rng.dirichlet([3, 2, 1], N).T * rng.uniform(0.5, 1.0, N)
+    v["SoilFraction"] = frac
+    v["SoilDepthTotal"] = soil["SoilDepth1a"] + soil["SoilDepth1b"] + soil["SoilDepth2"]
+    v["DirectRunoffFraction"] = rng.uniform(0, 0.15, N) * (rng.random(N) < 0.5)
+    v["WaterFraction"] = rng.uniform(0, 0.1, N) * (rng.random(N) < 0.3)
+    v["SMaxSealed"] = np.full(N, 1.0)
+    v["LowerZoneK"] = rng.uniform(0.001, 0.05, N)
+    v["LZThreshold"] = np.zeros(N)
+    v["GwLossStep"] = np.zeros(N)
+    v["LZ"] = rng.uniform(0, 100, N)
+    for k in ("CumInterSealed", "LZInflowCUM", "TaInterceptionCUM", "TaCUM", "ESActCUM", "GwLossCUM"):
+        v[k] = np.zeros(N)
+    pixel_length, pixel_area = 5000.0, 2.5e7
+    grad = rng.uniform(0.001, 0.2, N)
+    nman = np.stack([rng.uniform(0.05, 0.2, N), rng.uniform(0.2, 0.5, N), rng.uniform(0.01, 0.05, N)])
+    v["OFAlpha"] = ((nman / np.sqrt(grad)) ** beta) * ((pixel_length + 2 * 0.001 * 5.0) ** (2.0 / 3.0 * beta))
+    for k in ("OFQDirect", "OFQOther", "OFQForest"):
+        v[k] = rng.uniform(0, 0.3, N)
+    v["IsChannel"] = is_chan
+    p = router_params(N, seed=seed + 3)
+    alpha = np.where(is_chan, p["alpha"], 1.0)
+    length = p["dx"]
+    alpha2 = alpha * rng.uniform(1.2, 2.0, N)
+    q0 = np.where(is_chan, np.minimum(p["Q0"], 500.0), 0.0)
+    qlimit = 2.0 * q0 * rng.uniform(0.3, 1.2, N)
+    v.update(ChannelAlpha=alpha, InvChannelAlpha=1 / alpha, ChannelAlpha2=alpha2, InvChannelAlpha2=1 / alpha2,
+             ChanLength=length, InvChanLength=1 / length, QLimit=qlimit, M3Limit=alpha * length * qlimit ** beta,
+             Chan2M3Start=alpha2 * length * qlimit ** beta, Chan2QStart=0.1 * qlimit, PixelArea=np.full(N, pixel_area),
+             IsChannelKinematic=is_chan.copy())
+    v["Chan2M3Kin"] = v["Chan2M3Start"].copy()
+    v["ChanM3Kin"] = alpha * length * q0 ** beta
+    v["ChanQKin"] = q0.copy()
+    v["Chan2QKin"] = (v["Chan2M3Kin"] / length / alpha2) ** (1 / beta)
+    v["ChanQ"] = np.maximum(v["ChanQKin"] + v["Chan2QKin"] - qlimit, 0.0)
+    for k in ("CrossSection2Area", "Sideflow1Chan", "sumDisDay"):
+        v[k] = np.zeros(N)
+    scalars = dict(Beta=beta, DtSec=dt_sec, DtRouting=dt_routing, NoRoutSteps=nsteps, DtDay=1.0, InvDtDay=1.0,
+                   PixelLength=pixel_length, MMtoM3=0.001 * pixel_area, M3toMM=1 / (0.001 * pixel_area),
+                   LeafDrainageK=0.25, AvWaterThreshold=1.0, CourantCrit=0.4, DrainedFraction=0.1)
+    return v, scalars, mask, ldd_to_chan, ldd_kin
+
+
+def hotpath_forcing(N, step, seed=300):
+    rng = np.random.default_rng(seed + step)
+    return dict(Rain=rng.uniform(0, 20, N) * (rng.random(N) < 0.6), SnowMelt=np.zeros(N),
+                EWRef=rng.uniform(0, 5, N), ETRef=rng.uniform(0, 4, N), ESRef=rng.uniform(0, 3, N))

@@ -393,6 +393,50 @@ def test_pixel_aggregates_golden(amd):
                 np.testing.assert_allclose(getattr(v, k[5:]), g[k], rtol=1e-12, atol=1e-13, err_msg=k)
 
 
+def test_resident_hot_path_equals_the_module_classes(amd):
+    """HotPathDevice (every stage of a model step chained on device buffers) against the same stages run through
+    the module classes on host `var` arrays (each of which is pinned to the reference by its own golden test).
+    Same kernels, same order: the results must be bit-identical."""
+    from lisflood_amd import synthetic as syn
+    from lisflood_amd import pixel_aggregates as PA
+    from lisflood_amd.hotpath import HotPathDevice
+    from lisflood_amd.soilloop import soilloop
+    from lisflood_amd.surface_routing import surface_routing
+    H, W = 40, 50
+    N = H * W
+    values, sc, mask, ldd_to_chan, ldd_kin = syn.hotpath_scenario(H, W)
+    hp = HotPathDevice({k: np.array(a, copy=True) for k, a in values.items()}, sc, mask, ldd_to_chan, ldd_kin, split=True)
+    # the same scenario through the module classes
+    v = _model_var(N)
+    for k, a in values.items():
+        setattr(v, k, np.array(a, copy=True))
+    for k, a in sc.items():
+        setattr(v, k, a)
+    v.InvBeta, v.InvPixelLength, v.InvDtSec = 1 / v.Beta, 1 / v.PixelLength, 1 / v.DtSec
+    v.InvDtRouting, v.InvNoRoutSteps = 1 / v.DtRouting, 1 / v.NoRoutSteps
+    m_soil = soilloop(v); m_soil.initial()
+    m_surf = surface_routing(v); m_surf.initialSecond(ldd_to_chan, mask)
+    m_rout = amd.routing.routing(v, split_routing=True); m_rout.attach_router(ldd_kin, mask)
+    for step in range(2):
+        f = syn.hotpath_forcing(N, step)
+        hp.step(f, time_since_start=step + 1)
+        for k, a in f.items():
+            setattr(v, k, a)
+        v.TimeSinceStart = float(step + 1)
+        m_soil.dynamic_canopy(); m_soil.dynamic_soil()
+        PA.dynamic(v)
+        m_surf.dynamic()
+        v.sumDisDay = np.zeros(N)
+        m_rout.dynamic_fused()
+        m_rout.step_end()
+        for k in ("W1a", "W2", "UZ", "Infiltration", "LZ", "DirectRunoff", "UZOutflowPixel", "OFQOther", "ToChanM3RunoffDt",
+                  "ChanQKin", "Chan2QKin", "ChanM3Kin", "ChanQ"):
+            assert np.array_equal(hp.download(k), np.asarray(getattr(v, k)), equal_nan=True), (step, k)
+        assert np.array_equal(hp.chan_q_avg(), v.ChanQAvg)
+        assert np.isfinite(v.ChanQAvg).all() and v.ChanQAvg.max() > 0
+    hp.free()
+
+
 def test_interception_golden(amd):
     g = golden("interception")
     st = {k: g["in_" + k].copy() for k in ("Interception", "TaInterception", "LeafDrainage", "CumInterception")}
