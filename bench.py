@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads / soil kernel")
     ap.add_argument("--cpu-sample", type=int, default=2000, help="CPU baseline raster is sample x sample")
-    ap.add_argument("--only", choices=["soil", "model_step"], default=None, help="run only the named secondary benchmark")
+    ap.add_argument("--only", choices=["soil", "model_step", "hotpath"], default=None, help="run only the named secondary benchmark")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the row-block/RCCL path even with a single rank (smoke test of that path)")
     ap.add_argument("--calibrate", action="store_true",
@@ -285,6 +285,36 @@ def model_step_bench(size=5000, nsteps=24):
     return out
 
 
+def hotpath_bench(size=2000, steps=3):
+    """The whole device-resident hot path of a model step (canopy -> soil -> per-pixel aggregates -> 3 overland
+    routers -> 24 split-routing channel sub-steps), lisflood_amd.hotpath.HotPathDevice; only the five forcing
+    vectors cross PCIe per step."""
+    from lisflood_amd import _lib
+    from lisflood_amd import synthetic as syn
+    from lisflood_amd.hotpath import HotPathDevice
+    H = W = size
+    N = H * W
+    t = time.time()
+    values, sc, mask, ldd_to_chan, ldd_kin = syn.hotpath_scenario(H, W)
+    hp = HotPathDevice(values, sc, mask, ldd_to_chan, ldd_kin, split=True)
+    forc = [syn.hotpath_forcing(N, s) for s in range(2)]
+    log("[bench] hot-path scenario %dx%d built in %.1f s" % (H, W, time.time() - t))
+    hp.step(forc[0], 1)
+    _lib.synchronize()
+    t0 = time.perf_counter()
+    for s in range(steps):
+        hp.step(forc[s % 2], s + 2)
+    _lib.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / steps
+    q = hp.chan_q_avg()
+    out = dict(ms_per_model_step=round(ms, 3), model_steps_per_s=round(1e3 / ms, 2), pixels=N,
+               Mpixel_steps_per_s=round(N / ms / 1e3, 2), finite=bool(np.isfinite(q).all()),
+               config="%dx%d deep LDD, 30 %% channel pixels, V=3 fractions, NoRoutSteps=24 split routing; forcing "
+                      "uploaded from the host every step" % (H, W))
+    hp.free()
+    return out
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -293,6 +323,9 @@ def main():
         return dist_bench.main(a)
     if a.only == "soil":
         print(json.dumps(soil_bench()), flush=True)
+        return
+    if a.only == "hotpath":
+        print(json.dumps(hotpath_bench(min(a.size, 2000))), flush=True)
         return
     if a.only == "model_step":
         print(json.dumps(model_step_bench(min(a.size, 5000))), flush=True)
@@ -358,6 +391,10 @@ def main():
             extra["model_step_24_substeps_split"] = model_step_bench()
         except Exception as e:
             extra["model_step_error"] = repr(e)
+        try:
+            extra["resident_hot_path_step"] = hotpath_bench()
+        except Exception as e:
+            extra["resident_hot_path_error"] = repr(e)
         out["other_workloads"] = extra
     if not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.family, a.cpu_sample)
