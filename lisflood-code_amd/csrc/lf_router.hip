@@ -94,6 +94,9 @@ __global__ void __launch_bounds__(kBlock) k_count_nonfinite(long long n, const d
 struct segment {
     int k0, k1; // levels [k0, k1); wide segments have k1 == k0 + 1
     bool wide;
+    // window segments (ncomp > 0): levels [k0, k1) swept by k_window, one lane per component
+    int ncomp = 0;
+    int64_t ptr_off = 0; // first entry of this window in win_ptr
 };
 
 } // namespace
@@ -109,6 +112,7 @@ struct lf_router {
     lf_dbuf<int32_t> perm, ups_ptr;
     lf_dbuf<long long> level_start;
     lf_dbuf<double> a1, a2, dx, constant, qord, io_q, io_lat, tmp_ord, fused_qr1, fused_qr2;
+    lf_dbuf<int32_t> win_ptr, win_cells; // component lists of the window segments
     lf_dbuf<unsigned long long> counter;
     std::vector<int64_t> h_level_start;
     std::vector<segment> schedule;
@@ -208,7 +212,21 @@ int route_device(lf_router *r, double *q_dev, const double *lat_dev, int section
         ++launches;
     }
     for (const segment &g : r->schedule) {
-        if (g.wide) {
+        if (g.ncomp > 0) {
+            LF_TRY(r->prof_begin(1, r->h_level_start[g.k1] - r->h_level_start[g.k0]));
+            const dim3 grid(blocks_for(g.ncomp)), block(kBlock);
+            const int *cp = r->win_ptr.p + g.ptr_off;
+            if (r->fused && ordered)
+                hipLaunchKernelGGL((k_window<true, true>), grid, block, 0, s, g.ncomp, cp, r->win_cells.p, A);
+            else if (r->fused)
+                hipLaunchKernelGGL((k_window<true, false>), grid, block, 0, s, g.ncomp, cp, r->win_cells.p, A);
+            else if (ordered)
+                hipLaunchKernelGGL((k_window<false, true>), grid, block, 0, s, g.ncomp, cp, r->win_cells.p, A);
+            else
+                hipLaunchKernelGGL((k_window<false, false>), grid, block, 0, s, g.ncomp, cp, r->win_cells.p, A);
+            LF_TRY(r->prof_end());
+            ++wide;
+        } else if (g.wide) {
             const int first = (int)r->h_level_start[g.k0];
             const int count = (int)(r->h_level_start[g.k1] - r->h_level_start[g.k0]);
             LF_TRY(r->prof_begin(1, count));
@@ -311,17 +329,82 @@ int lf_router_create(const lf_graph *g, const double *alpha, double beta, const 
         return rc;
     }
     r->h_level_start = g->level_start;
-    // launch schedule
-    for (int64_t k = 0; k < g->NL;) {
-        const int64_t size = g->level_start[k + 1] - g->level_start[k];
-        if (size > kNarrowMax) {
-            r->schedule.push_back({(int)k, (int)k + 1, true});
-            ++k;
-        } else {
-            int64_t e = k + 1;
-            while (e < g->NL && g->level_start[e + 1] - g->level_start[e] <= kNarrowMax) ++e;
-            r->schedule.push_back({(int)k, (int)e, false});
-            k = e;
+    // launch schedule: narrow runs -> one single-workgroup launch; runs of wide levels -> windows of up to
+    // kWindow levels swept by k_window (one lane per independent component) when the components stay small,
+    // else one launch per level.  LF_WINDOWS=0 disables the windows.
+    {
+        const char *w = std::getenv("LF_WINDOWS");
+        const bool use_windows = !(w && w[0] == '0');
+        constexpr int kWindow = 32, kMinRun = 8;
+        const int64_t NL = g->NL;
+        std::vector<int32_t> down_pos, root, h_ptr, h_cells, count;
+        if (use_windows) {
+            std::vector<int32_t> pos(n);
+            for (int64_t p = 0; p < n; ++p) pos[g->perm[p]] = (int32_t)p;
+            down_pos.resize(n);
+            for (int64_t p = 0; p < n; ++p) {
+                const int32_t d = g->down[g->perm[p]];
+                down_pos[p] = d >= 0 ? pos[d] : -1;
+            }
+            root.resize(n);
+        }
+        auto level_size = [&](int64_t k) { return g->level_start[k + 1] - g->level_start[k]; };
+        for (int64_t k = 0; k < NL;) {
+            if (level_size(k) <= kNarrowMax) {
+                int64_t e = k + 1;
+                while (e < NL && level_size(e) <= kNarrowMax) ++e;
+                r->schedule.push_back({(int)k, (int)e, false});
+                k = e;
+                continue;
+            }
+            int64_t run_end = k + 1;
+            while (run_end < NL && level_size(run_end) > kNarrowMax) ++run_end;
+            while (k < run_end) {
+                int T = use_windows && (run_end - k) >= kMinRun ? (int)std::min<int64_t>(kWindow, run_end - k) : 1;
+                int ncomp = 0;
+                while (T >= 4) {
+                    // components of the window [k, k+T): root = the component's cell in the window's last level
+                    const int64_t top = k + T - 1;
+                    const int64_t top0 = g->level_start[top];
+                    ncomp = (int)level_size(top);
+                    for (int64_t p = top0; p < g->level_start[top + 1]; ++p) root[p] = (int32_t)p;
+                    for (int64_t lev = top - 1; lev >= k; --lev)
+                        for (int64_t p = g->level_start[lev]; p < g->level_start[lev + 1]; ++p) root[p] = root[down_pos[p]];
+                    count.assign(ncomp + 1, 0);
+                    for (int64_t p = g->level_start[k]; p < g->level_start[top + 1]; ++p) count[root[p] - top0 + 1]++;
+                    int32_t biggest = 0;
+                    for (int c = 1; c <= ncomp; ++c) biggest = std::max(biggest, count[c]);
+                    // a lane walks its component serially: windows only pay off while components stay small
+                    if (biggest <= 16 * T && (int64_t)ncomp >= 2048) break;
+                    T /= 2;
+                }
+                if (T >= 4) {
+                    const int64_t top0 = g->level_start[k + T - 1];
+                    segment sg{(int)k, (int)(k + T), true};
+                    sg.ncomp = ncomp;
+                    sg.ptr_off = (int64_t)h_ptr.size();
+                    const int32_t base = (int32_t)h_cells.size();
+                    for (int c = 0; c < ncomp; ++c) count[c + 1] += count[c]; // exclusive prefix in count[0..ncomp]
+                    for (int c = 0; c <= ncomp; ++c) h_ptr.push_back(base + count[c]);
+                    h_cells.resize(base + count[ncomp]);
+                    std::vector<int32_t> cursor(count.begin(), count.end() - 1);
+                    for (int64_t p = g->level_start[k]; p < g->level_start[k + T]; ++p) // ascending level order
+                        h_cells[base + cursor[root[p] - top0]++] = (int32_t)p;
+                    r->schedule.push_back(sg);
+                    k += T;
+                } else {
+                    r->schedule.push_back({(int)k, (int)k + 1, true});
+                    ++k;
+                }
+            }
+        }
+        if (!h_ptr.empty()) {
+            rc = r->win_ptr.upload(h_ptr.data(), h_ptr.size());
+            if (rc == LF_OK) rc = r->win_cells.upload(h_cells.data(), h_cells.size());
+            if (rc != LF_OK) {
+                delete r;
+                return rc;
+            }
         }
     }
     *out = r;
@@ -479,10 +562,12 @@ int lf_accuflux_host(lf_router *r, const double *x_host, double *out_host)
     hipLaunchKernelGGL(k_gather, dim3(blocks_for(n)), dim3(kBlock), 0, s, n, r->perm.p, r->io_lat.p, r->tmp_ord.p);
     for (const segment &g : r->schedule) {
         if (g.wide) {
-            const int first = (int)r->h_level_start[g.k0];
-            const int count = (int)(r->h_level_start[g.k1] - r->h_level_start[g.k0]);
-            hipLaunchKernelGGL(k_accu_level, dim3(blocks_for(count)), dim3(kBlock), 0, s, first, count, r->ups_ptr.p,
-                               r->tmp_ord.p, r->qord.p);
+            for (int k = g.k0; k < g.k1; ++k) { // window segments are walked level by level here
+                const int first = (int)r->h_level_start[k];
+                const int count = (int)(r->h_level_start[k + 1] - r->h_level_start[k]);
+                hipLaunchKernelGGL(k_accu_level, dim3(blocks_for(count)), dim3(kBlock), 0, s, first, count, r->ups_ptr.p,
+                                   r->tmp_ord.p, r->qord.p);
+            }
         } else {
             hipLaunchKernelGGL(k_accu_narrow, dim3(1), dim3(kNarrowBlock), 0, s, g.k0, g.k1, r->level_start.p,
                                r->ups_ptr.p, r->tmp_ord.p, r->qord.p);

@@ -150,6 +150,33 @@ def test_route_mid_size_vs_oracle(amd, oracle, solver, family, seed):
     close(gpu.from_engine_order(Qo).download(), Qc, (family, "ordered"))
 
 
+def test_route_windowed_sweep_vs_oracle(amd, oracle, solver, monkeypatch):
+    """Runs of wide levels are swept in windows of up to 32 levels, one lane per independent component (k_window).
+    260 x 3000 `deep`: ~260 levels of ~3000 cells -> windows; must equal the oracle and the per-level schedule."""
+    from lisflood_amd import synthetic as syn
+    H, W = 260, 3000
+    codes = syn.make_ldd("deep", H, W, 2)
+    mask = np.ones((H, W), bool)
+    c = codes.reshape(-1).astype(np.float64)
+    N = H * W
+    p = syn.router_params(N, seed=14)
+    cpu = oracle.kinematicWave(c, mask, p["alpha"], p["beta"], p["dx"], p["dt"])
+    gpu = amd.kw.kinematicWave(c, mask, p["alpha"], p["beta"], p["dx"], p["dt"])
+    monkeypatch.setenv("LF_WINDOWS", "0")
+    ref = amd.kw.kinematicWave(c, mask, p["alpha"], p["beta"], p["dx"], p["dt"])
+    Qg, Qr, Qc = p["Q0"].copy(), p["Q0"].copy(), p["Q0"].copy()
+    for s in range(2):
+        q = syn.lateral_inflow(N, s)
+        gpu.kinematicWaveRouting(Qg, q); ref.kinematicWaveRouting(Qr, q); cpu.kinematicWaveRouting(Qc, q)
+        assert np.array_equal(Qg, Qr)
+        close(Qg, Qc, s)
+    assert gpu.last_launches()["launches"] < ref.last_launches()["launches"] / 4
+    Qo = gpu.to_engine_order(amd.lib.DeviceArray.from_host(p["Q0"]))
+    for s in range(2):
+        gpu.route_ordered(Qo, gpu.to_engine_order(amd.lib.DeviceArray.from_host(syn.lateral_inflow(N, s))))
+    assert np.array_equal(gpu.from_engine_order(Qo).download(), Qg)
+
+
 def test_route_full_size_closure_property(amd):
     """Size-independent property at 4000 x 4000 (1.6e7 cells, beyond what the oracle does in seconds):
     every cell satisfies the discretised kinematic-wave equation
