@@ -329,12 +329,14 @@ int lf_router_create(const lf_graph *g, const double *alpha, double beta, const 
         return rc;
     }
     r->h_level_start = g->level_start;
-    // launch schedule: narrow runs -> one single-workgroup launch; runs of wide levels -> windows of up to
-    // kWindow levels swept by k_window (one lane per independent component) when the components stay small,
-    // else one launch per level.  LF_WINDOWS=0 disables the windows.
+    // launch schedule: narrow runs -> one single-workgroup launch; wide levels -> one launch per level.
+    // Experimental (LF_WINDOWS=1, off by default): runs of wide levels swept in windows of up to kWindow levels by
+    // k_window, one lane per independent component.  Measured on the 10 000^2 `deep` raster it cuts launches from
+    // 10 002 to 347 but is 6x SLOWER (215 ms vs 36 ms per call): a lane walks its component serially with ~3
+    // dependent, uncoalesced memory round trips per cell and a wavefront waits for its largest component.
     {
         const char *w = std::getenv("LF_WINDOWS");
-        const bool use_windows = !(w && w[0] == '0');
+        const bool use_windows = w && w[0] == '1';
         constexpr int kWindow = 32, kMinRun = 8;
         const int64_t NL = g->NL;
         std::vector<int32_t> down_pos, root, h_ptr, h_cells, count;

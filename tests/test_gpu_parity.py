@@ -151,8 +151,9 @@ def test_route_mid_size_vs_oracle(amd, oracle, solver, family, seed):
 
 
 def test_route_windowed_sweep_vs_oracle(amd, oracle, solver, monkeypatch):
-    """Runs of wide levels are swept in windows of up to 32 levels, one lane per independent component (k_window).
-    260 x 3000 `deep`: ~260 levels of ~3000 cells -> windows; must equal the oracle and the per-level schedule."""
+    """Experimental schedule (LF_WINDOWS=1): runs of wide levels swept in windows of up to 32 levels, one lane per
+    independent component (k_window).  260 x 3000 `deep`: ~260 levels of ~3000 cells -> windows; must equal the
+    oracle and the default per-level schedule bit for bit."""
     from lisflood_amd import synthetic as syn
     H, W = 260, 3000
     codes = syn.make_ldd("deep", H, W, 2)
@@ -161,8 +162,9 @@ def test_route_windowed_sweep_vs_oracle(amd, oracle, solver, monkeypatch):
     N = H * W
     p = syn.router_params(N, seed=14)
     cpu = oracle.kinematicWave(c, mask, p["alpha"], p["beta"], p["dx"], p["dt"])
+    monkeypatch.setenv("LF_WINDOWS", "1")
     gpu = amd.kw.kinematicWave(c, mask, p["alpha"], p["beta"], p["dx"], p["dt"])
-    monkeypatch.setenv("LF_WINDOWS", "0")
+    monkeypatch.delenv("LF_WINDOWS")
     ref = amd.kw.kinematicWave(c, mask, p["alpha"], p["beta"], p["dx"], p["dt"])
     Qg, Qr, Qc = p["Q0"].copy(), p["Q0"].copy(), p["Q0"].copy()
     for s in range(2):
