@@ -747,63 +747,91 @@ __global__ void __launch_bounds__(kBlock) k_fused_substeps(fused_args F)
     const bool b35 = A.Beta == 0.6;     // fix-up round trips, as k_substep_main / k_substep_floodplain
     const bool s35 = F.solve35 != 0;    // router solve + old-discharge term, as the router itself
     const long long par = (long long)(s & 1) * F.n;
+    // ---- every load first: the argument pointers are not restrict-qualified, so a store in the middle of the
+    // ---- kernel would pin all later loads behind it (the kernel is a stream of ~30 vectors) -------------------
     const double dxp = F.dx ? F.dx[p] : F.dx_scalar;
     const double inv_len = A.InvChanLength[p], len = A.ChanLength[p];
     const int u0 = F.ups_ptr[p], u1 = F.ups_ptr[p + 1];
-    // sideflow (routing.py:512, 524 / 549-567)
-    double side = A.IsChannelKinematic[p] ? A.SideflowChanM3[(long long)s * F.side_stride + p] * inv_len * A.InvDtRouting : 0.0;
+    const bool is_chan = A.IsChannelKinematic[p] != 0;
+    const double side_m3 = A.SideflowChanM3[(long long)s * F.side_stride + p];
+    const double ap1 = F.a1[p], qold = A.ChanQKin[p], alpha1 = A.ChannelAlpha[p], inv_alpha1 = A.InvChannelAlpha[p];
+    const double sum_old = A.sumDisDay[p];
+    const double ups1 = upstream_sum8(F.qr1 + par, u0, u1, F.kmax);
+    double m3 = 0, m3_2 = 0, start = 0, m3limit = 0, q2start = 0, ap2 = 0, q2old = 0, alpha2 = 0, inv_alpha2 = 0, qlimit = 0,
+           ups2 = 0;
+    if (SPLIT) {
+        m3 = A.ChanM3Kin[p];
+        m3_2 = A.Chan2M3Kin[p];
+        start = A.Chan2M3Start[p];
+        m3limit = A.M3Limit[p];
+        q2start = A.Chan2QStart[p];
+        ap2 = F.a2[p];
+        q2old = A.Chan2QKin[p];
+        alpha2 = A.ChannelAlpha2[p];
+        inv_alpha2 = A.InvChannelAlpha2[p];
+        qlimit = A.QLimit[p];
+        ups2 = upstream_sum8(F.qr2 + par, u0, u1, F.kmax);
+    }
+    const bool last = s == F.nsteps - 1;
+    double pix_area = 0;
+    if (last) pix_area = A.PixelArea[p];
+    // ---- sideflow (routing.py:512, 524 / 549-567) ----
+    const double side = is_chan ? side_m3 * inv_len * A.InvDtRouting : 0.0;
     double s1 = side, s2 = 0.0;
     if (!SPLIT) {
         if (isnan(side)) s1 = 0.0;
     } else {
-        const double m3 = A.ChanM3Kin[p], m3_2 = A.Chan2M3Kin[p];
         const double tot = m3 + m3_2;
         const double ratio = (tot > 0) ? m3 / tot : 0.0;
-        s1 = ((tot - A.Chan2M3Start[p]) > A.M3Limit[p]) ? ratio * side : side;
+        s1 = ((tot - start) > m3limit) ? ratio * side : side;
         if (fabs(side) < 1e-7) s1 = side;
-        A.Sideflow1Chan[p] = s1;
-        s2 = (side - s1) + A.Chan2QStart[p] * inv_len;
+        s2 = (side - s1) + q2start * inv_len;
     }
-    // main channel: router call + fix-up (routing.py:526-532 / 573-578)
-    const double ap1 = F.a1[p];
-    const double qold = A.ChanQKin[p];
+    // ---- main channel: router call + fix-up (routing.py:526-532 / 573-578) ----
     const double cst = ap1 * (s35 ? lf_pow_3_5(qold) : pow(qold, F.beta)) + s1 * dxp;
-    const double c = upstream_sum8(F.qr1 + par, u0, u1, F.kmax) + cst;
+    const double c = ups1 + cst;
     const double qr = solve_any(c, ap1, s35, F);
-    F.qr1[par + p] = qr;
-    double v = len * A.ChannelAlpha[p] * (b35 ? lf_pow_3_5(qr) : pow(qr, A.Beta));
+    double v = len * alpha1 * (b35 ? lf_pow_3_5(qr) : pow(qr, A.Beta));
     if (v < 0.0) v = 0.0;
-    const double x = v * inv_len * A.InvChannelAlpha[p];
+    const double x = v * inv_len * inv_alpha1;
     const double q = b35 ? lf_pow_5_3(x) : pow(x, A.InvBeta);
+    double chanq = q, q2r = 0, v2 = 0, q2 = 0;
+    if (SPLIT) { // ---- floodplains (routing.py:583-603) ----
+        const double cst2 = ap2 * (s35 ? lf_pow_3_5(q2old) : pow(q2old, F.beta)) + s2 * dxp;
+        const double c2 = ups2 + cst2;
+        q2r = solve_any(c2, ap2, s35, F);
+        v2 = len * alpha2 * (b35 ? lf_pow_3_5(q2r) : pow(q2r, A.Beta));
+        if ((v2 - start) < 0.0) v2 = start;
+        const double x2 = v2 * inv_len * inv_alpha2;
+        q2 = b35 ? lf_pow_5_3(x2) : pow(x2, A.InvBeta);
+        chanq = q + q2 - qlimit;
+        if (chanq < 0.0) chanq = 0.0;
+    }
+    // ---- stores ----
+    F.qr1[par + p] = qr;
     A.ChanM3Kin[p] = v;
     A.ChanQKin[p] = q;
-    const bool last = s == F.nsteps - 1;
-    if (!SPLIT) {
-        A.ChanQ[p] = q;
-        A.sumDisDay[p] += q;
-        if (last) velocity(A, (int)p, v, q);
-        return;
+    A.ChanQ[p] = chanq;
+    A.sumDisDay[p] = sum_old + chanq;
+    if (SPLIT) {
+        A.Sideflow1Chan[p] = s1;
+        F.qr2[par + p] = q2r;
+        A.Chan2M3Kin[p] = v2;
+        A.CrossSection2Area[p] = (v2 - start) * inv_len;
+        A.Chan2QKin[p] = q2;
     }
-    // floodplains (routing.py:583-603)
-    const double ap2 = F.a2[p];
-    const double q2old = A.Chan2QKin[p];
-    const double cst2 = ap2 * (s35 ? lf_pow_3_5(q2old) : pow(q2old, F.beta)) + s2 * dxp;
-    const double c2 = upstream_sum8(F.qr2 + par, u0, u1, F.kmax) + cst2;
-    const double q2r = solve_any(c2, ap2, s35, F);
-    F.qr2[par + p] = q2r;
-    const double start = A.Chan2M3Start[p];
-    double v2 = len * A.ChannelAlpha2[p] * (b35 ? lf_pow_3_5(q2r) : pow(q2r, A.Beta));
-    if ((v2 - start) < 0.0) v2 = start;
-    A.Chan2M3Kin[p] = v2;
-    A.CrossSection2Area[p] = (v2 - start) * inv_len;
-    const double x2 = v2 * inv_len * A.InvChannelAlpha2[p];
-    const double q2 = b35 ? lf_pow_5_3(x2) : pow(x2, A.InvBeta);
-    A.Chan2QKin[p] = q2;
-    double qq = q + q2 - A.QLimit[p];
-    if (qq < 0.0) qq = 0.0;
-    A.ChanQ[p] = qq;
-    A.sumDisDay[p] += qq;
-    if (last) velocity(A, (int)p, v, q);
+    if (last) { // routing.py:693-703
+        double area = v * inv_len;
+        if (area < 0.01) area = 0.01;
+        const double v1 = q / area, vv2 = 0.36 * pow(q, 0.24);
+        double vel = (vv2 < v1) ? vv2 : v1;
+        if (isnan(vv2)) vel = vv2;
+        double sinu = sqrt(pix_area) * inv_len;
+        if (sinu > 1) sinu = 1;
+        vel *= sinu;
+        A.FlowVelocity[p] = vel;
+        A.TravelDistance[p] = vel * A.DtSec;
+    }
 }
 
 } // namespace
