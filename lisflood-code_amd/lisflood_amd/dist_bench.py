@@ -92,6 +92,12 @@ def main(a):
                        "layout": "engine sweep order per rank, ghost slots appended",
                        "parallelism": "row-block x%d, RCCL Send/Recv halo per phase" % world},
             "hbm_frac_whole_step": round(B_ALG * N / (ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), 6),
+            # per-GPU algorithmic bandwidth over the WHOLE step (sweeps + packs + RCCL halo rounds), not a
+            # per-kernel hipEvent figure: the per-kernel roofline is reported by the N = 1 run
+            "roofline": {"bound": "hbm", "kernel": "k_level[fused+ordered+indexed] (whole step, per GPU)",
+                         "achieved": round(B_ALG * N / world / (ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(B_ALG * N / world / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                         "traffic": None},
             "checksum_sumQ": float(chk[0].item()), "finite": bool(chk[1].item() == world),
         }
         print(json.dumps(out), flush=True)
