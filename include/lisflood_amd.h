@@ -172,6 +172,10 @@ int lf_routing_substeps_fused(lf_router *r, const lf_substep_args *a, int nsteps
  * ------------------------------------------------------------------------------------------- */
 int lf_upstream_sum_device(lf_router *r, const double *w_dev, double *out_dev);
 int lf_upstream_sum_host(lf_router *r, const double *w_host, double *out_host);
+/* the same reduction directly on H x W rasters (uint8 LDD codes, 0 = sea / missing; fp64 weights, device memory):
+ * LDS-staged 3 x 3 neighbourhoods, coalesced rows, neighbours added in ascending source index. */
+int lf_upstream_sum_raster_device(int device, const uint8_t *ldd_raster_dev, const double *w_raster_dev,
+                                  double *out_raster_dev, int H, int W);
 /* accuflux(ldd, x): sum of x over all upstream cells including the cell itself (routing.py:98) */
 int lf_accuflux_host(lf_router *r, const double *x_host, double *out_host);
 

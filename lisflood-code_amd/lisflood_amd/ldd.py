@@ -111,3 +111,21 @@ def cut_at_structures(codes, land_mask, is_structure):
     out = np.asarray(codes).copy()
     out[ups] = PIT
     return lddrepair(out, land_mask), ups
+
+
+def upstream_raster(ldd_raster, w_raster, device=0):
+    """PCRaster upstream(ldd, w) on whole H x W rasters, on the device (LDS-staged 3 x 3 neighbourhoods):
+    out[cell] = sum of w over the neighbours draining into the cell, ascending source index.  Cells whose code
+    is 0 send nothing."""
+    import ctypes as C
+    from ._lib import DeviceArray, check, lib
+    ldd_raster = np.ascontiguousarray(ldd_raster, dtype=np.uint8)
+    w_raster = np.ascontiguousarray(w_raster, dtype=np.float64)
+    H, W = ldd_raster.shape
+    d_l, d_w = DeviceArray.from_host(ldd_raster, device), DeviceArray.from_host(w_raster, device)
+    d_o = DeviceArray((H, W), np.float64, device)
+    check(lib().lf_upstream_sum_raster_device(C.c_int(device), d_l.ptr, d_w.ptr, d_o.ptr, C.c_int(H), C.c_int(W)))
+    out = d_o.download()
+    for d in (d_l, d_w, d_o):
+        d.free()
+    return out
