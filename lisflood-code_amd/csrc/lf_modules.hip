@@ -414,44 +414,53 @@ int lf_surface_step(lf_router *direct_router, lf_router *other_router, lf_router
 // ================================================================================================
 // Raster-space one-hop upstream reduction: out[cell] = sum of w over the (up to 8) neighbours whose LDD points at
 // the cell -- PCRaster upstream(ldd, w) / np.bincount(downstruct, weights=w) (routing.py:159-164, 387;
-// lakes.py:215) on a full H x W raster.  A 32 x 8 tile of LDD codes and weights is staged in LDS with a one-cell
+// lakes.py:215) on a full H x W raster.  A 64 x 16 tile of LDD codes and weights is staged in LDS with a one-cell
 // halo, so every global access is a coalesced row segment and the 3 x 3 neighbourhood tests hit LDS.  Neighbours
 // are added in ascending source index (NW, N, NE, W, E, SW, S, SE) = the reference's summation order.
 // Cells with code 0 (sea / missing) neither send nor (unless pointed at) matter; flow off the raster is dropped.
 // ================================================================================================
 namespace {
-constexpr int kTX = 32, kTY = 8;
+constexpr int kTX = 64, kTY = 16, kRY = 4;   // tile 64 x 16 cells, 64 x 4 threads, 4 rows per thread
 
-__global__ void __launch_bounds__(kTX *kTY) k_upstream_sum_raster(int H, int W, const uint8_t *__restrict__ ldd,
+__global__ void __launch_bounds__(kTX *kRY) k_upstream_sum_raster(int H, int W, const uint8_t *__restrict__ ldd,
                                                                   const double *__restrict__ w, double *__restrict__ out)
 {
     __shared__ uint8_t s_ldd[kTY + 2][kTX + 2];
     __shared__ double s_w[kTY + 2][kTX + 2];
     const int c0 = blockIdx.x * kTX - 1, r0 = blockIdx.y * kTY - 1;
-    for (int i = threadIdx.y * kTX + threadIdx.x; i < (kTY + 2) * (kTX + 2); i += kTX * kTY) {
-        const int lr = i / (kTX + 2), lc = i - lr * (kTX + 2);
-        const int r = r0 + lr, c = c0 + lc;
-        const bool in = r >= 0 && r < H && c >= 0 && c < W;
-        s_ldd[lr][lc] = in ? ldd[(long long)r * W + c] : (uint8_t)0;
-        s_w[lr][lc] = in ? w[(long long)r * W + c] : 0.0;
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    for (int lr = ty; lr < kTY + 2; lr += kRY) {             // one wavefront per staged row: coalesced 512 B
+        const int r = r0 + lr;
+        const bool rin = r >= 0 && r < H;
+        for (int lc = tx; lc < kTX + 2; lc += kTX) {
+            const int c = c0 + lc;
+            const bool in = rin && c >= 0 && c < W;
+            s_ldd[lr][lc] = in ? ldd[(long long)r * W + c] : (uint8_t)0;
+            s_w[lr][lc] = in ? w[(long long)r * W + c] : 0.0;
+        }
     }
     __syncthreads();
-    const int r = blockIdx.y * kTY + threadIdx.y, c = blockIdx.x * kTX + threadIdx.x;
-    if (r >= H || c >= W) return;
-    const int lr = threadIdx.y + 1, lc = threadIdx.x + 1;
+    const int c = blockIdx.x * kTX + tx;
+    if (c >= W) return;
+    const int lc = tx + 1;
     // keypad code a neighbour at (dr, dc) must carry to drain into this cell: it points by (-dr, -dc)
     //   NW(-1,-1) -> 3 (SE), N(-1,0) -> 2 (S), NE(-1,+1) -> 1 (SW), W(0,-1) -> 6 (E), E(0,+1) -> 4 (W),
     //   SW(+1,-1) -> 9 (NE), S(+1,0) -> 8 (N), SE(+1,+1) -> 7 (NW)
-    double s = 0.0;
-    if (s_ldd[lr - 1][lc - 1] == 3) s += s_w[lr - 1][lc - 1];
-    if (s_ldd[lr - 1][lc] == 2) s += s_w[lr - 1][lc];
-    if (s_ldd[lr - 1][lc + 1] == 1) s += s_w[lr - 1][lc + 1];
-    if (s_ldd[lr][lc - 1] == 6) s += s_w[lr][lc - 1];
-    if (s_ldd[lr][lc + 1] == 4) s += s_w[lr][lc + 1];
-    if (s_ldd[lr + 1][lc - 1] == 9) s += s_w[lr + 1][lc - 1];
-    if (s_ldd[lr + 1][lc] == 8) s += s_w[lr + 1][lc];
-    if (s_ldd[lr + 1][lc + 1] == 7) s += s_w[lr + 1][lc + 1];
-    out[(long long)r * W + c] = s;
+#pragma unroll
+    for (int k = 0; k < kTY / kRY; ++k) {
+        const int lr = ty + k * kRY + 1, r = blockIdx.y * kTY + ty + k * kRY;
+        if (r >= H) break;
+        double s = 0.0;
+        if (s_ldd[lr - 1][lc - 1] == 3) s += s_w[lr - 1][lc - 1];
+        if (s_ldd[lr - 1][lc] == 2) s += s_w[lr - 1][lc];
+        if (s_ldd[lr - 1][lc + 1] == 1) s += s_w[lr - 1][lc + 1];
+        if (s_ldd[lr][lc - 1] == 6) s += s_w[lr][lc - 1];
+        if (s_ldd[lr][lc + 1] == 4) s += s_w[lr][lc + 1];
+        if (s_ldd[lr + 1][lc - 1] == 9) s += s_w[lr + 1][lc - 1];
+        if (s_ldd[lr + 1][lc] == 8) s += s_w[lr + 1][lc];
+        if (s_ldd[lr + 1][lc + 1] == 7) s += s_w[lr + 1][lc + 1];
+        out[(long long)r * W + c] = s;
+    }
 }
 } // namespace
 
@@ -462,7 +471,7 @@ extern "C" int lf_upstream_sum_raster_device(int device, const uint8_t *ldd_rast
         return lf_set_error(LF_E_INVALID, "bad argument");
     lf_device_ctx *c;
     LF_TRY(lf_ctx(device, &c));
-    const dim3 grid((W + kTX - 1) / kTX, (H + kTY - 1) / kTY), block(kTX, kTY);
+    const dim3 grid((W + kTX - 1) / kTX, (H + kTY - 1) / kTY), block(kTX, kRY);
     hipLaunchKernelGGL(k_upstream_sum_raster, grid, block, 0, c->stream, H, W, ldd_raster_dev, w_raster_dev,
                        out_raster_dev);
     LF_HIP(hipGetLastError());
