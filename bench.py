@@ -50,6 +50,18 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def level_sizes(g):
+    """Level-size histogram of the input (throughput is a function of NL): the full list when short,
+    else a summary."""
+    import numpy as np
+    ls = np.diff(g.layout()[2])
+    if len(ls) <= 32:
+        return [int(x) for x in ls]
+    q = np.percentile(ls, [0, 25, 50, 75, 100])
+    return {"levels": int(len(ls)), "min": int(q[0]), "p25": int(q[1]), "median": int(q[2]), "p75": int(q[3]),
+            "max": int(q[4]), "narrow_levels_le_1024": int((ls <= 1024).sum())}
+
+
 def build_case(family, H, W):
     from lisflood_amd import synthetic as syn
     from lisflood_amd.kinematic_wave_parallel import Graph, kinematicWave
@@ -353,7 +365,8 @@ def main():
         "config": {"workload": "%dx%d fp64 raster, %s LDD (seed %d), all land, beta=0.6, 1 router call per step"
                                % (H, W, "random ('shallow')" if a.family == "shallow" else "sheet-flow ('deep')",
                                   1 if a.family == "shallow" else 2),
-                   "cells": N, "levels": g.num_levels, "launches_per_step": res["stats"]["launches"],
+                   "cells": N, "levels": g.num_levels, "level_sizes": level_sizes(g),
+                   "launches_per_step": res["stats"]["launches"],
                    "layout": "discharge and lateral inflow resident in HBM in the engine's sweep order "
                              "(lf_router_route_ordered); see pixel_order_call for the reference-order device call",
                    "parallelism": "1 GPU"},
@@ -379,6 +392,7 @@ def main():
             r2 = run_routing(kw2, p2, max(2, a.steps // 5), 1, nq=1, profile_steps=1)
             extra[other] = dict(value=round(kw2.num_pixels / r2["ms_per_step"] / 1e3, 2), unit="Mcell-steps/s",
                                 ms_per_step=round(r2["ms_per_step"], 3), levels=g2.num_levels,
+                                level_sizes=level_sizes(g2),
                                 launches_per_step=r2["stats"]["launches"], roofline=roofline_of(r2))
             kw2.close()
         except Exception as e:  # secondary numbers must never break the headline line
