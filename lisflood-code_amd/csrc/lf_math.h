@@ -118,13 +118,15 @@ __device__ __forceinline__ double lf_solve_3_5(double c, double a)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double lf_pow_pos(double x, double y)
 {
-    if (!(x > 0.0)) return (x == 0.0) ? 0.0 : (x + y); // 0 -> 0 ; negative / NaN -> NaN via the general pow below
-    int e = __builtin_amdgcn_frexp_exp(x);
-    double m = __builtin_amdgcn_frexp_mant(x); // [0.5, 1)
-    if (m < 0.70710678118654752440) {
-        m *= 2.0;
-        e -= 1;
-    }
+    // branch-free: the main path runs on a sanitised argument and the special cases are selected at the end, so
+    // several inlined calls form ONE basic block and the scheduler interleaves their dependent chains
+    const bool pos = x > 0.0;
+    const double xs = pos ? x : 1.0;
+    int e = __builtin_amdgcn_frexp_exp(xs);
+    double m = __builtin_amdgcn_frexp_mant(xs); // [0.5, 1)
+    const bool lo = m < 0.70710678118654752440;
+    m = lo ? m * 2.0 : m;
+    e = lo ? e - 1 : e;
     const double f = m - 1.0;
     const double s = f / (2.0 + f);
     const double z = s * s, w = z * z;
@@ -143,20 +145,19 @@ __device__ __forceinline__ double lf_pow_pos(double x, double y)
     const double r = ((p - n) + q) + p_err; // |r| <= ~0.5
     const double u = r * 0.69314718055994530942;
     // e^u, |u| <= 0.36
-    double ex = 1.6059043836821613e-10; // 1/13!
-    ex = fma(ex, u, 2.08767569878681e-09);
-    ex = fma(ex, u, 2.505210838544172e-08);
-    ex = fma(ex, u, 2.755731922398589e-07);
-    ex = fma(ex, u, 2.7557319223985893e-06);
-    ex = fma(ex, u, 2.48015873015873e-05);
-    ex = fma(ex, u, 1.984126984126984e-04);
-    ex = fma(ex, u, 1.388888888888889e-03);
-    ex = fma(ex, u, 8.333333333333333e-03);
-    ex = fma(ex, u, 4.1666666666666664e-02);
-    ex = fma(ex, u, 1.6666666666666666e-01);
-    ex = fma(ex, u, 0.5);
-    ex = fma(ex, u, 1.0);
-    ex = fma(ex, u, 1.0);
+    // degree-13 Taylor polynomial in Estrin form (dependent depth 5 instead of 14)
+    const double u2 = u * u, u4 = u2 * u2, u8 = u4 * u4;
+    const double a0 = fma(1.0, u, 1.0);
+    const double a1 = fma(1.6666666666666666e-01, u, 0.5);
+    const double a2 = fma(8.333333333333333e-03, u, 4.1666666666666664e-02);
+    const double a3 = fma(1.984126984126984e-04, u, 1.388888888888889e-03);
+    const double a4 = fma(2.7557319223985893e-06, u, 2.48015873015873e-05);
+    const double a5 = fma(2.505210838544172e-08, u, 2.755731922398589e-07);
+    const double a6 = fma(1.6059043836821613e-10, u, 2.08767569878681e-09);
+    const double b0 = fma(a1, u2, a0), b1 = fma(a3, u2, a2), b2 = fma(a5, u2, a4);
+    const double d0 = fma(b1, u4, b0), d1 = fma(a6, u4, b2);
+    const double ex = fma(d1, u8, d0);
     const double nn = fmin(fmax(n, -2000.0), 2000.0);
-    return ldexp(ex, (int)nn);
+    const double val = ldexp(ex, (int)nn);
+    return pos ? val : ((x == 0.0) ? 0.0 : (x + y)); // 0 -> 0 ; negative / NaN -> NaN
 }

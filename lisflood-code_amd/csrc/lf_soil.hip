@@ -273,8 +273,12 @@ __global__ void __launch_bounds__(kBlock) k_soil_columns(lf_soil_args A, veg_pla
 }
 
 // Pass 2: the deferred columns of kGroup consecutive tiles, sorted by sub-step class, one lane each.
+#ifndef LF_SOIL_P2_WAVES
+#define LF_SOIL_P2_WAVES 2
+#endif
 template <bool FASTPOW>
-__global__ void __launch_bounds__(kBlock) k_soil_columns_deferred(lf_soil_args A, veg_plan P,
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(LF_SOIL_P2_WAVES)))
+k_soil_columns_deferred(lf_soil_args A, veg_plan P,
                                                                   const unsigned short *__restrict__ tile_list,
                                                                   const unsigned int *__restrict__ tile_count,
                                                                   unsigned int ntiles, unsigned int tiles_per_veg)

@@ -20,7 +20,8 @@ class LisfloodAmdError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(_HERE, _LIBNAME)
+    """In-tree build by default; LISFLOOD_AMD_LIBRARY overrides (an alternative build of the same C ABI)."""
+    return os.environ.get("LISFLOOD_AMD_LIBRARY") or os.path.join(_HERE, _LIBNAME)
 
 
 def lib():

@@ -407,11 +407,15 @@ typedef struct {
 /* statistics of the last lfo_soil_columns call: columns, columns with > 1 sub-step, sum and max of nsub */
 static int64_t g_soil_stats[4];
 void lfo_soil_stats(int64_t out[4]) { memcpy(out, g_soil_stats, sizeof(g_soil_stats)); }
+/* histogram of floor(log2(nsub)) over the columns of the last call (workload characterisation for the bench) */
+static int64_t g_soil_hist[32];
+void lfo_soil_substep_hist(int64_t out[32]) { memcpy(out, g_soil_hist, sizeof(g_soil_hist)); }
 
 void lfo_soil_columns(const lfo_soil_args *A)
 {
     int64_t st_cols = 0, st_multi = 0, st_sum = 0, st_max = 0;
     const int64_t N = A->N;
+    memset(g_soil_hist, 0, sizeof(g_soil_hist));
     int64_t count_paddy = 0;
     for (int64_t veg = 0; veg < A->V; ++veg) {
         const uint8_t *inactive = NULL;
@@ -488,6 +492,11 @@ void lfo_soil_columns(const lfo_soil_args *A)
             st_multi += nsub > 1;
             st_sum += nsub;
             if (nsub > st_max) st_max = nsub;
+            {
+                int c = 0;
+                for (int64_t t = nsub; t > 1 && c < 31; t >>= 1) ++c;
+                g_soil_hist[c] += 1;
+            }
             /* sub-step loop, :266-312 */
             double wt1a = w1a, wt1b = w1b, wt2 = w2;
             double sa = 0., sb = 0., sg = 0.;
