@@ -246,8 +246,13 @@ constexpr int kClasses = 8; // class = floor(log2(nsub)) clamped to kClasses-1: 
 constexpr int kGroup = 16;  // tiles per pass-2 workgroup (a pool of 4096 columns: enough deferred columns to fill
                             // wavefronts with similar trip counts even when the sub-step distribution has a long tail)
 
+#ifndef LF_SOIL_P1_WAVES
+#define LF_SOIL_P1_WAVES 4
+#endif
+// waves_per_eu(4): pass 1 streams ~500 B per column and needs the occupancy; the allocator otherwise wobbles
+// between 126 and 133 VGPRs (4 vs 3 waves per SIMD) with unrelated edits to this file; 5 waves spill and are slower
 template <bool FASTPOW>
-__global__ void __launch_bounds__(kBlock) k_soil_columns(lf_soil_args A, veg_plan P, unsigned short *__restrict__ tile_list,
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(LF_SOIL_P1_WAVES))) k_soil_columns(lf_soil_args A, veg_plan P, unsigned short *__restrict__ tile_list,
                                                          unsigned int *__restrict__ tile_count)
 {
     __shared__ unsigned int count;
