@@ -381,6 +381,19 @@ def main():
                                        ms_per_step=round(rp["ms_per_step"], 4),
                                        note="same call with vectors resident in the reference's pixel order "
                                             "(lf_router_route_device: gather/scatter through perm inside the sweep)")
+        # the reference's own call signature: host numpy vectors in, discharge updated in place (PCIe both ways,
+        # pageable memory) -- never the headline value, reported so the cost of staying on the host is visible
+        import numpy as _np
+        from lisflood_amd import synthetic as _syn
+        Qh, qh = _np.array(p["Q0"]), _syn.lateral_inflow(N, 0)
+        kw.kinematicWaveRouting(Qh, qh)
+        t0 = time.perf_counter()
+        for _ in range(2):
+            kw.kinematicWaveRouting(Qh, qh)
+        host_ms = (time.perf_counter() - t0) / 2 * 1e3
+        out["pixel_order_call"]["host_vectors_call"] = dict(
+            ms_per_step=round(host_ms, 2), value=round(N / host_ms / 1e3, 2), unit="Mcell-steps/s",
+            note="kinematicWaveRouting(discharge, lateral) on host numpy arrays: 16 B/cell up + 8 B/cell down over PCIe")
     except Exception as e:
         out["pixel_order_call"] = {"error": repr(e)}
     kw.close()

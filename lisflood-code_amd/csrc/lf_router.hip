@@ -128,10 +128,49 @@ struct lf_router {
     std::vector<rec> recs;
     size_t ev_used = 0;
     double prof_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // hipGraph replay of a call's launch sequence (LF_HIPGRAPH=1): one captured graph per distinct argument set
+    bool use_graph = false;
+    struct graph_entry {
+        std::string key;
+        hipGraph_t graph;
+        hipGraphExec_t exec;
+    };
+    std::vector<graph_entry> graphs;
+    static constexpr size_t kMaxGraphs = 8;
 
     ~lf_router()
     {
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
+        for (graph_entry &g : graphs) {
+            (void)hipGraphExecDestroy(g.exec);
+            (void)hipGraphDestroy(g.graph);
+        }
+    }
+    // Replays the launches `enqueue` puts on the stream as a captured graph; the first call with a new key captures.
+    template <class F> int replay(const std::string &key, F enqueue)
+    {
+        for (graph_entry &g : graphs)
+            if (g.key == key) {
+                LF_HIP(hipGraphLaunch(g.exec, ctx->stream));
+                return LF_OK;
+            }
+        if (graphs.size() == kMaxGraphs) {
+            LF_HIP(hipStreamSynchronize(ctx->stream));
+            (void)hipGraphExecDestroy(graphs.front().exec);
+            (void)hipGraphDestroy(graphs.front().graph);
+            graphs.erase(graphs.begin());
+        }
+        graph_entry g;
+        g.key = key;
+        LF_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+        const int rc = enqueue();
+        const hipError_t e = hipStreamEndCapture(ctx->stream, &g.graph);
+        if (rc != LF_OK) return rc;
+        LF_HIP(e);
+        LF_HIP(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
+        graphs.push_back(g);
+        LF_HIP(hipGraphLaunch(g.exec, ctx->stream));
+        return LF_OK;
     }
     int ev_get(size_t *idx)
     {
@@ -178,13 +217,8 @@ struct lf_router {
 
 namespace {
 
-int route_device(lf_router *r, double *q_dev, const double *lat_dev, int section, bool ordered = false)
+int enqueue_route(lf_router *r, double *q_dev, const double *lat_dev, int section, bool ordered)
 {
-    if (section != LF_SECTION_MAIN && section != LF_SECTION_FLOODPLAINS)
-        return lf_set_error(LF_E_SECTION, "The section parameter must be either 'main_channel' or 'floodplain'!");
-    if (section == LF_SECTION_FLOODPLAINS && !r->has_floodplains)
-        return lf_set_error(LF_E_SECTION, "floodplains routing requested but alpha_floodplains was not given");
-    LF_HIP(hipSetDevice(r->device));
     hipStream_t s = r->ctx->stream;
     const double *a = (section == LF_SECTION_MAIN) ? r->a1.p : r->a2.p;
     const int n = (int)r->N;
@@ -258,11 +292,27 @@ int route_device(lf_router *r, double *q_dev, const double *lat_dev, int section
         }
         ++launches;
     }
-    LF_HIP(hipGetLastError());
     r->last_stats[0] = launches;
     r->last_stats[1] = wide;
     r->last_stats[2] = narrow;
     r->last_stats[3] = r->NL;
+    return LF_OK;
+}
+
+int route_device(lf_router *r, double *q_dev, const double *lat_dev, int section, bool ordered = false)
+{
+    if (section != LF_SECTION_MAIN && section != LF_SECTION_FLOODPLAINS)
+        return lf_set_error(LF_E_SECTION, "The section parameter must be either 'main_channel' or 'floodplain'!");
+    if (section == LF_SECTION_FLOODPLAINS && !r->has_floodplains)
+        return lf_set_error(LF_E_SECTION, "floodplains routing requested but alpha_floodplains was not given");
+    LF_HIP(hipSetDevice(r->device));
+    if (r->use_graph && !r->profile && r->schedule.size() >= 8) {
+        char key[96];
+        std::snprintf(key, sizeof key, "route %p %p %d %d", (void *)q_dev, (const void *)lat_dev, section, (int)ordered);
+        LF_TRY(r->replay(key, [&] { return enqueue_route(r, q_dev, lat_dev, section, ordered); }));
+    } else
+        LF_TRY(enqueue_route(r, q_dev, lat_dev, section, ordered));
+    LF_HIP(hipGetLastError());
     if (r->profile) LF_TRY(r->prof_collect());
     return LF_OK;
 }
@@ -291,6 +341,10 @@ int lf_router_create(const lf_graph *g, const double *alpha, double beta, const 
     r->has_floodplains = alpha_floodplains != nullptr;
     // beta == 3/5 (every LISFLOOD setting): fused prep + polynomial solve.  LF_GENERAL_POW=1 forces the
     // general path (the reference's own Newton iteration with pow) for A/B parity and timing.
+    {
+        const char *hg = std::getenv("LF_HIPGRAPH");
+        r->use_graph = hg && hg[0] == '1';
+    }
     const char *force_general = std::getenv("LF_GENERAL_POW");
     r->fused = (beta == 0.6) && !(force_general && force_general[0] == '1');
     const int64_t n = g->N;
