@@ -275,9 +275,9 @@ def model_step_bench(size=5000, nsteps=24):
     vals["Chan2QKin"] = (vals["Chan2M3Kin"] / length / alpha2) ** (1 / beta)
     out = {}
     ref = None
-    for mode in ("fused", "sequential"):
+    for mode in ("fused", "sequential", "sequential_single_sweep"):
         st = RoutingStepDevice(kw, vals, True, beta, 1.0 / dt, dt * nsteps)
-        run = st.run_fused if mode == "fused" else st.run_sequential
+        run = {"fused": st.run_fused, "sequential": st.run_sequential, "sequential_single_sweep": st.run_single_sweep}[mode]
         reps = 3 if mode == "fused" else 1
         if mode == "fused":
             run(nsteps)                  # warm-up
@@ -289,7 +289,7 @@ def model_step_bench(size=5000, nsteps=24):
         ms = (time.perf_counter() - t0) * 1e3 / reps
         out[mode] = dict(ms_per_model_step=round(ms, 3), value=round(2 * nsteps * N / ms / 1e3, 2),
                          unit="Mcell-steps/s", launches_per_model_step=kw.last_launches()["launches"] *
-                         (1 if mode == "fused" else 2 * nsteps))
+                         {"fused": 1, "sequential": 2 * nsteps, "sequential_single_sweep": nsteps}[mode])
         st.free()
     out["config"] = "%dx%d deep LDD (NL=%d), NoRoutSteps=%d, split routing: %d cell-steps per cell per model step" % (
         H, W, g.num_levels, nsteps, 2 * nsteps)

@@ -86,6 +86,16 @@ int lf_calibration_copy(int device, const double *src_dev, double *dst_dev, int6
 /* ldd_codes: N compressed LISFLOOD keypad codes (doubles, as the reference passes them; 0 = sea,
  * 5 = pit; any value outside {1,2,3,4,6,7,8,9} is "no flow").  land_mask: H*W bytes, non-zero = land. */
 int lf_graph_create(const double *ldd_codes, const uint8_t *land_mask, int H, int W, lf_graph **out);
+/* same, with zero-length links for the structures of the routing loop: virtual_down[N] (may be NULL; -1 = none)
+ * names, for a pit u of THIS (cut) LDD, the pixel v it drains into in the uncut LDD (structures.py:44-61 cuts the
+ * LDD just upstream of lakes and reservoirs; routing.py:159-164 keeps the uncut link in `downstruct`).  u gets the
+ * same level as v, which is what lets lf_routing_substeps_fused_structures run lakes.py / reservoir.py between two
+ * launches of the wavefront.  Levels then differ from the reference's routing orders; router results do not. */
+int lf_graph_create_ex(const double *ldd_codes, const uint8_t *land_mask, int H, int W, const int64_t *virtual_down,
+                       lf_graph **out);
+/* linked[N], by engine position: 1 = the cell is such a zero-length link (it sits at the end of its level, outside
+ * every upstream range) */
+int lf_graph_get_links(const lf_graph *g, uint8_t *linked);
 /* raster form for large domains: H*W uint8 codes; land_mask may be NULL (= all land). */
 int lf_graph_create_raster(const uint8_t *ldd_raster, const uint8_t *land_mask, int H, int W, lf_graph **out);
 void lf_graph_destroy(lf_graph *g);
@@ -302,6 +312,15 @@ typedef struct lf_inloop_args {
     int32_t step; /* NoRoutingExecuted */
 } lf_inloop_args;
 int lf_inloop_structures(int device, const lf_inloop_args *a);
+/* The whole loop `for s in range(NoRoutSteps): lakes/reservoir/inflow/transmission.dynamic_inloop(s);
+ * routing.dynamic(s)` (Lisflood_dynamic.py:179-180 with routing.py:441-478) as ONE skewed wavefront: the cell kernel
+ * of lf_routing_substeps_fused assembles SideflowChanM3 itself (inflow hydrographs, transmission loss, the
+ * structures' outflow) and a one-lane-per-site kernel runs each lake / reservoir for sub-step s = t - level(site)
+ * right before launch t.  Needs: engine_order = 1 everywhere (`in` holds engine-order vectors and site lists in
+ * engine positions, `in->step` is ignored), and a router whose graph was built by lf_graph_create_ex with the
+ * uncut links of the structures (every cell feeding a site on the site's level; checked).  Bit-identical to the
+ * sub-step-by-sub-step sequence lf_inloop_structures + lf_routing_substep. */
+int lf_routing_substeps_fused_structures(lf_router *r, const lf_substep_args *a, const lf_inloop_args *in, int nsteps);
 
 /* The per-pixel aggregates between the soil columns and surface routing, one pass:
  * opensealed.dynamic (opensealed.py:40-71), soil.dynamic_perpixel (soil.py:471-514; deffraction =

@@ -51,6 +51,12 @@ struct lf_graph {
     std::vector<int32_t> perm;        // [N] position -> pixel
     std::vector<int32_t> ups_ptr;     // [N+1]
     std::vector<int64_t> level_start; // [NL+1]
+    // zero-length structure links (lf_graph_create_ex): flag per POSITION, 1 = this pit hangs on a structure cell of
+    // its own level.  Such cells sit at the end of their level outside every upstream range, so the LAST cell of
+    // the next level finds them behind its own children: only sweeps that write a separate router-output buffer
+    // (the fused sub-step wavefront, which stores 0 for them) may run on such a graph.
+    std::vector<uint8_t> linked;
+    bool has_links = false;
 };
 
 template <typename T>

@@ -34,8 +34,13 @@ inline int decode(int code)
 }
 
 // codes_at(i): LDD code of raster cell i (row-major); is_land(i): land mask.
+// virtual_down (optional, [N], -1 = none): for a pit u of this LDD, the pixel v it drains into in the UNCUT LDD
+// (structures.py:44-61 turns the cells just upstream of a lake / reservoir into pits).  Such a link carries no
+// router flow but the structure at v reads ChanQ(u) of the previous sub-step, so u is given the SAME level as v
+// (a zero-length edge): the fused sub-step wavefront can then run the structure between two launches.
 template <typename CodeAt, typename IsLand>
-int build(int H, int W, CodeAt codes_at, IsLand is_land, bool all_land, lf_graph **out)
+int build(int H, int W, CodeAt codes_at, IsLand is_land, bool all_land, lf_graph **out,
+          const int64_t *virtual_down = nullptr)
 {
     if (H <= 0 || W <= 0) return lf_set_error(LF_E_INVALID, "bad raster shape %d x %d", H, W);
     const int64_t HW = (int64_t)H * W;
@@ -107,17 +112,53 @@ int build(int H, int W, CodeAt codes_at, IsLand is_land, bool all_land, lf_graph
         std::vector<int32_t> queue(n);
         std::vector<int64_t> gen_start;
         int64_t tail = 0;
-        for (int64_t p = 0; p < n; ++p)
-            if (g->down[p] < 0) queue[tail++] = (int32_t)p;
-        int64_t head = 0;
-        gen_start.push_back(0);
-        while (head < tail) {
-            const int64_t gen_end = tail;
-            for (; head < gen_end; ++head) {
-                const int32_t p = queue[head];
-                for (int32_t e = uptr[p]; e < uptr[p + 1]; ++e) queue[tail++] = uidx[e];
+        if (!virtual_down) {
+            for (int64_t p = 0; p < n; ++p)
+                if (g->down[p] < 0) queue[tail++] = (int32_t)p;
+            int64_t head = 0;
+            gen_start.push_back(0);
+            while (head < tail) {
+                const int64_t gen_end = tail;
+                for (; head < gen_end; ++head) {
+                    const int32_t p = queue[head];
+                    for (int32_t e = uptr[p]; e < uptr[p + 1]; ++e) queue[tail++] = uidx[e];
+                }
+                gen_start.push_back(gen_end);
             }
-            gen_start.push_back(gen_end);
+        } else {
+            // zero-length links: CSR of the pits hanging on every pixel, ascending id
+            std::vector<int32_t> vptr(n + 1, 0);
+            for (int64_t u = 0; u < n; ++u) {
+                const int64_t v = virtual_down[u];
+                if (v < 0) continue;
+                if (v >= n || v == u || g->down[u] >= 0) {
+                    delete g;
+                    return lf_set_error(LF_E_INVALID, "virtual_down[%lld] = %lld: the source must be a pit of this LDD and "
+                                        "the target another pixel", (long long)u, (long long)v);
+                }
+                vptr[v + 1]++;
+            }
+            for (int64_t p = 0; p < n; ++p) vptr[p + 1] += vptr[p];
+            std::vector<int32_t> vidx(vptr[n] > 0 ? vptr[n] : 1), vfill(vptr.begin(), vptr.end() - 1);
+            for (int64_t u = 0; u < n; ++u)
+                if (virtual_down[u] >= 0) vidx[vfill[virtual_down[u]]++] = (int32_t)u;
+            std::vector<int32_t> cur, next;
+            for (int64_t p = 0; p < n; ++p)
+                if (g->down[p] < 0 && virtual_down[p] < 0) cur.push_back((int32_t)p);
+            gen_start.push_back(0);
+            while (!cur.empty() && tail < n) {
+                for (size_t i = 0; i < cur.size() && (int64_t)(cur.size() + next.size()) <= n; ++i) { // cur grows
+                    const int32_t p = cur[i];
+                    for (int32_t e = uptr[p]; e < uptr[p + 1]; ++e) next.push_back(uidx[e]);
+                    for (int32_t e = vptr[p]; e < vptr[p + 1]; ++e) cur.push_back(vidx[e]); // same generation
+                }
+                if (tail + (int64_t)cur.size() > n) break; // a cycle through a virtual link
+                std::memcpy(queue.data() + tail, cur.data(), sizeof(int32_t) * cur.size());
+                tail += (int64_t)cur.size();
+                gen_start.push_back(tail);
+                cur.swap(next);
+                next.clear();
+            }
         }
         if (tail != n) {
             delete g;
@@ -153,6 +194,15 @@ int build(int H, int W, CodeAt codes_at, IsLand is_land, bool all_land, lf_graph
             }
         }
         g->ups_ptr[n] = (int32_t)(NL >= 1 ? g->level_start[NL - 1] : 0);
+        if (virtual_down) {
+            g->linked.assign(n, 0);
+            for (int64_t p = 0; p < n; ++p)
+                if (virtual_down[g->perm[p]] >= 0) {
+                    g->linked[p] = 1;
+                    g->has_links = true;
+                }
+            if (!g->has_links) g->linked.clear();
+        }
     } catch (const std::bad_alloc &) {
         delete g;
         return lf_set_error(LF_E_INVALID, "out of host memory while building the graph");
@@ -165,7 +215,8 @@ int build(int H, int W, CodeAt codes_at, IsLand is_land, bool all_land, lf_graph
 
 extern "C" {
 
-int lf_graph_create(const double *ldd_codes, const uint8_t *land_mask, int H, int W, lf_graph **out)
+int lf_graph_create_ex(const double *ldd_codes, const uint8_t *land_mask, int H, int W, const int64_t *virtual_down,
+                       lf_graph **out)
 {
     if (!ldd_codes || !land_mask || !out) return lf_set_error(LF_E_INVALID, "null argument");
     auto code = [&](int64_t, int64_t p) {
@@ -173,7 +224,12 @@ int lf_graph_create(const double *ldd_codes, const uint8_t *land_mask, int H, in
         return (c >= 0.0 && c <= 9.0 && c == std::floor(c)) ? (int)c : 0;
     };
     auto land = [&](int64_t i) { return land_mask[i] != 0; };
-    return build(H, W, code, land, false, out);
+    return build(H, W, code, land, false, out, virtual_down);
+}
+
+int lf_graph_create(const double *ldd_codes, const uint8_t *land_mask, int H, int W, lf_graph **out)
+{
+    return lf_graph_create_ex(ldd_codes, land_mask, H, W, nullptr, out);
 }
 
 int lf_graph_create_raster(const uint8_t *ldd_raster, const uint8_t *land_mask, int H, int W, lf_graph **out)
@@ -229,6 +285,17 @@ int lf_graph_get_layout(const lf_graph *g, int32_t *perm, int32_t *ups_ptr, int6
     if (perm) std::memcpy(perm, g->perm.data(), sizeof(int32_t) * g->perm.size());
     if (ups_ptr) std::memcpy(ups_ptr, g->ups_ptr.data(), sizeof(int32_t) * g->ups_ptr.size());
     if (level_start) std::memcpy(level_start, g->level_start.data(), sizeof(int64_t) * g->level_start.size());
+    return LF_OK;
+}
+
+/* linked[N] by POSITION: 1 = zero-length structure link (all 0 for a graph without links) */
+int lf_graph_get_links(const lf_graph *g, uint8_t *linked)
+{
+    if (!g || !linked) return lf_set_error(LF_E_INVALID, "null argument");
+    if (g->has_links)
+        std::memcpy(linked, g->linked.data(), (size_t)g->N);
+    else
+        std::memset(linked, 0, (size_t)g->N);
     return LF_OK;
 }
 

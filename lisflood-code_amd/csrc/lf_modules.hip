@@ -7,6 +7,7 @@
 
 #include "lf_common.h"
 #include "lf_math.h"
+#include "lf_structures.h"
 
 namespace {
 constexpr int kBlock = 256;
@@ -242,60 +243,7 @@ __global__ void __launch_bounds__(kBlock) k_pixel_aggregates(lf_pixel_args A)
 // lakes.dynamic_inloop (lakes.py:215-258) and reservoir.dynamic_inloop (reservoir.py:190-296): one lane per site
 __global__ void __launch_bounds__(kBlock) k_inloop_sites(lf_inloop_args A)
 {
-    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
-    if (i < A.n_lakes) {
-        double inflow = 0.0; // np.bincount(downstruct, weights=ChanQ)[LakeIndex]: ascending source id
-        for (int e = A.lake_ups_ptr[i]; e < A.lake_ups_ptr[i + 1]; ++e) inflow += A.ChanQ[A.lake_ups_idx[e]];
-        A.LakeInflowCC[i] = inflow;
-        const double lake_in = (inflow + A.LakeInflowOldCC[i]) * 0.5;
-        A.LakeInflowOldCC[i] = inflow;
-        const double si = A.LakeStorageM3CC[i] / A.DtRouting - 0.5 * A.LakeOutflowCC[i] + lake_in;
-        const double y = -A.LakeFactor[i] + sqrt(A.LakeFactorSqr[i] + 2 * si);
-        const double out = y * y; // np.square
-        A.LakeOutflowCC[i] = out;
-        const double out_m3 = out * A.DtRouting;
-        double st = (si - out * 0.5) * A.DtRouting;
-        if (st < 0 || st != st) st = 0; // lakes.py:250-255
-        A.LakeStorageM3CC[i] = st;
-        A.LakeStorageM3BalanceCC[i] += lake_in * A.DtRouting - out_m3;
-        A.LakeLevelCC[i] = st / A.LakeAreaCC[i];
-        A.QLakeOutM3Dt[A.lake_cell[i]] = out_m3;
-    }
-    const long long r = i - A.n_lakes;
-    if (r >= 0 && r < A.n_res) {
-        const double inv_day = 1 / 86400.0; // 1 / float(86400)
-        double inflow = 0.0;
-        for (int e = A.res_ups_ptr[r]; e < A.res_ups_ptr[r + 1]; ++e) inflow += A.ChanQ[A.res_ups_idx[e]];
-        A.ReservoirInflowCC[r] = inflow;
-        const double tot = A.TotalReservoirStorageM3CC[r];
-        double st = A.ReservoirStorageM3CC[r] + inflow * A.DtRouting;
-        const double fill = st / tot;
-        const double qmin = A.MinReservoirOutflowCC[r], qnorm = A.NormalReservoirOutflowCC[r],
-                     qnd = A.NonDamagingReservoirOutflowCC[r];
-        const double lc2 = 2 * A.ConservativeStorageLimitCC[r], ln = A.NormalStorageLimitCC[r],
-                     lf = A.FloodStorageLimitCC[r], lnf = A.Normal_FloodStorageLimitCC[r];
-        const double o1 = npmin(qmin, st * inv_day);
-        const double o2 = qmin + A.DeltaO[r] * (fill - lc2) / A.DeltaLN[r];
-        const double o3b = qnorm + ((fill - lnf) / A.DeltaNFL[r]) * (qnd - qnorm);
-        const double tmp = npmin(qnd, npmax(inflow * 1.2, qnorm));
-        const double o4 = npmax((fill - lf - 0.01) * tot * inv_day, tmp);
-        double o = o1;
-        if (fill > lc2) o = o2;
-        if (fill > ln) o = qnorm;
-        if (fill > lnf) o = o3b;
-        if (fill > lf) o = o4;
-        const double tmp2 = npmin(o, npmax(inflow, qnorm));
-        if ((o > 1.2 * inflow) && (o > qnorm) && (fill < lf)) o = tmp2;
-        double out_m3 = o * A.DtRouting;
-        out_m3 = npmin(out_m3, st);
-        out_m3 = npmax(out_m3, st - tot);
-        st -= out_m3;
-        double f2 = st / tot;
-        if (f2 != f2 || f2 < 0) f2 = 0;
-        A.ReservoirStorageM3CC[r] = st;
-        A.ReservoirFillCC[r] = f2;
-        A.QResOutM3Dt[A.res_cell[r]] = out_m3;
-    }
+    lf_site_update(A, (long long)blockIdx.x * kBlock + threadIdx.x);
 }
 
 // inflow.py:142-144, transmission.py:76-87 and the sideflow assembly routing.py:462-478

@@ -22,7 +22,9 @@
 #include <cmath>
 
 #include <cstdlib>
+#include <cstring>
 
+#include "lf_structures.h"
 #include "lf_sweep.h"
 
 namespace {
@@ -35,14 +37,16 @@ __global__ void __launch_bounds__(kBlock) k_gather(int n, const int *__restrict_
 }
 
 // out[pixel(p)] = sum of w over the upstream cells of p, ascending pixel id (np.bincount order)
+// (`linked`: zero-length structure links of lf_graph_create_ex sit behind the last range of a level -- skipped)
 __global__ void __launch_bounds__(kBlock) k_upstream_sum(int n, const int *__restrict__ perm,
                                                          const int *__restrict__ ups_ptr, const double *__restrict__ w_pix,
-                                                         double *__restrict__ out_pix)
+                                                         double *__restrict__ out_pix, const uint8_t *__restrict__ linked)
 {
     const int p = blockIdx.x * kBlock + threadIdx.x;
     if (p >= n) return;
     double s = 0.0;
-    for (int e = ups_ptr[p]; e < ups_ptr[p + 1]; ++e) s += w_pix[perm[e]];
+    for (int e = ups_ptr[p]; e < ups_ptr[p + 1]; ++e)
+        if (!linked || !linked[e]) s += w_pix[perm[e]];
     out_pix[perm[p]] = s;
 }
 
@@ -114,6 +118,8 @@ struct lf_router {
     lf_dbuf<double> a1, a2, dx, constant, qord, io_q, io_lat, tmp_ord, fused_qr1, fused_qr2;
     lf_dbuf<int32_t> win_ptr, win_cells; // component lists of the window segments
     lf_dbuf<unsigned long long> counter;
+    lf_dbuf<uint8_t> linked; // zero-length structure links (lf_graph_create_ex); null without them
+    lf_dbuf<int> site_level; // levels of the lake and reservoir cells of the last fused-with-structures call
     std::vector<int64_t> h_level_start;
     std::vector<segment> schedule;
     int64_t last_stats[4] = {0, 0, 0, 0};
@@ -305,6 +311,9 @@ int route_device(lf_router *r, double *q_dev, const double *lat_dev, int section
         return lf_set_error(LF_E_SECTION, "The section parameter must be either 'main_channel' or 'floodplain'!");
     if (section == LF_SECTION_FLOODPLAINS && !r->has_floodplains)
         return lf_set_error(LF_E_SECTION, "floodplains routing requested but alpha_floodplains was not given");
+    if (r->linked.p)
+        return lf_set_error(LF_E_INVALID, "a router on a graph with structure links (lf_graph_create_ex) runs only the "
+                            "fused sub-step path (lf_routing_substeps_fused*)");
     LF_HIP(hipSetDevice(r->device));
     if (r->use_graph && !r->profile && r->schedule.size() >= 8) {
         char key[96];
@@ -371,6 +380,7 @@ int lf_router_create(const lf_graph *g, const double *alpha, double beta, const 
     }
     if (rc == LF_OK) rc = r->perm.upload(g->perm.data(), n);
     if (rc == LF_OK) rc = r->ups_ptr.upload(g->ups_ptr.data(), n + 1);
+    if (rc == LF_OK && g->has_links) rc = r->linked.upload(g->linked.data(), n);
     if (rc == LF_OK) {
         std::vector<long long> ls(g->level_start.begin(), g->level_start.end());
         rc = r->level_start.upload(ls.data(), ls.size());
@@ -583,7 +593,7 @@ int lf_upstream_sum_device(lf_router *r, const double *w_dev, double *out_dev)
     const int n = (int)r->N;
     if (n > 0)
         hipLaunchKernelGGL(k_upstream_sum, dim3(blocks_for(n)), dim3(kBlock), 0, r->ctx->stream, n, r->perm.p,
-                           r->ups_ptr.p, w_dev, out_dev);
+                           r->ups_ptr.p, w_dev, out_dev, (const uint8_t *)r->linked.p);
     LF_HIP(hipGetLastError());
     return LF_OK;
 }
@@ -606,6 +616,7 @@ int lf_upstream_sum_host(lf_router *r, const double *w_host, double *out_host)
 int lf_accuflux_host(lf_router *r, const double *x_host, double *out_host)
 {
     if (!r || !x_host || !out_host) return lf_set_error(LF_E_INVALID, "null argument");
+    if (r->linked.p) return lf_set_error(LF_E_INVALID, "accuflux is not defined on a graph with structure links");
     LF_HIP(hipSetDevice(r->device));
     const int n = (int)r->N;
     const size_t bytes = sizeof(double) * (size_t)r->N;
@@ -728,6 +739,8 @@ extern "C" int lf_routing_substep(lf_router *r, const lf_substep_args *a)
     if (!r || !a) return lf_set_error(LF_E_INVALID, "null argument");
     if (a->split && !r->has_floodplains)
         return lf_set_error(LF_E_SECTION, "split routing requested but the router has no floodplain alpha");
+    if (r->linked.p)
+        return lf_set_error(LF_E_INVALID, "a router on a graph with structure links runs only lf_routing_substeps_fused*");
     LF_HIP(hipSetDevice(r->device));
     hipStream_t s = r->ctx->stream;
     const int n = (int)r->N;
@@ -768,7 +781,22 @@ struct fused_args {
     double dx_scalar, beta, inv_beta, b_minus_1;
     int kmax, nlevels, nsteps, t;
     int solve35; // router runs the beta = 3/5 quintic solve (false: general path, e.g. LF_GENERAL_POW=1)
+    const uint8_t *__restrict__ linked; // zero-length structure links: their router output is stored as 0
+    lf_inloop_args I;                   // STRUCT: lakes / reservoirs / inflow / transmission loss / sideflow assembly
+    const int *__restrict__ site_level; // STRUCT: level of every lake, then every reservoir cell
 };
+
+// Lakes and reservoirs inside the wavefront: site v handles sub-step s = t - level(v) right BEFORE launch t of the
+// cell kernel.  The cells that drain into v in the uncut LDD are zero-length links of the graph, i.e. on v's level:
+// their ChanQ of sub-step s-1 was stored by launch t-1 and is overwritten only by launch t.
+__global__ void __launch_bounds__(kBlock) k_sites_wave(fused_args F)
+{
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= F.I.n_lakes + F.I.n_res) return;
+    const int s = F.t - F.site_level[i];
+    if (s < 0 || s >= F.nsteps) return;
+    lf_site_update(F.I, i);
+}
 
 __device__ __forceinline__ double solve_any(double c, double ap, bool b35, const fused_args &F)
 {
@@ -787,7 +815,7 @@ __device__ __forceinline__ double upstream_sum8(const double *q, int u0, int u1,
     return ups;
 }
 
-template <bool SPLIT>
+template <bool SPLIT, bool STRUCT>
 __global__ void __launch_bounds__(kBlock) k_fused_substeps(fused_args F)
 {
     const int s = blockIdx.y;          // sub-step
@@ -807,7 +835,31 @@ __global__ void __launch_bounds__(kBlock) k_fused_substeps(fused_args F)
     const double inv_len = A.InvChanLength[p], len = A.ChanLength[p];
     const int u0 = F.ups_ptr[p], u1 = F.ups_ptr[p + 1];
     const bool is_chan = A.IsChannelKinematic[p] != 0;
-    const double side_m3 = A.SideflowChanM3[(long long)s * F.side_stride + p];
+    const bool cut = F.linked && F.linked[p];
+    double side_m3, qin = 0, qin_added = 0, loss = 0, trans_cum = 0;
+    if (!STRUCT)
+        side_m3 = A.SideflowChanM3[(long long)s * F.side_stride + p];
+    else { // inflow.py:142-144, transmission.py:76-87, sideflow assembly routing.py:462-478 -- as k_inloop_dense
+        const lf_inloop_args &I = F.I;
+        side_m3 = I.ToChanM3RunoffDt[p];
+        if (I.EvaAddM3Dt) side_m3 -= I.EvaAddM3Dt[p];
+        if (I.WUseAddM3Dt) side_m3 -= I.WUseAddM3Dt[p];
+        if (I.QInM3Old) {
+            qin = (I.QInM3Old[p] + (s + 1) * I.QDelta[p]) * I.InvNoRoutSteps;
+            qin_added = (s < 1 ? 0.0 : I.QinADDEDM3[p]) + qin;
+            side_m3 += qin;
+        }
+        if (I.UpTrans) {
+            const double qc = A.ChanQ[p];
+            const double tout = I.UpTrans[p] ? pow(pow(qc, I.TransPower2) - I.TransSub, I.TransPower1) : qc;
+            loss = (qc - tout) * I.DtRouting;
+            trans_cum = I.TransCum[p] + loss;
+            side_m3 -= loss;
+        }
+        if (I.QLakeOutM3Dt) side_m3 += I.QLakeOutM3Dt[p];
+        if (I.QResOutM3Dt) side_m3 += I.QResOutM3Dt[p];
+        if (I.ChannelToPolderM3Dt) side_m3 -= I.ChannelToPolderM3Dt[p];
+    }
     const double ap1 = F.a1[p], qold = A.ChanQKin[p], alpha1 = A.ChannelAlpha[p], inv_alpha1 = A.InvChannelAlpha[p];
     const double sum_old = A.sumDisDay[p];
     const double ups1 = upstream_sum8(F.qr1 + par, u0, u1, F.kmax);
@@ -862,14 +914,26 @@ __global__ void __launch_bounds__(kBlock) k_fused_substeps(fused_args F)
         if (chanq < 0.0) chanq = 0.0;
     }
     // ---- stores ----
-    F.qr1[par + p] = qr;
+    if (STRUCT) {
+        const lf_inloop_args &I = F.I;
+        if (I.QInM3Old) {
+            I.QInDt[p] = qin;
+            I.QinADDEDM3[p] = qin_added;
+        }
+        if (I.UpTrans) {
+            I.TransLossM3Dt[p] = loss;
+            I.TransCum[p] = trans_cum;
+        }
+        I.SideflowChanM3[p] = side_m3;
+    }
+    F.qr1[par + p] = cut ? 0.0 : qr;
     A.ChanM3Kin[p] = v;
     A.ChanQKin[p] = q;
     A.ChanQ[p] = chanq;
     A.sumDisDay[p] = sum_old + chanq;
     if (SPLIT) {
         A.Sideflow1Chan[p] = s1;
-        F.qr2[par + p] = q2r;
+        F.qr2[par + p] = cut ? 0.0 : q2r;
         A.Chan2M3Kin[p] = v2;
         A.CrossSection2Area[p] = (v2 - start) * inv_len;
         A.Chan2QKin[p] = q2;
@@ -890,7 +954,9 @@ __global__ void __launch_bounds__(kBlock) k_fused_substeps(fused_args F)
 
 } // namespace
 
-extern "C" int lf_routing_substeps_fused(lf_router *r, const lf_substep_args *a, int nsteps, int64_t sideflow_stride)
+namespace {
+
+int fused_impl(lf_router *r, const lf_substep_args *a, int nsteps, int64_t sideflow_stride, const lf_inloop_args *in)
 {
     if (!r || !a || nsteps < 1) return lf_set_error(LF_E_INVALID, "bad argument");
     if (!a->engine_order) return lf_set_error(LF_E_INVALID, "the fused sub-step wavefront needs engine-order vectors");
@@ -921,8 +987,63 @@ extern "C" int lf_routing_substeps_fused(lf_router *r, const lf_substep_args *a,
     F.nlevels = (int)r->NL;
     F.nsteps = nsteps;
     F.solve35 = r->fused ? 1 : 0;
+    F.linked = r->linked.p;
+    F.site_level = nullptr;
+    std::memset(&F.I, 0, sizeof(F.I));
     hipStream_t s = r->ctx->stream;
     const int NL = (int)r->NL;
+    // ---- structures: levels of the site cells; every cell feeding a site must sit on the site's own level ----------
+    std::vector<int> lv_sorted;
+    int64_t nsites = 0;
+    if (in) {
+        F.I = *in;
+        lf_inloop_args &I = F.I;
+        if (I.n_lakes <= 0) {
+            I.n_lakes = 0;
+            I.QLakeOutM3Dt = nullptr;
+        }
+        if (I.n_res <= 0) {
+            I.n_res = 0;
+            I.QResOutM3Dt = nullptr;
+        }
+        if (!I.ToChanM3RunoffDt || !I.SideflowChanM3 || I.N != n)
+            return lf_set_error(LF_E_INVALID, "lf_inloop_args: ToChanM3RunoffDt, SideflowChanM3 and N = num_pixels are needed");
+        I.ChanQ = a->ChanQ;
+        nsites = I.n_lakes + I.n_res;
+        if (nsites > 0) {
+            auto level_of = [&](int pos) {
+                return (int)(std::upper_bound(r->h_level_start.begin(), r->h_level_start.end(), (int64_t)pos) -
+                             r->h_level_start.begin()) - 1;
+            };
+            std::vector<int> lv(nsites);
+            auto check_sites = [&](int64_t cnt, const int32_t *cell_dev, const int32_t *ptr_dev, const int32_t *idx_dev,
+                                   int64_t off, const char *what) -> int {
+                if (cnt == 0) return LF_OK;
+                if (!cell_dev || !ptr_dev || !idx_dev) return lf_set_error(LF_E_INVALID, "%s site lists missing", what);
+                std::vector<int32_t> cell(cnt), ptr(cnt + 1);
+                LF_HIP(hipMemcpy(cell.data(), cell_dev, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost));
+                LF_HIP(hipMemcpy(ptr.data(), ptr_dev, sizeof(int32_t) * (cnt + 1), hipMemcpyDeviceToHost));
+                std::vector<int32_t> idx(std::max<int32_t>(ptr[cnt], 1));
+                if (ptr[cnt] > 0)
+                    LF_HIP(hipMemcpy(idx.data(), idx_dev, sizeof(int32_t) * ptr[cnt], hipMemcpyDeviceToHost));
+                for (int64_t i = 0; i < cnt; ++i) {
+                    if (cell[i] < 0 || cell[i] >= n) return lf_set_error(LF_E_INVALID, "%s cell out of range", what);
+                    lv[off + i] = level_of(cell[i]);
+                    for (int32_t e = ptr[i]; e < ptr[i + 1]; ++e)
+                        if (idx[e] < 0 || idx[e] >= n || level_of(idx[e]) != lv[off + i])
+                            return lf_set_error(LF_E_INVALID, "%s %lld: a cell draining into it is not on its level -- build "
+                                                "the router's graph with lf_graph_create_ex(virtual_down)", what, (long long)i);
+                }
+                return LF_OK;
+            };
+            LF_TRY(check_sites(I.n_lakes, I.lake_cell, I.lake_ups_ptr, I.lake_ups_idx, 0, "lake"));
+            LF_TRY(check_sites(I.n_res, I.res_cell, I.res_ups_ptr, I.res_ups_idx, I.n_lakes, "reservoir"));
+            LF_TRY(r->site_level.upload(lv.data(), (size_t)nsites));
+            F.site_level = r->site_level.p;
+            lv_sorted = lv;
+            std::sort(lv_sorted.begin(), lv_sorted.end());
+        }
+    }
     int64_t launches = 0;
     for (int t = 0; t < NL + nsteps - 1; ++t) {
         // widest level inside the window [t - nsteps + 1, t]
@@ -930,11 +1051,22 @@ extern "C" int lf_routing_substeps_fused(lf_router *r, const lf_substep_args *a,
         int64_t widest = 0;
         for (int k = k_lo; k <= k_hi; ++k) widest = std::max(widest, r->h_level_start[k + 1] - r->h_level_start[k]);
         F.t = t;
+        if (nsites > 0) { // any site with a level in [k_lo, k_hi]?
+            auto it = std::lower_bound(lv_sorted.begin(), lv_sorted.end(), k_lo);
+            if (it != lv_sorted.end() && *it <= k_hi) {
+                hipLaunchKernelGGL(k_sites_wave, dim3(blocks_for(nsites)), dim3(kBlock), 0, s, F);
+                ++launches;
+            }
+        }
         const dim3 grid(blocks_for(widest), nsteps), block(kBlock);
-        if (a->split)
-            hipLaunchKernelGGL(k_fused_substeps<true>, grid, block, 0, s, F);
+        if (in && a->split)
+            hipLaunchKernelGGL((k_fused_substeps<true, true>), grid, block, 0, s, F);
+        else if (in)
+            hipLaunchKernelGGL((k_fused_substeps<false, true>), grid, block, 0, s, F);
+        else if (a->split)
+            hipLaunchKernelGGL((k_fused_substeps<true, false>), grid, block, 0, s, F);
         else
-            hipLaunchKernelGGL(k_fused_substeps<false>, grid, block, 0, s, F);
+            hipLaunchKernelGGL((k_fused_substeps<false, false>), grid, block, 0, s, F);
         ++launches;
     }
     LF_HIP(hipGetLastError());
@@ -943,6 +1075,20 @@ extern "C" int lf_routing_substeps_fused(lf_router *r, const lf_substep_args *a,
     r->last_stats[2] = 0;
     r->last_stats[3] = r->NL;
     return LF_OK;
+}
+
+} // namespace
+
+extern "C" int lf_routing_substeps_fused(lf_router *r, const lf_substep_args *a, int nsteps, int64_t sideflow_stride)
+{
+    return fused_impl(r, a, nsteps, sideflow_stride, nullptr);
+}
+
+extern "C" int lf_routing_substeps_fused_structures(lf_router *r, const lf_substep_args *a, const lf_inloop_args *in,
+                                                    int nsteps)
+{
+    if (!in) return lf_set_error(LF_E_INVALID, "null argument");
+    return fused_impl(r, a, nsteps, 0, in);
 }
 
 // ================================================================================================

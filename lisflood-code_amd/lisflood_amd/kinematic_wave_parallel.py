@@ -25,8 +25,12 @@ except Exception:  # stand-alone
 class Graph:
     """LDD -> adjacency -> routing orders (lf_graph); host memory only."""
 
-    def __init__(self, compressed_encoded_ldd=None, land_mask=None, ldd_raster=None):
+    def __init__(self, compressed_encoded_ldd=None, land_mask=None, ldd_raster=None, virtual_down=None):
+        """virtual_down ([N] int, -1 = none; compressed form only): for the pits that structures.py:44-61 cut just
+        upstream of a lake / reservoir, the pixel they drain into in the uncut LDD -- they are put on that pixel's
+        level (lf_graph_create_ex), which the fused sub-step wavefront with structures needs."""
         self._h = C.c_void_p()
+        self.has_links = virtual_down is not None
         if ldd_raster is not None:
             r = np.ascontiguousarray(ldd_raster, dtype=np.uint8)
             H, W = r.shape
@@ -40,7 +44,10 @@ class Graph:
             if codes.size != int(m.sum()):
                 raise ValueError("compressed LDD has %d values but the land mask has %d land cells"
                                  % (codes.size, int(m.sum())))
-            check(lib().lf_graph_create(ptr(codes), ptr(m), C.c_int(H), C.c_int(W), C.byref(self._h)))
+            vd = None if virtual_down is None else np.ascontiguousarray(virtual_down, dtype=np.int64)
+            if vd is not None and vd.size != codes.size:
+                raise ValueError("virtual_down needs one entry per land pixel")
+            check(lib().lf_graph_create_ex(ptr(codes), ptr(m), C.c_int(H), C.c_int(W), ptr(vd), C.byref(self._h)))
         self.shape = (H, W)
         self.num_pixels = int(lib().lf_graph_num_pixels(self._h))
         self.num_levels = int(lib().lf_graph_num_levels(self._h))
@@ -59,6 +66,12 @@ class Graph:
         ss = np.empty((self.num_levels, 2), np.int64)
         check(lib().lf_graph_get_orders(self._h, ptr(po), ptr(ss)))
         return po, ss
+
+    def links(self):
+        """[N] bool by engine position: zero-length structure links (Graph(virtual_down=...))."""
+        out = np.zeros(self.num_pixels, np.uint8)
+        check(lib().lf_graph_get_links(self._h, ptr(out)))
+        return out.astype(bool)
 
     def layout(self):
         perm = np.empty(self.num_pixels, np.int32)

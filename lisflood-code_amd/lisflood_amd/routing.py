@@ -70,7 +70,12 @@ class routing(HydroModule):
     module_name = 'Routing'
 
     def __init__(self, routing_variable, split_routing=False, init_lisflood=False, options=None, device=0,
-                 inloop_modules=()):
+                 inloop_modules=(), engine_order=False):
+        """engine_order=True keeps the module's device vectors in the router's sweep order (permuted on upload and
+        download, site lists of the structures mapped to positions) and runs each sub-step as ONE level sweep that
+        updates both routers of a cell (lf_routing_substeps_fused with one sub-step): half the launches of the
+        pixel-order path under split routing and contiguous upstream reads; results are bit-identical."""
+        self.engine_order = bool(engine_order)
         self.var = routing_variable
         self.options = dict(options or {})
         self.options.setdefault("SplitRouting", split_routing)
@@ -177,13 +182,54 @@ class routing(HydroModule):
         if hasattr(v, "AtLastPointC"):
             v.DischargeM3Out = getattr(v, "DischargeM3Out", 0.0) + np.where(v.AtLastPointC, v.ChanQ * v.DtSec, 0)
 
+    def structure_links(self, compressed_ldd_kinematic):
+        """[N] int64, -1 = none: for every pit of the (cut) kinematic LDD that drains into a lake or reservoir cell
+        in the uncut LDD (`downstruct`, routing.py:159-164), that cell."""
+        v, o = self.var, self.options
+        N = np.asarray(compressed_ldd_kinematic).size
+        site = np.zeros(N + 1, bool)
+        if o.get("simulateLakes") and not o.get("InitLisflood"):
+            site[np.asarray(v.LakeIndex).astype(np.int64)] = True
+        if o.get("simulateReservoirs") and not o.get("InitLisflood"):
+            site[np.asarray(v.ReservoirIndex).astype(np.int64)] = True
+        ds = np.minimum(np.asarray(v.downstruct).astype(np.int64), N)
+        feeds = site[ds] & (ds < N)
+        return np.where(feeds, ds, -1)
+
     def attach_router(self, compressed_ldd_kinematic, land_mask, flagnancheck=False):
-        """The router construction of initialSecond (routing.py:401-403)."""
-        v = self.var
+        """The router construction of initialSecond (routing.py:401-403).  In engine order with lakes or reservoirs
+        switched on, the graph also carries their uncut links (Graph(virtual_down=...)), so that dynamic_fused()
+        can run the structures inside the wavefront."""
+        v, o = self.var, self.options
+        graph = None
+        if self.engine_order and not o.get("InitLisflood") and (o.get("simulateLakes") or o.get("simulateReservoirs")) \
+                and hasattr(v, "downstruct"):
+            from .kinematic_wave_parallel import Graph
+            graph = Graph(compressed_ldd_kinematic, land_mask, virtual_down=self.structure_links(compressed_ldd_kinematic))
         self.river_router = kinematicWave(compressed_ldd_kinematic, land_mask, v.ChannelAlpha, v.Beta, v.ChanLength,
                                           v.DtRouting, alpha_floodplains=getattr(v, "ChannelAlpha2", None),
-                                          flagnancheck=flagnancheck, device=self.device)
+                                          flagnancheck=flagnancheck, device=self.device, graph=graph)
+        if self.engine_order:
+            self._perm = self.river_router.graph.layout()[0].astype(np.int64)     # position -> pixel
+            self._pos = np.empty_like(self._perm)
+            self._pos[self._perm] = np.arange(self._perm.size)                    # pixel -> position
         return self.river_router
+
+    def _up(self, x):
+        """host [N] vector in pixel order -> the order the device vectors are kept in"""
+        return x[self._perm] if self.engine_order else x
+
+    def _down(self, a, out=None):
+        """device-order [N] vector -> pixel order (into `out` when given)"""
+        if not self.engine_order:
+            if out is None:
+                return a
+            out[...] = a
+            return out
+        if out is None:
+            out = np.empty_like(a)
+        out[self._perm] = a
+        return out
 
     def initialSecond(self, compressed_ldd_kinematic=None, land_mask=None, flagnancheck=False):
         """Split-routing start values (routing.py:355-397) + router (401-403).  The one-hop upstream sum of
@@ -225,7 +271,8 @@ class routing(HydroModule):
             a = getattr(v, k, None)
             if a is None:
                 a = np.ones(N, bool) if k == "IsChannelKinematic" else zeros
-            a = u8(np.broadcast_to(a, (N,))) if k == "IsChannelKinematic" else f64(np.broadcast_to(a, (N,)))
+            a = self._up(np.broadcast_to(a, (N,)))
+            a = u8(a) if k == "IsChannelKinematic" else f64(a)
             self._dev[k] = DeviceArray.from_host(a, self.device)
         for k in _STATE + _OUT + ["SideflowChanM3", "scratch0", "scratch1"]:
             self._dev[k] = DeviceArray(N, np.float64, self.device).zero()
@@ -233,6 +280,7 @@ class routing(HydroModule):
         for k, d in self._dev.items():
             setattr(a, k, d.ptr.value)
         a.Beta, a.InvBeta, a.InvDtRouting, a.DtSec = float(v.Beta), float(v.InvBeta), float(v.InvDtRouting), float(v.DtSec)
+        a.engine_order = 1 if self.engine_order else 0
 
     def _upload_state(self):
         v = self.var
@@ -242,7 +290,7 @@ class routing(HydroModule):
             if a is None:
                 a = np.zeros(N)
                 setattr(v, k, a)
-            self._dev[k].upload(f64(np.broadcast_to(a, (N,))))
+            self._dev[k].upload(f64(self._up(np.broadcast_to(a, (N,)))))
 
     def _download_state(self):
         v = self.var
@@ -250,8 +298,15 @@ class routing(HydroModule):
         names = _STATE + _OUT if split else ["ChanQKin", "ChanM3Kin", "ChanQ", "sumDisDay"] + _OUT
         for k in names:
             cur = getattr(v, k, None)
-            if isinstance(cur, np.ndarray) and cur.dtype == np.float64 and cur.flags.c_contiguous and \
-                    cur.size == self.river_router.num_pixels and cur.flags.writeable:
+            inplace = isinstance(cur, np.ndarray) and cur.dtype == np.float64 and cur.flags.c_contiguous and \
+                cur.size == self.river_router.num_pixels and cur.flags.writeable
+            if self.engine_order:
+                a = self._dev[k].download()
+                if inplace:
+                    self._down(a, cur)
+                else:
+                    setattr(v, k, self._down(a))
+            elif inplace:
                 self._dev[k].download(cur)          # in place, like the numba kernels
             else:
                 setattr(v, k, self._dev[k].download())
@@ -313,8 +368,15 @@ class routing(HydroModule):
                 u = order[starts[c]:starts[c + 1]]
                 idx.append(u)
                 ptr[i + 1] = ptr[i] + u.size
-            idx = np.concatenate(idx).astype(np.int32) if idx else np.zeros(0, np.int32)
+            idx = np.concatenate(idx).astype(np.int64) if idx else np.zeros(0, np.int64)
+            if self.engine_order:                      # same summation order (ascending pixel id), device positions
+                idx = self._pos[idx]
+            idx = idx.astype(np.int32)
             return ptr, (idx if idx.size else np.zeros(1, np.int32))
+
+        def cell_ids(cells):
+            cells = np.asarray(cells).astype(np.int64)
+            return (self._pos[cells] if self.engine_order else cells).astype(np.int32)
 
         def put(name, arr):
             st["dev"][name] = DeviceArray.from_host(np.ascontiguousarray(arr), self.device)
@@ -324,7 +386,7 @@ class routing(HydroModule):
             cells = np.asarray(v.LakeIndex).astype(np.int32)
             st["lakes"] = a.n_lakes = cells.size
             ptr, idx = site_csr(cells)
-            put("lake_cell", cells); put("lake_ups_ptr", ptr); put("lake_ups_idx", idx)
+            put("lake_cell", cell_ids(cells)); put("lake_ups_ptr", ptr); put("lake_ups_idx", idx)
             for k in _LAKE_PARAM:
                 put(k, f64(np.broadcast_to(getattr(v, k), (cells.size,))))
             for k in _LAKE_STATE:
@@ -334,18 +396,18 @@ class routing(HydroModule):
             cells = np.asarray(v.ReservoirIndex).astype(np.int32)
             st["res"] = a.n_res = cells.size
             ptr, idx = site_csr(cells)
-            put("res_cell", cells); put("res_ups_ptr", ptr); put("res_ups_idx", idx)
+            put("res_cell", cell_ids(cells)); put("res_ups_ptr", ptr); put("res_ups_idx", idx)
             for k in _RES_PARAM:
                 put(k, f64(np.broadcast_to(getattr(v, k), (cells.size,))))
             for k in _RES_STATE:
                 put(k, f64(np.broadcast_to(getattr(v, k, 0.0), (cells.size,))))
             put("QResOutM3Dt", np.zeros(N))
         if o.get("inflow"):
-            put("QInM3Old", f64(v.QInM3Old)); put("QDelta", f64(v.QDelta))
+            put("QInM3Old", f64(self._up(np.asarray(v.QInM3Old)))); put("QDelta", f64(self._up(np.asarray(v.QDelta))))
             put("QInDt", np.zeros(N)); put("QinADDEDM3", np.zeros(N))
         if o.get("TransLoss"):
-            put("UpTrans", u8(v.UpTrans)); put("TransLossM3Dt", np.zeros(N))
-            put("TransCum", f64(np.broadcast_to(getattr(v, "TransCum", 0.0), (N,))))
+            put("UpTrans", u8(self._up(np.asarray(v.UpTrans)))); put("TransLossM3Dt", np.zeros(N))
+            put("TransCum", f64(self._up(np.broadcast_to(getattr(v, "TransCum", 0.0), (N,)))))
             a.TransPower1, a.TransPower2, a.TransSub = float(v.TransPower1), float(v.TransPower2), float(v.TransSub)
         for k in ("ToChanM3RunoffDt", "EvaAddM3Dt", "WUseAddM3Dt", "ChannelToPolderM3Dt"):
             st["dev"][k] = DeviceArray(N, np.float64, self.device).zero()
@@ -354,7 +416,7 @@ class routing(HydroModule):
         a.SideflowChanM3 = self._dev["SideflowChanM3"].ptr.value
         a.DtRouting, a.InvNoRoutSteps, a.N = float(v.DtRouting), float(v.InvNoRoutSteps), N
 
-    def _structures_substep(self, s):
+    def _structures_substep(self, s, launch=True):
         v, o, st, a = self.var, self.options, self._st, self._inloop
         N = self.river_router.num_pixels
         if s == 0:      # lakes.py:211-212, reservoir.py:195-196: site state from the dense state maps
@@ -362,15 +424,16 @@ class routing(HydroModule):
                 st["dev"]["LakeStorageM3CC"].upload(f64(np.asarray(v.LakeStorageM3)[np.asarray(v.LakeIndex)]))
             if st["res"]:
                 st["dev"]["ReservoirStorageM3CC"].upload(f64(np.asarray(v.ReservoirStorageM3)[np.asarray(v.ReservoirIndex)]))
-        st["dev"]["ToChanM3RunoffDt"].upload(f64(np.broadcast_to(v.ToChanM3RunoffDt, (N,))))
+        st["dev"]["ToChanM3RunoffDt"].upload(f64(self._up(np.broadcast_to(v.ToChanM3RunoffDt, (N,)))))
         for k, opt in (("EvaAddM3Dt", "openwaterevapo"), ("WUseAddM3Dt", "wateruse"), ("ChannelToPolderM3Dt", "simulatePolders")):
             if o.get(opt):
                 if k == "WUseAddM3Dt":
                     v.WUseAddM3Dt = v.withdrawal_CH_actual_M3_routStep - v.returnflow_GwAbs2Channel_M3_routStep
-                st["dev"][k].upload(f64(np.broadcast_to(getattr(v, k), (N,))))
+                st["dev"][k].upload(f64(self._up(np.broadcast_to(getattr(v, k), (N,)))))
                 setattr(a, k, st["dev"][k].ptr.value)
         a.step = int(s)
-        check(lib().lf_inloop_structures(C.c_int(self.device), C.byref(a)))
+        if launch:
+            check(lib().lf_inloop_structures(C.c_int(self.device), C.byref(a)))
 
     def _structures_download(self, s):
         v, st = self.var, self._st
@@ -380,8 +443,10 @@ class routing(HydroModule):
         if st["res"]:
             names += _RES_STATE + ["QResOutM3Dt"]
         names += [k for k in ("QInDt", "QinADDEDM3", "TransLossM3Dt", "TransCum") if k in st["dev"]]
+        dense = ("QLakeOutM3Dt", "QResOutM3Dt", "QInDt", "QinADDEDM3", "TransLossM3Dt", "TransCum")
         for k in names:
-            setattr(v, k, st["dev"][k].download())
+            x = st["dev"][k].download()
+            setattr(v, k, self._down(x) if k in dense else x)
         if s == v.NoRoutSteps - 1:      # lakes.py:283-292, reservoir.py:311-315: expand to the dense state maps
             N = self.river_router.num_pixels
             if st["lakes"]:
@@ -403,8 +468,30 @@ class routing(HydroModule):
         if self.river_router is None:
             raise RuntimeError("routing.initialSecond()/attach_router() must be called first")
         if self.inloop_modules:
-            raise RuntimeError("dynamic_fused cannot run in-loop modules; use dynamic()")
+            raise RuntimeError("dynamic_fused cannot run host in-loop modules; use dynamic() or attach_structures()")
+        if getattr(self, "_inloop", None) is not None:
+            if not self.engine_order or sideflows is not None:
+                raise RuntimeError("structures inside the wavefront need routing(..., engine_order=True) and the "
+                                   "sideflow assembled from `var`")
+            return self._fused_with_structures()
         _fused(self, self.sideflow_m3() if sideflows is None else sideflows)
+
+    def _fused_with_structures(self):
+        """Lakes, reservoirs, inflow and transmission loss inside the wavefront
+        (lf_routing_substeps_fused_structures): the loop of Lisflood_dynamic.py:179-180 in one call."""
+        v = self.var
+        nsteps = int(v.NoRoutSteps)
+        self._ensure_device()
+        if not self._resident:
+            self._upload_state()
+        self._structures_substep(0, launch=False)      # site state + the dense terms of the sideflow, once
+        self._args.split = 1 if self._split() else 0
+        check(lib().lf_routing_substeps_fused_structures(self.river_router._h, C.byref(self._args),
+                                                         C.byref(self._inloop), C.c_int(nsteps)))
+        if not self._resident:
+            self._download_state()
+        self._structures_download(nsteps - 1)
+        v.SideflowChanM3 = self._down(self._dev["SideflowChanM3"].download())
 
     def dynamic(self, NoRoutingExecuted):
         """One routing sub-step (routing.py:435-706)."""
@@ -418,9 +505,12 @@ class routing(HydroModule):
         if getattr(self, "_inloop", None) is not None:
             self._structures_substep(NoRoutingExecuted)      # structures + sideflow assembly on the device
         else:
-            self._dev["SideflowChanM3"].upload(f64(self.sideflow_m3()))
+            self._dev["SideflowChanM3"].upload(f64(self._up(self.sideflow_m3())))
         self._args.split = 1 if self._split() else 0
-        check(lib().lf_routing_substep(self.river_router._h, C.byref(self._args)))
+        if self.engine_order:       # one level sweep updating both routers of a cell (one sub-step of the wavefront)
+            check(lib().lf_routing_substeps_fused(self.river_router._h, C.byref(self._args), C.c_int(1), C.c_int64(0)))
+        else:
+            check(lib().lf_routing_substep(self.river_router._h, C.byref(self._args)))
         if not self._resident:
             self._download_state()
         if getattr(self, "_inloop", None) is not None:

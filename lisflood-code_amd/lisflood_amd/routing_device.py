@@ -42,6 +42,11 @@ class RoutingStepDevice:
         for _ in range(nsteps):
             check(lib().lf_routing_substep(self.router._h, C.byref(self.args)))
 
+    def run_single_sweep(self, nsteps):
+        """sub-step by sub-step (structures can run in between), each as ONE level sweep over both routers"""
+        for _ in range(nsteps):
+            check(lib().lf_routing_substeps_fused(self.router._h, C.byref(self.args), C.c_int(1), C.c_int64(0)))
+
     def run_fused(self, nsteps):
         check(lib().lf_routing_substeps_fused(self.router._h, C.byref(self.args), C.c_int(nsteps), C.c_int64(0)))
 

@@ -303,12 +303,14 @@ def test_accuflux_matches_reference_uparea(amd):
     assert np.isclose(acc, ref, rtol=1e-6).mean() > 0.95
 
 
+@pytest.mark.parametrize("engine_order", [False, True])
 @pytest.mark.parametrize("mode", ["split", "single"])
-def test_routing_substeps_golden(amd, solver, mode):
-    """routing.dynamic() sub-steps (routing.py:435-706) through the HydroModule-shaped wrapper."""
+def test_routing_substeps_golden(amd, solver, mode, engine_order):
+    """routing.dynamic() sub-steps (routing.py:435-706) through the HydroModule-shaped wrapper; engine_order=True
+    keeps the device vectors in sweep order and runs a sub-step as one level sweep over both routers."""
     g = golden("substep_" + mode)
     v = amd.routing.var_from_fixture(g)
-    mod = amd.routing.routing(v, split_routing=(mode == "split"))
+    mod = amd.routing.routing(v, split_routing=(mode == "split"), engine_order=engine_order)
     mod.attach_router(g["codes"], g["mask"])
     sampled = g["sampled"].tolist()
     keys = ["ChanQKin", "ChanM3Kin", "ChanQ", "sumDisDay", "FlowVelocity", "TravelDistance"]
@@ -408,12 +410,7 @@ def test_routing_module_initial_to_step_end_on_etrs89(amd, oracle):
     close(v.TotalCrossSectionArea, sub.v.ChanM3Kin * v.InvChanLength)
 
 
-def test_routing_with_inloop_structures_golden(amd, solver):
-    """routing.dynamic with lakes, reservoirs, inflow hydrographs and transmission loss inside the loop
-    (routing.py:441-478), all on the device, against vectors captured from the reference's own modules
-    (lakes.py, reservoir.py, inflow.py, transmission.py driven by routing.dynamic) on LF_ETRS89's 5 lake and
-    64 reservoir sites."""
-    g = golden("inloop_structures")
+def _structures_module(amd, g, engine_order):
     v = amd.routing.var_from_fixture(g)
     v.ChanQ = g["init_ChanQ"].copy()
     v.InvNoRoutSteps = 1 / v.NoRoutSteps
@@ -427,22 +424,68 @@ def test_routing_with_inloop_structures_golden(amd, solver):
         setattr(v, k, g["init_" + k].copy())
     v.TransPower1, v.TransPower2, v.TransSub = float(g["TransPower1"]), float(g["TransPower2"]), float(g["TransSub"])
     m = amd.routing.routing(v, options=dict(SplitRouting=True, InitLisflood=False, simulateLakes=True,
-                                            simulateReservoirs=True, inflow=True, TransLoss=True))
+                                            simulateReservoirs=True, inflow=True, TransLoss=True),
+                            engine_order=engine_order)
     m.attach_router(g["codes_cut"], g["mask"])
     m.attach_structures()
+    return v, m
+
+
+_STRUCT_KEYS = ("ChanQKin", "ChanM3Kin", "Chan2QKin", "Chan2M3Kin", "ChanQ", "sumDisDay", "QLakeOutM3Dt", "QResOutM3Dt",
+                "LakeStorageM3CC", "LakeOutflowCC", "LakeInflowOldCC", "LakeStorageM3BalanceCC", "LakeLevelCC",
+                "ReservoirStorageM3CC", "ReservoirFillCC", "QInDt", "QinADDEDM3", "TransLossM3Dt", "TransCum")
+
+
+@pytest.mark.parametrize("engine_order", [False, True])
+def test_routing_with_inloop_structures_golden(amd, solver, engine_order):
+    """routing.dynamic with lakes, reservoirs, inflow hydrographs and transmission loss inside the loop
+    (routing.py:441-478), all on the device, against vectors captured from the reference's own modules
+    (lakes.py, reservoir.py, inflow.py, transmission.py driven by routing.dynamic) on LF_ETRS89's 5 lake and
+    64 reservoir sites.  engine_order=True also puts the structures' uncut links into the graph."""
+    g = golden("inloop_structures")
+    v, m = _structures_module(amd, g, engine_order)
     sampled = g["sampled"].tolist()
-    keys = ("ChanQKin", "ChanM3Kin", "Chan2QKin", "Chan2M3Kin", "ChanQ", "sumDisDay", "QLakeOutM3Dt", "QResOutM3Dt",
-            "LakeStorageM3CC", "LakeOutflowCC", "LakeInflowOldCC", "LakeStorageM3BalanceCC", "LakeLevelCC",
-            "ReservoirStorageM3CC", "ReservoirFillCC", "QInDt", "QinADDEDM3", "TransLossM3Dt", "TransCum")
     for s in range(v.NoRoutSteps):
         v.ToChanM3RunoffDt = g["ToChanM3RunoffDt"][s]
         m.dynamic(s)
         if s in sampled:
             i = sampled.index(s)
-            for k in keys:
+            for k in _STRUCT_KEYS:
                 # volumes of 1e6..1e8 m3: the 1e-9 relative bar, with the Newton tolerance scaled by DtRouting as atol
                 np.testing.assert_allclose(getattr(v, k), g["out_" + k][i], rtol=RTOL, atol=1e-8, err_msg=str((s, k)))
     assert (v.LakeStorageM3[g["LakeIndex"]] == v.LakeStorageM3CC).all()
+
+
+def test_structures_inside_the_fused_wavefront(amd, solver):
+    """lf_routing_substeps_fused_structures: the whole loop `for s: lakes/reservoirs/inflow/transmission
+    .dynamic_inloop(s); routing.dynamic(s)` as ONE wavefront (sites run between two launches, on a graph that puts
+    the cells draining into a structure on the structure's level).  With the same runoff in every sub-step (the
+    model's case) it must be bit-identical to the sub-step-by-sub-step engine, for every state and output vector,
+    and use ~NoRoutSteps x fewer launches."""
+    g = golden("inloop_structures")
+    va, ma = _structures_module(amd, g, True)
+    vb, mb = _structures_module(amd, g, True)
+    runoff = g["ToChanM3RunoffDt"][0]
+    va.ToChanM3RunoffDt = runoff
+    vb.ToChanM3RunoffDt = runoff
+    for s in range(va.NoRoutSteps):
+        ma.dynamic(s)
+    seq_launches = ma.river_router.last_launches()["launches"]
+    mb.dynamic_fused()
+    for k in _STRUCT_KEYS + ("CrossSection2Area", "Sideflow1Chan", "FlowVelocity", "TravelDistance", "LakeStorageM3",
+                             "ReservoirStorageM3", "LakeInflowCC", "ReservoirInflowCC"):
+        assert np.array_equal(getattr(va, k), getattr(vb, k)), k
+    fused = mb.river_router.last_launches()["launches"]
+    assert fused < 2 * (mb.river_router.graph.num_levels + va.NoRoutSteps) and seq_launches * va.NoRoutSteps > 5 * fused
+    # a second model step continues from the state of the first
+    for s in range(va.NoRoutSteps):
+        ma.dynamic(s)
+    mb.dynamic_fused()
+    for k in ("ChanQ", "sumDisDay", "LakeStorageM3CC", "ReservoirStorageM3CC", "TransCum"):
+        assert np.array_equal(getattr(va, k), getattr(vb, k)), k
+    # the plain sweeps refuse a graph with structure links
+    with pytest.raises(amd.lib.LisfloodAmdError):
+        mb.river_router.kinematicWaveRouting(np.zeros(mb.river_router.num_pixels), np.zeros(mb.river_router.num_pixels))
 
 
 def test_pixel_aggregates_golden(amd):

@@ -127,3 +127,47 @@ def test_compute_fails_loudly_without_gpu():
     d = syn.soil_params(8)
     with pytest.raises(_lib.LisfloodAmdError):
         soilColumnsWaterBalance(*[d[k] for k in syn.SOIL_ARG_ORDER])
+
+
+def test_graph_with_structure_links():
+    """lf_graph_create_ex: the pits cut just upstream of a structure are put on the structure's level (zero-length
+    links) at the end of that level, outside every upstream range; everything else keeps the sweep-order invariants."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "lisflood-code_amd"))
+    from lisflood_amd import ldd as L
+    from lisflood_amd.kinematic_wave_parallel import Graph
+    z = np.load(os.path.join(ROOT, "tests", "golden", "inloop_structures.npz"))
+    mask, cut = z["mask"], z["codes_cut"]
+    N = cut.size
+    ds = z["downstruct"].astype(np.int64)
+    sites = np.concatenate([z["LakeIndex"], z["ReservoirIndex"]]).astype(np.int64)
+    is_site = np.zeros(N + 1, bool); is_site[sites] = True
+    vd = np.where(is_site[np.minimum(ds, N)] & (ds < N), ds, -1)
+    assert (vd >= 0).sum() > 50
+    g0, g = Graph(cut, mask), Graph(cut, mask, virtual_down=vd)
+    perm, ups_ptr, level_start = g.layout()
+    linked = g.links()
+    pos = np.empty(N, np.int64); pos[perm] = np.arange(N)
+    level = np.searchsorted(level_start, np.arange(N), side="right") - 1          # by position
+    assert np.array_equal(np.sort(perm), np.arange(N))
+    assert linked.sum() == (vd >= 0).sum() and np.array_equal(np.nonzero(linked)[0], np.sort(pos[vd >= 0]))
+    # links: same level as their structure cell
+    u = np.nonzero(vd >= 0)[0]
+    assert np.array_equal(level[pos[u]], level[pos[vd[u]]])
+    # real edges: strictly increasing level, and the upstream ranges (minus links) are the real upstream cells
+    down = g.lookups()[0].astype(np.int64)
+    assert np.array_equal(down, g0.lookups()[0].astype(np.int64))
+    has = down >= 0
+    assert (level[pos[np.nonzero(has)[0]]] + 1 == level[pos[down[has]]]).all()
+    for p in range(N):
+        rng = np.arange(ups_ptr[p], ups_ptr[p + 1])
+        rng = rng[~linked[rng]]
+        want = np.nonzero(down == perm[p])[0]
+        assert np.array_equal(perm[rng], want), p
+    assert g.num_levels >= g0.num_levels
+    # a link whose source is not a pit is rejected
+    bad = np.full(N, -1, np.int64)
+    src = int(np.nonzero(has)[0][0])
+    bad[src] = int(down[src])
+    with pytest.raises(Exception):
+        Graph(cut, mask, virtual_down=bad)
