@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads / soil kernel")
     ap.add_argument("--cpu-sample", type=int, default=2000, help="CPU baseline raster is sample x sample")
-    ap.add_argument("--only", choices=["soil", "model_step", "hotpath"], default=None, help="run only the named secondary benchmark")
+    ap.add_argument("--only", choices=["soil", "model_step", "hotpath", "structures"], default=None, help="run only the named secondary benchmark")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the row-block/RCCL path even with a single rank (smoke test of that path)")
     ap.add_argument("--calibrate", action="store_true",
@@ -297,6 +297,75 @@ def model_step_bench(size=5000, nsteps=24):
     return out
 
 
+def structures_step_bench(size=3000, nsteps=24):
+    """A model step of routing WITH lakes, reservoirs, inflow hydrographs and transmission loss in the loop
+    (routing.py:441-478), device-resident: the whole loop as one wavefront (lf_routing_substeps_fused_structures)
+    against sub-step by sub-step (lf_inloop_structures + one level sweep over both routers)."""
+    import ctypes as C
+    import types
+    from lisflood_amd import _lib
+    from lisflood_amd import synthetic as syn
+    from lisflood_amd.routing import routing
+    H = W = size
+    N = H * W
+    codes = syn.make_ldd("deep", H, W, 2).reshape(-1).astype(np.float64)
+    mask = np.ones((H, W), bool)
+    p = syn.router_params(N)
+    rng = np.random.default_rng(17)
+    beta, dt = p["beta"], 3600.0
+    alpha, length = p["alpha"], p["dx"]
+    alpha2 = alpha * rng.uniform(1.2, 2.0, N)
+    qlimit = 2.0 * p["Q0"] * rng.uniform(0.3, 1.2, N)
+    v = types.SimpleNamespace(
+        ChanLength=length, InvChanLength=1 / length, ChannelAlpha=alpha, InvChannelAlpha=1 / alpha, ChannelAlpha2=alpha2,
+        InvChannelAlpha2=1 / alpha2, QLimit=qlimit, M3Limit=alpha * length * qlimit ** beta,
+        Chan2M3Start=alpha2 * length * qlimit ** beta, Chan2QStart=qlimit * 0.1, PixelArea=np.full(N, 2.5e7),
+        IsChannelKinematic=np.ones(N, bool), Beta=beta, InvBeta=1 / beta, DtRouting=dt, InvDtRouting=1 / dt,
+        NoRoutSteps=nsteps, InvNoRoutSteps=1 / nsteps, DtSec=dt * nsteps,
+        ToChanM3RunoffDt=syn.lateral_inflow(N, 0) * length * dt)
+    v.Chan2M3Kin = v.Chan2M3Start.copy()
+    v.ChanM3Kin = alpha * length * p["Q0"] ** beta
+    v.ChanQKin = p["Q0"].copy()
+    v.Chan2QKin = (v.Chan2M3Kin / length / alpha2) ** (1 / beta)
+    v.ChanQ = v.ChanQKin.copy()
+    v.CrossSection2Area, v.Sideflow1Chan, v.sumDisDay = np.zeros(N), np.zeros(N), np.zeros(N)
+    d, cut = syn.structures_scenario(codes, (H, W), v.ChanQ, dt)
+    for k, x in d.items():
+        setattr(v, k, x)
+    m = routing(v, options=dict(SplitRouting=True, InitLisflood=False, simulateLakes=True, simulateReservoirs=True,
+                                inflow=True, TransLoss=True), engine_order=True)
+    m.attach_router(cut, mask)
+    m.attach_structures()
+    m.begin_step()
+    m.dynamic_fused()                                   # warm-up; leaves every argument block wired
+    L, r = _lib.lib(), m.river_router
+    out = {}
+    _lib.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        _lib.check(L.lf_routing_substeps_fused_structures(r._h, C.byref(m._args), C.byref(m._inloop), C.c_int(nsteps)))
+    _lib.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / 3
+    out["fused"] = dict(ms_per_model_step=round(ms, 3), value=round(2 * nsteps * N / ms / 1e3, 2), unit="Mcell-steps/s",
+                        launches_per_model_step=r.last_launches()["launches"])
+    _lib.synchronize()
+    t0 = time.perf_counter()
+    for s in range(nsteps):
+        m._inloop.step = s
+        _lib.check(L.lf_inloop_structures(C.c_int(0), C.byref(m._inloop)))
+        _lib.check(L.lf_routing_substeps_fused(r._h, C.byref(m._args), C.c_int(1), C.c_int64(0)))
+    _lib.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3
+    out["sequential"] = dict(ms_per_model_step=round(ms, 3), value=round(2 * nsteps * N / ms / 1e3, 2), unit="Mcell-steps/s",
+                             launches_per_model_step=(r.last_launches()["launches"] + 2) * nsteps)
+    out["config"] = ("%dx%d deep LDD cut at %d lakes + %d reservoirs (NL=%d with their links), 32 inflow points, "
+                     "transmission loss on 30 %% of the reaches, NoRoutSteps=%d, split routing"
+                     % (H, W, d["LakeIndex"].size, d["ReservoirIndex"].size, r.graph.num_levels, nsteps))
+    finite = bool(np.isfinite(m._dev["ChanQ"].download()).all())
+    out["finite"] = finite
+    return out
+
+
 def hotpath_bench(size=2000, steps=3):
     """The whole device-resident hot path of a model step (canopy -> soil -> per-pixel aggregates -> 3 overland
     routers -> 24 split-routing channel sub-steps), lisflood_amd.hotpath.HotPathDevice; only the five forcing
@@ -335,6 +404,9 @@ def main():
         return dist_bench.main(a)
     if a.only == "soil":
         print(json.dumps(soil_bench()), flush=True)
+        return
+    if a.only == "structures":
+        print(json.dumps(structures_step_bench()))
         return
     if a.only == "hotpath":
         print(json.dumps(hotpath_bench(min(a.size, 2000))), flush=True)
@@ -418,6 +490,10 @@ def main():
             extra["model_step_24_substeps_split"] = model_step_bench()
         except Exception as e:
             extra["model_step_error"] = repr(e)
+        try:
+            extra["model_step_with_structures"] = structures_step_bench()
+        except Exception as e:
+            extra["structures_error"] = repr(e)
         try:
             extra["resident_hot_path_step"] = hotpath_bench()
         except Exception as e:

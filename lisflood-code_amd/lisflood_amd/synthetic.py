@@ -294,3 +294,59 @@ def hotpath_forcing(N, step, seed=300):
     rng = np.random.default_rng(seed + step)
     return dict(Rain=rng.uniform(0, 20, N) * (rng.random(N) < 0.6), SnowMelt=np.zeros(N),
                 EWRef=rng.uniform(0, 5, N), ETRef=rng.uniform(0, 4, N), ESRef=rng.uniform(0, 3, N))
+
+
+def structures_scenario(codes, shape, chan_q, dt_routing, n_lakes=64, n_res=192, seed=23):
+    """Synthetic lakes / reservoirs / inflow points / transmission-loss reaches on an all-land compressed LDD
+    (parameter ranges as tests/golden/make_golden.py used on LF_ETRS89: lakes.py:96-160, reservoir.py:73-165).
+    Returns (var attributes dict, cut LDD codes): the cells just upstream of a site are pits of the cut LDD
+    (structures.py:44-61), `downstruct` keeps the uncut links (routing.py:159-164)."""
+    from . import ldd as L
+    H, W = shape
+    N = H * W
+    rng = np.random.default_rng(seed)
+    mask = np.ones((H, W), bool)
+    codes = np.asarray(codes, np.float64)
+    down = L.downstream_index(codes, mask)
+    nups = np.bincount(down[down >= 0], minlength=N)
+    cand = np.nonzero((nups > 0) & (down >= 0))[0]                 # sites with something upstream and downstream
+    sites = rng.choice(cand, n_lakes + n_res, replace=False)
+    lake, res = np.sort(sites[:n_lakes]), np.sort(sites[n_lakes:])
+    is_site = np.zeros(N, bool); is_site[sites] = True
+    ups = (down >= 0) & is_site[np.maximum(down, 0)]
+    cut = codes.copy(); cut[ups] = 5.0
+    d = {}
+    ds = np.where(down >= 0, down, N).astype(np.int32); ds[codes == 5] = N
+    d["downstruct"] = ds
+    d["LakeIndex"], d["ReservoirIndex"] = lake, res
+    d["LakeAreaCC"] = rng.uniform(2e6, 5e7, n_lakes)
+    lake_a = rng.uniform(5.0, 80.0, n_lakes)
+    d["LakeFactor"] = d["LakeAreaCC"] / (dt_routing * np.sqrt(lake_a))
+    d["LakeFactorSqr"] = np.square(d["LakeFactor"])
+    qin = np.bincount(ds, weights=chan_q, minlength=N + 1)
+    d["LakeInflowOldCC"] = qin[lake]
+    d["LakeLevelCC"] = rng.uniform(0.5, 3.0, n_lakes)
+    d["LakeStorageM3"] = np.zeros(N); d["LakeStorageM3"][lake] = d["LakeAreaCC"] * d["LakeLevelCC"]
+    d["LakeOutflowCC"] = np.square(d["LakeLevelCC"]) * lake_a
+    d["LakeStorageM3BalanceCC"] = d["LakeStorageM3"][lake].copy()
+    d["TotalReservoirStorageM3CC"] = np.exp(rng.uniform(np.log(1e6), np.log(5e8), n_res))
+    d["ConservativeStorageLimitCC"] = rng.uniform(0.05, 0.15, n_res)
+    d["NormalStorageLimitCC"] = rng.uniform(0.4, 0.7, n_res)
+    d["FloodStorageLimitCC"] = rng.uniform(0.8, 0.97, n_res)
+    d["Normal_FloodStorageLimitCC"] = d["NormalStorageLimitCC"] + 0.5 * (d["FloodStorageLimitCC"] - d["NormalStorageLimitCC"])
+    q0 = qin[res]
+    d["MinReservoirOutflowCC"], d["NormalReservoirOutflowCC"] = 0.1 * q0 + 0.01, 0.9 * q0 + 0.05
+    d["NonDamagingReservoirOutflowCC"] = 4.0 * q0 + 1.0
+    d["DeltaO"] = d["NormalReservoirOutflowCC"] - d["MinReservoirOutflowCC"]
+    d["DeltaLN"] = d["NormalStorageLimitCC"] - 2 * d["ConservativeStorageLimitCC"]
+    d["DeltaNFL"] = d["FloodStorageLimitCC"] - d["Normal_FloodStorageLimitCC"]
+    d["ReservoirStorageM3"] = np.zeros(N)
+    d["ReservoirStorageM3"][res] = rng.uniform(0.02, 1.0, n_res) * d["TotalReservoirStorageM3CC"]
+    d["QInM3Old"], d["QDelta"] = np.zeros(N), np.zeros(N)
+    pts = rng.choice(N, 32, replace=False)
+    d["QInM3Old"][pts] = rng.uniform(1e4, 2e5, 32); d["QDelta"][pts] = rng.uniform(0.0, 2e3, 32)
+    d["UpTrans"] = (rng.random(N) < 0.3) & (chan_q > 1.0)
+    # (Q^p2 - TransSub) must stay positive on every flagged reach for as long as the scenario is stepped
+    d["TransPower1"], d["TransPower2"], d["TransSub"] = 1 / 0.95, 0.95, 1e-9
+    d["TransCum"] = np.zeros(N)
+    return d, cut
