@@ -12,6 +12,7 @@ device buffers from one stage to the next.  Channel vectors live in the channel 
 vector that crosses from the surface graph to the channel graph (ToChanM3RunoffDt) is permuted on the device.
 """
 import ctypes as C
+import types
 
 import numpy as np
 
@@ -26,12 +27,16 @@ FORCING = ("Rain", "SnowMelt", "EWRef", "ETRef", "ESRef")
 
 
 class HotPathDevice:
-    def __init__(self, values, scalars, land_mask, ldd_to_chan, ldd_kinematic, split=True, device=0):
+    def __init__(self, values, scalars, land_mask, ldd_to_chan, ldd_kinematic, split=True, device=0, structures=None):
         """values: name -> host array in pixel order ([N], [3,N]) for every vector of the stages (reference
         attribute names); scalars: Beta, DtSec, DtRouting, NoRoutSteps, DtDay, PixelLength, MMtoM3, M3toMM,
         LeafDrainageK, AvWaterThreshold, CourantCrit, DrainedFraction, InvDtDay.  ldd_to_chan / ldd_kinematic:
-        compressed LDD codes of the overland and the channel graph."""
+        compressed LDD codes of the overland and the channel graph.
+        structures: optional dict of the reference's lake / reservoir / inflow / transmission attributes (the names
+        routing.attach_structures reads, incl. `downstruct` of the uncut LDD); ldd_kinematic is then the CUT LDD
+        (structures.py:44-61) and the sub-step loop runs with the structures inside the wavefront."""
         self.device, self.split = device, bool(split)
+        self.rmod = None
         self.sc = dict(scalars)
         self.N = N = int(np.asarray(land_mask, bool).sum())
         sc = self.sc
@@ -41,17 +46,39 @@ class HotPathDevice:
         mk = lambda row: kinematicWave(None, None, alpha_of[row], sc["Beta"], sc["PixelLength"], sc["DtSec"],
                                        device=device, graph=g_surf)
         self.r_other, self.r_forest, self.r_direct = mk(0), mk(1), mk(2)
-        self.river = kinematicWave(ldd_kinematic, land_mask, values["ChannelAlpha"], sc["Beta"], values["ChanLength"],
-                                   sc["DtRouting"], alpha_floodplains=values["ChannelAlpha2"] if split else None,
-                                   device=device)
+        chan_names = set(RT._STATIC + RT._STATE)
+        self.d = {}
+        if structures is None:
+            self.river = kinematicWave(ldd_kinematic, land_mask, values["ChannelAlpha"], sc["Beta"], values["ChanLength"],
+                                       sc["DtRouting"], alpha_floodplains=values["ChannelAlpha2"] if split else None,
+                                       device=device)
+        else:       # the channel part is a resident, engine-order routing module with its structures attached
+            v = types.SimpleNamespace(**{k: np.array(values[k], copy=True) for k in chan_names if k in values})
+            v.Beta, v.InvBeta, v.DtRouting, v.InvDtRouting = sc["Beta"], 1 / sc["Beta"], sc["DtRouting"], 1 / sc["DtRouting"]
+            v.DtSec, v.NoRoutSteps, v.InvNoRoutSteps = sc["DtSec"], int(sc["NoRoutSteps"]), 1 / sc["NoRoutSteps"]
+            v.ToChanM3RunoffDt = np.zeros(N)
+            for k, a in structures.items():
+                setattr(v, k, a)
+            opts = dict(SplitRouting=self.split, InitLisflood=False, simulateLakes="LakeIndex" in structures,
+                        simulateReservoirs="ReservoirIndex" in structures, inflow="QInM3Old" in structures,
+                        TransLoss="UpTrans" in structures)
+            m = self.rmod = RT.routing(v, options=opts, device=device, engine_order=True)
+            m.attach_router(ldd_kinematic, land_mask)
+            m.attach_structures()
+            m.begin_step()                              # uploads the channel state once; it stays resident
+            m._structures_substep(0, launch=False)      # site state from the dense maps, once
+            m._args.split = 1 if self.split else 0
+            self.river = m.river_router
+            for k in chan_names | set(RT._OUT) | {"SideflowChanM3"}:
+                self.d[k] = m._dev[k]
         self.perm = self.river.graph.layout()[0].astype(np.int64)
         # ---- device vectors ------------------------------------------------------------------------
-        self.d = {}
-        chan_names = set(RT._STATIC + RT._STATE)
         bool_names = SL._BOOL | {"IsChannel", "IsChannelKinematic"}
         for k, a in values.items():
             a = np.asarray(a)
             if k in chan_names:                       # channel vectors: engine order of the river router
+                if self.rmod is not None:
+                    continue
                 a = np.broadcast_to(a, (N,))[self.perm]
             self.d[k] = DeviceArray.from_host(u8(a) if k in bool_names else f64(a), device)
 
@@ -115,6 +142,13 @@ class HotPathDevice:
         check(L.lf_pixel_aggregates_device(C.c_int(dev), C.byref(self.pixel)))                          # dyn.py:129-149
         check(L.lf_surface_step(self.r_direct._h, self.r_other._h, self.r_forest._h, C.byref(self.surface)))  # :165
         d["sumDisDay"].zero()                                                                           # dyn.py:177
+        if self.rmod is not None:       # lakes / reservoirs / inflow / transmission loss inside the wavefront
+            m = self.rmod
+            check(L.lf_router_to_engine_order(self.river._h, d["ToChanM3RunoffDt"].ptr,
+                                              m._st["dev"]["ToChanM3RunoffDt"].ptr))
+            check(L.lf_routing_substeps_fused_structures(self.river._h, C.byref(m._args), C.byref(m._inloop),
+                                                         C.c_int(int(self.sc["NoRoutSteps"]))))          # dyn.py:179-180
+            return
         check(L.lf_router_to_engine_order(self.river._h, d["ToChanM3RunoffDt"].ptr, d["SideflowChanM3"].ptr))
         check(L.lf_routing_substeps_fused(self.river._h, C.byref(self.rout), C.c_int(int(self.sc["NoRoutSteps"])),
                                           C.c_int64(0)))                                                # dyn.py:179-180
@@ -127,12 +161,20 @@ class HotPathDevice:
             return out
         return a
 
+    def download_site(self, name):
+        """lake / reservoir site vectors (LakeStorageM3CC, ReservoirStorageM3CC, ...) and the dense in-loop outputs"""
+        a = self.rmod._st["dev"][name].download()
+        return self.rmod._down(a) if a.size == self.N and name not in RT._LAKE_STATE + RT._RES_STATE else a
+
     def chan_q_avg(self):
         """ChanQAvg = sumDisDay / NoRoutSteps (Lisflood_dynamic.py:209): the `dis` output of the reference."""
         return self.download("sumDisDay") / self.sc["NoRoutSteps"]
 
     def free(self):
-        for a in self.d.values():
+        arrays = {id(a): a for a in self.d.values()}
+        if self.rmod is not None:
+            arrays.update({id(a): a for a in list(self.rmod._st["dev"].values()) + list(self.rmod._dev.values())})
+        for a in arrays.values():
             a.free()
         for r in (self.r_other, self.r_forest, self.r_direct, self.river):
             r.close()

@@ -555,6 +555,55 @@ def test_resident_hot_path_equals_the_module_classes(amd):
     hp.free()
 
 
+def test_resident_hot_path_with_structures(amd):
+    """The resident chain with lakes, reservoirs, inflow points and transmission loss inside the channel wavefront
+    against the module classes stepping the same loop sub-step by sub-step (lf_inloop_structures + one sweep)."""
+    from lisflood_amd import synthetic as syn
+    from lisflood_amd import pixel_aggregates as PA
+    from lisflood_amd.hotpath import HotPathDevice
+    from lisflood_amd.soilloop import soilloop
+    from lisflood_amd.surface_routing import surface_routing
+    H, W = 48, 60
+    N = H * W
+    values, sc, mask, ldd_to_chan, ldd_kin = syn.hotpath_scenario(H, W)
+    st, cut = syn.structures_scenario(ldd_kin, (H, W), values["ChanQ"], sc["DtRouting"], n_lakes=3, n_res=5)
+    st["QInM3Old"][:] = 0; st["QDelta"][:] = 0
+    pts = np.nonzero(values["IsChannelKinematic"])[0][::37]
+    st["QInM3Old"][pts] = 5e3; st["QDelta"][pts] = 40.0
+    cp = lambda d: {k: (np.array(a, copy=True) if isinstance(a, np.ndarray) else a) for k, a in d.items()}
+    hp = HotPathDevice(cp(values), sc, mask, ldd_to_chan, cut, split=True, structures=cp(st))
+    v = _model_var(N)
+    for k, a in list(cp(values).items()) + list(sc.items()) + list(cp(st).items()):
+        setattr(v, k, a)
+    v.InvBeta, v.InvPixelLength, v.InvDtSec = 1 / v.Beta, 1 / v.PixelLength, 1 / v.DtSec
+    v.InvDtRouting, v.InvNoRoutSteps = 1 / v.DtRouting, 1 / v.NoRoutSteps
+    m_soil = soilloop(v); m_soil.initial()
+    m_surf = surface_routing(v); m_surf.initialSecond(ldd_to_chan, mask)
+    m_rout = amd.routing.routing(v, options=dict(SplitRouting=True, InitLisflood=False, simulateLakes=True,
+                                                 simulateReservoirs=True, inflow=True, TransLoss=True), engine_order=True)
+    m_rout.attach_router(cut, mask)
+    m_rout.attach_structures()
+    for step in range(2):
+        f = syn.hotpath_forcing(N, step)
+        hp.step(f, time_since_start=step + 1)
+        for k, a in f.items():
+            setattr(v, k, a)
+        v.TimeSinceStart = float(step + 1)
+        m_soil.dynamic_canopy(); m_soil.dynamic_soil()
+        PA.dynamic(v)
+        m_surf.dynamic()
+        v.sumDisDay = np.zeros(N)
+        for s in range(int(v.NoRoutSteps)):
+            m_rout.dynamic(s)
+        for k in ("ToChanM3RunoffDt", "ChanQKin", "Chan2QKin", "ChanM3Kin", "ChanQ", "sumDisDay"):
+            assert np.array_equal(hp.download(k), np.asarray(getattr(v, k)), equal_nan=True), (step, k)
+        for k in ("LakeStorageM3CC", "LakeOutflowCC", "ReservoirStorageM3CC", "ReservoirFillCC", "QLakeOutM3Dt",
+                  "QResOutM3Dt", "TransCum", "QinADDEDM3"):
+            assert np.array_equal(hp.download_site(k), np.asarray(getattr(v, k))), (step, k)
+        assert np.isfinite(v.ChanQ).all() and v.ReservoirStorageM3CC.min() >= 0
+    hp.free()
+
+
 def test_interception_golden(amd):
     g = golden("interception")
     st = {k: g["in_" + k].copy() for k in ("Interception", "TaInterception", "LeafDrainage", "CumInterception")}
