@@ -31,7 +31,9 @@ def main(a):
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import datetime
+    # a rank that dies must not leave the others waiting for gloo's 30-minute default
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
     ndev = _lib.device_count()
     device = local_rank % max(ndev, 1)
     t_setup = time.time()
