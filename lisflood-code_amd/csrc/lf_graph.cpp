@@ -112,9 +112,14 @@ int build(int H, int W, CodeAt codes_at, IsLand is_land, bool all_land, lf_graph
         std::vector<int32_t> queue(n);
         std::vector<int64_t> gen_start;
         int64_t tail = 0;
+        // outlets WITH upstream cells first, isolated pixels (no upstream, no downstream: e.g. the non-channel land
+        // pixels of the channel LDD) after them: they end up side by side at the end of the last level, where the
+        // fused sub-step wavefront can skip them line by line while their state is zero
         if (!virtual_down) {
             for (int64_t p = 0; p < n; ++p)
-                if (g->down[p] < 0) queue[tail++] = (int32_t)p;
+                if (g->down[p] < 0 && nups[p] > 0) queue[tail++] = (int32_t)p;
+            for (int64_t p = 0; p < n; ++p)
+                if (g->down[p] < 0 && nups[p] == 0) queue[tail++] = (int32_t)p;
             int64_t head = 0;
             gen_start.push_back(0);
             while (head < tail) {
@@ -144,7 +149,9 @@ int build(int H, int W, CodeAt codes_at, IsLand is_land, bool all_land, lf_graph
                 if (virtual_down[u] >= 0) vidx[vfill[virtual_down[u]]++] = (int32_t)u;
             std::vector<int32_t> cur, next;
             for (int64_t p = 0; p < n; ++p)
-                if (g->down[p] < 0 && virtual_down[p] < 0) cur.push_back((int32_t)p);
+                if (g->down[p] < 0 && virtual_down[p] < 0 && (nups[p] > 0 || vptr[p + 1] > vptr[p])) cur.push_back((int32_t)p);
+            for (int64_t p = 0; p < n; ++p)
+                if (g->down[p] < 0 && virtual_down[p] < 0 && nups[p] == 0 && vptr[p + 1] == vptr[p]) cur.push_back((int32_t)p);
             gen_start.push_back(0);
             while (!cur.empty() && tail < n) {
                 for (size_t i = 0; i < cur.size() && (int64_t)(cur.size() + next.size()) <= n; ++i) { // cur grows

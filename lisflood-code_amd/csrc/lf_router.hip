@@ -119,6 +119,9 @@ struct lf_router {
     lf_dbuf<int32_t> win_ptr, win_cells; // component lists of the window segments
     lf_dbuf<unsigned long long> counter;
     lf_dbuf<uint8_t> linked; // zero-length structure links (lf_graph_create_ex); null without them
+    lf_dbuf<uint8_t> isolated; // [N] by position: 1 = no upstream and no downstream cell (e.g. non-channel land pixels)
+    lf_dbuf<uint8_t> inert;    // [N] per fused call: isolated, not a channel, zero split-routing thresholds
+    int64_t n_isolated = 0;
     lf_dbuf<int> site_level; // levels of the lake and reservoir cells of the last fused-with-structures call
     std::vector<int64_t> h_level_start;
     std::vector<segment> schedule;
@@ -381,6 +384,17 @@ int lf_router_create(const lf_graph *g, const double *alpha, double beta, const 
     if (rc == LF_OK) rc = r->perm.upload(g->perm.data(), n);
     if (rc == LF_OK) rc = r->ups_ptr.upload(g->ups_ptr.data(), n + 1);
     if (rc == LF_OK && g->has_links) rc = r->linked.upload(g->linked.data(), n);
+    if (rc == LF_OK && n > 0) {
+        std::vector<uint8_t> has_up(n, 0), iso(n, 0);
+        for (int64_t p = 0; p < n; ++p)
+            if (g->down[p] >= 0) has_up[g->down[p]] = 1;
+        for (int64_t p = 0; p < n; ++p) {
+            const int32_t pix = g->perm[p];
+            iso[p] = (g->down[pix] < 0 && !has_up[pix] && !(g->has_links && g->linked[p])) ? 1 : 0;
+            r->n_isolated += iso[p];
+        }
+        if (r->n_isolated > 0) rc = r->isolated.upload(iso.data(), n);
+    }
     if (rc == LF_OK) {
         std::vector<long long> ls(g->level_start.begin(), g->level_start.end());
         rc = r->level_start.upload(ls.data(), ls.size());
@@ -771,6 +785,8 @@ extern "C" int lf_routing_substep(lf_router *r, const lf_substep_args *a)
 // ================================================================================================
 namespace {
 
+constexpr int kMaxPackedSteps = 128;
+
 struct fused_args {
     lf_substep_args S;
     const int *__restrict__ ups_ptr;
@@ -782,9 +798,41 @@ struct fused_args {
     int kmax, nlevels, nsteps, t;
     int solve35; // router runs the beta = 3/5 quintic solve (false: general path, e.g. LF_GENERAL_POW=1)
     const uint8_t *__restrict__ linked; // zero-length structure links: their router output is stored as 0
+    const uint8_t *__restrict__ inert;  // cells whose sub-step is the identity while their state is all +0.0
     lf_inloop_args I;                   // STRUCT: lakes / reservoirs / inflow / transmission loss / sideflow assembly
     const int *__restrict__ site_level; // STRUCT: level of every lake, then every reservoir cell
+    // 1-D grid packed by sub-step: blocks [blk_start[s], blk_start[s+1]) work on (level t - s, sub-step s), so no
+    // block is launched for the part of a narrow level that a 2-D grid sized by the widest level would cover
+    // (packed = 0: 2-D grid, blockIdx.y = sub-step; used when nsteps > kMaxPackedSteps)
+    int packed;
+    int blk_start[kMaxPackedSteps + 1];
 };
+
+__device__ __forceinline__ bool plus_zero(double x) { return __double_as_longlong(x) == 0; }
+
+// Non-channel land pixels sit in the channel router as isolated nodes without sideflow (routing.py:512): once their
+// state is zero, a sub-step leaves every vector as it is.  inert[p] marks the candidates (static part of the test);
+// the cell kernel then checks the state itself and returns early -- on real domains most land pixels are such cells,
+// and being outlets without upstream cells they lie side by side in the last level, so whole lines are skipped.
+// The parameters must be finite too: 0 * inf would turn the zero state into NaN, as it does in the reference.
+__global__ void __launch_bounds__(kBlock) k_inert_flags(long long n, lf_substep_args A, const uint8_t *__restrict__ isolated,
+                                                        const double *__restrict__ a1, const double *__restrict__ a2,
+                                                        const double *__restrict__ dx, uint8_t *__restrict__ inert)
+{
+    const long long p = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (p >= n) return;
+    bool f = isolated[p] && !A.IsChannelKinematic[p];
+    if (f) {
+        const double t = A.InvChanLength[p] * A.ChanLength[p] * A.ChannelAlpha[p] * A.InvChannelAlpha[p] * a1[p] *
+                         (dx ? dx[p] : 1.0);
+        f = isfinite(t) && A.InvChanLength[p] >= 0.0;
+    }
+    if (f && A.split) {
+        const double t = A.ChannelAlpha2[p] * A.InvChannelAlpha2[p] * a2[p];
+        f = isfinite(t) && plus_zero(A.QLimit[p]) && plus_zero(A.Chan2QStart[p]) && plus_zero(A.Chan2M3Start[p]);
+    }
+    inert[p] = f ? 1 : 0;
+}
 
 // Lakes and reservoirs inside the wavefront: site v handles sub-step s = t - level(v) right BEFORE launch t of the
 // cell kernel.  The cells that drain into v in the uncut LDD are zero-length links of the graph, i.e. on v's level:
@@ -818,14 +866,35 @@ __device__ __forceinline__ double upstream_sum8(const double *q, int u0, int u1,
 template <bool SPLIT, bool STRUCT>
 __global__ void __launch_bounds__(kBlock) k_fused_substeps(fused_args F)
 {
-    const int s = blockIdx.y;          // sub-step
+    int s, blk;
+    if (F.packed) { // the last sub-step whose first block is <= blockIdx.x (starts are non-decreasing; independent
+                    // scalar loads and compares -- a binary search would chain its kernarg loads)
+        int cnt = 0, start = 0;
+        for (int q = 0; q < F.nsteps; ++q) {
+            const bool ge = (int)blockIdx.x >= F.blk_start[q];
+            cnt += ge ? 1 : 0;
+            start = ge ? F.blk_start[q] : start;
+        }
+        s = cnt - 1;
+        blk = (int)blockIdx.x - start;
+    } else {
+        s = blockIdx.y;
+        blk = blockIdx.x;
+    }
     const int k = F.t - s;             // level handled by this sub-step at wave time t
     if (k < 0 || k >= F.nlevels) return;
     const long long first = F.level_start[k];
-    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    const long long i = (long long)blk * kBlock + threadIdx.x;
     if (i >= F.level_start[k + 1] - first) return;
     const long long p = first + i;
     const lf_substep_args &A = F.S;
+    if (!STRUCT && F.inert && F.inert[p] && s != F.nsteps - 1) { // see k_inert_flags; the last sub-step also writes
+        bool zero = plus_zero(A.ChanQKin[p]) && plus_zero(A.ChanM3Kin[p]) && plus_zero(A.ChanQ[p]); // velocities
+        if (SPLIT && zero)
+            zero = plus_zero(A.Chan2QKin[p]) && plus_zero(A.Chan2M3Kin[p]) && plus_zero(A.CrossSection2Area[p]) &&
+                   plus_zero(A.Sideflow1Chan[p]);
+        if (zero) return;
+    }
     const bool b35 = A.Beta == 0.6;     // fix-up round trips, as k_substep_main / k_substep_floodplain
     const bool s35 = F.solve35 != 0;    // router solve + old-discharge term, as the router itself
     const long long par = (long long)(s & 1) * F.n;
@@ -988,6 +1057,7 @@ int fused_impl(lf_router *r, const lf_substep_args *a, int nsteps, int64_t sidef
     F.nsteps = nsteps;
     F.solve35 = r->fused ? 1 : 0;
     F.linked = r->linked.p;
+    F.inert = nullptr;
     F.site_level = nullptr;
     std::memset(&F.I, 0, sizeof(F.I));
     hipStream_t s = r->ctx->stream;
@@ -1045,6 +1115,19 @@ int fused_impl(lf_router *r, const lf_substep_args *a, int nsteps, int64_t sidef
         }
     }
     int64_t launches = 0;
+    bool grid2d = false;
+    {
+        const char *e2 = std::getenv("LF_FUSED_2D_GRID"); // A/B switch: one grid row per sub-step, sized by the widest
+        grid2d = e2 && e2[0] == '1';
+        const char *e = std::getenv("LF_NO_INERT_SKIP"); // A/B switch
+        if (!in && r->n_isolated > 0 && nsteps > 1 && !(e && e[0] == '1')) {
+            if (!r->inert.p) LF_TRY(r->inert.alloc(n));
+            hipLaunchKernelGGL(k_inert_flags, dim3(blocks_for(n)), dim3(kBlock), 0, s, (long long)n, *a, r->isolated.p,
+                               r->a1.p, r->a2.p, F.dx, r->inert.p);
+            F.inert = r->inert.p;
+            ++launches;
+        }
+    }
     for (int t = 0; t < NL + nsteps - 1; ++t) {
         // widest level inside the window [t - nsteps + 1, t]
         const int k_lo = std::max(0, t - nsteps + 1), k_hi = std::min(NL - 1, t);
@@ -1058,7 +1141,25 @@ int fused_impl(lf_router *r, const lf_substep_args *a, int nsteps, int64_t sidef
                 ++launches;
             }
         }
-        const dim3 grid(blocks_for(widest), nsteps), block(kBlock);
+        dim3 grid(blocks_for(widest), nsteps);
+        const dim3 block(kBlock);
+        // packed 1-D grid only where it saves at least half of the blocks: finding its sub-step costs a block ~1.7 us
+        // (24 scalar kernarg loads), which shows on latency-bound launches (deep 5000^2: 65.2 vs 56.7 ms per model
+        // step, same-call A/B) but is nothing against 360 000 empty blocks (2000^2 hot path: 14.5 vs 16.1 ms)
+        F.packed = 0;
+        if (nsteps <= kMaxPackedSteps && !grid2d) {
+            int64_t acc = 0;
+            for (int q = 0; q < nsteps; ++q) {
+                F.blk_start[q] = (int)acc;
+                const int k = t - q;
+                if (k >= 0 && k < NL) acc += blocks_for(r->h_level_start[k + 1] - r->h_level_start[k]);
+            }
+            F.blk_start[nsteps] = (int)acc;
+            if (2 * acc <= (int64_t)blocks_for(widest) * nsteps && acc < ((int64_t)1 << 31)) {
+                F.packed = 1;
+                grid = dim3((unsigned)std::max<int64_t>(acc, 1), 1);
+            }
+        }
         if (in && a->split)
             hipLaunchKernelGGL((k_fused_substeps<true, true>), grid, block, 0, s, F);
         else if (in)

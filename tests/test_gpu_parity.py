@@ -351,7 +351,7 @@ def test_routing_substeps_fused_wavefront(amd, solver, mode):
     m2.attach_router(g["codes"], g["mask"])
     m2.dynamic_fused(g["ToChanM3RunoffDt"])
     st = m2.river_router.last_launches()
-    assert st["launches"] == st["levels"] + n - 1
+    assert st["levels"] + n - 1 <= st["launches"] <= st["levels"] + n     # + the flag pass for isolated pixels
     keys = ["ChanQKin", "ChanM3Kin", "ChanQ", "sumDisDay", "FlowVelocity", "TravelDistance"]
     if split:
         keys += ["Chan2QKin", "Chan2M3Kin", "CrossSection2Area", "Sideflow1Chan"]
@@ -454,6 +454,48 @@ def test_routing_with_inloop_structures_golden(amd, solver, engine_order):
                 # volumes of 1e6..1e8 m3: the 1e-9 relative bar, with the Newton tolerance scaled by DtRouting as atol
                 np.testing.assert_allclose(getattr(v, k), g["out_" + k][i], rtol=RTOL, atol=1e-8, err_msg=str((s, k)))
     assert (v.LakeStorageM3[g["LakeIndex"]] == v.LakeStorageM3CC).all()
+
+
+def test_fused_wavefront_skips_only_true_fixed_points(amd, monkeypatch):
+    """Non-channel land pixels are isolated nodes of the channel router; the wavefront leaves them untouched while
+    their state is +0.0 and their parameters are regular.  Against the sub-step-by-sub-step engine (which skips
+    nothing) on a 30 %-channel scenario where some non-channel pixels still hold water, some have alpha = 0
+    (1/alpha = inf: the reference's arithmetic turns their zero state into NaN) and some a split-routing threshold."""
+    from lisflood_amd import synthetic as syn
+    from lisflood_amd.kinematic_wave_parallel import kinematicWave
+    from lisflood_amd.routing import _OUT, _STATE
+    from lisflood_amd.routing_device import RoutingStepDevice
+    H, W = 60, 70
+    N = H * W
+    values, sc, mask, _, ldd_kin = syn.hotpath_scenario(H, W)
+    rng = np.random.default_rng(3)
+    non = np.nonzero(~values["IsChannelKinematic"])[0]
+    wet, odd, thr = non[:20], non[20:30], non[30:40]
+    values["ChanQKin"][wet] = rng.uniform(1, 9, wet.size)
+    values["ChanM3Kin"][wet] = values["ChannelAlpha"][wet] * values["ChanLength"][wet] * values["ChanQKin"][wet] ** sc["Beta"]
+    values["ChannelAlpha"][odd] = 0.0
+    with np.errstate(divide="ignore"):
+        values["InvChannelAlpha"] = 1 / values["ChannelAlpha"]
+    values["QLimit"][thr] = 3.0
+    values["SideflowChanM3"] = syn.lateral_inflow(N, 0) * values["ChanLength"] * sc["DtRouting"]
+    kw = kinematicWave(ldd_kin, mask, values["ChannelAlpha"], sc["Beta"], values["ChanLength"], sc["DtRouting"],
+                       alpha_floodplains=values["ChannelAlpha2"])
+    nsteps = int(sc["NoRoutSteps"])
+    res = {}
+    for mode in ("fused", "sequential", "fused_noskip"):
+        if mode == "fused_noskip":
+            monkeypatch.setenv("LF_NO_INERT_SKIP", "1")
+        st = RoutingStepDevice(kw, values, True, sc["Beta"], 1 / sc["DtRouting"], sc["DtSec"])
+        for _ in range(2):
+            (st.run_sequential if mode == "sequential" else st.run_fused)(nsteps)
+        res[mode] = {k: st.download(k) for k in _STATE + _OUT}
+        st.free()
+    for k in _STATE + _OUT:
+        assert np.array_equal(res["fused"][k], res["sequential"][k], equal_nan=True), k
+        assert np.array_equal(res["fused"][k], res["fused_noskip"][k], equal_nan=True), k
+    assert np.isnan(res["fused"]["ChanQKin"][odd]).all() and (res["fused"]["ChanQKin"][wet] > 0).all()
+    assert (res["fused"]["ChanQKin"][non[40:]] == 0).all()
+    kw.close()
 
 
 def test_structures_inside_the_fused_wavefront(amd, solver):
