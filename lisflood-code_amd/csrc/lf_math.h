@@ -94,8 +94,11 @@ __device__ __forceinline__ double lf_solve_3_5(double c, double a)
     }
     double r = (double)rf;
     // fp64 Newton: 1e-7 -> 2e-14 -> rounding (third step is insurance for the worst start)
+#ifndef LF_SOLVE_F64_STEPS
+#define LF_SOLVE_F64_STEPS 3
+#endif
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < LF_SOLVE_F64_STEPS; ++i) {
         const double r2 = r * r, r3 = r2 * r;
         const double g = fma(r3, r2, fma(a, r3, -c));
         const double gp = r2 * fma(5.0, r2, 3.0 * a);
