@@ -244,7 +244,7 @@ def soil_bench(N=4_000_000, steps=10):
     return out
 
 
-def model_step_bench(size=5000, nsteps=24):
+def model_step_bench(size=5000, nsteps=24, family="deep"):
     """One LISFLOOD model step of channel routing on the `deep` raster: NoRoutSteps = 24 sub-steps, split routing
     (2 router calls per sub-step) = 48 cell-steps per cell, all vectors resident in engine order.
     `fused` = lf_routing_substeps_fused (one skewed wavefront), `sequential` = 24 x lf_routing_substep."""
@@ -254,7 +254,7 @@ def model_step_bench(size=5000, nsteps=24):
     from lisflood_amd.routing_device import RoutingStepDevice
     H = W = size
     N = H * W
-    codes = syn.make_ldd("deep", H, W, 2)
+    codes = syn.make_ldd(family, H, W, {"shallow": 1, "deep": 2}[family])
     p = syn.router_params(N)
     rng = np.random.default_rng(17)
     beta, dt = p["beta"], 3600.0
@@ -291,8 +291,8 @@ def model_step_bench(size=5000, nsteps=24):
                          unit="Mcell-steps/s", launches_per_model_step=kw.last_launches()["launches"] *
                          {"fused": 1, "sequential": 2 * nsteps, "sequential_single_sweep": nsteps}[mode])
         st.free()
-    out["config"] = "%dx%d deep LDD (NL=%d), NoRoutSteps=%d, split routing: %d cell-steps per cell per model step" % (
-        H, W, g.num_levels, nsteps, 2 * nsteps)
+    out["config"] = "%dx%d %s LDD (NL=%d), NoRoutSteps=%d, split routing: %d cell-steps per cell per model step" % (
+        H, W, family, g.num_levels, nsteps, 2 * nsteps)
     kw.close()
     return out
 
@@ -412,7 +412,9 @@ def main():
         print(json.dumps(hotpath_bench(min(a.size, 2000))), flush=True)
         return
     if a.only == "model_step":
-        print(json.dumps(model_step_bench(min(a.size, 5000))), flush=True)
+        # default: the 5000^2 deep raster; `--family shallow --size 10000` with --only model_step gives the wide-level case
+        explicit = any(x.startswith("--size") or x.startswith("--family") for x in sys.argv)
+        print(json.dumps(model_step_bench(a.size if explicit else 5000, family=a.family if explicit else "deep")), flush=True)
         return
     H = W = a.size
     if a.calibrate:
