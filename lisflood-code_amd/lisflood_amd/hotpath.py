@@ -166,6 +166,38 @@ class HotPathDevice:
         a = self.rmod._st["dev"][name].download()
         return self.rmod._down(a) if a.size == self.N and name not in RT._LAKE_STATE + RT._RES_STATE else a
 
+    # ---- warm start (the reference writes its state maps as end / state files, default_options.py:131-160) --------
+    # everything a stage reads back from the previous step: the in/out vectors of the canopy and soil kernels, the
+    # accumulators of the per-pixel aggregates, the overland and channel router states
+    STATE = tuple(dict.fromkeys(SL._CANOPY_IO + list(SL._V_IO) + PA._STATE + SR._STATE +
+                                ["OFM3Direct", "OFM3Other", "OFM3Forest"] + RT._STATE))
+
+    def state_names(self):
+        return [k for k in self.STATE if k in self.d]
+
+    def save_state(self, path):
+        """every state vector of the chain, pixel order, as one .npz (+ the site vectors of the structures)"""
+        out = {k: self.download(k) for k in self.state_names()}
+        if self.rmod is not None:
+            for k in RT._LAKE_STATE + RT._RES_STATE + ["TransCum"]:
+                if k in self.rmod._st["dev"]:
+                    out["site_" + k] = self.download_site(k)
+        out["steps_done"] = np.int64(self.steps_done)
+        np.savez(path, **out)
+
+    def load_state(self, path):
+        z = np.load(path)
+        chan = set(RT._STATIC + RT._STATE + RT._OUT)
+        for k in self.state_names():
+            a = z[k]
+            self.d[k].upload(f64(a[self.perm] if k in chan else a))
+        if self.rmod is not None:
+            for k in RT._LAKE_STATE + RT._RES_STATE + ["TransCum"]:
+                if "site_" + k in z.files:
+                    a = z["site_" + k]
+                    self.rmod._st["dev"][k].upload(f64(self.rmod._up(a) if k == "TransCum" else a))
+        self.steps_done = int(z["steps_done"])
+
     def chan_q_avg(self):
         """ChanQAvg = sumDisDay / NoRoutSteps (Lisflood_dynamic.py:209): the `dis` output of the reference."""
         return self.download("sumDisDay") / self.sc["NoRoutSteps"]

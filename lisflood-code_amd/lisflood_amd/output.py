@@ -1,0 +1,76 @@
+"""Time-series output in the reference's `.tss` layout (pcrcalc `timeoutput` style, global_modules/zusatz.py:196-290)
+and state snapshots of the resident hot path.
+
+A `.tss` file is text: one header line, the number of columns + 1, the word `timestep`, one line per outlet id, then
+one row per time step -- the step as ` %8g`, every value as ` %14g`, missing values as `1e31` right-aligned in 15
+characters.  The reference samples a map (e.g. ChanQAvg for `dis.tss`, Lisflood_dynamic.py:209 + output.py:565-575)
+at the pixels of an id map; `sample()` does that for a compressed vector.
+"""
+import time
+
+import numpy as np
+
+MISSING = "           1e31"
+
+
+def sample(vector, pixel_index):
+    """values of a compressed [N] vector at the outlet pixels (compressed indices, in id order)"""
+    return np.asarray(vector, dtype=np.float64)[np.asarray(pixel_index, dtype=np.int64)]
+
+
+def header_line(datatype="valuescale.scalar", settings_path="", date=None):
+    """zusatz.py:209-211"""
+    return "timeseries {} settingsfile: {} date: {}\n".format(datatype.lower(), settings_path,
+                                                              time.ctime(time.time()) if date is None else date)
+
+
+def write_tss(path, ids, first_timestep, values, header=True, datatype="valuescale.scalar", settings_path="", date=None,
+              first_line=None):
+    """ids: outlet ids (column order); values: [T, len(ids)] (NaN = missing); rows are numbered from first_timestep.
+    header=False reproduces the reference's `noheader` flag.  first_line overrides the generated header line."""
+    values = np.atleast_2d(np.asarray(values, dtype=np.float64))
+    ids = list(ids)
+    if values.shape[1] != len(ids):
+        raise ValueError("values must have one column per id")
+    with open(path, "w") as f:
+        if header:
+            f.write(first_line if first_line is not None else header_line(datatype, settings_path, date))
+            f.write(str(len(ids) + 1) + "\n")
+            f.write("timestep\n")
+            for c in ids:
+                f.write(str(c) + "\n")
+        for t in range(values.shape[0]):
+            row = " %8g" % (first_timestep + t)
+            for x in values[t]:
+                row += MISSING if x != x else " %14g" % x
+            f.write(row + "\n")
+
+
+def read_tss(path):
+    """-> (first line, ids, first_timestep, values[T, len(ids)])"""
+    with open(path) as f:
+        first = f.readline()
+        ncols = int(f.readline())
+        assert f.readline().strip() == "timestep"
+        ids = [int(f.readline()) for _ in range(ncols - 1)]
+        rows = [ln.split() for ln in f if ln.strip()]
+    steps = np.array([int(float(r[0])) for r in rows])
+    vals = np.array([[np.nan if x == "1e31" else float(x) for x in r[1:]] for r in rows], dtype=np.float64)
+    assert (np.diff(steps) == 1).all()
+    return first, ids, int(steps[0]), vals
+
+
+class TssWriter:
+    """Collects one row per model step and writes the file at the end, like TimeoutputTimeseries.sample() /
+    _writeTssFile (zusatz.py:246-290)."""
+
+    def __init__(self, path, ids, pixel_index, first_timestep=1, **header_kw):
+        self.path, self.ids, self.pix, self.first = path, list(ids), np.asarray(pixel_index, np.int64), first_timestep
+        self.rows, self.header_kw = [], header_kw
+
+    def sample(self, vector):
+        self.rows.append(sample(vector, self.pix))
+
+    def close(self):
+        write_tss(self.path, self.ids, self.first, np.array(self.rows).reshape(len(self.rows), len(self.ids)),
+                  **self.header_kw)

@@ -646,6 +646,31 @@ def test_resident_hot_path_with_structures(amd):
     hp.free()
 
 
+def test_hot_path_warm_start(amd, tmp_path):
+    """save_state after step 1 -> a fresh HotPathDevice + load_state must continue exactly like the original run
+    (with lakes / reservoirs in the loop, so the site vectors travel too)."""
+    from lisflood_amd import synthetic as syn
+    from lisflood_amd.hotpath import HotPathDevice
+    H, W = 48, 60
+    N = H * W
+    values, sc, mask, ldd_to_chan, ldd_kin = syn.hotpath_scenario(H, W)
+    st, cut = syn.structures_scenario(ldd_kin, (H, W), values["ChanQ"], sc["DtRouting"], n_lakes=3, n_res=5)
+    cp = lambda d: {k: (np.array(a, copy=True) if isinstance(a, np.ndarray) else a) for k, a in d.items()}
+    f = [syn.hotpath_forcing(N, s) for s in range(3)]
+    a = HotPathDevice(cp(values), sc, mask, ldd_to_chan, cut, split=True, structures=cp(st))
+    a.step(f[0], 1)
+    a.save_state(str(tmp_path / "state.npz"))
+    a.step(f[1], 2); a.step(f[2], 3)
+    b = HotPathDevice(cp(values), sc, mask, ldd_to_chan, cut, split=True, structures=cp(st))
+    b.load_state(str(tmp_path / "state.npz"))
+    b.step(f[1], 2); b.step(f[2], 3)
+    for k in a.state_names() + ["sumDisDay", "Infiltration", "ToChanM3RunoffDt"]:
+        assert np.array_equal(a.download(k), b.download(k), equal_nan=True), k
+    for k in ("LakeStorageM3CC", "ReservoirStorageM3CC", "LakeOutflowCC", "TransCum"):
+        assert np.array_equal(a.download_site(k), b.download_site(k)), k
+    a.free(); b.free()
+
+
 def test_interception_golden(amd):
     g = golden("interception")
     st = {k: g["in_" + k].copy() for k in ("Interception", "TaInterception", "LeafDrainage", "CumInterception")}

@@ -171,3 +171,24 @@ def test_graph_with_structure_links():
     bad[src] = int(down[src])
     with pytest.raises(Exception):
         Graph(cut, mask, virtual_down=bad)
+
+
+def test_tss_writer_reproduces_the_reference_file(tmp_path):
+    """The reference's own dis.tss (LF_ETRS89_UseCase/reference/output_reference_daily) parsed and written back must
+    be byte-identical: header layout, ` %8g` step column, ` %14g` values (zusatz.py:201-290)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "lisflood-code_amd"))
+    from lisflood_amd import output as O
+    src = os.path.join(ROOT, "tests", "golden", "etrs89_dis_reference.tss")
+    first, ids, t0, vals = O.read_tss(src)
+    assert len(ids) == 30 and t0 == 9497 and vals.shape == (216 - 33, 30) and np.isfinite(vals).all()
+    dst = tmp_path / "dis.tss"
+    O.write_tss(str(dst), ids, t0, vals, first_line=first)
+    assert open(src).read() == open(dst).read()
+    # missing values and the writer object
+    w = O.TssWriter(str(tmp_path / "x.tss"), [7, 9], [2, 0], first_timestep=5, date="D")
+    w.sample(np.array([1.5, 2.0, np.nan])); w.sample(np.array([1e-7, 2.0, 123456789.0]))
+    w.close()
+    txt = open(tmp_path / "x.tss").read().splitlines()
+    assert txt[0] == "timeseries valuescale.scalar settingsfile:  date: D" and txt[1:5] == ["3", "timestep", "7", "9"]
+    assert txt[5] == "        5           1e31            1.5" and txt[6] == "        6    1.23457e+08          1e-07"
