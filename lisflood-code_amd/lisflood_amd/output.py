@@ -74,3 +74,70 @@ class TssWriter:
     def close(self):
         write_tss(self.path, self.ids, self.first, np.array(self.rows).reshape(len(self.rows), len(self.ids)),
                   **self.header_kw)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Maps.  The reference writes netCDF-4 (zlib, chunks (1, H, W), netcdf.py:432-583); the image has no HDF5 writer, so
+# the same structure is written as netCDF-3 (classic, 64-bit offsets) through scipy: same dimensions
+# (time, y|lat, x|lon), coordinate variables, `_FillValue` = -9999, CF attributes -- files that netCDF4 / xarray
+# (and therefore the reference's own map reader) open like the originals; only compression and chunking differ.
+# ------------------------------------------------------------------------------------------------------------------
+FILL = -9999.0
+
+
+def decompress(vector, land_mask, fill=FILL):
+    """compressed [N] vector -> [H, W] map, `fill` outside the land mask (add1.py:285-305)"""
+    land_mask = np.asarray(land_mask, bool)
+    out = np.full(land_mask.shape, fill, dtype=np.float64)
+    out[land_mask] = np.asarray(vector, dtype=np.float64)
+    return out
+
+
+def write_netcdf_classic(path, var_name, maps, x, y, time_values=None, time_units="days since 1990-01-01 00:00:00.0",
+                         calendar="proleptic_gregorian", dtype="f8", standard_name="", long_name="", units="",
+                         dims=("y", "x"), settings_path=""):
+    """maps: [H, W] (a state / end map) or [T, H, W] with time_values[T] (netcdf.py:552-570); NaN -> _FillValue."""
+    from scipy.io import netcdf_file
+    maps = np.asarray(maps, dtype=np.float64)
+    timed = maps.ndim == 3
+    if timed and (time_values is None or len(time_values) != maps.shape[0]):
+        raise ValueError("a [T, H, W] stack needs time_values[T]")
+    H, W = maps.shape[-2:]
+    if len(y) != H or len(x) != W:
+        raise ValueError("coordinate vectors do not match the map shape")
+    dy, dx = dims
+    f = netcdf_file(path, "w", version=2)
+    f.settingsfile = settings_path
+    f.date_created = time.ctime(time.time())
+    f.Source_Software = "lisflood_amd"
+    f.source = "Lisflood output maps"
+    f.keywords = "Lisflood, EFAS, GLOFAS"
+    f.Conventions = "CF-1.6"
+    f.createDimension(dx, W)
+    vx = f.createVariable(dx, "f8", (dx,)); vx[:] = np.asarray(x, np.float64)
+    f.createDimension(dy, H)
+    vy = f.createVariable(dy, "f8", (dy,)); vy[:] = np.asarray(y, np.float64)
+    if timed:
+        f.createDimension("time", maps.shape[0])
+        vt = f.createVariable("time", "f8", ("time",))
+        vt.standard_name = "time"; vt.calendar = calendar; vt.units = time_units
+        vt[:] = np.asarray(time_values, np.float64)
+        v = f.createVariable(var_name, dtype, ("time", dy, dx))
+    else:
+        v = f.createVariable(var_name, dtype, (dy, dx))
+    v._FillValue = np.array(FILL, dtype=dtype)
+    v.standard_name, v.long_name, v.units = standard_name, long_name, units
+    v[:] = np.where(np.isnan(maps), FILL, maps).astype(dtype)
+    f.close()
+
+
+def read_netcdf_classic(path, var_name):
+    """-> (maps with NaN at _FillValue, x, y, time or None)"""
+    from scipy.io import netcdf_file
+    with netcdf_file(path, "r", mmap=False) as f:
+        v = f.variables[var_name]
+        a = np.array(v[:], dtype=np.float64)
+        a[a == float(v._FillValue)] = np.nan
+        dy, dx = v.dimensions[-2:]
+        t = np.array(f.variables["time"][:]) if "time" in f.variables else None
+        return a, np.array(f.variables[dx][:]), np.array(f.variables[dy][:]), t

@@ -192,3 +192,25 @@ def test_tss_writer_reproduces_the_reference_file(tmp_path):
     txt = open(tmp_path / "x.tss").read().splitlines()
     assert txt[0] == "timeseries valuescale.scalar settingsfile:  date: D" and txt[1:5] == ["3", "timestep", "7", "9"]
     assert txt[5] == "        5           1e31            1.5" and txt[6] == "        6    1.23457e+08          1e-07"
+
+
+def test_netcdf_classic_maps_round_trip(tmp_path):
+    """dis-style [T, H, W] stack and a single state map written in the reference's structure (netcdf.py:432-583:
+    time / y / x, _FillValue -9999 outside the land mask) and read back."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "lisflood-code_amd"))
+    from lisflood_amd import output as O
+    rng = np.random.default_rng(0)
+    mask = rng.random((7, 9)) > 0.3
+    N = int(mask.sum())
+    x, y = 4e6 + 5000.0 * np.arange(9), 3e6 - 5000.0 * np.arange(7)
+    stack = np.stack([O.decompress(rng.random(N), mask) for _ in range(4)])
+    O.write_netcdf_classic(str(tmp_path / "dis.nc"), "dis", np.where(stack == O.FILL, np.nan, stack), x, y,
+                           time_values=[1, 2, 3, 4], standard_name="dis", long_name="discharge", units="m3/s")
+    a, rx, ry, t = O.read_netcdf_classic(str(tmp_path / "dis.nc"), "dis")
+    assert np.array_equal(rx, x) and np.array_equal(ry, y) and np.array_equal(t, [1, 2, 3, 4])
+    assert np.array_equal(np.isnan(a), np.broadcast_to(~mask, a.shape)) and np.array_equal(a[:, mask], stack[:, mask])
+    O.write_netcdf_classic(str(tmp_path / "ch.nc"), "chanq", O.decompress(np.arange(N), mask, np.nan), x, y)
+    b, _, _, t = O.read_netcdf_classic(str(tmp_path / "ch.nc"), "chanq")
+    assert t is None and np.array_equal(b[mask], np.arange(N)) and np.isnan(b[~mask]).all()
+    assert open(tmp_path / "dis.nc", "rb").read(4) == b"CDF\x02"
