@@ -378,6 +378,8 @@ int lf_dist_graph_finalize(lf_dist_graph *g, int nphases);
 int64_t lf_dist_graph_state_size(const lf_dist_graph *g); /* N local cells + ghost slots */
 int lf_dist_graph_num_phases(const lf_dist_graph *g);
 int64_t lf_dist_graph_num_launch_units(const lf_dist_graph *g);
+/* cells whose upstream positions are not consecutive in the sweep order (they read through the index list) */
+int64_t lf_dist_graph_num_noncontiguous(const lf_dist_graph *g);
 int lf_dist_graph_get_layout(const lf_dist_graph *g, int32_t *perm, int32_t *phase_of_position);
 int lf_dist_graph_get_csr(const lf_dist_graph *g, int32_t *ups_ptr, int32_t *ups_idx, int64_t *n_edges);
 int lf_dist_graph_phase_range(const lf_dist_graph *g, int phase, int64_t out[2]);

@@ -21,6 +21,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "lf_sweep.h"
@@ -46,6 +47,8 @@ struct lf_dist_graph {
     // finalized layout
     std::vector<int32_t> perm, pos;       // position <-> local id
     std::vector<int32_t> ups_ptr, ups_idx;
+    std::vector<int32_t> ups_base;        // [N] first upstream position when they are consecutive, else -1 (-> ups_idx)
+    int64_t n_noncontiguous = 0;
     std::vector<int64_t> level_start;     // launch units: runs of equal (phase, height)
     std::vector<int32_t> phase_level;     // [nphases+1] first launch unit of each phase
     std::vector<int32_t> export_pos[2];   // positions of exports sorted by (phase, column)
@@ -178,6 +181,7 @@ int lf_dist_graph_create(const uint8_t *ldd_local, const uint8_t *mask_local, in
     for (int64_t p = 0; p < n; ++p)
         if (g->down[p] < 0) queue[tail++] = (int32_t)p;
     int32_t gen = 0;
+    std::vector<int64_t> gen_start(1, 0);
     while (head < tail) {
         const int64_t gen_end = tail;
         for (; head < gen_end; ++head) {
@@ -185,6 +189,7 @@ int lf_dist_graph_create(const uint8_t *ldd_local, const uint8_t *mask_local, in
             g->height[p] = gen;
             for (int32_t e = g->uptr[p]; e < g->uptr[p + 1]; ++e) queue[tail++] = g->uidx[e];
         }
+        gen_start.push_back(gen_end);
         ++gen;
     }
     if (tail != n) {
@@ -192,7 +197,11 @@ int lf_dist_graph_create(const uint8_t *ldd_local, const uint8_t *mask_local, in
         return lf_set_error(LF_E_CYCLE, "LDD has a cycle inside the row block");
     }
     for (int64_t p = 0; p < n; ++p) g->height[p] = (gen - 1) - g->height[p]; // level: every local upstream cell is one lower
-    g->topo.assign(queue.rbegin(), queue.rend());
+    // generations from the farthest to the outlets, each in its breadth-first order: the children of consecutive cells
+    // are consecutive AND ascending in pixel id, so a cell's upstream positions are one ascending run
+    g->topo.clear();
+    g->topo.reserve(n);
+    for (int32_t k = gen - 1; k >= 0; --k) g->topo.insert(g->topo.end(), queue.begin() + gen_start[k], queue.begin() + gen_start[k + 1]);
     g->phase.assign(n, 0);
     local_phases(g);
     *out = g;
@@ -338,9 +347,26 @@ int lf_dist_graph_finalize(lf_dist_graph *g, int nphases)
         for (size_t i = 0; i < g->ghost_target[1].size(); ++i) // row below, ascending column
             g->ups_idx[cursor[g->ghost_target[1][i]]++] = (int32_t)(n + ghost_slot[1][i]);
     }
+    // the (phase, level, breadth-first rank) order leaves the upstream positions of nearly every cell consecutive:
+    // those cells read their inflow as a coalesced run, only the others (ghost or cross-phase inflow) go through the list
+    g->ups_base.assign(n, 0);
+    g->n_noncontiguous = 0;
+    for (int64_t p = 0; p < n; ++p) {
+        const int32_t a = g->ups_ptr[p], b = g->ups_ptr[p + 1];
+        int32_t base = (b > a) ? g->ups_idx[a] : 0;
+        for (int32_t k = a; k < b; ++k)
+            if (g->ups_idx[k] != base + (k - a)) {
+                base = -1;
+                break;
+            }
+        g->ups_base[p] = base;
+        g->n_noncontiguous += base < 0;
+    }
     g->finalized = true;
     return LF_OK;
 }
+
+int64_t lf_dist_graph_num_noncontiguous(const lf_dist_graph *g) { return g ? g->n_noncontiguous : -1; }
 
 int64_t lf_dist_graph_state_size(const lf_dist_graph *g)
 {
@@ -536,7 +562,7 @@ struct lf_dist_router {
     int nphases = 1, kmax = 8;
     double beta = 0, inv_beta = 0, b_minus_1 = 0, dx_scalar = 0;
     bool has_floodplains = false, dx_per_pixel = false, fused = false;
-    lf_dbuf<int32_t> perm, ups_ptr, ups_idx, export_pos[2];
+    lf_dbuf<int32_t> perm, ups_ptr, ups_idx, ups_base, export_pos[2];
     lf_dbuf<long long> level_start;
     lf_dbuf<double> a1, a2, dx, constant, sendbuf[2];
     std::vector<int64_t> h_level_start;
@@ -559,6 +585,7 @@ int dist_compute_phase(lf_dist_router *r, double *q, const double *lat, int sect
     sweep_args A;
     A.ups_ptr = r->ups_ptr.p;
     A.ups_idx = r->ups_idx.p;
+    A.ups_base = r->ups_base.p;
     A.perm = nullptr;
     A.a = section == LF_SECTION_MAIN ? r->a1.p : r->a2.p;
     A.constant = r->constant.p;
@@ -666,6 +693,14 @@ int lf_dist_router_create(const lf_dist_graph *g, const double *alpha, double be
     if (rc == LF_OK) rc = r->perm.upload(g->perm.data(), n);
     if (rc == LF_OK) rc = r->ups_ptr.upload(g->ups_ptr.data(), n + 1);
     if (rc == LF_OK) rc = r->ups_idx.upload(g->ups_idx.data(), g->ups_idx.size());
+    if (rc == LF_OK) {
+        const char *e = std::getenv("LF_DIST_ALL_INDEXED"); // A/B switch: every cell through the index list
+        if (e && e[0] == '1') {
+            std::vector<int32_t> none(g->ups_base.size(), -1);
+            rc = r->ups_base.upload(none.data(), none.size());
+        } else
+            rc = r->ups_base.upload(g->ups_base.data(), g->ups_base.size());
+    }
     if (rc == LF_OK) {
         std::vector<long long> ls(g->level_start.begin(), g->level_start.end());
         rc = r->level_start.upload(ls.data(), ls.size());

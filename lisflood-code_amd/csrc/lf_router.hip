@@ -235,6 +235,7 @@ int enqueue_route(lf_router *r, double *q_dev, const double *lat_dev, int sectio
     sweep_args A;
     A.ups_ptr = r->ups_ptr.p;
     A.ups_idx = nullptr;
+    A.ups_base = nullptr;
     A.perm = r->perm.p;
     A.a = a;
     A.constant = r->constant.p;

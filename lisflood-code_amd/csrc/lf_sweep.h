@@ -59,6 +59,7 @@ __global__ void __launch_bounds__(kBlock) k_prep(int n, const int *__restrict__ 
 struct sweep_args {
     const int *__restrict__ ups_ptr;
     const int *__restrict__ ups_idx;     // INDEXED only: upstream positions (may point into the ghost slots)
+    const int *__restrict__ ups_base;    // INDEXED only: first upstream position if they are consecutive, else -1
     const int *__restrict__ perm;        // pixel-order I/O only
     const double *__restrict__ a;        // alpha*dx/dt, sweep order
     const double *__restrict__ constant; // general path: written by k_prep
@@ -99,13 +100,13 @@ __device__ __forceinline__ void sweep_cell(int p, const sweep_args &A)
     // at most 8 upstream neighbours: all candidate loads are issued at once (predicated) instead of a
     // dependent load per loop trip; missing ones contribute +0.0, which leaves the sum bit-identical.
     double v[8];
+    const int base = INDEXED ? A.ups_base[p] : u0;
+    if (!INDEXED || base >= 0) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const bool on = k < A.kmax && u0 + k < u1;
-        if (INDEXED)
-            v[k] = on ? A.qord[A.ups_idx[u0 + k]] : 0.0;
-        else
-            v[k] = on ? A.qord[u0 + k] : 0.0;
+        for (int k = 0; k < 8; ++k) v[k] = (k < A.kmax && u0 + k < u1) ? A.qord[base + k] : 0.0;
+    } else { // ghost or cross-phase inflow: positions from the list (a second, dependent load)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (k < A.kmax && u0 + k < u1) ? A.qord[A.ups_idx[u0 + k]] : 0.0;
     }
     double ups = 0.0;
 #pragma unroll

@@ -43,6 +43,7 @@ class DistGraph:
         L.lf_dist_graph_num_pixels.restype = C.c_int64
         L.lf_dist_graph_state_size.restype = C.c_int64
         L.lf_dist_graph_num_launch_units.restype = C.c_int64
+        L.lf_dist_graph_num_noncontiguous.restype = C.c_int64
         L.lf_dist_graph_round_recv_slot.restype = C.c_int64
         self.num_pixels = int(L.lf_dist_graph_num_pixels(self._h))
         c = (C.c_int64 * 4)()
@@ -75,6 +76,7 @@ class DistGraph:
         self.num_phases = nphases
         self.state_size = int(lib().lf_dist_graph_state_size(self._h))
         self.num_launch_units = int(lib().lf_dist_graph_num_launch_units(self._h))
+        self.num_noncontiguous = int(lib().lf_dist_graph_num_noncontiguous(self._h))
 
     # --- plan getters -----------------------------------------------------------------------------
     def layout(self):

@@ -59,9 +59,9 @@ def main(a):
     nq = 3
     qs = [router.new_state(syn.lateral_inflow_slice(N, s, i0, i1)) for s in range(nq)]
     _lib.synchronize(device)
-    log(rank, "rows [%d,%d) cells=%d phases=%d launch_units=%d ghosts=%s exports=%s setup %.1f s"
-        % (r0, r1, graph.num_pixels, graph.num_phases, graph.num_launch_units, graph.n_ghost, graph.n_export,
-           time.time() - t_setup))
+    log(rank, "rows [%d,%d) cells=%d phases=%d launch_units=%d ghosts=%s exports=%s non-contiguous inflow: %d cells; "
+        "setup %.1f s" % (r0, r1, graph.num_pixels, graph.num_phases, graph.num_launch_units, graph.n_ghost,
+                          graph.n_export, graph.num_noncontiguous, time.time() - t_setup))
     for s in range(a.warmup):
         router.route(Q, qs[s % nq])
     _lib.synchronize(device)
