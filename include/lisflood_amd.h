@@ -318,7 +318,8 @@ int lf_inloop_structures(int device, const lf_inloop_args *a);
  * structures' outflow) and a one-lane-per-site kernel runs each lake / reservoir for sub-step s = t - level(site)
  * right before launch t.  Needs: engine_order = 1 everywhere (`in` holds engine-order vectors and site lists in
  * engine positions, `in->step` is ignored), and a router whose graph was built by lf_graph_create_ex with the
- * uncut links of the structures (every cell feeding a site on the site's level; checked).  Bit-identical to the
+ * uncut links of the structures (every cell feeding a site on the site's level; checked once per set of device
+ * site lists, whose contents must not change afterwards).  Bit-identical to the
  * sub-step-by-sub-step sequence lf_inloop_structures + lf_routing_substep. */
 int lf_routing_substeps_fused_structures(lf_router *r, const lf_substep_args *a, const lf_inloop_args *in, int nsteps);
 

@@ -123,6 +123,9 @@ struct lf_router {
     lf_dbuf<uint8_t> inert;    // [N] per fused call: isolated, not a channel, zero split-routing thresholds
     int64_t n_isolated = 0;
     lf_dbuf<int> site_level; // levels of the lake and reservoir cells of the last fused-with-structures call
+    std::vector<int> site_level_sorted;
+    const void *site_key[4] = {nullptr, nullptr, nullptr, nullptr}; // the site lists those levels were checked for
+    int64_t site_cnt[2] = {-1, -1};
     std::vector<int64_t> h_level_start;
     std::vector<segment> schedule;
     int64_t last_stats[4] = {0, 0, 0, 0};
@@ -1081,7 +1084,13 @@ int fused_impl(lf_router *r, const lf_substep_args *a, int nsteps, int64_t sidef
             return lf_set_error(LF_E_INVALID, "lf_inloop_args: ToChanM3RunoffDt, SideflowChanM3 and N = num_pixels are needed");
         I.ChanQ = a->ChanQ;
         nsites = I.n_lakes + I.n_res;
-        if (nsites > 0) {
+        const void *key[4] = {I.lake_cell, I.lake_ups_idx, I.res_cell, I.res_ups_idx};
+        const bool checked = nsites > 0 && r->site_level.p && r->site_cnt[0] == I.n_lakes && r->site_cnt[1] == I.n_res &&
+                             std::memcmp(key, r->site_key, sizeof(key)) == 0;
+        if (checked) { // same device lists as the last call: levels already validated and resident
+            F.site_level = r->site_level.p;
+            lv_sorted = r->site_level_sorted;
+        } else if (nsites > 0) {
             auto level_of = [&](int pos) {
                 return (int)(std::upper_bound(r->h_level_start.begin(), r->h_level_start.end(), (int64_t)pos) -
                              r->h_level_start.begin()) - 1;
@@ -1113,6 +1122,10 @@ int fused_impl(lf_router *r, const lf_substep_args *a, int nsteps, int64_t sidef
             F.site_level = r->site_level.p;
             lv_sorted = lv;
             std::sort(lv_sorted.begin(), lv_sorted.end());
+            r->site_level_sorted = lv_sorted;
+            std::memcpy(r->site_key, key, sizeof(key));
+            r->site_cnt[0] = I.n_lakes;
+            r->site_cnt[1] = I.n_res;
         }
     }
     int64_t launches = 0;

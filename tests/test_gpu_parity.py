@@ -85,6 +85,42 @@ def test_route_edge_cases_golden(amd, solver):
     close(Q, g["Q_alpha_zero"])
 
 
+def test_route_random_rasters_vs_oracle(amd, oracle):
+    """Ragged inputs: 24 random rasters (1 x 1 up to 40 x 40, random land masks, extra pits, non-channel cells,
+    single rows / columns), beta = 3/5 and a general beta, zero and large discharge, negative lateral inflow --
+    graph attributes and three consecutive router calls against the oracle."""
+    from lisflood_amd import synthetic as syn
+    rng = np.random.default_rng(77)
+    shapes = [(1, 1), (1, 17), (23, 1), (2, 2)] + [(int(rng.integers(3, 41)), int(rng.integers(3, 41))) for _ in range(20)]
+    for i, (H, W) in enumerate(shapes):
+        mask = rng.random((H, W)) < rng.uniform(0.5, 1.0)
+        if not mask.any():
+            mask[0, 0] = True
+        raster = syn.make_ldd("shallow" if i % 2 else "deep", H, W, 100 + i, land_mask=mask)
+        codes = raster[mask].astype(np.float64)
+        r = rng.random(codes.size)
+        codes[r < 0.08] = 5.0            # extra pits
+        codes[(r >= 0.08) & (r < 0.16)] = 0.0   # non-channel cells of a channel LDD
+        N = codes.size
+        beta = 0.6 if i % 3 else 0.72
+        p = syn.router_params(N, seed=200 + i, beta=beta)
+        Q0 = p["Q0"].copy()
+        Q0[rng.random(N) < 0.2] = 0.0
+        Q0[rng.random(N) < 0.05] *= 1e4
+        dx = p["dx"] if i % 4 else 2500.0
+        gpu = amd.kw.kinematicWave(codes, mask, p["alpha"], beta, dx, p["dt"])
+        cpu = oracle.kinematicWave(codes, mask, p["alpha"], beta, dx, p["dt"])
+        assert np.array_equal(gpu.downstream_lookup, cpu.downstream_lookup)
+        assert np.array_equal(gpu.pixels_ordered, cpu.pixels_ordered) and np.array_equal(gpu.order_start_stop, cpu.order_start_stop)
+        Qg, Qc = Q0.copy(), Q0.copy()
+        for s in range(3):
+            q = syn.lateral_inflow(N, 300 + s) - (1e-4 if s == 1 else 0.0)     # partly negative in the second call
+            gpu.kinematicWaveRouting(Qg, q); cpu.kinematicWaveRouting(Qc, q)
+            close(Qg, Qc, (i, H, W, beta, s))
+        assert (Qg >= 0).all()
+        gpu.close()
+
+
 def test_route_scalar_dx_and_device_form_vs_oracle(amd, oracle):
     from lisflood_amd import synthetic as syn
     H, W = 120, 90
