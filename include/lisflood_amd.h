@@ -170,6 +170,9 @@ typedef struct lf_substep_args {
  * sumDisDay, FlowVelocity/TravelDistance.  All pointers are device memory, all in the same order
  * (pixel order, or engine order when engine_order = 1). */
 int lf_routing_substep(lf_router *r, const lf_substep_args *a);
+/* its three element-wise stages on their own (0: sideflow assembly, 1: main-channel fix-up + sums, 2: floodplain
+ * fix-up) over n cells, for callers that run the router calls in between (lf_dist_routing_substep) */
+int lf_substep_stage(int device, int stage, int64_t n, const lf_substep_args *a);
 /* nsteps consecutive sub-steps as one skewed wavefront over (level, sub-step): NL + nsteps - 1 launches
  * instead of nsteps x (1..2) x NL.  Needs engine_order = 1.  a->SideflowChanM3 holds the sideflow of every
  * sub-step: sideflow_stride = 0 (one vector used by all sub-steps) or N (nsteps vectors back to back).
@@ -406,6 +409,10 @@ int lf_dist_router_from_engine_order(lf_dist_router *r, const double *src_ord_de
  * rank_bottom = -1 at the raster's edge.  Asynchronous on the library stream. */
 int lf_dist_router_route(lf_dist_router *r, lf_comm *comm, double *q_ord_dev, const double *lat_ord_dev, int section,
                          int rank_top, int rank_bottom);
+/* One routing.dynamic() sub-step on the partition (= lf_routing_substep on the whole raster): element-wise stages on
+ * the rank's own N cells, each router call with its halo exchanges.  engine_order = 1 (the rank's engine order);
+ * a->ChanQKin and a->Chan2QKin are state vectors (lf_dist_router_state_size entries), all others have N entries. */
+int lf_dist_routing_substep(lf_dist_router *r, lf_comm *comm, const lf_substep_args *a, int rank_top, int rank_bottom);
 /* the pieces of a call, for transports other than RCCL and for tests */
 int lf_dist_router_compute_phase(lf_dist_router *r, double *q_ord_dev, const double *lat_ord_dev, int section,
                                  int phase);

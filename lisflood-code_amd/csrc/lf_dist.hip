@@ -860,4 +860,24 @@ int lf_dist_router_route(lf_dist_router *r, lf_comm *comm, double *q_ord_dev, co
     return LF_OK;
 }
 
+// One routing.dynamic() sub-step (routing.py:512-603, 693-703) on the row-block partition: the element-wise stages run
+// on the rank's own cells, each router call is lf_dist_router_route (sweeps + halo exchange per phase).  All vectors
+// in the rank's engine order; ChanQKin and Chan2QKin are STATE vectors (lf_dist_router_state_size entries, ghost slots
+// behind the N local cells), every other vector has N entries.  Equals lf_routing_substep on the whole raster.
+int lf_dist_routing_substep(lf_dist_router *r, lf_comm *comm, const lf_substep_args *a, int rank_top, int rank_bottom)
+{
+    if (!r || !a) return lf_set_error(LF_E_INVALID, "null argument");
+    if (!a->engine_order) return lf_set_error(LF_E_INVALID, "the partitioned sub-step needs engine-order vectors");
+    if (a->split && !r->has_floodplains)
+        return lf_set_error(LF_E_SECTION, "split routing requested but the router has no floodplain alpha");
+    LF_TRY(lf_substep_stage(r->device, 0, r->N, a));
+    LF_TRY(lf_dist_router_route(r, comm, a->ChanQKin, a->scratch0, LF_SECTION_MAIN, rank_top, rank_bottom));
+    LF_TRY(lf_substep_stage(r->device, 1, r->N, a));
+    if (a->split) {
+        LF_TRY(lf_dist_router_route(r, comm, a->Chan2QKin, a->scratch1, LF_SECTION_FLOODPLAINS, rank_top, rank_bottom));
+        LF_TRY(lf_substep_stage(r->device, 2, r->N, a));
+    }
+    return LF_OK;
+}
+
 } // extern "C"

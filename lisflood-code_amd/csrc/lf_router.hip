@@ -752,6 +752,26 @@ __global__ void __launch_bounds__(kBlock) k_substep_floodplain(int n, lf_substep
 
 } // namespace
 
+// The three element-wise stages of a sub-step on their own (stage 0: sideflow assembly, 1: main-channel fix-up and
+// discharge sums, 2: floodplain fix-up), for callers that run the router calls in between themselves -- the row-block
+// partition (lf_dist_routing_substep) does, with halo exchanges inside each router call.
+extern "C" int lf_substep_stage(int device, int stage, int64_t n, const lf_substep_args *a)
+{
+    if (!a || stage < 0 || stage > 2 || n < 0) return lf_set_error(LF_E_INVALID, "bad argument");
+    lf_device_ctx *c;
+    LF_TRY(lf_ctx(device, &c));
+    if (n == 0) return LF_OK;
+    const dim3 grid(blocks_for(n)), block(kBlock);
+    if (stage == 0)
+        hipLaunchKernelGGL(k_substep_sideflow, grid, block, 0, c->stream, (int)n, *a);
+    else if (stage == 1)
+        hipLaunchKernelGGL(k_substep_main, grid, block, 0, c->stream, (int)n, *a);
+    else
+        hipLaunchKernelGGL(k_substep_floodplain, grid, block, 0, c->stream, (int)n, *a);
+    LF_HIP(hipGetLastError());
+    return LF_OK;
+}
+
 extern "C" int lf_routing_substep(lf_router *r, const lf_substep_args *a)
 {
     if (!r || !a) return lf_set_error(LF_E_INVALID, "null argument");

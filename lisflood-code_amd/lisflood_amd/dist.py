@@ -289,6 +289,79 @@ class DistRouter:
             pass
 
 
+class DistRoutingStep:
+    """One rank's vectors of routing.dynamic() (routing.py:435-706) on the partition, resident in the rank's engine
+    order.  `substep()` = lf_dist_routing_substep (RCCL halo inside each router call); `stage(i)` runs one of the
+    element-wise stages alone (the in-process loopback drives the router calls itself)."""
+
+    def __init__(self, router, values, split, Beta, InvDtRouting, DtSec):
+        """values: name -> host vector of the rank's cells in local pixel order (names of lf_substep_args)."""
+        from .routing import _OUT, _STATE, _STATIC, _SubstepArgs
+        self.router, self.split, self.device = router, bool(split), router.device
+        N = self.N = router.num_pixels
+        self.perm = router.graph.layout()[0].astype(np.int64)
+        self.dev = {}
+        zeros = np.zeros(N)
+        for k in _STATIC + _STATE:
+            x = values.get(k)
+            if x is None:
+                x = np.ones(N, bool) if k == "IsChannelKinematic" else zeros
+            x = np.broadcast_to(x, (N,))[self.perm]
+            if k in ("ChanQKin", "Chan2QKin"):          # router state vectors: ghost slots behind the N cells
+                st = DeviceArray(max(router.state_size, 1), np.float64, self.device).zero()
+                _upload_prefix(st, f64(x), self.device)
+                self.dev[k] = st
+            else:
+                self.dev[k] = DeviceArray.from_host(_lib.u8(x) if k == "IsChannelKinematic" else f64(x), self.device)
+        for k in _OUT + ["scratch0", "scratch1"]:
+            self.dev[k] = DeviceArray(max(N, 1), np.float64, self.device).zero()
+        side = np.broadcast_to(values.get("SideflowChanM3", zeros), (N,))[self.perm]
+        self.dev["SideflowChanM3"] = DeviceArray.from_host(f64(side), self.device)
+        a = self.args = _SubstepArgs()
+        for k, d in self.dev.items():
+            setattr(a, k, d.ptr.value)
+        a.Beta, a.InvBeta, a.InvDtRouting, a.DtSec = float(Beta), 1.0 / float(Beta), float(InvDtRouting), float(DtSec)
+        a.split, a.engine_order = (1 if self.split else 0), 1
+
+    def substep(self):
+        r = self.router
+        ch = r.comm._h if r.comm is not None else None
+        check(lib().lf_dist_routing_substep(r._h, ch, C.byref(self.args), C.c_int(r.rank_top), C.c_int(r.rank_bottom)))
+
+    def stage(self, i):
+        check(lib().lf_substep_stage(C.c_int(self.device), C.c_int(i), C.c_int64(self.N), C.byref(self.args)))
+
+    def download(self, name):
+        out = np.empty(self.N)
+        out[self.perm] = self.dev[name].download()[:self.N]
+        return out
+
+    def free(self):
+        for d in self.dev.values():
+            d.free()
+        self.dev = {}
+
+
+def _upload_prefix(dst, host, device):
+    """host vector -> the first host.size entries of a larger device array"""
+    if host.size:
+        check(lib().lf_memcpy_h2d(C.c_int(device), dst.ptr, ptr(host), C.c_size_t(host.nbytes)))
+
+
+def loopback_substep(steps):
+    """One routing sub-step over blocks that all live on one GPU (see loopback_route)."""
+    routers = [s.router for s in steps]
+    for s in steps:
+        s.stage(0)
+    loopback_route(routers, [s.dev["ChanQKin"] for s in steps], [s.dev["scratch0"] for s in steps], "main_channel")
+    for s in steps:
+        s.stage(1)
+    if steps[0].split:
+        loopback_route(routers, [s.dev["Chan2QKin"] for s in steps], [s.dev["scratch1"] for s in steps], "floodplains")
+        for s in steps:
+            s.stage(2)
+
+
 def loopback_route(routers, q_states, lat_states, section="main_channel"):
     """One call over blocks that all live on ONE GPU in ONE process: the halo exchange is a device-to-device
     copy instead of RCCL Send/Recv.  Exercises exactly the kernels and the plan of the multi-GPU path."""

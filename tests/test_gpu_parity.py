@@ -791,6 +791,65 @@ def test_row_block_partition_loopback(amd, oracle, solver, family, seed, nblocks
     assert nph >= (nblocks if family == "deep" else 2)
 
 
+@pytest.mark.parametrize("family,nblocks", [("deep", 3), ("shallow", 4)])
+def test_row_block_routing_substep_loopback(amd, family, nblocks):
+    """A whole routing.dynamic() sub-step (sideflow assembly, two router calls with their halo exchanges, fix-ups, sums)
+    on the row-block partition -- nblocks routers on one GPU, exchange by device copy -- against lf_routing_substep on
+    the whole raster: bit-identical state after 4 split-routing sub-steps."""
+    from lisflood_amd import dist as D
+    from lisflood_amd import synthetic as syn
+    from lisflood_amd.kinematic_wave_parallel import Graph, kinematicWave
+    from lisflood_amd.routing import _OUT, _STATE
+    from lisflood_amd.routing_device import RoutingStepDevice
+    H, W = 150, 130
+    N = H * W
+    codes = syn.make_ldd(family, H, W, 2 if family == "deep" else 1)
+    p = syn.router_params(N, seed=6)
+    rng = np.random.default_rng(19)
+    beta, dt, nsteps = p["beta"], 3600.0, 4
+    alpha, length = p["alpha"], p["dx"]
+    alpha2 = alpha * rng.uniform(1.2, 2.0, N)
+    qlimit = 2.0 * p["Q0"] * rng.uniform(0.3, 1.2, N)
+    vals = dict(ChanLength=length, InvChanLength=1 / length, ChannelAlpha=alpha, InvChannelAlpha=1 / alpha,
+                ChannelAlpha2=alpha2, InvChannelAlpha2=1 / alpha2, QLimit=qlimit, M3Limit=alpha * length * qlimit ** beta,
+                Chan2M3Start=alpha2 * length * qlimit ** beta, Chan2QStart=qlimit * 0.1, PixelArea=np.full(N, 2.5e7),
+                IsChannelKinematic=rng.random(N) < 0.9, SideflowChanM3=syn.lateral_inflow(N, 0) * length * dt)
+    vals["Chan2M3Kin"] = vals["Chan2M3Start"].copy()
+    vals["ChanM3Kin"] = alpha * length * p["Q0"] ** beta
+    vals["ChanQKin"] = p["Q0"].copy()
+    vals["Chan2QKin"] = (vals["Chan2M3Kin"] / length / alpha2) ** (1 / beta)
+    # whole raster
+    kw = kinematicWave(None, None, alpha, beta, length, dt, alpha_floodplains=alpha2, graph=Graph(ldd_raster=codes))
+    ref = RoutingStepDevice(kw, vals, True, beta, 1 / dt, dt * nsteps)
+    ref.run_sequential(nsteps)
+    # row blocks
+    blocks = D.row_blocks(H, nblocks)
+    graphs = [D.DistGraph(codes[r0:r1], None, codes[r0 - 1] if r0 > 0 else None, None,
+                          codes[r1] if r1 < H else None, None) for (r0, r1) in blocks]
+    D.settle_phases_local(graphs)
+    sl = [slice(r0 * W, r1 * W) for (r0, r1) in blocks]
+    routers = [D.DistRouter(g, alpha[s], beta, length[s], dt, alpha_floodplains=alpha2[s]) for g, s in zip(graphs, sl)]
+    steps = [D.DistRoutingStep(r, {k: (a[s] if isinstance(a, np.ndarray) else a) for k, a in vals.items()}, True, beta,
+                               1 / dt, dt * nsteps) for r, s in zip(routers, sl)]
+    for _ in range(nsteps):
+        D.loopback_substep(steps)
+    for k in _STATE + _OUT:
+        got = np.concatenate([st.download(k) for st in steps])
+        assert np.array_equal(got, ref.download(k), equal_nan=True), (family, k)
+    # one block holding everything: the composite C entry point (no exchange needed, no communicator)
+    g1 = D.DistGraph(codes, None, None, None, None, None)
+    D.settle_phases_local([g1])
+    one = D.DistRoutingStep(D.DistRouter(g1, alpha, beta, length, dt, alpha_floodplains=alpha2), vals, True, beta, 1 / dt,
+                            dt * nsteps)
+    for _ in range(nsteps):
+        one.substep()
+    for k in _STATE + _OUT:
+        assert np.array_equal(one.download(k), ref.download(k), equal_nan=True), ("one block", k)
+    for st in steps + [one]:
+        st.free()
+    ref.free()
+
+
 def _model_var(N):
     """The slice of LisfloodModel_ini (Lisflood_initial.py:108-113, 272-345) the module classes read."""
     from collections import OrderedDict
