@@ -534,6 +534,49 @@ def test_fused_wavefront_skips_only_true_fixed_points(amd, monkeypatch):
     kw.close()
 
 
+@pytest.mark.parametrize("family,shape", [("shallow", (1500, 1500)), ("deep", (500, 1100))])
+def test_fused_wavefront_equals_sequential_mid_size(amd, family, shape):
+    """2.25e6 / 5.5e5 cells, 20 % non-channel pixels (isolated, partly inert), 12 split-routing sub-steps: the wavefront
+    (packed or 2-D grid, inert pixels skipped) against 12 x lf_routing_substep -- every state and output vector
+    bit for bit, and the discharge sum grows by exactly the ChanQ of every sub-step."""
+    from lisflood_amd import synthetic as syn
+    from lisflood_amd import ldd as L
+    from lisflood_amd.kinematic_wave_parallel import kinematicWave
+    from lisflood_amd.routing import _OUT, _STATE
+    from lisflood_amd.routing_device import RoutingStepDevice
+    H, W = shape
+    N = H * W
+    mask = np.ones((H, W), bool)
+    codes = syn.make_ldd(family, H, W, 5).reshape(-1).astype(np.float64)
+    rng = np.random.default_rng(23)
+    is_chan = rng.random(N) < 0.8
+    kin, _ = L.lddmask(codes, mask, is_chan)
+    ldd_kin = np.zeros(N); ldd_kin[is_chan] = kin
+    p = syn.router_params(N, seed=12)
+    beta, dt, nsteps = p["beta"], 3600.0, 12
+    alpha, length = p["alpha"], p["dx"]
+    alpha2 = alpha * rng.uniform(1.2, 2.0, N)
+    q0 = np.where(is_chan, p["Q0"], 0.0)
+    qlimit = 2.0 * q0 * rng.uniform(0.3, 1.2, N)
+    vals = dict(ChanLength=length, InvChanLength=1 / length, ChannelAlpha=alpha, InvChannelAlpha=1 / alpha,
+                ChannelAlpha2=alpha2, InvChannelAlpha2=1 / alpha2, QLimit=qlimit, M3Limit=alpha * length * qlimit ** beta,
+                Chan2M3Start=alpha2 * length * qlimit ** beta, Chan2QStart=qlimit * 0.1, PixelArea=np.full(N, 2.5e7),
+                IsChannelKinematic=is_chan, SideflowChanM3=syn.lateral_inflow(N, 0) * length * dt)
+    vals["Chan2M3Kin"] = vals["Chan2M3Start"].copy()
+    vals["ChanM3Kin"] = alpha * length * q0 ** beta
+    vals["ChanQKin"] = q0.copy()
+    vals["Chan2QKin"] = (vals["Chan2M3Kin"] / length / alpha2) ** (1 / beta)
+    kw = kinematicWave(ldd_kin, mask, alpha, beta, length, dt, alpha_floodplains=alpha2)
+    a = RoutingStepDevice(kw, vals, True, beta, 1 / dt, dt * nsteps); a.run_fused(nsteps)
+    b = RoutingStepDevice(kw, vals, True, beta, 1 / dt, dt * nsteps); b.run_sequential(nsteps)
+    for k in _STATE + _OUT:
+        assert np.array_equal(a.download(k), b.download(k), equal_nan=True), (family, k)
+    q = a.download("ChanQ")
+    assert np.isfinite(q).all() and (q >= 0).all() and (q[~is_chan] == 0).all() and q[is_chan].max() > 0
+    assert (a.download("sumDisDay") >= q).all()          # the sum holds the last sub-step's ChanQ plus 11 non-negative ones
+    a.free(); b.free(); kw.close()
+
+
 def test_structures_inside_the_fused_wavefront(amd, solver):
     """lf_routing_substeps_fused_structures: the whole loop `for s: lakes/reservoirs/inflow/transmission
     .dynamic_inloop(s); routing.dynamic(s)` as ONE wavefront (sites run between two launches, on a graph that puts
