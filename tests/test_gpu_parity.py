@@ -609,6 +609,57 @@ def test_structures_inside_the_fused_wavefront(amd, solver):
         mb.river_router.kinematicWaveRouting(np.zeros(mb.river_router.num_pixels), np.zeros(mb.river_router.num_pixels))
 
 
+@pytest.mark.parametrize("family", ["deep", "shallow"])
+def test_structures_wavefront_mid_size_synthetic(amd, family):
+    """2e5 cells, 16 lakes + 48 reservoirs + 32 inflow points + transmission loss, 24 split-routing sub-steps, two model
+    steps: the wavefront with the structures inside against the sub-step-by-sub-step engine (itself pinned to the
+    reference's modules by the LF_ETRS89 fixture) -- every vector bit for bit."""
+    from lisflood_amd import synthetic as syn
+    H, W = 400, 500
+    N = H * W
+    mask = np.ones((H, W), bool)
+    codes = syn.make_ldd(family, H, W, 8).reshape(-1).astype(np.float64)
+    p = syn.router_params(N, seed=4)
+    rng = np.random.default_rng(31)
+    beta, dt, nsteps = p["beta"], 3600.0, 24
+    alpha, length = p["alpha"], p["dx"]
+    alpha2 = alpha * rng.uniform(1.2, 2.0, N)
+    qlimit = 2.0 * p["Q0"] * rng.uniform(0.3, 1.2, N)
+
+    def module():
+        v = types.SimpleNamespace(
+            ChanLength=length, InvChanLength=1 / length, ChannelAlpha=alpha, InvChannelAlpha=1 / alpha,
+            ChannelAlpha2=alpha2, InvChannelAlpha2=1 / alpha2, QLimit=qlimit, M3Limit=alpha * length * qlimit ** beta,
+            Chan2M3Start=alpha2 * length * qlimit ** beta, Chan2QStart=qlimit * 0.1, PixelArea=np.full(N, 2.5e7),
+            IsChannelKinematic=np.ones(N, bool), Beta=beta, InvBeta=1 / beta, DtRouting=dt, InvDtRouting=1 / dt,
+            NoRoutSteps=nsteps, InvNoRoutSteps=1 / nsteps, DtSec=dt * nsteps,
+            ToChanM3RunoffDt=syn.lateral_inflow(N, 0) * length * dt)
+        v.Chan2M3Kin = v.Chan2M3Start.copy()
+        v.ChanM3Kin = alpha * length * p["Q0"] ** beta
+        v.ChanQKin = p["Q0"].copy()
+        v.Chan2QKin = (v.Chan2M3Kin / length / alpha2) ** (1 / beta)
+        v.ChanQ = v.ChanQKin.copy()
+        v.CrossSection2Area, v.Sideflow1Chan, v.sumDisDay = np.zeros(N), np.zeros(N), np.zeros(N)
+        d, cut = syn.structures_scenario(codes, (H, W), v.ChanQ, dt, n_lakes=16, n_res=48)
+        for k, x in d.items():
+            setattr(v, k, np.array(x, copy=True) if isinstance(x, np.ndarray) else x)
+        m = amd.routing.routing(v, options=dict(SplitRouting=True, InitLisflood=False, simulateLakes=True,
+                                                simulateReservoirs=True, inflow=True, TransLoss=True), engine_order=True)
+        m.attach_router(cut, mask)
+        m.attach_structures()
+        return v, m
+
+    (va, ma), (vb, mb) = module(), module()
+    for step in range(2):
+        va.sumDisDay = np.zeros(N); vb.sumDisDay = np.zeros(N)
+        for s in range(nsteps):
+            ma.dynamic(s)
+        mb.dynamic_fused()
+        for k in _STRUCT_KEYS + ("CrossSection2Area", "Sideflow1Chan", "LakeStorageM3", "ReservoirStorageM3"):
+            assert np.array_equal(getattr(va, k), getattr(vb, k), equal_nan=True), (family, step, k)
+    assert np.isfinite(va.ChanQ).all() and va.QLakeOutM3Dt.max() > 0 and va.QResOutM3Dt.max() > 0 and va.TransCum.max() > 0
+
+
 def test_pixel_aggregates_golden(amd):
     """opensealed.dynamic -> soil.dynamic_perpixel -> groundwater.dynamic as one device pass, against vectors
     captured from the reference's own module methods (two consecutive steps)."""
