@@ -19,6 +19,70 @@ def log(rank, *a):
     print("[bench rank %d]" % rank, *a, file=sys.stderr, flush=True)
 
 
+def catchment_leg(a, dist, torch, rank, world, device):
+    """Same raster, same calls, ranks own whole catchments (lisflood_amd.partition): no halo, no collective on the data
+    path.  Every rank derives the partition from the full LDD itself (set-up, untimed)."""
+    from . import _lib
+    from . import partition as P
+    from . import synthetic as syn
+    from .kinematic_wave_parallel import Graph, kinematicWave
+    H = W = a.size
+    N = H * W
+    seed = {"shallow": 1, "deep": 2}[a.family]
+    t0 = time.time()
+    raster = syn.make_ldd(a.family, H, W, seed)
+    g = Graph(ldd_raster=raster)
+    roots = P.catchment_roots(g)
+    g.close()
+    pix_rank, sizes = P.split_catchments(roots, world)
+    del roots
+    ids = np.nonzero(pix_rank == rank)[0]
+    mask = np.zeros(N, bool)
+    mask[ids] = True
+    codes = raster.reshape(-1)[ids].astype(np.float64)
+    del raster, pix_rank
+    p = syn.router_params(N)
+    kw = kinematicWave(codes, mask.reshape(H, W), p["alpha"][ids], p["beta"], p["dx"][ids], p["dt"], device=device)
+    n = kw.num_pixels
+    Q = _lib.DeviceArray.from_host(np.ascontiguousarray(p["Q0"][ids]), device)
+    del p
+    nq = 3
+    qs = [_lib.DeviceArray.from_host(np.ascontiguousarray(syn.lateral_inflow(N, s)[ids]), device) for s in range(nq)]
+    tmp = _lib.DeviceArray(max(n, 1), np.float64, device)
+    for d in [Q] + qs:
+        kw.to_engine_order(d, tmp)
+        d.copy_from(tmp)
+    _lib.synchronize(device)
+    tmp.free()
+    log(rank, "catchment partition: %d cells in %d levels, set-up %.1f s" % (n, kw.graph.num_levels, time.time() - t0))
+    for s in range(a.warmup):
+        kw.route_ordered(Q, qs[s % nq])
+    _lib.synchronize(device)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for s in range(a.steps):
+        kw.route_ordered(Q, qs[s % nq])
+    _lib.synchronize(device)
+    dt_local = time.perf_counter() - t0
+    dist.barrier()
+    t = torch.tensor([dt_local], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    Qh = Q.download()
+    ok = torch.tensor([float(np.isfinite(Qh).all() and (Qh >= 0).all()), float(n)], dtype=torch.float64)
+    dist.all_reduce(ok, op=dist.ReduceOp.SUM)
+    cells = torch.zeros(world, dtype=torch.int64)
+    cells[rank] = n
+    dist.all_reduce(cells, op=dist.ReduceOp.SUM)
+    for d in qs + [Q]:
+        d.free()
+    kw.close()
+    ms = float(t.item()) * 1e3 / a.steps
+    return {"value": round(N / ms / 1e3, 2), "unit": "Mcell-steps/s", "ms_per_step": round(ms, 4),
+            "cells_per_rank": [int(x) for x in cells.tolist()], "catchments": int(sizes.size),
+            "largest_catchment": int(sizes.max()), "finite": bool(ok[0].item() == world and int(ok[1].item()) == N),
+            "note": "ranks own whole catchments (no exchange on the data path); engine-order vectors as in the N = 1 run"}
+
+
 def main(a):
     import torch
     import torch.distributed as dist
@@ -80,6 +144,13 @@ def main(a):
     dist.all_reduce(chk, op=dist.ReduceOp.SUM)
     launches = torch.tensor([router.last_launches()], dtype=torch.int64)
     dist.all_reduce(launches, op=dist.ReduceOp.MAX)
+    # secondary: the same raster partitioned by whole catchments -- no exchange, every rank runs the single-GPU engine
+    catch = None
+    if not getattr(a, "no_extra", False):
+        try:
+            catch = catchment_leg(a, dist, torch, rank, world, device)
+        except Exception as e:  # must never cost the headline line
+            catch = {"error": repr(e)}
     if rank == 0:
         ms = dt_max * 1e3 / a.steps
         value = N / ms / 1e3
@@ -102,6 +173,8 @@ def main(a):
                          "traffic": None},
             "checksum_sumQ": float(chk[0].item()), "finite": bool(chk[1].item() == world),
         }
+        if catch is not None:
+            out["catchment_partition"] = catch
         print(json.dumps(out), flush=True)
     dist.barrier()
     comm.close()

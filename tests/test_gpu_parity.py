@@ -980,6 +980,33 @@ def test_row_block_routing_substep_loopback(amd, family, nblocks):
     ref.free()
 
 
+@pytest.mark.parametrize("family,nparts", [("shallow", 3), ("deep", 4)])
+def test_catchment_partition_routes_like_the_whole_domain(amd, family, nparts):
+    """Ranks that own whole catchments need no exchange: nparts independent routers on compressed sub-domains give,
+    pixel by pixel, exactly the discharge of the router on the whole raster (3 calls)."""
+    from lisflood_amd import partition as P
+    from lisflood_amd import synthetic as syn
+    H, W = 240, 260
+    N = H * W
+    mask = np.ones((H, W), bool)
+    codes = syn.make_ldd(family, H, W, 4).reshape(-1).astype(np.float64)
+    p = syn.router_params(N, seed=2)
+    whole = amd.kw.kinematicWave(codes, mask, p["alpha"], p["beta"], p["dx"], p["dt"])
+    parts, counts = P.catchment_partition(codes, mask, nparts)
+    assert counts.sum() == N and counts.min() > 0
+    subs = [amd.kw.kinematicWave(c, m, p["alpha"][ids], p["beta"], p["dx"][ids], p["dt"]) for c, m, ids in parts]
+    Qw = p["Q0"].copy()
+    Qs = [p["Q0"][ids].copy() for _, _, ids in parts]
+    for s in range(3):
+        q = syn.lateral_inflow(N, s)
+        whole.kinematicWaveRouting(Qw, q)
+        got = np.empty(N)
+        for kw, Q, (_, _, ids) in zip(subs, Qs, parts):
+            kw.kinematicWaveRouting(Q, q[ids])
+            got[ids] = Q
+        assert np.array_equal(got, Qw), (family, s)
+
+
 def _model_var(N):
     """The slice of LisfloodModel_ini (Lisflood_initial.py:108-113, 272-345) the module classes read."""
     from collections import OrderedDict

@@ -214,3 +214,37 @@ def test_netcdf_classic_maps_round_trip(tmp_path):
     b, _, _, t = O.read_netcdf_classic(str(tmp_path / "ch.nc"), "chanq")
     assert t is None and np.array_equal(b[mask], np.arange(N)) and np.isnan(b[~mask]).all()
     assert open(tmp_path / "dis.nc", "rb").read(4) == b"CDF\x02"
+
+
+@pytest.mark.parametrize("family", ["shallow", "deep"])
+def test_catchment_partition_is_closed_and_balanced(family):
+    """Every pixel's outlet label equals the outlet reached by walking the LDD; a rank's pixels form a self-contained
+    domain (no link leaves it) and the ranks are balanced up to the largest catchment."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "lisflood-code_amd"))
+    from lisflood_amd import partition as P, synthetic as syn
+    from lisflood_amd.kinematic_wave_parallel import Graph
+    H, W = 90, 120
+    mask = np.ones((H, W), bool); mask[:7, :9] = False
+    raster = syn.make_ldd(family, H, W, 3, land_mask=mask)
+    codes = raster[mask].astype(np.float64)
+    g = Graph(codes, mask)
+    down = g.lookups()[0].astype(np.int64)
+    roots = P.catchment_roots(g)
+    walk = np.arange(down.size)
+    for _ in range(H * W):
+        nxt = np.where(down[walk] >= 0, down[walk], walk)
+        if np.array_equal(nxt, walk):
+            break
+        walk = nxt
+    assert np.array_equal(roots, walk)
+    rank, sizes = P.split_catchments(roots, 4)
+    cnt = np.bincount(rank, minlength=4)
+    assert cnt.sum() == down.size and cnt.max() - cnt.min() <= 2 * sizes.max()
+    has = down >= 0
+    assert np.array_equal(rank[has], rank[down[has]])                       # no link crosses ranks
+    parts, counts = P.catchment_partition(codes, mask, 4)
+    assert np.array_equal(counts, cnt)
+    for c, m, ids in parts:
+        gs = Graph(c, m)                                                     # builds: a closed sub-domain
+        assert gs.num_pixels == ids.size and (gs.lookups()[0] >= -1).all()
