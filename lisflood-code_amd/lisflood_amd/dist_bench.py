@@ -30,31 +30,40 @@ def catchment_leg(a, dist, torch, rank, world, device):
     N = H * W
     seed = {"shallow": 1, "deep": 2}[a.family]
     t0 = time.time()
-    raster = syn.make_ldd(a.family, H, W, seed)
-    g = Graph(ldd_raster=raster)
-    roots = P.catchment_roots(g)
-    g.close()
-    pix_rank, sizes = P.split_catchments(roots, world)
-    del roots
-    ids = np.nonzero(pix_rank == rank)[0]
-    mask = np.zeros(N, bool)
-    mask[ids] = True
-    codes = raster.reshape(-1)[ids].astype(np.float64)
-    del raster, pix_rank
-    p = syn.router_params(N)
-    kw = kinematicWave(codes, mask.reshape(H, W), p["alpha"][ids], p["beta"], p["dx"][ids], p["dt"], device=device)
-    n = kw.num_pixels
-    Q = _lib.DeviceArray.from_host(np.ascontiguousarray(p["Q0"][ids]), device)
-    del p
     nq = 3
-    qs = [_lib.DeviceArray.from_host(np.ascontiguousarray(syn.lateral_inflow(N, s)[ids]), device) for s in range(nq)]
-    tmp = _lib.DeviceArray(max(n, 1), np.float64, device)
-    for d in [Q] + qs:
-        kw.to_engine_order(d, tmp)
-        d.copy_from(tmp)
-    _lib.synchronize(device)
-    tmp.free()
-    log(rank, "catchment partition: %d cells in %d levels, set-up %.1f s" % (n, kw.graph.num_levels, time.time() - t0))
+    err = None
+    try:
+        raster = syn.make_ldd(a.family, H, W, seed)
+        g = Graph(ldd_raster=raster)
+        roots = P.catchment_roots(g)
+        g.close()
+        pix_rank, sizes = P.split_catchments(roots, world)
+        del roots
+        ids = np.nonzero(pix_rank == rank)[0]
+        mask = np.zeros(N, bool)
+        mask[ids] = True
+        codes = raster.reshape(-1)[ids].astype(np.float64)
+        del raster, pix_rank
+        p = syn.router_params(N)
+        kw = kinematicWave(codes, mask.reshape(H, W), p["alpha"][ids], p["beta"], p["dx"][ids], p["dt"], device=device)
+        n = kw.num_pixels
+        Q = _lib.DeviceArray.from_host(np.ascontiguousarray(p["Q0"][ids]), device)
+        del p
+        qs = [_lib.DeviceArray.from_host(np.ascontiguousarray(syn.lateral_inflow(N, s)[ids]), device) for s in range(nq)]
+        tmp = _lib.DeviceArray(max(n, 1), np.float64, device)
+        for d in [Q] + qs:
+            kw.to_engine_order(d, tmp)
+            d.copy_from(tmp)
+        _lib.synchronize(device)
+        tmp.free()
+        log(rank, "catchment partition: %d cells in %d levels, set-up %.1f s" % (n, kw.graph.num_levels, time.time() - t0))
+    except Exception as e:
+        err = repr(e)
+    # all ranks take the same branch: a rank that failed its set-up must not leave the others in a barrier
+    flag = torch.tensor([0 if err else 1], dtype=torch.int64)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 0:
+        return {"error": err or "set-up failed on another rank"}
     for s in range(a.warmup):
         kw.route_ordered(Q, qs[s % nq])
     _lib.synchronize(device)
