@@ -383,8 +383,10 @@ def hotpath_bench(size=2000, steps=3):
     hp.step(forc[0], 1)
     _lib.synchronize()
     t0 = time.perf_counter()
+    hp.prefetch(forc[0])
     for s in range(steps):
         hp.step(forc[s % 2], s + 2)
+        hp.prefetch(forc[(s + 1) % 2])          # next step's forcing goes up while this step's kernels run
     _lib.synchronize()
     ms = (time.perf_counter() - t0) * 1e3 / steps
     q = hp.chan_q_avg()

@@ -65,6 +65,16 @@ int lf_device_name(int device, char *buf, size_t buflen); /* gcnArchName, e.g. "
 int lf_device_alloc(int device, size_t bytes, void **ptr_dev);
 int lf_device_free(int device, void *ptr_dev);
 int lf_memcpy_h2d(int device, void *dst_dev, const void *src_host, size_t bytes);
+/* Double-buffered uploads on a second HIP stream, so that the copies of the NEXT step's inputs overlap the kernels of
+ * the current step.  For buffer set b in {0, 1}:
+ *     lf_upload_begin(b); lf_upload_copy(...) ...; lf_upload_end(b)            -- at any time, e.g. right after a step
+ *     lf_compute_acquire(b); <entry points whose kernels read set b>; lf_compute_release(b)
+ * The copies wait for the kernels that last read set b, those kernels wait for the copies; the other set is free. */
+int lf_upload_begin(int device, int set);
+int lf_upload_copy(int device, void *dst_dev, const void *src_host, size_t bytes);
+int lf_upload_end(int device, int set);
+int lf_compute_acquire(int device, int set);
+int lf_compute_release(int device, int set);
 int lf_memcpy_d2h(int device, void *dst_host, const void *src_dev, size_t bytes);
 int lf_memcpy_d2d(int device, void *dst_dev, const void *src_dev, size_t bytes);
 int lf_memset(int device, void *dst_dev, int value, size_t bytes);

@@ -36,6 +36,11 @@ struct lf_device_ctx {
     hipEvent_t t0 = nullptr, t1 = nullptr;
     void *soil_ws = nullptr; // work list of deferred soil columns (lf_soil.hip)
     size_t soil_ws_bytes = 0, soil_ntiles = 0;
+    // upload stream for double-buffered inputs (lf_upload_*): copies of the NEXT step's forcing overlap the kernels of
+    // the current one; per buffer set an event "copy finished" and an event "last kernel reading the set finished"
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t copied[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
+    bool consumed_valid[2] = {false, false};
 };
 int lf_ctx(int device, lf_device_ctx **out); // makes `device` current, creates the context on first use
 

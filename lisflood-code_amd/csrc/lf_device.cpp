@@ -133,6 +133,68 @@ int lf_memcpy_h2d(int device, void *dst_dev, const void *src_host, size_t bytes)
     return LF_OK;
 }
 
+// ---- double-buffered uploads on a second stream ------------------------------------------------------------------
+// Protocol for buffer set b in {0, 1}:   lf_upload_begin(b); lf_upload_copy(...) x n; lf_upload_end(b)   [any time]
+//                                        lf_compute_acquire(b); <kernels reading set b>; lf_compute_release(b)
+// The copies wait for the kernels that last read set b, the kernels wait for the copies; neither blocks the other set.
+static int upload_ctx(int device, int set, lf_device_ctx **out)
+{
+    if (set < 0 || set > 1) return lf_set_error(LF_E_INVALID, "buffer set must be 0 or 1");
+    lf_device_ctx *c;
+    LF_TRY(lf_ctx(device, &c));
+    if (!c->copy_stream) {
+        LF_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        for (int b = 0; b < 2; ++b) {
+            LF_HIP(hipEventCreateWithFlags(&c->copied[b], hipEventDisableTiming));
+            LF_HIP(hipEventCreateWithFlags(&c->consumed[b], hipEventDisableTiming));
+        }
+    }
+    *out = c;
+    return LF_OK;
+}
+
+int lf_upload_begin(int device, int set)
+{
+    lf_device_ctx *c;
+    LF_TRY(upload_ctx(device, set, &c));
+    if (c->consumed_valid[set]) LF_HIP(hipStreamWaitEvent(c->copy_stream, c->consumed[set], 0));
+    return LF_OK;
+}
+
+int lf_upload_copy(int device, void *dst_dev, const void *src_host, size_t bytes)
+{
+    if (!dst_dev || (!src_host && bytes)) return lf_set_error(LF_E_INVALID, "null argument");
+    lf_device_ctx *c;
+    LF_TRY(upload_ctx(device, 0, &c));
+    if (bytes) LF_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, c->copy_stream));
+    return LF_OK;
+}
+
+int lf_upload_end(int device, int set)
+{
+    lf_device_ctx *c;
+    LF_TRY(upload_ctx(device, set, &c));
+    LF_HIP(hipEventRecord(c->copied[set], c->copy_stream));
+    return LF_OK;
+}
+
+int lf_compute_acquire(int device, int set)
+{
+    lf_device_ctx *c;
+    LF_TRY(upload_ctx(device, set, &c));
+    LF_HIP(hipStreamWaitEvent(c->stream, c->copied[set], 0));
+    return LF_OK;
+}
+
+int lf_compute_release(int device, int set)
+{
+    lf_device_ctx *c;
+    LF_TRY(upload_ctx(device, set, &c));
+    LF_HIP(hipEventRecord(c->consumed[set], c->stream));
+    c->consumed_valid[set] = true;
+    return LF_OK;
+}
+
 int lf_memcpy_d2h(int device, void *dst_host, const void *src_dev, size_t bytes)
 {
     lf_device_ctx *c;

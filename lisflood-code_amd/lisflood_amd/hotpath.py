@@ -86,8 +86,12 @@ class HotPathDevice:
             if name not in self.d:
                 self.d[name] = DeviceArray(shape, np.float64, device).zero()
             return self.d[name]
+        # forcing: two buffer sets, so that the upload of the next step's vectors (second HIP stream) overlaps the
+        # kernels of the current step -- see prefetch()
+        self.force = [{k: DeviceArray(N, np.float64, device).zero() for k in FORCING} for _ in range(2)]
+        self._prefetched, self._keep = [None, None], [None, None]
         for k in FORCING:
-            zeros(k, N)
+            self.d[k] = self.force[0][k]
         # ---- argument blocks (pointers into self.d) -----------------------------------------------------
         def fill(args, names, shape_of):
             for k in names:
@@ -128,10 +132,47 @@ class HotPathDevice:
         r.split, r.engine_order = (1 if self.split else 0), 1
         self.steps_done = 0
 
+    def _upload(self, b, forcing):
+        L, dev = lib(), self.device
+        host = [f64(forcing[k]) for k in FORCING]
+        check(L.lf_upload_begin(C.c_int(dev), C.c_int(b)))
+        for k, a in zip(FORCING, host):
+            if a.size != self.N:
+                raise ValueError("forcing vector %s must have %d entries" % (k, self.N))
+            check(L.lf_upload_copy(C.c_int(dev), self.force[b][k].ptr, a.ctypes.data_as(C.c_void_p), C.c_size_t(a.nbytes)))
+        check(L.lf_upload_end(C.c_int(dev), C.c_int(b)))
+        self._keep[b] = host                 # the host vectors stay alive until the set is uploaded again
+
+    def prefetch(self, forcing):
+        """Start uploading the forcing of the NEXT step() call now: the copies run on a second stream while the kernels
+        of the step just enqueued are still executing.  Pass the same dict object to the next step()."""
+        b = self.steps_done % 2
+        self._upload(b, forcing)
+        self._prefetched[b] = forcing
+
+    def _use_set(self, b):
+        for k in FORCING:
+            self.d[k] = self.force[b][k]
+            for st in (self.canopy, self.soil, self.pixel, self.surface):
+                if hasattr(type(st), k):
+                    setattr(st, k, self.force[b][k].ptr.value)
+
     def step(self, forcing, time_since_start=None):
         d, dev = self.d, self.device
-        for k in FORCING:
-            d[k].upload(f64(forcing[k]))
+        L = lib()
+        b = self.steps_done % 2
+        if self._prefetched[b] is not forcing:
+            self._upload(b, forcing)
+        self._prefetched[b] = None
+        check(L.lf_compute_acquire(C.c_int(dev), C.c_int(b)))
+        self._use_set(b)
+        try:
+            self._enqueue(time_since_start)
+        finally:
+            check(L.lf_compute_release(C.c_int(dev), C.c_int(b)))
+
+    def _enqueue(self, time_since_start):
+        d, dev = self.d, self.device
         L = lib()
         check(L.lf_canopy_device(C.c_int(dev), C.byref(self.canopy)))                                   # dyn.py:114
         check(L.lf_scale_rows_device(C.c_int(dev), d["ESRef"].ptr, d["LAITerm"].ptr, d["ESMax"].ptr,
@@ -204,6 +245,7 @@ class HotPathDevice:
 
     def free(self):
         arrays = {id(a): a for a in self.d.values()}
+        arrays.update({id(a): a for fs in self.force for a in fs.values()})
         if self.rmod is not None:
             arrays.update({id(a): a for a in list(self.rmod._st["dev"].values()) + list(self.rmod._dev.values())})
         for a in arrays.values():

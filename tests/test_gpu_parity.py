@@ -707,9 +707,12 @@ def test_resident_hot_path_equals_the_module_classes(amd):
     m_soil = soilloop(v); m_soil.initial()
     m_surf = surface_routing(v); m_surf.initialSecond(ldd_to_chan, mask)
     m_rout = amd.routing.routing(v, split_routing=True); m_rout.attach_router(ldd_kin, mask)
-    for step in range(2):
-        f = syn.hotpath_forcing(N, step)
+    fs = [syn.hotpath_forcing(N, step) for step in range(3)]
+    for step in range(3):
+        f = fs[step]
         hp.step(f, time_since_start=step + 1)
+        if step == 0:
+            hp.prefetch(fs[1])          # uploaded on the copy stream while step 0 runs; step 2 uploads inside step()
         for k, a in f.items():
             setattr(v, k, a)
         v.TimeSinceStart = float(step + 1)
