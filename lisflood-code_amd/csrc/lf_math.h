@@ -56,6 +56,7 @@ __device__ __forceinline__ bool lf_fast_range(double x) { return x >= LF_FAST_MI
 // x^0.6 for beta = 3/5; exact pow semantics outside the fast range (0, negatives, NaN, inf, extremes)
 __device__ __forceinline__ double lf_pow_3_5(double x)
 {
+    if (x == 0.0) return 0.0; // pow(+-0, 0.6) = +0: dry cells are common and must not take the OCML path
     if (lf_fast_range(x)) {
         const double r = lf_root5(x);
         return r * r * r;
@@ -66,6 +67,7 @@ __device__ __forceinline__ double lf_pow_3_5(double x)
 // x^(1/0.6) = x^(5/3) = x * cbrt(x)^2
 __device__ __forceinline__ double lf_pow_5_3(double x)
 {
+    if (x == 0.0) return 0.0; // pow(+-0, 5/3) = +0
     if (lf_fast_range(x)) {
         const double r = lf_cbrt(x);
         return x * (r * r);
