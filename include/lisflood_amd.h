@@ -142,6 +142,9 @@ int lf_router_route_device(lf_router *r, double *discharge_dev, const double *la
  * a coalesced stream and discharge is updated in place.  Element-wise work (routing.dynamic's fix-ups,
  * sideflow assembly) is order-agnostic, so a model step can keep all its vectors in engine order and
  * convert only at its boundary with these two permutations (dst[p] = src[perm[p]] and its inverse). */
+/* dst[i] = src[index[i]], i < n: permutation between two domains (e.g. full-raster pixel order -> engine order of a
+ * router that covers a subset of the pixels) */
+int lf_gather_device(int device, int64_t n, const int32_t *index_dev, const double *src_dev, double *dst_dev);
 int lf_router_to_engine_order(lf_router *r, const double *src_pix_dev, double *dst_ord_dev);
 int lf_router_from_engine_order(lf_router *r, const double *src_ord_dev, double *dst_pix_dev);
 int lf_router_route_ordered(lf_router *r, double *discharge_ord_dev, const double *lateral_ord_dev, int section);

@@ -515,6 +515,20 @@ int lf_router_route_ordered(lf_router *r, double *discharge_ord_dev, const doubl
     return route_device(r, discharge_ord_dev, lateral_ord_dev, section, true);
 }
 
+// dst[i] = src[index[i]] for i < n (device vectors; index is int32): the permutation between two domains, e.g. a
+// full-raster pixel vector into the engine order of a router that covers only a subset of the pixels
+int lf_gather_device(int device, int64_t n, const int32_t *index_dev, const double *src_dev, double *dst_dev)
+{
+    if (n < 0 || (n > 0 && (!index_dev || !src_dev || !dst_dev))) return lf_set_error(LF_E_INVALID, "bad argument");
+    lf_device_ctx *c;
+    LF_TRY(lf_ctx(device, &c));
+    if (n > 0)
+        hipLaunchKernelGGL(k_gather, dim3(blocks_for(n)), dim3(kBlock), 0, c->stream, (int)n, (const int *)index_dev, src_dev,
+                           dst_dev);
+    LF_HIP(hipGetLastError());
+    return LF_OK;
+}
+
 int lf_router_to_engine_order(lf_router *r, const double *src_pix_dev, double *dst_ord_dev)
 {
     if (!r || !src_pix_dev || !dst_ord_dev) return lf_set_error(LF_E_INVALID, "null argument");

@@ -27,19 +27,40 @@ FORCING = ("Rain", "SnowMelt", "EWRef", "ETRef", "ESRef")
 
 
 class HotPathDevice:
-    def __init__(self, values, scalars, land_mask, ldd_to_chan, ldd_kinematic, split=True, device=0, structures=None):
+    def __init__(self, values, scalars, land_mask, ldd_to_chan, ldd_kinematic, split=True, device=0, structures=None,
+                 compact=True):
         """values: name -> host array in pixel order ([N], [3,N]) for every vector of the stages (reference
         attribute names); scalars: Beta, DtSec, DtRouting, NoRoutSteps, DtDay, PixelLength, MMtoM3, M3toMM,
         LeafDrainageK, AvWaterThreshold, CourantCrit, DrainedFraction, InvDtDay.  ldd_to_chan / ldd_kinematic:
         compressed LDD codes of the overland and the channel graph.
         structures: optional dict of the reference's lake / reservoir / inflow / transmission attributes (the names
         routing.attach_structures reads, incl. `downstruct` of the uncut LDD); ldd_kinematic is then the CUT LDD
-        (structures.py:44-61) and the sub-step loop runs with the structures inside the wavefront."""
+        (structures.py:44-61) and the sub-step loop runs with the structures inside the wavefront.
+        compact: leave inert pixels out of the channel router's domain (see inert_pixels): on real domains most land
+        pixels are not channel pixels, and the channel wavefront then touches only the ones that are."""
         self.device, self.split = device, bool(split)
         self.rmod = None
         self.sc = dict(scalars)
-        self.N = N = int(np.asarray(land_mask, bool).sum())
+        land_mask = np.asarray(land_mask, bool)
+        self.N = N = int(land_mask.sum())
         sc = self.sc
+        # ---- channel domain: all land pixels, or only the ones whose routing sub-step is not the identity ----------
+        values = dict(values)
+        ldd_kinematic = np.asarray(ldd_kinematic, np.float64)
+        drop = inert_pixels(values, ldd_kinematic, land_mask, self.split, structures) if compact else np.zeros(N, bool)
+        if drop.sum() < 0.1 * N:
+            drop[:] = False
+        self.ids = np.nonzero(~drop)[0]                       # channel-domain pixel -> land pixel
+        Nk = self.Nk = self.ids.size
+        chan_mask = land_mask
+        if Nk < N:
+            chan_mask = np.zeros(land_mask.shape, bool)
+            chan_mask[land_mask] = ~drop
+            ldd_kinematic = ldd_kinematic[self.ids]
+            for k in set(RT._STATIC + RT._STATE) & set(values):
+                values[k] = np.broadcast_to(np.asarray(values[k]), (N,))[self.ids]
+            if structures is not None:
+                structures = _structures_on_subdomain(structures, self.ids, N)
         # ---- routers -------------------------------------------------------------------------------
         g_surf = Graph(ldd_to_chan, land_mask)
         alpha_of = np.asarray(values["OFAlpha"], float)
@@ -49,21 +70,21 @@ class HotPathDevice:
         chan_names = set(RT._STATIC + RT._STATE)
         self.d = {}
         if structures is None:
-            self.river = kinematicWave(ldd_kinematic, land_mask, values["ChannelAlpha"], sc["Beta"], values["ChanLength"],
+            self.river = kinematicWave(ldd_kinematic, chan_mask, values["ChannelAlpha"], sc["Beta"], values["ChanLength"],
                                        sc["DtRouting"], alpha_floodplains=values["ChannelAlpha2"] if split else None,
                                        device=device)
         else:       # the channel part is a resident, engine-order routing module with its structures attached
             v = types.SimpleNamespace(**{k: np.array(values[k], copy=True) for k in chan_names if k in values})
             v.Beta, v.InvBeta, v.DtRouting, v.InvDtRouting = sc["Beta"], 1 / sc["Beta"], sc["DtRouting"], 1 / sc["DtRouting"]
             v.DtSec, v.NoRoutSteps, v.InvNoRoutSteps = sc["DtSec"], int(sc["NoRoutSteps"]), 1 / sc["NoRoutSteps"]
-            v.ToChanM3RunoffDt = np.zeros(N)
+            v.ToChanM3RunoffDt = np.zeros(Nk)
             for k, a in structures.items():
                 setattr(v, k, a)
             opts = dict(SplitRouting=self.split, InitLisflood=False, simulateLakes="LakeIndex" in structures,
                         simulateReservoirs="ReservoirIndex" in structures, inflow="QInM3Old" in structures,
                         TransLoss="UpTrans" in structures)
             m = self.rmod = RT.routing(v, options=opts, device=device, engine_order=True)
-            m.attach_router(ldd_kinematic, land_mask)
+            m.attach_router(ldd_kinematic, chan_mask)
             m.attach_structures()
             m.begin_step()                              # uploads the channel state once; it stays resident
             m._structures_substep(0, launch=False)      # site state from the dense maps, once
@@ -71,7 +92,9 @@ class HotPathDevice:
             self.river = m.river_router
             for k in chan_names | set(RT._OUT) | {"SideflowChanM3"}:
                 self.d[k] = m._dev[k]
-        self.perm = self.river.graph.layout()[0].astype(np.int64)
+        self.perm = self.river.graph.layout()[0].astype(np.int64)        # engine position -> channel-domain pixel
+        self.gpix = self.ids[self.perm]                                   # engine position -> land pixel
+        self._gidx = DeviceArray.from_host(self.gpix.astype(np.int32), device)
         # ---- device vectors ------------------------------------------------------------------------
         bool_names = SL._BOOL | {"IsChannel", "IsChannelKinematic"}
         for k, a in values.items():
@@ -79,7 +102,7 @@ class HotPathDevice:
             if k in chan_names:                       # channel vectors: engine order of the river router
                 if self.rmod is not None:
                     continue
-                a = np.broadcast_to(a, (N,))[self.perm]
+                a = np.broadcast_to(a, (Nk,))[self.perm]
             self.d[k] = DeviceArray.from_host(u8(a) if k in bool_names else f64(a), device)
 
         def zeros(name, shape):
@@ -127,7 +150,7 @@ class HotPathDevice:
         f.PixelLength, f.InvPixelLength = sc["PixelLength"], 1 / sc["PixelLength"]
         f.DtSec, f.InvDtSec, f.InvNoRoutSteps, f.N = sc["DtSec"], 1 / sc["DtSec"], 1 / sc["NoRoutSteps"], N
         r = self.rout = RT._SubstepArgs()
-        fill(r, RT._STATIC + ["SideflowChanM3"] + RT._STATE + RT._OUT + ["scratch0", "scratch1"], n1)
+        fill(r, RT._STATIC + ["SideflowChanM3"] + RT._STATE + RT._OUT + ["scratch0", "scratch1"], lambda k: max(Nk, 1))
         r.Beta, r.InvBeta, r.InvDtRouting, r.DtSec = sc["Beta"], 1 / sc["Beta"], 1 / sc["DtRouting"], sc["DtSec"]
         r.split, r.engine_order = (1 if self.split else 0), 1
         self.steps_done = 0
@@ -185,27 +208,32 @@ class HotPathDevice:
         d["sumDisDay"].zero()                                                                           # dyn.py:177
         if self.rmod is not None:       # lakes / reservoirs / inflow / transmission loss inside the wavefront
             m = self.rmod
-            check(L.lf_router_to_engine_order(self.river._h, d["ToChanM3RunoffDt"].ptr,
-                                              m._st["dev"]["ToChanM3RunoffDt"].ptr))
+            check(L.lf_gather_device(C.c_int(dev), C.c_int64(self.Nk), self._gidx.ptr, d["ToChanM3RunoffDt"].ptr,
+                                     m._st["dev"]["ToChanM3RunoffDt"].ptr))
             check(L.lf_routing_substeps_fused_structures(self.river._h, C.byref(m._args), C.byref(m._inloop),
                                                          C.c_int(int(self.sc["NoRoutSteps"]))))          # dyn.py:179-180
             return
-        check(L.lf_router_to_engine_order(self.river._h, d["ToChanM3RunoffDt"].ptr, d["SideflowChanM3"].ptr))
+        check(L.lf_gather_device(C.c_int(dev), C.c_int64(self.Nk), self._gidx.ptr, d["ToChanM3RunoffDt"].ptr,
+                                 d["SideflowChanM3"].ptr))
         check(L.lf_routing_substeps_fused(self.river._h, C.byref(self.rout), C.c_int(int(self.sc["NoRoutSteps"])),
                                           C.c_int64(0)))                                                # dyn.py:179-180
 
     def download(self, name):
         a = self.d[name].download()
-        if name in set(RT._STATIC + RT._STATE + RT._OUT):
-            out = np.empty_like(a)
-            out[self.perm] = a
+        if name in set(RT._STATIC + RT._STATE + RT._OUT + ["SideflowChanM3"]):
+            out = np.zeros(self.N, a.dtype)          # pixels outside the channel domain: their state is identically 0
+            out[self.gpix] = a[:self.Nk]
             return out
         return a
 
     def download_site(self, name):
         """lake / reservoir site vectors (LakeStorageM3CC, ReservoirStorageM3CC, ...) and the dense in-loop outputs"""
         a = self.rmod._st["dev"][name].download()
-        return self.rmod._down(a) if a.size == self.N and name not in RT._LAKE_STATE + RT._RES_STATE else a
+        if a.size == self.Nk and name not in RT._LAKE_STATE + RT._RES_STATE:
+            out = np.zeros(self.N)
+            out[self.ids] = self.rmod._down(a)
+            return out
+        return a
 
     # ---- warm start (the reference writes its state maps as end / state files, default_options.py:131-160) --------
     # everything a stage reads back from the previous step: the in/out vectors of the canopy and soil kernels, the
@@ -231,12 +259,19 @@ class HotPathDevice:
         chan = set(RT._STATIC + RT._STATE + RT._OUT)
         for k in self.state_names():
             a = z[k]
-            self.d[k].upload(f64(a[self.perm] if k in chan else a))
+            if k in chan:
+                if self.Nk < self.N:
+                    rest = np.ones(self.N, bool); rest[self.ids] = False
+                    if np.any(a[rest] != 0):
+                        raise ValueError("state file holds water in %s on pixels this object left out of the channel "
+                                         "domain; build it with compact=False" % k)
+                a = a[self.gpix]
+            self.d[k].upload(f64(a))
         if self.rmod is not None:
             for k in RT._LAKE_STATE + RT._RES_STATE + ["TransCum"]:
                 if "site_" + k in z.files:
                     a = z["site_" + k]
-                    self.rmod._st["dev"][k].upload(f64(self.rmod._up(a) if k == "TransCum" else a))
+                    self.rmod._st["dev"][k].upload(f64(self.rmod._up(a[self.ids]) if k == "TransCum" else a))
         self.steps_done = int(z["steps_done"])
 
     def chan_q_avg(self):
@@ -244,7 +279,7 @@ class HotPathDevice:
         return self.download("sumDisDay") / self.sc["NoRoutSteps"]
 
     def free(self):
-        arrays = {id(a): a for a in self.d.values()}
+        arrays = {id(a): a for a in list(self.d.values()) + [self._gidx]}
         arrays.update({id(a): a for fs in self.force for a in fs.values()})
         if self.rmod is not None:
             arrays.update({id(a): a for a in list(self.rmod._st["dev"].values()) + list(self.rmod._dev.values())})
@@ -252,3 +287,55 @@ class HotPathDevice:
             a.free()
         for r in (self.r_other, self.r_forest, self.r_direct, self.river):
             r.close()
+
+
+def inert_pixels(values, ldd_kinematic, land_mask, split, structures=None):
+    """Land pixels whose routing sub-step is the identity for the whole run: no upstream and no downstream pixel in the
+    kinematic LDD, not a channel pixel (so no sideflow, routing.py:512), regular parameters (0 * inf would turn the
+    zero state into NaN, as it does in the reference), zero split-routing thresholds, an all-zero state, and no part
+    in a structure.  Host mirror of k_inert_flags + the state test of the cell kernel (csrc/lf_router.hip)."""
+    from . import ldd as L
+    N = int(np.asarray(land_mask, bool).sum())
+    get = lambda k, default=0.0: np.broadcast_to(np.asarray(values.get(k, default), dtype=np.float64), (N,))
+    plus0 = lambda a: np.ascontiguousarray(a).view(np.int64) == 0
+    down = L.downstream_index(ldd_kinematic, land_mask)
+    has_up = np.bincount(down[down >= 0], minlength=N) > 0
+    ok = (down < 0) & ~has_up & ~np.broadcast_to(np.asarray(values["IsChannelKinematic"], bool), (N,))
+    with np.errstate(all="ignore"):
+        t = get("InvChanLength") * get("ChanLength") * get("ChannelAlpha") * get("InvChannelAlpha")
+        ok &= np.isfinite(t) & (get("InvChanLength") >= 0)
+        names = ["ChanQKin", "ChanM3Kin", "ChanQ"]
+        if split:
+            ok &= np.isfinite(get("ChannelAlpha2") * get("InvChannelAlpha2"))
+            names += ["QLimit", "Chan2QStart", "Chan2M3Start", "Chan2QKin", "Chan2M3Kin", "CrossSection2Area",
+                      "Sideflow1Chan"]
+    for k in names:
+        ok &= plus0(get(k))
+    if structures is not None:
+        for k in ("LakeIndex", "ReservoirIndex"):
+            if k in structures:
+                ok[np.asarray(structures[k]).astype(np.int64)] = False
+        for k in ("QInM3Old", "QDelta", "TransCum"):
+            if k in structures:
+                ok &= np.broadcast_to(np.asarray(structures[k], np.float64), (N,)) == 0
+    return ok
+
+
+def _structures_on_subdomain(st, ids, N):
+    """The structure attributes (routing.attach_structures) renumbered for the channel domain `ids` of an N-pixel one."""
+    Nk = ids.size
+    new_id = np.full(N + 1, Nk, np.int64)
+    new_id[ids] = np.arange(Nk)
+    out = {}
+    for k, a in st.items():
+        if k in ("LakeIndex", "ReservoirIndex"):
+            out[k] = new_id[np.asarray(a).astype(np.int64)]
+            if (out[k] == Nk).any():
+                raise ValueError("a structure sits on a pixel outside the channel domain")
+        elif k == "downstruct":
+            out[k] = new_id[np.minimum(np.asarray(a).astype(np.int64), N)][ids].astype(np.int32)
+        elif isinstance(a, np.ndarray) and a.shape == (N,):
+            out[k] = a[ids]
+        else:
+            out[k] = a
+    return out
