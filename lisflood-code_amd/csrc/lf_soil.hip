@@ -91,31 +91,59 @@ struct veg_plan {
 // One soil column (vegetation fraction `veg`, pixel `pix`) of soilColumnsWaterBalance, soilloop.py:123-354.
 // Nothing is stored before the end, so a column can be abandoned and recomputed later: with DEFER, a column
 // that needs more than one Courant sub-step returns that number without writing anything (0 = column done).
-template <bool DEFER, bool FASTPOW>
-__device__ __forceinline__ long long soil_column(const lf_soil_args &A, const veg_plan &P, int veg, long long pix)
+// Inputs of deferred columns are handed from pass 1 to pass 2 through a staging area: pass 1 has all of them in
+// registers when it finds that a column needs several sub-steps, and writes them next to the inputs of the tile's
+// other deferred columns (field-major, slot = tile * cap + rank in the tile's list); pass 2 then reads compact, mostly
+// fully used lines instead of one 64-byte sector per 8-byte value scattered over ~46 vectors (measured: 6 GB fetched
+// for 0.8 GB of inputs).  A tile has room for `cap` columns; the ones beyond gather from the vectors as before.
+constexpr int kStageFields = 46;
+struct soil_stage {
+    double *buf;      // [kStageFields][nslots]
+    size_t nslots;    // ntiles * cap
+    unsigned int cap; // slots per tile, 0 = staging off
+};
+
+// DEFER (pass 1): *lds_count is the tile's list counter; a deferred column takes its rank from it, stages its inputs
+// and returns (nsub, rank).  !DEFER (pass 2): `slot` < nslots reads the inputs from the staging area.
+// STAGE (pass 1 only): compile the staging stores in.  They cost pass 1 registers (spills around a block that every
+// wavefront with a deferred lane executes), so the host uses the variant without them while few columns defer.
+template <bool DEFER, bool FASTPOW, bool STAGE = false>
+__device__ __forceinline__ long long soil_column(const lf_soil_args &A, const veg_plan &P, int veg, long long pix,
+                                                 const soil_stage &S, size_t slot, unsigned int *lds_count,
+                                                 unsigned int tile, unsigned int *rank_out)
 {
     const long long N = A.N;
     const double DtDay = A.DtDay;
     const long long i = (long long)veg * N + pix, j = (long long)P.landuse[veg] * N + pix;
+    const bool staged = !DEFER && slot < S.nslots;
+    int f_ = 0;
+#define LD(expr) (staged ? S.buf[(size_t)(f_++) * S.nslots + slot] : (f_++, (double)(expr)))
     // Every input of the column is fetched here, before any arithmetic: ~50 independent loads in flight per lane
     // instead of the handful the compiler keeps when loads sit next to their first use (the kernel is a stream
     // of ~90 vectors; memory-level parallelism, not ALU, sets its speed).
-    const double in_rain = A.Rain[pix], in_snow = A.SnowMelt[pix], in_leaf = A.LeafDrainage[i], in_int = A.Interception[i];
-    const double in_dslr = A.DSLR[i], in_w1a = A.W1a[i], in_w1b = A.W1b[i], in_w1 = A.W1[i], in_w2 = A.W2[i], in_uz = A.UZ[i];
-    const double in_esmax = A.ESMax[i], in_wres1 = A.WRes1[j], in_ws1 = A.WS1[j], in_store = A.StoreMaxPervious[j];
-    const double in_bx = A.b_Xinanjiang[pix], in_pinf = A.PowerInfPot[pix], in_ppref = A.PowerPrefFlow[pix];
-    const double in_uzk = A.UpperZoneK[pix], in_gwp = A.GwPercStep[pix];
-    const double in_sd1a = A.SoilDepth1a[j], in_sd1b = A.SoilDepth1b[j], in_sd2 = A.SoilDepth2[j];
-    const double wwp1a = A.WWP1a[j], wwp1b = A.WWP1b[j], wwp1 = A.WWP1[j], wwp2 = A.WWP2[j];
-    const double in_wfc1a = A.WFC1a[j], in_wfc1b = A.WFC1b[j], in_wfc1 = A.WFC1[j], in_wfc2 = A.WFC2[j];
-    const double ks1a = A.KSat1a[j], ks1b = A.KSat1b[j], ks2 = A.KSat2[j];
-    const double im1a = A.GenuInvM1a[j], im1b = A.GenuInvM1b[j], im2 = A.GenuInvM2[j];
-    const double m1a = A.GenuM1a[j], m1b = A.GenuM1b[j], m2 = A.GenuM2[j];
-    const bool frozen = A.isFrozenSoil[pix] != 0;
-    const double wres1a = A.WRes1a[j], wres1b = A.WRes1b[j], wres2 = A.WRes2[j];
-    const double ws1a = A.WS1a[j], ws1b = A.WS1b[j], ws2 = A.WS2[j];
-    const bool pore1a = A.PoreSpaceNotZero1a[j] != 0, pore1b = A.PoreSpaceNotZero1b[j] != 0,
-               pore2 = A.PoreSpaceNotZero2[j] != 0;
+    const double in_rain = LD(A.Rain[pix]), in_snow = LD(A.SnowMelt[pix]), in_leaf = LD(A.LeafDrainage[i]),
+                 in_int = LD(A.Interception[i]);
+    const double in_dslr = LD(A.DSLR[i]), in_w1a = LD(A.W1a[i]), in_w1b = LD(A.W1b[i]), in_w1 = LD(A.W1[i]),
+                 in_w2 = LD(A.W2[i]), in_uz = LD(A.UZ[i]);
+    const double in_esmax = LD(A.ESMax[i]), in_wres1 = LD(A.WRes1[j]), in_ws1 = LD(A.WS1[j]),
+                 in_store = LD(A.StoreMaxPervious[j]);
+    const double in_bx = LD(A.b_Xinanjiang[pix]), in_pinf = LD(A.PowerInfPot[pix]), in_ppref = LD(A.PowerPrefFlow[pix]);
+    const double in_uzk = LD(A.UpperZoneK[pix]), in_gwp = LD(A.GwPercStep[pix]);
+    const double in_sd1a = LD(A.SoilDepth1a[j]), in_sd1b = LD(A.SoilDepth1b[j]), in_sd2 = LD(A.SoilDepth2[j]);
+    const double wwp1a = LD(A.WWP1a[j]), wwp1b = LD(A.WWP1b[j]), wwp1 = LD(A.WWP1[j]), wwp2 = LD(A.WWP2[j]);
+    const double in_wfc1a = LD(A.WFC1a[j]), in_wfc1b = LD(A.WFC1b[j]), in_wfc1 = LD(A.WFC1[j]), in_wfc2 = LD(A.WFC2[j]);
+    const double ks1a = LD(A.KSat1a[j]), ks1b = LD(A.KSat1b[j]), ks2 = LD(A.KSat2[j]);
+    const double im1a = LD(A.GenuInvM1a[j]), im1b = LD(A.GenuInvM1b[j]), im2 = LD(A.GenuInvM2[j]);
+    const double m1a = LD(A.GenuM1a[j]), m1b = LD(A.GenuM1b[j]), m2 = LD(A.GenuM2[j]);
+    const double wres1a = LD(A.WRes1a[j]), wres1b = LD(A.WRes1b[j]), wres2 = LD(A.WRes2[j]);
+    const double ws1a = LD(A.WS1a[j]), ws1b = LD(A.WS1b[j]), ws2 = LD(A.WS2[j]);
+    // the four flags travel as one small integer
+    const double flags_d = LD((A.isFrozenSoil[pix] != 0 ? 1 : 0) | (A.PoreSpaceNotZero1a[j] != 0 ? 2 : 0) |
+                              (A.PoreSpaceNotZero1b[j] != 0 ? 4 : 0) | (A.PoreSpaceNotZero2[j] != 0 ? 8 : 0));
+#undef LD
+    const int flags = (int)flags_d;
+    const bool frozen = (flags & 1) != 0, pore1a = (flags & 2) != 0, pore1b = (flags & 4) != 0, pore2 = (flags & 8) != 0;
+    static_assert(kStageFields == 46, "one staging field per LD() above");
     // available water for infiltration, :100,131
     double awi = dmax((in_rain + in_snow) + in_leaf - in_int, 0.);
     // days since last rain, :137-140
@@ -163,7 +191,33 @@ __device__ __forceinline__ long long soil_column(const lf_soil_args &A, const ve
     const double courant = dmax(dmax(ca, cb), cg);
     const double nsub_f = dmax(1., ceil(courant / A.CourantCrit));
     const long long nsub = (long long)nsub_f;
-    if (DEFER && nsub > 1) return nsub;
+    if (DEFER && nsub > 1) {
+        const unsigned int rank = atomicAdd(lds_count, 1u); // LDS: position in the tile's list
+        *rank_out = rank;
+        if (STAGE && rank < S.cap) {
+            const size_t sl = (size_t)tile * S.cap + rank;
+            int f = 0;
+#define ST(v) S.buf[(size_t)(f++) * S.nslots + sl] = (v)
+            // the inputs whose registers are dead by now are read again (cache hits, deferred lanes only) rather than
+            // kept alive across the infiltration arithmetic: pass 1 has no registers to spare
+            ST(A.Rain[pix]); ST(A.SnowMelt[pix]); ST(A.LeafDrainage[i]); ST(A.Interception[i]);
+            ST(A.DSLR[i]); ST(A.W1a[i]); ST(A.W1b[i]); ST(A.W1[i]); ST(A.W2[i]); ST(in_uz);
+            ST(A.ESMax[i]); ST(A.WRes1[j]); ST(A.WS1[j]); ST(A.StoreMaxPervious[j]);
+            ST(A.b_Xinanjiang[pix]); ST(A.PowerInfPot[pix]); ST(A.PowerPrefFlow[pix]);
+            ST(in_uzk); ST(in_gwp);
+            ST(in_sd1a); ST(in_sd1b); ST(in_sd2);
+            ST(wwp1a); ST(wwp1b); ST(wwp1); ST(wwp2);
+            ST(in_wfc1a); ST(in_wfc1b); ST(in_wfc1); ST(in_wfc2);
+            ST(ks1a); ST(ks1b); ST(ks2);
+            ST(im1a); ST(im1b); ST(im2);
+            ST(m1a); ST(m1b); ST(m2);
+            ST(wres1a); ST(wres1b); ST(wres2);
+            ST(ws1a); ST(ws1b); ST(ws2);
+            ST(flags_d);
+#undef ST
+        }
+        return nsub;
+    }
     // sub-step loop, :266-312
     double wt1a = w1a, wt1b = w1b, wt2 = w2;
     double sa = 0., sb = 0., sg = 0.;
@@ -251,9 +305,9 @@ constexpr int kGroup = 16;  // tiles per pass-2 workgroup (a pool of 4096 column
 #endif
 // waves_per_eu(4): pass 1 streams ~500 B per column and needs the occupancy; the allocator otherwise wobbles
 // between 126 and 133 VGPRs (4 vs 3 waves per SIMD) with unrelated edits to this file; 5 waves spill and are slower
-template <bool FASTPOW>
+template <bool FASTPOW, bool STAGE>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(LF_SOIL_P1_WAVES))) k_soil_columns(lf_soil_args A, veg_plan P, unsigned short *__restrict__ tile_list,
-                                                         unsigned int *__restrict__ tile_count)
+                                                         unsigned int *__restrict__ tile_count, soil_stage S)
 {
     __shared__ unsigned int count;
     if (threadIdx.x == 0) count = 0;
@@ -265,12 +319,12 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(LF_
     bool active = pix < A.N && mode != 0;
     if (active && mode == 2 && !A.paddy_inactive[(long long)P.paddy_row[veg] * A.N + pix]) active = false;
     if (active) {
-        const long long nsub = soil_column<true, FASTPOW>(A, P, veg, pix);
+        unsigned int rank = 0;
+        const long long nsub = soil_column<true, FASTPOW, STAGE>(A, P, veg, pix, S, 0, &count, tile, &rank);
         if (nsub > 0) {
             int c = 63 - __clzll((unsigned long long)nsub); // floor(log2(nsub)) >= 1
             c = c < kClasses - 1 ? c : kClasses - 1;
-            const unsigned int slot = atomicAdd(&count, 1u); // LDS
-            tile_list[(size_t)tile * kBlock + slot] = (unsigned short)(threadIdx.x | (c << 8));
+            tile_list[(size_t)tile * kBlock + rank] = (unsigned short)(threadIdx.x | (c << 8));
         }
     }
     __syncthreads();
@@ -286,10 +340,11 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(LF_
 k_soil_columns_deferred(lf_soil_args A, veg_plan P,
                                                                   const unsigned short *__restrict__ tile_list,
                                                                   const unsigned int *__restrict__ tile_count,
-                                                                  unsigned int ntiles, unsigned int tiles_per_veg)
+                                                                  unsigned int ntiles, unsigned int tiles_per_veg,
+                                                                  soil_stage S, unsigned long long *__restrict__ deferred_total)
 {
     __shared__ unsigned int cnt[kGroup], h[kClasses], base[kClasses], total;
-    __shared__ unsigned int entry[kGroup * kBlock]; // (tile-in-group << 8 | lane), sorted by class
+    __shared__ unsigned int entry[kGroup * kBlock]; // (rank in tile list << 16 | tile-in-group << 8 | lane), by class
     const unsigned int t0 = blockIdx.x * kGroup;
     if (threadIdx.x < kGroup) cnt[threadIdx.x] = (t0 + threadIdx.x < ntiles) ? tile_count[t0 + threadIdx.x] : 0;
     if (threadIdx.x < kClasses) h[threadIdx.x] = 0;
@@ -301,6 +356,7 @@ k_soil_columns_deferred(lf_soil_args A, veg_plan P,
     }
     __syncthreads();
     if (total == 0) return;
+    if (threadIdx.x == 0) atomicAdd(deferred_total, (unsigned long long)total); // one per pool: feeds the staging policy
     // class histogram, exclusive scan, scatter (all in LDS)
     unsigned short mine[kGroup];
     unsigned int rank[kGroup];
@@ -323,14 +379,16 @@ k_soil_columns_deferred(lf_soil_args A, veg_plan P,
     __syncthreads();
 #pragma unroll
     for (int g = 0; g < kGroup; ++g)
-        if (mine[g] != 0xffff) entry[base[mine[g] >> 8] + rank[g]] = ((unsigned int)g << 8) | (mine[g] & 0xff);
+        if (mine[g] != 0xffff)
+            entry[base[mine[g] >> 8] + rank[g]] = (threadIdx.x << 16) | ((unsigned int)g << 8) | (mine[g] & 0xff);
     __syncthreads();
     for (unsigned int k = threadIdx.x; k < total; k += kBlock) {
         const unsigned int e = entry[k];
-        const unsigned int tile = t0 + (e >> 8);
+        const unsigned int tile = t0 + ((e >> 8) & 0xff), trank = e >> 16;
         const int veg = (int)(tile / tiles_per_veg);
         const long long pix = (long long)(tile - (unsigned int)veg * tiles_per_veg) * kBlock + (e & 0xff);
-        soil_column<false, FASTPOW>(A, P, veg, pix);
+        const size_t slot = trank < S.cap ? (size_t)tile * S.cap + trank : (size_t)-1;
+        soil_column<false, FASTPOW>(A, P, veg, pix, S, slot, nullptr, tile, nullptr);
     }
 }
 
@@ -408,7 +466,30 @@ int lf_soil_columns_device(int device, const lf_soil_args *a)
     // tile counts | per-tile lane lists
     const unsigned int tiles_per_veg = (unsigned int)blocks_for(a->N);
     const size_t ntiles = (size_t)tiles_per_veg * (size_t)a->V;
-    const size_t need = sizeof(unsigned int) * (ntiles + 4) + sizeof(unsigned short) * ntiles * kBlock;
+    // staging area of the deferred columns' inputs: LF_SOIL_STAGE_SLOTS per tile (default 96 of 256, 0 = off), used
+    // when the previous call deferred at least 4 % of its columns (the count comes back asynchronously)
+    unsigned int cap = 96;
+    if (const char *e = std::getenv("LF_SOIL_STAGE_SLOTS")) cap = (unsigned int)std::min(256L, std::max(0L, std::atol(e)));
+    const char *force = std::getenv("LF_SOIL_STAGE_ALWAYS"); // A/B switch
+    if (!c->soil_deferred_host) {
+        LF_HIP(hipHostMalloc((void **)&c->soil_deferred_host, sizeof(unsigned long long), hipHostMallocDefault));
+        *c->soil_deferred_host = 0;
+        LF_HIP(hipMalloc((void **)&c->soil_deferred_dev, sizeof(unsigned long long)));
+        LF_HIP(hipEventCreateWithFlags(&c->soil_deferred_ready, hipEventDisableTiming));
+    }
+    bool stage = false;
+    if (cap > 0) {
+        if (force && force[0] == '1')
+            stage = true;
+        else if (c->soil_deferred_pending && hipEventQuery(c->soil_deferred_ready) == hipSuccess)
+            stage = (double)*c->soil_deferred_host >= 0.04 * (double)c->soil_deferred_columns;
+        else
+            stage = c->soil_stage_last;
+    }
+    c->soil_stage_last = stage;
+    if (!stage) cap = 0;
+    const size_t lists = (sizeof(unsigned int) * (ntiles + 4) + sizeof(unsigned short) * ntiles * kBlock + 255) & ~(size_t)255;
+    const size_t need = lists + sizeof(double) * (size_t)kStageFields * ntiles * cap;
     if (c->soil_ws_bytes < need) {
         if (c->soil_ws) LF_HIP(hipFree(c->soil_ws));
         c->soil_ws = nullptr;
@@ -419,20 +500,35 @@ int lf_soil_columns_device(int device, const lf_soil_args *a)
     unsigned int *tile_count = (unsigned int *)c->soil_ws;
     unsigned short *tile_list = (unsigned short *)(tile_count + ntiles + 4);
     c->soil_ntiles = ntiles;
+    soil_stage S;
+    S.buf = (double *)((char *)c->soil_ws + lists);
+    S.cap = cap;
+    S.nslots = ntiles * cap;
     // LF_GENERAL_POW=1: OCML pow instead of lf_pow_pos (A/B parity and timing)
     const char *force_general = std::getenv("LF_GENERAL_POW");
     const bool fastpow = !(force_general && force_general[0] == '1');
     const dim3 grid1(tiles_per_veg, (unsigned)a->V), block(kBlock);
     const dim3 grid2((unsigned)((ntiles + kGroup - 1) / kGroup));
-    if (fastpow) {
-        hipLaunchKernelGGL(k_soil_columns<true>, grid1, block, 0, c->stream, *a, P, tile_list, tile_count);
+    LF_HIP(hipMemsetAsync(c->soil_deferred_dev, 0, sizeof(unsigned long long), c->stream));
+    if (fastpow && stage)
+        hipLaunchKernelGGL((k_soil_columns<true, true>), grid1, block, 0, c->stream, *a, P, tile_list, tile_count, S);
+    else if (fastpow)
+        hipLaunchKernelGGL((k_soil_columns<true, false>), grid1, block, 0, c->stream, *a, P, tile_list, tile_count, S);
+    else if (stage)
+        hipLaunchKernelGGL((k_soil_columns<false, true>), grid1, block, 0, c->stream, *a, P, tile_list, tile_count, S);
+    else
+        hipLaunchKernelGGL((k_soil_columns<false, false>), grid1, block, 0, c->stream, *a, P, tile_list, tile_count, S);
+    if (fastpow)
         hipLaunchKernelGGL(k_soil_columns_deferred<true>, grid2, block, 0, c->stream, *a, P, tile_list, tile_count,
-                           (unsigned int)ntiles, tiles_per_veg);
-    } else {
-        hipLaunchKernelGGL(k_soil_columns<false>, grid1, block, 0, c->stream, *a, P, tile_list, tile_count);
+                           (unsigned int)ntiles, tiles_per_veg, S, c->soil_deferred_dev);
+    else
         hipLaunchKernelGGL(k_soil_columns_deferred<false>, grid2, block, 0, c->stream, *a, P, tile_list, tile_count,
-                           (unsigned int)ntiles, tiles_per_veg);
-    }
+                           (unsigned int)ntiles, tiles_per_veg, S, c->soil_deferred_dev);
+    LF_HIP(hipMemcpyAsync(c->soil_deferred_host, c->soil_deferred_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                          c->stream));
+    LF_HIP(hipEventRecord(c->soil_deferred_ready, c->stream));
+    c->soil_deferred_pending = true;
+    c->soil_deferred_columns = (unsigned long long)a->V * (unsigned long long)a->N;
     LF_HIP(hipGetLastError());
     return LF_OK;
 }
