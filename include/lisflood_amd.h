@@ -21,7 +21,11 @@
  *   - pointers named *_host are caller-owned host memory, *_dev are device memory obtained from
  *     lf_device_alloc (or any hipMalloc'ed pointer of the same device);
  *   - there is NO CPU fallback: every compute entry point fails with LF_E_NO_DEVICE when no gfx950
- *     device is usable.
+ *     device is usable;
+ *   - execution model: one HIP stream per device, every entry point enqueues on it and returns (only the *_host
+ *     forms, lf_memcpy_* and lf_device_synchronize wait); per-device scratch (soil work lists, router buffers) is
+ *     not locked, so drive a device from ONE host thread -- use one process per GPU for multi-GPU work, as
+ *     bench.py does.
  */
 #ifndef LISFLOOD_AMD_H
 #define LISFLOOD_AMD_H
