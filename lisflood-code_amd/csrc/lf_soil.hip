@@ -97,6 +97,7 @@ struct veg_plan {
 // fully used lines instead of one 64-byte sector per 8-byte value scattered over ~46 vectors (measured: 6 GB fetched
 // for 0.8 GB of inputs).  A tile has room for `cap` columns; the ones beyond gather from the vectors as before.
 constexpr int kStageFields = 46;
+constexpr unsigned int kStageCap = 96; // slots per tile (of 256 columns); pass 1 collects them in LDS: 46 x 96 x 8 B = 35 KB
 struct soil_stage {
     double *buf;      // [kStageFields][nslots]
     size_t nslots;    // ntiles * cap
@@ -110,7 +111,7 @@ struct soil_stage {
 template <bool DEFER, bool FASTPOW, bool STAGE = false>
 __device__ __forceinline__ long long soil_column(const lf_soil_args &A, const veg_plan &P, int veg, long long pix,
                                                  const soil_stage &S, size_t slot, unsigned int *lds_count,
-                                                 unsigned int tile, unsigned int *rank_out)
+                                                 unsigned int tile, unsigned int *rank_out, double *lds_stage = nullptr)
 {
     const long long N = A.N;
     const double DtDay = A.DtDay;
@@ -194,10 +195,9 @@ __device__ __forceinline__ long long soil_column(const lf_soil_args &A, const ve
     if (DEFER && nsub > 1) {
         const unsigned int rank = atomicAdd(lds_count, 1u); // LDS: position in the tile's list
         *rank_out = rank;
-        if (STAGE && rank < S.cap) {
-            const size_t sl = (size_t)tile * S.cap + rank;
+        if (STAGE && rank < kStageCap) { // into the block's LDS table; the block writes it out in full lines afterwards
             int f = 0;
-#define ST(v) S.buf[(size_t)(f++) * S.nslots + sl] = (v)
+#define ST(v) lds_stage[(f++) * kStageCap + rank] = (v)
             // the inputs whose registers are dead by now are read again (cache hits, deferred lanes only) rather than
             // kept alive across the infiltration arithmetic: pass 1 has no registers to spare
             ST(A.Rain[pix]); ST(A.SnowMelt[pix]); ST(A.LeafDrainage[i]); ST(A.Interception[i]);
@@ -310,6 +310,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(LF_
                                                          unsigned int *__restrict__ tile_count, soil_stage S)
 {
     __shared__ unsigned int count;
+    __shared__ double lds_stage[STAGE ? kStageFields * kStageCap : 1];
     if (threadIdx.x == 0) count = 0;
     __syncthreads();
     const long long pix = (long long)blockIdx.x * kBlock + threadIdx.x;
@@ -320,7 +321,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(LF_
     if (active && mode == 2 && !A.paddy_inactive[(long long)P.paddy_row[veg] * A.N + pix]) active = false;
     if (active) {
         unsigned int rank = 0;
-        const long long nsub = soil_column<true, FASTPOW, STAGE>(A, P, veg, pix, S, 0, &count, tile, &rank);
+        const long long nsub = soil_column<true, FASTPOW, STAGE>(A, P, veg, pix, S, 0, &count, tile, &rank, lds_stage);
         if (nsub > 0) {
             int c = 63 - __clzll((unsigned long long)nsub); // floor(log2(nsub)) >= 1
             c = c < kClasses - 1 ? c : kClasses - 1;
@@ -329,6 +330,13 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(LF_
     }
     __syncthreads();
     if (threadIdx.x == 0) tile_count[tile] = count;
+    if (STAGE) { // the tile's staged inputs, field by field: contiguous runs of up to 96 doubles (no partial lines)
+        const unsigned int n = count < kStageCap ? count : kStageCap;
+        for (unsigned int idx = threadIdx.x; idx < (unsigned int)kStageFields * n; idx += kBlock) {
+            const unsigned int f = idx / n, t = idx - f * n;
+            S.buf[(size_t)f * S.nslots + (size_t)tile * kStageCap + t] = lds_stage[f * kStageCap + t];
+        }
+    }
 }
 
 // Pass 2: the deferred columns of kGroup consecutive tiles, sorted by sub-step class, one lane each.
@@ -466,10 +474,10 @@ int lf_soil_columns_device(int device, const lf_soil_args *a)
     // tile counts | per-tile lane lists
     const unsigned int tiles_per_veg = (unsigned int)blocks_for(a->N);
     const size_t ntiles = (size_t)tiles_per_veg * (size_t)a->V;
-    // staging area of the deferred columns' inputs: LF_SOIL_STAGE_SLOTS per tile (default 96 of 256, 0 = off), used
+    // staging area of the deferred columns' inputs: 96 slots per tile of 256 columns (LF_SOIL_STAGE_SLOTS=0: off), used
     // when the previous call deferred at least 4 % of its columns (the count comes back asynchronously)
-    unsigned int cap = 96;
-    if (const char *e = std::getenv("LF_SOIL_STAGE_SLOTS")) cap = (unsigned int)std::min(256L, std::max(0L, std::atol(e)));
+    unsigned int cap = kStageCap;
+    if (const char *e = std::getenv("LF_SOIL_STAGE_SLOTS")) cap = std::atol(e) > 0 ? kStageCap : 0; // 0 = never stage
     const char *force = std::getenv("LF_SOIL_STAGE_ALWAYS"); // A/B switch
     if (!c->soil_deferred_host) {
         LF_HIP(hipHostMalloc((void **)&c->soil_deferred_host, sizeof(unsigned long long), hipHostMallocDefault));
