@@ -248,3 +248,50 @@ def test_catchment_partition_is_closed_and_balanced(family):
     for c, m, ids in parts:
         gs = Graph(c, m)                                                     # builds: a closed sub-domain
         assert gs.num_pixels == ids.size and (gs.lookups()[0] >= -1).all()
+
+
+def test_inert_pixels_and_subdomain_renumbering():
+    """Host logic of the compact channel domain (lisflood_amd.hotpath): a pixel may be left out only if EVERY condition
+    holds -- isolated in the kinematic LDD, not a channel pixel, regular parameters, zero thresholds, +0.0 state, no
+    structure on it -- and the structure attributes are renumbered consistently."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "lisflood-code_amd"))
+    from lisflood_amd import hotpath as HP, synthetic as syn
+    H, W = 30, 40
+    values, sc, mask, l2c, kin = syn.hotpath_scenario(H, W)
+    N = H * W
+    base = HP.inert_pixels(values, kin, mask, True)
+    non = np.nonzero(~values["IsChannelKinematic"])[0]
+    assert base.sum() == non.size and not base[values["IsChannelKinematic"]].any()
+    def with_(k, i, x):
+        v = {a: (np.array(b, copy=True) if isinstance(b, np.ndarray) else b) for a, b in values.items()}
+        v[k][i] = x
+        return HP.inert_pixels(v, kin, mask, True)
+    p = int(non[3])
+    for k, x in (("ChanQKin", 1e-300), ("ChanM3Kin", 2.0), ("ChanQ", -0.0), ("Chan2QKin", 1.0), ("Chan2M3Kin", 1.0),
+                 ("CrossSection2Area", 1.0), ("Sideflow1Chan", 1.0), ("QLimit", 3.0), ("Chan2QStart", 1.0),
+                 ("Chan2M3Start", 1.0), ("InvChannelAlpha", np.inf), ("InvChanLength", np.nan), ("InvChannelAlpha2", np.inf)):
+        r = with_(k, p, x)
+        assert not r[p] and r.sum() == base.sum() - 1, k
+    assert with_("IsChannelKinematic", p, True)[p] == False
+    # a pixel that receives flow, or sends it, is never inert even if it is not a channel pixel
+    kin2 = kin.copy()
+    kin2[p] = 6.0 if (p % W) < W - 1 else 4.0
+    r = HP.inert_pixels(values, kin2, mask, True)
+    tgt = p + 1 if (p % W) < W - 1 else p - 1
+    assert not r[p] and not r[tgt]
+    # without split routing the floodplain vectors do not matter
+    v = dict(values); v["QLimit"] = values["QLimit"] + 1.0
+    assert HP.inert_pixels(v, kin, mask, False).sum() == base.sum()
+    # structures: a site pixel stays; indices and downstruct are renumbered onto the kept pixels
+    st = {"LakeIndex": np.array([int(non[5])]), "ReservoirIndex": np.array([int(np.nonzero(~base)[0][7])]),
+          "downstruct": np.arange(1, N + 1).astype(np.int32), "QInM3Old": np.zeros(N), "QDelta": np.zeros(N)}
+    st["QInM3Old"][non[9]] = 5.0
+    r = HP.inert_pixels(values, kin, mask, True, st)
+    assert not r[non[5]] and not r[non[9]] and r.sum() == base.sum() - 2
+    ids = np.nonzero(~r)[0]
+    sub = HP._structures_on_subdomain(st, ids, N)
+    assert ids[sub["LakeIndex"][0]] == non[5] and ids[sub["ReservoirIndex"][0]] == st["ReservoirIndex"][0]
+    ds = sub["downstruct"]
+    assert ds.size == ids.size and ((ds == ids.size) | (ids[np.minimum(ds, ids.size - 1)] == st["downstruct"][ids])).all()
+    assert sub["QInM3Old"].size == ids.size and sub["QInM3Old"].sum() == 5.0
