@@ -609,3 +609,125 @@ void lfo_sweep_positions(double *state, const double *constant, const int32_t *u
         state[p] = q;
     }
 }
+
+
+/* ------------------------------------------------------------------------------------------------
+ * Structures inside the routing loop (routing.py:441-478): lakes.dynamic_inloop (lakes.py:199-297),
+ * reservoir.dynamic_inloop (reservoir.py:173-322), inflow.dynamic_inloop (inflow.py:129-147),
+ * transmission.dynamic_inloop (transmission.py:67-89) and the SideflowChanM3 assembly (routing.py:462-478).
+ * Same argument block as lf_inloop_args of include/lisflood_amd.h, host pointers, pixel order.
+ * Site inflow = np.bincount(downstruct, weights=ChanQ)[site]: the cells draining into the site, ascending id
+ * (lakes.py:215, reservoir.py:190), given as CSR lists.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    const double *ChanQ;
+    int64_t n_lakes;
+    const int32_t *lake_cell, *lake_ups_ptr, *lake_ups_idx;
+    const double *LakeFactor, *LakeFactorSqr, *LakeAreaCC;
+    double *LakeStorageM3CC, *LakeInflowOldCC, *LakeOutflowCC, *LakeStorageM3BalanceCC, *LakeLevelCC, *LakeInflowCC;
+    double *QLakeOutM3Dt;
+    int64_t n_res;
+    const int32_t *res_cell, *res_ups_ptr, *res_ups_idx;
+    const double *TotalReservoirStorageM3CC, *MinReservoirOutflowCC, *NormalReservoirOutflowCC,
+        *NonDamagingReservoirOutflowCC, *ConservativeStorageLimitCC, *NormalStorageLimitCC, *FloodStorageLimitCC,
+        *Normal_FloodStorageLimitCC, *DeltaO, *DeltaLN, *DeltaNFL;
+    double *ReservoirStorageM3CC, *ReservoirFillCC, *ReservoirInflowCC;
+    double *QResOutM3Dt;
+    const double *QInM3Old, *QDelta;
+    double *QInDt, *QinADDEDM3;
+    const uint8_t *UpTrans;
+    double *TransLossM3Dt, *TransCum;
+    double TransPower1, TransPower2, TransSub;
+    const double *ToChanM3RunoffDt, *EvaAddM3Dt, *WUseAddM3Dt, *ChannelToPolderM3Dt;
+    double *SideflowChanM3;
+    double DtRouting, InvNoRoutSteps;
+    int64_t N;
+    int32_t step;
+} lfo_inloop_args;
+
+/* np.minimum / np.maximum: a NaN operand wins, first operand first */
+static double np_min(double a, double b) { return (a != a) ? a : ((b != b) ? b : (b < a ? b : a)); }
+static double np_max(double a, double b) { return (a != a) ? a : ((b != b) ? b : (b > a ? b : a)); }
+
+void lfo_inloop_structures(const lfo_inloop_args *A)
+{
+    const double dt = A->DtRouting;
+    /* lakes: modified Puls with the outflow as a parabola of the level (lakes.py:215-258) */
+    for (int64_t i = 0; i < A->n_lakes; ++i) {
+        double qin = 0.0;
+        for (int32_t e = A->lake_ups_ptr[i]; e < A->lake_ups_ptr[i + 1]; ++e) qin += A->ChanQ[A->lake_ups_idx[e]];
+        A->LakeInflowCC[i] = qin;
+        const double mean_in = (qin + A->LakeInflowOldCC[i]) * 0.5; /* lakes.py:218 */
+        A->LakeInflowOldCC[i] = qin;
+        const double si = A->LakeStorageM3CC[i] / dt - 0.5 * A->LakeOutflowCC[i] + mean_in; /* :224 */
+        const double root = -A->LakeFactor[i] + sqrt(A->LakeFactorSqr[i] + 2 * si);           /* :228 */
+        const double qout = root * root;
+        A->LakeOutflowCC[i] = qout;
+        const double vol_out = qout * dt;
+        double st = (si - qout * 0.5) * dt; /* :245 */
+        if (st < 0 || st != st) st = 0;     /* :250-255 */
+        A->LakeStorageM3CC[i] = st;
+        A->LakeStorageM3BalanceCC[i] += mean_in * dt - vol_out;
+        A->LakeLevelCC[i] = st / A->LakeAreaCC[i];
+        A->QLakeOutM3Dt[A->lake_cell[i]] = vol_out;
+    }
+    /* reservoirs: piecewise outflow rule on the filling fraction (reservoir.py:190-296) */
+    for (int64_t r = 0; r < A->n_res; ++r) {
+        const double per_day = 1 / 86400.0;
+        double qin = 0.0;
+        for (int32_t e = A->res_ups_ptr[r]; e < A->res_ups_ptr[r + 1]; ++e) qin += A->ChanQ[A->res_ups_idx[e]];
+        A->ReservoirInflowCC[r] = qin;
+        const double cap = A->TotalReservoirStorageM3CC[r];
+        double st = A->ReservoirStorageM3CC[r] + qin * dt; /* reservoir.py:206 */
+        const double fill = st / cap;
+        const double qmin = A->MinReservoirOutflowCC[r], qnorm = A->NormalReservoirOutflowCC[r],
+                     qnd = A->NonDamagingReservoirOutflowCC[r];
+        const double two_lc = 2 * A->ConservativeStorageLimitCC[r], ln = A->NormalStorageLimitCC[r],
+                     lf = A->FloodStorageLimitCC[r], lnf = A->Normal_FloodStorageLimitCC[r];
+        /* the four candidate rules, :212-229, then the cascade of np.where in the reference's order, :235-245 */
+        const double rule1 = np_min(qmin, st * per_day);
+        const double rule2 = qmin + A->DeltaO[r] * (fill - two_lc) / A->DeltaLN[r];
+        const double rule3 = qnorm + ((fill - lnf) / A->DeltaNFL[r]) * (qnd - qnorm);
+        const double rule4 = np_max((fill - lf - 0.01) * cap * per_day, np_min(qnd, np_max(qin * 1.2, qnorm)));
+        double q = rule1;
+        if (fill > two_lc) q = rule2;
+        if (fill > ln) q = qnorm;
+        if (fill > lnf) q = rule3;
+        if (fill > lf) q = rule4;
+        const double damped = np_min(q, np_max(qin, qnorm)); /* :247-251 */
+        if ((q > 1.2 * qin) && (q > qnorm) && (fill < lf)) q = damped;
+        double vol_out = q * dt;
+        vol_out = np_min(vol_out, st);       /* :253-258: not more than is stored, not less than the overflow */
+        vol_out = np_max(vol_out, st - cap);
+        st -= vol_out;
+        double f2 = st / cap;
+        if (f2 != f2 || f2 < 0) f2 = 0;
+        A->ReservoirStorageM3CC[r] = st;
+        A->ReservoirFillCC[r] = f2;
+        A->QResOutM3Dt[A->res_cell[r]] = vol_out;
+    }
+    /* inflow hydrographs, transmission loss, sideflow assembly */
+    for (int64_t p = 0; p < A->N; ++p) {
+        double side = A->ToChanM3RunoffDt[p];
+        if (A->EvaAddM3Dt) side -= A->EvaAddM3Dt[p];
+        if (A->WUseAddM3Dt) side -= A->WUseAddM3Dt[p];
+        if (A->QInM3Old) { /* inflow.py:142-144 */
+            const double qin = (A->QInM3Old[p] + (A->step + 1) * A->QDelta[p]) * A->InvNoRoutSteps;
+            A->QInDt[p] = qin;
+            A->QinADDEDM3[p] = (A->step < 1 ? 0.0 : A->QinADDEDM3[p]) + qin;
+            side += qin;
+        }
+        if (A->UpTrans) { /* transmission.py:76-87 */
+            const double q = A->ChanQ[p];
+            const double below = A->UpTrans[p] ? pow(pow(q, A->TransPower2) - A->TransSub, A->TransPower1) : q;
+            const double loss = (q - below) * dt;
+            A->TransLossM3Dt[p] = loss;
+            A->TransCum[p] += loss;
+            side -= loss;
+        }
+        if (A->QLakeOutM3Dt) side += A->QLakeOutM3Dt[p];
+        if (A->QResOutM3Dt) side += A->QResOutM3Dt[p];
+        if (A->ChannelToPolderM3Dt) side -= A->ChannelToPolderM3Dt[p];
+        A->SideflowChanM3[p] = side;
+    }
+}

@@ -198,12 +198,13 @@ class RoutingSubstep:
     def __init__(self, router, v):
         self.r, self.v = router, v   # v: namespace with the reference's var names
 
-    def dynamic(self, split):
+    def dynamic(self, split, sideflow_m3=None):
+        """sideflow_m3: SideflowChanM3 of the sub-step (default: the runoff alone, no in-loop modules)"""
         v, L = self.v, lib()
         N = v.ChanQKin.size
         n = C.c_int64(N)
         side = np.empty(N)
-        L.lfo_sideflow(_ptr(_f(v.ToChanM3RunoffDt)), _ptr(_u8(v.IsChannelKinematic)), _ptr(_f(v.InvChanLength)),
+        L.lfo_sideflow(_ptr(_f(v.ToChanM3RunoffDt if sideflow_m3 is None else sideflow_m3)), _ptr(_u8(v.IsChannelKinematic)), _ptr(_f(v.InvChanLength)),
                        C.c_double(v.InvDtRouting), C.c_int(0 if split else 1), n, _ptr(side))
         fix = lambda: L.lfo_main_fixup(_ptr(v.ChanQKin), _ptr(v.ChanM3Kin), _ptr(_f(v.ChanLength)),
                                        _ptr(_f(v.ChannelAlpha)), _ptr(_f(v.InvChanLength)),
@@ -231,6 +232,84 @@ class RoutingSubstep:
         v.FlowVelocity, v.TravelDistance = np.empty(N), np.empty(N)
         L.lfo_velocity(_ptr(v.ChanM3Kin), _ptr(v.ChanQKin), _ptr(_f(v.InvChanLength)), _ptr(_f(v.PixelArea)),
                        C.c_double(v.DtSec), n, _ptr(v.FlowVelocity), _ptr(v.TravelDistance))
+
+
+_INLOOP_PTRS = (
+    "ChanQ n_lakes lake_cell lake_ups_ptr lake_ups_idx LakeFactor LakeFactorSqr LakeAreaCC LakeStorageM3CC "
+    "LakeInflowOldCC LakeOutflowCC LakeStorageM3BalanceCC LakeLevelCC LakeInflowCC QLakeOutM3Dt n_res res_cell "
+    "res_ups_ptr res_ups_idx TotalReservoirStorageM3CC MinReservoirOutflowCC NormalReservoirOutflowCC "
+    "NonDamagingReservoirOutflowCC ConservativeStorageLimitCC NormalStorageLimitCC FloodStorageLimitCC "
+    "Normal_FloodStorageLimitCC DeltaO DeltaLN DeltaNFL ReservoirStorageM3CC ReservoirFillCC ReservoirInflowCC "
+    "QResOutM3Dt QInM3Old QDelta QInDt QinADDEDM3 UpTrans TransLossM3Dt TransCum").split()
+
+
+class _InloopArgs(C.Structure):  # lfo_inloop_args (lf_oracle.c)
+    _fields_ = ([(k, C.c_int64 if k in ("n_lakes", "n_res") else C.c_void_p) for k in _INLOOP_PTRS] +
+                [("TransPower1", C.c_double), ("TransPower2", C.c_double), ("TransSub", C.c_double)] +
+                [(k, C.c_void_p) for k in ("ToChanM3RunoffDt", "EvaAddM3Dt", "WUseAddM3Dt", "ChannelToPolderM3Dt",
+                                           "SideflowChanM3")] +
+                [("DtRouting", C.c_double), ("InvNoRoutSteps", C.c_double), ("N", C.c_int64), ("step", C.c_int32)])
+
+
+class InloopStructures:
+    """lakes / reservoir / inflow / transmission .dynamic_inloop + the SideflowChanM3 assembly (routing.py:441-478)
+    on host arrays of a `var` namespace with the reference's attribute names (all four options on)."""
+
+    def __init__(self, v):
+        self.v = v
+        N = self.N = np.asarray(v.ChanQ).size
+        ds = np.asarray(v.downstruct).astype(np.int64)
+        order = np.argsort(ds, kind="stable")
+        starts = np.searchsorted(ds[order], np.arange(N + 1))
+
+        def csr(cells):
+            ptr, idx = np.zeros(len(cells) + 1, np.int32), []
+            for i, c in enumerate(cells):
+                u = order[starts[c]:starts[c + 1]]
+                idx.append(u)
+                ptr[i + 1] = ptr[i] + u.size
+            idx = np.concatenate(idx).astype(np.int32) if idx else np.zeros(0, np.int32)
+            return ptr, (idx if idx.size else np.zeros(1, np.int32))
+        self.lake_cell = np.asarray(v.LakeIndex).astype(np.int32)
+        self.res_cell = np.asarray(v.ReservoirIndex).astype(np.int32)
+        self.lake_csr, self.res_csr = csr(self.lake_cell), csr(self.res_cell)
+        nl, nr = self.lake_cell.size, self.res_cell.size
+        for k in ("LakeInflowCC",):
+            setattr(v, k, np.zeros(nl))
+        for k in ("ReservoirInflowCC", "ReservoirFillCC"):
+            setattr(v, k, np.zeros(nr))
+        for k in ("QLakeOutM3Dt", "QResOutM3Dt", "QInDt", "QinADDEDM3", "TransLossM3Dt", "SideflowChanM3"):
+            setattr(v, k, np.zeros(N))
+
+    def dynamic_inloop(self, step):
+        v = self.v
+        if step == 0:      # lakes.py:212-213, reservoir.py:195-196
+            v.LakeStorageM3CC = _f(np.asarray(v.LakeStorageM3)[self.lake_cell]).copy()
+            v.ReservoirStorageM3CC = _f(np.asarray(v.ReservoirStorageM3)[self.res_cell]).copy()
+        a, keep = _InloopArgs(), []
+
+        def put(name, arr):
+            keep.append(arr)
+            setattr(a, name, arr.ctypes.data)
+        put("ChanQ", _f(v.ChanQ))
+        a.n_lakes, a.n_res = self.lake_cell.size, self.res_cell.size
+        put("lake_cell", self.lake_cell); put("lake_ups_ptr", self.lake_csr[0]); put("lake_ups_idx", self.lake_csr[1])
+        put("res_cell", self.res_cell); put("res_ups_ptr", self.res_csr[0]); put("res_ups_idx", self.res_csr[1])
+        for k in ("LakeFactor", "LakeFactorSqr", "LakeAreaCC", "TotalReservoirStorageM3CC", "MinReservoirOutflowCC",
+                  "NormalReservoirOutflowCC", "NonDamagingReservoirOutflowCC", "ConservativeStorageLimitCC",
+                  "NormalStorageLimitCC", "FloodStorageLimitCC", "Normal_FloodStorageLimitCC", "DeltaO", "DeltaLN",
+                  "DeltaNFL", "QInM3Old", "QDelta", "ToChanM3RunoffDt"):
+            put(k, _f(np.broadcast_to(getattr(v, k), (self.N,) if k in ("QInM3Old", "QDelta", "ToChanM3RunoffDt") else np.shape(getattr(v, k)))))
+        put("UpTrans", _u8(v.UpTrans))
+        for k in ("LakeStorageM3CC", "LakeInflowOldCC", "LakeOutflowCC", "LakeStorageM3BalanceCC", "LakeLevelCC",
+                  "LakeInflowCC", "QLakeOutM3Dt", "ReservoirStorageM3CC", "ReservoirFillCC", "ReservoirInflowCC",
+                  "QResOutM3Dt", "QInDt", "QinADDEDM3", "TransLossM3Dt", "TransCum", "SideflowChanM3"):
+            x = getattr(v, k)
+            assert x.dtype == np.float64 and x.flags.c_contiguous, k
+            put(k, x)
+        a.TransPower1, a.TransPower2, a.TransSub = float(v.TransPower1), float(v.TransPower2), float(v.TransSub)
+        a.DtRouting, a.InvNoRoutSteps, a.N, a.step = float(v.DtRouting), float(v.InvNoRoutSteps), self.N, int(step)
+        lib().lfo_inloop_structures(C.byref(a))
 
 
 def sweep_positions(state, constant, ups_ptr, ups_idx, a, ba, beta, begin, end):

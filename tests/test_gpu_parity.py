@@ -660,6 +660,62 @@ def test_structures_wavefront_mid_size_synthetic(amd, family):
     assert np.isfinite(va.ChanQ).all() and va.QLakeOutM3Dt.max() > 0 and va.QResOutM3Dt.max() > 0 and va.TransCum.max() > 0
 
 
+def test_structures_mid_size_vs_oracle(amd, oracle):
+    """The device's structures + routing sub-step loop against the C oracle (itself 0 ulp from the reference's modules
+    on the LF_ETRS89 fixture) on a 1.2e5-cell synthetic network with 12 lakes, 36 reservoirs, inflow points and
+    transmission loss: 24 sub-steps, every state vector within the parity tolerance."""
+    from lisflood_amd import synthetic as syn
+    H, W = 300, 400
+    N = H * W
+    mask = np.ones((H, W), bool)
+    codes = syn.make_ldd("deep", H, W, 11).reshape(-1).astype(np.float64)
+    p = syn.router_params(N, seed=7)
+    rng = np.random.default_rng(37)
+    beta, dt, nsteps = p["beta"], 3600.0, 24
+    alpha, length = p["alpha"], p["dx"]
+    alpha2 = alpha * rng.uniform(1.2, 2.0, N)
+    qlimit = 2.0 * p["Q0"] * rng.uniform(0.3, 1.2, N)
+
+    def var():
+        v = types.SimpleNamespace(
+            ChanLength=length, InvChanLength=1 / length, ChannelAlpha=alpha, InvChannelAlpha=1 / alpha,
+            ChannelAlpha2=alpha2, InvChannelAlpha2=1 / alpha2, QLimit=qlimit, M3Limit=alpha * length * qlimit ** beta,
+            Chan2M3Start=alpha2 * length * qlimit ** beta, Chan2QStart=qlimit * 0.1, PixelArea=np.full(N, 2.5e7),
+            IsChannelKinematic=np.ones(N, bool), Beta=beta, InvBeta=1 / beta, DtRouting=dt, InvDtRouting=1 / dt,
+            NoRoutSteps=nsteps, InvNoRoutSteps=1 / nsteps, DtSec=dt * nsteps,
+            ToChanM3RunoffDt=syn.lateral_inflow(N, 0) * length * dt)
+        v.Chan2M3Kin = v.Chan2M3Start.copy()
+        v.ChanM3Kin = alpha * length * p["Q0"] ** beta
+        v.ChanQKin = p["Q0"].copy()
+        v.Chan2QKin = (v.Chan2M3Kin / length / alpha2) ** (1 / beta)
+        v.ChanQ = v.ChanQKin.copy()
+        v.CrossSection2Area, v.Sideflow1Chan, v.sumDisDay = np.zeros(N), np.zeros(N), np.zeros(N)
+        d, cut = syn.structures_scenario(codes, (H, W), v.ChanQ, dt, n_lakes=12, n_res=36)
+        for k, x in d.items():
+            setattr(v, k, np.array(x, copy=True) if isinstance(x, np.ndarray) else x)
+        return v, cut
+
+    vg, cut = var()
+    m = amd.routing.routing(vg, options=dict(SplitRouting=True, InitLisflood=False, simulateLakes=True,
+                                             simulateReservoirs=True, inflow=True, TransLoss=True), engine_order=True)
+    m.attach_router(cut, mask)
+    m.attach_structures()
+    m.dynamic_fused()
+    vc, _ = var()
+    kw = oracle.kinematicWave(cut, mask, alpha, beta, length, dt, alpha_floodplains=alpha2)
+    st, sub = oracle.InloopStructures(vc), oracle.RoutingSubstep(kw, vc)
+    for s in range(nsteps):
+        st.dynamic_inloop(s)
+        sub.dynamic(split=True, sideflow_m3=vc.SideflowChanM3)
+    # transmission loss = (Q - (Q^p2 - sub)^p1) * dt is a difference of nearly equal numbers: its absolute error is a few
+    # ulp of Q * dt whatever the loss itself is, so that is the scale of its tolerance
+    cancel = 256 * np.finfo(float).eps * float(np.max(vc.ChanQ)) * dt
+    for k in _STRUCT_KEYS:
+        atol = cancel * (nsteps if k == "TransCum" else 1) if k in ("TransLossM3Dt", "TransCum") else 1e-6
+        np.testing.assert_allclose(getattr(vg, k), getattr(vc, k), rtol=RTOL, atol=atol, err_msg=k)
+    assert vc.QLakeOutM3Dt.max() > 0 and vc.QResOutM3Dt.max() > 0 and vc.TransCum.max() > 0
+
+
 def test_pixel_aggregates_golden(amd):
     """opensealed.dynamic -> soil.dynamic_perpixel -> groundwater.dynamic as one device pass, against vectors
     captured from the reference's own module methods (two consecutive steps)."""
