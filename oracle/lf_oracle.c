@@ -731,3 +731,97 @@ void lfo_inloop_structures(const lfo_inloop_args *A)
         A->SideflowChanM3[p] = side;
     }
 }
+
+
+/* ------------------------------------------------------------------------------------------------
+ * Per-pixel aggregates between the soil columns and surface routing (Lisflood_dynamic.py:129-149):
+ * opensealed.dynamic (opensealed.py:40-71), soil.dynamic_perpixel (soil.py:471-514), groundwater.dynamic
+ * (groundwater.py:134-180), three prescribed vegetation fractions.  Same argument block as lf_pixel_args.
+ * deffraction(X) = (SoilFraction * X).sum("vegetation") = ((f0*x0 + f1*x1) + f2*x2)  (soil.py:460-468).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    const double *SoilFraction, *TaInterception, *Ta, *ESAct, *PrefFlow, *Infiltration, *SeepTopToSubA, *SeepTopToSubB,
+        *SeepSubToGW, *Theta1a, *Theta1b, *Theta2, *W1a, *W1b, *W2, *UZOutflow, *GwPercUZLZ, *SoilDepthTotal;
+    const double *Rain, *SnowMelt, *EWRef, *SMaxSealed, *DirectRunoffFraction, *WaterFraction, *LowerZoneK, *LZThreshold,
+        *GwLossStep;
+    double *CumInterSealed, *LZ, *LZInflowCUM, *TaInterceptionCUM, *TaCUM, *ESActCUM, *GwLossCUM;
+    double *RainSnowmelt, *EWaterAct, *InterSealed, *TASealed, *DirectRunoff, *TaInterceptionAll, *TaPixel, *ESActPixel,
+        *PrefFlowPixel, *InfiltrationPixel, *ThetaAll, *SeepTopToSubPixelA, *SeepTopToSubPixelB, *SeepSubToGWPixel,
+        *Theta1aPixel, *Theta1bPixel, *Theta2Pixel, *LZOutflow, *UZOutflowPixel, *GwPercUZLZPixel, *GwLossLZ, *LZAvInflow,
+        *LZOutflowToChannelPixel;
+    double *Theta;
+    double InvDtDay, TimeSinceStart;
+    int64_t N;
+} lfo_pixel_args;
+
+static double frac_sum(const double *f, const double *x, int64_t N, int64_t p)
+{
+    return (f[p] * x[p] + f[N + p] * x[N + p]) + f[2 * N + p] * x[2 * N + p];
+}
+
+void lfo_pixel_aggregates(const lfo_pixel_args *A)
+{
+    const int64_t N = A->N;
+    const double *f = A->SoilFraction;
+    for (int64_t p = 0; p < N; ++p) {
+        /* direct runoff from sealed area and open water, opensealed.py:45-70 */
+        const double ewref = A->EWRef[p], sealed = A->DirectRunoffFraction[p], water = A->WaterFraction[p];
+        const double supply = np_max(A->Rain[p] + A->SnowMelt[p], 0.0);
+        const double ewact = np_max(np_min(ewref, supply) * 1.0, 0.0);
+        double store = A->CumInterSealed[p];
+        const double caught = np_min(np_max(A->SMaxSealed[p] - store, 0.0), supply);
+        store += caught;
+        const double evap = np_max(np_min(store, ewref), 0.0);
+        store = np_max(store - evap, 0.0);
+        A->RainSnowmelt[p] = supply;
+        A->EWaterAct[p] = ewact;
+        A->InterSealed[p] = caught;
+        A->TASealed[p] = evap;
+        A->CumInterSealed[p] = store;
+        A->DirectRunoff[p] = sealed * (supply - caught) + water * (supply - ewact);
+        /* fraction-weighted pixel totals, soil.py:475-513 */
+        const double ta_int = frac_sum(f, A->TaInterception, N, p) + sealed * evap;
+        A->TaInterceptionAll[p] = ta_int;
+        A->TaInterceptionCUM[p] += ta_int;
+        const double ta = frac_sum(f, A->Ta, N, p);
+        A->TaPixel[p] = ta;
+        A->TaCUM[p] += ta;
+        const double es = frac_sum(f, A->ESAct, N, p) + water * ewact;
+        A->ESActPixel[p] = es;
+        A->ESActCUM[p] += es;
+        A->PrefFlowPixel[p] = frac_sum(f, A->PrefFlow, N, p);
+        A->InfiltrationPixel[p] = frac_sum(f, A->Infiltration, N, p);
+        double th[3];
+        for (int v = 0; v < 3; ++v) {
+            const int64_t i = v * N + p;
+            th[v] = f[i] * (A->W1a[i] + A->W1b[i] + A->W2[i]) / A->SoilDepthTotal[i];
+            A->Theta[i] = th[v];
+        }
+        const double fsum = (f[p] + f[N + p]) + f[2 * N + p];
+        A->ThetaAll[p] = (fsum > 0) ? ((th[0] + th[1]) + th[2]) / fsum : 0.0;
+        A->SeepTopToSubPixelA[p] = frac_sum(f, A->SeepTopToSubA, N, p);
+        A->SeepTopToSubPixelB[p] = frac_sum(f, A->SeepTopToSubB, N, p);
+        A->SeepSubToGWPixel[p] = frac_sum(f, A->SeepSubToGW, N, p);
+        A->Theta1aPixel[p] = frac_sum(f, A->Theta1a, N, p);
+        A->Theta1bPixel[p] = frac_sum(f, A->Theta1b, N, p);
+        A->Theta2Pixel[p] = frac_sum(f, A->Theta2, N, p);
+        /* lower groundwater zone, groundwater.py:137-180 */
+        double lz = A->LZ[p];
+        const double out = np_max(np_min(A->LowerZoneK[p] * lz, lz - A->LZThreshold[p]), 0.0);
+        A->LZOutflow[p] = out;
+        lz -= out;
+        A->UZOutflowPixel[p] = frac_sum(f, A->UZOutflow, N, p);
+        const double perc = frac_sum(f, A->GwPercUZLZ, N, p);
+        A->GwPercUZLZPixel[p] = perc;
+        lz += perc;
+        const double loss = np_max(np_min(A->GwLossStep[p], lz), 0.0);
+        lz -= loss;
+        A->GwLossLZ[p] = loss;
+        A->LZ[p] = lz;
+        const double cum = np_max(A->LZInflowCUM[p] + (perc - loss), 0.0);
+        A->LZInflowCUM[p] = cum;
+        A->GwLossCUM[p] += loss;
+        A->LZAvInflow[p] = (cum * A->InvDtDay) / A->TimeSinceStart;
+        A->LZOutflowToChannelPixel[p] = out;
+    }
+}

@@ -312,6 +312,46 @@ class InloopStructures:
         lib().lfo_inloop_structures(C.byref(a))
 
 
+_PIX_V_IN = ("SoilFraction TaInterception Ta ESAct PrefFlow Infiltration SeepTopToSubA SeepTopToSubB SeepSubToGW Theta1a "
+             "Theta1b Theta2 W1a W1b W2 UZOutflow GwPercUZLZ SoilDepthTotal").split()
+_PIX_N_IN = "Rain SnowMelt EWRef SMaxSealed DirectRunoffFraction WaterFraction LowerZoneK LZThreshold GwLossStep".split()
+_PIX_STATE = "CumInterSealed LZ LZInflowCUM TaInterceptionCUM TaCUM ESActCUM GwLossCUM".split()
+_PIX_OUT = ("RainSnowmelt EWaterAct InterSealed TASealed DirectRunoff TaInterceptionAll TaPixel ESActPixel PrefFlowPixel "
+            "InfiltrationPixel ThetaAll SeepTopToSubPixelA SeepTopToSubPixelB SeepSubToGWPixel Theta1aPixel Theta1bPixel "
+            "Theta2Pixel LZOutflow UZOutflowPixel GwPercUZLZPixel GwLossLZ LZAvInflow LZOutflowToChannelPixel").split()
+
+
+class _PixelArgs(C.Structure):  # lfo_pixel_args (lf_oracle.c)
+    _fields_ = ([(k, C.c_void_p) for k in _PIX_V_IN + _PIX_N_IN + _PIX_STATE + _PIX_OUT + ["Theta"]] +
+                [("InvDtDay", C.c_double), ("TimeSinceStart", C.c_double), ("N", C.c_int64)])
+
+
+def pixel_aggregates(v):
+    """opensealed.dynamic(); soil.dynamic_perpixel(); groundwater.dynamic() on a `var` namespace (in place)."""
+    N = np.asarray(v.SoilFraction).shape[1]
+    a, keep = _PixelArgs(), []
+
+    def put(name, arr):
+        keep.append(arr)
+        setattr(a, name, arr.ctypes.data)
+    for k in _PIX_V_IN:
+        put(k, _f(np.asarray(getattr(v, k))))
+    for k in _PIX_N_IN:
+        put(k, _f(np.broadcast_to(np.asarray(getattr(v, k)), (N,))))
+    for k in _PIX_STATE:
+        x = np.array(np.broadcast_to(np.asarray(getattr(v, k), dtype=np.float64), (N,)))
+        setattr(v, k, x)
+        put(k, x)
+    for k in _PIX_OUT:
+        x = np.empty(N)
+        setattr(v, k, x)
+        put(k, x)
+    v.Theta = np.empty((3, N))
+    put("Theta", v.Theta)
+    a.InvDtDay, a.TimeSinceStart, a.N = float(v.InvDtDay), float(v.TimeSinceStart), N
+    lib().lfo_pixel_aggregates(C.byref(a))
+
+
 def sweep_positions(state, constant, ups_ptr, ups_idx, a, ba, beta, begin, end):
     """solve1Pixel over positions [begin, end) of an indexed state vector (row-block plan tests)."""
     assert state.dtype == np.float64 and state.flags.c_contiguous

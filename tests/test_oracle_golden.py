@@ -153,6 +153,30 @@ def test_inloop_structures_match_reference(oracle):
                 assert u == 0, (s, k, u)
 
 
+def test_pixel_aggregates_match_reference(oracle):
+    """opensealed.dynamic -> soil.dynamic_perpixel -> groundwater.dynamic: the C restatement against vectors captured
+    from the reference's own module methods, two consecutive steps."""
+    g = golden("pixel_aggregates")
+    v = types.SimpleNamespace(SoilFraction=g["SoilFraction"], SoilDepthTotal=g["SoilDepthTotal"], InvDtDay=float(g["InvDtDay"]))
+    for k in g.files:
+        if k.startswith("static_"):
+            setattr(v, k[7:], g[k])
+        elif k.startswith("init_"):
+            setattr(v, k[5:], g[k].copy())
+    n = 0
+    for s in range(2):
+        v.TimeSinceStart = float(s + 3)
+        for k in g.files:
+            if k.startswith("in%d_" % s):
+                setattr(v, k[4:], g[k])
+        oracle.pixel_aggregates(v)
+        for k in g.files:
+            if k.startswith("out%d_" % s) and hasattr(v, k[5:]):
+                assert max_ulp(np.asarray(getattr(v, k[5:])), g[k]) == 0, (s, k)
+                n += 1
+    assert n >= 50
+
+
 def test_upstream_sum(oracle):
     g = golden("upstream_sum")
     for name in ("syn48_masked", "etrs89"):
