@@ -825,3 +825,54 @@ void lfo_pixel_aggregates(const lfo_pixel_args *A)
         A->LZOutflowToChannelPixel[p] = out;
     }
 }
+
+
+/* ------------------------------------------------------------------------------------------------
+ * surface_routing.dynamic (surface_routing.py:115-212) around its three router calls:
+ * lfo_surface_pre  -- runoff components and the three lateral inflows (:122-149)
+ * lfo_surface_post -- volumes from the routed discharges, flow into the channel, water depth (:191-212)
+ * V = 3 prescribed fractions in the order Rainfed, Forest, Irrigated; OFAlpha rows = (Other, Forest, Direct)
+ * (Lisflood_initial.py:288-290).  side[3][N] receives (Direct, Other, Forest).
+ * ---------------------------------------------------------------------------------------------- */
+void lfo_surface_pre(const double *soil_fraction, const double *avail, const double *infiltration,
+                     const double *direct_runoff, const double *uz_out, const double *lz_out, double mm_to_m3,
+                     double inv_pixel_length, double inv_dt_sec, int64_t N, double *surface_run_soil,
+                     double *surface_runoff, double *total_runoff, double *side)
+{
+    for (int64_t p = 0; p < N; ++p) {
+        double part[3];
+        for (int l = 0; l < 3; ++l) {
+            const int64_t i = l * N + p;
+            part[l] = soil_fraction[i] * np_max(avail[i] - infiltration[i], 0.);
+            surface_run_soil[i] = part[l];
+        }
+        const double surf = direct_runoff[p] + ((part[0] + part[1]) + part[2]);
+        surface_runoff[p] = surf;
+        total_runoff[p] = surf + uz_out[p] + lz_out[p];
+        side[p] = direct_runoff[p] * mm_to_m3 * inv_pixel_length * inv_dt_sec;
+        side[N + p] = (part[0] + part[2]) * mm_to_m3 * inv_pixel_length * inv_dt_sec;
+        side[2 * N + p] = part[1] * mm_to_m3 * inv_pixel_length * inv_dt_sec;
+    }
+}
+
+void lfo_surface_post(const double *q_direct, const double *q_other, const double *q_forest, const double *of_alpha,
+                      const uint8_t *is_channel, const double *uz_out, const double *lz_out, double beta,
+                      double pixel_length, double dt_sec, double mm_to_m3, double m3_to_mm, double inv_no_rout_steps,
+                      int64_t N, double *m3_direct, double *m3_other, double *m3_forest, double *to_chan_m3,
+                      double *water_depth, double *to_chan_runoff, double *to_chan_runoff_dt)
+{
+    for (int64_t p = 0; p < N; ++p) {
+        const double vd = pixel_length * of_alpha[2 * N + p] * pow(q_direct[p], beta);
+        const double vo = pixel_length * of_alpha[p] * pow(q_other[p], beta);
+        const double vf = pixel_length * of_alpha[N + p] * pow(q_forest[p], beta);
+        m3_direct[p] = vd;
+        m3_other[p] = vo;
+        m3_forest[p] = vf;
+        const double into_channel = is_channel[p] ? (q_direct[p] + q_other[p] + q_forest[p]) * dt_sec : 0.;
+        to_chan_m3[p] = into_channel;
+        water_depth[p] = (vd + vo + vf) * m3_to_mm;
+        const double run = (uz_out[p] + lz_out[p]) * mm_to_m3 + into_channel;
+        to_chan_runoff[p] = run;
+        to_chan_runoff_dt[p] = run * inv_no_rout_steps;
+    }
+}

@@ -352,6 +352,39 @@ def pixel_aggregates(v):
     lib().lfo_pixel_aggregates(C.byref(a))
 
 
+class SurfaceRouting:
+    """surface_routing.dynamic (surface_routing.py:115-212) on a `var` namespace: three oracle routers on LddToChan
+    (initialSecond, :103-113) and the arithmetic around them."""
+
+    def __init__(self, v, ldd_to_chan, land_mask):
+        self.v = v
+        a = np.asarray(v.OFAlpha, dtype=np.float64)
+        mk = lambda row: kinematicWave(ldd_to_chan, land_mask, a[row], v.Beta, v.PixelLength, v.DtSec)
+        self.other, self.forest, self.direct = mk(0), mk(1), mk(2)
+
+    def dynamic(self):
+        v, L = self.v, lib()
+        N = np.asarray(v.DirectRunoff).size
+        n = C.c_int64(N)
+        v.SurfaceRunSoil, v.SurfaceRunoff, v.TotalRunoff = np.empty((3, N)), np.empty(N), np.empty(N)
+        side = np.empty((3, N))
+        uz, lz = _f(v.UZOutflowPixel), _f(v.LZOutflowToChannelPixel)
+        L.lfo_surface_pre(_ptr(_f(v.SoilFraction)), _ptr(_f(v.AvailableWaterForInfiltration)), _ptr(_f(v.Infiltration)),
+                          _ptr(_f(v.DirectRunoff)), _ptr(uz), _ptr(lz), C.c_double(v.MMtoM3),
+                          C.c_double(v.InvPixelLength), C.c_double(v.InvDtSec), n, _ptr(v.SurfaceRunSoil),
+                          _ptr(v.SurfaceRunoff), _ptr(v.TotalRunoff), _ptr(side))
+        self.direct.kinematicWaveRouting(v.OFQDirect, side[0])          # :151-153
+        self.other.kinematicWaveRouting(v.OFQOther, side[1])
+        self.forest.kinematicWaveRouting(v.OFQForest, side[2])
+        for k in ("OFM3Direct", "OFM3Other", "OFM3Forest", "OFToChanM3", "WaterDepth", "ToChanM3Runoff", "ToChanM3RunoffDt"):
+            setattr(v, k, np.empty(N))
+        L.lfo_surface_post(_ptr(v.OFQDirect), _ptr(v.OFQOther), _ptr(v.OFQForest), _ptr(_f(v.OFAlpha)),
+                           _ptr(_u8(v.IsChannel)), _ptr(uz), _ptr(lz), C.c_double(v.Beta), C.c_double(v.PixelLength),
+                           C.c_double(v.DtSec), C.c_double(v.MMtoM3), C.c_double(v.M3toMM), C.c_double(v.InvNoRoutSteps),
+                           n, _ptr(v.OFM3Direct), _ptr(v.OFM3Other), _ptr(v.OFM3Forest), _ptr(v.OFToChanM3),
+                           _ptr(v.WaterDepth), _ptr(v.ToChanM3Runoff), _ptr(v.ToChanM3RunoffDt))
+
+
 def sweep_positions(state, constant, ups_ptr, ups_idx, a, ba, beta, begin, end):
     """solve1Pixel over positions [begin, end) of an indexed state vector (row-block plan tests)."""
     assert state.dtype == np.float64 and state.flags.c_contiguous

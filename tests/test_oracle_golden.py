@@ -177,6 +177,31 @@ def test_pixel_aggregates_match_reference(oracle):
     assert n >= 50
 
 
+def test_surface_routing_matches_reference(oracle):
+    """surface_routing.dynamic(): the C restatement (+ three oracle routers) against vectors captured from the
+    reference's own module method on an 18 x 24 LDD with 30 % channel pixels, two consecutive steps."""
+    g = golden("surface_step")
+    v = types.SimpleNamespace()
+    v.Beta = float(g["Beta"])
+    v.PixelLength, v.DtSec = float(g["PixelLength"]), float(g["DtSec"])
+    v.InvPixelLength, v.InvDtSec = 1 / v.PixelLength, 1 / v.DtSec
+    v.MMtoM3 = 0.001 * float(g["PixelArea"]); v.M3toMM = 1 / v.MMtoM3
+    v.InvNoRoutSteps = 1 / float(g["NoRoutSteps"])
+    v.IsChannel, v.OFAlpha, v.SoilFraction = g["IsChannel"], g["OFAlpha"], g["SoilFraction"]
+    for k in ("OFQDirect", "OFQOther", "OFQForest"):
+        setattr(v, k, g["init_" + k].copy())
+    m = oracle.SurfaceRouting(v, g["ldd_to_chan"], g["mask"])
+    keys = ("OFQDirect", "OFQOther", "OFQForest", "OFM3Direct", "OFM3Other", "OFM3Forest", "SurfaceRunoff",
+            "TotalRunoff", "OFToChanM3", "WaterDepth", "ToChanM3Runoff", "ToChanM3RunoffDt")
+    for s in range(2):
+        for k in ("AvailableWaterForInfiltration", "Infiltration", "DirectRunoff", "UZOutflowPixel",
+                  "LZOutflowToChannelPixel"):
+            setattr(v, k, g["in%d_%s" % (s, k)])
+        m.dynamic()
+        for k in keys:
+            assert max_ulp(getattr(v, k), g["out%d_%s" % (s, k)]) <= 1, (s, k, max_ulp(getattr(v, k), g["out%d_%s" % (s, k)]))
+
+
 def test_upstream_sum(oracle):
     g = golden("upstream_sum")
     for name in ("syn48_masked", "etrs89"):
