@@ -876,3 +876,81 @@ void lfo_surface_post(const double *q_direct, const double *q_other, const doubl
         to_chan_runoff_dt[p] = run * inv_no_rout_steps;
     }
 }
+
+
+/* ------------------------------------------------------------------------------------------------
+ * soilloop.dynamic_canopy (soilloop.py:519-627) for the prescribed vegetation fractions: interception (the a15
+ * kernel inlined, :27-70), potential transpiration (:549-556), water-stress reduction and the abstraction of the
+ * transpiration from soil layers 1a / 1b (:564-627).  [V,N] arrays by vegetation row, [L,N] by land-use row
+ * (landuse[v] = index_landuse_prescr), Rain/EWRef/ETRef/isFrozenSoil per pixel.
+ * ---------------------------------------------------------------------------------------------- */
+void lfo_canopy(double *Interception, double *TaInterception, double *LeafDrainage, double *CumInterception,
+                double *potential_transpiration, double *RWS, double *Ta, double *W1a, double *W1b, double *W1,
+                const double *LAI, const double *LAITerm, const double *CropCoef, const double *CropGroupNumber,
+                const double *WFC1, const double *WFC1a, const double *WFC1b, const double *WWP1, const double *WWP1a,
+                const double *WWP1b, const double *Rain, const double *EWRef, const double *ETRef,
+                const uint8_t *isFrozenSoil, const int64_t *landuse, double LeafDrainageK, double InvDtDay, int64_t V,
+                int64_t N)
+{
+    for (int64_t pix = 0; pix < N; ++pix) {
+        const double rain = Rain[pix], ewref = EWRef[pix], etref = ETRef[pix];
+        for (int64_t veg = 0; veg < V; ++veg) {
+            const int64_t i = veg * N + pix, j = landuse[veg] * N + pix;
+            /* interception */
+            const double bare = 1. - LAITerm[i];
+            const double ta_max = ewref * bare;
+            const double lai = LAI[i];
+            double smax = (lai <= .1) ? 0. : (lai <= 43.3 ? 0.935 + 0.498 * lai - 0.00575 * (lai * lai) : 11.718);
+            double cum = CumInterception[i], caught = 0.;
+            if (smax > 0) {
+                caught = dmin(dmin(smax - cum, smax * (1. - exp(-0.046 * lai * rain / smax))), rain);
+                cum += caught;
+            }
+            double ta_int = 0., drain = 0.;
+            if (cum > 0.) {
+                ta_int = dmax(dmin(cum, ta_max), 0.);
+                cum = dmax(cum - ta_int, 0.);
+                drain = LeafDrainageK * cum;
+                cum = dmax(cum - drain, 0.);
+            }
+            Interception[i] = caught;
+            TaInterception[i] = ta_int;
+            LeafDrainage[i] = drain;
+            CumInterception[i] = cum;
+            /* potential transpiration */
+            const double pot = np_max(CropCoef[j] * etref * bare - ta_int, 0.);
+            potential_transpiration[i] = pot;
+            /* soil water depletion fraction (crop group number), critical soil moisture, stress factor */
+            const double cgn = CropGroupNumber[j];
+            const double e = np_min(0.1 * etref * InvDtDay, 1.0);
+            double swdf = 1 / (0.76 + 1.5 * e) - 0.10 * (5 - cgn);
+            if (cgn <= 2.5) swdf = swdf + (e - 0.6) / (cgn * (cgn + 3));
+            swdf = np_max(np_min(swdf, 1.0), 0.);
+            const double wcrit1 = ((1 - swdf) * (WFC1[j] - WWP1[j])) + WWP1[j];
+            const double wcrit1a = ((1 - swdf) * (WFC1a[j] - WWP1a[j])) + WWP1a[j];
+            const double wcrit1b = ((1 - swdf) * (WFC1b[j] - WWP1b[j])) + WWP1b[j];
+            const double w1 = W1[j]; /* land-use row, :592 */
+            double rws = ((wcrit1 - WWP1[j]) > 0) ? (w1 - WWP1[j]) / (wcrit1 - WWP1[j]) : 1.;
+            rws = np_max(np_min(rws, 1.), 0.);
+            RWS[i] = rws;
+            double ta = np_min(rws * pot, np_max(w1 - WWP1[j], 0.));
+            if (isFrozenSoil[pix]) ta = 0.;
+            Ta[i] = ta;
+            /* abstraction: first what each layer holds above its critical amount, the rest by available water */
+            double w1a = W1a[j], w1b = W1b[j];
+            double from_a = np_min(ta, np_max(w1a - wcrit1a, 0.));
+            double rest = np_max(ta - from_a, 0.);
+            double from_b = np_min(rest, np_max(w1b - wcrit1b, 0.));
+            rest = np_max(rest - from_b, 0.);
+            const double left_a = np_max(w1a - from_a - WWP1a[j], 0.), left_b = np_max(w1b - from_b - WWP1b[j], 0.);
+            const double left = left_a + left_b;
+            from_a += (left > 0 ? left_a / left : 0.) * rest;
+            from_b += (left > 0 ? left_b / left : 0.) * rest;
+            w1a -= from_a;
+            w1b -= from_b;
+            W1a[j] = w1a;
+            W1b[j] = w1b;
+            W1[i] = w1a + w1b; /* vegetation row, :627 */
+        }
+    }
+}

@@ -352,6 +352,23 @@ def pixel_aggregates(v):
     lib().lfo_pixel_aggregates(C.byref(a))
 
 
+def canopy(v, index_landuse):
+    """soilloop.dynamic_canopy() on a `var` namespace (in place): [V,N] / [L,N] float64 C-contiguous arrays."""
+    V, N = np.asarray(v.Interception).shape
+    io = ("Interception", "TaInterception", "LeafDrainage", "CumInterception", "potential_transpiration", "RWS", "Ta",
+          "W1a", "W1b", "W1")
+    for k in io:
+        x = getattr(v, k)
+        assert isinstance(x, np.ndarray) and x.dtype == np.float64 and x.flags.c_contiguous, k
+    ins = [_f(np.asarray(getattr(v, k))) for k in ("LAI", "LAITerm", "CropCoef", "CropGroupNumber", "WFC1", "WFC1a", "WFC1b",
+                                                    "WWP1", "WWP1a", "WWP1b")]
+    pix = [_f(np.broadcast_to(np.asarray(getattr(v, k)), (N,))) for k in ("Rain", "EWRef", "ETRef")]
+    frozen = _u8(v.isFrozenSoil)
+    idx = np.ascontiguousarray(index_landuse, dtype=np.int64)
+    lib().lfo_canopy(*[_ptr(getattr(v, k)) for k in io], *[_ptr(a) for a in ins], *[_ptr(a) for a in pix], _ptr(frozen),
+                     _ptr(idx), C.c_double(v.LeafDrainageK), C.c_double(v.InvDtDay), C.c_int64(V), C.c_int64(N))
+
+
 class SurfaceRouting:
     """surface_routing.dynamic (surface_routing.py:115-212) on a `var` namespace: three oracle routers on LddToChan
     (initialSecond, :103-113) and the arithmetic around them."""

@@ -202,6 +202,39 @@ def test_surface_routing_matches_reference(oracle):
             assert max_ulp(getattr(v, k), g["out%d_%s" % (s, k)]) <= 1, (s, k, max_ulp(getattr(v, k), g["out%d_%s" % (s, k)]))
 
 
+def test_canopy_and_soil_step_match_reference(oracle):
+    """soilloop.dynamic_canopy() + dynamic_soil() (soilloop.py:519-704): the C restatements (canopy, ESMax, soil columns)
+    against vectors captured from the reference's own class methods, two consecutive steps."""
+    g = golden("canopy_soil_step")
+    v = types.SimpleNamespace()
+    for k in g.files:
+        if k.startswith("static_"):
+            setattr(v, k[7:], g[k].copy())
+        elif k.startswith("init_"):
+            setattr(v, k[5:], np.ascontiguousarray(g[k], dtype=np.float64).copy())
+    v.LeafDrainageK, v.DtDay = float(g["LeafDrainageK"]), float(g["DtDay"])
+    v.InvDtDay = 1 / v.DtDay
+    N = v.W1a.shape[1]
+    idx = np.arange(3)                       # Rainfed, Forest, Irrigated fractions on their own land-use rows
+    soil_keys = [k[6:] for k in g.files if k.startswith("soil0_")]
+    for s in range(2):
+        for k in ("Rain", "EWRef", "ETRef", "ESRef"):
+            setattr(v, k, g["forc%d_%s" % (s, k)])
+        oracle.canopy(v, idx)
+        for k in ("Interception", "TaInterception", "LeafDrainage", "CumInterception", "potential_transpiration", "RWS",
+                  "Ta", "W1a", "W1b", "W1"):
+            assert max_ulp(getattr(v, k), g["canopy%d_%s" % (s, k)]) <= 2, (s, k, max_ulp(getattr(v, k), g["canopy%d_%s" % (s, k)]))
+        d = {k: getattr(v, k) for k in vars(v)}
+        d["ESMax"] = np.ascontiguousarray(v.ESRef * v.LAITerm)                  # soilloop.py:638
+        d.update(index_landuse_all=idx, is_irrigated=np.array([False, False, True]), is_paddy_irrig=np.zeros(3, bool),
+                 paddy_inactive=np.zeros((1, N), bool), AvWaterThreshold=float(g["AvWaterThreshold"]),
+                 CourantCrit=float(g["CourantCrit"]), DrainedFraction=float(g["DrainedFraction"]))
+        d.setdefault("SnowMelt", np.zeros(N))
+        oracle.soil_columns(d)
+        for k in soil_keys:
+            assert max_ulp(d[k], g["soil%d_%s" % (s, k)]) <= 2, (s, k, max_ulp(d[k], g["soil%d_%s" % (s, k)]))
+
+
 def test_upstream_sum(oracle):
     g = golden("upstream_sum")
     for name in ("syn48_masked", "etrs89"):
