@@ -70,12 +70,17 @@ class routing(HydroModule):
     module_name = 'Routing'
 
     def __init__(self, routing_variable, split_routing=False, init_lisflood=False, options=None, device=0,
-                 inloop_modules=(), engine_order=False):
+                 inloop_modules=(), engine_order=False, compact=False):
         """engine_order=True keeps the module's device vectors in the router's sweep order (permuted on upload and
         download, site lists of the structures mapped to positions) and runs each sub-step as ONE level sweep that
         updates both routers of a cell (lf_routing_substeps_fused with one sub-step): half the launches of the
         pixel-order path under split routing and contiguous upstream reads; results are bit-identical."""
         self.engine_order = bool(engine_order)
+        # compact (engine order only): pixels whose sub-step is the identity for the whole run (hotpath.inert_pixels:
+        # isolated, not a channel pixel, regular parameters, zero thresholds and state, no structure) are left out of
+        # the router's domain; their vectors stay zero.  Decided in attach_router from the state `var` holds then.
+        self.compact = bool(compact) and self.engine_order
+        self._nfull = None
         self.var = routing_variable
         self.options = dict(options or {})
         self.options.setdefault("SplitRouting", split_routing)
@@ -201,33 +206,61 @@ class routing(HydroModule):
         switched on, the graph also carries their uncut links (Graph(virtual_down=...)), so that dynamic_fused()
         can run the structures inside the wavefront."""
         v, o = self.var, self.options
+        land_mask = np.asarray(land_mask, bool)
+        codes = np.asarray(compressed_ldd_kinematic, np.float64)
+        N = self._nfull = int(land_mask.sum())
+        structures = not o.get("InitLisflood") and (o.get("simulateLakes") or o.get("simulateReservoirs")) and \
+            hasattr(v, "downstruct")
+        ids = np.arange(N)
+        if self.compact and all(hasattr(v, k) for k in _STATE[:-1]):
+            from .hotpath import inert_pixels
+            vals = {k: getattr(v, k) for k in _STATIC + _STATE if hasattr(v, k)}
+            st = {k: getattr(v, k) for k, opt in (("LakeIndex", "simulateLakes"), ("ReservoirIndex", "simulateReservoirs"),
+                                                  ("QInM3Old", "inflow"), ("QDelta", "inflow"), ("TransCum", "TransLoss"))
+                  if o.get(opt) and hasattr(v, k)}
+            drop = inert_pixels(vals, codes, land_mask, self._split(), st or None)
+            if drop.sum() >= 0.1 * N:
+                ids = np.nonzero(~drop)[0]
+        self._ids = ids
+        sub = lambda a: np.broadcast_to(np.asarray(a), (N,))[ids]
+        mask = land_mask
+        if ids.size < N:
+            mask = np.zeros(land_mask.shape, bool)
+            mask[land_mask] = False
+            flat = np.zeros(N, bool); flat[ids] = True
+            mask[land_mask] = flat
         graph = None
-        if self.engine_order and not o.get("InitLisflood") and (o.get("simulateLakes") or o.get("simulateReservoirs")) \
-                and hasattr(v, "downstruct"):
+        if self.engine_order and structures:
             from .kinematic_wave_parallel import Graph
-            graph = Graph(compressed_ldd_kinematic, land_mask, virtual_down=self.structure_links(compressed_ldd_kinematic))
-        self.river_router = kinematicWave(compressed_ldd_kinematic, land_mask, v.ChannelAlpha, v.Beta, v.ChanLength,
-                                          v.DtRouting, alpha_floodplains=getattr(v, "ChannelAlpha2", None),
+            vd = self.structure_links(codes)
+            new_id = np.full(N, -1, np.int64); new_id[ids] = np.arange(ids.size)
+            vd = np.where(vd >= 0, new_id[np.maximum(vd, 0)], -1)[ids]
+            graph = Graph(codes[ids], mask, virtual_down=vd)
+        a2 = getattr(v, "ChannelAlpha2", None)
+        self.river_router = kinematicWave(codes[ids], mask, sub(v.ChannelAlpha), v.Beta, sub(v.ChanLength), v.DtRouting,
+                                          alpha_floodplains=None if a2 is None else sub(a2),
                                           flagnancheck=flagnancheck, device=self.device, graph=graph)
         if self.engine_order:
-            self._perm = self.river_router.graph.layout()[0].astype(np.int64)     # position -> pixel
-            self._pos = np.empty_like(self._perm)
-            self._pos[self._perm] = np.arange(self._perm.size)                    # pixel -> position
+            self._perm = ids[self.river_router.graph.layout()[0].astype(np.int64)]     # position -> pixel
+            self._pos = np.full(N, -1, np.int64)
+            self._pos[self._perm] = np.arange(self._perm.size)                        # pixel -> position (-1: left out)
         return self.river_router
 
     def _up(self, x):
-        """host [N] vector in pixel order -> the order the device vectors are kept in"""
+        """host [N] vector in pixel order -> the order (and domain) the device vectors are kept in"""
         return x[self._perm] if self.engine_order else x
 
     def _down(self, a, out=None):
-        """device-order [N] vector -> pixel order (into `out` when given)"""
+        """device-order vector -> pixel order (into `out` when given); pixels outside a compact domain get 0"""
         if not self.engine_order:
             if out is None:
                 return a
             out[...] = a
             return out
         if out is None:
-            out = np.empty_like(a)
+            out = np.zeros(self._nfull, a.dtype)
+        elif self._perm.size < self._nfull:
+            out[...] = 0
         out[self._perm] = a
         return out
 
@@ -250,7 +283,9 @@ class routing(HydroModule):
         if split and not self.options["InitLisflood"]:
             v.M3Limit = v.ChannelAlpha * v.ChanLength * (v.QLimit ** v.Beta)                       # :371
             v.Chan2M3Start = v.ChannelAlpha2 * v.ChanLength * (v.QLimit ** v.Beta)                 # :384
-            v.Chan2QStart = v.QLimit - self.river_router.upstream_sum(v.QLimit)                    # :387
+            ups = np.zeros(self._nfull)
+            ups[self._ids] = self.river_router.upstream_sum(np.broadcast_to(v.QLimit, (self._nfull,))[self._ids])
+            v.Chan2QStart = v.QLimit - ups                                                         # :387
             v.Chan2M3Kin = v.CrossSection2Area * v.ChanLength + v.Chan2M3Start                     # :391
             v.ChanM3Kin = v.ChanM3 - v.Chan2M3Kin + v.Chan2M3Start                                 # :392
             v.ChanM3Kin = np.where((v.ChanM3Kin < 0.0) & (v.ChanM3Kin > -0.0000001), 0.0, v.ChanM3Kin)  # :394
@@ -263,7 +298,7 @@ class routing(HydroModule):
 
     def _ensure_device(self):
         v = self.var
-        N = self.river_router.num_pixels
+        N, Nk = self._nfull, self.river_router.num_pixels      # host vectors / device vectors (compact domain)
         if "scratch0" in self._dev:
             return
         zeros = np.zeros(N)
@@ -275,7 +310,7 @@ class routing(HydroModule):
             a = u8(a) if k == "IsChannelKinematic" else f64(a)
             self._dev[k] = DeviceArray.from_host(a, self.device)
         for k in _STATE + _OUT + ["SideflowChanM3", "scratch0", "scratch1"]:
-            self._dev[k] = DeviceArray(N, np.float64, self.device).zero()
+            self._dev[k] = DeviceArray(max(Nk, 1), np.float64, self.device).zero()
         a = self._args = _SubstepArgs()
         for k, d in self._dev.items():
             setattr(a, k, d.ptr.value)
@@ -284,7 +319,7 @@ class routing(HydroModule):
 
     def _upload_state(self):
         v = self.var
-        N = self.river_router.num_pixels
+        N = self._nfull
         for k in _STATE:
             a = getattr(v, k, None)
             if a is None:
@@ -299,7 +334,7 @@ class routing(HydroModule):
         for k in names:
             cur = getattr(v, k, None)
             inplace = isinstance(cur, np.ndarray) and cur.dtype == np.float64 and cur.flags.c_contiguous and \
-                cur.size == self.river_router.num_pixels and cur.flags.writeable
+                cur.size == self._nfull and cur.flags.writeable
             if self.engine_order:
                 a = self._dev[k].download()
                 if inplace:
@@ -353,7 +388,7 @@ class routing(HydroModule):
         (inflow.py); UpTrans, TransPower1/2, TransSub, TransCum (transmission.py); and `downstruct` of the UNCUT
         kinematic LDD (routing.py:159-164) for the structures' inflow."""
         v, o = self.var, self.options
-        N = self.river_router.num_pixels
+        N, Nk = self._nfull, self.river_router.num_pixels        # host vectors / device vectors (compact domain)
         self._ensure_device()
         st = self._st = dict(dev={}, lakes=0, res=0)
         a = self._inloop = _InloopArgs()
@@ -371,6 +406,8 @@ class routing(HydroModule):
             idx = np.concatenate(idx).astype(np.int64) if idx else np.zeros(0, np.int64)
             if self.engine_order:                      # same summation order (ascending pixel id), device positions
                 idx = self._pos[idx]
+                if (idx < 0).any():
+                    raise ValueError("a pixel draining into a structure was left out of the compact domain")
             idx = idx.astype(np.int32)
             return ptr, (idx if idx.size else np.zeros(1, np.int32))
 
@@ -391,7 +428,7 @@ class routing(HydroModule):
                 put(k, f64(np.broadcast_to(getattr(v, k), (cells.size,))))
             for k in _LAKE_STATE:
                 put(k, f64(np.broadcast_to(getattr(v, k, 0.0), (cells.size,))))
-            put("QLakeOutM3Dt", np.zeros(N))
+            put("QLakeOutM3Dt", np.zeros(Nk))
         if o.get("simulateReservoirs") and not o.get("InitLisflood"):
             cells = np.asarray(v.ReservoirIndex).astype(np.int32)
             st["res"] = a.n_res = cells.size
@@ -401,24 +438,24 @@ class routing(HydroModule):
                 put(k, f64(np.broadcast_to(getattr(v, k), (cells.size,))))
             for k in _RES_STATE:
                 put(k, f64(np.broadcast_to(getattr(v, k, 0.0), (cells.size,))))
-            put("QResOutM3Dt", np.zeros(N))
+            put("QResOutM3Dt", np.zeros(Nk))
         if o.get("inflow"):
             put("QInM3Old", f64(self._up(np.asarray(v.QInM3Old)))); put("QDelta", f64(self._up(np.asarray(v.QDelta))))
-            put("QInDt", np.zeros(N)); put("QinADDEDM3", np.zeros(N))
+            put("QInDt", np.zeros(Nk)); put("QinADDEDM3", np.zeros(Nk))
         if o.get("TransLoss"):
-            put("UpTrans", u8(self._up(np.asarray(v.UpTrans)))); put("TransLossM3Dt", np.zeros(N))
+            put("UpTrans", u8(self._up(np.asarray(v.UpTrans)))); put("TransLossM3Dt", np.zeros(Nk))
             put("TransCum", f64(self._up(np.broadcast_to(getattr(v, "TransCum", 0.0), (N,)))))
             a.TransPower1, a.TransPower2, a.TransSub = float(v.TransPower1), float(v.TransPower2), float(v.TransSub)
         for k in ("ToChanM3RunoffDt", "EvaAddM3Dt", "WUseAddM3Dt", "ChannelToPolderM3Dt"):
-            st["dev"][k] = DeviceArray(N, np.float64, self.device).zero()
+            st["dev"][k] = DeviceArray(max(Nk, 1), np.float64, self.device).zero()
         a.ToChanM3RunoffDt = st["dev"]["ToChanM3RunoffDt"].ptr.value
         a.ChanQ = self._dev["ChanQ"].ptr.value
         a.SideflowChanM3 = self._dev["SideflowChanM3"].ptr.value
-        a.DtRouting, a.InvNoRoutSteps, a.N = float(v.DtRouting), float(v.InvNoRoutSteps), N
+        a.DtRouting, a.InvNoRoutSteps, a.N = float(v.DtRouting), float(v.InvNoRoutSteps), Nk
 
     def _structures_substep(self, s, launch=True):
         v, o, st, a = self.var, self.options, self._st, self._inloop
-        N = self.river_router.num_pixels
+        N = self._nfull
         if s == 0:      # lakes.py:211-212, reservoir.py:195-196: site state from the dense state maps
             if st["lakes"]:
                 st["dev"]["LakeStorageM3CC"].upload(f64(np.asarray(v.LakeStorageM3)[np.asarray(v.LakeIndex)]))
@@ -448,7 +485,7 @@ class routing(HydroModule):
             x = st["dev"][k].download()
             setattr(v, k, self._down(x) if k in dense else x)
         if s == v.NoRoutSteps - 1:      # lakes.py:283-292, reservoir.py:311-315: expand to the dense state maps
-            N = self.river_router.num_pixels
+            N = self._nfull
             if st["lakes"]:
                 for dense, cc in (("LakeStorageM3", "LakeStorageM3CC"), ("LakeStorageM3Balance", "LakeStorageM3BalanceCC"),
                                   ("LakeLevel", "LakeLevelCC"), ("LakeInflowOld", "LakeInflowOldCC"),
@@ -521,10 +558,10 @@ def _fused(self, sideflows):
     """See routing.dynamic_fused."""
     v = self.var
     r = self.river_router
-    N = r.num_pixels
-    perm = r.graph.layout()[0].astype(np.int64)
+    N, Nk = self._nfull, r.num_pixels                         # host vectors / device vectors (compact domain)
+    perm = self._perm if self.engine_order else self._ids[r.graph.layout()[0].astype(np.int64)]
     sideflows = np.ascontiguousarray(np.atleast_2d(np.asarray(sideflows, dtype=np.float64)))
-    nsteps_in, stride = (sideflows.shape[0], N) if sideflows.shape[0] > 1 else (1, 0)
+    nsteps_in, stride = (sideflows.shape[0], Nk) if sideflows.shape[0] > 1 else (1, 0)
     nsteps = int(v.NoRoutSteps)
     if stride and nsteps_in != nsteps:
         raise ValueError("need one sideflow vector, or NoRoutSteps of them")
@@ -541,7 +578,7 @@ def _fused(self, sideflows):
         x = getattr(v, k, None)
         dev[k] = DeviceArray.from_host(f64(np.broadcast_to(zeros if x is None else x, (N,))[perm]), self.device)
     for k in _OUT + ["scratch0", "scratch1"]:
-        dev[k] = DeviceArray(N, np.float64, self.device).zero()
+        dev[k] = DeviceArray(max(Nk, 1), np.float64, self.device).zero()
     dev["SideflowChanM3"] = DeviceArray.from_host(np.ascontiguousarray(sideflows[:, perm]), self.device)
     for k, d in dev.items():
         setattr(a, k, d.ptr.value)
@@ -551,8 +588,8 @@ def _fused(self, sideflows):
     check(lib().lf_routing_substeps_fused(r._h, C.byref(a), C.c_int(nsteps), C.c_int64(stride)))
     names = _STATE + _OUT if self._split() else ["ChanQKin", "ChanM3Kin", "ChanQ", "sumDisDay"] + _OUT
     for k in names:
-        out = np.empty(N)
-        out[perm] = dev[k].download()
+        out = np.zeros(N)                # pixels outside a compact domain keep their zero state
+        out[perm] = dev[k].download()[:Nk]
         setattr(v, k, out)
     for d in dev.values():
         d.free()

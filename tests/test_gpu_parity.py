@@ -716,6 +716,53 @@ def test_structures_mid_size_vs_oracle(amd, oracle):
     assert vc.QLakeOutM3Dt.max() > 0 and vc.QResOutM3Dt.max() > 0 and vc.TransCum.max() > 0
 
 
+@pytest.mark.parametrize("with_structures", [False, True])
+def test_routing_module_compact_domain(amd, with_structures):
+    """routing(..., engine_order=True, compact=True): the 70 % of the land pixels that are not channel pixels (isolated,
+    zero state) are left out of the router's domain.  Every vector must equal the full-domain module's, for the
+    sub-step-by-sub-step calls and for the wavefront, with and without lakes / reservoirs / inflow / transmission loss."""
+    from lisflood_amd import synthetic as syn
+    H, W = 60, 80
+    N = H * W
+    values, sc, mask, _, ldd_kin = syn.hotpath_scenario(H, W)
+    st, cut = syn.structures_scenario(ldd_kin, (H, W), values["ChanQ"], sc["DtRouting"], n_lakes=3, n_res=6)
+    codes = cut if with_structures else ldd_kin
+    runoff = syn.lateral_inflow(N, 3) * values["ChanLength"] * sc["DtRouting"]
+
+    def module(compact):
+        v = types.SimpleNamespace(**{k: (np.array(a, copy=True) if isinstance(a, np.ndarray) else a) for k, a in values.items()
+                                     if k in amd.routing._STATIC + amd.routing._STATE})
+        v.Beta, v.InvBeta, v.DtRouting, v.InvDtRouting = sc["Beta"], 1 / sc["Beta"], sc["DtRouting"], 1 / sc["DtRouting"]
+        v.DtSec, v.NoRoutSteps, v.InvNoRoutSteps = sc["DtSec"], int(sc["NoRoutSteps"]), 1 / sc["NoRoutSteps"]
+        v.ToChanM3RunoffDt = runoff
+        opts = dict(SplitRouting=True, InitLisflood=False)
+        if with_structures:
+            for k, a in st.items():
+                setattr(v, k, np.array(a, copy=True) if isinstance(a, np.ndarray) else a)
+            opts.update(simulateLakes=True, simulateReservoirs=True, inflow=True, TransLoss=True)
+        m = amd.routing.routing(v, options=opts, engine_order=True, compact=compact)
+        m.attach_router(codes, mask)
+        if with_structures:
+            m.attach_structures()
+        return v, m
+
+    keys = amd.routing._STATE + amd.routing._OUT + (list(_STRUCT_KEYS[6:]) if with_structures else [])
+    for fused in (False, True):
+        (va, ma), (vb, mb) = module(False), module(True)
+        assert mb.river_router.num_pixels < 0.5 * ma.river_router.num_pixels
+        for step in range(2):
+            va.sumDisDay = np.zeros(N); vb.sumDisDay = np.zeros(N)
+            for v, m in ((va, ma), (vb, mb)):
+                if fused:
+                    m.dynamic_fused()
+                else:
+                    for s in range(v.NoRoutSteps):
+                        m.dynamic(s)
+            for k in keys:
+                assert np.array_equal(getattr(va, k), getattr(vb, k), equal_nan=True), (fused, step, k)
+        assert np.isfinite(va.ChanQ).all() and va.ChanQ.max() > 0
+
+
 def test_pixel_aggregates_golden(amd):
     """opensealed.dynamic -> soil.dynamic_perpixel -> groundwater.dynamic as one device pass, against vectors
     captured from the reference's own module methods (two consecutive steps)."""
