@@ -93,13 +93,13 @@ struct veg_plan {
 // that needs more than one Courant sub-step returns that number without writing anything (0 = column done).
 // Inputs of deferred columns are handed from pass 1 to pass 2 through a staging area: pass 1 has all of them in
 // registers when it finds that a column needs several sub-steps, and writes them next to the inputs of the tile's
-// other deferred columns (field-major, slot = tile * cap + rank in the tile's list); pass 2 then reads compact, mostly
-// fully used lines instead of one 64-byte sector per 8-byte value scattered over ~46 vectors (measured: 6 GB fetched
+// other deferred columns (slot = tile * cap + rank in the tile's list, 46 values per slot); pass 2 then reads six
+// lines per column instead of one 64-byte sector per 8-byte value scattered over ~46 vectors (measured: 6 GB fetched
 // for 0.8 GB of inputs).  A tile has room for `cap` columns; the ones beyond gather from the vectors as before.
 constexpr int kStageFields = 46;
 constexpr unsigned int kStageCap = 96; // slots per tile (of 256 columns); pass 1 collects them in LDS: 46 x 96 x 8 B = 35 KB
 struct soil_stage {
-    double *buf;      // [kStageFields][nslots]
+    double *buf;      // [nslots][kStageFields]: a column's inputs side by side, a tile's columns one contiguous run
     size_t nslots;    // ntiles * cap
     unsigned int cap; // slots per tile, 0 = staging off
 };
@@ -118,7 +118,7 @@ __device__ __forceinline__ long long soil_column(const lf_soil_args &A, const ve
     const long long i = (long long)veg * N + pix, j = (long long)P.landuse[veg] * N + pix;
     const bool staged = !DEFER && slot < S.nslots;
     int f_ = 0;
-#define LD(expr) (staged ? S.buf[(size_t)(f_++) * S.nslots + slot] : (f_++, (double)(expr)))
+#define LD(expr) (staged ? S.buf[slot * kStageFields + (size_t)(f_++)] : (f_++, (double)(expr)))
     // Every input of the column is fetched here, before any arithmetic: ~50 independent loads in flight per lane
     // instead of the handful the compiler keeps when loads sit next to their first use (the kernel is a stream
     // of ~90 vectors; memory-level parallelism, not ALU, sets its speed).
@@ -330,11 +330,12 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(LF_
     }
     __syncthreads();
     if (threadIdx.x == 0) tile_count[tile] = count;
-    if (STAGE) { // the tile's staged inputs, field by field: contiguous runs of up to 96 doubles (no partial lines)
+    if (STAGE) { // the tile's staged inputs as ONE contiguous run: slot-major, the 46 fields of a column side by side
         const unsigned int n = count < kStageCap ? count : kStageCap;
+        double *dst = S.buf + (size_t)tile * kStageCap * kStageFields;
         for (unsigned int idx = threadIdx.x; idx < (unsigned int)kStageFields * n; idx += kBlock) {
-            const unsigned int f = idx / n, t = idx - f * n;
-            S.buf[(size_t)f * S.nslots + (size_t)tile * kStageCap + t] = lds_stage[f * kStageCap + t];
+            const unsigned int t = idx / kStageFields, f = idx - t * kStageFields;
+            dst[idx] = lds_stage[f * kStageCap + t];
         }
     }
 }
