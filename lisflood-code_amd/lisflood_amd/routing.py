@@ -225,10 +225,10 @@ class routing(HydroModule):
         sub = lambda a: np.broadcast_to(np.asarray(a), (N,))[ids]
         mask = land_mask
         if ids.size < N:
+            keep = np.zeros(N, bool)
+            keep[ids] = True
             mask = np.zeros(land_mask.shape, bool)
-            mask[land_mask] = False
-            flat = np.zeros(N, bool); flat[ids] = True
-            mask[land_mask] = flat
+            mask[land_mask] = keep
         graph = None
         if self.engine_order and structures:
             from .kinematic_wave_parallel import Graph
