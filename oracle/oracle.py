@@ -310,6 +310,11 @@ class InloopStructures:
         a.TransPower1, a.TransPower2, a.TransSub = float(v.TransPower1), float(v.TransPower2), float(v.TransSub)
         a.DtRouting, a.InvNoRoutSteps, a.N, a.step = float(v.DtRouting), float(v.InvNoRoutSteps), self.N, int(step)
         lib().lfo_inloop_structures(C.byref(a))
+        if step == int(v.NoRoutSteps) - 1:      # lakes.py:283-292, reservoir.py:311-315: back to the dense state maps
+            v.LakeStorageM3 = np.zeros(self.N)
+            v.LakeStorageM3[self.lake_cell] = v.LakeStorageM3CC
+            v.ReservoirStorageM3 = np.zeros(self.N)
+            v.ReservoirStorageM3[self.res_cell] = v.ReservoirStorageM3CC
 
 
 _PIX_V_IN = ("SoilFraction TaInterception Ta ESAct PrefFlow Infiltration SeepTopToSubA SeepTopToSubB SeepSubToGW Theta1a "

@@ -882,6 +882,56 @@ def test_resident_hot_path_with_structures(amd):
     hp.free()
 
 
+def test_resident_hot_path_vs_oracle_chain(amd, oracle):
+    """The whole resident model step -- canopy, soil columns, per-pixel aggregates, overland routing, 24 split-routing
+    sub-steps with lakes / reservoirs / inflow / transmission loss in the wavefront, compact channel domain -- against
+    the same chain assembled from the C oracle (independent code, each piece 0-2 ulp from the reference's own methods):
+    two model steps, every state vector within the parity tolerance."""
+    from lisflood_amd import synthetic as syn
+    from lisflood_amd.hotpath import HotPathDevice
+    H, W = 48, 60
+    N = H * W
+    values, sc, mask, ldd_to_chan, ldd_kin = syn.hotpath_scenario(H, W)
+    st, cut = syn.structures_scenario(ldd_kin, (H, W), values["ChanQ"], sc["DtRouting"], n_lakes=3, n_res=5)
+    cp = lambda d: {k: (np.array(a, copy=True) if isinstance(a, np.ndarray) else a) for k, a in d.items()}
+    hp = HotPathDevice(cp(values), sc, mask, ldd_to_chan, cut, split=True, structures=cp(st))
+    v = types.SimpleNamespace()
+    for k, a in list(cp(values).items()) + list(sc.items()) + list(cp(st).items()):
+        setattr(v, k, np.ascontiguousarray(a, dtype=np.float64) if isinstance(a, np.ndarray) and a.dtype.kind == "f" else a)
+    v.InvBeta, v.InvPixelLength, v.InvDtSec = 1 / v.Beta, 1 / v.PixelLength, 1 / v.DtSec
+    v.InvDtRouting, v.InvNoRoutSteps, v.NoRoutSteps = 1 / v.DtRouting, 1 / v.NoRoutSteps, int(v.NoRoutSteps)
+    idx = np.arange(3)
+    surf = oracle.SurfaceRouting(v, ldd_to_chan, mask)
+    kw = oracle.kinematicWave(cut, mask, v.ChannelAlpha, v.Beta, v.ChanLength, v.DtRouting, alpha_floodplains=v.ChannelAlpha2)
+    stru, sub = oracle.InloopStructures(v), oracle.RoutingSubstep(kw, v)
+    for step in range(2):
+        f = syn.hotpath_forcing(N, step)
+        hp.step(f, time_since_start=step + 1)
+        for k, a in f.items():
+            setattr(v, k, a)
+        oracle.canopy(v, idx)                                                      # Lisflood_dynamic.py:114
+        d = dict(vars(v))
+        d["ESMax"] = np.ascontiguousarray(v.ESRef * v.LAITerm)
+        d.update(index_landuse_all=idx, is_irrigated=np.array([False, False, True]), is_paddy_irrig=np.zeros(3, bool),
+                 paddy_inactive=np.zeros((1, N), bool))
+        oracle.soil_columns(d)                                                     # :123
+        v.TimeSinceStart = float(step + 1)
+        oracle.pixel_aggregates(v)                                                 # :129-149
+        surf.dynamic()                                                             # :165
+        v.sumDisDay = np.zeros(N)
+        for s in range(v.NoRoutSteps):                                             # :179-180
+            stru.dynamic_inloop(s)
+            sub.dynamic(split=True, sideflow_m3=v.SideflowChanM3)
+        for k in ("W1a", "W1b", "W2", "UZ", "Infiltration", "CumInterception", "LZ", "DirectRunoff", "OFQOther",
+                  "OFQDirect", "ToChanM3RunoffDt", "ChanQKin", "Chan2QKin", "ChanM3Kin", "ChanQ", "sumDisDay"):
+            got, want = hp.download(k), np.asarray(getattr(v, k))
+            np.testing.assert_allclose(got, want, rtol=1e-8, atol=1e-9 * max(1.0, float(np.abs(want).max())), err_msg=(step, k))
+        for k in ("LakeStorageM3CC", "ReservoirStorageM3CC", "LakeOutflowCC"):
+            np.testing.assert_allclose(hp.download_site(k), getattr(v, k), rtol=1e-8, err_msg=(step, k))
+    assert np.isfinite(v.ChanQ).all() and v.ChanQ.max() > 0
+    hp.free()
+
+
 def test_hot_path_warm_start(amd, tmp_path):
     """save_state after step 1 -> a fresh HotPathDevice + load_state must continue exactly like the original run
     (with lakes / reservoirs in the loop, so the site vectors travel too)."""
