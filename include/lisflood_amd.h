@@ -342,6 +342,9 @@ int lf_inloop_structures(int device, const lf_inloop_args *a);
  * site lists, whose contents must not change afterwards).  Bit-identical to the
  * sub-step-by-sub-step sequence lf_inloop_structures + lf_routing_substep. */
 int lf_routing_substeps_fused_structures(lf_router *r, const lf_substep_args *a, const lf_inloop_args *in, int nsteps);
+/* drops the cached validation of the site lists (call after rebuilding lake_cell / lake_ups_idx / res_cell /
+ * res_ups_idx, even if the new lists live at the old addresses) */
+int lf_router_reset_site_cache(lf_router *r);
 
 /* The per-pixel aggregates between the soil columns and surface routing, one pass:
  * opensealed.dynamic (opensealed.py:40-71), soil.dynamic_perpixel (soil.py:471-514; deffraction =

@@ -87,7 +87,12 @@ struct lf_dbuf { // owning device buffer
     int upload(const T *src, size_t count)
     {
         LF_TRY(alloc(count));
-        if (count) LF_HIP(hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice));
+        if (count) {
+            // the library's kernels run on a non-blocking stream that does not synchronise with the legacy stream this
+            // copy uses: wait for the DMA itself, not just for the staging of the pageable source
+            LF_HIP(hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice));
+            LF_HIP(hipStreamSynchronize(nullptr));
+        }
         return LF_OK;
     }
     void release()

@@ -164,5 +164,7 @@ __device__ __forceinline__ double lf_pow_pos(double x, double y)
     const double ex = fma(d1, u8, d0);
     const double nn = fmin(fmax(n, -2000.0), 2000.0);
     const double val = ldexp(ex, (int)nn);
-    return pos ? val : ((x == 0.0) ? 0.0 : (x + y)); // 0 -> 0 ; negative / NaN -> NaN
+    // 0 -> 0; negative base or NaN -> NaN, as OCML pow and numpy's ** for a non-integer exponent; a NaN exponent
+    // propagates through val (y * ed)
+    return pos ? val : ((x == 0.0) ? ((y != y) ? y : 0.0) : __builtin_nan(""));
 }

@@ -602,6 +602,17 @@ int lf_router_last_launches(const lf_router *r, int64_t stats[4])
     return LF_OK;
 }
 
+// The fused-with-structures call validates the levels of the site lists once per set of device pointers; a caller
+// that rebuilds its site lists (possibly at the same addresses) drops that cache here.
+int lf_router_reset_site_cache(lf_router *r)
+{
+    if (!r) return lf_set_error(LF_E_INVALID, "null argument");
+    r->site_cnt[0] = r->site_cnt[1] = -1;
+    for (const void *&k : r->site_key) k = nullptr;
+    r->site_level_sorted.clear();
+    return LF_OK;
+}
+
 int lf_router_profile_enable(lf_router *r, int on)
 {
     if (!r) return lf_set_error(LF_E_INVALID, "null argument");

@@ -15,6 +15,9 @@
 
 namespace {
 
+constexpr double kMaxSoilSubSteps = 1048576.0; // cap of the per-column Courant sub-step count (see soil_column)
+
+
 constexpr int kBlock = 256;
 constexpr int kMaxVeg = 16;
 
@@ -190,7 +193,10 @@ __device__ __forceinline__ long long soil_column(const lf_soil_args &A, const ve
     const double cb = (av1b == 0) ? 0. : k1b * DtDay / av1b;
     const double cg = (av2 == 0) ? 0. : k2 * DtDay / av2;
     const double courant = dmax(dmax(ca, cb), cg);
-    const double nsub_f = dmax(1., ceil(courant / A.CourantCrit));
+    // NoSubS = max(1, ceil(Courant / CourantCrit)), :249.  A non-finite or absurd Courant number (zero available water
+    // next to a huge conductivity) would make the reference's int conversion overflow and this loop spin for ever:
+    // the trip count is capped (documented deviation; CourantCrit > 0 is checked on the host).
+    const double nsub_f = dmin(dmax(1., ceil(courant / A.CourantCrit)), kMaxSoilSubSteps);
     const long long nsub = (long long)nsub_f;
     if (DEFER && nsub > 1) {
         const unsigned int rank = atomicAdd(lds_count, 1u); // LDS: position in the tile's list
@@ -469,6 +475,9 @@ int lf_soil_columns_device(int device, const lf_soil_args *a)
     veg_plan P;
     LF_TRY(make_plan(a, a->paddy_any, &P));
     if (a->N <= 0 || a->V <= 0) return LF_OK;
+    if (!(a->CourantCrit > 0.0) || !(a->DtDay > 0.0))
+        return lf_set_error(LF_E_INVALID, "CourantCrit and DtDay must be positive (soilloop.py:249: NoSubS = "
+                            "ceil(Courant / CourantCrit))");
     if ((unsigned long long)a->V * (unsigned long long)a->N >= 0xffffffffull)
         return lf_set_error(LF_E_INVALID, "V*N exceeds the 32-bit column id range");
     // per-tile lists of the columns that need more than one Courant sub-step (grow-only per-device workspace):

@@ -90,6 +90,8 @@ class HotPathDevice:
             m._structures_substep(0, launch=False)      # site state from the dense maps, once
             m._args.split = 1 if self.split else 0
             self.river = m.river_router
+            if "QInM3Old" in structures:       # inflow hydrographs: QInM3 of the previous model step, channel domain
+                self._qin_old = f64(np.broadcast_to(structures["QInM3Old"], (Nk,))).copy()
             for k in chan_names | set(RT._OUT) | {"SideflowChanM3"}:
                 self.d[k] = m._dev[k]
         self.perm = self.river.graph.layout()[0].astype(np.int64)        # engine position -> channel-domain pixel
@@ -180,9 +182,30 @@ class HotPathDevice:
                 if hasattr(type(st), k):
                     setattr(st, k, self.force[b][k].ptr.value)
 
-    def step(self, forcing, time_since_start=None):
+    def set_inflow(self, QInM3):
+        """inflow.dynamic + dynamic_init (inflow.py:108-125) for the coming step: QInM3 [N] is the hydrograph volume of
+        the model step [m3]; QDelta = (QInM3 - QInM3Old) * InvNoRoutSteps goes to the device next to QInM3Old, and
+        QInM3 becomes QInM3Old once the step is enqueued (Lisflood_dynamic.py:185)."""
+        if self.rmod is None or getattr(self, "_qin_old", None) is None:
+            raise RuntimeError("inflow hydrographs need structures= with QInM3Old / QDelta (the `inflow` option)")
+        q = f64(np.broadcast_to(np.asarray(QInM3, np.float64), (self.N,)))
+        if self.Nk < self.N:
+            rest = np.ones(self.N, bool); rest[self.ids] = False
+            if np.any(q[rest] != 0):
+                raise ValueError("inflow at a pixel this object left out of the channel domain; flag the inflow pixels in "
+                                 "structures['InflowPoints'] or build it with compact=False")
+        q = np.ascontiguousarray(q[self.ids])
+        m, dev = self.rmod, self.rmod._st["dev"]
+        delta = (q - self._qin_old) * m.var.InvNoRoutSteps
+        dev["QInM3Old"].upload(f64(m._up(self._qin_old)))
+        dev["QDelta"].upload(f64(m._up(delta)))
+        self._qin_old = q
+
+    def step(self, forcing, time_since_start=None, QInM3=None):
         d, dev = self.d, self.device
         L = lib()
+        if QInM3 is not None:
+            self.set_inflow(QInM3)
         b = self.steps_done % 2
         if self._prefetched[b] is not forcing:
             self._upload(b, forcing)
@@ -318,6 +341,8 @@ def inert_pixels(values, ldd_kinematic, land_mask, split, structures=None):
         for k in ("QInM3Old", "QDelta", "TransCum"):
             if k in structures:
                 ok &= np.broadcast_to(np.asarray(structures[k], np.float64), (N,)) == 0
+        if "InflowPoints" in structures:      # pixels that receive a hydrograph in later steps
+            ok &= ~np.broadcast_to(np.asarray(structures["InflowPoints"], bool), (N,))
     return ok
 
 

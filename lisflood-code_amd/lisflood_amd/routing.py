@@ -390,6 +390,7 @@ class routing(HydroModule):
         v, o = self.var, self.options
         N, Nk = self._nfull, self.river_router.num_pixels        # host vectors / device vectors (compact domain)
         self._ensure_device()
+        check(lib().lf_router_reset_site_cache(self.river_router._h))    # new site lists: their levels are re-validated
         st = self._st = dict(dev={}, lakes=0, res=0)
         a = self._inloop = _InloopArgs()
         ds = np.asarray(v.downstruct).astype(np.int64)
@@ -461,6 +462,9 @@ class routing(HydroModule):
                 st["dev"]["LakeStorageM3CC"].upload(f64(np.asarray(v.LakeStorageM3)[np.asarray(v.LakeIndex)]))
             if st["res"]:
                 st["dev"]["ReservoirStorageM3CC"].upload(f64(np.asarray(v.ReservoirStorageM3)[np.asarray(v.ReservoirIndex)]))
+            if "QInM3Old" in st["dev"]:      # inflow.dynamic_init recomputes QDelta and the driver moves QInM3Old on
+                for k in ("QInM3Old", "QDelta"):    # every model step (inflow.py:108, Lisflood_dynamic.py:185)
+                    st["dev"][k].upload(f64(self._up(np.broadcast_to(np.asarray(getattr(v, k), np.float64), (N,)))))
         st["dev"]["ToChanM3RunoffDt"].upload(f64(self._up(np.broadcast_to(v.ToChanM3RunoffDt, (N,)))))
         for k, opt in (("EvaAddM3Dt", "openwaterevapo"), ("WUseAddM3Dt", "wateruse"), ("ChannelToPolderM3Dt", "simulatePolders")):
             if o.get(opt):

@@ -43,3 +43,18 @@ for key, fn in FILES.items():
             out[key + "_fill"] = np.asarray(fill).reshape(-1)[:1]
 np.savez_compressed(OUT, **out)
 print("wrote", OUT, os.path.getsize(OUT))
+
+# ---- meteorological forcing of the same use case (meteo_1950/, 6-hourly fields): the first NT fields of
+# precipitation and the three reference evaporation rates, as the forcing of the model-step chain fixture
+# (make_golden.py chain).  Data files of the reference's own tests; float32 as stored.
+NT = 16
+MET = os.path.join(os.path.dirname(SRC), "meteo_1950")
+met = {}
+for key, fn in (("pr", "pr.nc"), ("e0", "e0.nc"), ("es", "es.nc"), ("et", "et.nc"), ("ta", "ta.nc")):
+    with h5py.File(os.path.join(MET, fn), "r") as f:
+        name = [k for k, v in f.items() if isinstance(v, h5py.Dataset) and v.ndim == 3][0]
+        met[key] = f[name][:NT].astype(np.float32)
+        print(key, fn, name, met[key].shape, float(np.nanmin(met[key])), float(np.nanmax(met[key])))
+OUT_MET = os.path.join(os.path.dirname(os.path.abspath(__file__)), "etrs89_meteo.npz")
+np.savez_compressed(OUT_MET, **met)
+print("wrote", OUT_MET, os.path.getsize(OUT_MET))

@@ -702,11 +702,230 @@ def gen_inloop():
     opts.clear()
 
 
+# ------------------------------------------------------------------------------------------------
+# the whole model step, chained (row N1): Lisflood_dynamic.py:114-229 on LF_ETRS89
+# ------------------------------------------------------------------------------------------------
+CHAIN_STEPS = 12
+
+
+def chain_inputs():
+    """Inputs of the model-step chain on the LF_ETRS89 domain: real LDD / channel geometry / lake and reservoir sites
+    (etrs89_static.npz), real meteorological fields (etrs89_meteo.npz: the first fields of meteo_1950/pr, e0, et, es),
+    seeded soil / land-use / structure parameters in the ranges of the other generators (the soil maps of the use
+    case need ~40 tables and PCRaster look-ups to turn into these parameters).
+    -> values, scalars, structures, mask, ldd_to_chan, cut LDD, forcing[step], QInM3[step]"""
+    z, ldd, mask = etrs89()
+    N = int(mask.sum())
+    cp = etrs89_channel_params(z, mask)
+    rng = np.random.default_rng(2024)
+    nsteps, dt_sec, beta = 24, 86400.0, 0.6
+    dt_routing = dt_sec / nsteps
+    values, sc, mask2, ldd_to_chan, ldd_kin = syn.hotpath_scenario(mask.shape[0], mask.shape[1], seed=909)
+    # hotpath_scenario is an all-land raster: take its per-pixel parameter vectors on the land pixels of the mask
+    # (soil columns, canopy, land-use fractions, groundwater, overland roughness) and replace everything that has to
+    # do with the river network by the real maps
+    take = np.flatnonzero(mask.ravel())
+    values = {k: np.ascontiguousarray(np.asarray(a)[..., take]) for k, a in values.items()}
+    codes = ldd[mask].astype(np.float64)
+    is_chan = cp["IsChannel"]
+    assert is_chan.all()                                   # LF_ETRS89: every land pixel is a channel pixel
+    ldd_to_chan = np.where(is_chan, 5.0, codes)            # routing.py:125
+    alpha, alpha2, length = cp["alpha"], cp["alpha2"], cp["ChanLength"]
+    q0 = cp["Q0"]
+    qlimit = 2.0 * q0 * rng.uniform(0.3, 1.2, N)           # QSplitMult * AvgDis stand-in (routing.py:364-366)
+    values.update(IsChannel=is_chan, IsChannelKinematic=is_chan.copy(), ChannelAlpha=alpha, InvChannelAlpha=1 / alpha,
+                  ChannelAlpha2=alpha2, InvChannelAlpha2=1 / alpha2, ChanLength=length, InvChanLength=1 / length,
+                  QLimit=qlimit, M3Limit=alpha * length * qlimit ** beta, Chan2M3Start=alpha2 * length * qlimit ** beta,
+                  PixelArea=z["pixarea"][mask].astype(np.float64))
+    # structures: the real lake / reservoir cells, the LDD cut just upstream of them (structures.py:51-59)
+    full = build_router(ldd, mask, alpha, beta, length, dt_routing)
+    down = full.downstream_lookup.astype(np.int64)
+    st = {}
+    st["downstruct"] = np.where(down < 0, N, down).astype(np.int32)                        # routing.py:159-164
+    lake_sites = (z["lakes"][mask] > 0)
+    res_sites = (z["res"][mask] > 0) & ~lake_sites
+    is_struct = lake_sites | res_sites
+    ups_of_struct = (down >= 0) & is_struct[np.maximum(down, 0)]
+    cut = np.where(ups_of_struct, 5.0, codes)
+    cut2d = np.zeros(mask.shape, ldd.dtype); cut2d[mask] = cut
+    kw = build_router(cut2d, mask, alpha, beta, length, dt_routing, alpha2=alpha2)
+    values["Chan2QStart"] = qlimit - kwp.kwpt.immediateUpstreamInflow(qlimit, kw.upstream_lookup, kw.num_upstream_pixels)
+    ChanM3 = cp["area0"] * length * rng.uniform(0.5, 3.0, N)
+    values["CrossSection2Area"] = np.zeros(N)
+    values["Chan2M3Kin"] = values["CrossSection2Area"] * length + values["Chan2M3Start"]       # routing.py:391-397
+    values["ChanM3Kin"] = np.maximum(ChanM3 - values["Chan2M3Kin"] + values["Chan2M3Start"], 0.0)
+    values["Chan2QKin"] = (values["Chan2M3Kin"] * (1 / length) * (1 / alpha2)) ** (1 / beta)
+    values["ChanQKin"] = (values["ChanM3Kin"] * (1 / length) * (1 / alpha)) ** (1 / beta)
+    values["ChanQ"] = np.maximum(values["ChanQKin"] + values["Chan2QKin"] - qlimit, 0.0)
+    values["Sideflow1Chan"] = np.zeros(N); values["sumDisDay"] = np.zeros(N)
+    ChanQ = values["ChanQ"]
+    st["LakeIndex"] = np.nonzero(lake_sites)[0]
+    nl = st["LakeIndex"].size
+    st["LakeAreaCC"] = rng.uniform(2e6, 5e7, nl)
+    LakeACC = rng.uniform(5.0, 80.0, nl)
+    st["LakeFactor"] = st["LakeAreaCC"] / (dt_routing * np.sqrt(LakeACC))                  # lakes.py:140-160
+    st["LakeFactorSqr"] = np.square(st["LakeFactor"])
+    st["LakeInflowOldCC"] = np.bincount(st["downstruct"], weights=ChanQ, minlength=N + 1)[st["LakeIndex"]]
+    st["LakeLevelCC"] = rng.uniform(0.5, 3.0, nl)
+    st["LakeStorageM3"] = np.zeros(N); st["LakeStorageM3"][st["LakeIndex"]] = st["LakeAreaCC"] * st["LakeLevelCC"]
+    st["LakeOutflowCC"] = np.square(st["LakeLevelCC"]) * LakeACC
+    st["LakeStorageM3BalanceCC"] = st["LakeStorageM3"][st["LakeIndex"]].copy()
+    st["ReservoirIndex"] = np.nonzero(res_sites)[0]
+    nr = st["ReservoirIndex"].size
+    st["TotalReservoirStorageM3CC"] = np.exp(rng.uniform(np.log(1e6), np.log(5e8), nr))   # reservoir.py:73-165
+    st["ConservativeStorageLimitCC"] = rng.uniform(0.05, 0.15, nr)
+    st["NormalStorageLimitCC"] = rng.uniform(0.4, 0.7, nr)
+    st["FloodStorageLimitCC"] = rng.uniform(0.8, 0.97, nr)
+    st["Normal_FloodStorageLimitCC"] = st["NormalStorageLimitCC"] + 0.5 * (st["FloodStorageLimitCC"] - st["NormalStorageLimitCC"])
+    qin0 = np.bincount(st["downstruct"], weights=ChanQ, minlength=N + 1)[st["ReservoirIndex"]]
+    st["MinReservoirOutflowCC"] = 0.1 * qin0 + 0.01
+    st["NormalReservoirOutflowCC"] = 0.9 * qin0 + 0.05
+    st["NonDamagingReservoirOutflowCC"] = 4.0 * qin0 + 1.0
+    st["DeltaO"] = st["NormalReservoirOutflowCC"] - st["MinReservoirOutflowCC"]
+    st["DeltaLN"] = st["NormalStorageLimitCC"] - 2 * st["ConservativeStorageLimitCC"]
+    st["DeltaNFL"] = st["FloodStorageLimitCC"] - st["Normal_FloodStorageLimitCC"]
+    st["ReservoirStorageM3"] = np.zeros(N)
+    st["ReservoirStorageM3"][st["ReservoirIndex"]] = rng.uniform(0.02, 1.0, nr) * st["TotalReservoirStorageM3CC"]
+    # inflow hydrographs at the use case's own inflow points would need its .tss tables: six seeded points instead
+    pts = rng.choice(N, 6, replace=False)
+    st["QInM3Old"] = np.zeros(N); st["QDelta"] = np.zeros(N)
+    qin = np.zeros((CHAIN_STEPS, N))
+    base = rng.uniform(2e5, 4e6, 6)                        # m3 per model step
+    for s in range(CHAIN_STEPS):
+        qin[s, pts] = base * (1.0 + 0.5 * np.sin(0.7 * s + np.arange(6)))
+    st["UpTrans"] = (rng.random(N) < 0.3) & (ChanQ > 1.0)
+    st["TransPower1"], st["TransPower2"], st["TransSub"] = 1 / 0.95, 0.95, 1e-4
+    st["TransCum"] = np.zeros(N)
+    sc = dict(sc)
+    sc.update(DtRouting=dt_routing, NoRoutSteps=nsteps, DtSec=dt_sec, PixelLength=float(z["pixleng"][mask][0]))
+    pa = float(values["PixelArea"][0])
+    assert (values["PixelArea"] == pa).all() and (z["pixleng"][mask] == sc["PixelLength"]).all()
+    sc.update(MMtoM3=0.001 * pa, M3toMM=1 / (0.001 * pa))
+    # forcing: real fields (precipitation x4: January 1950 was dry there) plus a seeded three-day storm, so that
+    # surface runoff and Courant sub-stepping happen
+    met = np.load(os.path.join(HERE, "etrs89_meteo.npz"))
+    forcing = []
+    for s in range(CHAIN_STEPS):
+        rain = 4.0 * met["pr"][s][mask].astype(np.float64)
+        if s in (3, 4, 5):
+            rain = rain + rng.uniform(0.0, 45.0, N) * (rng.random(N) < 0.35)
+        f = dict(Rain=rain, EWRef=met["e0"][s][mask].astype(np.float64),
+                 ETRef=met["et"][s][mask].astype(np.float64), ESRef=met["es"][s][mask].astype(np.float64))
+        ta = met["ta"][s][mask].astype(np.float64)
+        f["SnowMelt"] = np.where((ta > 0) & (ta < 3), 0.8 * ta, 0.0)          # degree-day stand-in for snow.py
+        assert all(np.isfinite(a).all() for a in f.values())
+        forcing.append(f)
+    return values, sc, st, mask, ldd_to_chan, cut, forcing, qin
+
+
+def gen_chain():
+    """CHAIN_STEPS model steps of the hot path in the order of Lisflood_dynamic.py:114-229, every stage run by the
+    reference's OWN module methods on one shared `var`: soilloop.dynamic_canopy -> soilloop.dynamic_soil ->
+    opensealed.dynamic -> soil.dynamic_perpixel -> groundwater.dynamic -> surface_routing.dynamic ->
+    inflow.dynamic_init -> NoRoutSteps x routing.dynamic(s) (lakes / reservoir / inflow / transmission
+    dynamic_inloop inside) -> the post-loop block (QInM3Old, ChanM3, sumDis, ChanQAvg = `dis`)."""
+    values, sc, st, mask, ldd_to_chan, cut, forcing, qin = chain_inputs()
+    N = int(mask.sum())
+    opts = REF["LisSettings"].options
+    opts.clear()
+    opts.update(InitLisflood=False, SplitRouting=True, simulateLakes=True, simulateReservoirs=True, TransLoss=True,
+                inflow=True)
+    REF["MaskInfo"].n = N
+    REF["LisSettings"].soil_uses = SOIL_USES[:]
+    REF["LisSettings"].vegetation_landuse = dict(zip(PRESCRIBED, SOIL_USES))
+    v = model_var(N)
+    vn, ln = ["vegetation", "pixel"], ["landuse", "pixel"]
+    V_NAMES = set(syn.SOIL_WRITTEN) | {"LeafDrainage", "Interception", "LAI", "LAITerm", "CumInterception", "TaInterception",
+                                      "potential_transpiration", "RWS", "Ta", "SoilFraction"}
+    for k, a in values.items():
+        a = np.array(a, copy=True)
+        if a.ndim == 2:
+            a = VA(a, vn if k in V_NAMES else (["runoff", "pixel"] if k == "OFAlpha" else ln))
+        setattr(v, k, a)
+    for k, a in sc.items():
+        setattr(v, k, a)
+    for k, a in st.items():
+        setattr(v, k, np.array(a, copy=True) if isinstance(a, np.ndarray) else a)
+    v.NoRoutSteps = int(v.NoRoutSteps)
+    v.InvBeta, v.InvPixelLength, v.InvDtSec = 1 / v.Beta, 1 / v.PixelLength, 1 / v.DtSec
+    v.InvDtRouting, v.InvNoRoutSteps = 1 / v.DtRouting, 1 / v.NoRoutSteps
+    v.LakeSitesC2 = np.zeros(N); v.LakeSitesC2[v.LakeIndex] = 1.0
+    v.ReservoirSitesC = np.zeros(N); v.ReservoirSitesC[v.ReservoirIndex] = 1.0
+    v.WPF3a = VA(values["WWP1a"] + 0.6 * (values["WFC1a"] - values["WWP1a"]), ln)     # only SoilMoistureStressDays reads them
+    v.WPF3b = VA(values["WWP1b"] + 0.6 * (values["WFC1b"] - values["WWP1b"]), ln)
+    v.SoilMoistureStressDays = VA(np.zeros((3, N)), vn)
+    v.Theta = VA(np.zeros((3, N)), vn)
+    v.deffraction = lambda variable: (np.asarray(v.SoilFraction) * np.asarray(variable)).sum(0)   # Lisflood_initial.py:69-71
+    v.SMaxSealed = 1.0
+    v.sumDis = np.zeros(N)
+    m_loop = REF["soilloop"].soilloop(v); m_loop.initial()
+    m_open, m_soil, m_gw = REF["opensealed"].opensealed(v), REF["soil"].soil(v), REF["groundwater"].groundwater(v)
+    m_surf = REF["surface"].surface_routing(v)
+    mk = lambda i: kwp.kinematicWave(ldd_to_chan.copy(), mask.copy(), v.OFAlpha.values[i], v.Beta, v.PixelLength, v.DtSec)
+    m_surf.other_surface_router, m_surf.forest_surface_router, m_surf.direct_surface_router = mk(0), mk(1), mk(2)
+    m_rout = REF["routing"].routing(v)
+    cut2d = np.zeros(mask.shape); cut2d[mask] = cut
+    m_rout.river_router = kwp.kinematicWave(cut.copy(), mask.copy(), v.ChannelAlpha, v.Beta, v.ChanLength, v.DtRouting,
+                                            alpha_floodplains=v.ChannelAlpha2)
+    m_rout.lakes_module = REF["lakes"].lakes(v)
+    m_rout.reservoir_module = REF["reservoir"].reservoir(v)
+    m_inflow = m_rout.inflow_module = REF["inflow"].inflow(v)
+    m_rout.transmission_module = REF["transmission"].transmission(v)
+    m_rout.polder_module = types.SimpleNamespace(dynamic_inloop=lambda *a, **k: None)
+    per_step = ("ChanQAvg", "ChanQ", "ToChanM3RunoffDt")
+    sampled_keys = ("W1a", "W1b", "W2", "UZ", "LZ", "CumInterception", "DSLR", "Infiltration", "DirectRunoff", "OFQDirect",
+                    "OFQOther", "OFQForest", "ChanQKin", "Chan2QKin", "ChanM3Kin", "Chan2M3Kin", "ChanM3", "sumDis",
+                    "LakeStorageM3CC", "LakeOutflowCC", "LakeLevelCC", "ReservoirStorageM3CC", "ReservoirFillCC", "TransCum",
+                    "QinADDEDM3", "CrossSection2Area", "Sideflow1Chan", "UZOutflowPixel", "LZOutflowToChannelPixel",
+                    "TotalCrossSectionArea")
+    sampled = [0, 4, CHAIN_STEPS - 1]
+    traj = {k: [] for k in per_step}
+    snap = {k: [] for k in sampled_keys}
+    deferred = []
+    with np.errstate(all="ignore"):
+        for s in range(CHAIN_STEPS):
+            for k, a in forcing[s].items():
+                setattr(v, k, a.copy())
+            v.TimeSinceStart = float(s + 1)
+            m_loop.dynamic_canopy()                                   # Lisflood_dynamic.py:114
+            m_loop.dynamic_soil()                                     # :123
+            m_open.dynamic()                                          # :129
+            m_soil.dynamic_perpixel()                                 # :147
+            m_gw.dynamic()                                            # :149
+            m_surf.dynamic()                                          # :165
+            v.QInM3 = qin[s].copy()                                   # inflow.dynamic (time-series read), :inflow.py:113-125
+            m_inflow.dynamic_init()                                   # :171
+            v.sumDisDay = np.zeros(N)                                 # :177
+            for sub in range(v.NoRoutSteps):                          # :179-180
+                m_rout.dynamic(sub)
+            v.QInM3Old = v.QInM3                                      # :185
+            v.ChanM3 = v.ChanM3Kin + v.Chan2M3Kin - v.Chan2M3Start    # :198 (split routing)
+            v.TotalCrossSectionArea = v.ChanM3 * v.InvChanLength      # :205
+            v.sumDis += v.sumDisDay                                   # :207
+            v.ChanQAvg = v.sumDisDay / v.NoRoutSteps                  # :208
+            for k in per_step:
+                traj[k].append(np.array(getattr(v, k), dtype=np.float64).copy())
+            if s in sampled:
+                for k in sampled_keys:
+                    snap[k].append(np.array(getattr(v, k), dtype=np.float64).copy())
+    q = np.array(traj["ChanQAvg"])
+    assert np.isfinite(q).all() and q.max() > 10
+    out = {"val_" + k: np.asarray(a) for k, a in values.items()}
+    out.update({"sc_" + k: np.float64(a) for k, a in sc.items()})
+    out.update({"st_" + k: np.asarray(a) for k, a in st.items()})
+    for name in forcing[0]:
+        out["forc_" + name] = np.array([f[name] for f in forcing])
+    save("etrs89_chain", mask=mask, ldd_to_chan=ldd_to_chan, ldd_cut=cut, QInM3=qin, sampled=np.array(sampled),
+         **out, **{"out_" + k: np.array(a) for k, a in traj.items()},
+         **{"snap_" + k: np.array(a) for k, a in snap.items()})
+    opts.clear()
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["graphs", "routes", "edge", "substeps", "upsum", "interception", "soil", "surface",
-                             "canopy", "inloop", "pixel"]
+                             "canopy", "inloop", "pixel", "chain"]
     fns = dict(graphs=gen_graphs, routes=gen_routes, edge=gen_route_edge, substeps=gen_substeps,
                upsum=gen_upstream_sum, interception=gen_interception, soil=gen_soil_columns,
-               surface=gen_surface_step, canopy=gen_canopy_soil_step, inloop=gen_inloop, pixel=gen_pixel_aggregates)
+               surface=gen_surface_step, canopy=gen_canopy_soil_step, inloop=gen_inloop, pixel=gen_pixel_aggregates, chain=gen_chain)
     for w in which:
         fns[w]()
