@@ -50,6 +50,51 @@ __global__ void __launch_bounds__(kBlock) k_upstream_sum(int n, const int *__res
     out_pix[perm[p]] = s;
 }
 
+// the same on the component layout: same-tier range [ups_ptr[p], ups_end[p]) for tier 0, the index list for tier >= 1
+__global__ void __launch_bounds__(kBlock) k_upstream_sum_comp(int n, const int *__restrict__ perm,
+                                                              const int *__restrict__ ups_ptr,
+                                                              const int *__restrict__ ups_end, int trunk_first,
+                                                              const int *__restrict__ t_ptr, const int *__restrict__ t_idx,
+                                                              const double *__restrict__ w_pix, double *__restrict__ out_pix)
+{
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= n) return;
+    double s = 0.0;
+    if (p < trunk_first) {
+        for (int e = ups_ptr[p]; e < ups_end[p]; ++e) s += w_pix[perm[e]];
+    } else {
+        for (int e = t_ptr[p - trunk_first]; e < t_ptr[p - trunk_first + 1]; ++e) s += w_pix[perm[t_idx[e]]];
+    }
+    out_pix[perm[p]] = s;
+}
+
+// accuflux on the component layout: one wavefront per bin, as k_comp_bins
+template <bool TRUNK>
+__global__ void __launch_bounds__(64) k_comp_accu(int bin0, comp_args C, const int *__restrict__ ups_ptr,
+                                                  const double *__restrict__ x_ord, double *acc)
+{
+    const int b = bin0 + (int)blockIdx.x;
+    const int l0 = C.bin_lvl_off[b], nl = C.bin_nl[b];
+    const int lls = C.lvl[l0 + nl - 1];
+    for (int k = 0; k < nl; ++k) {
+        const int first = C.lvl[l0 + k], last = C.lvl[l0 + k + 1];
+        for (int p = first + (int)threadIdx.x; p < last; p += 64) {
+            double s = 0.0;
+            if (TRUNK) {
+                const int q = p - C.trunk_first;
+                for (int e = C.t_ptr[q]; e < C.t_ptr[q + 1]; ++e) s += acc[C.t_idx[e]];
+            } else {
+                int u1 = ups_ptr[p + 1];
+                u1 = u1 < lls ? u1 : lls;
+                for (int e = ups_ptr[p]; e < u1; ++e) s += acc[e];
+            }
+            acc[p] = s + x_ord[p];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+}
+
 // accuflux: acc[p] = x[p] + sum over upstream acc (upstream first, ascending pixel id, then the cell itself)
 __global__ void __launch_bounds__(kBlock) k_accu_level(int first, int count, const int *__restrict__ ups_ptr,
                                                        const double *__restrict__ x_ord, double *acc)
@@ -117,6 +162,11 @@ struct lf_router {
     lf_dbuf<long long> level_start;
     lf_dbuf<double> a1, a2, dx, constant, qord, io_q, io_lat, tmp_ord, fused_qr1, fused_qr2;
     lf_dbuf<int32_t> win_ptr, win_cells; // component lists of the window segments
+    // component layout (lf_graph_build_components): one launch per tier, one wavefront per bin
+    bool comp = false;
+    lf_dbuf<int32_t> c_bin_lvl_off, c_bin_nl, c_lvl, c_t_ptr, c_t_idx, c_ups_end;
+    std::vector<int32_t> c_tier_bin_start;
+    int64_t c_trunk_first = 0;
     lf_dbuf<unsigned long long> counter;
     lf_dbuf<uint8_t> linked; // zero-length structure links (lf_graph_create_ex); null without them
     lf_dbuf<uint8_t> isolated; // [N] by position: 1 = no upstream and no downstream cell (e.g. non-channel land pixels)
@@ -258,6 +308,46 @@ int enqueue_route(lf_router *r, double *q_dev, const double *lat_dev, int sectio
         LF_TRY(r->prof_end());
         ++launches;
     }
+    if (r->comp) {
+        comp_args C;
+        C.bin_lvl_off = r->c_bin_lvl_off.p;
+        C.bin_nl = r->c_bin_nl.p;
+        C.lvl = r->c_lvl.p;
+        C.t_ptr = r->c_t_ptr.p;
+        C.t_idx = r->c_t_idx.p;
+        C.trunk_first = (int)r->c_trunk_first;
+        const int T = (int)r->c_tier_bin_start.size() - 1;
+        for (int t = 0; t < T; ++t) {
+            const int b0 = r->c_tier_bin_start[t], nb = r->c_tier_bin_start[t + 1] - b0;
+            if (nb <= 0) continue;
+            LF_TRY(r->prof_begin(t == 0 ? 1 : 2, 0));
+            const dim3 grid(nb), block(64);
+#define LF_COMP_LAUNCH(TR)                                                                               \
+    do {                                                                                                 \
+        if (r->fused && ordered)                                                                         \
+            hipLaunchKernelGGL((k_comp_bins<true, true, TR>), grid, block, 0, s, b0, C, A);              \
+        else if (r->fused)                                                                               \
+            hipLaunchKernelGGL((k_comp_bins<true, false, TR>), grid, block, 0, s, b0, C, A);             \
+        else if (ordered)                                                                                \
+            hipLaunchKernelGGL((k_comp_bins<false, true, TR>), grid, block, 0, s, b0, C, A);             \
+        else                                                                                             \
+            hipLaunchKernelGGL((k_comp_bins<false, false, TR>), grid, block, 0, s, b0, C, A);            \
+    } while (0)
+            if (t == 0)
+                LF_COMP_LAUNCH(false);
+            else
+                LF_COMP_LAUNCH(true);
+#undef LF_COMP_LAUNCH
+            LF_TRY(r->prof_end());
+            ++launches;
+            ++wide;
+        }
+        r->last_stats[0] = launches;
+        r->last_stats[1] = wide;
+        r->last_stats[2] = 0;
+        r->last_stats[3] = r->NL;
+        return LF_OK;
+    }
     for (const segment &g : r->schedule) {
         if (g.ncomp > 0) {
             LF_TRY(r->prof_begin(1, r->h_level_start[g.k1] - r->h_level_start[g.k0]));
@@ -365,12 +455,15 @@ int lf_router_create(const lf_graph *g, const double *alpha, double beta, const 
     r->fused = (beta == 0.6) && !(force_general && force_general[0] == '1');
     const int64_t n = g->N;
     int rc = LF_OK;
+    r->comp = g->comp != nullptr;
+    const std::vector<int32_t> &g_perm = g->comp ? g->comp->perm : g->perm;
+    const std::vector<int32_t> &g_ups_ptr = g->comp ? g->comp->ups_ptr : g->ups_ptr;
     {
         // a_dx_div_dt = alpha * dx / dt, evaluated left to right (:127), permuted into sweep order
         std::vector<double> h(n);
         auto fill = [&](const double *al) {
             for (int64_t p = 0; p < n; ++p) {
-                const int32_t pix = g->perm[p];
+                const int32_t pix = g_perm[p];
                 h[p] = al[pix] * (dx ? dx[pix] : dx_scalar) / dt;
             }
         };
@@ -381,19 +474,38 @@ int lf_router_create(const lf_graph *g, const double *alpha, double beta, const 
             rc = r->a2.upload(h.data(), n);
         }
         if (rc == LF_OK && dx) {
-            for (int64_t p = 0; p < n; ++p) h[p] = dx[g->perm[p]];
+            for (int64_t p = 0; p < n; ++p) h[p] = dx[g_perm[p]];
             rc = r->dx.upload(h.data(), n);
         }
     }
-    if (rc == LF_OK) rc = r->perm.upload(g->perm.data(), n);
-    if (rc == LF_OK) rc = r->ups_ptr.upload(g->ups_ptr.data(), n + 1);
+    if (rc == LF_OK) rc = r->perm.upload(g_perm.data(), n);
+    if (rc == LF_OK) rc = r->ups_ptr.upload(g_ups_ptr.data(), n + 1);
+    if (rc == LF_OK && g->comp) {
+        const lf_comp_plan &c = *g->comp;
+        r->c_tier_bin_start = c.tier_bin_start;
+        r->c_trunk_first = c.trunk_first;
+        rc = r->c_bin_lvl_off.upload(c.bin_lvl_off.data(), c.bin_lvl_off.size());
+        if (rc == LF_OK) rc = r->c_bin_nl.upload(c.bin_nl.data(), c.bin_nl.size());
+        if (rc == LF_OK) rc = r->c_lvl.upload(c.lvl.data(), c.lvl.size());
+        if (rc == LF_OK) rc = r->c_t_ptr.upload(c.t_ptr.data(), c.t_ptr.size());
+        if (rc == LF_OK) rc = r->c_t_idx.upload(c.t_idx.data(), c.t_idx.size());
+        if (rc == LF_OK) { // end of every cell's same-tier upstream range (the one-hop reductions read it)
+            std::vector<int32_t> ends(n);
+            for (size_t b = 0; b < c.bin_nl.size(); ++b) {
+                const int32_t l0 = c.bin_lvl_off[b], nl = c.bin_nl[b];
+                const int32_t lls = c.lvl[l0 + nl - 1];
+                for (int32_t p = c.lvl[l0]; p < c.lvl[l0 + nl]; ++p) ends[p] = std::min(c.ups_ptr[p + 1], lls);
+            }
+            rc = r->c_ups_end.upload(ends.data(), n);
+        }
+    }
     if (rc == LF_OK && g->has_links) rc = r->linked.upload(g->linked.data(), n);
     if (rc == LF_OK && n > 0) {
         std::vector<uint8_t> has_up(n, 0), iso(n, 0);
         for (int64_t p = 0; p < n; ++p)
             if (g->down[p] >= 0) has_up[g->down[p]] = 1;
         for (int64_t p = 0; p < n; ++p) {
-            const int32_t pix = g->perm[p];
+            const int32_t pix = g_perm[p];
             iso[p] = (g->down[pix] < 0 && !has_up[pix] && !(g->has_links && g->linked[p])) ? 1 : 0;
             r->n_isolated += iso[p];
         }
@@ -411,6 +523,10 @@ int lf_router_create(const lf_graph *g, const double *alpha, double beta, const 
         return rc;
     }
     r->h_level_start = g->level_start;
+    if (r->comp) { // no level schedule: the sweep runs tier by tier over the bins
+        *out = r;
+        return LF_OK;
+    }
     // launch schedule: narrow runs -> one single-workgroup launch; wide levels -> one launch per level.
     // Experimental (LF_WINDOWS=1, off by default): runs of wide levels swept in windows of up to kWindow levels by
     // k_window, one lane per independent component.  Measured on the 10 000^2 `deep` raster it cuts launches from
@@ -634,7 +750,10 @@ int lf_upstream_sum_device(lf_router *r, const double *w_dev, double *out_dev)
     if (!r || !w_dev || !out_dev) return lf_set_error(LF_E_INVALID, "null argument");
     LF_HIP(hipSetDevice(r->device));
     const int n = (int)r->N;
-    if (n > 0)
+    if (n > 0 && r->comp)
+        hipLaunchKernelGGL(k_upstream_sum_comp, dim3(blocks_for(n)), dim3(kBlock), 0, r->ctx->stream, n, r->perm.p,
+                           r->ups_ptr.p, r->c_ups_end.p, (int)r->c_trunk_first, r->c_t_ptr.p, r->c_t_idx.p, w_dev, out_dev);
+    else if (n > 0)
         hipLaunchKernelGGL(k_upstream_sum, dim3(blocks_for(n)), dim3(kBlock), 0, r->ctx->stream, n, r->perm.p,
                            r->ups_ptr.p, w_dev, out_dev, (const uint8_t *)r->linked.p);
     LF_HIP(hipGetLastError());
@@ -670,6 +789,24 @@ int lf_accuflux_host(lf_router *r, const double *x_host, double *out_host)
     if (n == 0) return LF_OK;
     LF_HIP(hipMemcpyAsync(r->io_lat.p, x_host, bytes, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_gather, dim3(blocks_for(n)), dim3(kBlock), 0, s, n, r->perm.p, r->io_lat.p, r->tmp_ord.p);
+    if (r->comp) {
+        comp_args C;
+        C.bin_lvl_off = r->c_bin_lvl_off.p;
+        C.bin_nl = r->c_bin_nl.p;
+        C.lvl = r->c_lvl.p;
+        C.t_ptr = r->c_t_ptr.p;
+        C.t_idx = r->c_t_idx.p;
+        C.trunk_first = (int)r->c_trunk_first;
+        const int T = (int)r->c_tier_bin_start.size() - 1;
+        for (int t = 0; t < T; ++t) {
+            const int b0 = r->c_tier_bin_start[t], nb = r->c_tier_bin_start[t + 1] - b0;
+            if (nb <= 0) continue;
+            if (t == 0)
+                hipLaunchKernelGGL(k_comp_accu<false>, dim3(nb), dim3(64), 0, s, b0, C, r->ups_ptr.p, r->tmp_ord.p, r->qord.p);
+            else
+                hipLaunchKernelGGL(k_comp_accu<true>, dim3(nb), dim3(64), 0, s, b0, C, r->ups_ptr.p, r->tmp_ord.p, r->qord.p);
+        }
+    }
     for (const segment &g : r->schedule) {
         if (g.wide) {
             for (int k = g.k0; k < g.k1; ++k) { // window segments are walked level by level here
@@ -1078,6 +1215,9 @@ int fused_impl(lf_router *r, const lf_substep_args *a, int nsteps, int64_t sidef
 {
     if (!r || !a || nsteps < 1) return lf_set_error(LF_E_INVALID, "bad argument");
     if (!a->engine_order) return lf_set_error(LF_E_INVALID, "the fused sub-step wavefront needs engine-order vectors");
+    if (r->comp)
+        return lf_set_error(LF_E_INVALID, "the fused sub-step wavefront runs on the level layout (router built on a graph "
+                            "with a component layout)");
     if (a->split && !r->has_floodplains)
         return lf_set_error(LF_E_SECTION, "split routing requested but the router has no floodplain alpha");
     if (sideflow_stride != 0 && sideflow_stride != r->N) return lf_set_error(LF_E_INVALID, "sideflow_stride must be 0 or N");

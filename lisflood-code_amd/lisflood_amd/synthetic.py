@@ -5,6 +5,9 @@ potential phi, or is a pit):
   shallow : phi = U(0,1)                                   -> ~11 % pits, NL ~ 7-8 ("random LDD")
   deep    : phi = row-from-bottom + 0.25*col/W + 0.6*U(0,1) -> NL = H+2, ~W cells per level (sheet flow)
   saddle  : like deep, but the right half of the raster drains upward (tests: flow crosses a row cut both ways)
+  river   : phi = distance to the nearest of M seeded outlets + 0.75*U(0,1) (M ~ one per 2.5 Mcells): convergent,
+            dendritic drainage towards a few outlets -- NL ~ basin radius (hundreds to thousands of levels), level
+            widths from 1 cell next to an outlet to tens of thousands: the regime of a real river network
 Codes follow the LISFLOOD/PCRaster keypad convention of the reference
 (kinematic_wave_parallel.py:49-51): index 0..7 <-> codes [2,3,6,9,8,7,4,1], 5 = pit, and the
 (row, col) shifts IX_ADDS.  Ties are resolved to the first minimum in IX_ADDS order.
@@ -17,7 +20,14 @@ import numpy as np
 IX_ADDS = ((1, 0), (1, 1), (0, 1), (-1, 1), (-1, 0), (-1, -1), (0, -1), (1, -1))
 FLOW_CODE = (2, 3, 6, 9, 8, 7, 4, 1, 5)
 ROWS_PER_CHUNK = 256
-FAMILIES = ("shallow", "deep")
+FAMILIES = ("shallow", "deep", "river")
+
+
+def river_outlets(H, W, seed):
+    """(rows, cols) of the outlets of the `river` family: M = max(3, H*W / 2.5e6) seeded positions"""
+    m = max(3, int(round(H * W / 2.5e6)))
+    rng = np.random.default_rng([int(seed), 777])
+    return rng.integers(0, H, m).astype(np.float64), rng.integers(0, W, m).astype(np.float64)
 
 
 def _noise_rows(seed, r0, r1, W):
@@ -39,6 +49,14 @@ def potential_rows(family, H, W, seed, r0, r1):
     u = _noise_rows(seed, r0, r1, W)
     if family == "shallow":
         return u
+    if family == "river":
+        orow, ocol = river_outlets(H, W, seed)
+        rr = np.arange(r0, r1, dtype=np.float64)[:, None]
+        cc = np.arange(W, dtype=np.float64)[None, :]
+        d = np.full((r1 - r0, W), np.inf)
+        for a, b in zip(orow, ocol):
+            np.minimum(d, np.sqrt((rr - a) ** 2 + (cc - b) ** 2), out=d)
+        return d + 0.75 * u
     rows_from_bottom = (H - 1 - np.arange(r0, r1, dtype=np.float64))[:, None]
     cols = np.arange(W, dtype=np.float64)[None, :]
     if family == "deep":
