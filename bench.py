@@ -34,7 +34,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=10000, help="raster is size x size cells")
-    ap.add_argument("--family", default="shallow", choices=["shallow", "deep"])
+    ap.add_argument("--family", default="shallow", choices=["shallow", "deep", "river"])
+    ap.add_argument("--layout", default="auto", choices=["auto", "levels", "components"],
+                    help="engine layout of the router: level sweep (one launch per level), component layout (one launch "
+                         "per tier, one wavefront per bin), auto = components when the raster has more than 64 levels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads / soil kernel")
     ap.add_argument("--cpu-sample", type=int, default=2000, help="CPU baseline raster is sample x sample")
@@ -54,7 +57,9 @@ def level_sizes(g):
     """Level-size histogram of the input (throughput is a function of NL): the full list when short,
     else a summary."""
     import numpy as np
-    ls = np.diff(g.layout()[2])
+    ls = getattr(g, "level_widths", None)
+    if ls is None:
+        ls = np.diff(g.layout()[2])
     if len(ls) <= 32:
         return [int(x) for x in ls]
     q = np.percentile(ls, [0, 25, 50, 75, 100])
@@ -62,18 +67,29 @@ def level_sizes(g):
             "max": int(q[4]), "narrow_levels_le_1024": int((ls <= 1024).sum())}
 
 
-def build_case(family, H, W):
+SEEDS = {"shallow": 1, "deep": 2, "river": 7}
+
+
+def build_case(family, H, W, layout="auto"):
+    """layout: "levels" = one launch per level (wide levels: the HBM-bound regime), "components" = independent bins of
+    the drainage forest, one wavefront each, one launch per tier (deep / dendritic networks: the launch-latency-bound
+    regime), "auto" = components when the network has more than 64 levels."""
     from lisflood_amd import synthetic as syn
     from lisflood_amd.kinematic_wave_parallel import Graph, kinematicWave
     t = time.time()
-    seed = {"shallow": 1, "deep": 2}[family]
-    codes = syn.make_ldd(family, H, W, seed)
+    codes = syn.make_ldd(family, H, W, SEEDS[family])
     N = H * W
     p = syn.router_params(N)
     g = Graph(ldd_raster=codes)
+    levels = np.diff(g.layout()[2])
+    if layout == "components" or (layout == "auto" and g.num_levels > 64):
+        g.close()
+        g = Graph(ldd_raster=codes, components=True)
+    g.level_widths = levels
     kw = kinematicWave(None, None, p["alpha"], p["beta"], p["dx"], p["dt"], graph=g)
-    log("[bench] %s %dx%d: N=%d NL=%d K=%d built in %.1f s" % (family, H, W, N, g.num_levels, g.max_upstream,
-                                                               time.time() - t))
+    log("[bench] %s %dx%d: N=%d NL=%d K=%d layout=%s built in %.1f s" % (
+        family, H, W, N, g.num_levels, g.max_upstream, "components %s" % g.components if g.components else "levels",
+        time.time() - t))
     return kw, p, g
 
 
@@ -123,7 +139,7 @@ def run_routing(kw, p, steps, warmup, nq=3, profile_steps=2, ordered=True):
     for d in qs + [Q]:
         d.free()
     return dict(ms_per_step=(t1 - t0) * 1e3 / steps, event_ms_per_step=ev_ms / steps, prof=prof, stats=stats,
-                finite=ok, profile_steps=profile_steps)
+                finite=ok, profile_steps=profile_steps, components=kw.graph.components, cells=N)
 
 
 def pmc_traffic(kernel_key, cells_per_launch):
@@ -149,6 +165,20 @@ def roofline_of(res, kernel_key=None):
     """Dominant sweep kernel: achieved algorithmic GB/s = 48 B x cells per launch / mean launch duration."""
     prof = res["prof"]
     wide, narrow = prof["wide_level"], prof["narrow_run"]
+    if res.get("components"):       # component layout: the tier launches together sweep every cell once per call
+        ms = wide["ms"] + narrow["ms"]
+        calls = max(res.get("profile_steps", 1), 1)
+        if ms == 0:
+            return None
+        achieved = B_ALG * res["cells"] * calls / (ms * 1e-3) / 1e9
+        return dict(bound="hbm", kernel="k_comp_bins (all tiers of a call)", achieved=round(achieved, 3), peak=HBM_PEAK_GBS,
+                    unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 6), traffic=None, traffic_unit="bytes per call",
+                    traffic_source=None, alg_bytes_per_launch=B_ALG * res["cells"],
+                    launches_per_step=int(round((wide["launches"] + narrow["launches"]) / calls)),
+                    mean_launch_us=round(ms * 1e3 / calls, 3), cells_per_launch=float(res["cells"]),
+                    alg_bytes_per_cell_step=B_ALG, components=res["components"],
+                    note="dependent chain of %d local levels (sum over tiers of the deepest bin): latency-bound, not "
+                         "bandwidth-bound" % res["components"]["chain_levels"])
     dom = wide if wide["ms"] >= narrow["ms"] else narrow
     name = "k_level" if dom is wide else "k_levels_narrow"
     if dom["launches"] == 0 or dom["ms"] == 0:
@@ -174,8 +204,7 @@ def cpu_baseline(family, sample, steps=2):
     from lisflood_amd import synthetic as syn
     oracle.build()
     H = W = sample
-    seed = {"shallow": 1, "deep": 2}[family]
-    codes = syn.make_ldd(family, H, W, seed)
+    codes = syn.make_ldd(family, H, W, SEEDS[family])
     mask = np.ones((H, W), bool)
     N = H * W
     p = syn.router_params(N)
@@ -254,7 +283,7 @@ def model_step_bench(size=5000, nsteps=24, family="deep"):
     from lisflood_amd.routing_device import RoutingStepDevice
     H = W = size
     N = H * W
-    codes = syn.make_ldd(family, H, W, {"shallow": 1, "deep": 2}[family])
+    codes = syn.make_ldd(family, H, W, SEEDS[family])
     p = syn.router_params(N)
     rng = np.random.default_rng(17)
     beta, dt = p["beta"], 3600.0
@@ -431,7 +460,7 @@ def main():
                 _lib.check(_lib.lib().lf_calibration_copy(C.c_int(0), src.ptr, dst.ptr, C.c_int64(n), C.c_int(width)))
         _lib.synchronize()
         src.free(); dst.free()
-    kw, p, g = build_case(a.family, H, W)
+    kw, p, g = build_case(a.family, H, W, a.layout)
     res = run_routing(kw, p, a.steps, a.warmup)
     N = kw.num_pixels
     value = N / res["ms_per_step"] / 1e3          # Mcell-steps/s
@@ -440,8 +469,9 @@ def main():
         "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(res["ms_per_step"], 4),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "%dx%d fp64 raster, %s LDD (seed %d), all land, beta=0.6, 1 router call per step"
-                               % (H, W, "random ('shallow')" if a.family == "shallow" else "sheet-flow ('deep')",
-                                  1 if a.family == "shallow" else 2),
+                               % (H, W, {"shallow": "random ('shallow')", "deep": "sheet-flow ('deep')",
+                                         "river": "dendritic ('river')"}[a.family], SEEDS[a.family]),
+                   "engine_layout": "components %s" % g.components if g.components else "levels",
                    "cells": N, "levels": g.num_levels, "level_sizes": level_sizes(g),
                    "launches_per_step": res["stats"]["launches"],
                    "layout": "discharge and lateral inflow resident in HBM in the engine's sweep order "
@@ -476,17 +506,27 @@ def main():
     kw.close()
     if not a.no_extra:
         extra = {}
-        try:
-            other = "deep" if a.family == "shallow" else "shallow"
-            kw2, p2, g2 = build_case(other, H, W)
-            r2 = run_routing(kw2, p2, max(2, a.steps // 5), 1, nq=1, profile_steps=1)
-            extra[other] = dict(value=round(kw2.num_pixels / r2["ms_per_step"] / 1e3, 2), unit="Mcell-steps/s",
-                                ms_per_step=round(r2["ms_per_step"], 3), levels=g2.num_levels,
-                                level_sizes=level_sizes(g2),
-                                launches_per_step=r2["stats"]["launches"], roofline=roofline_of(r2))
-            kw2.close()
-        except Exception as e:  # secondary numbers must never break the headline line
-            extra["error"] = repr(e)
+        for other in [f for f in ("deep", "river", "shallow") if f != a.family]:
+            try:    # the other LDD families, each on the layout `auto` picks and -- for A/B -- on the level sweep
+                entry = {}
+                for layout in ("auto", "levels"):
+                    kw2, p2, g2 = build_case(other, H, W, layout)
+                    if layout == "levels" and "engine_layout" in entry and entry["engine_layout"] == "levels":
+                        kw2.close()
+                        break
+                    r2 = run_routing(kw2, p2, max(2, a.steps // 5), 1, nq=1, profile_steps=1)
+                    d = dict(value=round(kw2.num_pixels / r2["ms_per_step"] / 1e3, 2), unit="Mcell-steps/s",
+                             ms_per_step=round(r2["ms_per_step"], 3), launches_per_step=r2["stats"]["launches"],
+                             roofline=roofline_of(r2))
+                    if layout == "auto":
+                        entry.update(d, levels=g2.num_levels, level_sizes=level_sizes(g2),
+                                     engine_layout="components" if g2.components else "levels")
+                    else:
+                        entry["level_sweep"] = d
+                    kw2.close()
+                extra[other] = entry
+            except Exception as e:  # secondary numbers must never break the headline line
+                extra[other + "_error"] = repr(e)
         try:
             extra["soil"] = soil_bench()
         except Exception as e:

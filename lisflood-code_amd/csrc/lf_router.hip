@@ -165,6 +165,11 @@ struct lf_router {
     // component layout (lf_graph_build_components): one launch per tier, one wavefront per bin
     bool comp = false;
     lf_dbuf<int32_t> c_bin_lvl_off, c_bin_nl, c_lvl, c_t_ptr, c_t_idx, c_ups_end;
+    // fused sub-steps on the component layout: slot of every bin's last level in the root slabs, the tier >= 1 index
+    // list with lower-tier tributaries as -(slot) - 1, the slabs themselves ([nsteps][nroots] per section)
+    lf_dbuf<int32_t> c_root_base, c_t_idx_fused;
+    lf_dbuf<double> c_root1, c_root2;
+    int64_t c_nroots = 0, c_root_steps = 0;
     std::vector<int32_t> c_tier_bin_start;
     int64_t c_trunk_first = 0;
     lf_dbuf<unsigned long long> counter;
@@ -489,6 +494,32 @@ int lf_router_create(const lf_graph *g, const double *alpha, double beta, const 
         if (rc == LF_OK) rc = r->c_lvl.upload(c.lvl.data(), c.lvl.size());
         if (rc == LF_OK) rc = r->c_t_ptr.upload(c.t_ptr.data(), c.t_ptr.size());
         if (rc == LF_OK) rc = r->c_t_idx.upload(c.t_idx.data(), c.t_idx.size());
+        if (rc == LF_OK && c.tier_bin_start.size() > 2) { // more than one tier: root slots for the fused sub-steps
+            const int T = (int)c.tier_bin_start.size() - 1;
+            const size_t B = c.bin_nl.size();
+            std::vector<int32_t> root_base(B, -1), slot_of(n, -1);
+            int64_t slots = 0;
+            for (int t = 0; t + 1 < T; ++t)
+                for (int32_t b = c.tier_bin_start[t]; b < c.tier_bin_start[t + 1]; ++b) {
+                    const int32_t l0 = c.bin_lvl_off[b], nl = c.bin_nl[b];
+                    root_base[b] = (int32_t)slots;
+                    for (int32_t p = c.lvl[l0 + nl - 1]; p < c.lvl[l0 + nl]; ++p) slot_of[p] = (int32_t)slots++;
+                }
+            r->c_nroots = slots;
+            std::vector<int32_t> tf(c.t_idx.size());
+            for (int t = 1; t < T; ++t)
+                for (int32_t b = c.tier_bin_start[t]; b < c.tier_bin_start[t + 1]; ++b) {
+                    const int32_t l0 = c.bin_lvl_off[b], nl = c.bin_nl[b];
+                    const int32_t b_first = c.lvl[l0], b_end = c.lvl[l0 + nl];
+                    for (int32_t p = b_first; p < b_end; ++p)
+                        for (int32_t e = c.t_ptr[p - c.trunk_first]; e < c.t_ptr[p - c.trunk_first + 1]; ++e) {
+                            const int32_t u = c.t_idx[e];
+                            tf[e] = (u >= b_first && u < b_end) ? u : -(slot_of[u] + 1);
+                        }
+                }
+            rc = r->c_root_base.upload(root_base.data(), B);
+            if (rc == LF_OK) rc = r->c_t_idx_fused.upload(tf.data(), tf.size());
+        }
         if (rc == LF_OK) { // end of every cell's same-tier upstream range (the one-hop reductions read it)
             std::vector<int32_t> ends(n);
             for (size_t b = 0; b < c.bin_nl.size(); ++b) {
@@ -979,6 +1010,10 @@ struct fused_args {
     const double *__restrict__ a1, *__restrict__ a2, *__restrict__ dx;
     const long long *__restrict__ level_start;
     double *qr1, *qr2; // [2][N] router outputs by sub-step parity (main channel / floodplains)
+    // component layout: router outputs of the tree roots of every tier but the last, one slab per sub-step
+    // ([nsteps][nroots]): the next tier runs after this one has finished ALL its sub-steps
+    double *root1, *root2;
+    long long nroots;
     long long n, side_stride;
     double dx_scalar, beta, inv_beta, b_minus_1;
     int kmax, nlevels, nsteps, t;
@@ -1049,30 +1084,13 @@ __device__ __forceinline__ double upstream_sum8(const double *q, int u0, int u1,
     return ups;
 }
 
-template <bool SPLIT, bool STRUCT>
-__global__ void __launch_bounds__(kBlock) k_fused_substeps(fused_args F)
+// One (cell, sub-step) of the fused sub-steps: everything but the choice of the cell.  `UPS` sums the router outputs of
+// the upstream cells (ascending pixel id) from the parity buffer it is handed: the contiguous range of the level
+// layout, or the ranges / index lists of the component layout.
+template <bool SPLIT, bool STRUCT, class UPS>
+__device__ __forceinline__ void fused_cell(const fused_args &F, long long p, int s, const UPS &ups_of,
+                                           long long root_slot = -1)
 {
-    int s, blk;
-    if (F.packed) { // the last sub-step whose first block is <= blockIdx.x (starts are non-decreasing; independent
-                    // scalar loads and compares -- a binary search would chain its kernarg loads)
-        int cnt = 0, start = 0;
-        for (int q = 0; q < F.nsteps; ++q) {
-            const bool ge = (int)blockIdx.x >= F.blk_start[q];
-            cnt += ge ? 1 : 0;
-            start = ge ? F.blk_start[q] : start;
-        }
-        s = cnt - 1;
-        blk = (int)blockIdx.x - start;
-    } else {
-        s = blockIdx.y;
-        blk = blockIdx.x;
-    }
-    const int k = F.t - s;             // level handled by this sub-step at wave time t
-    if (k < 0 || k >= F.nlevels) return;
-    const long long first = F.level_start[k];
-    const long long i = (long long)blk * kBlock + threadIdx.x;
-    if (i >= F.level_start[k + 1] - first) return;
-    const long long p = first + i;
     const lf_substep_args &A = F.S;
     if (!STRUCT && F.inert && F.inert[p] && s != F.nsteps - 1) { // see k_inert_flags; the last sub-step also writes
         bool zero = plus_zero(A.ChanQKin[p]) && plus_zero(A.ChanM3Kin[p]) && plus_zero(A.ChanQ[p]); // velocities
@@ -1088,7 +1106,6 @@ __global__ void __launch_bounds__(kBlock) k_fused_substeps(fused_args F)
     // ---- kernel would pin all later loads behind it (the kernel is a stream of ~30 vectors) -------------------
     const double dxp = F.dx ? F.dx[p] : F.dx_scalar;
     const double inv_len = A.InvChanLength[p], len = A.ChanLength[p];
-    const int u0 = F.ups_ptr[p], u1 = F.ups_ptr[p + 1];
     const bool is_chan = A.IsChannelKinematic[p] != 0;
     const bool cut = F.linked && F.linked[p];
     double side_m3, qin = 0, qin_added = 0, loss = 0, trans_cum = 0;
@@ -1117,7 +1134,7 @@ __global__ void __launch_bounds__(kBlock) k_fused_substeps(fused_args F)
     }
     const double ap1 = F.a1[p], qold = A.ChanQKin[p], alpha1 = A.ChannelAlpha[p], inv_alpha1 = A.InvChannelAlpha[p];
     const double sum_old = A.sumDisDay[p];
-    const double ups1 = upstream_sum8(F.qr1 + par, u0, u1, F.kmax);
+    const double ups1 = ups_of(F.qr1 + par, 0);
     double m3 = 0, m3_2 = 0, start = 0, m3limit = 0, q2start = 0, ap2 = 0, q2old = 0, alpha2 = 0, inv_alpha2 = 0, qlimit = 0,
            ups2 = 0;
     if (SPLIT) {
@@ -1131,7 +1148,7 @@ __global__ void __launch_bounds__(kBlock) k_fused_substeps(fused_args F)
         alpha2 = A.ChannelAlpha2[p];
         inv_alpha2 = A.InvChannelAlpha2[p];
         qlimit = A.QLimit[p];
-        ups2 = upstream_sum8(F.qr2 + par, u0, u1, F.kmax);
+        ups2 = ups_of(F.qr2 + par, 1);
     }
     const bool last = s == F.nsteps - 1;
     double pix_area = 0;
@@ -1182,6 +1199,7 @@ __global__ void __launch_bounds__(kBlock) k_fused_substeps(fused_args F)
         I.SideflowChanM3[p] = side_m3;
     }
     F.qr1[par + p] = cut ? 0.0 : qr;
+    if (root_slot >= 0) F.root1[(long long)s * F.nroots + root_slot] = qr; // component layout: kept for the next tier
     A.ChanM3Kin[p] = v;
     A.ChanQKin[p] = q;
     A.ChanQ[p] = chanq;
@@ -1189,6 +1207,7 @@ __global__ void __launch_bounds__(kBlock) k_fused_substeps(fused_args F)
     if (SPLIT) {
         A.Sideflow1Chan[p] = s1;
         F.qr2[par + p] = cut ? 0.0 : q2r;
+        if (root_slot >= 0) F.root2[(long long)s * F.nroots + root_slot] = q2r;
         A.Chan2M3Kin[p] = v2;
         A.CrossSection2Area[p] = (v2 - start) * inv_len;
         A.Chan2QKin[p] = q2;
@@ -1207,6 +1226,119 @@ __global__ void __launch_bounds__(kBlock) k_fused_substeps(fused_args F)
     }
 }
 
+template <bool SPLIT, bool STRUCT>
+__global__ void __launch_bounds__(kBlock) k_fused_substeps(fused_args F)
+{
+    int s, blk;
+    if (F.packed) { // the last sub-step whose first block is <= blockIdx.x (starts are non-decreasing; independent
+                    // scalar loads and compares -- a binary search would chain its kernarg loads)
+        int cnt = 0, start = 0;
+        for (int q = 0; q < F.nsteps; ++q) {
+            const bool ge = (int)blockIdx.x >= F.blk_start[q];
+            cnt += ge ? 1 : 0;
+            start = ge ? F.blk_start[q] : start;
+        }
+        s = cnt - 1;
+        blk = (int)blockIdx.x - start;
+    } else {
+        s = blockIdx.y;
+        blk = blockIdx.x;
+    }
+    const int k = F.t - s;             // level handled by this sub-step at wave time t
+    if (k < 0 || k >= F.nlevels) return;
+    const long long first = F.level_start[k];
+    const long long i = (long long)blk * kBlock + threadIdx.x;
+    if (i >= F.level_start[k + 1] - first) return;
+    const long long p = first + i;
+    const int u0 = F.ups_ptr[p], u1 = F.ups_ptr[p + 1];
+    const int kmax = F.kmax;
+    fused_cell<SPLIT, STRUCT>(F, p, s, [u0, u1, kmax](const double *q, int) { return upstream_sum8(q, u0, u1, kmax); });
+}
+
+// ---- the same wavefront INSIDE every bin of the component layout ---------------------------------------------------
+// One workgroup (4 wavefronts) per bin walks t = local level + sub-step; the items (level t - s, sub-step s) of one t
+// are packed over its lanes (a thin level has a few cells, but there are up to nsteps of them per t).  Cells read the router
+// outputs of their upstream cells from the parity buffers (same bin, one level up, written at t - 1) or, for the
+// tributaries of a tier >= 1 cell, from the root slabs the lower tiers left behind.  Arithmetic = fused_cell.
+struct comp_fused_args {
+    comp_args C;
+    const int *__restrict__ root_base; // [B] slot of the first cell of the bin's last level in the root slabs, -1 = none
+    int bin0;
+};
+
+constexpr int kCompFusedBlock = 256; // 4 wavefronts share the items of a t: a thin level x 24 sub-steps is one pass
+
+template <bool SPLIT, bool TRUNK>
+__global__ void __launch_bounds__(kCompFusedBlock) k_comp_fused(comp_fused_args G, fused_args F)
+{
+    const comp_args &C = G.C;
+    const int lane = (int)threadIdx.x & 63; // every wavefront lays the items of a t out for itself (same result)
+    const int b = G.bin0 + (int)blockIdx.x;
+    const int l0 = ld_table(C.bin_lvl_off, b), nl = ld_table(C.bin_nl, b);
+    const int lls = ld_table(C.lvl, l0 + nl - 1);
+    const int rbase = G.root_base ? ld_table(G.root_base, b) : -1;
+    const int S = F.nsteps; // <= 64: lane s owns sub-step s while the items of a t are laid out
+    for (int t = 0; t < nl + S - 1; ++t) {
+        // lane s: the level of sub-step s at this t, its first position and width; exclusive prefix = item offset
+        const int k = t - lane;
+        const bool valid = lane < S && k >= 0 && k < nl;
+        const int first = valid ? C.lvl[l0 + k] : 0;
+        const int width = valid ? C.lvl[l0 + k + 1] - first : 0;
+        int incl = width;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += up;
+        }
+        const int excl = incl - width;
+        const int total = __shfl(incl, 63, 64);
+        for (int base = 0; base < total; base += kCompFusedBlock) {
+            const int i = base + (int)threadIdx.x;
+            // sub-step of item i: the last s whose items start at or before i (empty levels own no item)
+            int s = 0;
+            for (int q = 0; q < S; ++q) {
+                const int eq = __builtin_amdgcn_readlane(excl, q), wq = __builtin_amdgcn_readlane(width, q);
+                s = (wq > 0 && i >= eq) ? q : s;
+            }
+            const int f = __shfl(first, s, 64), e = __shfl(excl, s, 64);
+            if (i < total) {
+                const int p = f + (i - e);
+                const int kmax = F.kmax;
+                const long long slot = (rbase >= 0 && p >= lls) ? (long long)rbase + (p - lls) : -1;
+                if (TRUNK) {
+                    const int q = p - C.trunk_first;
+                    const int u0 = C.t_ptr[q], u1 = C.t_ptr[q + 1];
+                    const int *idx = C.t_idx;
+                    const double *r1 = F.root1 + (long long)s * F.nroots, *r2 = F.root2 + (long long)s * F.nroots;
+                    fused_cell<SPLIT, false>(F, p, s, [=](const double *qr, int section) {
+                        double v[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            double x = 0.0;
+                            if (j < kmax && u0 + j < u1) {
+                                const int src = idx[u0 + j]; // >= 0: position in this bin; < 0: -(root slot) - 1
+                                x = src >= 0 ? qr[src] : (section ? r2 : r1)[-(src + 1)];
+                            }
+                            v[j] = x;
+                        }
+                        double ups = 0.0;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) ups += v[j];
+                        return ups;
+                    }, slot);
+                } else {
+                    const int u0 = F.ups_ptr[p];
+                    int u1 = F.ups_ptr[p + 1];
+                    u1 = u1 < lls ? u1 : lls;
+                    fused_cell<SPLIT, false>(F, p, s, [=](const double *qr, int) { return upstream_sum8(qr, u0, u1, kmax); },
+                                             slot);
+                }
+            }
+        }
+        __syncthreads(); // workgroup-scope fence + barrier: t + 1 reads what t wrote
+    }
+}
+
 } // namespace
 
 namespace {
@@ -1215,9 +1347,9 @@ int fused_impl(lf_router *r, const lf_substep_args *a, int nsteps, int64_t sidef
 {
     if (!r || !a || nsteps < 1) return lf_set_error(LF_E_INVALID, "bad argument");
     if (!a->engine_order) return lf_set_error(LF_E_INVALID, "the fused sub-step wavefront needs engine-order vectors");
-    if (r->comp)
-        return lf_set_error(LF_E_INVALID, "the fused sub-step wavefront runs on the level layout (router built on a graph "
-                            "with a component layout)");
+    if (r->comp && (in || nsteps > 64))
+        return lf_set_error(LF_E_INVALID, "on the component layout the fused sub-steps run without structures and with at "
+                            "most 64 sub-steps");
     if (a->split && !r->has_floodplains)
         return lf_set_error(LF_E_SECTION, "split routing requested but the router has no floodplain alpha");
     if (sideflow_stride != 0 && sideflow_stride != r->N) return lf_set_error(LF_E_INVALID, "sideflow_stride must be 0 or N");
@@ -1235,6 +1367,8 @@ int fused_impl(lf_router *r, const lf_substep_args *a, int nsteps, int64_t sidef
     F.level_start = r->level_start.p;
     F.qr1 = r->fused_qr1.p;
     F.qr2 = r->fused_qr2.p;
+    F.root1 = F.root2 = nullptr;
+    F.nroots = 0;
     F.n = n;
     F.side_stride = sideflow_stride;
     F.dx_scalar = r->dx_scalar;
@@ -1314,6 +1448,56 @@ int fused_impl(lf_router *r, const lf_substep_args *a, int nsteps, int64_t sidef
         }
     }
     int64_t launches = 0;
+    if (r->comp) { // one launch per tier, one wavefront per bin (k_comp_fused)
+        const char *e = std::getenv("LF_NO_INERT_SKIP");
+        if (r->n_isolated > 0 && nsteps > 1 && !(e && e[0] == '1')) {
+            if (!r->inert.p) LF_TRY(r->inert.alloc(n));
+            hipLaunchKernelGGL(k_inert_flags, dim3(blocks_for(n)), dim3(kBlock), 0, s, (long long)n, *a, r->isolated.p,
+                               r->a1.p, r->a2.p, F.dx, r->inert.p);
+            F.inert = r->inert.p;
+            ++launches;
+        }
+        const int T = (int)r->c_tier_bin_start.size() - 1;
+        if (T > 1 && (r->c_root_steps < nsteps || !r->c_root1.p || (a->split && !r->c_root2.p))) {
+            LF_TRY(r->c_root1.alloc((size_t)nsteps * (size_t)r->c_nroots));
+            if (a->split) LF_TRY(r->c_root2.alloc((size_t)nsteps * (size_t)r->c_nroots));
+            r->c_root_steps = nsteps;
+        }
+        F.root1 = r->c_root1.p;
+        F.root2 = r->c_root2.p;
+        F.nroots = r->c_nroots;
+        F.packed = 0;
+        F.t = 0;
+        comp_fused_args G;
+        G.C.bin_lvl_off = r->c_bin_lvl_off.p;
+        G.C.bin_nl = r->c_bin_nl.p;
+        G.C.lvl = r->c_lvl.p;
+        G.C.t_ptr = r->c_t_ptr.p;
+        G.C.t_idx = r->c_t_idx_fused.p;
+        G.C.trunk_first = (int)r->c_trunk_first;
+        for (int t = 0; t < T; ++t) {
+            const int b0 = r->c_tier_bin_start[t], nb = r->c_tier_bin_start[t + 1] - b0;
+            if (nb <= 0) continue;
+            G.bin0 = b0;
+            G.root_base = (t + 1 < T) ? r->c_root_base.p : nullptr;
+            const dim3 grid(nb), block(kCompFusedBlock);
+            if (t == 0 && a->split)
+                hipLaunchKernelGGL((k_comp_fused<true, false>), grid, block, 0, s, G, F);
+            else if (t == 0)
+                hipLaunchKernelGGL((k_comp_fused<false, false>), grid, block, 0, s, G, F);
+            else if (a->split)
+                hipLaunchKernelGGL((k_comp_fused<true, true>), grid, block, 0, s, G, F);
+            else
+                hipLaunchKernelGGL((k_comp_fused<false, true>), grid, block, 0, s, G, F);
+            ++launches;
+        }
+        LF_HIP(hipGetLastError());
+        r->last_stats[0] = launches;
+        r->last_stats[1] = launches;
+        r->last_stats[2] = 0;
+        r->last_stats[3] = r->NL;
+        return LF_OK;
+    }
     bool grid2d = false;
     {
         const char *e2 = std::getenv("LF_FUSED_2D_GRID"); // A/B switch: one grid row per sub-step, sized by the widest

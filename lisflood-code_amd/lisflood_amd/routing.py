@@ -230,9 +230,9 @@ class routing(HydroModule):
             mask = np.zeros(land_mask.shape, bool)
             mask[land_mask] = keep
         graph = None
-        if components:       # the component layout (pixel-order sub-steps only: the fused wavefront needs levels)
-            if self.engine_order:
-                raise ValueError("engine_order=True runs the fused sub-step wavefront, which needs the level layout")
+        if components:       # the component layout (lf_graph_build_components); structures need the level layout
+            if self.engine_order and structures:
+                raise ValueError("lakes / reservoirs inside the wavefront need the level layout (components=None)")
             from .kinematic_wave_parallel import Graph
             graph = Graph(codes[ids], mask, components=components)
         if self.engine_order and structures:

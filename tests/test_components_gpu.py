@@ -96,3 +96,54 @@ def test_components_scalar_dx_and_substep_module(amd):
             m.dynamic(s)
     for k in ("ChanQKin", "Chan2QKin", "ChanM3Kin", "ChanQ", "sumDisDay", "CrossSection2Area"):
         assert np.array_equal(getattr(v_a, k), getattr(v_b, k)), k
+
+
+@pytest.mark.parametrize("split", [True, False])
+@pytest.mark.parametrize("family,shape,comp", [("deep", (500, 900), (24, 128)), ("shallow", (700, 700), True),
+                                               ("river", (400, 500), (16, 64))])
+def test_components_fused_substeps_equal_the_level_wavefront(amd, family, shape, comp, split):
+    """A model step of NoRoutSteps sub-steps inside every bin of the component layout (k_comp_fused; the roots of a tier
+    hand their router outputs of every sub-step to the next tier) against the level wavefront: every state and output
+    vector bit for bit.  20 % non-channel pixels (isolated; inert ones are skipped by both)."""
+    from lisflood_amd import synthetic as syn
+    from lisflood_amd import ldd as L
+    from lisflood_amd.kinematic_wave_parallel import kinematicWave
+    from lisflood_amd.routing import _OUT, _STATE
+    from lisflood_amd.routing_device import RoutingStepDevice
+    H, W = shape
+    N = H * W
+    mask = np.ones((H, W), bool)
+    codes = syn.make_ldd(family, H, W, 5).reshape(-1).astype(np.float64)
+    rng = np.random.default_rng(23)
+    is_chan = rng.random(N) < 0.8
+    kin, _ = L.lddmask(codes, mask, is_chan)
+    ldd_kin = np.zeros(N); ldd_kin[is_chan] = kin
+    p = syn.router_params(N, seed=12)
+    beta, dt, nsteps = p["beta"], 3600.0, 9
+    alpha, length = p["alpha"], p["dx"]
+    alpha2 = alpha * rng.uniform(1.2, 2.0, N)
+    q0 = np.where(is_chan, p["Q0"], 0.0)
+    qlimit = 2.0 * q0 * rng.uniform(0.3, 1.2, N)
+    vals = dict(ChanLength=length, InvChanLength=1 / length, ChannelAlpha=alpha, InvChannelAlpha=1 / alpha,
+                ChannelAlpha2=alpha2, InvChannelAlpha2=1 / alpha2, QLimit=qlimit, M3Limit=alpha * length * qlimit ** beta,
+                Chan2M3Start=alpha2 * length * qlimit ** beta, Chan2QStart=qlimit * 0.1, PixelArea=np.full(N, 2.5e7),
+                IsChannelKinematic=is_chan, SideflowChanM3=syn.lateral_inflow(N, 0) * length * dt)
+    vals["Chan2M3Kin"] = vals["Chan2M3Start"].copy()
+    vals["ChanM3Kin"] = alpha * length * q0 ** beta
+    vals["ChanQKin"] = q0.copy()
+    vals["Chan2QKin"] = (vals["Chan2M3Kin"] / length / alpha2) ** (1 / beta)
+    kwa = kinematicWave(ldd_kin, mask, alpha, beta, length, dt, alpha_floodplains=alpha2)
+    kwb = kinematicWave(ldd_kin, mask, alpha, beta, length, dt, alpha_floodplains=alpha2, components=comp)
+    a = RoutingStepDevice(kwa, vals, split, beta, 1 / dt, dt * nsteps)
+    b = RoutingStepDevice(kwb, vals, split, beta, 1 / dt, dt * nsteps)
+    for rep in range(2):                                   # two model steps: the second starts from the first's state
+        a.run_fused(nsteps); b.run_fused(nsteps)
+        names = _STATE + _OUT if split else ["ChanQKin", "ChanM3Kin", "ChanQ", "sumDisDay"] + _OUT
+        for k in names:
+            assert np.array_equal(a.download(k), b.download(k), equal_nan=True), (family, rep, k)
+    q = b.download("ChanQ")
+    assert np.isfinite(q).all() and q[is_chan].max() > 0
+    assert kwb.last_launches()["launches"] <= kwb.graph.components["tiers"] + 1
+    if family != "shallow":
+        assert kwb.graph.components["tiers"] >= 2 and kwb.graph.components["trunk_cells"] > 1000   # root slabs in use
+    a.free(); b.free(); kwa.close(); kwb.close()
