@@ -229,6 +229,32 @@ int lf_upstream_sum_raster_device(int device, const uint8_t *ldd_raster_dev, con
 /* accuflux(ldd, x): sum of x over all upstream cells including the cell itself (routing.py:98) */
 int lf_accuflux_host(lf_router *r, const double *x_host, double *out_host);
 
+/* accuflux on engine-order device vectors (acc_ord[p] = x_ord[p] + sum over the upstream cells) */
+int lf_accuflux_ordered_device(lf_router *r, const double *x_ord_dev, double *acc_ord_dev);
+
+/* ---------------------------------------------------------------------------------------------
+ * LDD operations of routing.initial / structures.initial (routing.py:90-171, structures.py:44-61; the reference calls
+ * PCRaster 4.3.3: lddrepair, lddmask, downstream, catchment) and the per-catchment totals of routing.dynamic's
+ * mass-balance bookkeeping (routing.py:483-499, 645-691).  Rasters are H x W uint8 keypad codes, 0 = missing value.
+ * ------------------------------------------------------------------------------------------- */
+/* lddrepair: cells draining off the map or into a missing value become pits (routing.py:125) */
+int lf_lddrepair_raster_device(int device, const uint8_t *ldd_dev, uint8_t *out_dev, int H, int W);
+/* lddmask(ldd, keep): cells outside keep become missing values, cells draining out of keep become pits (:90, :118) */
+int lf_lddmask_raster_device(int device, const uint8_t *ldd_dev, const uint8_t *keep_dev, uint8_t *out_dev, int H, int W);
+/* host-buffer form of both: keep_host = NULL -> lddrepair, else lddmask */
+int lf_ldd_raster_host(int device, const uint8_t *ldd_host, const uint8_t *keep_host, uint8_t *out_host, int H, int W);
+/* downstream(ldd, x): value of x at the downstream cell, pits keep their own (routing.py:141, 162; structures.py:51) */
+int lf_downstream_device(lf_router *r, const double *x_pix_dev, double *out_pix_dev);
+int lf_downstream_host(lf_router *r, const double *x_host, double *out_host);
+/* catchment(ldd, points): id of the first non-zero point met going downstream (a point cell belongs to its own
+ * catchment), 0 if none (routing.py:168-171).  Pointer jumping over the downstream links: O(log depth) passes. */
+int lf_catchments_device(lf_router *r, const int32_t *points_pix_dev, int32_t *labels_pix_dev);
+int lf_catchments(lf_router *r, const int64_t *points_host, int64_t *labels_host);
+/* np.take(np.bincount(Catchments, weights=w), Catchments) for Catchments = catchment(ldd, pit(ldd)): every cell gets
+ * the total of w over its whole tree (routing.py:483-499, 645-691; equal to rounding, the summation order differs) */
+int lf_catchment_totals_device(lf_router *r, const double *w_pix_dev, double *out_pix_dev);
+int lf_catchment_totals_host(lf_router *r, const double *w_host, double *out_host);
+
 /* ---------------------------------------------------------------------------------------------
  * soil: replaces interception_water_balance (soilloop.py:27-70) and soilColumnsWaterBalance
  * (soilloop.py:78-355).  Layouts as in the reference: [V,N] / [L,N] C-order fp64, bool arrays 1 byte.
@@ -290,6 +316,21 @@ typedef struct lf_canopy_args {
     int64_t V, L, N;
 } lf_canopy_args;
 int lf_canopy_device(int device, const lf_canopy_args *a);
+
+/* suctionUnsaturatedSoilPF + pressureHead (soilloop.py:427-432, 673-695; option simulatePF): pF = log10 of the capillary
+ * head of the three soil layers, -1 where the head is not positive.  [V,N] by vegetation row, [L,N] by land-use row. */
+typedef struct lf_soil_pf_args {
+    double *pF0, *pF1, *pF2;                 /* [V,N] out */
+    const double *W1a, *W1b, *W2;            /* [V,N] */
+    const double *WRes1a, *WRes1b, *WRes2, *WS1a, *WS1b, *WS2; /* [L,N] */
+    const uint8_t *PoreSpaceNotZero1a, *PoreSpaceNotZero1b, *PoreSpaceNotZero2;
+    const double *GenuInvAlpha1a, *GenuInvAlpha1b, *GenuInvAlpha2, *GenuInvM1a, *GenuInvM1b, *GenuInvM2, *GenuInvN1a,
+        *GenuInvN1b, *GenuInvN2;             /* [L,N] */
+    const int64_t *index_landuse_all;        /* [V], host */
+    double HeadMax;
+    int64_t V, L, N;
+} lf_soil_pf_args;
+int lf_soil_pf_device(int device, const lf_soil_pf_args *a);
 /* out[v,p] = row[p] * m[v,p]  (ESMax = ESRef * LAITerm, soilloop.py:638) */
 int lf_scale_rows_device(int device, const double *row_dev, const double *m_dev, double *out_dev, int64_t V, int64_t N);
 

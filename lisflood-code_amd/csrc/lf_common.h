@@ -34,6 +34,11 @@ struct lf_device_ctx {
     bool ready = false;
     hipStream_t stream = nullptr;
     hipEvent_t t0 = nullptr, t1 = nullptr;
+    // staging arena of the *_host entry points (lf_soil.hip): one grow-only device allocation carved up per call
+    // instead of ~70 hipMalloc / hipFree pairs; a call that needs more gets overflow buffers and the arena grows
+    // before the next one
+    void *stage_base = nullptr;
+    size_t stage_bytes = 0, stage_need = 0;
     void *soil_ws = nullptr; // work list of deferred soil columns (lf_soil.hip)
     size_t soil_ws_bytes = 0, soil_ntiles = 0;
     // deferred-column count of the last soil call, copied back asynchronously: decides whether the next call stages
@@ -113,14 +118,15 @@ struct lf_dbuf { // owning device buffer
         }
         return LF_OK;
     }
-    int upload(const T *src, size_t count)
+    // `stream`: the stream the kernels that read the buffer run on.  The library's compute stream is non-blocking, i.e. it
+    // does not synchronise with the legacy stream a plain hipMemcpy uses, and a pageable H2D copy may return once the
+    // source is staged: the copy is therefore enqueued on the consumer's own stream and waited for there.
+    int upload(const T *src, size_t count, hipStream_t stream = nullptr)
     {
         LF_TRY(alloc(count));
         if (count) {
-            // the library's kernels run on a non-blocking stream that does not synchronise with the legacy stream this
-            // copy uses: wait for the DMA itself, not just for the staging of the pageable source
-            LF_HIP(hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice));
-            LF_HIP(hipStreamSynchronize(nullptr));
+            LF_HIP(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, stream));
+            LF_HIP(hipStreamSynchronize(stream));
         }
         return LF_OK;
     }

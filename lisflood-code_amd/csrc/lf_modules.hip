@@ -273,9 +273,51 @@ __global__ void __launch_bounds__(kBlock) k_inloop_dense(lf_inloop_args A)
     if (A.ChannelToPolderM3Dt) side -= A.ChannelToPolderM3Dt[p];
     A.SideflowChanM3[p] = side;
 }
+// pressureHead of one layer (soilloop.py:427-432) behind saturationDegree (:378-383), then log10 (:691-695)
+__device__ __forceinline__ double pf_layer(double w, bool pore, double wres, double ws, double inv_alpha, double inv_m,
+                                           double inv_n, double head_max)
+{
+    double sat = 0.0;
+    if (pore) sat = dmax(dmin((w - wres) / (ws - wres), 1.), 0.); // builtins max / min, as the soil kernel
+    double head = head_max;
+    if (sat != 0.0) head = dmin(head_max, inv_alpha * pow(pow(1. / sat, inv_m) - 1., inv_n));
+    return head > 0 ? log10(head) : -1.;
+}
+
+__global__ void __launch_bounds__(kBlock) k_soil_pf(lf_soil_pf_args A, veg_map M)
+{
+    const long long pix = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (pix >= A.N) return;
+    for (int veg = 0; veg < (int)A.V; ++veg) {
+        const long long i = (long long)veg * A.N + pix, j = (long long)M.landuse[veg] * A.N + pix;
+        A.pF0[i] = pf_layer(A.W1a[i], A.PoreSpaceNotZero1a[j] != 0, A.WRes1a[j], A.WS1a[j], A.GenuInvAlpha1a[j], A.GenuInvM1a[j],
+                            A.GenuInvN1a[j], A.HeadMax);
+        A.pF1[i] = pf_layer(A.W1b[i], A.PoreSpaceNotZero1b[j] != 0, A.WRes1b[j], A.WS1b[j], A.GenuInvAlpha1b[j], A.GenuInvM1b[j],
+                            A.GenuInvN1b[j], A.HeadMax);
+        A.pF2[i] = pf_layer(A.W2[i], A.PoreSpaceNotZero2[j] != 0, A.WRes2[j], A.WS2[j], A.GenuInvAlpha2[j], A.GenuInvM2[j],
+                            A.GenuInvN2[j], A.HeadMax);
+    }
+}
 } // namespace
 
 extern "C" {
+
+int lf_soil_pf_device(int device, const lf_soil_pf_args *a)
+{
+    if (!a || !a->index_landuse_all) return lf_set_error(LF_E_INVALID, "null argument");
+    lf_device_ctx *c;
+    LF_TRY(lf_ctx(device, &c));
+    if (a->V > kMaxVeg || a->V < 0) return lf_set_error(LF_E_INVALID, "too many vegetation rows");
+    veg_map M;
+    for (int v = 0; v < (int)a->V; ++v) {
+        if (a->index_landuse_all[v] < 0 || a->index_landuse_all[v] >= a->L) return lf_set_error(LF_E_INVALID, "bad land-use row");
+        M.landuse[v] = (int)a->index_landuse_all[v];
+    }
+    if (a->N <= 0 || a->V == 0) return LF_OK;
+    hipLaunchKernelGGL(k_soil_pf, dim3(blocks_for(a->N)), dim3(kBlock), 0, c->stream, *a, M);
+    LF_HIP(hipGetLastError());
+    return LF_OK;
+}
 
 int lf_pixel_aggregates_device(int device, const lf_pixel_args *a)
 {

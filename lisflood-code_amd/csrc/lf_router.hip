@@ -174,6 +174,7 @@ struct lf_router {
     int64_t c_trunk_first = 0;
     lf_dbuf<unsigned long long> counter;
     lf_dbuf<uint8_t> linked; // zero-length structure links (lf_graph_create_ex); null without them
+    lf_dbuf<int32_t> parent; // [N] downstream position of every position, -1 = outlet (lf_ldd.hip builds it on demand)
     lf_dbuf<uint8_t> isolated; // [N] by position: 1 = no upstream and no downstream cell (e.g. non-channel land pixels)
     lf_dbuf<uint8_t> inert;    // [N] per fused call: isolated, not a channel, zero split-routing thresholds
     int64_t n_isolated = 0;
@@ -473,27 +474,27 @@ int lf_router_create(const lf_graph *g, const double *alpha, double beta, const 
             }
         };
         fill(alpha);
-        rc = r->a1.upload(h.data(), n);
+        rc = r->a1.upload(h.data(), n, ctx->stream);
         if (rc == LF_OK && alpha_floodplains) {
             fill(alpha_floodplains);
-            rc = r->a2.upload(h.data(), n);
+            rc = r->a2.upload(h.data(), n, ctx->stream);
         }
         if (rc == LF_OK && dx) {
             for (int64_t p = 0; p < n; ++p) h[p] = dx[g_perm[p]];
-            rc = r->dx.upload(h.data(), n);
+            rc = r->dx.upload(h.data(), n, ctx->stream);
         }
     }
-    if (rc == LF_OK) rc = r->perm.upload(g_perm.data(), n);
-    if (rc == LF_OK) rc = r->ups_ptr.upload(g_ups_ptr.data(), n + 1);
+    if (rc == LF_OK) rc = r->perm.upload(g_perm.data(), n, ctx->stream);
+    if (rc == LF_OK) rc = r->ups_ptr.upload(g_ups_ptr.data(), n + 1, ctx->stream);
     if (rc == LF_OK && g->comp) {
         const lf_comp_plan &c = *g->comp;
         r->c_tier_bin_start = c.tier_bin_start;
         r->c_trunk_first = c.trunk_first;
-        rc = r->c_bin_lvl_off.upload(c.bin_lvl_off.data(), c.bin_lvl_off.size());
-        if (rc == LF_OK) rc = r->c_bin_nl.upload(c.bin_nl.data(), c.bin_nl.size());
-        if (rc == LF_OK) rc = r->c_lvl.upload(c.lvl.data(), c.lvl.size());
-        if (rc == LF_OK) rc = r->c_t_ptr.upload(c.t_ptr.data(), c.t_ptr.size());
-        if (rc == LF_OK) rc = r->c_t_idx.upload(c.t_idx.data(), c.t_idx.size());
+        rc = r->c_bin_lvl_off.upload(c.bin_lvl_off.data(), c.bin_lvl_off.size(), ctx->stream);
+        if (rc == LF_OK) rc = r->c_bin_nl.upload(c.bin_nl.data(), c.bin_nl.size(), ctx->stream);
+        if (rc == LF_OK) rc = r->c_lvl.upload(c.lvl.data(), c.lvl.size(), ctx->stream);
+        if (rc == LF_OK) rc = r->c_t_ptr.upload(c.t_ptr.data(), c.t_ptr.size(), ctx->stream);
+        if (rc == LF_OK) rc = r->c_t_idx.upload(c.t_idx.data(), c.t_idx.size(), ctx->stream);
         if (rc == LF_OK && c.tier_bin_start.size() > 2) { // more than one tier: root slots for the fused sub-steps
             const int T = (int)c.tier_bin_start.size() - 1;
             const size_t B = c.bin_nl.size();
@@ -517,8 +518,8 @@ int lf_router_create(const lf_graph *g, const double *alpha, double beta, const 
                             tf[e] = (u >= b_first && u < b_end) ? u : -(slot_of[u] + 1);
                         }
                 }
-            rc = r->c_root_base.upload(root_base.data(), B);
-            if (rc == LF_OK) rc = r->c_t_idx_fused.upload(tf.data(), tf.size());
+            rc = r->c_root_base.upload(root_base.data(), B, ctx->stream);
+            if (rc == LF_OK) rc = r->c_t_idx_fused.upload(tf.data(), tf.size(), ctx->stream);
         }
         if (rc == LF_OK) { // end of every cell's same-tier upstream range (the one-hop reductions read it)
             std::vector<int32_t> ends(n);
@@ -527,10 +528,10 @@ int lf_router_create(const lf_graph *g, const double *alpha, double beta, const 
                 const int32_t lls = c.lvl[l0 + nl - 1];
                 for (int32_t p = c.lvl[l0]; p < c.lvl[l0 + nl]; ++p) ends[p] = std::min(c.ups_ptr[p + 1], lls);
             }
-            rc = r->c_ups_end.upload(ends.data(), n);
+            rc = r->c_ups_end.upload(ends.data(), n, ctx->stream);
         }
     }
-    if (rc == LF_OK && g->has_links) rc = r->linked.upload(g->linked.data(), n);
+    if (rc == LF_OK && g->has_links) rc = r->linked.upload(g->linked.data(), n, ctx->stream);
     if (rc == LF_OK && n > 0) {
         std::vector<uint8_t> has_up(n, 0), iso(n, 0);
         for (int64_t p = 0; p < n; ++p)
@@ -540,11 +541,11 @@ int lf_router_create(const lf_graph *g, const double *alpha, double beta, const 
             iso[p] = (g->down[pix] < 0 && !has_up[pix] && !(g->has_links && g->linked[p])) ? 1 : 0;
             r->n_isolated += iso[p];
         }
-        if (r->n_isolated > 0) rc = r->isolated.upload(iso.data(), n);
+        if (r->n_isolated > 0) rc = r->isolated.upload(iso.data(), n, ctx->stream);
     }
     if (rc == LF_OK) {
         std::vector<long long> ls(g->level_start.begin(), g->level_start.end());
-        rc = r->level_start.upload(ls.data(), ls.size());
+        rc = r->level_start.upload(ls.data(), ls.size(), ctx->stream);
     }
     if (rc == LF_OK && !r->fused) rc = r->constant.alloc(n);
     if (rc == LF_OK) rc = r->qord.alloc(n);
@@ -630,8 +631,8 @@ int lf_router_create(const lf_graph *g, const double *alpha, double beta, const 
             }
         }
         if (!h_ptr.empty()) {
-            rc = r->win_ptr.upload(h_ptr.data(), h_ptr.size());
-            if (rc == LF_OK) rc = r->win_cells.upload(h_cells.data(), h_cells.size());
+            rc = r->win_ptr.upload(h_ptr.data(), h_ptr.size(), ctx->stream);
+            if (rc == LF_OK) rc = r->win_cells.upload(h_cells.data(), h_cells.size(), ctx->stream);
             if (rc != LF_OK) {
                 delete r;
                 return rc;
@@ -806,6 +807,49 @@ int lf_upstream_sum_host(lf_router *r, const double *w_host, double *out_host)
     return LF_OK;
 }
 
+// accuflux over engine-order device vectors: acc[p] = x[p] + sum of acc over the upstream cells
+int lf_accuflux_ordered_device(lf_router *r, const double *x_ord_dev, double *acc_ord_dev)
+{
+    if (!r || !x_ord_dev || !acc_ord_dev) return lf_set_error(LF_E_INVALID, "null argument");
+    if (r->linked.p) return lf_set_error(LF_E_INVALID, "accuflux is not defined on a graph with structure links");
+    LF_HIP(hipSetDevice(r->device));
+    hipStream_t s = r->ctx->stream;
+    if (r->N == 0) return LF_OK;
+    if (r->comp) {
+        comp_args C;
+        C.bin_lvl_off = r->c_bin_lvl_off.p;
+        C.bin_nl = r->c_bin_nl.p;
+        C.lvl = r->c_lvl.p;
+        C.t_ptr = r->c_t_ptr.p;
+        C.t_idx = r->c_t_idx.p;
+        C.trunk_first = (int)r->c_trunk_first;
+        const int T = (int)r->c_tier_bin_start.size() - 1;
+        for (int t = 0; t < T; ++t) {
+            const int b0 = r->c_tier_bin_start[t], nb = r->c_tier_bin_start[t + 1] - b0;
+            if (nb <= 0) continue;
+            if (t == 0)
+                hipLaunchKernelGGL(k_comp_accu<false>, dim3(nb), dim3(64), 0, s, b0, C, r->ups_ptr.p, x_ord_dev, acc_ord_dev);
+            else
+                hipLaunchKernelGGL(k_comp_accu<true>, dim3(nb), dim3(64), 0, s, b0, C, r->ups_ptr.p, x_ord_dev, acc_ord_dev);
+        }
+    }
+    for (const segment &g : r->schedule) {
+        if (g.wide) {
+            for (int k = g.k0; k < g.k1; ++k) { // window segments are walked level by level here
+                const int first = (int)r->h_level_start[k];
+                const int count = (int)(r->h_level_start[k + 1] - r->h_level_start[k]);
+                hipLaunchKernelGGL(k_accu_level, dim3(blocks_for(count)), dim3(kBlock), 0, s, first, count, r->ups_ptr.p,
+                                   x_ord_dev, acc_ord_dev);
+            }
+        } else {
+            hipLaunchKernelGGL(k_accu_narrow, dim3(1), dim3(kNarrowBlock), 0, s, g.k0, g.k1, r->level_start.p,
+                               r->ups_ptr.p, x_ord_dev, acc_ord_dev);
+        }
+    }
+    LF_HIP(hipGetLastError());
+    return LF_OK;
+}
+
 int lf_accuflux_host(lf_router *r, const double *x_host, double *out_host)
 {
     if (!r || !x_host || !out_host) return lf_set_error(LF_E_INVALID, "null argument");
@@ -820,37 +864,7 @@ int lf_accuflux_host(lf_router *r, const double *x_host, double *out_host)
     if (n == 0) return LF_OK;
     LF_HIP(hipMemcpyAsync(r->io_lat.p, x_host, bytes, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_gather, dim3(blocks_for(n)), dim3(kBlock), 0, s, n, r->perm.p, r->io_lat.p, r->tmp_ord.p);
-    if (r->comp) {
-        comp_args C;
-        C.bin_lvl_off = r->c_bin_lvl_off.p;
-        C.bin_nl = r->c_bin_nl.p;
-        C.lvl = r->c_lvl.p;
-        C.t_ptr = r->c_t_ptr.p;
-        C.t_idx = r->c_t_idx.p;
-        C.trunk_first = (int)r->c_trunk_first;
-        const int T = (int)r->c_tier_bin_start.size() - 1;
-        for (int t = 0; t < T; ++t) {
-            const int b0 = r->c_tier_bin_start[t], nb = r->c_tier_bin_start[t + 1] - b0;
-            if (nb <= 0) continue;
-            if (t == 0)
-                hipLaunchKernelGGL(k_comp_accu<false>, dim3(nb), dim3(64), 0, s, b0, C, r->ups_ptr.p, r->tmp_ord.p, r->qord.p);
-            else
-                hipLaunchKernelGGL(k_comp_accu<true>, dim3(nb), dim3(64), 0, s, b0, C, r->ups_ptr.p, r->tmp_ord.p, r->qord.p);
-        }
-    }
-    for (const segment &g : r->schedule) {
-        if (g.wide) {
-            for (int k = g.k0; k < g.k1; ++k) { // window segments are walked level by level here
-                const int first = (int)r->h_level_start[k];
-                const int count = (int)(r->h_level_start[k + 1] - r->h_level_start[k]);
-                hipLaunchKernelGGL(k_accu_level, dim3(blocks_for(count)), dim3(kBlock), 0, s, first, count, r->ups_ptr.p,
-                                   r->tmp_ord.p, r->qord.p);
-            }
-        } else {
-            hipLaunchKernelGGL(k_accu_narrow, dim3(1), dim3(kNarrowBlock), 0, s, g.k0, g.k1, r->level_start.p,
-                               r->ups_ptr.p, r->tmp_ord.p, r->qord.p);
-        }
-    }
+    LF_TRY(lf_accuflux_ordered_device(r, r->tmp_ord.p, r->qord.p));
     hipLaunchKernelGGL(k_scatter, dim3(blocks_for(n)), dim3(kBlock), 0, s, n, r->perm.p, r->qord.p, r->io_q.p);
     LF_HIP(hipGetLastError());
     LF_HIP(hipMemcpyAsync(out_host, r->io_q.p, bytes, hipMemcpyDeviceToHost, s));
@@ -859,6 +873,42 @@ int lf_accuflux_host(lf_router *r, const double *x_host, double *out_host)
 }
 
 } // extern "C"
+
+// accessors for lf_ldd.hip (the router struct is private to this file)
+struct lf_router_view {
+    int device;
+    lf_device_ctx *ctx;
+    int64_t N;
+    const int32_t *perm, *ups_ptr, *ups_end;
+    const uint8_t *linked;
+    int64_t trunk_first;
+    const int32_t *t_ptr, *t_idx;
+    int32_t **parent_slot;
+};
+
+int lf_router_view_of(lf_router *r, lf_router_view *v)
+{
+    if (!r || !v) return lf_set_error(LF_E_INVALID, "null argument");
+    LF_HIP(hipSetDevice(r->device));
+    v->device = r->device;
+    v->ctx = r->ctx;
+    v->N = r->N;
+    v->perm = r->perm.p;
+    v->ups_ptr = r->ups_ptr.p;
+    v->ups_end = r->comp ? r->c_ups_end.p : nullptr;
+    v->linked = r->linked.p;
+    v->trunk_first = r->comp ? r->c_trunk_first : r->N;
+    v->t_ptr = r->c_t_ptr.p;
+    v->t_idx = r->c_t_idx.p;
+    v->parent_slot = &r->parent.p;
+    return LF_OK;
+}
+
+int lf_router_alloc_parent(lf_router *r)
+{
+    if (!r) return lf_set_error(LF_E_INVALID, "null argument");
+    return r->parent.p ? LF_OK : r->parent.alloc((size_t)r->N);
+}
 
 // ================================================================================================
 // routing.dynamic() sub-step: element-wise arithmetic around the router calls (routing.py:512-603,
@@ -1437,7 +1487,7 @@ int fused_impl(lf_router *r, const lf_substep_args *a, int nsteps, int64_t sidef
             };
             LF_TRY(check_sites(I.n_lakes, I.lake_cell, I.lake_ups_ptr, I.lake_ups_idx, 0, "lake"));
             LF_TRY(check_sites(I.n_res, I.res_cell, I.res_ups_ptr, I.res_ups_idx, I.n_lakes, "reservoir"));
-            LF_TRY(r->site_level.upload(lv.data(), (size_t)nsites));
+            LF_TRY(r->site_level.upload(lv.data(), (size_t)nsites, r->ctx->stream));
             F.site_level = r->site_level.p;
             lv_sorted = lv;
             std::sort(lv_sorted.begin(), lv_sorted.end());

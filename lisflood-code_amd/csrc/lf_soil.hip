@@ -558,24 +558,55 @@ int lf_soil_columns_device(int device, const lf_soil_args *a)
 namespace {
 struct stager {
     hipStream_t s;
-    std::vector<void *> bufs;
+    std::vector<void *> bufs; // overflow buffers of this call (freed at its end)
     struct wb {
         void *host;
         void *dev;
         size_t bytes;
     };
     std::vector<wb> writeback;
+    lf_device_ctx *ctx = nullptr; // owner of the staging arena; nullptr: every buffer is its own allocation
+    size_t used = 0;
     ~stager()
     {
         for (void *p : bufs) (void)hipFree(p);
+        if (ctx) ctx->stage_need = used > ctx->stage_need ? used : ctx->stage_need;
+    }
+    int begin(lf_device_ctx *c)
+    {
+        ctx = c;
+        if (c->stage_need > c->stage_bytes) { // the previous call overflowed: grow now, while nothing is in flight
+            LF_HIP(hipStreamSynchronize(s));
+            if (c->stage_base) (void)hipFree(c->stage_base);
+            c->stage_base = nullptr;
+            c->stage_bytes = 0;
+            const size_t want = c->stage_need + c->stage_need / 8;
+            if (hipMalloc(&c->stage_base, want) == hipSuccess)
+                c->stage_bytes = want;
+            else
+                (void)hipGetLastError(); // no arena: fall back to per-buffer allocations
+        }
+        return LF_OK;
+    }
+    int carve(size_t bytes, void **out)
+    {
+        const size_t need = (bytes + 8 + 255) & ~(size_t)255;
+        if (ctx && used + need <= ctx->stage_bytes) {
+            *out = (char *)ctx->stage_base + used;
+            used += need;
+            return LF_OK;
+        }
+        used += need;
+        LF_HIP(hipMalloc(out, need));
+        bufs.push_back(*out);
+        return LF_OK;
     }
     template <typename T>
     int in(const T *&field, size_t count)
     {
         if (!field) return lf_set_error(LF_E_INVALID, "null array argument");
         void *d = nullptr;
-        LF_HIP(hipMalloc(&d, count * sizeof(T) + 8));
-        bufs.push_back(d);
+        LF_TRY(carve(count * sizeof(T), &d));
         LF_HIP(hipMemcpyAsync(d, field, count * sizeof(T), hipMemcpyHostToDevice, s));
         field = (const T *)d;
         return LF_OK;
@@ -585,8 +616,7 @@ struct stager {
     {
         if (!field) return lf_set_error(LF_E_INVALID, "null array argument");
         void *d = nullptr;
-        LF_HIP(hipMalloc(&d, count * sizeof(T) + 8));
-        bufs.push_back(d);
+        LF_TRY(carve(count * sizeof(T), &d));
         LF_HIP(hipMemcpyAsync(d, field, count * sizeof(T), hipMemcpyHostToDevice, s));
         writeback.push_back({(void *)field, d, count * sizeof(T)});
         field = (T *)d;
@@ -610,6 +640,7 @@ int lf_interception_host(int device, const lf_interception_args *a_in)
     LF_TRY(lf_ctx(device, &c));
     lf_interception_args a = *a_in;
     stager st{c->stream, {}, {}};
+    LF_TRY(st.begin(c));
     const size_t vn = (size_t)(a.V * a.N), n = (size_t)a.N;
     LF_TRY(st.inout(a.Interception, vn));
     LF_TRY(st.inout(a.TaInterception, vn));
@@ -629,6 +660,7 @@ int lf_soil_columns_host(int device, const lf_soil_args *a_in)
     LF_TRY(lf_ctx(device, &c));
     lf_soil_args a = *a_in;
     stager st{c->stream, {}, {}};
+    LF_TRY(st.begin(c));
     const size_t vn = (size_t)(a.V * a.N), ln = (size_t)(a.L * a.N), n = (size_t)a.N;
     // which paddy rows have any inactive pixel (soilloop.py:109)
     std::vector<uint8_t> any;

@@ -139,6 +139,36 @@ class DeviceArray:
             pass
 
 
+class BufferCache:
+    """Device buffers of a module instance, kept between calls: `put(name, host)` uploads into the buffer of that name
+    (allocated once, re-allocated only when shape or dtype change), `zeros(name, shape)` hands out a scratch buffer.
+    The drop-in module classes stage their `var` arrays through the host on every call, as the reference's contract
+    requires (other modules may have changed them); the allocations themselves are not repeated."""
+
+    def __init__(self, device=0):
+        self.device, self.buf = device, {}
+
+    def get(self, name, shape, dtype=np.float64):
+        shape = tuple(np.atleast_1d(shape).tolist()) if not isinstance(shape, tuple) else shape
+        d = self.buf.get(name)
+        if d is None or d.shape != shape or d.dtype != np.dtype(dtype):
+            if d is not None:
+                d.free()
+            d = self.buf[name] = DeviceArray(shape, dtype, self.device)
+        return d
+
+    def put(self, name, host):
+        host = np.ascontiguousarray(host)
+        if host.dtype == np.bool_:
+            host = host.view(np.uint8)
+        return self.get(name, host.shape, host.dtype).upload(host)
+
+    def free(self):
+        for d in self.buf.values():
+            d.free()
+        self.buf = {}
+
+
 def synchronize(device=0):
     check(lib().lf_device_synchronize(C.c_int(device)))
 

@@ -2,13 +2,19 @@
 
 The reference calls PCRaster 4.3.3 (un-vendored C++) for these at initialisation: `lddmask`, `lddrepair`, `pit`,
 `downstream`, `upstream`, `accuflux`, `catchment`, `uniqueid` (routing.py:90-171, 387; structures.py:51-59).
-They are restated here from PCRaster's documented semantics on the engine's own graph (host side: init-time
-work, exactly as in the reference).  No reference test pins them at unit level -- PARITY UNPINNED except
-`accuflux`, which reproduces the reference's `ec_upArea.nc` where the test mask is upstream-closed, and the
-one-hop `upstream`, pinned by the np.bincount fixture.
+They are restated from PCRaster's documented semantics.  What pins them is the reference's own DATA: `accuflux`
+reproduces `ec_upArea.nc` where the test mask is upstream-closed, `catchment` reproduces the PCRaster-made catchment
+masks of the use case (`mask.map`, `subcatchment_mask.map`), the one-hop `upstream` the np.bincount fixture; the rest
+is checked against brute-force walks.
+
+Two forms of every operation:
+  * `<name>_device` -- the product path (routing.initial uses it): csrc/lf_ldd.hip through the C ABI (`lf_lddrepair_raster`,
+    `lf_lddmask_raster`, `lf_downstream`, `lf_catchments`, `lf_catchment_totals`); catchment labels by pointer jumping;
+  * `<name>` -- a host helper over the host-side graph (scenario generators, tests; needs no GPU).
 
 All functions take / return 1-D vectors over the land pixels of `land_mask` (row-major, add1.py:268-305).
 """
+import ctypes as C
 import numpy as np
 
 from .kinematic_wave_parallel import Graph
@@ -35,8 +41,8 @@ def lddmask(codes, land_mask, keep):
     keep = np.asarray(keep, bool)
     down = downstream_index(codes, land_mask)
     out = np.asarray(codes).copy()
-    lost = (down >= 0) & ~keep[np.maximum(down, 0)]
-    out[lost] = PIT
+    lost = (down < 0) | ~keep[np.maximum(down, 0)]      # drains off the map / into a missing value / out of `keep`
+    out[lost & np.isin(out, (1, 2, 3, 4, 6, 7, 8, 9))] = PIT
     sub = land_mask.copy()
     sub[land_mask] = keep
     return out[keep], sub
@@ -129,3 +135,92 @@ def upstream_raster(ldd_raster, w_raster, device=0):
     for d in (d_l, d_w, d_o):
         d.free()
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# device forms (csrc/lf_ldd.hip)
+# ---------------------------------------------------------------------------------------------------------------------
+def _codes_raster(codes, land_mask):
+    """compressed codes -> H x W uint8 raster, 0 = missing value (outside the mask or not a keypad code)"""
+    c = np.asarray(codes, np.float64)
+    ok = (c >= 1) & (c <= 9) & (c == np.floor(c))
+    r = np.zeros(np.asarray(land_mask).shape, np.uint8)
+    r[np.asarray(land_mask, bool)] = np.where(ok, c, 0).astype(np.uint8)
+    return r
+
+
+def _raster_op(ldd_raster, keep_raster, device):
+    from ._lib import check, lib, ptr
+    ldd_raster = np.ascontiguousarray(ldd_raster, np.uint8)
+    H, W = ldd_raster.shape
+    out = np.empty((H, W), np.uint8)
+    keep = None if keep_raster is None else np.ascontiguousarray(keep_raster, np.uint8)
+    check(lib().lf_ldd_raster_host(C.c_int(device), ptr(ldd_raster), ptr(keep), ptr(out), C.c_int(H), C.c_int(W)))
+    return out
+
+
+def lddrepair_device(codes, land_mask, device=0):
+    """lddrepair on the device; same contract as lddrepair (cells with an unknown code become pits too)"""
+    land_mask = np.asarray(land_mask, bool)
+    c = np.asarray(codes, np.float64)
+    r = _codes_raster(c, land_mask)
+    valid = r[land_mask] > 0
+    out = _raster_op(r, None, device)[land_mask].astype(np.float64)
+    return np.where(valid, out, PIT)
+
+
+def lddmask_device(codes, land_mask, keep, device=0):
+    """lddmask on the device -> (codes of the kept pixels, their land mask)"""
+    land_mask = np.asarray(land_mask, bool)
+    keep = np.asarray(keep, bool)
+    k2 = np.zeros(land_mask.shape, np.uint8)
+    k2[land_mask] = keep
+    out = _raster_op(_codes_raster(codes, land_mask), k2, device)
+    sub = land_mask.copy()
+    sub[land_mask] = keep
+    return out[sub].astype(np.float64), sub
+
+
+class LddDevice:
+    """The downstream / catchment operations of one LDD on the device: a router on the LDD's graph with unit parameters
+    (kinematicWave also carries upstream_sum and accuflux)."""
+
+    def __init__(self, codes, land_mask, device=0, components=None):
+        from .kinematic_wave_parallel import kinematicWave
+        self.N = int(np.asarray(land_mask, bool).sum())
+        self.kw = kinematicWave(np.asarray(codes, np.float64), land_mask, np.ones(self.N), 0.6, 1.0, 1.0, device=device,
+                                components=components)
+
+    def downstream(self, x):
+        from ._lib import check, f64, lib, ptr
+        x = f64(np.broadcast_to(x, (self.N,)))
+        out = np.empty(self.N)
+        if self.N:
+            check(lib().lf_downstream_host(self.kw._h, ptr(x), ptr(out)))
+        return out
+
+    def catchment(self, points):
+        from ._lib import check, lib, ptr
+        pts = np.ascontiguousarray(np.broadcast_to(points, (self.N,)), dtype=np.int64)
+        out = np.empty(self.N, np.int64)
+        if self.N:
+            check(lib().lf_catchments(self.kw._h, ptr(pts), ptr(out)))
+        return out
+
+    def catchment_totals(self, w):
+        """np.take(np.bincount(Catchments, weights=w), Catchments) for Catchments = catchment(ldd, pit(ldd))"""
+        from ._lib import check, f64, lib, ptr
+        w = f64(np.broadcast_to(w, (self.N,)))
+        out = np.empty(self.N)
+        if self.N:
+            check(lib().lf_catchment_totals_host(self.kw._h, ptr(w), ptr(out)))
+        return out
+
+    def upstream(self, w):
+        return self.kw.upstream_sum(w)
+
+    def accuflux(self, x):
+        return self.kw.accuflux(x)
+
+    def close(self):
+        self.kw.close()

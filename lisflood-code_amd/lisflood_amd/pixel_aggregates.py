@@ -5,7 +5,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import DeviceArray, check, f64, lib
+from ._lib import BufferCache, check, f64, lib
 
 _V_IN = ("SoilFraction TaInterception Ta ESAct PrefFlow Infiltration SeepTopToSubA SeepTopToSubB SeepSubToGW Theta1a "
          "Theta1b Theta2 W1a W1b W2 UZOutflow GwPercUZLZ SoilDepthTotal").split()
@@ -33,13 +33,16 @@ def dynamic(var, device=0):
         raise NotImplementedError("only the three prescribed fractions are supported")
     a = _PixelArgs()
     dev = {}
+    cache = getattr(v, "_lf_pixel_buffers", None)       # device buffers live as long as `var` does
+    if cache is None or cache.device != device:
+        cache = v._lf_pixel_buffers = BufferCache(device)
     for k in _V_IN:
-        dev[k] = DeviceArray.from_host(f64(_values(getattr(v, k))), device)
+        dev[k] = cache.put(k, f64(_values(getattr(v, k))))
     for k in _N_IN + _STATE:
-        dev[k] = DeviceArray.from_host(f64(np.broadcast_to(_values(getattr(v, k)), (N,))), device)
+        dev[k] = cache.put(k, f64(np.broadcast_to(_values(getattr(v, k)), (N,))))
     for k in _OUT:
-        dev[k] = DeviceArray(N, np.float64, device)
-    dev["Theta"] = DeviceArray((3, N), np.float64, device)
+        dev[k] = cache.get(k, N)
+    dev["Theta"] = cache.get("Theta", (3, N))
     for k, d in dev.items():
         setattr(a, k, d.ptr.value)
     a.InvDtDay, a.TimeSinceStart, a.N = float(v.InvDtDay), float(v.TimeSinceStart), N
@@ -54,5 +57,3 @@ def dynamic(var, device=0):
         v.Theta = th
     v.TaInterceptionWB, v.TaWB, v.ESActWB = v.TaInterceptionAll, v.TaPixel, v.ESActPixel      # soil.py:477,484,489
     v.LZOutflowToChannel, v.GwLossPixel, v.GwLossWB = v.LZOutflow, v.GwLossLZ, v.GwLossLZ       # groundwater.py:141,170,172
-    for d in dev.values():
-        d.free()

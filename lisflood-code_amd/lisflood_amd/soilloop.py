@@ -13,7 +13,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import DeviceArray, check, f64, lib, ptr, u8
+from ._lib import BufferCache, DeviceArray, check, f64, lib, ptr, u8
 
 _L_FIELDS = ("PoreSpaceNotZero1a PoreSpaceNotZero1b PoreSpaceNotZero2 KSat1a KSat1b KSat2 GenuInvM1a GenuInvM1b "
              "GenuInvM2 GenuM1a GenuM1b GenuM2 WRes1a WRes1b WRes1 WRes2 WWP1a WWP1b WWP1 WWP2 WFC1a WFC1b WFC1 WFC2 "
@@ -174,13 +174,16 @@ class soilloop(HydroModule):
     write the same `var` attributes as the reference methods; each is one device pass.
     Option-gated extras of the reference that need other modules are not produced here: `cropsEPIC` rows (the
     EPIC module is not part of the reference checkout), `SoilMoistureStressDays` (repStressDays), `WFilla/WFillb`
-    (wateruse) and `pF*` (simulatePF)."""
+    (wateruse).  `pF0..2` are produced with options={"simulatePF": True}."""
     input_files_keys = {'wateruse': []}
     module_name = 'SoilLoop'
 
-    def __init__(self, soilloop_variable, device=0):
+    def __init__(self, soilloop_variable, device=0, options=None):
+        """options: the reference's option switches this module reads (`simulatePF`)"""
         self.var = soilloop_variable
         self.device = device
+        self.options = dict(options or {})
+        self._cache = BufferCache(device)      # device buffers live as long as the module (no hipMalloc per call)
 
     def initial(self):
         v = self.var
@@ -201,15 +204,16 @@ class soilloop(HydroModule):
         v = self.var
         a = _CanopyArgs()
         dev, host = {}, {}
+        put = self._cache.put
         V, N = _values(v.Interception).shape
         for k in _CANOPY_IO:
             host[k] = self._inplace_rows(k)
-            dev[k] = DeviceArray.from_host(host[k], self.device)
+            dev[k] = put("canopy." + k, host[k])
         for k in _CANOPY_V_IN + _CANOPY_L_IN:
-            dev[k] = DeviceArray.from_host(f64(_values(getattr(v, k))), self.device)
+            dev[k] = put("canopy." + k, f64(_values(getattr(v, k))))
         for k in _CANOPY_N_IN:
             x = _values(getattr(v, k))
-            dev[k] = DeviceArray.from_host(u8(x) if k == "isFrozenSoil" else f64(np.broadcast_to(x, (N,))), self.device)
+            dev[k] = put("canopy." + k, u8(x) if k == "isFrozenSoil" else f64(np.broadcast_to(x, (N,))))
         for k, d in dev.items():
             setattr(a, k, d.ptr.value)
         idx = np.ascontiguousarray(self.index_landuse_prescr, dtype=np.int64)
@@ -219,21 +223,17 @@ class soilloop(HydroModule):
         check(lib().lf_canopy_device(C.c_int(self.device), C.byref(a)))
         for k in _CANOPY_IO:
             dev[k].download(host[k])
-        for d in dev.values():
-            d.free()
 
     def dynamic_soil(self):
         v = self.var
         N = _values(v.Interception).shape[1]
         # ESMax = ESRef * LAITerm (soilloop.py:638)
-        es = DeviceArray.from_host(f64(np.broadcast_to(_values(v.ESRef), (N,))), self.device)
-        lt = DeviceArray.from_host(f64(_values(v.LAITerm)), self.device)
+        es = self._cache.put("soil.ESRef", f64(np.broadcast_to(_values(v.ESRef), (N,))))
+        lt = self._cache.put("soil.LAITerm", f64(_values(v.LAITerm)))
         V = _values(v.LAITerm).shape[0]
-        out = DeviceArray((V, N), np.float64, self.device)
+        out = self._cache.get("soil.ESMax", (V, N))
         check(lib().lf_scale_rows_device(C.c_int(self.device), es.ptr, lt.ptr, out.ptr, C.c_int64(V), C.c_int64(N)))
         ESMax = out.download()
-        for d in (es, lt, out):
-            d.free()
         paddy_inactive = np.zeros(N, bool)[None]           # soilloop.py:644
         g = lambda k: _values(getattr(v, k))
         soilColumnsWaterBalance(
@@ -250,3 +250,39 @@ class soilloop(HydroModule):
             g("WFC1a"), g("WFC1b"), g("WFC1"), g("WFC2"), g("SoilDepth1a"), g("SoilDepth1b"), g("SoilDepth2"),
             g("WS1a"), g("WS1b"), g("WS1"), g("WS2"), g("UpperZoneK"), v.DrainedFraction, g("GwPercStep"),
             g("UZOutflow"), g("UZ"), g("GwPercUZLZ"), device=self.device)
+        if self.options.get("simulatePF"):
+            self.soil_pf()
+
+    _PF_V = "W1a W1b W2".split()
+    _PF_L = ("WRes1a WRes1b WRes2 WS1a WS1b WS2 PoreSpaceNotZero1a PoreSpaceNotZero1b PoreSpaceNotZero2 GenuInvAlpha1a "
+             "GenuInvAlpha1b GenuInvAlpha2 GenuInvM1a GenuInvM1b GenuInvM2 GenuInvN1a GenuInvN1b GenuInvN2").split()
+
+    def soil_pf(self):
+        """suctionUnsaturatedSoilPF (soilloop.py:673-704, option simulatePF): var.pF0 / pF1 / pF2 from the soil moisture"""
+        v = self.var
+        a = _SoilPfArgs()
+        V, N = _values(v.W1a).shape
+        outs = {}
+        for k in ("pF0", "pF1", "pF2"):
+            cur = getattr(v, k, None)
+            if cur is None:
+                cur = np.zeros((V, N))
+                setattr(v, k, cur)
+            outs[k] = _inplace(_values(cur), k)
+            setattr(a, k, self._cache.get("pf." + k, (V, N)).ptr.value)
+        for k in self._PF_V + self._PF_L:
+            x = _values(getattr(v, k))
+            setattr(a, k, self._cache.put("pf." + k, u8(x) if k.startswith("Pore") else f64(x)).ptr.value)
+        idx = np.ascontiguousarray(self.index_landuse_all, dtype=np.int64)
+        a.index_landuse_all = idx.ctypes.data
+        a.HeadMax = float(v.HeadMax)
+        a.V, a.L, a.N = V, _values(v.WS1a).shape[0], N
+        check(lib().lf_soil_pf_device(C.c_int(self.device), C.byref(a)))
+        for k in outs:
+            self._cache.buf["pf." + k].download(outs[k])
+
+
+class _SoilPfArgs(C.Structure):  # lf_soil_pf_args
+    _fields_ = ([(k, C.c_void_p) for k in ["pF0", "pF1", "pF2"] + soilloop._PF_V + soilloop._PF_L] +
+                [("index_landuse_all", C.c_void_p), ("HeadMax", C.c_double), ("V", C.c_int64), ("L", C.c_int64),
+                 ("N", C.c_int64)])

@@ -9,7 +9,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import DeviceArray, check, f64, lib, u8
+from ._lib import BufferCache, DeviceArray, check, f64, lib, u8
 from .hydro_module import HydroModule
 from .kinematic_wave_parallel import Graph, kinematicWave
 
@@ -84,19 +84,22 @@ class surface_routing(HydroModule):
         N = self.direct_surface_router.num_pixels
         a = _SurfaceArgs()
         dev = {}
+        if getattr(self, "_cache", None) is None:        # device buffers live as long as the module
+            self._cache = BufferCache(self.device)
+        put, get = self._cache.put, self._cache.get
         for k in _V_IN:
-            dev[k] = DeviceArray.from_host(f64(_values(getattr(v, k))), self.device)
+            dev[k] = put(k, f64(_values(getattr(v, k))))
         for k in _N_IN:
             x = _values(getattr(v, k))
-            dev[k] = DeviceArray.from_host(u8(x) if k == "IsChannel" else f64(np.broadcast_to(x, (N,))), self.device)
+            dev[k] = put(k, u8(x) if k == "IsChannel" else f64(np.broadcast_to(x, (N,))))
         host_state = {}
         for k in _STATE:
             host_state[k] = np.ascontiguousarray(getattr(v, k), dtype=np.float64)
-            dev[k] = DeviceArray.from_host(host_state[k], self.device)
+            dev[k] = put(k, host_state[k])
         for k in _OUT:
-            dev[k] = DeviceArray(N, np.float64, self.device)
-        dev["SurfaceRunSoil"] = DeviceArray((3, N), np.float64, self.device)
-        dev["scratch"] = DeviceArray((3, N), np.float64, self.device)
+            dev[k] = get(k, N)
+        dev["SurfaceRunSoil"] = get("SurfaceRunSoil", (3, N))
+        dev["scratch"] = get("scratch", (3, N))
         for k, d in dev.items():
             setattr(a, k, d.ptr.value)
         a.Beta = float(v.Beta)
@@ -123,5 +126,3 @@ class surface_routing(HydroModule):
             v.SurfaceRunSoil = srs
         v.Qall = v.OFQDirect + v.OFQOther + v.OFQForest                 # surface_routing.py:195-196
         v.M3all = v.OFM3Direct + v.OFM3Other + v.OFM3Forest
-        for d in dev.values():
-            d.free()

@@ -954,3 +954,33 @@ void lfo_canopy(double *Interception, double *TaInterception, double *LeafDraina
         }
     }
 }
+
+
+/* ------------------------------------------------------------------------------------------------
+ * suctionUnsaturatedSoilPF + pressureHead (soilloop.py:427-432, 673-695): pF of the three soil layers.
+ * ---------------------------------------------------------------------------------------------- */
+static double lfo_pf_layer(double w, int pore, double wres, double ws, double inv_alpha, double inv_m, double inv_n,
+                           double head_max)
+{
+    double sat = 0.;
+    if (pore) sat = dmax(dmin((w - wres) / (ws - wres), 1.), 0.);      /* saturationDegree, :378-383 */
+    double head = head_max;
+    if (sat != 0) head = dmin(head_max, inv_alpha * pow(pow(1. / sat, inv_m) - 1., inv_n));   /* :427-432 */
+    return head > 0 ? log10(head) : -1.;                                /* :691-695 */
+}
+
+void lfo_soil_pf(double *pF0, double *pF1, double *pF2, const double *W1a, const double *W1b, const double *W2,
+                 const double *WRes1a, const double *WRes1b, const double *WRes2, const double *WS1a, const double *WS1b,
+                 const double *WS2, const uint8_t *P1a, const uint8_t *P1b, const uint8_t *P2, const double *IA1a,
+                 const double *IA1b, const double *IA2, const double *IM1a, const double *IM1b, const double *IM2,
+                 const double *IN1a, const double *IN1b, const double *IN2, const int64_t *landuse, double HeadMax, int64_t V,
+                 int64_t N)
+{
+    for (int64_t veg = 0; veg < V; ++veg)
+        for (int64_t pix = 0; pix < N; ++pix) {
+            const int64_t i = veg * N + pix, j = landuse[veg] * N + pix;
+            pF0[i] = lfo_pf_layer(W1a[i], P1a[j], WRes1a[j], WS1a[j], IA1a[j], IM1a[j], IN1a[j], HeadMax);
+            pF1[i] = lfo_pf_layer(W1b[i], P1b[j], WRes1b[j], WS1b[j], IA1b[j], IM1b[j], IN1b[j], HeadMax);
+            pF2[i] = lfo_pf_layer(W2[i], P2[j], WRes2[j], WS2[j], IA2[j], IM2[j], IN2[j], HeadMax);
+        }
+}

@@ -413,3 +413,18 @@ def sweep_positions(state, constant, ups_ptr, ups_idx, a, ba, beta, begin, end):
     lib().lfo_sweep_positions(_ptr(state), _ptr(_f(constant)), _ptr(np.ascontiguousarray(ups_ptr, dtype=np.int32)),
                               _ptr(np.ascontiguousarray(ups_idx, dtype=np.int32)), _ptr(_f(a)), _ptr(_f(ba)),
                               C.c_double(beta), C.c_int64(begin), C.c_int64(end))
+
+
+PF_L = ("WRes1a WRes1b WRes2 WS1a WS1b WS2 PoreSpaceNotZero1a PoreSpaceNotZero1b PoreSpaceNotZero2 GenuInvAlpha1a "
+        "GenuInvAlpha1b GenuInvAlpha2 GenuInvM1a GenuInvM1b GenuInvM2 GenuInvN1a GenuInvN1b GenuInvN2").split()
+
+
+def soil_pf(d, index_landuse, HeadMax):
+    """suctionUnsaturatedSoilPF (soilloop.py:673-695): d holds W1a, W1b, W2 [V,N] and the [L,N] arrays of PF_L -> pF0, pF1, pF2"""
+    V, N = np.asarray(d["W1a"]).shape
+    out = [np.empty((V, N)) for _ in range(3)]
+    args = [_f(d[k]) for k in ("W1a", "W1b", "W2")] + [(_u8(d[k]) if k.startswith("Pore") else _f(d[k])) for k in PF_L]
+    idx = np.ascontiguousarray(index_landuse, dtype=np.int64)
+    lib().lfo_soil_pf(*[_ptr(a) for a in out], *[_ptr(a) for a in args], _ptr(idx), C.c_double(HeadMax), C.c_int64(V),
+                      C.c_int64(N))
+    return out

@@ -18,7 +18,11 @@ FILES = {
     "pixarea": "pixarea.nc", "pixleng": "pixleng.nc", "gradient": "gradient.nc",
     "lakes": "ec_lakes.nc", "res": "ec_res.nc", "outlets": "ec_outlets.nc", "uparea": "ec_upArea.nc",
     "calchanman1": "parameters/params_CalChanMan1.nc", "calchanman2": "parameters/params_CalChanMan2.nc",
+    "lakemultiplier": "parameters/params_LakeMultiplier.nc", "adjust_normal_flood": "parameters/params_adjust_Normal_Flood.nc",
+    "reservoirrnormqmult": "parameters/params_ReservoirRnormqMult.nc", "avgdis": "safe_init/avgdis.nc",
 }
+# look-up tables of lakes.initial / reservoir.initial (lakes.py:96-131, reservoir.py:84-118): two columns, id value
+TABLES = ("lakearea", "lakea", "lakeavinflow", "rtstor", "rclim", "rnlim", "rflim", "rndq", "rnormq", "rminq")
 
 def main_var(f):
     best = None
@@ -41,6 +45,38 @@ for key, fn in FILES.items():
         out[key] = arr
         if fill is not None:
             out[key + "_fill"] = np.asarray(fill).reshape(-1)[:1]
+for t in TABLES:
+    rows = [ln.split() for ln in open(os.path.join(SRC, "tables", t + ".txt")) if ln.strip()]
+    out["table_" + t] = np.array([[float(a), float(b)] for a, b in rows])
+    print("table", t, out["table_" + t].shape)
+
+# ---- PCRaster .map catchment masks of the use case (CSF 2 files: 256-byte header, then the cells; UINT1 boolean maps
+# with 255 = missing value): mask.map is the model domain of cold.xml, subcatchment_mask.map / intercatchment_mask.map
+# the sub-domains of the reference's tests/test_subcatchments.py.  Each is a PCRaster-made catchment of the LDD: the only
+# PCRaster `catchment` outputs in the checkout, placed here on the 57 x 80 grid of the netCDF maps by their origin.
+import struct
+
+
+def read_csf_mask(path):
+    b = open(path, "rb").read()
+    assert b[:27] == b"RUU CROSS SYSTEM MAP FORMAT"
+    cell_repr, = struct.unpack_from("<H", b, 66)
+    xul, yul = struct.unpack_from("<dd", b, 84)
+    nr, nc = struct.unpack_from("<II", b, 100)
+    cs, = struct.unpack_from("<d", b, 108)
+    assert cell_repr == 0                                   # CR_UINT1
+    a = np.frombuffer(b, np.uint8, nr * nc, 256).reshape(nr, nc)
+    return a == 1, int(round((2615000.0 - yul) / cs)), int(round((xul - 4050000.0) / cs))
+
+
+shape = out["ldd"].shape
+for key, fn in (("mask_map", "mask.map"), ("subcatchment_mask", "subcatchment_mask.map"),
+                ("intercatchment_mask", "intercatchment_mask.map")):
+    m, r0, c0 = read_csf_mask(os.path.join(SRC, fn))
+    full = np.zeros(shape, bool)
+    full[r0:r0 + m.shape[0], c0:c0 + m.shape[1]] = m
+    out[key] = full
+    print(key, fn, m.shape, "origin row/col", r0, c0, "cells", int(full.sum()))
 np.savez_compressed(OUT, **out)
 print("wrote", OUT, os.path.getsize(OUT))
 

@@ -921,11 +921,273 @@ def gen_chain():
     opts.clear()
 
 
+def gen_soil_pf():
+    """soilloop.dynamic_soil with option simulatePF (soilloop.py:630-704): the pF values of the three layers after one
+    soil step, computed by the reference's own (un-jitted) suctionUnsaturatedSoilPF / pressureHead."""
+    soil = REF["soilloop"]
+    N = 400
+    rng = np.random.default_rng(81)
+    p = syn.soil_params(N, seed=82)
+    v = model_var(N)
+    REF["MaskInfo"].n = N
+    opts = REF["LisSettings"].options
+    opts.clear()
+    opts.update(simulatePF=True)
+    REF["LisSettings"].soil_uses = SOIL_USES[:]
+    REF["LisSettings"].vegetation_landuse = dict(zip(PRESCRIBED, SOIL_USES))
+    vn, ln = ["vegetation", "pixel"], ["landuse", "pixel"]
+    L_KEYS = [k for k in syn.SOIL_ARG_ORDER if np.ndim(p[k]) == 2 and k not in syn.SOIL_WRITTEN and
+              k not in ("LeafDrainage", "Interception", "ESMax", "paddy_inactive")]
+    p["W1a"][:, :40] = p["WRes1a"][p["index_landuse_all"]][:, :40]          # SatTerm == 0 -> HeadMax
+    p["W2"][:, 40:80] = p["WS2"][p["index_landuse_all"]][:, 40:80] * 1.01    # saturated: head 0 -> pF = -1
+    for k in L_KEYS:
+        setattr(v, k, VA(p[k].copy(), ln))
+    for k in syn.SOIL_WRITTEN + ["LeafDrainage", "Interception"]:
+        setattr(v, k, VA(p[k].copy(), vn))
+    for k in ("Rain", "SnowMelt", "isFrozenSoil", "b_Xinanjiang", "PowerInfPot", "PowerPrefFlow", "UpperZoneK", "GwPercStep"):
+        setattr(v, k, p[k].copy())
+    for k in ("DtDay", "AvWaterThreshold", "CourantCrit", "DrainedFraction"):
+        setattr(v, k, p[k])
+    v.isFrozenSoil[:] = True                      # no seepage, no infiltration: W1a / W2 keep the special values above
+    v.Rain[:] = 0.0; v.SnowMelt[:] = 0.0
+    v.LeafDrainage[:] = 0.0
+    v.ESRef = np.zeros(N)
+    v.LAITerm = VA(np.ones((3, N)), vn)
+    lam = {k: rng.uniform(0.1, 0.4, (3, N)) for k in ("1a", "1b", "2")}
+    for k in ("1a", "1b", "2"):
+        setattr(v, "GenuInvN" + k, VA(1 / (1 + lam[k]), ln))               # soil.py:186-206
+        setattr(v, "GenuInvAlpha" + k, VA(1 / rng.uniform(0.005, 0.05, (3, N)), ln))
+    v.HeadMax = 1.0e7
+    for k in ("pF0", "pF1", "pF2"):
+        setattr(v, k, VA(np.zeros((3, N)), vn))
+    m = soil.soilloop(v)
+    m.initial()
+    with np.errstate(all="ignore"):
+        m.dynamic_soil()
+    keys = ("W1a W1b W2 WRes1a WRes1b WRes2 WS1a WS1b WS2 PoreSpaceNotZero1a PoreSpaceNotZero1b PoreSpaceNotZero2 "
+            "GenuInvAlpha1a GenuInvAlpha1b GenuInvAlpha2 GenuInvM1a GenuInvM1b GenuInvM2 GenuInvN1a GenuInvN1b GenuInvN2 "
+            "pF0 pF1 pF2").split()
+    out = {k: np.array(getattr(v, k)) for k in keys}
+    assert (out["pF0"][:, :40] == 7.0).all() and (out["pF2"][:, 40:80] == -1.0).all()
+    save("soil_pf", HeadMax=v.HeadMax, **out)
+    opts.clear()
+
+
+# ------------------------------------------------------------------------------------------------
+# initialisation of the channel part on the REAL inputs of cold.xml: routing.initial -> lakes.initial ->
+# reservoir.initial -> structures.initial -> routing.initialSecond (Lisflood_initial.py:184-226 order), every one the
+# reference's own method.  PCRaster is not installed: its operations are emulated on compressed vectors (class PcrEmu
+# below -- lddmask / lddrepair / downstream / catchment / accuflux through the host graph helpers of lisflood_amd.ldd,
+# lookupscalar by reading the use case's tables); what this fixture pins is therefore everything BUT those LDD
+# operations: the order of the steps, -9999 cold-start handling, channel geometry and alpha, the split-routing start
+# values, lake / reservoir parameter derivation, the cut LDD, the mass-balance start values.
+# ------------------------------------------------------------------------------------------------
+class PcrEmu:
+    """PCRaster operations on compressed vectors over a fixed land mask (missing value: 0 for ldd / nominal / boolean maps,
+    NaN for scalar maps)."""
+
+    def __init__(self, mask, maps, tables):
+        from lisflood_amd import ldd as L
+        self.L, self.mask, self.N = L, mask, int(mask.sum())
+        self.maps, self.tables = maps, tables
+
+    def loadmap(self, name, pcr=False, lddflag=False, **kw):
+        v = self.maps[name]
+        return v.copy() if isinstance(v, np.ndarray) else v
+
+    def lddmask(self, ldd, keep):
+        keep = np.asarray(keep).astype(bool)
+        codes, _ = self.L.lddmask(np.asarray(ldd, float), self.mask, keep)
+        out = np.zeros(self.N)
+        out[keep] = codes
+        return out
+
+    def lddrepair(self, ldd):
+        ldd = np.asarray(ldd, float)
+        defined = (ldd >= 1) & (ldd <= 9)
+        sub = np.zeros(self.mask.shape, bool); sub[self.mask] = defined
+        out = np.zeros(self.N)
+        out[defined] = self.L.lddrepair(ldd[defined], sub)
+        return out
+
+    def _down(self, ldd):
+        ldd = np.asarray(ldd, float)
+        defined = (ldd >= 1) & (ldd <= 9)
+        sub = np.zeros(self.mask.shape, bool); sub[self.mask] = defined
+        d = self.L.downstream_index(ldd[defined], sub)
+        ids = np.nonzero(defined)[0]
+        down = np.full(self.N, -1, np.int64)
+        down[defined] = np.where(d >= 0, ids[np.maximum(d, 0)], -1)
+        return down, defined
+
+    def downstream(self, ldd, x):
+        down, _ = self._down(ldd)
+        x = np.asarray(x)
+        return np.where(down >= 0, x[np.maximum(down, 0)], x)
+
+    def upstream(self, ldd, x):
+        down, _ = self._down(ldd)
+        return np.bincount(np.where(down >= 0, down, self.N), weights=np.asarray(x, float), minlength=self.N + 1)[:self.N]
+
+    def accuflux(self, ldd, x):
+        down, defined = self._down(ldd)
+        acc = np.array(np.broadcast_to(np.asarray(x, float), (self.N,)))
+        order = self._topo(down)
+        for p in order:
+            if down[p] >= 0:
+                acc[down[p]] += acc[p]
+        return acc
+
+    def _topo(self, down):
+        nups = np.bincount(down[down >= 0], minlength=self.N)
+        stack = list(np.nonzero(nups == 0)[0])
+        out = []
+        while stack:
+            p = stack.pop()
+            out.append(p)
+            d = down[p]
+            if d >= 0:
+                nups[d] -= 1
+                if nups[d] == 0:
+                    stack.append(d)
+        return out
+
+    def catchment(self, ldd, points):
+        down, defined = self._down(ldd)
+        pts = np.asarray(points).astype(np.int64)
+        lab = np.zeros(self.N, np.int64)
+        for p in reversed(self._topo(down)):          # outlets first
+            lab[p] = pts[p] if pts[p] != 0 else (lab[down[p]] if down[p] >= 0 else 0)
+        return lab
+
+    def pit(self, ldd):
+        return self.L.pit(np.asarray(ldd))
+
+    def uniqueid(self, b):
+        return self.L.uniqueid(np.asarray(b).astype(bool))
+
+    def lookupscalar(self, table, ids):
+        t = self.tables[os.path.splitext(os.path.basename(str(table)))[0]]
+        ids = np.asarray(ids)
+        out = np.full(ids.shape, np.nan)
+        for key, val in t:
+            out[ids == key] = val
+        return out
+
+    # element-wise
+    boolean = staticmethod(lambda x: np.asarray(x) != 0)
+    scalar = staticmethod(lambda x: np.asarray(x, float))
+    nominal = staticmethod(lambda x: np.asarray(x))
+    defined = staticmethod(lambda x: np.asarray(x) != 0)
+    cover = staticmethod(lambda x, v: np.where(np.asarray(x) != 0, x, v))
+    ifthen = staticmethod(lambda c, x: np.where(c, x, 0))
+    ifthenelse = staticmethod(lambda c, a, b: np.where(c, a, b))
+    compressArray = staticmethod(lambda x: np.asarray(x))
+    decompress = staticmethod(lambda x: np.asarray(x))
+
+    def makenumpy(self, x):
+        return x if isinstance(x, np.ndarray) else np.full(self.N, float(x))
+
+    def install(self, *modules):
+        names = ("loadmap lddmask lddrepair downstream upstream accuflux catchment pit uniqueid lookupscalar boolean scalar "
+                 "nominal defined cover ifthen ifthenelse compressArray decompress makenumpy").split()
+        pcr = sys.modules["pcraster"]
+        for n in names:
+            setattr(pcr, n, getattr(self, n))
+        for m in modules:
+            for n in names:
+                if n in vars(m):
+                    setattr(m, n, getattr(self, n))
+            if "loadmap_base" in vars(m):
+                m.loadmap_base = self.loadmap
+
+
+INITIAL_OUT = ("Ldd UpArea IsChannel LddKinematic LddToChan AtLastPointC downstruct Catchments InvCatchArea ChanGrad ChanMan "
+               "ChanBottomWidth ChanUpperWidth TotalCrossSectionAreaBankFull TotalCrossSectionArea CrossSection2Area "
+               "Sideflow1Chan ChanWettedPerimeterAlpha ChannelAlpha InvChannelAlpha ChanM3 ChanM3Kin ChanQKin ChanQ "
+               "ChannelAlpha2 InvChannelAlpha2 QLimit M3Limit Chan2M3Start Chan2QStart Chan2M3Kin Chan2QKin StorageStepINIT "
+               "DischargeM3StructuresIni IsStructureKinematic IsUpsOfStructureKinematicC LddStructuresKinematic "
+               "LakeIndex LakeSitesCC LakeAreaCC LakeACC LakeAvNetCC LakeLevelCC LakeInflowOldCC LakeFactor LakeFactorSqr "
+               "LakeOutflowCC LakeStorageM3CC LakeStorageM3BalanceCC LakeStorageIniM3 LakeStorageM3 IsUpsOfStructureLake "
+               "ReservoirIndex ReservoirSitesCC TotalReservoirStorageM3CC ConservativeStorageLimitCC NormalStorageLimitCC "
+               "FloodStorageLimitCC NonDamagingReservoirOutflowCC NormalReservoirOutflowCC MinReservoirOutflowCC "
+               "Normal_FloodStorageLimitCC DeltaO DeltaLN DeltaLF DeltaNFL ReservoirFillCC ReservoirStorageM3CC "
+               "ReservoirStorageIniM3 ReservoirStorageM3").split()
+
+
+def initial_inputs():
+    """maps (binding name -> compressed vector / scalar) and tables of cold.xml's channel initialisation on the model
+    domain mask.map (2 847 pixels); values from the settings file (settings/cold.xml) where they are scalars there"""
+    z = np.load(os.path.join(HERE, "etrs89_static.npz"))
+    mask = z["mask_map"]
+    f = lambda k: z[k][mask].astype(np.float64)
+    ldd = z["ldd"][mask].astype(np.float64)
+    maps = dict(beta=0.6, ChanLength=f("chanlength"), Ldd=ldd, Channels=(z["chan"][mask] == 1).astype(np.float64),
+                ChanGrad=f("changrad"), ChanGradMin=0.0001, CalChanMan=f("calchanman1"), ChanMan=f("chanman"),
+                ChanBottomWidth=f("chanbw"), ChanDepthThreshold=f("chanbnkf"), ChanSdXdY=f("chans"),
+                TotalCrossSectionAreaInitValue=-9999.0, PrevDischarge=-9999.0, CrossSection2AreaInitValue=-9999.0,
+                PrevSideflowInitValue=-9999.0, CalChanMan2=f("calchanman2"), AvgDis=f("avgdis"), QSplitMult=2.0,
+                LakeSites=f("lakes"), LakeMultiplier=f("lakemultiplier"), LakeInitialLevelValue=-9999.0,
+                LakePrevInflowValue=-9999.0, LakePrevOutflowValue=-9999.0, ReservoirSites=f("res"),
+                adjust_Normal_Flood=f("adjust_normal_flood"), ReservoirRnormqMult=f("reservoirrnormqmult"),
+                ReservoirInitialFillValue=-9999.0, PixelArea=f("pixarea"))
+    tables = {k[6:]: z[k] for k in z.files if k.startswith("table_")}
+    scal = dict(DtSec=86400.0, DtSecChannel=3600.0)
+    return mask, maps, tables, scal
+
+
+def gen_initial():
+    mask, maps, tables, scal = initial_inputs()
+    N = int(mask.sum())
+    import importlib
+    st_mod = importlib.import_module("lisflood.hydrological_modules.structures")
+    rout, lakes, res = REF["routing"], REF["lakes"], REF["reservoir"]
+    emu = PcrEmu(mask, maps, tables)
+    emu.install(rout, lakes, res, st_mod)
+    S = REF["LisSettings"]
+    S.options.clear()
+    S.options.update(InitLisflood=False, SplitRouting=True, simulateLakes=True, simulateReservoirs=True, repMBTs=True)
+    S.flags = {"nancheck": False}
+    S.binding = dict(TabLakeArea="lakearea.txt", TabLakeA="lakea.txt", TabLakeAvNetInflowEstimate="lakeavinflow.txt",
+                     TabTotStorage="rtstor.txt", TabConservativeStorageLimit="rclim.txt", TabNormalStorageLimit="rnlim.txt",
+                     TabFloodStorageLimit="rflim.txt", TabNonDamagingOutflowQ="rndq.txt", TabNormalOutflowQ="rnormq.txt",
+                     TabMinOutflowQ="rminq.txt")
+    M = REF["MaskInfo"]
+    M.n = N
+    M.info = types.SimpleNamespace(mask=~mask, mapC=(N,))
+    v = types.SimpleNamespace(DtSec=scal["DtSec"], DtSecChannel=scal["DtSecChannel"], MaskMap=np.ones(N, bool),
+                              PixelAreaPcr=maps["PixelArea"], PixelArea=maps["PixelArea"])
+    m_rout = rout.routing(v)
+    with np.errstate(all="ignore"):
+        m_rout.initial()                                         # Lisflood_initial.py:184
+        lakes.lakes(v).initial()                                 # :208
+        res.reservoir(v).initial()                               # :210
+        st_mod.structures(v).initial()                           # :216
+        m_rout.initialSecond()                                   # :218
+        # waterbalance.initial (waterbalance.py:91-109; repMBTs reads its DischargeM3StructuresIni in routing.dynamic)
+        DisStructure = np.where(v.IsUpsOfStructureKinematicC, v.ChanQ * v.DtRouting, 0)
+        DisStructure += np.where(v.IsUpsOfStructureLake, 0.5 * v.ChanQ * v.DtRouting, 0)
+        v.DischargeM3StructuresIni = np.take(np.bincount(v.Catchments, weights=DisStructure), v.Catchments)
+    out = {}
+    for k in INITIAL_OUT:
+        a = getattr(v, k)
+        out["out_" + k] = np.asarray(a[0] if isinstance(a, tuple) else a, dtype=None if np.asarray(a).dtype != object else float)
+    for k in ("Beta", "NoRoutSteps", "DtRouting", "AlpPow"):
+        out["out_" + k] = np.float64(getattr(v, k))
+    kw = m_rout.river_router
+    assert kw.order_start_stop.shape[0] > 10 and np.isfinite(v.ChanQKin).all()
+    save("etrs89_initial", mask=mask, DtSec=scal["DtSec"], DtSecChannel=scal["DtSecChannel"],
+         **{"map_" + k: np.asarray(a) for k, a in maps.items()}, **{"table_" + k: a for k, a in tables.items()},
+         router_pixels_ordered=kw.pixels_ordered, router_order_start_stop=kw.order_start_stop, **out)
+    print("  N=%d lakes=%d reservoirs=%d NL(cut)=%d" % (N, v.LakeIndex.size, v.ReservoirIndex.size, kw.order_start_stop.shape[0]))
+    S.options.clear()
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["graphs", "routes", "edge", "substeps", "upsum", "interception", "soil", "surface",
-                             "canopy", "inloop", "pixel", "chain"]
+                             "canopy", "inloop", "pixel", "chain", "pf", "initial"]
     fns = dict(graphs=gen_graphs, routes=gen_routes, edge=gen_route_edge, substeps=gen_substeps,
                upsum=gen_upstream_sum, interception=gen_interception, soil=gen_soil_columns,
-               surface=gen_surface_step, canopy=gen_canopy_soil_step, inloop=gen_inloop, pixel=gen_pixel_aggregates, chain=gen_chain)
+               surface=gen_surface_step, canopy=gen_canopy_soil_step, inloop=gen_inloop, pixel=gen_pixel_aggregates, chain=gen_chain, pf=gen_soil_pf, initial=gen_initial)
     for w in which:
         fns[w]()

@@ -1242,3 +1242,20 @@ def test_empty_inputs(amd):
     Q = np.zeros(0)
     kw.kinematicWaveRouting(Q, np.zeros(0))
     assert kw.upstream_sum(np.zeros(0)).size == 0
+
+
+def test_soil_pf_golden(amd):
+    """soilloop.soil_pf (lf_soil_pf_device) against the pF values the reference's own dynamic_soil produced"""
+    from lisflood_amd.soilloop import soilloop
+    g = golden("soil_pf")
+    N = g["W1a"].shape[1]
+    v = _model_var(N)
+    for k in g.files:
+        if k not in ("pF0", "pF1", "pF2", "HeadMax"):
+            setattr(v, k, g[k].copy())
+    v.HeadMax = float(g["HeadMax"])
+    m = soilloop(v, options={"simulatePF": True}); m.initial()
+    m.soil_pf()
+    for k in ("pF0", "pF1", "pF2"):
+        np.testing.assert_allclose(getattr(v, k), g[k], rtol=1e-12, atol=1e-13, err_msg=k)
+    assert (v.pF0 == 7.0).any() and (v.pF2 == -1.0).any()

@@ -81,3 +81,19 @@ def test_cut_at_structures_matches_the_reference_driven_fixture():
     off_mask = (L.downstream_index(want, mask) < 0)            # lddrepair also pits cells leaving the mask
     assert np.array_equal(cut[~off_mask], want[~off_mask]) and (cut[off_mask] == L.PIT).all()
     assert ups.sum() > 0 and (cut[ups] == L.PIT).all()
+
+
+def test_host_catchment_reproduces_the_pcraster_masks_of_the_use_case():
+    """mask.map and subcatchment_mask.map of LF_ETRS89 are PCRaster-made catchments of ec_ldd: the only `catchment`
+    outputs of PCRaster in the reference's checkout.  catchment(ldd, the mask's outlet) must give exactly the mask."""
+    from conftest import golden
+    z = golden("etrs89_static")
+    land = z["ldd"] != -1
+    codes = z["ldd"][land].astype(float)
+    down = L.downstream_index(codes, land)
+    for key in ("mask_map", "subcatchment_mask"):
+        m = z[key][land]
+        outlet = np.nonzero(m & ~((down >= 0) & m[np.maximum(down, 0)]))[0]
+        assert outlet.size == 1
+        pts = np.zeros(codes.size, np.int64); pts[outlet[0]] = 1
+        assert np.array_equal(L.catchment(codes, land, pts) == 1, m), key

@@ -1,0 +1,161 @@
+"""LDD operations on the device (csrc/lf_ldd.hip through the C ABI) against brute-force walks, against the host
+helpers, and against the reference's own PCRaster-made maps of LF_ETRS89: ec_upArea.nc (accuflux) and the catchment
+masks mask.map / subcatchment_mask.map (catchment)."""
+import numpy as np
+import pytest
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import lisflood_amd
+    from lisflood_amd import _lib
+    if _lib.device_count() < 1:
+        pytest.fail("no HIP device visible: the -m gpu tests need an MI355X")
+    return lisflood_amd
+
+
+def walk_down(down, p):
+    while down[p] >= 0:
+        p = down[p]
+    return p
+
+
+def case(H=61, W=47):
+    from lisflood_amd import synthetic as syn
+    mask = np.ones((H, W), bool); mask[:4, :6] = False; mask[22, 10:14] = False
+    codes = syn.make_ldd("deep", H, W, 21, land_mask=mask)[mask].astype(np.float64)
+    return codes, mask
+
+
+@pytest.mark.parametrize("components", [None, (32, 64)])
+def test_downstream_catchment_totals_vs_walks(amd, components):
+    from lisflood_amd import ldd as L
+    codes, mask = case()
+    N = codes.size
+    down = L.downstream_index(codes, mask)
+    d = L.LddDevice(codes, mask, components=components)
+    x = np.random.default_rng(3).uniform(0, 9, N)
+    assert np.array_equal(d.downstream(x), np.where(down >= 0, x[np.maximum(down, 0)], x))
+    assert np.array_equal(d.downstream(x), L.downstream(codes, mask, x))
+    outlets = L.uniqueid(down < 0)
+    lab = d.catchment(outlets)
+    root = np.array([walk_down(down, p) for p in range(N)])
+    assert np.array_equal(lab, outlets[root]) and (lab > 0).all()
+    pts = np.zeros(N, np.int64); pts[[50, 300, 400, 1700]] = [7, 8, 9, 7]          # interior points stop the walk
+    lab2 = d.catchment(pts)
+    assert np.array_equal(lab2, L.catchment(codes, mask, pts))
+    for p in range(0, N, 11):
+        q, hit = p, 0
+        while True:
+            if pts[q]:
+                hit = pts[q]; break
+            if down[q] < 0:
+                break
+            q = down[q]
+        assert lab2[p] == hit
+    w = np.random.default_rng(4).uniform(0, 5, N)
+    tot = d.catchment_totals(w)
+    want = np.bincount(root, weights=w, minlength=N)[root]                          # routing.py:483-499
+    np.testing.assert_allclose(tot, want, rtol=1e-13)
+    d.close()
+
+
+def test_lddrepair_and_lddmask_device_equal_the_host_helpers(amd):
+    from lisflood_amd import ldd as L
+    codes, mask = case()
+    N = codes.size
+    bad = codes.copy(); bad[3] = 0; bad[5] = 77; bad[9] = 2.5
+    assert np.array_equal(L.lddrepair_device(bad, mask), L.lddrepair(bad, mask))
+    keep = np.random.default_rng(5).random(N) < 0.6
+    a, am = L.lddmask_device(codes, mask, keep)
+    b, bm = L.lddmask(codes, mask, keep)
+    assert np.array_equal(a, b) and np.array_equal(am, bm)
+    # the channel / overland LDDs of routing.initial (routing.py:118, 125)
+    assert np.array_equal(L.lddrepair_device(np.where(keep, L.PIT, codes), mask), L.lddrepair(np.where(keep, L.PIT, codes), mask))
+
+
+def test_catchment_reproduces_the_pcraster_masks_of_the_use_case(amd):
+    """mask.map (the model domain of cold.xml) and subcatchment_mask.map (tests/test_subcatchments.py) are PCRaster
+    catchments of LF_ETRS89's LDD: catchment(ldd, outlet of the mask) must give exactly the mask."""
+    from lisflood_amd import ldd as L
+    z = golden("etrs89_static")
+    ldd = z["ldd"]
+    land = ldd != -1
+    codes = ldd[land].astype(np.float64)
+    down = L.downstream_index(codes, land)
+    d = L.LddDevice(codes, land)
+    for key, cells in (("mask_map", 2847), ("subcatchment_mask", 1023)):
+        m = z[key][land]
+        assert m.sum() == cells
+        inside_down = (down >= 0) & m[np.maximum(down, 0)]
+        outlet = np.nonzero(m & ~inside_down)[0]
+        assert outlet.size == 1                                   # one outlet: the mask is one catchment
+        pts = np.zeros(codes.size, np.int64); pts[outlet[0]] = 1
+        assert np.array_equal(d.catchment(pts) == 1, m), key
+    # accuflux against ec_upArea.nc on the upstream-closed model domain
+    m = z["mask_map"][land]
+    up = d.accuflux(z["pixarea"][land].astype(np.float64))
+    np.testing.assert_allclose(up[m], z["uparea"][land][m].astype(np.float64), rtol=1e-6)
+    d.close()
+
+
+def test_catchments_large_deep_raster(amd):
+    """pointer jumping on a 10^3-level network: every cell's label is its outlet's"""
+    from lisflood_amd import ldd as L
+    from lisflood_amd import synthetic as syn
+    H, W = 1500, 400
+    codes = syn.make_ldd("deep", H, W, 8).reshape(-1).astype(np.float64)
+    mask = np.ones((H, W), bool)
+    down = L.downstream_index(codes, mask)
+    d = L.LddDevice(codes, mask)
+    lab = d.catchment(L.uniqueid(down < 0))
+    assert (lab > 0).all()
+    ok = down >= 0
+    assert np.array_equal(lab[ok], lab[down[ok]])                  # a label never changes along a flow path
+    assert np.array_equal(lab[~ok], L.uniqueid(down < 0)[~ok])
+    d.close()
+
+
+def test_channel_initialisation_reproduces_the_reference_on_cold_xml_inputs(amd):
+    """routing.initial -> lakes.initial -> reservoir.initial -> structures.initial -> routing.initialSecond on the real
+    inputs of settings/cold.xml (model domain mask.map, 5 lakes, 31 reservoirs, avgdis of the use case's pre-run),
+    against tests/golden/etrs89_initial.npz -- produced by the reference's OWN methods in that order (PCRaster emulated:
+    tests/golden/make_golden.py gen_initial).  Pins a10, a11 (split branch + mass-balance start values), the lake and
+    reservoir parameter derivation and the cut LDD."""
+    import types
+    from lisflood_amd import structures as ST
+    g = golden("etrs89_initial")
+    mask = g["mask"]
+    maps = {k[4:]: (g[k] if g[k].ndim else float(g[k])) for k in g.files if k.startswith("map_")}
+    tab = {k[6:]: g[k] for k in g.files if k.startswith("table_")}
+    tables = dict(TabLakeArea=tab["lakearea"], TabLakeA=tab["lakea"], TabLakeAvNetInflowEstimate=tab["lakeavinflow"],
+                  TabTotStorage=tab["rtstor"], TabConservativeStorageLimit=tab["rclim"], TabNormalStorageLimit=tab["rnlim"],
+                  TabFloodStorageLimit=tab["rflim"], TabNonDamagingOutflowQ=tab["rndq"], TabNormalOutflowQ=tab["rnormq"],
+                  TabMinOutflowQ=tab["rminq"])
+    opts = dict(InitLisflood=False, SplitRouting=True, simulateLakes=True, simulateReservoirs=True, repMBTs=True)
+    v = types.SimpleNamespace(DtSec=float(g["DtSec"]), DtSecChannel=float(g["DtSecChannel"]))
+    m = amd.routing.routing(v, options=opts)
+    m.initial(maps, mask)
+    ST.lakes(v, opts, maps, tables).initial(mask)
+    ST.reservoir(v, opts, maps, tables).initial()
+    ST.structures(v, opts).initial(mask)
+    m.initialSecond()
+    exact = ("Ldd IsChannel LddKinematic LddToChan AtLastPointC downstruct Catchments LddStructuresKinematic "
+             "IsStructureKinematic IsUpsOfStructureKinematicC IsUpsOfStructureLake LakeIndex ReservoirIndex").split()
+    for k in exact:
+        assert np.array_equal(np.asarray(getattr(v, k)).astype(np.float64), g["out_" + k].astype(np.float64)), k
+    skip = set(exact) | {"UpArea", "StorageStepINIT", "DischargeM3StructuresIni", "InvCatchArea"}
+    for k in [f[4:] for f in g.files if f.startswith("out_")]:
+        if k in skip:
+            continue
+        np.testing.assert_allclose(np.asarray(getattr(v, k), np.float64).ravel(), g["out_" + k].astype(np.float64).ravel(),
+                                   rtol=1e-14, atol=0, err_msg=k)          # host arithmetic in the same order: to the bit
+    for k in ("UpArea", "StorageStepINIT", "DischargeM3StructuresIni", "InvCatchArea"):   # tree totals: summation order
+        np.testing.assert_allclose(getattr(v, k), g["out_" + k], rtol=1e-12, err_msg=k)
+    # the router initialSecond built sweeps the cut LDD exactly like the reference's
+    assert np.array_equal(m.river_router.pixels_ordered, g["router_pixels_ordered"])
+    assert np.array_equal(m.river_router.order_start_stop, g["router_order_start_stop"])

@@ -275,3 +275,14 @@ def test_soil_columns_match_reference(oracle):
             np.testing.assert_allclose(d[k], g["out%d_%s" % (s, k)], rtol=1e-12, atol=1e-13, err_msg=k)
     # the fixture really exercises frozen soil, zero pore space and drained irrigation
     assert g["in_isFrozenSoil"].any() and (~g["in_PoreSpaceNotZero1b"]).any() and g["in_is_irrigated"].any()
+
+
+def test_soil_pf_golden(oracle):
+    """suctionUnsaturatedSoilPF / pressureHead (soilloop.py:427-432, 673-695) captured from the reference's own
+    dynamic_soil with simulatePF: HeadMax at zero saturation (pF 7), -1 at full saturation, log10 of the head between."""
+    g = golden("soil_pf")
+    d = {k: g[k] for k in g.files}
+    pf = oracle.soil_pf(d, np.arange(3), float(g["HeadMax"]))
+    for i, k in enumerate(("pF0", "pF1", "pF2")):
+        assert max_ulp(pf[i], g[k]) <= 2, k
+    assert (g["pF0"] == 7.0).any() and (g["pF2"] == -1.0).any() and ((g["pF1"] > 0) & (g["pF1"] < 7)).any()
