@@ -297,6 +297,20 @@ class HotPathDevice:
                     self.rmod._st["dev"][k].upload(f64(self.rmod._up(a[self.ids]) if k == "TransCum" else a))
         self.steps_done = int(z["steps_done"])
 
+    def mass_balance(self):
+        """Option repMBTs after a step() with structures: downloads the channel state into the routing module's `var`
+        and runs its bookkeeping (routing.mbts_after_fused) -> (MBErrorSplitRoutingM3, OutletDischargeErrorSplitRouting)
+        over the channel domain's pixels.  A diagnostic: it synchronises."""
+        m = self.rmod
+        if m is None:
+            raise RuntimeError("mass_balance() needs structures=")
+        m.options["repMBTs"] = True
+        m._download_state()
+        m._structures_download(int(self.sc["NoRoutSteps"]) - 1)
+        m.var.ToChanM3RunoffDt = m._down(m._st["dev"]["ToChanM3RunoffDt"].download())
+        m.mbts_after_fused()
+        return m.var.MBErrorSplitRoutingM3, m.var.OutletDischargeErrorSplitRouting
+
     def chan_q_avg(self):
         """ChanQAvg = sumDisDay / NoRoutSteps (Lisflood_dynamic.py:209): the `dis` output of the reference."""
         return self.download("sumDisDay") / self.sc["NoRoutSteps"]

@@ -208,6 +208,7 @@ class routing(HydroModule):
         can run the structures inside the wavefront."""
         v, o = self.var, self.options
         land_mask = np.asarray(land_mask, bool)
+        self._land_mask = land_mask
         codes = np.asarray(compressed_ldd_kinematic, np.float64)
         N = self._nfull = int(land_mask.sum())
         structures = not o.get("InitLisflood") and (o.get("simulateLakes") or o.get("simulateReservoirs")) and \
@@ -313,6 +314,48 @@ class routing(HydroModule):
             from . import ldd as L
             d = self._ldd_all = L.LddDevice(self.var.Ldd, self._land_mask, self.device)
         return d.catchment_totals(w)
+
+    def _mbts_added(self, s, nsub=1, qin=None):
+        """AddedTRUN (routing.py:483-499): water added to the channels, summed per catchment and over the sub-steps.
+        nsub > 1: the sub-steps of a fused call at once (the terms are constant over the model step; `qin` = QinADDEDM3,
+        the inflow of all sub-steps)."""
+        v, o = self.var, self.options
+        w = np.array(v.ToChanM3RunoffDt, dtype=np.float64) * nsub
+        if o.get('inflow'):
+            w = w + (np.asarray(v.QInDt, np.float64) if qin is None else np.asarray(qin, np.float64))
+        if o.get('openwaterevapo'):
+            w = w - np.asarray(v.EvaAddM3Dt, np.float64) * nsub
+        if o.get('wateruse'):
+            w = w - np.asarray(v.WUseAddM3Dt, np.float64) * nsub
+        tot = self._catchment_totals(w)
+        v.AddedTRUN = tot if s < 1 else v.AddedTRUN + tot
+
+    def _mbts_last(self):
+        """mass-balance error of the split-routing module at the last sub-step (routing.py:645-691)"""
+        v, o = self.var, self.options
+        if o.get('InitLisflood') or not o.get('SplitRouting'):
+            return                                  # the reference's code for these cases is commented out (:608-643)
+        N = self._nfull
+        at_last = np.asarray(v.AtLastPointC).astype(bool)
+        avg = v.sumDisDay / v.NoRoutSteps
+        out_step = self._catchment_totals(np.where(at_last, avg, 0.0) * v.DtSec)                          # :649-651
+        storage = v.ChanM3Kin + v.Chan2M3Kin - v.Chan2M3Start                                             # :654
+        ups = np.asarray(getattr(v, "IsUpsOfStructureKinematicC", np.zeros(N))) > 0
+        r = np.zeros(N)
+        if o.get('simulateReservoirs'):
+            storage = storage + v.ReservoirStorageM3                                                      # :664
+            r = self._catchment_totals(np.where(ups, v.ChanQ * v.DtRouting, 0.0)) - v.DischargeM3StructuresIni
+        if o.get('simulateLakes'):
+            storage = storage + v.LakeStorageM3Balance                                                    # :672
+            r = self._catchment_totals(np.where(ups, v.ChanQ * v.DtRouting, 0.0))
+            lake = np.zeros(N)
+            lake[np.asarray(v.LakeIndex)] = 0.5 * np.asarray(v.LakeInflowCC) * v.DtRouting                # :676
+            r = r + self._catchment_totals(lake) - v.DischargeM3StructuresIni
+        storage1 = self._catchment_totals(storage)                                                        # :683
+        v.MBErrorSplitRoutingM3 = -storage1 + v.StorageStepINIT - out_step - r + v.AddedTRUN              # :685
+        corr = np.where(at_last, v.MBErrorSplitRoutingM3 / v.DtRouting, 0.0)                              # :687-688
+        v.OutletDischargeErrorSplitRouting = self._catchment_totals(corr)
+        v.StorageStepINIT = storage1 + r                                                                  # :691
 
     def _mbts_initial(self):
         """mass-balance start values of option repMBTs (routing.py:405-431; with split routing the reference takes
@@ -581,6 +624,16 @@ class routing(HydroModule):
             self._download_state()
         self._structures_download(nsteps - 1)
         v.SideflowChanM3 = self._down(self._dev["SideflowChanM3"].download())
+        if self.options.get("repMBTs"):
+            self.mbts_after_fused()
+
+    def mbts_after_fused(self):
+        """The mass-balance bookkeeping of a whole model step after a fused call (state already on `var`): AddedTRUN of
+        all sub-steps at once, then the last-sub-step block.  Equal to the sub-step-by-sub-step sums to rounding."""
+        v = self.var
+        nsteps = int(v.NoRoutSteps)
+        self._mbts_added(0, nsub=nsteps, qin=getattr(v, "QinADDEDM3", None))
+        self._mbts_last()
 
     def dynamic(self, NoRoutingExecuted):
         """One routing sub-step (routing.py:435-706)."""
@@ -604,6 +657,13 @@ class routing(HydroModule):
             self._download_state()
         if getattr(self, "_inloop", None) is not None:
             self._structures_download(NoRoutingExecuted)
+        if self.options.get("repMBTs"):                  # routing.py:483-499, 645-691
+            if self._resident:
+                raise RuntimeError("repMBTs reads the routing state on `var` every sub-step: use the drop-in mode or "
+                                   "dynamic_fused()")
+            self._mbts_added(NoRoutingExecuted)
+            if NoRoutingExecuted == int(self.var.NoRoutSteps) - 1:
+                self._mbts_last()
 
 
 def _fused(self, sideflows):

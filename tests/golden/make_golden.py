@@ -709,83 +709,52 @@ CHAIN_STEPS = 12
 
 
 def chain_inputs():
-    """Inputs of the model-step chain on the LF_ETRS89 domain: real LDD / channel geometry / lake and reservoir sites
-    (etrs89_static.npz), real meteorological fields (etrs89_meteo.npz: the first fields of meteo_1950/pr, e0, et, es),
-    seeded soil / land-use / structure parameters in the ranges of the other generators (the soil maps of the use
-    case need ~40 tables and PCRaster look-ups to turn into these parameters).
+    """Inputs of the model-step chain on the model domain of cold.xml (mask.map, 2 847 pixels): the channel network,
+    split-routing thresholds, lakes and reservoirs exactly as the reference's own initialisation produced them
+    (etrs89_initial.npz: routing.initial .. initialSecond on the real maps, tables and the pre-run's avgdis), real
+    meteorological fields (etrs89_meteo.npz: the first fields of meteo_1950/pr, e0, et, es), seeded soil / land-use
+    parameters in the ranges of the other generators (the soil maps of the use case need ~40 more tables and PCRaster
+    look-ups), seeded inflow hydrographs and transmission-loss reaches.
     -> values, scalars, structures, mask, ldd_to_chan, cut LDD, forcing[step], QInM3[step]"""
-    z, ldd, mask = etrs89()
+    ini = np.load(os.path.join(HERE, "etrs89_initial.npz"))
+    mask = ini["mask"]
     N = int(mask.sum())
-    cp = etrs89_channel_params(z, mask)
     rng = np.random.default_rng(2024)
-    nsteps, dt_sec, beta = 24, 86400.0, 0.6
-    dt_routing = dt_sec / nsteps
-    values, sc, mask2, ldd_to_chan, ldd_kin = syn.hotpath_scenario(mask.shape[0], mask.shape[1], seed=909)
+    nsteps, dt_sec, beta = int(ini["out_NoRoutSteps"]), float(ini["DtSec"]), float(ini["out_Beta"])
+    dt_routing = float(ini["out_DtRouting"])
+    values, sc, mask2, _, _ = syn.hotpath_scenario(mask.shape[0], mask.shape[1], seed=909)
     # hotpath_scenario is an all-land raster: take its per-pixel parameter vectors on the land pixels of the mask
-    # (soil columns, canopy, land-use fractions, groundwater, overland roughness) and replace everything that has to
-    # do with the river network by the real maps
+    # (soil columns, canopy, land-use fractions, groundwater, overland roughness); everything that has to do with the
+    # river network comes from the reference's initialisation
     take = np.flatnonzero(mask.ravel())
     values = {k: np.ascontiguousarray(np.asarray(a)[..., take]) for k, a in values.items()}
-    codes = ldd[mask].astype(np.float64)
-    is_chan = cp["IsChannel"]
+    o = lambda k: np.array(ini["out_" + k], dtype=np.float64).ravel()
+    is_chan = ini["out_IsChannel"].astype(bool)
     assert is_chan.all()                                   # LF_ETRS89: every land pixel is a channel pixel
-    ldd_to_chan = np.where(is_chan, 5.0, codes)            # routing.py:125
-    alpha, alpha2, length = cp["alpha"], cp["alpha2"], cp["ChanLength"]
-    q0 = cp["Q0"]
-    qlimit = 2.0 * q0 * rng.uniform(0.3, 1.2, N)           # QSplitMult * AvgDis stand-in (routing.py:364-366)
-    values.update(IsChannel=is_chan, IsChannelKinematic=is_chan.copy(), ChannelAlpha=alpha, InvChannelAlpha=1 / alpha,
-                  ChannelAlpha2=alpha2, InvChannelAlpha2=1 / alpha2, ChanLength=length, InvChanLength=1 / length,
-                  QLimit=qlimit, M3Limit=alpha * length * qlimit ** beta, Chan2M3Start=alpha2 * length * qlimit ** beta,
-                  PixelArea=z["pixarea"][mask].astype(np.float64))
-    # structures: the real lake / reservoir cells, the LDD cut just upstream of them (structures.py:51-59)
-    full = build_router(ldd, mask, alpha, beta, length, dt_routing)
-    down = full.downstream_lookup.astype(np.int64)
-    st = {}
-    st["downstruct"] = np.where(down < 0, N, down).astype(np.int32)                        # routing.py:159-164
-    lake_sites = (z["lakes"][mask] > 0)
-    res_sites = (z["res"][mask] > 0) & ~lake_sites
-    is_struct = lake_sites | res_sites
-    ups_of_struct = (down >= 0) & is_struct[np.maximum(down, 0)]
-    cut = np.where(ups_of_struct, 5.0, codes)
-    cut2d = np.zeros(mask.shape, ldd.dtype); cut2d[mask] = cut
-    kw = build_router(cut2d, mask, alpha, beta, length, dt_routing, alpha2=alpha2)
-    values["Chan2QStart"] = qlimit - kwp.kwpt.immediateUpstreamInflow(qlimit, kw.upstream_lookup, kw.num_upstream_pixels)
-    ChanM3 = cp["area0"] * length * rng.uniform(0.5, 3.0, N)
-    values["CrossSection2Area"] = np.zeros(N)
-    values["Chan2M3Kin"] = values["CrossSection2Area"] * length + values["Chan2M3Start"]       # routing.py:391-397
-    values["ChanM3Kin"] = np.maximum(ChanM3 - values["Chan2M3Kin"] + values["Chan2M3Start"], 0.0)
-    values["Chan2QKin"] = (values["Chan2M3Kin"] * (1 / length) * (1 / alpha2)) ** (1 / beta)
-    values["ChanQKin"] = (values["ChanM3Kin"] * (1 / length) * (1 / alpha)) ** (1 / beta)
-    values["ChanQ"] = np.maximum(values["ChanQKin"] + values["Chan2QKin"] - qlimit, 0.0)
-    values["Sideflow1Chan"] = np.zeros(N); values["sumDisDay"] = np.zeros(N)
+    ldd_to_chan = o("LddToChan")
+    cut = o("LddKinematic")
+    length = np.asarray(ini["map_ChanLength"], np.float64)
+    values.update(IsChannel=is_chan, IsChannelKinematic=is_chan.copy(), ChanLength=length, InvChanLength=1 / length,
+                  PixelArea=np.asarray(ini["map_PixelArea"], np.float64))
+    for k in ("ChannelAlpha", "InvChannelAlpha", "ChannelAlpha2", "InvChannelAlpha2", "QLimit", "M3Limit", "Chan2M3Start",
+              "Chan2QStart", "ChanM3Kin", "Chan2M3Kin", "ChanQKin", "Chan2QKin", "ChanQ", "CrossSection2Area", "Sideflow1Chan"):
+        values[k] = o(k)
+    values["sumDisDay"] = np.zeros(N)
+    st = {"downstruct": ini["out_downstruct"].astype(np.int32)}
+    st["LakeIndex"] = ini["out_LakeIndex"].astype(np.int64)
+    for k in ("LakeAreaCC", "LakeFactor", "LakeFactorSqr", "LakeInflowOldCC", "LakeLevelCC", "LakeOutflowCC",
+              "LakeStorageM3BalanceCC", "LakeStorageM3"):
+        st[k] = o(k)
+    st["ReservoirIndex"] = ini["out_ReservoirIndex"].astype(np.int64)
+    for k in ("TotalReservoirStorageM3CC", "ConservativeStorageLimitCC", "NormalStorageLimitCC", "FloodStorageLimitCC",
+              "Normal_FloodStorageLimitCC", "MinReservoirOutflowCC", "NormalReservoirOutflowCC", "NonDamagingReservoirOutflowCC",
+              "DeltaO", "DeltaLN", "DeltaNFL", "ReservoirStorageM3"):
+        st[k] = o(k)
+    # mass-balance bookkeeping of routing.dynamic (option repMBTs)
+    for k in ("Catchments", "AtLastPointC", "IsUpsOfStructureKinematicC", "StorageStepINIT", "DischargeM3StructuresIni"):
+        st[k] = ini["out_" + k]
+    st["Ldd"] = o("Ldd")
     ChanQ = values["ChanQ"]
-    st["LakeIndex"] = np.nonzero(lake_sites)[0]
-    nl = st["LakeIndex"].size
-    st["LakeAreaCC"] = rng.uniform(2e6, 5e7, nl)
-    LakeACC = rng.uniform(5.0, 80.0, nl)
-    st["LakeFactor"] = st["LakeAreaCC"] / (dt_routing * np.sqrt(LakeACC))                  # lakes.py:140-160
-    st["LakeFactorSqr"] = np.square(st["LakeFactor"])
-    st["LakeInflowOldCC"] = np.bincount(st["downstruct"], weights=ChanQ, minlength=N + 1)[st["LakeIndex"]]
-    st["LakeLevelCC"] = rng.uniform(0.5, 3.0, nl)
-    st["LakeStorageM3"] = np.zeros(N); st["LakeStorageM3"][st["LakeIndex"]] = st["LakeAreaCC"] * st["LakeLevelCC"]
-    st["LakeOutflowCC"] = np.square(st["LakeLevelCC"]) * LakeACC
-    st["LakeStorageM3BalanceCC"] = st["LakeStorageM3"][st["LakeIndex"]].copy()
-    st["ReservoirIndex"] = np.nonzero(res_sites)[0]
-    nr = st["ReservoirIndex"].size
-    st["TotalReservoirStorageM3CC"] = np.exp(rng.uniform(np.log(1e6), np.log(5e8), nr))   # reservoir.py:73-165
-    st["ConservativeStorageLimitCC"] = rng.uniform(0.05, 0.15, nr)
-    st["NormalStorageLimitCC"] = rng.uniform(0.4, 0.7, nr)
-    st["FloodStorageLimitCC"] = rng.uniform(0.8, 0.97, nr)
-    st["Normal_FloodStorageLimitCC"] = st["NormalStorageLimitCC"] + 0.5 * (st["FloodStorageLimitCC"] - st["NormalStorageLimitCC"])
-    qin0 = np.bincount(st["downstruct"], weights=ChanQ, minlength=N + 1)[st["ReservoirIndex"]]
-    st["MinReservoirOutflowCC"] = 0.1 * qin0 + 0.01
-    st["NormalReservoirOutflowCC"] = 0.9 * qin0 + 0.05
-    st["NonDamagingReservoirOutflowCC"] = 4.0 * qin0 + 1.0
-    st["DeltaO"] = st["NormalReservoirOutflowCC"] - st["MinReservoirOutflowCC"]
-    st["DeltaLN"] = st["NormalStorageLimitCC"] - 2 * st["ConservativeStorageLimitCC"]
-    st["DeltaNFL"] = st["FloodStorageLimitCC"] - st["Normal_FloodStorageLimitCC"]
-    st["ReservoirStorageM3"] = np.zeros(N)
-    st["ReservoirStorageM3"][st["ReservoirIndex"]] = rng.uniform(0.02, 1.0, nr) * st["TotalReservoirStorageM3CC"]
     # inflow hydrographs at the use case's own inflow points would need its .tss tables: six seeded points instead
     pts = rng.choice(N, 6, replace=False)
     st["QInM3Old"] = np.zeros(N); st["QDelta"] = np.zeros(N)
@@ -797,9 +766,10 @@ def chain_inputs():
     st["TransPower1"], st["TransPower2"], st["TransSub"] = 1 / 0.95, 0.95, 1e-4
     st["TransCum"] = np.zeros(N)
     sc = dict(sc)
-    sc.update(DtRouting=dt_routing, NoRoutSteps=nsteps, DtSec=dt_sec, PixelLength=float(z["pixleng"][mask][0]))
+    pl = np.load(os.path.join(HERE, "etrs89_static.npz"))["pixleng"][mask]
+    sc.update(DtRouting=dt_routing, NoRoutSteps=nsteps, DtSec=dt_sec, PixelLength=float(pl[0]), Beta=beta)
     pa = float(values["PixelArea"][0])
-    assert (values["PixelArea"] == pa).all() and (z["pixleng"][mask] == sc["PixelLength"]).all()
+    assert (values["PixelArea"] == pa).all() and (pl == sc["PixelLength"]).all()
     sc.update(MMtoM3=0.001 * pa, M3toMM=1 / (0.001 * pa))
     # forcing: real fields (precipitation x4: January 1950 was dry there) plus a seeded three-day storm, so that
     # surface runoff and Courant sub-stepping happen
@@ -829,7 +799,7 @@ def gen_chain():
     opts = REF["LisSettings"].options
     opts.clear()
     opts.update(InitLisflood=False, SplitRouting=True, simulateLakes=True, simulateReservoirs=True, TransLoss=True,
-                inflow=True)
+                inflow=True, repMBTs=True)
     REF["MaskInfo"].n = N
     REF["LisSettings"].soil_uses = SOIL_USES[:]
     REF["LisSettings"].vegetation_landuse = dict(zip(PRESCRIBED, SOIL_USES))
@@ -872,7 +842,8 @@ def gen_chain():
     m_inflow = m_rout.inflow_module = REF["inflow"].inflow(v)
     m_rout.transmission_module = REF["transmission"].transmission(v)
     m_rout.polder_module = types.SimpleNamespace(dynamic_inloop=lambda *a, **k: None)
-    per_step = ("ChanQAvg", "ChanQ", "ToChanM3RunoffDt")
+    per_step = ("ChanQAvg", "ChanQ", "ToChanM3RunoffDt", "AddedTRUN", "MBErrorSplitRoutingM3",
+                "OutletDischargeErrorSplitRouting", "StorageStepINIT")
     sampled_keys = ("W1a", "W1b", "W2", "UZ", "LZ", "CumInterception", "DSLR", "Infiltration", "DirectRunoff", "OFQDirect",
                     "OFQOther", "OFQForest", "ChanQKin", "Chan2QKin", "ChanM3Kin", "Chan2M3Kin", "ChanM3", "sumDis",
                     "LakeStorageM3CC", "LakeOutflowCC", "LakeLevelCC", "ReservoirStorageM3CC", "ReservoirFillCC", "TransCum",

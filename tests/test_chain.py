@@ -42,6 +42,12 @@ def close(got, want, rtol, msg):
     np.testing.assert_allclose(got, want, rtol=rtol, atol=rtol * 1e-3 * scale, err_msg=str(msg))
 
 
+def close_mb(got, want, g, msg):
+    """mass-balance terms are differences of catchment storages (~2e9 m3): held to 1e-12 of that scale"""
+    scale = float(np.abs(g["st_StorageStepINIT"]).max())
+    np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-12 * scale, err_msg=str(msg))
+
+
 def namespace(values, sc, st):
     v = types.SimpleNamespace()
     for k, a in list(cp(values).items()) + list(sc.items()) + list(cp(st).items()):
@@ -114,7 +120,7 @@ def test_dis_series_round_trips_through_the_writers(tmp_path):
     g = golden("etrs89_chain")
     mask = g["mask"]
     dis = g["out_ChanQAvg"]
-    gauges = np.array([10, 999, 2500, 4461])
+    gauges = np.array([10, 999, 2500, 2846])
     path = str(tmp_path / "dis.tss")
     out.write_tss(path, list(gauges + 1), 1, dis[:, gauges])
     first, ids, step0, data = out.read_tss(path)
@@ -158,6 +164,10 @@ def test_hot_path_reproduces_the_reference_dis(amd):
         close(hp.download("ChanQ"), g["out_ChanQ"][step], RTOL_DIS, (step, "ChanQ"))
         close(hp.download("ToChanM3RunoffDt"), g["out_ToChanM3RunoffDt"][step], RTOL_DIS, (step, "ToChanM3RunoffDt"))
         sum_dis += hp.download("sumDisDay")
+        mb, qerr = hp.mass_balance()                       # option repMBTs (routing.py:483-499, 645-691)
+        close_mb(mb, g["out_MBErrorSplitRoutingM3"][step], g, (step, "MBErrorSplitRoutingM3"))
+        close_mb(qerr * 3600.0, g["out_OutletDischargeErrorSplitRouting"][step] * 3600.0, g, (step, "OutletDischargeError"))
+        close_mb(hp.rmod.var.StorageStepINIT, g["out_StorageStepINIT"][step], g, (step, "StorageStepINIT"))
         if step in sampled:
             i = sampled.index(step)
             check_snapshots(g, i, hp.download, ("W1a", "W1b", "W2", "UZ", "LZ", "CumInterception", "DSLR", "Infiltration",
@@ -193,7 +203,7 @@ def test_module_classes_reproduce_the_reference_dis(amd, engine_order):
     m_soil = soilloop(v); m_soil.initial()
     m_surf = surface_routing(v); m_surf.initialSecond(g["ldd_to_chan"], mask)
     m_rout = amd.routing.routing(v, options=dict(SplitRouting=True, InitLisflood=False, simulateLakes=True,
-                                                 simulateReservoirs=True, inflow=True, TransLoss=True),
+                                                 simulateReservoirs=True, inflow=True, TransLoss=True, repMBTs=True),
                                  engine_order=engine_order)
     m_rout.attach_router(g["ldd_cut"], mask)
     m_rout.attach_structures()
@@ -214,3 +224,45 @@ def test_module_classes_reproduce_the_reference_dis(amd, engine_order):
         m_rout.step_end()
         close(v.ChanQAvg, g["out_ChanQAvg"][step], RTOL_DIS, (step, "dis"))
         close(v.ChanQ, g["out_ChanQ"][step], RTOL_DIS, (step, "ChanQ"))
+        close_mb(v.AddedTRUN, g["out_AddedTRUN"][step], g, (step, "AddedTRUN"))
+        close_mb(v.MBErrorSplitRoutingM3, g["out_MBErrorSplitRoutingM3"][step], g, (step, "MBErrorSplitRoutingM3"))
+        close_mb(v.StorageStepINIT, g["out_StorageStepINIT"][step], g, (step, "StorageStepINIT"))
+
+
+@pytest.mark.gpu
+def test_subcatchment_run_equals_the_whole_domain(amd):
+    """The reference's own test strategy for this path (tests/test_subcatchments.py): a run on subcatchment_mask.map
+    must give, on that mask, exactly the arrays of the run on the whole domain (NetCDFComparator(array_equal=True)).
+    Here: the resident chain on the 1 023-pixel sub-catchment against the 2 847-pixel domain, six model steps, `dis`
+    and the state bit for bit."""
+    from lisflood_amd.hotpath import HotPathDevice, _structures_on_subdomain
+    g, values, sc, st, forcing = fixture()
+    mask = g["mask"]
+    N = int(mask.sum())
+    sub2d = golden("etrs89_static")["subcatchment_mask"] & mask
+    sel = sub2d[mask]
+    ids = np.nonzero(sel)[0]
+    assert ids.size == 1023
+    for k in ("Catchments", "AtLastPointC", "IsUpsOfStructureKinematicC", "StorageStepINIT", "DischargeM3StructuresIni", "Ldd"):
+        st.pop(k)                                           # mass-balance bookkeeping is not part of this comparison
+    keep_lake = sel[st["LakeIndex"]]
+    keep_res = sel[st["ReservoirIndex"]]
+    st_sub = dict(st)
+    for k, a in st.items():                                # site vectors of the structures inside the sub-catchment
+        if isinstance(a, np.ndarray) and a.shape == st["LakeIndex"].shape and k.startswith("Lake") and k != "LakeStorageM3":
+            st_sub[k] = a[keep_lake]
+        elif isinstance(a, np.ndarray) and a.shape == st["ReservoirIndex"].shape and k != "ReservoirStorageM3" and (
+                k.startswith("Reservoir") or k.endswith("CC") or k.startswith("Delta")):
+            st_sub[k] = a[keep_res]
+    st_sub = _structures_on_subdomain(st_sub, ids, N)
+    assert st_sub["LakeIndex"].size + st_sub["ReservoirIndex"].size > 0
+    vals_sub = {k: np.ascontiguousarray(np.asarray(a)[..., ids]) for k, a in values.items()}
+    whole = HotPathDevice(cp(values), sc, mask, g["ldd_to_chan"], g["ldd_cut"], split=True, structures=cp(st))
+    part = HotPathDevice(vals_sub, sc, sub2d, g["ldd_to_chan"][ids], g["ldd_cut"][ids], split=True, structures=st_sub)
+    for step, f in enumerate(forcing[:6]):
+        whole.step(f, step + 1, QInM3=g["QInM3"][step])
+        part.step({k: np.ascontiguousarray(a[ids]) for k, a in f.items()}, step + 1, QInM3=g["QInM3"][step][ids])
+        assert np.array_equal(part.chan_q_avg(), whole.chan_q_avg()[ids]), step
+        for k in ("ChanQ", "ChanQKin", "Chan2QKin", "W1a", "UZ", "LZ", "OFQOther"):
+            assert np.array_equal(part.download(k), whole.download(k)[..., ids]), (step, k)
+    whole.free(); part.free()
