@@ -143,9 +143,6 @@ __global__ void __launch_bounds__(kBlock) k_count_nonfinite(long long n, const d
 struct segment {
     int k0, k1; // levels [k0, k1); wide segments have k1 == k0 + 1
     bool wide;
-    // window segments (ncomp > 0): levels [k0, k1) swept by k_window, one lane per component
-    int ncomp = 0;
-    int64_t ptr_off = 0; // first entry of this window in win_ptr
 };
 
 } // namespace
@@ -161,7 +158,6 @@ struct lf_router {
     lf_dbuf<int32_t> perm, ups_ptr;
     lf_dbuf<long long> level_start;
     lf_dbuf<double> a1, a2, dx, constant, qord, io_q, io_lat, tmp_ord, fused_qr1, fused_qr2;
-    lf_dbuf<int32_t> win_ptr, win_cells; // component lists of the window segments
     // component layout (lf_graph_build_components): one launch per tier, one wavefront per bin
     bool comp = false;
     lf_dbuf<int32_t> c_bin_lvl_off, c_bin_nl, c_lvl, c_t_ptr, c_t_idx, c_ups_end;
@@ -196,49 +192,9 @@ struct lf_router {
     std::vector<rec> recs;
     size_t ev_used = 0;
     double prof_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    // hipGraph replay of a call's launch sequence (LF_HIPGRAPH=1): one captured graph per distinct argument set
-    bool use_graph = false;
-    struct graph_entry {
-        std::string key;
-        hipGraph_t graph;
-        hipGraphExec_t exec;
-    };
-    std::vector<graph_entry> graphs;
-    static constexpr size_t kMaxGraphs = 8;
-
     ~lf_router()
     {
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
-        for (graph_entry &g : graphs) {
-            (void)hipGraphExecDestroy(g.exec);
-            (void)hipGraphDestroy(g.graph);
-        }
-    }
-    // Replays the launches `enqueue` puts on the stream as a captured graph; the first call with a new key captures.
-    template <class F> int replay(const std::string &key, F enqueue)
-    {
-        for (graph_entry &g : graphs)
-            if (g.key == key) {
-                LF_HIP(hipGraphLaunch(g.exec, ctx->stream));
-                return LF_OK;
-            }
-        if (graphs.size() == kMaxGraphs) {
-            LF_HIP(hipStreamSynchronize(ctx->stream));
-            (void)hipGraphExecDestroy(graphs.front().exec);
-            (void)hipGraphDestroy(graphs.front().graph);
-            graphs.erase(graphs.begin());
-        }
-        graph_entry g;
-        g.key = key;
-        LF_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-        const int rc = enqueue();
-        const hipError_t e = hipStreamEndCapture(ctx->stream, &g.graph);
-        if (rc != LF_OK) return rc;
-        LF_HIP(e);
-        LF_HIP(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
-        graphs.push_back(g);
-        LF_HIP(hipGraphLaunch(g.exec, ctx->stream));
-        return LF_OK;
     }
     int ev_get(size_t *idx)
     {
@@ -355,21 +311,7 @@ int enqueue_route(lf_router *r, double *q_dev, const double *lat_dev, int sectio
         return LF_OK;
     }
     for (const segment &g : r->schedule) {
-        if (g.ncomp > 0) {
-            LF_TRY(r->prof_begin(1, r->h_level_start[g.k1] - r->h_level_start[g.k0]));
-            const dim3 grid(blocks_for(g.ncomp)), block(kBlock);
-            const int *cp = r->win_ptr.p + g.ptr_off;
-            if (r->fused && ordered)
-                hipLaunchKernelGGL((k_window<true, true>), grid, block, 0, s, g.ncomp, cp, r->win_cells.p, A);
-            else if (r->fused)
-                hipLaunchKernelGGL((k_window<true, false>), grid, block, 0, s, g.ncomp, cp, r->win_cells.p, A);
-            else if (ordered)
-                hipLaunchKernelGGL((k_window<false, true>), grid, block, 0, s, g.ncomp, cp, r->win_cells.p, A);
-            else
-                hipLaunchKernelGGL((k_window<false, false>), grid, block, 0, s, g.ncomp, cp, r->win_cells.p, A);
-            LF_TRY(r->prof_end());
-            ++wide;
-        } else if (g.wide) {
+        if (g.wide) {
             const int first = (int)r->h_level_start[g.k0];
             const int count = (int)(r->h_level_start[g.k1] - r->h_level_start[g.k0]);
             LF_TRY(r->prof_begin(1, count));
@@ -418,12 +360,7 @@ int route_device(lf_router *r, double *q_dev, const double *lat_dev, int section
         return lf_set_error(LF_E_INVALID, "a router on a graph with structure links (lf_graph_create_ex) runs only the "
                             "fused sub-step path (lf_routing_substeps_fused*)");
     LF_HIP(hipSetDevice(r->device));
-    if (r->use_graph && !r->profile && r->schedule.size() >= 8) {
-        char key[96];
-        std::snprintf(key, sizeof key, "route %p %p %d %d", (void *)q_dev, (const void *)lat_dev, section, (int)ordered);
-        LF_TRY(r->replay(key, [&] { return enqueue_route(r, q_dev, lat_dev, section, ordered); }));
-    } else
-        LF_TRY(enqueue_route(r, q_dev, lat_dev, section, ordered));
+    LF_TRY(enqueue_route(r, q_dev, lat_dev, section, ordered));
     LF_HIP(hipGetLastError());
     if (r->profile) LF_TRY(r->prof_collect());
     return LF_OK;
@@ -453,10 +390,6 @@ int lf_router_create(const lf_graph *g, const double *alpha, double beta, const 
     r->has_floodplains = alpha_floodplains != nullptr;
     // beta == 3/5 (every LISFLOOD setting): fused prep + polynomial solve.  LF_GENERAL_POW=1 forces the
     // general path (the reference's own Newton iteration with pow) for A/B parity and timing.
-    {
-        const char *hg = std::getenv("LF_HIPGRAPH");
-        r->use_graph = hg && hg[0] == '1';
-    }
     const char *force_general = std::getenv("LF_GENERAL_POW");
     r->fused = (beta == 0.6) && !(force_general && force_general[0] == '1');
     const int64_t n = g->N;
@@ -559,27 +492,9 @@ int lf_router_create(const lf_graph *g, const double *alpha, double beta, const 
         *out = r;
         return LF_OK;
     }
-    // launch schedule: narrow runs -> one single-workgroup launch; wide levels -> one launch per level.
-    // Experimental (LF_WINDOWS=1, off by default): runs of wide levels swept in windows of up to kWindow levels by
-    // k_window, one lane per independent component.  Measured on the 10 000^2 `deep` raster it cuts launches from
-    // 10 002 to 347 but is 6x SLOWER (215 ms vs 36 ms per call): a lane walks its component serially with ~3
-    // dependent, uncoalesced memory round trips per cell and a wavefront waits for its largest component.
+    // launch schedule: runs of narrow levels -> one single-workgroup launch each; wide levels -> one launch per level
     {
-        const char *w = std::getenv("LF_WINDOWS");
-        const bool use_windows = w && w[0] == '1';
-        constexpr int kWindow = 32, kMinRun = 8;
         const int64_t NL = g->NL;
-        std::vector<int32_t> down_pos, root, h_ptr, h_cells, count;
-        if (use_windows) {
-            std::vector<int32_t> pos(n);
-            for (int64_t p = 0; p < n; ++p) pos[g->perm[p]] = (int32_t)p;
-            down_pos.resize(n);
-            for (int64_t p = 0; p < n; ++p) {
-                const int32_t d = g->down[g->perm[p]];
-                down_pos[p] = d >= 0 ? pos[d] : -1;
-            }
-            root.resize(n);
-        }
         auto level_size = [&](int64_t k) { return g->level_start[k + 1] - g->level_start[k]; };
         for (int64_t k = 0; k < NL;) {
             if (level_size(k) <= kNarrowMax) {
@@ -587,55 +502,9 @@ int lf_router_create(const lf_graph *g, const double *alpha, double beta, const 
                 while (e < NL && level_size(e) <= kNarrowMax) ++e;
                 r->schedule.push_back({(int)k, (int)e, false});
                 k = e;
-                continue;
-            }
-            int64_t run_end = k + 1;
-            while (run_end < NL && level_size(run_end) > kNarrowMax) ++run_end;
-            while (k < run_end) {
-                int T = use_windows && (run_end - k) >= kMinRun ? (int)std::min<int64_t>(kWindow, run_end - k) : 1;
-                int ncomp = 0;
-                while (T >= 4) {
-                    // components of the window [k, k+T): root = the component's cell in the window's last level
-                    const int64_t top = k + T - 1;
-                    const int64_t top0 = g->level_start[top];
-                    ncomp = (int)level_size(top);
-                    for (int64_t p = top0; p < g->level_start[top + 1]; ++p) root[p] = (int32_t)p;
-                    for (int64_t lev = top - 1; lev >= k; --lev)
-                        for (int64_t p = g->level_start[lev]; p < g->level_start[lev + 1]; ++p) root[p] = root[down_pos[p]];
-                    count.assign(ncomp + 1, 0);
-                    for (int64_t p = g->level_start[k]; p < g->level_start[top + 1]; ++p) count[root[p] - top0 + 1]++;
-                    int32_t biggest = 0;
-                    for (int c = 1; c <= ncomp; ++c) biggest = std::max(biggest, count[c]);
-                    // a lane walks its component serially: windows only pay off while components stay small
-                    if (biggest <= 16 * T && (int64_t)ncomp >= 2048) break;
-                    T /= 2;
-                }
-                if (T >= 4) {
-                    const int64_t top0 = g->level_start[k + T - 1];
-                    segment sg{(int)k, (int)(k + T), true};
-                    sg.ncomp = ncomp;
-                    sg.ptr_off = (int64_t)h_ptr.size();
-                    const int32_t base = (int32_t)h_cells.size();
-                    for (int c = 0; c < ncomp; ++c) count[c + 1] += count[c]; // exclusive prefix in count[0..ncomp]
-                    for (int c = 0; c <= ncomp; ++c) h_ptr.push_back(base + count[c]);
-                    h_cells.resize(base + count[ncomp]);
-                    std::vector<int32_t> cursor(count.begin(), count.end() - 1);
-                    for (int64_t p = g->level_start[k]; p < g->level_start[k + T]; ++p) // ascending level order
-                        h_cells[base + cursor[root[p] - top0]++] = (int32_t)p;
-                    r->schedule.push_back(sg);
-                    k += T;
-                } else {
-                    r->schedule.push_back({(int)k, (int)k + 1, true});
-                    ++k;
-                }
-            }
-        }
-        if (!h_ptr.empty()) {
-            rc = r->win_ptr.upload(h_ptr.data(), h_ptr.size(), ctx->stream);
-            if (rc == LF_OK) rc = r->win_cells.upload(h_cells.data(), h_cells.size(), ctx->stream);
-            if (rc != LF_OK) {
-                delete r;
-                return rc;
+            } else {
+                r->schedule.push_back({(int)k, (int)k + 1, true});
+                ++k;
             }
         }
     }
@@ -835,7 +704,7 @@ int lf_accuflux_ordered_device(lf_router *r, const double *x_ord_dev, double *ac
     }
     for (const segment &g : r->schedule) {
         if (g.wide) {
-            for (int k = g.k0; k < g.k1; ++k) { // window segments are walked level by level here
+            for (int k = g.k0; k < g.k1; ++k) {
                 const int first = (int)r->h_level_start[k];
                 const int count = (int)(r->h_level_start[k + 1] - r->h_level_start[k]);
                 hipLaunchKernelGGL(k_accu_level, dim3(blocks_for(count)), dim3(kBlock), 0, s, first, count, r->ups_ptr.p,

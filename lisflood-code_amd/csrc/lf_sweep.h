@@ -350,20 +350,6 @@ __global__ void __launch_bounds__(kBlock) k_level(int first, int count, sweep_ar
     sweep_cell<FUSED, ORDERED, INDEXED>(first + i, A);
 }
 
-// A window of T consecutive levels, one lane per COMPONENT.  Inside a window the cells split into independent
-// components (a cell's only downstream link leads to the unique cell of its component in the window's last level),
-// so a lane can walk its component level by level with no synchronisation at all: T levels cost one launch
-// instead of T.  comp_cells lists every component's positions in ascending level order.
-template <bool FUSED, bool ORDERED>
-__global__ void __launch_bounds__(kBlock) k_window(int ncomp, const int *__restrict__ comp_ptr,
-                                                   const int *__restrict__ comp_cells, sweep_args A)
-{
-    const int ci = blockIdx.x * kBlock + threadIdx.x;
-    if (ci >= ncomp) return;
-    const int e0 = comp_ptr[ci], e1 = comp_ptr[ci + 1];
-    for (int e = e0; e < e1; ++e) sweep_cell<FUSED, ORDERED, false>(comp_cells[e], A);
-}
-
 // a run of narrow levels [k0, k1): one workgroup, barrier between levels
 template <bool FUSED, bool ORDERED, bool INDEXED = false>
 __global__ void __launch_bounds__(kNarrowBlock) k_levels_narrow(int k0, int k1, const long long *__restrict__ level_start,

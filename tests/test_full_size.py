@@ -1,0 +1,186 @@
+"""Correctness at BASELINE.json's full sizes on one GPU.
+
+The oracle cannot sweep 1e8 cells in seconds, but catchments are independent (the reference's sub-catchment runs rely
+on it, tests/test_subcatchments.py:110-112): a few hundred WHOLE catchments are picked out of the full raster, the
+oracle runs on those sub-domains alone, and the full-raster GPU result must agree with it there at the parity
+tolerance.  Plus the size-independent properties: every cell satisfies the discretised equation (closure), the
+a warm start continues bit for bit.
+
+  configs[2] / [3]   5000^2 .. 10000^2 random LDD, single router calls        test_catchments_of_the_full_raster_vs_oracle
+  configs[4]         20000^2, 24 sub-steps + split routing + warm start       test_config4_workload_20000 (LF_FULL_SIZE=1;
+                                                                              the default run does the same at 8000^2)
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 1e-9, 1e-12          # the parity tolerance of tests/test_gpu_parity.py (NEWTON_TOL = 1e-12)
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import lisflood_amd
+    from lisflood_amd import _lib
+    if _lib.device_count() < 1:
+        pytest.fail("no HIP device visible: the -m gpu tests need an MI355X")
+    return lisflood_amd
+
+
+def pick_catchments(graph, rng, want_cells=150_000, n_small=200):
+    """pixel ids of a set of WHOLE catchments: the largest one plus random ones until ~want_cells cells"""
+    from lisflood_amd.partition import catchment_roots
+    roots = catchment_roots(graph)
+    ids, sizes = np.unique(roots, return_counts=True)
+    chosen = [ids[np.argmax(sizes)]]
+    budget = want_cells - int(sizes.max())
+    for i in rng.permutation(ids.size):
+        if len(chosen) > n_small or budget <= 0:
+            break
+        if ids[i] != chosen[0] and sizes[i] <= budget:
+            chosen.append(ids[i])
+            budget -= int(sizes[i])
+    return np.nonzero(np.isin(roots, np.array(chosen)))[0], len(chosen)
+
+
+def sub_domain(codes_raster, pix, W):
+    """(compressed codes, land mask) of the pixels `pix` (ascending) of an all-land raster, cropped to their bounding box"""
+    H = codes_raster.shape[0]
+    r, c = pix // W, pix % W
+    r0, r1, c0, c1 = r.min(), r.max() + 1, c.min(), c.max() + 1
+    mask = np.zeros((r1 - r0, c1 - c0), bool)
+    mask[r - r0, c - c0] = True
+    return codes_raster[r, c].astype(np.float64), mask
+
+
+@pytest.mark.parametrize("family,size,layout", [("shallow", 10000, None), ("deep", 10000, True), ("river", 6000, True),
+                                                ("shallow", 5000, True)])
+def test_catchments_of_the_full_raster_vs_oracle(amd, oracle, family, size, layout):
+    from lisflood_amd import synthetic as syn
+    from lisflood_amd._lib import DeviceArray
+    from lisflood_amd.kinematic_wave_parallel import Graph, kinematicWave
+    H = W = size
+    N = H * W
+    seed = {"shallow": 1, "deep": 2, "river": 7}[family]
+    codes = syn.make_ldd(family, H, W, seed)
+    p = syn.router_params(N)
+    g = Graph(ldd_raster=codes, components=layout)
+    kw = kinematicWave(None, None, p["alpha"], p["beta"], p["dx"], p["dt"], graph=g)
+    perm = g.layout()[0].astype(np.int64)
+    pix, ncatch = pick_catchments(Graph(ldd_raster=codes) if layout else g, np.random.default_rng(5),
+                                  want_cells=150_000 if family != "deep" else 400_000)
+    sub_codes, sub_mask = sub_domain(codes, pix, W)
+    cpu = oracle.kinematicWave(sub_codes, sub_mask, p["alpha"][pix], p["beta"], p["dx"][pix], p["dt"])
+    Qc = p["Q0"][pix].copy()
+    dq = DeviceArray.from_host(np.ascontiguousarray(p["Q0"][perm]))
+    steps = 3
+    Qold = None
+    for s in range(steps):
+        q = syn.lateral_inflow(N, s)
+        dl = DeviceArray.from_host(np.ascontiguousarray(q[perm]))
+        if s == steps - 1:
+            Qold = np.empty(N); Qold[perm] = dq.download()
+        kw.route_ordered(dq, dl)
+        dl.free()
+        cpu.kinematicWaveRouting(Qc, np.ascontiguousarray(q[pix]))
+    Q = np.empty(N); Q[perm] = dq.download()
+    assert np.isfinite(Q).all() and (Q >= 0).all()
+    np.testing.assert_allclose(Q[pix], Qc, rtol=RTOL, atol=ATOL,
+                               err_msg="%s %d^2: %d catchments, %d cells" % (family, size, ncatch, pix.size))
+    # closure of every cell of the full raster for the last call (kinematic_wave_parallel_tools.py:89-92)
+    a = p["alpha"] * p["dx"] / p["dt"]
+    rhs = a * Qold ** p["beta"] + q * p["dx"] + kw.upstream_sum(Q)
+    lhs = Q + a * Q ** p["beta"]
+    resid = np.abs(lhs - rhs)
+    assert (resid <= 1e-9 * np.maximum(rhs, 1.0) + 2e-12).all(), float(resid.max())
+    dq.free(); kw.close()
+
+
+def model_step_values(N, p, rng):
+    beta, dt = p["beta"], 3600.0
+    alpha, length = p["alpha"], p["dx"]
+    alpha2 = alpha * rng.uniform(1.2, 2.0, N)
+    qlimit = 2.0 * p["Q0"] * rng.uniform(0.3, 1.2, N)
+    vals = dict(ChanLength=length, InvChanLength=1 / length, ChannelAlpha=alpha, InvChannelAlpha=1 / alpha,
+                ChannelAlpha2=alpha2, InvChannelAlpha2=1 / alpha2, QLimit=qlimit, M3Limit=alpha * length * qlimit ** beta,
+                Chan2M3Start=alpha2 * length * qlimit ** beta, Chan2QStart=qlimit * 0.1, PixelArea=np.full(N, 2.5e7),
+                IsChannelKinematic=np.ones(N, bool))
+    vals["Chan2M3Kin"] = vals["Chan2M3Start"].copy()
+    vals["ChanM3Kin"] = alpha * length * p["Q0"] ** beta
+    vals["ChanQKin"] = p["Q0"].copy()
+    vals["Chan2QKin"] = (vals["Chan2M3Kin"] / length / alpha2) ** (1 / beta)
+    return vals, dt
+
+
+def run_config4(amd, oracle, size, tmp_path):
+    """configs[4]: size^2 raster, NoRoutSteps = 24, split routing, warm start: two model steps, the state saved after
+    the first and loaded into a fresh engine -> the second step must come out bit for bit; a few hundred whole
+    catchments are checked against the oracle's 2 x 24 sub-steps."""
+    from lisflood_amd import synthetic as syn
+    from lisflood_amd.kinematic_wave_parallel import Graph, kinematicWave
+    from lisflood_amd.routing import _STATE
+    from lisflood_amd.routing_device import RoutingStepDevice
+    H = W = size
+    N = H * W
+    nsteps = 24
+    codes = syn.make_ldd("shallow", H, W, 1)
+    p = syn.router_params(N)
+    vals, dt = model_step_values(N, p, np.random.default_rng(17))
+    side = [syn.lateral_inflow(N, s) * p["dx"] * dt for s in range(2)]      # SideflowChanM3 of the two model steps
+    g = Graph(ldd_raster=codes)
+    kw = kinematicWave(None, None, p["alpha"], p["beta"], p["dx"], dt, alpha_floodplains=vals["ChannelAlpha2"], graph=g)
+    vals["SideflowChanM3"] = side[0]
+    a = RoutingStepDevice(kw, vals, True, p["beta"], 1.0 / dt, dt * nsteps)
+    perm = a.perm
+    a.run_fused(nsteps)
+    state1 = {k: a.download(k) for k in _STATE}
+    assert np.isfinite(state1["ChanQ"]).all() and (state1["ChanQ"] >= 0).all()
+    assert (state1["sumDisDay"] >= state1["ChanQ"]).all()                   # the sum holds the last ChanQ plus 23 non-negative ones
+    path = str(tmp_path / "warm.npz")
+    np.savez(path, **state1)                                                # warm-start state maps (pixel order)
+    a.dev["SideflowChanM3"].upload(np.ascontiguousarray(side[1][perm]))
+    a.dev["sumDisDay"].zero()
+    a.run_fused(nsteps)
+    second = {k: a.download(k) for k in ("ChanQ", "ChanQKin", "Chan2QKin", "ChanM3Kin", "sumDisDay")}
+    a.free()
+    # warm start: a fresh engine from the state file
+    z = np.load(path)
+    vals2 = dict(vals)
+    vals2.update({k: z[k] for k in _STATE}, SideflowChanM3=side[1])
+    vals2["sumDisDay"] = np.zeros(N)
+    b = RoutingStepDevice(kw, vals2, True, p["beta"], 1.0 / dt, dt * nsteps)
+    b.run_fused(nsteps)
+    for k, want in second.items():
+        assert np.array_equal(b.download(k), want), ("warm start", k)
+    b.free()
+    # whole catchments against the oracle: 2 x 24 split-routing sub-steps
+    pix, ncatch = pick_catchments(g, np.random.default_rng(6), want_cells=40_000, n_small=300)
+    sub_codes, sub_mask = sub_domain(codes, pix, W)
+    import types
+    v = types.SimpleNamespace(**{k: (np.ascontiguousarray(x[pix]) if isinstance(x, np.ndarray) else x) for k, x in vals.items()})
+    v.Beta, v.InvBeta, v.DtRouting, v.InvDtRouting, v.DtSec = p["beta"], 1 / p["beta"], dt, 1 / dt, dt * nsteps
+    v.CrossSection2Area, v.Sideflow1Chan, v.ChanQ = np.zeros(pix.size), np.zeros(pix.size), v.ChanQKin.copy()
+    okw = oracle.kinematicWave(sub_codes, sub_mask, v.ChannelAlpha, v.Beta, v.ChanLength, dt, alpha_floodplains=v.ChannelAlpha2)
+    sub = oracle.RoutingSubstep(okw, v)
+    for step in range(2):
+        v.sumDisDay = np.zeros(pix.size)
+        for s in range(nsteps):
+            sub.dynamic(split=True, sideflow_m3=np.ascontiguousarray(side[step][pix]))
+    for k in ("ChanQ", "ChanQKin", "Chan2QKin", "ChanM3Kin", "sumDisDay"):
+        want = getattr(v, k)
+        np.testing.assert_allclose(second[k][pix], want, rtol=1e-8, atol=1e-9 * max(1.0, float(np.abs(want).max())),
+                                   err_msg="%s (%d catchments, %d cells of %d^2)" % (k, ncatch, pix.size, size))
+    assert np.isfinite(second["ChanQ"]).all()
+    kw.close()
+
+
+def test_config4_workload_8000(amd, oracle, tmp_path):
+    run_config4(amd, oracle, 8000, tmp_path)
+
+
+@pytest.mark.skipif(os.environ.get("LF_FULL_SIZE") != "1", reason="20000^2 needs ~40 GB of host memory and several minutes: "
+                    "LF_FULL_SIZE=1 (run once per round, log under profiles/)")
+def test_config4_workload_20000(amd, oracle, tmp_path):
+    run_config4(amd, oracle, 20000, tmp_path)

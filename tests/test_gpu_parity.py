@@ -186,57 +186,6 @@ def test_route_mid_size_vs_oracle(amd, oracle, solver, family, seed):
     close(gpu.from_engine_order(Qo).download(), Qc, (family, "ordered"))
 
 
-def test_route_windowed_sweep_vs_oracle(amd, oracle, solver, monkeypatch):
-    """Experimental schedule (LF_WINDOWS=1): runs of wide levels swept in windows of up to 32 levels, one lane per
-    independent component (k_window).  260 x 3000 `deep`: ~260 levels of ~3000 cells -> windows; must equal the
-    oracle and the default per-level schedule bit for bit."""
-    from lisflood_amd import synthetic as syn
-    H, W = 260, 3000
-    codes = syn.make_ldd("deep", H, W, 2)
-    mask = np.ones((H, W), bool)
-    c = codes.reshape(-1).astype(np.float64)
-    N = H * W
-    p = syn.router_params(N, seed=14)
-    cpu = oracle.kinematicWave(c, mask, p["alpha"], p["beta"], p["dx"], p["dt"])
-    monkeypatch.setenv("LF_WINDOWS", "1")
-    gpu = amd.kw.kinematicWave(c, mask, p["alpha"], p["beta"], p["dx"], p["dt"])
-    monkeypatch.delenv("LF_WINDOWS")
-    ref = amd.kw.kinematicWave(c, mask, p["alpha"], p["beta"], p["dx"], p["dt"])
-    Qg, Qr, Qc = p["Q0"].copy(), p["Q0"].copy(), p["Q0"].copy()
-    for s in range(2):
-        q = syn.lateral_inflow(N, s)
-        gpu.kinematicWaveRouting(Qg, q); ref.kinematicWaveRouting(Qr, q); cpu.kinematicWaveRouting(Qc, q)
-        assert np.array_equal(Qg, Qr)
-        close(Qg, Qc, s)
-    assert gpu.last_launches()["launches"] < ref.last_launches()["launches"] / 4
-    Qo = gpu.to_engine_order(amd.lib.DeviceArray.from_host(p["Q0"]))
-    for s in range(2):
-        gpu.route_ordered(Qo, gpu.to_engine_order(amd.lib.DeviceArray.from_host(syn.lateral_inflow(N, s))))
-    assert np.array_equal(gpu.from_engine_order(Qo).download(), Qg)
-
-
-def test_route_hipgraph_replay(amd, monkeypatch):
-    """LF_HIPGRAPH=1: a call's launch sequence is captured once per argument set and replayed as a hipGraph.
-    Results must equal the plain stream launches bit for bit, across repeated calls and alternating buffers."""
-    from lisflood_amd import synthetic as syn
-    H, W = 200, 1500
-    codes = syn.make_ldd("deep", H, W, 2).reshape(-1).astype(np.float64)
-    mask = np.ones((H, W), bool)
-    N = H * W
-    p = syn.router_params(N, seed=15)
-    monkeypatch.setenv("LF_HIPGRAPH", "1")
-    gpu = amd.kw.kinematicWave(codes, mask, p["alpha"], p["beta"], p["dx"], p["dt"])
-    monkeypatch.delenv("LF_HIPGRAPH")
-    ref = amd.kw.kinematicWave(codes, mask, p["alpha"], p["beta"], p["dx"], p["dt"])
-    DA = amd.lib.DeviceArray
-    Qg, Qr = DA.from_host(p["Q0"]), DA.from_host(p["Q0"])
-    lats = [DA.from_host(syn.lateral_inflow(N, s)) for s in range(2)]
-    for s in range(6):                                   # 2 distinct argument sets, each replayed 3 times
-        gpu.route_device(Qg, lats[s % 2]); ref.route_device(Qr, lats[s % 2])
-        assert np.array_equal(Qg.download(), Qr.download()), s
-    assert gpu.last_launches()["launches"] == ref.last_launches()["launches"] > 100
-
-
 def test_route_full_size_closure_property(amd):
     """Size-independent property at 4000 x 4000 (1.6e7 cells, beyond what the oracle does in seconds):
     every cell satisfies the discretised kinematic-wave equation
