@@ -2,11 +2,12 @@
 
 The reference has no distributed code; this module is the host side of csrc/lf_dist.hip.  A transport is
 any object with `exchange_int32(top_send, bottom_send, n_top_recv, n_bottom_recv) -> (top_recv, bottom_recv)`
-and `allreduce_max(int) -> int`; `TorchTransport` implements it on torch.distributed (gloo is enough: only
-the tiny phase vectors travel through it at set-up); `settle_phases_local` / `loopback_route` connect
+and `allreduce_max(int) -> int`: `SocketTransport` (plain TCP, no PyTorch -- what bench.py uses) or `TorchTransport`
+(torch.distributed; gloo is enough: only the tiny phase vectors travel through it at set-up); `settle_phases_local` / `loopback_route` connect
 several blocks living in one process (tests, single-GPU loopback).
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -189,6 +190,136 @@ class TorchTransport:
         t = torch.tensor([int(value)], dtype=torch.int64)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return int(t.item())
+
+
+class SocketTransport:
+    """Rendezvous and set-up transport over plain TCP sockets -- no PyTorch (BASELINE.json's north_star): rank 0 listens,
+    every other rank connects, collectives are a gather to rank 0 and a scatter back.  Only set-up traffic goes through
+    it (the phase fixpoint's int32 vectors, the 128-byte RCCL id, barriers and the max-over-ranks clock of the bench);
+    the data path is RCCL.
+
+    Rendezvous on one node: rank 0 binds an ephemeral port and publishes it in a file named after MASTER_ADDR /
+    MASTER_PORT (+ torchrun's TORCHELASTIC_RUN_ID when present), so it works under `python -m torch.distributed.run`
+    -- whose agent owns MASTER_PORT itself -- as well as under any launcher that sets RANK / WORLD_SIZE."""
+
+    def __init__(self, rank, nranks, rendezvous_file, timeout=300.0):
+        import pickle
+        import socket
+        import struct
+        import time
+        self.rank, self.nranks, self._pickle, self._struct = rank, nranks, pickle, struct
+        self.peers = {}
+        if nranks == 1:
+            return
+        if rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind(("127.0.0.1", 0))
+            srv.listen(nranks)
+            srv.settimeout(timeout)
+            tmp = rendezvous_file + ".tmp%d" % os.getpid()
+            with open(tmp, "w") as f:
+                f.write(str(srv.getsockname()[1]))
+            os.replace(tmp, rendezvous_file)
+            for _ in range(nranks - 1):
+                c, _addr = srv.accept()
+                c.settimeout(timeout)
+                c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                self.peers[self._recv(c)] = c
+            srv.close()
+            try:
+                os.unlink(rendezvous_file)
+            except OSError:
+                pass
+        else:
+            t0 = time.time()
+            port = None
+            while port is None:
+                try:
+                    with open(rendezvous_file) as f:
+                        port = int(f.read().strip())
+                except (OSError, ValueError):
+                    if time.time() - t0 > timeout:
+                        raise TimeoutError("rank 0 never published %s" % rendezvous_file)
+                    time.sleep(0.05)
+            c = socket.create_connection(("127.0.0.1", port), timeout=timeout)
+            c.settimeout(timeout)
+            c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            self._send(c, rank)
+            self.peers[0] = c
+
+    @classmethod
+    def from_env(cls, timeout=300.0):
+        """RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT as torch.distributed.run (or any launcher) exports them"""
+        import tempfile
+        rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+        tag = "%s_%s_%s" % (os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT", "29500"),
+                            os.environ.get("TORCHELASTIC_RUN_ID", "none"))
+        path = os.path.join(tempfile.gettempdir(), "lisflood_amd_rdv_" + "".join(ch if ch.isalnum() else "_" for ch in tag))
+        return cls(rank, world, path, timeout)
+
+    def _send(self, sock, obj):
+        data = self._pickle.dumps(obj, protocol=4)
+        sock.sendall(self._struct.pack("<q", len(data)) + data)
+
+    def _recv(self, sock):
+        def exact(n):
+            buf = bytearray()
+            while len(buf) < n:
+                chunk = sock.recv(min(n - len(buf), 1 << 20))
+                if not chunk:
+                    raise ConnectionError("peer closed the connection")
+                buf += chunk
+            return bytes(buf)
+        n, = self._struct.unpack("<q", exact(8))
+        return self._pickle.loads(exact(n))
+
+    def allgather(self, obj):
+        """-> [obj of rank 0, obj of rank 1, ...] on every rank"""
+        if self.nranks == 1:
+            return [obj]
+        if self.rank == 0:
+            out = [obj] + [None] * (self.nranks - 1)
+            for r, c in self.peers.items():
+                out[r] = self._recv(c)
+            for c in self.peers.values():
+                self._send(c, out)
+            return out
+        self._send(self.peers[0], obj)
+        return self._recv(self.peers[0])
+
+    def barrier(self):
+        self.allgather(None)
+
+    def broadcast(self, obj, src=0):
+        return self.allgather(obj if self.rank == src else None)[src]
+
+    def allreduce(self, value, op="max"):
+        vals = self.allgather(value)
+        f = {"max": np.maximum, "min": np.minimum, "sum": np.add}[op]
+        out = np.asarray(vals[0])
+        for v in vals[1:]:
+            out = f(out, np.asarray(v))
+        return out
+
+    def allreduce_max(self, value):
+        return int(self.allreduce(int(value), "max"))
+
+    def exchange_int32(self, top_send, bottom_send, n_top_recv, n_bottom_recv):
+        """set-up vectors with the vertical neighbours (rank -/+ 1): my top ghosts = the upper rank's bottom exports"""
+        allv = self.allgather((np.ascontiguousarray(top_send, np.int32), np.ascontiguousarray(bottom_send, np.int32)))
+        top = allv[self.rank - 1][1] if self.rank > 0 else np.zeros(0, np.int32)
+        bot = allv[self.rank + 1][0] if self.rank + 1 < self.nranks else np.zeros(0, np.int32)
+        assert top.size == n_top_recv and bot.size == n_bottom_recv
+        return top, bot
+
+    def close(self):
+        for c in self.peers.values():
+            try:
+                c.close()
+            except OSError:
+                pass
+        self.peers = {}
 
 
 class Comm:

@@ -1,8 +1,9 @@
 """bench.py's N > 1 leg: the raster is split into row blocks, one rank (process, GPU) per block, launched by
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
-torch.distributed (gloo) is used for rendezvous, the set-up fixpoint, the barrier and the max-over-ranks
-time; the data path (halo exchange of boundary discharge every call) is RCCL Send/Recv over xGMI from
-csrc/lf_dist.hip.  Strong scaling: the raster (BASELINE.json: 10000 x 10000) is fixed, each rank owns H/N rows.
+(or any launcher that exports RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT).  No PyTorch in the ranks:
+rendezvous, the set-up fixpoint, the barrier and the max-over-ranks clock go through lisflood_amd.dist.SocketTransport
+(plain TCP on the node); the data path (halo exchange of boundary discharge every call) is RCCL Send/Recv over xGMI
+from csrc/lf_dist.hip.  Strong scaling: the raster (BASELINE.json: 10000 x 10000) is fixed, each rank owns H/N rows.
 """
 import json
 import os
@@ -19,7 +20,7 @@ def log(rank, *a):
     print("[bench rank %d]" % rank, *a, file=sys.stderr, flush=True)
 
 
-def catchment_leg(a, dist, torch, rank, world, device):
+def catchment_leg(a, T, rank, world, device):
     """Same raster, same calls, ranks own whole catchments (lisflood_amd.partition): no halo, no collective on the data
     path.  Every rank derives the partition from the full LDD itself (set-up, untimed)."""
     from . import _lib
@@ -28,7 +29,7 @@ def catchment_leg(a, dist, torch, rank, world, device):
     from .kinematic_wave_parallel import Graph, kinematicWave
     H = W = a.size
     N = H * W
-    seed = {"shallow": 1, "deep": 2}[a.family]
+    seed = {"shallow": 1, "deep": 2, "river": 7}[a.family]
     t0 = time.time()
     nq = 3
     err = None
@@ -60,41 +61,33 @@ def catchment_leg(a, dist, torch, rank, world, device):
     except Exception as e:
         err = repr(e)
     # all ranks take the same branch: a rank that failed its set-up must not leave the others in a barrier
-    flag = torch.tensor([0 if err else 1], dtype=torch.int64)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    if int(flag.item()) == 0:
+    if int(T.allreduce(0 if err else 1, "min")) == 0:
         return {"error": err or "set-up failed on another rank"}
     for s in range(a.warmup):
         kw.route_ordered(Q, qs[s % nq])
     _lib.synchronize(device)
-    dist.barrier()
+    T.barrier()
     t0 = time.perf_counter()
     for s in range(a.steps):
         kw.route_ordered(Q, qs[s % nq])
     _lib.synchronize(device)
     dt_local = time.perf_counter() - t0
-    dist.barrier()
-    t = torch.tensor([dt_local], dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    T.barrier()
+    dt_max = float(T.allreduce(dt_local, "max"))
     Qh = Q.download()
-    ok = torch.tensor([float(np.isfinite(Qh).all() and (Qh >= 0).all()), float(n)], dtype=torch.float64)
-    dist.all_reduce(ok, op=dist.ReduceOp.SUM)
-    cells = torch.zeros(world, dtype=torch.int64)
-    cells[rank] = n
-    dist.all_reduce(cells, op=dist.ReduceOp.SUM)
+    ok = T.allreduce(np.array([float(np.isfinite(Qh).all() and (Qh >= 0).all()), float(n)]), "sum")
+    cells = T.allgather(int(n))
     for d in qs + [Q]:
         d.free()
     kw.close()
-    ms = float(t.item()) * 1e3 / a.steps
+    ms = dt_max * 1e3 / a.steps
     return {"value": round(N / ms / 1e3, 2), "unit": "Mcell-steps/s", "ms_per_step": round(ms, 4),
-            "cells_per_rank": [int(x) for x in cells.tolist()], "catchments": int(sizes.size),
-            "largest_catchment": int(sizes.max()), "finite": bool(ok[0].item() == world and int(ok[1].item()) == N),
+            "cells_per_rank": [int(x) for x in cells], "catchments": int(sizes.size),
+            "largest_catchment": int(sizes.max()), "finite": bool(ok[0] == world and int(ok[1]) == N),
             "note": "ranks own whole catchments (no exchange on the data path); engine-order vectors as in the N = 1 run"}
 
 
 def main(a):
-    import torch
-    import torch.distributed as dist
     from . import _lib
     from . import dist as D
     from . import synthetic as syn
@@ -102,16 +95,12 @@ def main(a):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", str(a.gpus)))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29500")
-    import datetime
-    # a rank that dies must not leave the others waiting for gloo's 30-minute default
-    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
+    T = D.SocketTransport.from_env(timeout=300.0)     # a rank that dies must not leave the others waiting for ever
     ndev = _lib.device_count()
     device = local_rank % max(ndev, 1)
     t_setup = time.time()
     H = W = a.size
-    seed = {"shallow": 1, "deep": 2}[a.family]
+    seed = {"shallow": 1, "deep": 2, "river": 7}[a.family]
     r0, r1 = D.row_blocks(H, world)[rank]
     g0, g1 = max(0, r0 - 1), min(H, r1 + 1)
     codes = syn.make_ldd(a.family, H, W, seed, r0=g0, r1=g1)
@@ -119,10 +108,9 @@ def main(a):
     bot = codes[-1] if r1 < H else None
     local = codes[(r0 - g0):(r0 - g0) + (r1 - r0)]
     graph = D.DistGraph(local, None, top, None, bot, None)
-    D.settle_phases(graph, D.TorchTransport(dist))
-    uid = [D.Comm.unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(uid, src=0)
-    comm = D.Comm(uid[0], world, rank, device)
+    D.settle_phases(graph, T)
+    uid = T.broadcast(D.Comm.unique_id() if rank == 0 else None, src=0)
+    comm = D.Comm(uid, world, rank, device)
     N = H * W
     i0, i1 = r0 * W, r1 * W
     p = syn.router_params_slice(N, i0, i1)
@@ -138,26 +126,22 @@ def main(a):
     for s in range(a.warmup):
         router.route(Q, qs[s % nq])
     _lib.synchronize(device)
-    dist.barrier()
+    T.barrier()
     t0 = time.perf_counter()
     for s in range(a.steps):
         router.route(Q, qs[s % nq])
     _lib.synchronize(device)
     dt_local = time.perf_counter() - t0
-    dist.barrier()
-    t = torch.tensor([dt_local], dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt_max = float(t.item())
+    T.barrier()
+    dt_max = float(T.allreduce(dt_local, "max"))
     Qh = router.download_pix(Q)
-    chk = torch.tensor([float(Qh.sum()), float(np.isfinite(Qh).all() and (Qh >= 0).all())], dtype=torch.float64)
-    dist.all_reduce(chk, op=dist.ReduceOp.SUM)
-    launches = torch.tensor([router.last_launches()], dtype=torch.int64)
-    dist.all_reduce(launches, op=dist.ReduceOp.MAX)
+    chk = T.allreduce(np.array([float(Qh.sum()), float(np.isfinite(Qh).all() and (Qh >= 0).all())]), "sum")
+    launches = int(T.allreduce(int(router.last_launches()), "max"))
     # secondary: the same raster partitioned by whole catchments -- no exchange, every rank runs the single-GPU engine
     catch = None
     if not getattr(a, "no_extra", False):
         try:
-            catch = catchment_leg(a, dist, torch, rank, world, device)
+            catch = catchment_leg(a, T, rank, world, device)
         except Exception as e:  # must never cost the headline line
             catch = {"error": repr(e)}
     if rank == 0:
@@ -168,11 +152,12 @@ def main(a):
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%dx%d fp64 raster, %s LDD (seed %d), all land, beta=0.6, 1 router call per step"
-                                   % (H, W, "random ('shallow')" if a.family == "shallow" else "sheet-flow ('deep')",
-                                      seed),
-                       "cells": N, "phases": graph.num_phases, "max_launches_per_step": int(launches.item()),
+                                   % (H, W, {"shallow": "random ('shallow')", "deep": "sheet-flow ('deep')",
+                                             "river": "dendritic ('river')"}[a.family], seed),
+                       "cells": N, "phases": graph.num_phases, "max_launches_per_step": launches,
                        "layout": "engine sweep order per rank, ghost slots appended",
-                       "parallelism": "row-block x%d, RCCL Send/Recv halo per phase" % world},
+                       "parallelism": "row-block x%d, RCCL Send/Recv halo per phase; rendezvous over TCP sockets "
+                                      "(no PyTorch in the ranks)" % world},
             "hbm_frac_whole_step": round(B_ALG * N / (ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), 6),
             # per-GPU algorithmic bandwidth over the WHOLE step (sweeps + packs + RCCL halo rounds), not a
             # per-kernel hipEvent figure: the per-kernel roofline is reported by the N = 1 run
@@ -180,11 +165,11 @@ def main(a):
                          "achieved": round(B_ALG * N / world / (ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(B_ALG * N / world / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
                          "traffic": None},
-            "checksum_sumQ": float(chk[0].item()), "finite": bool(chk[1].item() == world),
+            "checksum_sumQ": float(chk[0]), "finite": bool(chk[1] == world),
         }
         if catch is not None:
             out["catchment_partition"] = catch
         print(json.dumps(out), flush=True)
-    dist.barrier()
+    T.barrier()
     comm.close()
-    dist.destroy_process_group()
+    T.close()

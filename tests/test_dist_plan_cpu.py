@@ -122,3 +122,31 @@ def test_two_process_gloo_run():
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "DIST_GLOO_OK" in r.stdout
+
+
+def test_three_process_socket_run():
+    """3 ranks, no PyTorch: rendezvous, fixpoint and halo values over lisflood_amd.dist.SocketTransport (what bench.py's
+    N > 1 leg uses for everything but the RCCL data path); result bit-identical to the single-domain oracle."""
+    procs = []
+    for rank in range(3):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="3", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT="29547", TORCHELASTIC_RUN_ID="pytest%d" % os.getpid(), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker_socket.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, o[-2000:] + e[-2000:]
+    assert "DIST_SOCKET_OK" in outs[0][0] and "ranks=3" in outs[0][0]
+
+
+def test_bench_dist_leg_is_torch_free():
+    """the N > 1 bench leg and the transport it uses import no PyTorch (north_star: ctypes host code, no PyTorch)"""
+    import ast
+    for name in ("dist_bench.py", "dist.py"):
+        tree = ast.parse(open(os.path.join(ROOT, "lisflood-code_amd", "lisflood_amd", name)).read())
+        top = [n for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom))]
+        mods = [a.name for n in top if isinstance(n, ast.Import) for a in n.names] + \
+               [n.module or "" for n in top if isinstance(n, ast.ImportFrom)]
+        assert not any(m.split(".")[0] == "torch" for m in mods), (name, mods)
+    src = open(os.path.join(ROOT, "lisflood-code_amd", "lisflood_amd", "dist_bench.py")).read()
+    assert "import torch" not in src

@@ -139,14 +139,15 @@ def run_config4(amd, oracle, size, tmp_path):
     assert np.isfinite(state1["ChanQ"]).all() and (state1["ChanQ"] >= 0).all()
     assert (state1["sumDisDay"] >= state1["ChanQ"]).all()                   # the sum holds the last ChanQ plus 23 non-negative ones
     path = str(tmp_path / "warm.npz")
-    np.savez(path, **state1)                                                # warm-start state maps (pixel order)
+    if size <= 8000:
+        np.savez(path, **state1)                                            # warm-start state maps (pixel order)
     a.dev["SideflowChanM3"].upload(np.ascontiguousarray(side[1][perm]))
     a.dev["sumDisDay"].zero()
     a.run_fused(nsteps)
     second = {k: a.download(k) for k in ("ChanQ", "ChanQKin", "Chan2QKin", "ChanM3Kin", "sumDisDay")}
     a.free()
     # warm start: a fresh engine from the state file
-    z = np.load(path)
+    z = np.load(path) if size <= 8000 else state1                           # (20000^2: 25 GB of state stay in memory)
     vals2 = dict(vals)
     vals2.update({k: z[k] for k in _STATE}, SideflowChanM3=side[1])
     vals2["sumDisDay"] = np.zeros(N)

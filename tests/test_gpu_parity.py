@@ -1,6 +1,7 @@
 """-m gpu: parity of the HIP path (through the C ABI) against the CPU oracle and the committed golden
 vectors.  Tolerances: fp64, rtol 1e-9 / atol 1e-12 for routing (north-star bar: 1e-6 relative) -- OCML
 pow differs from glibc pow in the last ulp and the Newton iteration damps it; soil rtol 1e-9."""
+import os
 import types
 
 import numpy as np
@@ -1208,3 +1209,27 @@ def test_soil_pf_golden(amd):
     for k in ("pF0", "pF1", "pF2"):
         np.testing.assert_allclose(getattr(v, k), g[k], rtol=1e-12, atol=1e-13, err_msg=k)
     assert (v.pF0 == 7.0).any() and (v.pF2 == -1.0).any()
+
+
+@pytest.mark.parametrize("family", ["saddle", "shallow"])
+def test_two_rank_rccl_halo_exchange(amd, family):
+    """The multi-GPU transport itself: 2 processes, one GPU each, boundary discharge over RCCL Send/Recv
+    (lf_dist_router_route) against the single-domain oracle.  Needs two visible devices; the single-GPU boxes run the
+    same kernels and plan through the device-copy loopback (test_row_block_partition_loopback)."""
+    import subprocess
+    import sys
+    from lisflood_amd import _lib
+    if _lib.device_count() < 2:
+        pytest.skip("one GPU visible: RCCL Send/Recv needs a second device")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT="29561", TORCHELASTIC_RUN_ID="rccl%d" % os.getpid(), LF_TEST_FAMILY=family,
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "tests", "dist_worker_rccl.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, o[-2000:] + e[-2000:]
+    assert "DIST_RCCL_OK" in outs[0][0]
