@@ -24,6 +24,7 @@ from ._lib import DeviceArray, check, f64, lib, u8
 from .kinematic_wave_parallel import Graph, kinematicWave
 
 FORCING = ("Rain", "SnowMelt", "EWRef", "ETRef", "ESRef")
+_CHANNEL_NAMES = set(RT._STATIC + RT._STATE + RT._OUT)
 
 
 class HotPathDevice:
@@ -296,6 +297,150 @@ class HotPathDevice:
                     a = z["site_" + k]
                     self.rmod._st["dev"][k].upload(f64(self.rmod._up(a[self.ids]) if k == "TransCum" else a))
         self.steps_done = int(z["steps_done"])
+
+    # ---- state maps under the reference's names (default_options.py: the 'repStateMaps' / 'repEndMaps' entries) --------
+    # name of the state map -> (attribute, row of a [3,N] array or None).  What the reference writes at a state step and
+    # reads back through the *InitValue bindings of a warm run (settings/warm.xml); -9999 in a map read back means "cold
+    # start value" (routing.py:203-218, surface_routing.py:49-63, soil.py:239-251, 393-406, groundwater.py:93-107).
+    STATE_MAPS = dict(
+        ChanQState=("ChanQ", None), ChanCrossSectionState=("TotalCrossSectionArea", None),
+        CrossSection2State=("CrossSection2Area", None), ChSideState=("Sideflow1Chan", None),
+        OFDirectState=("OFM3Direct", None), OFOtherState=("OFM3Other", None), OFForestState=("OFM3Forest", None),
+        CumIntSealedState=("CumInterSealed", None), LZState=("LZ", None),
+        CumInterceptionState=("CumInterception", 0), CumInterceptionForestState=("CumInterception", 1),
+        CumInterceptionIrrigationState=("CumInterception", 2),
+        DSLRState=("DSLR", 0), DSLRForestState=("DSLR", 1), DSLRIrrigationState=("DSLR", 2),
+        UZState=("UZ", 0), UZForestState=("UZ", 1), UZIrrigationState=("UZ", 2),
+        Theta1State=("Theta1a", 0), Theta1ForestState=("Theta1a", 1), Theta1IrrigationState=("Theta1a", 2),
+        Theta2State=("Theta1b", 0), Theta2ForestState=("Theta1b", 1), Theta2IrrigationState=("Theta1b", 2),
+        Theta3State=("Theta2", 0), Theta3ForestState=("Theta2", 1), Theta3IrrigationState=("Theta2", 2),
+        LakeLevelState=("LakeLevel", None), LakePrevInflowState=("LakeInflowOld", None),
+        LakePrevOutflowState=("LakeOutflow", None), ReservoirFillState=("ReservoirFill", None))
+
+    def state_maps(self):
+        """dict: reference state-map name -> [N] vector in pixel order -- what `repStateMaps` writes at a state step"""
+        out = {}
+        chan = {k: self.download(k) for k in ("ChanQ", "ChanM3Kin", "Chan2M3Kin", "Chan2M3Start", "InvChanLength",
+                                              "CrossSection2Area", "Sideflow1Chan")}
+        m3 = chan["ChanM3Kin"] + chan["Chan2M3Kin"] - chan["Chan2M3Start"] if self.split else chan["ChanM3Kin"]
+        chan["TotalCrossSectionArea"] = m3 * chan["InvChanLength"]                  # Lisflood_dynamic.py:194-205
+        depth = {k: self.download(k) for k in ("SoilDepth1a", "SoilDepth1b", "SoilDepth2")}
+        pore = {k: self.download(k) for k in ("PoreSpaceNotZero1a", "PoreSpaceNotZero1b", "PoreSpaceNotZero2")}
+        for name, (attr, row) in self.STATE_MAPS.items():
+            if attr in chan:
+                out[name] = chan[attr]
+            elif attr.startswith("Theta"):          # thetaFun: W / SoilDepth, 0 without pore space (soilloop.py:386-387)
+                lay = attr[5:]
+                w, d, p = self.download("W" + lay)[row], depth["SoilDepth" + lay][row], pore["PoreSpaceNotZero" + lay][row]
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    out[name] = np.where(p != 0, w / d, 0.0)
+            elif attr in ("LakeLevel", "LakeInflowOld", "LakeOutflow", "ReservoirFill"):
+                if self.rmod is None:
+                    continue
+                cc = {"LakeLevel": "LakeLevelCC", "LakeInflowOld": "LakeInflowOldCC", "LakeOutflow": "LakeOutflowCC",
+                      "ReservoirFill": "ReservoirFillCC"}[attr]
+                if cc not in self.rmod._st["dev"]:
+                    continue
+                idx = np.asarray(self.rmod.var.LakeIndex if attr.startswith("Lake") else self.rmod.var.ReservoirIndex)
+                dense = np.zeros(self.N)
+                dense[self.ids[idx]] = self.rmod._st["dev"][cc].download()          # lakes.py:283-292, reservoir.py:311-315
+                out[name] = dense
+            elif attr in self.d:
+                a = self.download(attr)
+                out[name] = a if row is None else a[row]
+        return out
+
+    def load_state_maps(self, maps):
+        """Warm start from state maps under the reference's names (what a warm run reads through its *InitValue
+        bindings); a map that is missing, or -9999, keeps the value this object was constructed with -- the reference's
+        cold-start rule.  The channel state is rebuilt from TotalCrossSectionArea / CrossSection2Area exactly as
+        routing.initial + initialSecond do (routing.py:203-218, 391-397); like the reference's, such a warm start
+        continues to rounding, not to the bit (use save_state / load_state for that)."""
+        g = lambda name: (None if name not in maps else np.asarray(maps[name], np.float64))
+        up = lambda attr, a: self.d[attr].upload(f64(a[self.gpix] if attr in _CHANNEL_NAMES else a))
+        cur = lambda attr: self.download(attr)
+        beta = self.sc["Beta"]
+        # channel (routing.py:203-218, 243-248, 391-397)
+        area = g("ChanCrossSectionState")
+        if area is not None:
+            length, alpha = cur("ChanLength"), cur("ChannelAlpha")
+            with np.errstate(divide="ignore", invalid="ignore"):
+                m3_cur = cur("ChanM3Kin") + (cur("Chan2M3Kin") - cur("Chan2M3Start") if self.split else 0.0)
+                chan_m3 = np.where(area == -9999, m3_cur, area * length)
+                if self.split:
+                    c2 = g("CrossSection2State")
+                    c2 = cur("CrossSection2Area") if c2 is None else np.where(c2 == -9999, 0.0, c2)
+                    start, alpha2 = cur("Chan2M3Start"), cur("ChannelAlpha2")
+                    m3_2 = c2 * length + start
+                    m3_1 = chan_m3 - m3_2 + start
+                    m3_1 = np.where((m3_1 < 0.0) & (m3_1 > -0.0000001), 0.0, m3_1)
+                    up("CrossSection2Area", c2); up("Chan2M3Kin", m3_2); up("ChanM3Kin", m3_1)
+                    up("Chan2QKin", (m3_2 * (1 / length) * (1 / alpha2)) ** (1 / beta))
+                    up("ChanQKin", (m3_1 * (1 / length) * (1 / alpha)) ** (1 / beta))
+                else:
+                    up("ChanM3Kin", chan_m3)
+                    up("ChanQKin", np.where(alpha > 0, (chan_m3 / length / alpha) ** (1 / beta), 0.0))
+        q = g("ChanQState")
+        if q is not None:
+            up("ChanQ", np.where(q == -9999, cur("ChanQKin"), q))                   # routing.py:332-334
+        side = g("ChSideState")
+        if side is not None and self.split:
+            up("Sideflow1Chan", np.where(side == -9999, 0.0, side))
+        # overland flow (surface_routing.py:49-63, 93-95)
+        ofa = self.d["OFAlpha"].download()
+        for name, row in (("Other", 0), ("Forest", 1), ("Direct", 2)):
+            m3 = g("OF%sState" % name)
+            if m3 is None:
+                continue
+            m3 = np.where(m3 == -9999, 0.0, m3)
+            up("OFM3" + name, m3)
+            up("OFQ" + name, (m3 * (1 / self.sc["PixelLength"]) * (1 / ofa[row])) ** (1 / beta))
+        # soil, groundwater, interception
+        for attr in ("CumInterception", "DSLR", "UZ"):
+            a = cur(attr)
+            hit = False
+            for name, (at, row) in self.STATE_MAPS.items():
+                if at == attr and g(name) is not None:
+                    x = g(name)
+                    a[row] = np.where(x == -9999, a[row], x)
+                    hit = True
+            if hit:
+                up(attr, np.maximum(a, 1) if attr == "DSLR" else a)                  # soil.py:396-398
+        for lay, thetas in (("1a", "Theta1"), ("1b", "Theta2"), ("2", "Theta3")):
+            w, depth, pore = cur("W" + lay), cur("SoilDepth" + lay), cur("PoreSpaceNotZero" + lay)
+            hit = False
+            for row, suffix in enumerate(("State", "ForestState", "IrrigationState")):
+                x = g(thetas + suffix)
+                if x is not None:
+                    w[row] = np.where(pore[row] != 0, np.where(x == -9999, w[row], x * depth[row]), 0.0)   # soil.py:261-267
+                    hit = True
+            if hit:
+                up("W" + lay, w)
+        if any(g(n) is not None for n in ("Theta1State", "Theta2State", "Theta1ForestState", "Theta2ForestState",
+                                          "Theta1IrrigationState", "Theta2IrrigationState")):
+            up("W1", cur("W1a") + cur("W1b"))                                       # soil.py:268
+        for name, attr in (("LZState", "LZ"), ("CumIntSealedState", "CumInterSealed")):
+            x = g(name)
+            if x is not None:
+                up(attr, np.where(x == -9999, cur(attr), x))
+        if self.rmod is not None:
+            dev = self.rmod._st["dev"]
+            for name, cc, idx_name in (("LakeLevelState", "LakeLevelCC", "LakeIndex"),
+                                       ("LakePrevInflowState", "LakeInflowOldCC", "LakeIndex"),
+                                       ("LakePrevOutflowState", "LakeOutflowCC", "LakeIndex"),
+                                       ("ReservoirFillState", "ReservoirFillCC", "ReservoirIndex")):
+                x = g(name)
+                if x is None or cc not in dev:
+                    continue
+                sites = self.ids[np.asarray(getattr(self.rmod.var, idx_name))]
+                val = np.where(x[sites] == -9999, dev[cc].download(), x[sites])
+                dev[cc].upload(f64(val))
+                if cc == "LakeLevelCC":          # lakes.py:119-121: storage from level x area
+                    area = dev["LakeAreaCC"].download()
+                    dev["LakeStorageM3CC"].upload(f64(val * area))
+                    dev["LakeStorageM3BalanceCC"].upload(f64(val * area))
+                if cc == "ReservoirFillCC":      # reservoir.py:152-157
+                    dev["ReservoirStorageM3CC"].upload(f64(val * dev["TotalReservoirStorageM3CC"].download()))
 
     def mass_balance(self):
         """Option repMBTs after a step() with structures: downloads the channel state into the routing module's `var`

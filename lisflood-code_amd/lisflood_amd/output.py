@@ -141,3 +141,35 @@ def read_netcdf_classic(path, var_name):
         dy, dx = v.dimensions[-2:]
         t = np.array(f.variables["time"][:]) if "time" in f.variables else None
         return a, np.array(f.variables[dx][:]), np.array(f.variables[dy][:]), t
+
+
+def write_state_maps(directory, maps, land_mask, x=None, y=None, time_value=None, **kw):
+    """One file per state map, named as the reference names it (`ChanQState.nc`, `Theta1ForestState.nc`, ...: the
+    'repStateMaps' entries of default_options.py), each a [1, H, W] stack at the state step -- what a warm run reads back
+    through its *InitValue bindings.  `maps`: name -> compressed [N] vector (HotPathDevice.state_maps())."""
+    import os
+    land_mask = np.asarray(land_mask, bool)
+    H, W = land_mask.shape
+    x = np.arange(W, dtype=np.float64) if x is None else x
+    y = np.arange(H, dtype=np.float64)[::-1] if y is None else y
+    os.makedirs(directory, exist_ok=True)
+    for name, vec in maps.items():
+        stack = decompress(vec, land_mask, fill=np.nan)[None]
+        write_netcdf_classic(os.path.join(directory, name + ".nc"), name, stack, x, y,
+                             time_values=[0.0 if time_value is None else float(time_value)], **kw)
+
+
+def read_state_maps(directory, land_mask, names=None):
+    """-> name -> compressed [N] vector; a missing value inside the land mask reads as -9999 (cold start)"""
+    import glob
+    import os
+    land_mask = np.asarray(land_mask, bool)
+    out = {}
+    for path in sorted(glob.glob(os.path.join(directory, "*.nc"))):
+        name = os.path.splitext(os.path.basename(path))[0]
+        if names is not None and name not in names:
+            continue
+        a = read_netcdf_classic(path, name)[0]
+        v = a[-1][land_mask] if a.ndim == 3 else a[land_mask]
+        out[name] = np.where(np.isnan(v), FILL, v)
+    return out

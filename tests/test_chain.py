@@ -266,3 +266,44 @@ def test_subcatchment_run_equals_the_whole_domain(amd):
         for k in ("ChanQ", "ChanQKin", "Chan2QKin", "W1a", "UZ", "LZ", "OFQOther"):
             assert np.array_equal(part.download(k), whole.download(k)[..., ids]), (step, k)
     whole.free(); part.free()
+
+
+@pytest.mark.gpu
+def test_warm_start_from_reference_named_state_maps(amd, tmp_path):
+    """f4: the state of the resident chain written as the reference's state maps (ChanQState, ChanCrossSectionState,
+    Theta1ForestState, ... default_options.py 'repStateMaps'), read back, and a FRESH engine warm-started from them
+    (-9999 = cold value, channel state rebuilt as routing.initial / initialSecond do): the run continues to rounding
+    -- like the reference's own warm start, which goes through the same maps -- and dis stays within 1e-9."""
+    from lisflood_amd import output as out
+    from lisflood_amd.hotpath import HotPathDevice
+    g, values, sc, st, forcing = fixture()
+    mask = g["mask"]
+    mk = lambda: HotPathDevice(cp(values), sc, mask, g["ldd_to_chan"], g["ldd_cut"], split=True, structures=cp(st))
+    a = mk()
+    for step in range(4):
+        a.step(forcing[step], step + 1, QInM3=g["QInM3"][step])
+    maps = a.state_maps()
+    assert set(maps) == set(HotPathDevice.STATE_MAPS)
+    np.testing.assert_allclose(maps["ChanQState"], g["out_ChanQ"][3], rtol=1e-9)
+    out.write_state_maps(str(tmp_path / "state"), maps, mask, time_value=4)
+    back = out.read_state_maps(str(tmp_path / "state"), mask)
+    assert set(back) == set(maps) and all(np.array_equal(back[k], maps[k]) for k in maps)
+    b = mk()
+    b.load_state_maps(back)
+    b.set_inflow(g["QInM3"][3])                    # the previous step's hydrograph (QInM3Old) is not a state map
+    for step in range(4, 8):
+        a.step(forcing[step], step + 1, QInM3=g["QInM3"][step])
+        b.step(forcing[step], step + 1, QInM3=g["QInM3"][step])
+        close(b.chan_q_avg(), a.chan_q_avg(), 1e-9, (step, "dis after the warm start"))
+        close(b.chan_q_avg(), g["out_ChanQAvg"][step], 1e-9, (step, "dis vs the reference chain"))
+        close(b.download("W1a"), a.download("W1a"), 1e-12, (step, "W1a"))
+    # -9999 everywhere = the cold-start values the engine was built with
+    c = mk()
+    before = {k: c.download(k) for k in ("ChanQ", "ChanQKin", "Chan2QKin", "W1a", "W2", "UZ", "LZ", "OFQOther")}
+    c.load_state_maps({k: np.full(int(mask.sum()), -9999.0) for k in maps})
+    for k, want in before.items():
+        if k == "OFQOther":
+            continue                                # -9999 means "no water on the surface" (surface_routing.py:57-63)
+        close(c.download(k), want, 1e-12, ("cold", k))
+    assert (c.download("OFQOther") == 0).all()
+    a.free(); b.free(); c.free()
