@@ -439,6 +439,9 @@ int lf_interception_device(int device, const lf_interception_args *a);
 int lf_soil_columns_device(int device, const lf_soil_args *a);
 /* instrumentation: columns of the last lf_soil_columns_device call that needed > 1 Courant sub-step */
 int lf_soil_last_deferred(int device, int64_t *count);
+/* ... and their histogram by trip count (hist[k] = columns with k sub-steps, last bin = nbins-1 or more; the engine
+ * keeps counts up to 127) */
+int lf_soil_substep_histogram(int device, int64_t *hist, int nbins);
 
 /* ---------------------------------------------------------------------------------------------
  * multi-GPU: the raster is split into contiguous row blocks, one rank (process, GPU) per block; boundary

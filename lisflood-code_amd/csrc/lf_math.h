@@ -121,50 +121,124 @@ __device__ __forceinline__ double lf_solve_3_5(double c, double a)
 // ~70 instructions, relative error ~1e-15 for |y log2 x| <= 50 (measured against OCML in the gpu tests).
 // x == 0 -> 0, x == 1 -> 1, NaN propagates, x == +inf -> +inf.
 // ------------------------------------------------------------------------------------------------
+#ifndef LF_RCP_SEED
+#define LF_RCP_SEED(d) __builtin_amdgcn_rcp(d)
+#define LF_FREXP_EXP(x) __builtin_amdgcn_frexp_exp(x)
+#define LF_FREXP_MANT(x) __builtin_amdgcn_frexp_mant(x)
+#endif
+// N independent powers in LOCKSTEP: every stage of the algorithm is written for all N arguments before the next stage,
+// so the N dependent chains are interleaved in the instruction stream (the scheduler keeps calls that follow one another
+// in the source one after the other, each a ~90-instruction dependent chain: measured 45 % VALU busy at two wavefronts
+// per SIMD).  Element by element the arithmetic is exactly that of one call.
+template <int N>
+__device__ __forceinline__ void lf_pow_pos_n(const double (&x)[N], const double (&y)[N], double (&out)[N])
+{
+    // branch-free: the main path runs on a sanitised argument and the special cases are selected at the end by plain
+    // two-operand selects (no nested conditional expressions: the compiler turns those into divergent branches, which
+    // cut the caller's loop body into basic blocks)
+    bool pos[N];
+    int e[N];
+    double f[N], s[N], R[N], hfsq[N], l2m[N], p[N], p_err[N], n[N], u[N], ex[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        pos[i] = x[i] > 0.0;
+        const double xs = pos[i] ? x[i] : 1.0;
+        e[i] = LF_FREXP_EXP(xs);
+        double m = LF_FREXP_MANT(xs); // [0.5, 1)
+        const bool lo = m < 0.70710678118654752440;
+        m = lo ? m * 2.0 : m;
+        e[i] = lo ? e[i] - 1 : e[i];
+        f[i] = m - 1.0;
+    }
+    // s = f / (2 + f), 2 + f in [1.70, 3.42): hardware reciprocal seed, two Newton steps, one correction of the
+    // quotient (no scaling or fix-up needed in this range; <= 1 ulp)
+    double d[N], rc[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        d[i] = 2.0 + f[i];
+        rc[i] = LF_RCP_SEED(d[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) rc[i] = fma(fma(-d[i], rc[i], 1.0), rc[i], rc[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) rc[i] = fma(fma(-d[i], rc[i], 1.0), rc[i], rc[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const double s0 = f[i] * rc[i];
+        s[i] = fma(fma(-d[i], s0, f[i]), rc[i], s0);
+    }
+    // fdlibm-style log(m): 7-term minimax in z = s^2, split in even and odd powers of w = z^2
+    double z[N], w[N], t1[N], t2[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        z[i] = s[i] * s[i];
+        w[i] = z[i] * z[i];
+        hfsq[i] = 0.5 * f[i] * f[i];
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        t1[i] = fma(w[i], 1.531383769920937332e-01, 2.222219843214978396e-01);
+        t2[i] = fma(w[i], 1.479819860511658591e-01, 1.818357216161805012e-01);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        t1[i] = fma(w[i], t1[i], 3.999999999940941908e-01);
+        t2[i] = fma(w[i], t2[i], 2.857142874366239149e-01);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        t1[i] = w[i] * t1[i];
+        t2[i] = z[i] * fma(w[i], t2[i], 6.666666666666735130e-01);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        R[i] = t2[i] + t1[i];
+        const double ln_m = f[i] - fma(-s[i], hfsq[i] + R[i], hfsq[i]); // log(m), |error| < 1 ulp
+        l2m[i] = ln_m * 1.44269504088896340736;                          // log2(m), |l2m| <= 0.5
+    }
+    // y * log2(x) = y * e + y * log2(m), the first product carried with its rounding error; n = nearest integer
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const double ed = (double)e[i];
+        p[i] = y[i] * ed;
+        p_err[i] = fma(y[i], ed, -p[i]);
+        const double q = y[i] * l2m[i];
+        n[i] = rint(p[i] + q);
+        const double r = ((p[i] - n[i]) + q) + p_err[i]; // |r| <= ~0.5
+        u[i] = r * 0.69314718055994530942;
+    }
+    // e^u, |u| <= 0.36: degree-13 Taylor polynomial in Estrin form (dependent depth 5 instead of 14)
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const double u1 = u[i];
+        const double u2 = u1 * u1, u4 = u2 * u2, u8 = u4 * u4;
+        const double a0 = fma(1.0, u1, 1.0);
+        const double a1 = fma(1.6666666666666666e-01, u1, 0.5);
+        const double a2 = fma(8.333333333333333e-03, u1, 4.1666666666666664e-02);
+        const double a3 = fma(1.984126984126984e-04, u1, 1.388888888888889e-03);
+        const double a4 = fma(2.7557319223985893e-06, u1, 2.48015873015873e-05);
+        const double a5 = fma(2.505210838544172e-08, u1, 2.755731922398589e-07);
+        const double a6 = fma(1.6059043836821613e-10, u1, 2.08767569878681e-09);
+        const double b0 = fma(a1, u2, a0), b1 = fma(a3, u2, a2), b2 = fma(a5, u2, a4);
+        const double d0 = fma(b1, u4, b0), d1 = fma(a6, u4, b2);
+        ex[i] = fma(d1, u8, d0);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const double nn = fmin(fmax(n[i], -2000.0), 2000.0);
+        const double val = ldexp(ex[i], (int)nn);
+        // 0 -> 0; negative base or NaN -> NaN, as OCML pow and numpy's ** for a non-integer exponent; a NaN exponent
+        // propagates through val (y * ed) and through at_zero
+        const double at_zero = (y[i] != y[i]) ? y[i] : 0.0;
+        const double not_pos = (x[i] == 0.0) ? at_zero : __builtin_nan("");
+        out[i] = pos[i] ? val : not_pos;
+    }
+}
+
 __device__ __forceinline__ double lf_pow_pos(double x, double y)
 {
-    // branch-free: the main path runs on a sanitised argument and the special cases are selected at the end, so
-    // several inlined calls form ONE basic block and the scheduler interleaves their dependent chains
-    const bool pos = x > 0.0;
-    const double xs = pos ? x : 1.0;
-    int e = __builtin_amdgcn_frexp_exp(xs);
-    double m = __builtin_amdgcn_frexp_mant(xs); // [0.5, 1)
-    const bool lo = m < 0.70710678118654752440;
-    m = lo ? m * 2.0 : m;
-    e = lo ? e - 1 : e;
-    const double f = m - 1.0;
-    const double s = f / (2.0 + f);
-    const double z = s * s, w = z * z;
-    const double t1 = w * (3.999999999940941908e-01 + w * (2.222219843214978396e-01 + w * 1.531383769920937332e-01));
-    const double t2 = z * (6.666666666666735130e-01 +
-                           w * (2.857142874366239149e-01 + w * (1.818357216161805012e-01 + w * 1.479819860511658591e-01)));
-    const double R = t2 + t1;
-    const double hfsq = 0.5 * f * f;
-    const double ln_m = f - (hfsq - s * (hfsq + R)); // log(m), |error| < 1 ulp
-    const double l2m = ln_m * 1.44269504088896340736;  // log2(m), |l2m| <= 0.5
-    const double ed = (double)e;
-    const double p = y * ed;
-    const double p_err = fma(y, ed, -p);
-    const double q = y * l2m;
-    const double n = rint(p + q);
-    const double r = ((p - n) + q) + p_err; // |r| <= ~0.5
-    const double u = r * 0.69314718055994530942;
-    // e^u, |u| <= 0.36
-    // degree-13 Taylor polynomial in Estrin form (dependent depth 5 instead of 14)
-    const double u2 = u * u, u4 = u2 * u2, u8 = u4 * u4;
-    const double a0 = fma(1.0, u, 1.0);
-    const double a1 = fma(1.6666666666666666e-01, u, 0.5);
-    const double a2 = fma(8.333333333333333e-03, u, 4.1666666666666664e-02);
-    const double a3 = fma(1.984126984126984e-04, u, 1.388888888888889e-03);
-    const double a4 = fma(2.7557319223985893e-06, u, 2.48015873015873e-05);
-    const double a5 = fma(2.505210838544172e-08, u, 2.755731922398589e-07);
-    const double a6 = fma(1.6059043836821613e-10, u, 2.08767569878681e-09);
-    const double b0 = fma(a1, u2, a0), b1 = fma(a3, u2, a2), b2 = fma(a5, u2, a4);
-    const double d0 = fma(b1, u4, b0), d1 = fma(a6, u4, b2);
-    const double ex = fma(d1, u8, d0);
-    const double nn = fmin(fmax(n, -2000.0), 2000.0);
-    const double val = ldexp(ex, (int)nn);
-    // 0 -> 0; negative base or NaN -> NaN, as OCML pow and numpy's ** for a non-integer exponent; a NaN exponent
-    // propagates through val (y * ed)
-    return pos ? val : ((x == 0.0) ? ((y != y) ? y : 0.0) : __builtin_nan(""));
+    const double xs[1] = {x}, ys[1] = {y};
+    double r[1];
+    lf_pow_pos_n<1>(xs, ys, r);
+    return r[0];
 }

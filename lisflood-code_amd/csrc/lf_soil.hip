@@ -78,10 +78,39 @@ template <bool FASTPOW>
 __device__ __forceinline__ double unsat_k(double w, bool pore, double wres, double ws, double ksat, double inv_m,
                                           double m)
 {
-    double s = 0.;
-    if (pore) s = dmax(dmin((w - wres) / (ws - wres), 1.), 0.);
+    // evaluated for every lane and selected (a divergent branch here would split the sub-step loop into basic blocks
+    // and serialise the three layers' dependent chains); without pore space the quotient is discarded
+    const double sc = dmax(dmin((w - wres) / (ws - wres), 1.), 0.);
+    const double s = pore ? sc : 0.;
     const double t = 1. - powxy<FASTPOW>(1. - powxy<FASTPOW>(s, inv_m), m);
     return ksat * sqrt(s) * (t * t);
+}
+
+// the three layers of a column at once (lf_pow_pos_n: the dependent chains of the layers interleaved)
+template <bool FASTPOW>
+__device__ __forceinline__ void unsat_k3(const double (&w)[3], const bool (&pore)[3], const double (&wres)[3],
+                                         const double (&ws)[3], const double (&ksat)[3], const double (&inv_m)[3],
+                                         const double (&m)[3], double (&k)[3])
+{
+    if (!FASTPOW) {
+#pragma unroll
+        for (int l = 0; l < 3; ++l) k[l] = unsat_k<false>(w[l], pore[l], wres[l], ws[l], ksat[l], inv_m[l], m[l]);
+        return;
+    }
+    double s[3], a[3], b[3], t[3];
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+        const double sc = dmax(dmin((w[l] - wres[l]) / (ws[l] - wres[l]), 1.), 0.);
+        s[l] = pore[l] ? sc : 0.;
+    }
+    lf_pow_pos_n<3>(s, inv_m, a);
+#pragma unroll
+    for (int l = 0; l < 3; ++l) a[l] = 1. - a[l];
+    lf_pow_pos_n<3>(a, m, b);
+#pragma unroll
+    for (int l = 0; l < 3; ++l) t[l] = 1. - b[l];
+#pragma unroll
+    for (int l = 0; l < 3; ++l) k[l] = ksat[l] * sqrt(s[l]) * (t[l] * t[l]);
 }
 
 struct veg_plan {
@@ -94,13 +123,15 @@ struct veg_plan {
 // One soil column (vegetation fraction `veg`, pixel `pix`) of soilColumnsWaterBalance, soilloop.py:123-354.
 // Nothing is stored before the end, so a column can be abandoned and recomputed later: with DEFER, a column
 // that needs more than one Courant sub-step returns that number without writing anything (0 = column done).
-// Inputs of deferred columns are handed from pass 1 to pass 2 through a staging area: pass 1 has all of them in
-// registers when it finds that a column needs several sub-steps, and writes them next to the inputs of the tile's
-// other deferred columns (slot = tile * cap + rank in the tile's list, 46 values per slot); pass 2 then reads six
-// lines per column instead of one 64-byte sector per 8-byte value scattered over ~46 vectors (measured: 6 GB fetched
-// for 0.8 GB of inputs).  A tile has room for `cap` columns; the ones beyond gather from the vectors as before.
-constexpr int kStageFields = 46;
-constexpr unsigned int kStageCap = 96; // slots per tile (of 256 columns); pass 1 collects them in LDS: 46 x 96 x 8 B = 35 KB
+// Deferred columns are handed from pass 1 to pass 2 through a staging area: when pass 1 finds that a column needs
+// several sub-steps it has the column's state after evaporation / infiltration and the first conductivities in
+// registers, and writes that state, with the parameters the loop and the epilogue read, next to the records of the
+// tile's other deferred columns (slot = tile * cap + rank in the tile's list, 42 values per slot).  Pass 2 RESUMES at
+// the sub-step loop (no second prologue) and reads six lines per column instead of one 64-byte sector per 8-byte value
+// scattered over ~46 vectors (measured: 6 GB fetched for 0.8 GB of inputs).  A tile has room for `cap` columns; the
+// ones beyond are recomputed from the vectors.
+constexpr int kStageFields = 42;
+constexpr unsigned int kStageCap = 96; // slots per tile (of 256 columns); pass 1 collects them in LDS: 42 x 96 x 8 B = 32 KB
 struct soil_stage {
     double *buf;      // [nslots][kStageFields]: a column's inputs side by side, a tile's columns one contiguous run
     size_t nslots;    // ntiles * cap
@@ -120,83 +151,110 @@ __device__ __forceinline__ long long soil_column(const lf_soil_args &A, const ve
     const double DtDay = A.DtDay;
     const long long i = (long long)veg * N + pix, j = (long long)P.landuse[veg] * N + pix;
     const bool staged = !DEFER && slot < S.nslots;
-    int f_ = 0;
-#define LD(expr) (staged ? S.buf[slot * kStageFields + (size_t)(f_++)] : (f_++, (double)(expr)))
-    // Every input of the column is fetched here, before any arithmetic: ~50 independent loads in flight per lane
-    // instead of the handful the compiler keeps when loads sit next to their first use (the kernel is a stream
-    // of ~90 vectors; memory-level parallelism, not ALU, sets its speed).
-    const double in_rain = LD(A.Rain[pix]), in_snow = LD(A.SnowMelt[pix]), in_leaf = LD(A.LeafDrainage[i]),
-                 in_int = LD(A.Interception[i]);
-    const double in_dslr = LD(A.DSLR[i]), in_w1a = LD(A.W1a[i]), in_w1b = LD(A.W1b[i]), in_w1 = LD(A.W1[i]),
-                 in_w2 = LD(A.W2[i]), in_uz = LD(A.UZ[i]);
-    const double in_esmax = LD(A.ESMax[i]), in_wres1 = LD(A.WRes1[j]), in_ws1 = LD(A.WS1[j]),
-                 in_store = LD(A.StoreMaxPervious[j]);
-    const double in_bx = LD(A.b_Xinanjiang[pix]), in_pinf = LD(A.PowerInfPot[pix]), in_ppref = LD(A.PowerPrefFlow[pix]);
-    const double in_uzk = LD(A.UpperZoneK[pix]), in_gwp = LD(A.GwPercStep[pix]);
-    const double in_sd1a = LD(A.SoilDepth1a[j]), in_sd1b = LD(A.SoilDepth1b[j]), in_sd2 = LD(A.SoilDepth2[j]);
-    const double wwp1a = LD(A.WWP1a[j]), wwp1b = LD(A.WWP1b[j]), wwp1 = LD(A.WWP1[j]), wwp2 = LD(A.WWP2[j]);
-    const double in_wfc1a = LD(A.WFC1a[j]), in_wfc1b = LD(A.WFC1b[j]), in_wfc1 = LD(A.WFC1[j]), in_wfc2 = LD(A.WFC2[j]);
-    const double ks1a = LD(A.KSat1a[j]), ks1b = LD(A.KSat1b[j]), ks2 = LD(A.KSat2[j]);
-    const double im1a = LD(A.GenuInvM1a[j]), im1b = LD(A.GenuInvM1b[j]), im2 = LD(A.GenuInvM2[j]);
-    const double m1a = LD(A.GenuM1a[j]), m1b = LD(A.GenuM1b[j]), m2 = LD(A.GenuM2[j]);
-    const double wres1a = LD(A.WRes1a[j]), wres1b = LD(A.WRes1b[j]), wres2 = LD(A.WRes2[j]);
-    const double ws1a = LD(A.WS1a[j]), ws1b = LD(A.WS1b[j]), ws2 = LD(A.WS2[j]);
-    // the four flags travel as one small integer
-    const double flags_d = LD((A.isFrozenSoil[pix] != 0 ? 1 : 0) | (A.PoreSpaceNotZero1a[j] != 0 ? 2 : 0) |
-                              (A.PoreSpaceNotZero1b[j] != 0 ? 4 : 0) | (A.PoreSpaceNotZero2[j] != 0 ? 8 : 0));
-#undef LD
-    const int flags = (int)flags_d;
-    const bool frozen = (flags & 1) != 0, pore1a = (flags & 2) != 0, pore1b = (flags & 4) != 0, pore2 = (flags & 8) != 0;
-    static_assert(kStageFields == 46, "one staging field per LD() above");
-    // available water for infiltration, :100,131
-    double awi = dmax((in_rain + in_snow) + in_leaf - in_int, 0.);
-    // days since last rain, :137-140
-    double dslr = in_dslr;
-    if (awi > A.AvWaterThreshold)
-        dslr = 1;
-    else
-        dslr += DtDay;
-    // bare soil evaporation, :148-163
-    double w1a = in_w1a, w1b = in_w1b, esact;
-    if (frozen)
-        esact = 0.;
-    else {
-        esact = in_esmax * (sqrt(dslr) - sqrt(dslr - 1));
-        esact = dmax(dmin(esact, in_w1 - in_wres1), 0.);
-        const double supply1a = w1a - wres1a;
-        const double es1a = dmin(esact, supply1a);
-        const double es1b = dmax(esact - supply1a, 0.);
-        w1a = dmax(w1a - es1a, wres1a);
-        w1b = dmax(w1b - es1b, wres1b);
+    // everything the sub-step loop and the epilogue need; filled either from the staging area (pass 2: the state pass 1
+    // had reached when it found that the column needs several sub-steps) or by the prologue below
+    double w1a, w1b, w2, k1a, k1b, k2, inf, pref, awi, dslr, esact, in_uz, in_uzk, in_gwp;
+    double in_sd1a, in_sd1b, in_sd2, wwp1a, wwp1b, wwp1, wwp2, in_wfc1a, in_wfc1b, in_wfc1, in_wfc2;
+    double ks1a, ks1b, ks2, im1a, im1b, im2, m1a, m1b, m2, wres1a, wres1b, wres2, ws1a, ws1b, ws2;
+    double nsub_f;
+    int flags;
+    if (staged) {
+        const double *__restrict__ R = S.buf + slot * kStageFields;
+        int f = 0;
+#define LDS_(v) v = R[f++]
+        LDS_(w1a); LDS_(w1b); LDS_(w2); LDS_(k1a); LDS_(k1b); LDS_(k2);
+        LDS_(inf); LDS_(pref); LDS_(awi); LDS_(dslr); LDS_(esact);
+        LDS_(in_uz); LDS_(in_uzk); LDS_(in_gwp);
+        LDS_(in_sd1a); LDS_(in_sd1b); LDS_(in_sd2);
+        LDS_(wwp1a); LDS_(wwp1b); LDS_(wwp1); LDS_(wwp2);
+        LDS_(in_wfc1a); LDS_(in_wfc1b); LDS_(in_wfc1); LDS_(in_wfc2);
+        LDS_(ks1a); LDS_(ks1b); LDS_(ks2);
+        LDS_(im1a); LDS_(im1b); LDS_(im2);
+        LDS_(m1a); LDS_(m1b); LDS_(m2);
+        LDS_(wres1a); LDS_(wres1b); LDS_(wres2);
+        LDS_(ws1a); LDS_(ws1b); LDS_(ws2);
+        double flags_d;
+        LDS_(flags_d); LDS_(nsub_f);
+#undef LDS_
+        flags = (int)flags_d;
+    } else {
+        // Every input of the column is fetched here, before any arithmetic: ~50 independent loads in flight per lane
+        // instead of the handful the compiler keeps when loads sit next to their first use (the kernel is a stream
+        // of ~90 vectors; memory-level parallelism, not ALU, sets its speed).
+        const double in_rain = A.Rain[pix], in_snow = A.SnowMelt[pix], in_leaf = A.LeafDrainage[i], in_int = A.Interception[i];
+        const double in_dslr = A.DSLR[i], in_w1a = A.W1a[i], in_w1b = A.W1b[i], in_w1 = A.W1[i], in_w2 = A.W2[i];
+        in_uz = A.UZ[i];
+        const double in_esmax = A.ESMax[i], in_wres1 = A.WRes1[j], in_ws1 = A.WS1[j], in_store = A.StoreMaxPervious[j];
+        const double in_bx = A.b_Xinanjiang[pix], in_pinf = A.PowerInfPot[pix], in_ppref = A.PowerPrefFlow[pix];
+        in_uzk = A.UpperZoneK[pix];
+        in_gwp = A.GwPercStep[pix];
+        in_sd1a = A.SoilDepth1a[j]; in_sd1b = A.SoilDepth1b[j]; in_sd2 = A.SoilDepth2[j];
+        wwp1a = A.WWP1a[j]; wwp1b = A.WWP1b[j]; wwp1 = A.WWP1[j]; wwp2 = A.WWP2[j];
+        in_wfc1a = A.WFC1a[j]; in_wfc1b = A.WFC1b[j]; in_wfc1 = A.WFC1[j]; in_wfc2 = A.WFC2[j];
+        ks1a = A.KSat1a[j]; ks1b = A.KSat1b[j]; ks2 = A.KSat2[j];
+        im1a = A.GenuInvM1a[j]; im1b = A.GenuInvM1b[j]; im2 = A.GenuInvM2[j];
+        m1a = A.GenuM1a[j]; m1b = A.GenuM1b[j]; m2 = A.GenuM2[j];
+        wres1a = A.WRes1a[j]; wres1b = A.WRes1b[j]; wres2 = A.WRes2[j];
+        ws1a = A.WS1a[j]; ws1b = A.WS1b[j]; ws2 = A.WS2[j];
+        flags = (A.isFrozenSoil[pix] != 0 ? 1 : 0) | (A.PoreSpaceNotZero1a[j] != 0 ? 2 : 0) |
+                (A.PoreSpaceNotZero1b[j] != 0 ? 4 : 0) | (A.PoreSpaceNotZero2[j] != 0 ? 8 : 0);
+        const bool frozen = (flags & 1) != 0, pore1a = (flags & 2) != 0, pore1b = (flags & 4) != 0, pore2 = (flags & 8) != 0;
+        // available water for infiltration, :100,131
+        awi = dmax((in_rain + in_snow) + in_leaf - in_int, 0.);
+        // days since last rain, :137-140
+        dslr = in_dslr;
+        if (awi > A.AvWaterThreshold)
+            dslr = 1;
+        else
+            dslr += DtDay;
+        // bare soil evaporation, :148-163
+        w1a = in_w1a;
+        w1b = in_w1b;
+        if (frozen)
+            esact = 0.;
+        else {
+            esact = in_esmax * (sqrt(dslr) - sqrt(dslr - 1));
+            esact = dmax(dmin(esact, in_w1 - in_wres1), 0.);
+            const double supply1a = w1a - wres1a;
+            const double es1a = dmin(esact, supply1a);
+            const double es1b = dmax(esact - supply1a, 0.);
+            w1a = dmax(w1a - es1a, wres1a);
+            w1b = dmax(w1b - es1b, wres1b);
+        }
+        const double w1_ = w1a + w1b;
+        // Xinanjiang infiltration capacity, :168-179
+        const double relsat1 = pore1a ? dmin(w1_ / in_ws1, 1.0) : 0.0;
+        const double satfrac = 1.0 - powxy<FASTPOW>(1.0 - relsat1, in_bx);
+        const double infpot = frozen ? 0.0 : in_store * powxy<FASTPOW>(1. - satfrac, in_pinf) * DtDay;
+        // preferential flow, :190-194
+        pref = powxy<FASTPOW>(relsat1, in_ppref) * awi;
+        awi -= pref;
+        // infiltration, :201-211
+        inf = dmax(dmin(awi, infpot), 0.);
+        const double test1a = w1a + inf;
+        w1a = dmin(ws1a, test1a);
+        w1b += dmax(test1a - ws1a, 0.);
+        w2 = in_w2;
+        // Van Genuchten conductivities and Courant numbers, :223-249
+        {
+            const double w_[3] = {w1a, w1b, w2}, wres_[3] = {wres1a, wres1b, wres2}, ws_[3] = {ws1a, ws1b, ws2};
+            const double ks_[3] = {ks1a, ks1b, ks2}, im_[3] = {im1a, im1b, im2}, m_[3] = {m1a, m1b, m2};
+            const bool pore_[3] = {pore1a, pore1b, pore2};
+            double k_[3];
+            unsat_k3<FASTPOW>(w_, pore_, wres_, ws_, ks_, im_, m_, k_);
+            k1a = k_[0], k1b = k_[1], k2 = k_[2];
+        }
+        const double av1a_ = w1a - wres1a, av1b_ = w1b - wres1b, av2_ = w2 - wres2;
+        const double ca = (av1a_ == 0) ? 0. : k1a * DtDay / av1a_;
+        const double cb = (av1b_ == 0) ? 0. : k1b * DtDay / av1b_;
+        const double cg = (av2_ == 0) ? 0. : k2 * DtDay / av2_;
+        const double courant = dmax(dmax(ca, cb), cg);
+        // NoSubS = max(1, ceil(Courant / CourantCrit)), :249.  A non-finite or absurd Courant number (zero available
+        // water next to a huge conductivity) would make the reference's int conversion overflow and this loop spin for
+        // ever: the trip count is capped (documented deviation; CourantCrit > 0 is checked on the host).
+        nsub_f = dmin(dmax(1., ceil(courant / A.CourantCrit)), kMaxSoilSubSteps);
     }
-    double w1 = w1a + w1b;
-    // Xinanjiang infiltration capacity, :168-179
-    const double relsat1 = pore1a ? dmin(w1 / in_ws1, 1.0) : 0.0;
-    const double satfrac = 1.0 - powxy<FASTPOW>(1.0 - relsat1, in_bx);
-    const double infpot = frozen ? 0.0 : in_store * powxy<FASTPOW>(1. - satfrac, in_pinf) * DtDay;
-    // preferential flow, :190-194
-    const double pref = powxy<FASTPOW>(relsat1, in_ppref) * awi;
-    awi -= pref;
-    // infiltration, :201-211
-    double inf = dmax(dmin(awi, infpot), 0.);
-    const double test1a = w1a + inf;
-    w1a = dmin(ws1a, test1a);
-    w1b += dmax(test1a - ws1a, 0.);
-    double w2 = in_w2;
-    // Van Genuchten conductivities and Courant numbers, :223-249
-    double k1a = unsat_k<FASTPOW>(w1a, pore1a, wres1a, ws1a, ks1a, im1a, m1a);
-    double k1b = unsat_k<FASTPOW>(w1b, pore1b, wres1b, ws1b, ks1b, im1b, m1b);
-    double k2 = unsat_k<FASTPOW>(w2, pore2, wres2, ws2, ks2, im2, m2);
-    double av1a = w1a - wres1a, av1b = w1b - wres1b, av2 = w2 - wres2;
-    double cap1 = ws1b - w1b, cap2 = ws2 - w2;
-    const double ca = (av1a == 0) ? 0. : k1a * DtDay / av1a;
-    const double cb = (av1b == 0) ? 0. : k1b * DtDay / av1b;
-    const double cg = (av2 == 0) ? 0. : k2 * DtDay / av2;
-    const double courant = dmax(dmax(ca, cb), cg);
-    // NoSubS = max(1, ceil(Courant / CourantCrit)), :249.  A non-finite or absurd Courant number (zero available water
-    // next to a huge conductivity) would make the reference's int conversion overflow and this loop spin for ever:
-    // the trip count is capped (documented deviation; CourantCrit > 0 is checked on the host).
-    const double nsub_f = dmin(dmax(1., ceil(courant / A.CourantCrit)), kMaxSoilSubSteps);
+    const bool frozen = (flags & 1) != 0, pore1a = (flags & 2) != 0, pore1b = (flags & 4) != 0, pore2 = (flags & 8) != 0;
     const long long nsub = (long long)nsub_f;
     if (DEFER && nsub > 1) {
         const unsigned int rank = atomicAdd(lds_count, 1u); // LDS: position in the tile's list
@@ -204,36 +262,44 @@ __device__ __forceinline__ long long soil_column(const lf_soil_args &A, const ve
         if (STAGE && rank < kStageCap) { // into the block's LDS table; the block writes it out in full lines afterwards
             int f = 0;
 #define ST(v) lds_stage[(f++) * kStageCap + rank] = (v)
-            // the inputs whose registers are dead by now are read again (cache hits, deferred lanes only) rather than
-            // kept alive across the infiltration arithmetic: pass 1 has no registers to spare
-            ST(A.Rain[pix]); ST(A.SnowMelt[pix]); ST(A.LeafDrainage[i]); ST(A.Interception[i]);
-            ST(A.DSLR[i]); ST(A.W1a[i]); ST(A.W1b[i]); ST(A.W1[i]); ST(A.W2[i]); ST(in_uz);
-            ST(A.ESMax[i]); ST(A.WRes1[j]); ST(A.WS1[j]); ST(A.StoreMaxPervious[j]);
-            ST(A.b_Xinanjiang[pix]); ST(A.PowerInfPot[pix]); ST(A.PowerPrefFlow[pix]);
-            ST(in_uzk); ST(in_gwp);
-            ST(in_sd1a); ST(in_sd1b); ST(in_sd2);
-            ST(wwp1a); ST(wwp1b); ST(wwp1); ST(wwp2);
-            ST(in_wfc1a); ST(in_wfc1b); ST(in_wfc1); ST(in_wfc2);
+            // the state reached so far (pass 2 resumes at the sub-step loop) and the parameters the loop and the
+            // epilogue read; parameters whose registers are dead by now are read again (cache hits, deferred lanes
+            // only) rather than kept alive across the infiltration arithmetic: pass 1 has no registers to spare
+            ST(w1a); ST(w1b); ST(w2); ST(k1a); ST(k1b); ST(k2);
+            ST(inf); ST(pref); ST(awi); ST(dslr); ST(esact);
+            ST(in_uz); ST(in_uzk); ST(in_gwp);
+            ST(A.SoilDepth1a[j]); ST(A.SoilDepth1b[j]); ST(A.SoilDepth2[j]);
+            ST(A.WWP1a[j]); ST(A.WWP1b[j]); ST(A.WWP1[j]); ST(A.WWP2[j]);
+            ST(A.WFC1a[j]); ST(A.WFC1b[j]); ST(A.WFC1[j]); ST(A.WFC2[j]);
             ST(ks1a); ST(ks1b); ST(ks2);
             ST(im1a); ST(im1b); ST(im2);
             ST(m1a); ST(m1b); ST(m2);
             ST(wres1a); ST(wres1b); ST(wres2);
             ST(ws1a); ST(ws1b); ST(ws2);
-            ST(flags_d);
+            ST((double)flags); ST(nsub_f);
 #undef ST
         }
         return nsub;
     }
     // sub-step loop, :266-312
+    double av1a = w1a - wres1a, av1b = w1b - wres1b, av2 = w2 - wres2;
+    double cap1 = ws1b - w1b, cap2 = ws2 - w2;
     double wt1a = w1a, wt1b = w1b, wt2 = w2;
     double sa = 0., sb = 0., sg = 0.;
     const double dtsub = DtDay / (double)nsub;
+#ifdef LF_SOIL_DEBUG_MAXTRIPS /* timing experiments only: wrong results */
+    const long long trips = DEFER ? 1 : (nsub < LF_SOIL_DEBUG_MAXTRIPS ? nsub : LF_SOIL_DEBUG_MAXTRIPS);
+#else
     const long long trips = DEFER ? 1 : nsub; // DEFER: nsub == 1 here, the re-evaluation branch disappears
+#endif
     for (long long s = 0; s < trips; ++s) {
         if (s > 0) {
-            k1a = unsat_k<FASTPOW>(wt1a, pore1a, wres1a, ws1a, ks1a, im1a, m1a);
-            k1b = unsat_k<FASTPOW>(wt1b, pore1b, wres1b, ws1b, ks1b, im1b, m1b);
-            k2 = unsat_k<FASTPOW>(wt2, pore2, wres2, ws2, ks2, im2, m2);
+            const double w_[3] = {wt1a, wt1b, wt2}, wres_[3] = {wres1a, wres1b, wres2}, ws_[3] = {ws1a, ws1b, ws2};
+            const double ks_[3] = {ks1a, ks1b, ks2}, im_[3] = {im1a, im1b, im2}, m_[3] = {m1a, m1b, m2};
+            const bool pore_[3] = {pore1a, pore1b, pore2};
+            double k_[3];
+            unsat_k3<FASTPOW>(w_, pore_, wres_, ws_, ks_, im_, m_, k_);
+            k1a = k_[0], k1b = k_[1], k2 = k_[2];
         }
         const double fa = dmin(k1a * dtsub, cap1);
         const double fb = dmin(k1b * dtsub, cap2);
@@ -255,7 +321,7 @@ __device__ __forceinline__ long long soil_column(const lf_soil_args &A, const ve
     w1a -= sa;
     w1b = w1b + sa - sb;
     w2 = w2 + sb - sg;
-    w1 = w1a + w1b;
+    const double w1 = w1a + w1b;
     inf -= dmax(w1a - ws1a, 0.);
     w1a = dmin(w1a, ws1a);
     // upper zone, :340-354
@@ -302,7 +368,10 @@ __device__ __forceinline__ long long soil_column(const lf_soil_args &A, const ve
 // run similar trip counts) and finishes.  Keeping pass 2 tile-local keeps its gathers inside a 4096-column window
 // of every stream instead of scattering 8-byte reads over the whole vectors (measured 14x over-fetch with a
 // global, class-sorted list).
-constexpr int kClasses = 8; // class = floor(log2(nsub)) clamped to kClasses-1: trip counts inside a class differ < 2x
+// sort key of a deferred column inside its pool: the trip count itself, clamped to kClasses - 1 (LF_SOIL_LOG2_CLASSES=1:
+// floor(log2(nsub)) as before -- A/B switch).  With the inputs staged per column, the order inside the pool no longer
+// changes which lines a wavefront touches, so the finer the sort the closer the lanes of a wavefront finish together.
+constexpr int kClasses = 128;
 constexpr int kGroup = 16;  // tiles per pass-2 workgroup (a pool of 4096 columns: enough deferred columns to fill
                             // wavefronts with similar trip counts even when the sub-step distribution has a long tail)
 
@@ -313,7 +382,7 @@ constexpr int kGroup = 16;  // tiles per pass-2 workgroup (a pool of 4096 column
 // between 126 and 133 VGPRs (4 vs 3 waves per SIMD) with unrelated edits to this file; 5 waves spill and are slower
 template <bool FASTPOW, bool STAGE>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(LF_SOIL_P1_WAVES))) k_soil_columns(lf_soil_args A, veg_plan P, unsigned short *__restrict__ tile_list,
-                                                         unsigned int *__restrict__ tile_count, soil_stage S)
+                                                         unsigned int *__restrict__ tile_count, soil_stage S, int log2_classes)
 {
     __shared__ unsigned int count;
     __shared__ double lds_stage[STAGE ? kStageFields * kStageCap : 1];
@@ -329,14 +398,14 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(LF_
         unsigned int rank = 0;
         const long long nsub = soil_column<true, FASTPOW, STAGE>(A, P, veg, pix, S, 0, &count, tile, &rank, lds_stage);
         if (nsub > 0) {
-            int c = 63 - __clzll((unsigned long long)nsub); // floor(log2(nsub)) >= 1
+            long long c = log2_classes ? 63 - __clzll((unsigned long long)nsub) : nsub; // floor(log2(nsub)) >= 1 / nsub >= 2
             c = c < kClasses - 1 ? c : kClasses - 1;
-            tile_list[(size_t)tile * kBlock + rank] = (unsigned short)(threadIdx.x | (c << 8));
+            tile_list[(size_t)tile * kBlock + rank] = (unsigned short)(threadIdx.x | ((int)c << 8));
         }
     }
     __syncthreads();
     if (threadIdx.x == 0) tile_count[tile] = count;
-    if (STAGE) { // the tile's staged inputs as ONE contiguous run: slot-major, the 46 fields of a column side by side
+    if (STAGE) { // the tile's staged inputs as ONE contiguous run: slot-major, the 42 fields of a column side by side
         const unsigned int n = count < kStageCap ? count : kStageCap;
         double *dst = S.buf + (size_t)tile * kStageCap * kStageFields;
         for (unsigned int idx = threadIdx.x; idx < (unsigned int)kStageFields * n; idx += kBlock) {
@@ -358,16 +427,18 @@ k_soil_columns_deferred(lf_soil_args A, veg_plan P,
                                                                   unsigned int ntiles, unsigned int tiles_per_veg,
                                                                   soil_stage S, unsigned long long *__restrict__ deferred_total)
 {
-    __shared__ unsigned int cnt[kGroup], h[kClasses], base[kClasses], total;
+    __shared__ unsigned int cnt[kGroup], h[kClasses], base[kClasses], total, next_chunk;
     __shared__ unsigned int entry[kGroup * kBlock]; // (rank in tile list << 16 | tile-in-group << 8 | lane), by class
     const unsigned int t0 = blockIdx.x * kGroup;
     if (threadIdx.x < kGroup) cnt[threadIdx.x] = (t0 + threadIdx.x < ntiles) ? tile_count[t0 + threadIdx.x] : 0;
     if (threadIdx.x < kClasses) h[threadIdx.x] = 0;
+    static_assert(kClasses <= kBlock && kClasses % 64 == 0, "histogram layout");
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned int t = 0;
         for (int g = 0; g < kGroup; ++g) t += cnt[g];
         total = t;
+        next_chunk = 0;
     }
     __syncthreads();
     if (total == 0) return;
@@ -384,11 +455,22 @@ k_soil_columns_deferred(lf_soil_args A, veg_plan P,
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned int acc = 0;
-        for (int c = 0; c < kClasses; ++c) {
-            base[c] = acc;
-            acc += h[c];
+    if (threadIdx.x < 64) { // exclusive scan of the histogram by one wavefront: lane l owns kClasses / 64 consecutive bins
+        constexpr int per = kClasses / 64;
+        unsigned int mine_sum = 0;
+#pragma unroll
+        for (int q = 0; q < per; ++q) mine_sum += h[threadIdx.x * per + q];
+        unsigned int incl = mine_sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned int up = __shfl_up(incl, d, 64);
+            if ((int)threadIdx.x >= d) incl += up;
+        }
+        unsigned int acc = incl - mine_sum;
+#pragma unroll
+        for (int q = 0; q < per; ++q) {
+            base[threadIdx.x * per + q] = acc;
+            acc += h[threadIdx.x * per + q];
         }
     }
     __syncthreads();
@@ -397,11 +479,24 @@ k_soil_columns_deferred(lf_soil_args A, veg_plan P,
         if (mine[g] != 0xffff)
             entry[base[mine[g] >> 8] + rank[g]] = (threadIdx.x << 16) | ((unsigned int)g << 8) | (mine[g] & 0xff);
     __syncthreads();
-    for (unsigned int k = threadIdx.x; k < total; k += kBlock) {
+    // The sorted entries are handed out in chunks of one wavefront, heaviest first, from a counter in LDS: a wavefront that
+    // finishes a short chunk takes the next one, so the four wavefronts of the workgroup end together whatever the
+    // distribution of trip counts (measured neutral on the uniform synthetic soil of bench.py, where every pool holds the
+    // same mix; it bounds the imbalance when a few columns of a pool need 50x the sub-steps of the rest).
+    const unsigned int nchunks = (total + 63u) / 64u, lane = threadIdx.x & 63u;
+    for (;;) {
+        unsigned int c = 0;
+        if (lane == 0) c = atomicAdd(&next_chunk, 1u);
+        c = (unsigned int)__builtin_amdgcn_readfirstlane((int)c);
+        if (c >= nchunks) break;
+        const long long k = (long long)total - 1 - (long long)(c * 64u + lane);
+        if (k < 0) continue;
         const unsigned int e = entry[k];
         const unsigned int tile = t0 + ((e >> 8) & 0xff), trank = e >> 16;
         const int veg = (int)(tile / tiles_per_veg);
         const long long pix = (long long)(tile - (unsigned int)veg * tiles_per_veg) * kBlock + (e & 0xff);
+        // a staged column resumes at the sub-step loop from the state pass 1 left in its slot; the few beyond a tile's
+        // slots are recomputed from the vectors
         const size_t slot = trank < S.cap ? (size_t)tile * S.cap + trank : (size_t)-1;
         soil_column<false, FASTPOW>(A, P, veg, pix, S, slot, nullptr, tile, nullptr);
     }
@@ -467,6 +562,30 @@ int lf_soil_last_deferred(int device, int64_t *count)
     return LF_OK;
 }
 
+// sub-step histogram of the last call's deferred columns: hist[k] = columns whose trip count was k (the last bin holds
+// k >= nbins - 1; the lists keep the count clamped to kClasses - 1)
+int lf_soil_substep_histogram(int device, int64_t *hist, int nbins)
+{
+    if (!hist || nbins < 2) return lf_set_error(LF_E_INVALID, "null argument");
+    lf_device_ctx *c;
+    LF_TRY(lf_ctx(device, &c));
+    for (int k = 0; k < nbins; ++k) hist[k] = 0;
+    if (!c->soil_ws || c->soil_ntiles == 0) return LF_OK;
+    const size_t nt = c->soil_ntiles;
+    std::vector<unsigned int> cnt(nt);
+    std::vector<unsigned short> lst(nt * kBlock);
+    LF_HIP(hipMemcpyAsync(cnt.data(), c->soil_ws, sizeof(unsigned int) * nt, hipMemcpyDeviceToHost, c->stream));
+    LF_HIP(hipMemcpyAsync(lst.data(), (const unsigned int *)c->soil_ws + nt + 4, sizeof(unsigned short) * nt * kBlock,
+                          hipMemcpyDeviceToHost, c->stream));
+    LF_HIP(hipStreamSynchronize(c->stream));
+    for (size_t t = 0; t < nt; ++t)
+        for (unsigned int k = 0; k < cnt[t] && k < (unsigned int)kBlock; ++k) {
+            const int cls = lst[t * kBlock + k] >> 8;
+            hist[cls < nbins - 1 ? cls : nbins - 1] += 1;
+        }
+    return LF_OK;
+}
+
 int lf_soil_columns_device(int device, const lf_soil_args *a)
 {
     if (!a || !a->index_landuse_all) return lf_set_error(LF_E_INVALID, "null argument");
@@ -525,17 +644,19 @@ int lf_soil_columns_device(int device, const lf_soil_args *a)
     // LF_GENERAL_POW=1: OCML pow instead of lf_pow_pos (A/B parity and timing)
     const char *force_general = std::getenv("LF_GENERAL_POW");
     const bool fastpow = !(force_general && force_general[0] == '1');
+    const char *l2 = std::getenv("LF_SOIL_LOG2_CLASSES");
+    const int log2_classes = (l2 && l2[0] == '1') ? 1 : 0;
     const dim3 grid1(tiles_per_veg, (unsigned)a->V), block(kBlock);
     const dim3 grid2((unsigned)((ntiles + kGroup - 1) / kGroup));
     LF_HIP(hipMemsetAsync(c->soil_deferred_dev, 0, sizeof(unsigned long long), c->stream));
     if (fastpow && stage)
-        hipLaunchKernelGGL((k_soil_columns<true, true>), grid1, block, 0, c->stream, *a, P, tile_list, tile_count, S);
+        hipLaunchKernelGGL((k_soil_columns<true, true>), grid1, block, 0, c->stream, *a, P, tile_list, tile_count, S, log2_classes);
     else if (fastpow)
-        hipLaunchKernelGGL((k_soil_columns<true, false>), grid1, block, 0, c->stream, *a, P, tile_list, tile_count, S);
+        hipLaunchKernelGGL((k_soil_columns<true, false>), grid1, block, 0, c->stream, *a, P, tile_list, tile_count, S, log2_classes);
     else if (stage)
-        hipLaunchKernelGGL((k_soil_columns<false, true>), grid1, block, 0, c->stream, *a, P, tile_list, tile_count, S);
+        hipLaunchKernelGGL((k_soil_columns<false, true>), grid1, block, 0, c->stream, *a, P, tile_list, tile_count, S, log2_classes);
     else
-        hipLaunchKernelGGL((k_soil_columns<false, false>), grid1, block, 0, c->stream, *a, P, tile_list, tile_count, S);
+        hipLaunchKernelGGL((k_soil_columns<false, false>), grid1, block, 0, c->stream, *a, P, tile_list, tile_count, S, log2_classes);
     if (fastpow)
         hipLaunchKernelGGL(k_soil_columns_deferred<true>, grid2, block, 0, c->stream, *a, P, tile_list, tile_count,
                            (unsigned int)ntiles, tiles_per_veg, S, c->soil_deferred_dev);

@@ -139,6 +139,13 @@ class SoilColumnsDevice:
     def step(self):
         check(lib().lf_soil_columns_device(C.c_int(self.device), C.byref(self.args)))
 
+    def substep_histogram(self, nbins=128):
+        """hist[k] = columns of the last step that needed k Courant sub-steps, k >= 2 (columns with one sub-step are not
+        listed; the engine keeps trip counts up to 127, the last bin holds the rest) -- lf_soil_substep_histogram"""
+        hist = (C.c_int64 * nbins)()
+        check(lib().lf_soil_substep_histogram(C.c_int(self.device), hist, C.c_int(nbins)))
+        return np.array(hist[:], dtype=np.int64)
+
     def get(self, name):
         out = self.dev[name].download()
         return out

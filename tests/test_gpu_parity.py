@@ -993,6 +993,8 @@ def test_soil_full_size_water_balance_property(amd):
     nd = __import__("ctypes").c_int64(0)
     amd.lib.check(amd.lib.lib().lf_soil_last_deferred(__import__("ctypes").c_int(0), __import__("ctypes").byref(nd)))
     assert nd.value > 0.05 * 3 * N          # the multi-sub-step pass really ran on a sizeable share of the columns
+    hist = dev.substep_histogram()
+    assert hist.sum() == nd.value and hist[0] == 0 and hist[1] == 0 and hist[2] > 0   # deferred = 2 or more sub-steps
     for a in dev.dev.values():
         a.free()
 

@@ -1,7 +1,7 @@
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for C in "VALUBusy" "MemUnitBusy" "MemUnitStalled" "VALUUtilization" "LDSBankConflict" "OccupancyPercent"; do
+for C in "VALUBusy" "MemUnitBusy" "MemUnitStalled" "VALUUtilization" "SQ_INSTS_VALU" "SQ_WAVES" "SQ_WAVE_CYCLES" "SQ_ACTIVE_INST_VALU" "SQ_INST_CYCLES_VMEM" "SQ_WAIT_INST_ANY" "GRBM_GUI_ACTIVE"; do
   timeout 200 rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_soil_$C -o pmc -- python $ROOT/bench.py --only soil --steps 2 --warmup 1 > /dev/null 2> $OUT/pmc_soil_$C.err; echo "$C rc=$?"
 done
 cd $ROOT
