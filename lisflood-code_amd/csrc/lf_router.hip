@@ -180,6 +180,14 @@ struct lf_router {
     int64_t site_cnt[2] = {-1, -1};
     std::vector<int64_t> h_level_start;
     std::vector<segment> schedule;
+    // level blocks of the fused sub-step wavefront (build_level_blocks): block b = levels [fb_level[b], fb_level[b+1]),
+    // cut into cones = the upstream ranges of chunks of its last level, no range wider than a workgroup; block b has
+    // fb_row[b+1] - fb_row[b] - 1 cones and one more row (the end of every level) in fb_cone, from entry fb_off[b] on,
+    // one start per level and row
+    std::vector<int> fb_level, fb_row;
+    lf_dbuf<int> fb_level_dev, fb_row_dev, fb_cone;
+    lf_dbuf<int> fb_off_dev;
+    int fb_lmax = 0;
     int64_t last_stats[4] = {0, 0, 0, 0};
     // profiling
     bool profile = false;
@@ -368,6 +376,94 @@ int route_device(lf_router *r, double *q_dev, const double *lat_dev, int section
 
 } // namespace
 
+// Level blocks for the fused sub-step wavefront (k_fused_cones): runs of consecutive levels of at most `wide` cells are
+// cut into blocks of up to lmax levels (LF_FUSED_LEVELS, default 16; 1 = off); a wider level is a block of its own.  A
+// block is cut into cones: chunks of its last level, as long as possible with no level of the cone wider than kBlock
+// cells; a block whose thinnest possible cone (one cell of the last level) is still too wide somewhere loses levels
+// until it fits (one level always does).  Nothing is built when no block holds more than one level.
+static int build_level_blocks(lf_router *r, const lf_graph *g)
+{
+    int lmax = 16;
+    if (const char *e = std::getenv("LF_FUSED_LEVELS")) lmax = std::atoi(e);
+    lmax = lmax < 1 ? 1 : (lmax > 64 ? 64 : lmax);
+    int64_t wide = 262144;
+    if (const char *e = std::getenv("LF_FUSED_WIDE")) wide = std::atoll(e);
+    const int64_t NL = g->NL;
+    if (lmax <= 1 || NL < 2 || g->N >= ((int64_t)1 << 31)) return LF_OK;
+    const std::vector<int64_t> &ls = g->level_start;
+    auto width = [&](int64_t k) { return ls[k + 1] - ls[k]; };
+    std::vector<int> level, row(1, 0), cone, off;
+    std::vector<int64_t> st(lmax), en(lmax);
+    // starts of the cone above last-level position `pos` of the block [k0, k0 + nl): st[nl-1] = pos, st[j] = first
+    // upstream position of st[j+1] (the end of level j when st[j+1] is the end of level j+1)
+    auto chain = [&](int k0, int nl, int64_t pos, std::vector<int64_t> &out) {
+        out[nl - 1] = pos;
+        for (int j = nl - 2; j >= 0; --j) {
+            pos = (pos < ls[k0 + j + 2]) ? (int64_t)g->ups_ptr[pos] : ls[k0 + j + 1];
+            out[j] = pos;
+        }
+    };
+    bool any = false;
+    try {
+        for (int64_t k = 0; k < NL;) {
+            int nl = 1;
+            if (width(k) <= wide)
+                while (k + nl < NL && nl < lmax && width(k + nl) <= wide) ++nl;
+            std::vector<int> rows; // starts, nl per cone, then the closing row
+            for (;; --nl) {        // shrink until every cone fits a workgroup
+                rows.clear();
+                const int k0 = (int)k;
+                const int64_t lo = ls[k0 + nl - 1], hi = ls[k0 + nl];
+                bool fits = true;
+                for (int64_t a = lo; a < hi && fits;) {
+                    chain(k0, nl, a, st);
+                    auto ok = [&](int64_t e) { // cone [a, e) of the last level: every level's range <= kBlock?
+                        chain(k0, nl, e, en);
+                        for (int j = 0; j < nl; ++j)
+                            if (en[j] - st[j] > kBlock) return false;
+                        return true;
+                    };
+                    int64_t e = std::min<int64_t>(a + kBlock, hi);
+                    if (!ok(e)) { // largest e in (a, a + kBlock) that fits: the widths grow with e
+                        int64_t good = a, bad = e;
+                        while (bad - good > 1) {
+                            const int64_t mid = good + (bad - good) / 2;
+                            if (ok(mid)) good = mid; else bad = mid;
+                        }
+                        e = good;
+                    }
+                    if (e == a) { // even one cell of the last level has too wide a cone
+                        fits = false;
+                        break;
+                    }
+                    for (int j = 0; j < nl; ++j) rows.push_back((int)st[j]);
+                    a = e;
+                }
+                if (fits || nl == 1) break;
+            }
+            for (int j = 0; j < nl; ++j) rows.push_back((int)ls[k + j + 1]); // closing row: the end of every level
+            level.push_back((int)k);
+            off.push_back((int)cone.size());
+            row.push_back(row.back() + (int)(rows.size() / nl));
+            cone.insert(cone.end(), rows.begin(), rows.end());
+            any = any || nl > 1;
+            k += nl;
+        }
+    } catch (const std::bad_alloc &) {
+        return lf_set_error(LF_E_INVALID, "out of host memory while building the level blocks");
+    }
+    if (!any || cone.size() >= ((size_t)1 << 31)) return LF_OK;
+    level.push_back((int)NL);
+    LF_TRY(r->fb_level_dev.upload(level.data(), level.size(), r->ctx->stream));
+    LF_TRY(r->fb_row_dev.upload(row.data(), row.size(), r->ctx->stream));
+    LF_TRY(r->fb_off_dev.upload(off.data(), off.size(), r->ctx->stream));
+    LF_TRY(r->fb_cone.upload(cone.data(), cone.size(), r->ctx->stream));
+    r->fb_level = level;
+    r->fb_row = row;
+    r->fb_lmax = lmax;
+    return LF_OK;
+}
+
 extern "C" {
 
 int lf_router_create(const lf_graph *g, const double *alpha, double beta, const double *dx, double dx_scalar, double dt,
@@ -506,6 +602,13 @@ int lf_router_create(const lf_graph *g, const double *alpha, double beta, const 
                 r->schedule.push_back({(int)k, (int)k + 1, true});
                 ++k;
             }
+        }
+    }
+    if (!g->has_links) {
+        rc = build_level_blocks(r, g);
+        if (rc != LF_OK) {
+            delete r;
+            return rc;
         }
     }
     *out = r;
@@ -946,6 +1049,13 @@ struct fused_args {
     // (packed = 0: 2-D grid, blockIdx.y = sub-step; used when nsteps > kMaxPackedSteps)
     int packed;
     int blk_start[kMaxPackedSteps + 1];
+    // level blocks (k_fused_blocked): t counts blocks instead of levels
+    const int *__restrict__ fb_level, *__restrict__ fb_row, *__restrict__ fb_cone;
+    const int *__restrict__ fb_off; // first entry of block b in fb_cone (rows of fb_level[b+1] - fb_level[b] starts)
+    int fb_nblocks;
+    // k_fused_substeps beside k_fused_cones: the level of sub-step s at this wave time (-1: none) instead of t - s
+    int use_lvl;
+    int lvl[kMaxPackedSteps];
 };
 
 __device__ __forceinline__ bool plus_zero(double x) { return __double_as_longlong(x) == 0; }
@@ -1163,7 +1273,7 @@ __global__ void __launch_bounds__(kBlock) k_fused_substeps(fused_args F)
         s = blockIdx.y;
         blk = blockIdx.x;
     }
-    const int k = F.t - s;             // level handled by this sub-step at wave time t
+    const int k = F.use_lvl ? F.lvl[s] : F.t - s; // level handled by this sub-step at wave time t
     if (k < 0 || k >= F.nlevels) return;
     const long long first = F.level_start[k];
     const long long i = (long long)blk * kBlock + threadIdx.x;
@@ -1172,6 +1282,332 @@ __global__ void __launch_bounds__(kBlock) k_fused_substeps(fused_args F)
     const int u0 = F.ups_ptr[p], u1 = F.ups_ptr[p + 1];
     const int kmax = F.kmax;
     fused_cell<SPLIT, STRUCT>(F, p, s, [u0, u1, kmax](const double *q, int) { return upstream_sum8(q, u0, u1, kmax); });
+}
+
+// ---- several levels per launch: the wavefront over LEVEL BLOCKS, one workgroup per upstream cone --------------------
+// One (level, sub-step) of k_fused_substeps is a dependent chain of ~4 memory round trips (kernel arguments -> level
+// table -> upstream ranges -> router outputs and ~25 state vectors) plus the two closure solves: ~9 us of kernel and a
+// ~2.5 us boundary on a latency-bound network (deep 5000^2: 5024 launches, 58 ms per model step).  Grouping several
+// levels into one launch with a workgroup barrier between them does not help by itself (measured: 58 ms for 1, 2, 4 and
+// 8 levels per launch) -- the chain is the cost, not the boundary.  This kernel shortens the chain:
+//  * the levels are grouped into blocks of up to fb_lmax consecutive levels and launch t works on (block t - s,
+//    sub-step s).  Every cell below the last level has exactly one downstream cell, in the next level, and the upstream
+//    cells of a contiguous range of positions are a contiguous range of the level before (lf_common.h, sweep order): a
+//    workgroup that owns a chunk of the block's LAST level owns the whole cone above it, level by level one contiguous
+//    range (fb_cone: its starts, precomputed; chunks are cut so that no range exceeds the workgroup), and the cones tile
+//    every level of the block -- no synchronisation between workgroups inside a block;
+//  * inside a cone the router outputs travel through LDS (two buffers by level parity), so the barrier between two
+//    levels waits for LDS only -- not for the state stores, which drain behind it -- and only the block's last level
+//    writes its router outputs to the parity buffers in HBM (read by the next block in the next launch);
+//  * the state of the NEXT level's cell is loaded before the current level is solved (it does not depend on anything
+//    computed in this launch), so after a barrier a level costs: 8 LDS reads, the two solves, a few LDS writes.
+// The arithmetic of a cell is fused_cell's, operation by operation: results are bit-identical.
+struct cone_cell { // what a cell's load phase leaves in registers: loaded values only, nothing computed from them (a
+                   // compare on a loaded value would make the wavefront wait for the loads right where they are issued)
+    double dxp, inv_len, len, side_m3, ap1, qold, alpha1, inv_alpha1, sum_old;
+    double m3, m3_2, start, m3limit, q2start, ap2, q2old, alpha2, inv_alpha2, qlimit, pix_area;
+    double chanq_old, csa_old, sf1_old; // only for the inert test
+    int u0, u1;
+    unsigned char chan_raw, inert_raw;
+    bool active;
+};
+
+template <bool SPLIT>
+__device__ __forceinline__ void cone_load(const fused_args &F, long long p, int s, bool active, cone_cell &R)
+{
+    const lf_substep_args &A = F.S;
+    R.active = active;
+    if (!active) return;
+    R.u0 = F.ups_ptr[p];
+    R.u1 = F.ups_ptr[p + 1];
+    R.dxp = F.dx ? F.dx[p] : F.dx_scalar;
+    R.inv_len = A.InvChanLength[p];
+    R.len = A.ChanLength[p];
+    R.chan_raw = A.IsChannelKinematic[p];
+    R.side_m3 = A.SideflowChanM3[(long long)s * F.side_stride + p];
+    R.ap1 = F.a1[p];
+    R.qold = A.ChanQKin[p];
+    R.alpha1 = A.ChannelAlpha[p];
+    R.inv_alpha1 = A.InvChannelAlpha[p];
+    R.sum_old = A.sumDisDay[p];
+    R.m3 = R.m3_2 = R.start = R.m3limit = R.q2start = R.ap2 = R.q2old = R.alpha2 = R.inv_alpha2 = R.qlimit = 0;
+    R.chanq_old = R.csa_old = R.sf1_old = 0;
+    R.inert_raw = 0;
+    const bool test_inert = F.inert && s != F.nsteps - 1; // see k_inert_flags / fused_cell (uniform)
+    if (SPLIT || test_inert) R.m3 = A.ChanM3Kin[p];
+    if (SPLIT) {
+        R.m3_2 = A.Chan2M3Kin[p];
+        R.start = A.Chan2M3Start[p];
+        R.m3limit = A.M3Limit[p];
+        R.q2start = A.Chan2QStart[p];
+        R.ap2 = F.a2[p];
+        R.q2old = A.Chan2QKin[p];
+        R.alpha2 = A.ChannelAlpha2[p];
+        R.inv_alpha2 = A.InvChannelAlpha2[p];
+        R.qlimit = A.QLimit[p];
+    }
+    R.pix_area = (s == F.nsteps - 1) ? A.PixelArea[p] : 0.0;
+    if (test_inert) {
+        R.inert_raw = F.inert[p];
+        R.chanq_old = A.ChanQ[p];
+        if (SPLIT) {
+            R.csa_old = A.CrossSection2Area[p];
+            R.sf1_old = A.Sideflow1Chan[p];
+        }
+    }
+}
+
+// the early return of fused_cell: an inert cell whose state is all +0.0 stays as it is
+template <bool SPLIT>
+__device__ __forceinline__ bool cone_skip(const cone_cell &R)
+{
+    if (!R.active) return true;
+    if (!R.inert_raw) return false;
+    bool zero = plus_zero(R.qold) && plus_zero(R.m3) && plus_zero(R.chanq_old);
+    if (SPLIT && zero) zero = plus_zero(R.q2old) && plus_zero(R.m3_2) && plus_zero(R.csa_old) && plus_zero(R.sf1_old);
+    return zero;
+}
+
+// The general-exponent paths (OCML pow: ~200 instructions per call site, ~25 call sites inlined into fused_cell) are
+// taken by single lanes with extreme arguments or not at all when beta = 3/5.  In the cone kernel's beta = 3/5 variant
+// they live out of line, one copy each, so that the loop over the levels of a cone is a few KB of straight code instead
+// of ~60 KB of mostly skipped blocks.  Same functions, same results.
+__device__ __attribute__((noinline)) double cold_pow(double x, double y) { return pow(x, y); }
+__device__ __attribute__((noinline)) double cold_solve(double c, double a, double ba, double beta, double inv_beta,
+                                                       double b_minus_1)
+{
+    return lf_solve_cell(c, a, ba, beta, inv_beta, b_minus_1);
+}
+// ALL35: beta == 3/5 for the fix-up round trips and for the router (both flags of fused_cell set), known on the host;
+// otherwise the flags are tested at run time exactly as fused_cell does
+template <bool ALL35>
+__device__ __forceinline__ double cone_pow_3_5(double x, double y, bool is35)
+{
+    if (!ALL35) return is35 ? lf_pow_3_5(x) : pow(x, y);
+    if (x == 0.0) return 0.0; // as lf_pow_3_5
+    if (lf_fast_range(x)) {
+        const double r = lf_root5(x);
+        return r * r * r;
+    }
+    return cold_pow(x, 0.6);
+}
+template <bool ALL35>
+__device__ __forceinline__ double cone_pow_5_3(double x, double y, bool is35)
+{
+    if (!ALL35) return is35 ? lf_pow_5_3(x) : pow(x, y);
+    if (x == 0.0) return 0.0; // as lf_pow_5_3
+    if (lf_fast_range(x)) {
+        const double r = lf_cbrt(x);
+        return x * (r * r);
+    }
+    return cold_pow(x, 1.0 / 0.6);
+}
+template <bool ALL35>
+__device__ __forceinline__ double cone_solve(double c, double ap, bool is35, const fused_args &F)
+{
+    if (!ALL35) return solve_any(c, ap, is35, F);
+    if (lf_fast_range(c) && lf_fast_range(ap)) return (c <= LF_NEWTON_TOL) ? 0.0 : lf_solve_3_5(c, ap);
+    return cold_solve(c, ap, F.beta * ap, F.beta, F.inv_beta, F.b_minus_1);
+}
+
+// everything after the loads of fused_cell<SPLIT, false>, in its order, up to the stores: the new state stays in
+// registers (cone_out) and is stored one level later, so that the stores have a whole level's arithmetic to drain
+struct cone_out {
+    double v, q, chanq, sum, s1, v2, csa, q2, vel, trav;
+    long long p;
+    bool valid;
+};
+
+template <bool SPLIT, bool ALL35>
+__device__ __forceinline__ void cone_compute(const fused_args &F, const cone_cell &R, long long p, int s, double ups1,
+                                             double ups2, double &qr_out, double &q2r_out, cone_out &O)
+{
+    const lf_substep_args &A = F.S;
+    const bool b35 = A.Beta == 0.6;
+    const bool s35 = F.solve35 != 0;
+    const bool last = s == F.nsteps - 1;
+    const double side = (R.chan_raw != 0) ? R.side_m3 * R.inv_len * A.InvDtRouting : 0.0;
+    double s1 = side, s2 = 0.0;
+    if (!SPLIT) {
+        if (isnan(side)) s1 = 0.0;
+    } else {
+        const double tot = R.m3 + R.m3_2;
+        const double ratio = (tot > 0) ? R.m3 / tot : 0.0;
+        s1 = ((tot - R.start) > R.m3limit) ? ratio * side : side;
+        if (fabs(side) < 1e-7) s1 = side;
+        s2 = (side - s1) + R.q2start * R.inv_len;
+    }
+    const double cst = R.ap1 * cone_pow_3_5<ALL35>(R.qold, F.beta, s35) + s1 * R.dxp;
+    const double c = ups1 + cst;
+    const double qr = cone_solve<ALL35>(c, R.ap1, s35, F);
+    double v = R.len * R.alpha1 * cone_pow_3_5<ALL35>(qr, A.Beta, b35);
+    if (v < 0.0) v = 0.0;
+    const double x = v * R.inv_len * R.inv_alpha1;
+    const double q = cone_pow_5_3<ALL35>(x, A.InvBeta, b35);
+    double chanq = q, q2r = 0, v2 = 0, q2 = 0;
+    if (SPLIT) {
+        const double cst2 = R.ap2 * cone_pow_3_5<ALL35>(R.q2old, F.beta, s35) + s2 * R.dxp;
+        const double c2 = ups2 + cst2;
+        q2r = cone_solve<ALL35>(c2, R.ap2, s35, F);
+        v2 = R.len * R.alpha2 * cone_pow_3_5<ALL35>(q2r, A.Beta, b35);
+        if ((v2 - R.start) < 0.0) v2 = R.start;
+        const double x2 = v2 * R.inv_len * R.inv_alpha2;
+        q2 = cone_pow_5_3<ALL35>(x2, A.InvBeta, b35);
+        chanq = q + q2 - R.qlimit;
+        if (chanq < 0.0) chanq = 0.0;
+    }
+    qr_out = qr;
+    q2r_out = q2r;
+    O.valid = true;
+    O.p = p;
+    O.v = v;
+    O.q = q;
+    O.chanq = chanq;
+    O.sum = R.sum_old + chanq;
+    O.s1 = s1;
+    O.v2 = v2;
+    O.csa = (v2 - R.start) * R.inv_len;
+    O.q2 = q2;
+    O.vel = O.trav = 0.0;
+    if (last) { // routing.py:693-703
+        double area = v * R.inv_len;
+        if (area < 0.01) area = 0.01;
+        const double v1 = q / area, vv2 = 0.36 * (ALL35 ? cold_pow(q, 0.24) : pow(q, 0.24));
+        double vel = (vv2 < v1) ? vv2 : v1;
+        if (isnan(vv2)) vel = vv2;
+        double sinu = sqrt(R.pix_area) * R.inv_len;
+        if (sinu > 1) sinu = 1;
+        vel *= sinu;
+        O.vel = vel;
+        O.trav = vel * A.DtSec;
+    }
+}
+
+template <bool SPLIT>
+__device__ __forceinline__ void cone_store(const fused_args &F, const cone_out &O, int s)
+{
+    if (!O.valid) return;
+    const lf_substep_args &A = F.S;
+    const long long p = O.p;
+    A.ChanM3Kin[p] = O.v;
+    A.ChanQKin[p] = O.q;
+    A.ChanQ[p] = O.chanq;
+    A.sumDisDay[p] = O.sum;
+    if (SPLIT) {
+        A.Sideflow1Chan[p] = O.s1;
+        A.Chan2M3Kin[p] = O.v2;
+        A.CrossSection2Area[p] = O.csa;
+        A.Chan2QKin[p] = O.q2;
+    }
+    if (s == F.nsteps - 1) {
+        A.FlowVelocity[p] = O.vel;
+        A.TravelDistance[p] = O.trav;
+    }
+}
+
+// LDS barrier: the wavefronts of the workgroup have finished their LDS writes; global stores keep draining
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+#ifndef LF_CONES_WAVES
+#define LF_CONES_WAVES 2
+#endif
+template <bool SPLIT, bool ALL35>
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(LF_CONES_WAVES))) k_fused_cones(fused_args F)
+{
+    __shared__ double x1[2][kBlock], x2[SPLIT ? 2 : 1][SPLIT ? kBlock : 1];
+    int s, blk;
+    if (F.packed) {
+        int cnt = 0, start = 0;
+        for (int q = 0; q < F.nsteps; ++q) {
+            const bool ge = (int)blockIdx.x >= F.blk_start[q];
+            cnt += ge ? 1 : 0;
+            start = ge ? F.blk_start[q] : start;
+        }
+        s = cnt - 1;
+        blk = (int)blockIdx.x - start;
+    } else {
+        s = blockIdx.y;
+        blk = blockIdx.x;
+    }
+    const int b = F.t - s;
+    if (b < 0 || b >= F.fb_nblocks) return;
+    // the plan is read through the constant address space: scalar loads, no vector-memory wait on the way (ld_table)
+    const int row0 = ld_table(F.fb_row, b), ncones = ld_table(F.fb_row, b + 1) - row0 - 1;
+    if (blk >= ncones) return;
+    const int nl = ld_table(F.fb_level, b + 1) - ld_table(F.fb_level, b);
+    const int *c0 = F.fb_cone + (size_t)ld_table(F.fb_off, b) + (size_t)blk * nl, *c1 = c0 + nl; // this cone / the next
+    const int kmax = F.kmax;
+    const long long par = (long long)(s & 1) * F.n;
+    const int tid = threadIdx.x;
+    cone_out pend;
+    pend.valid = false;
+    int first_up = 0; // first position of the level above (LDS index 0)
+    // One level of the cone: `cur` holds the loaded state of this thread's cell of level j, `nxt` receives that of level
+    // j + 1.  The loop below calls it with the two register sets swapping roles (no copies).
+    auto level = [&](int j, const cone_cell &cur, cone_cell &nxt, int first) {
+        const long long p = first + tid;
+        if (j > 0) lds_barrier(); // level j-1 of this cone is in LDS
+        // Right behind the barrier: the state stores of level j-1 and the state loads of level j+1.  Both have the
+        // arithmetic of level j to complete, so the wait at the end of this level finds them done (issued after the
+        // arithmetic, the stores' acknowledgement would be waited for on every level).
+        cone_store<SPLIT>(F, pend, s);
+        pend.valid = false;
+        int nfirst = 0;
+        if (j + 1 < nl) { // nothing of the next level's state depends on this launch
+            nfirst = ld_table(c0, j + 1);
+            cone_load<SPLIT>(F, nfirst + tid, s, nfirst + tid < ld_table(c1, j + 1), nxt);
+        }
+        if (!cone_skip<SPLIT>(cur)) {
+            double ups1, ups2 = 0.0;
+            if (j == 0) { // from the block before (previous launch) through the parity buffers
+                ups1 = upstream_sum8(F.qr1 + par, cur.u0, cur.u1, kmax);
+                if (SPLIT) ups2 = upstream_sum8(F.qr2 + par, cur.u0, cur.u1, kmax);
+            } else { // from LDS, branch-free: absent neighbours read slot 0 and add +0.0 (the sum as upstream_sum8)
+                const double *y1 = &x1[(j - 1) & 1][0], *y2 = &x2[SPLIT ? (j - 1) & 1 : 0][0];
+                const int base = cur.u0 - first_up;
+                double v1[8], v2[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const bool have = k < kmax && cur.u0 + k < cur.u1;
+                    const int idx = have ? base + k : 0;
+                    v1[k] = y1[idx];
+                    if (SPLIT) v2[k] = y2[idx];
+                    v1[k] = have ? v1[k] : 0.0;
+                    if (SPLIT) v2[k] = have ? v2[k] : 0.0;
+                }
+                ups1 = 0.0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) ups1 += v1[k];
+                if (SPLIT) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) ups2 += v2[k];
+                }
+            }
+            double qr, q2r;
+            cone_compute<SPLIT, ALL35>(F, cur, p, s, ups1, ups2, qr, q2r, pend);
+            if (j + 1 < nl) {
+                x1[j & 1][tid] = qr;
+                if (SPLIT) x2[j & 1][tid] = q2r;
+            } else { // the block's last level: read by the next block in the next launch
+                F.qr1[par + p] = qr;
+                if (SPLIT) F.qr2[par + p] = q2r;
+            }
+        }
+        // the loads of the next level (issued before this level's arithmetic) and the stores of the previous one: done
+        // by now.  Stated explicitly so that the compiler does not wait for `nxt` behind the NEXT level's stores.
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        first_up = first;
+        return nfirst;
+    };
+    cone_cell ra, rb;
+    int first = ld_table(c0, 0);
+    cone_load<SPLIT>(F, first + tid, s, first + tid < ld_table(c1, 0), ra);
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): inside the loop the current level's registers are always complete
+    for (int j = 0; j < nl; j += 2) {
+        first = level(j, ra, rb, first);
+        if (j + 1 < nl) first = level(j + 1, rb, ra, first);
+    }
+    cone_store<SPLIT>(F, pend, s);
 }
 
 // ---- the same wavefront INSIDE every bin of the component layout ---------------------------------------------------
@@ -1301,6 +1737,10 @@ int fused_impl(lf_router *r, const lf_substep_args *a, int nsteps, int64_t sidef
     F.linked = r->linked.p;
     F.inert = nullptr;
     F.site_level = nullptr;
+    F.fb_level = F.fb_row = F.fb_cone = nullptr;
+    F.fb_off = nullptr;
+    F.fb_nblocks = 0;
+    F.use_lvl = 0;
     std::memset(&F.I, 0, sizeof(F.I));
     hipStream_t s = r->ctx->stream;
     const int NL = (int)r->NL;
@@ -1429,6 +1869,78 @@ int fused_impl(lf_router *r, const lf_substep_args *a, int nsteps, int64_t sidef
             F.inert = r->inert.p;
             ++launches;
         }
+    }
+    if (!in && r->fb_lmax > 1 && nsteps <= kMaxPackedSteps) { // several levels per launch (k_fused_cones)
+        const int NB = (int)r->fb_level.size() - 1;
+        F.fb_level = r->fb_level_dev.p;
+        F.fb_row = r->fb_row_dev.p;
+        F.fb_cone = r->fb_cone.p;
+        F.fb_off = r->fb_off_dev.p;
+        F.fb_nblocks = NB;
+        auto cones = [&](int b) { return (int64_t)(r->fb_row[b + 1] - r->fb_row[b] - 1); };
+        auto multi = [&](int b) { return r->fb_level[b + 1] - r->fb_level[b] > 1; };
+        const bool all35 = r->fused && a->Beta == 0.6; // otherwise: run-time flags and inlined OCML pow, as fused_cell
+        for (int t = 0; t < NB + nsteps - 1; ++t) {
+            // (block t - q, sub-step q), q = 0 .. nsteps-1, are independent of each other: the blocks of several levels go
+            // to the cone kernel, the single (wide) levels to the level kernel, which streams them at full occupancy
+            F.t = t;
+            int64_t acc = 0;
+            for (int q = 0; q < nsteps; ++q) {
+                F.blk_start[q] = (int)acc;
+                const int b = t - q;
+                if (b >= 0 && b < NB && multi(b)) acc += cones(b);
+            }
+            F.blk_start[nsteps] = (int)acc;
+            if (acc >= ((int64_t)1 << 31)) return lf_set_error(LF_E_INVALID, "fused sub-steps: grid too large");
+            if (acc > 0) {
+                F.packed = 1;
+                F.use_lvl = 0;
+                const dim3 grid((unsigned)acc);
+                if (a->split && all35)
+                    hipLaunchKernelGGL((k_fused_cones<true, true>), grid, dim3(kBlock), 0, s, F);
+                else if (a->split)
+                    hipLaunchKernelGGL((k_fused_cones<true, false>), grid, dim3(kBlock), 0, s, F);
+                else if (all35)
+                    hipLaunchKernelGGL((k_fused_cones<false, true>), grid, dim3(kBlock), 0, s, F);
+                else
+                    hipLaunchKernelGGL((k_fused_cones<false, false>), grid, dim3(kBlock), 0, s, F);
+                ++launches;
+            }
+            int64_t acc1 = 0, widest = 0;
+            for (int q = 0; q < nsteps; ++q) {
+                F.blk_start[q] = (int)acc1;
+                F.lvl[q] = -1;
+                const int b = t - q;
+                if (b >= 0 && b < NB && !multi(b)) {
+                    const int k = r->fb_level[b];
+                    const int64_t w = r->h_level_start[k + 1] - r->h_level_start[k];
+                    F.lvl[q] = k;
+                    acc1 += blocks_for(w);
+                    widest = std::max(widest, w);
+                }
+            }
+            F.blk_start[nsteps] = (int)acc1;
+            if (acc1 > 0) {
+                F.use_lvl = 1;
+                F.packed = 0;
+                dim3 grid(blocks_for(widest), nsteps);
+                if (!grid2d && 2 * acc1 <= (int64_t)blocks_for(widest) * nsteps && acc1 < ((int64_t)1 << 31)) {
+                    F.packed = 1; // as below: packed where it halves the grid
+                    grid = dim3((unsigned)acc1, 1);
+                }
+                if (a->split)
+                    hipLaunchKernelGGL((k_fused_substeps<true, false>), grid, dim3(kBlock), 0, s, F);
+                else
+                    hipLaunchKernelGGL((k_fused_substeps<false, false>), grid, dim3(kBlock), 0, s, F);
+                ++launches;
+            }
+        }
+        LF_HIP(hipGetLastError());
+        r->last_stats[0] = launches;
+        r->last_stats[1] = launches;
+        r->last_stats[2] = 0;
+        r->last_stats[3] = r->NL;
+        return LF_OK;
     }
     for (int t = 0; t < NL + nsteps - 1; ++t) {
         // widest level inside the window [t - nsteps + 1, t]
