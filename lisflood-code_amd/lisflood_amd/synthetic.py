@@ -368,3 +368,24 @@ def structures_scenario(codes, shape, chan_q, dt_routing, n_lakes=64, n_res=192,
     d["TransPower1"], d["TransPower2"], d["TransSub"] = 1 / 0.95, 0.95, 1e-9
     d["TransCum"] = np.zeros(N)
     return d, cut
+
+
+def model_step_values(N, p, seed=17, ids=None):
+    """State and parameter vectors of a routing model step (split routing) for the synthetic benches and tests, as the
+    dict `RoutingStepDevice` / `routing.var_from_values` take; `p` = router_params(N); `ids`: only these pixels."""
+    rng = np.random.default_rng(seed)
+    beta, dt = p["beta"], 3600.0
+    alpha, length = p["alpha"], p["dx"]
+    alpha2 = alpha * rng.uniform(1.2, 2.0, N)
+    qlimit = 2.0 * p["Q0"] * rng.uniform(0.3, 1.2, N)
+    vals = dict(ChanLength=length, InvChanLength=1 / length, ChannelAlpha=alpha, InvChannelAlpha=1 / alpha,
+                ChannelAlpha2=alpha2, InvChannelAlpha2=1 / alpha2, QLimit=qlimit, M3Limit=alpha * length * qlimit ** beta,
+                Chan2M3Start=alpha2 * length * qlimit ** beta, Chan2QStart=qlimit * 0.1, PixelArea=np.full(N, 2.5e7),
+                IsChannelKinematic=np.ones(N, bool), SideflowChanM3=lateral_inflow(N, 0) * length * dt)
+    vals["Chan2M3Kin"] = vals["Chan2M3Start"].copy()
+    vals["ChanM3Kin"] = alpha * length * p["Q0"] ** beta
+    vals["ChanQKin"] = p["Q0"].copy()
+    vals["Chan2QKin"] = (vals["Chan2M3Kin"] / length / alpha2) ** (1 / beta)
+    if ids is not None:
+        vals = {k: np.ascontiguousarray(v[ids]) for k, v in vals.items()}
+    return vals, dt

@@ -1115,6 +1115,51 @@ def test_catchment_partition_routes_like_the_whole_domain(amd, family, nparts):
         assert np.array_equal(got, Qw), (family, s)
 
 
+@pytest.mark.parametrize("family,nparts", [("deep", 3), ("river", 2)])      # (this river raster has two catchments)
+def test_catchment_partition_model_step_fused(amd, family, nparts):
+    """configs[4]'s workload shape on a partition: every part runs the FUSED wavefront (24 split-routing sub-steps, level
+    blocks + cones) on its own whole catchments, no exchange -- state and outputs equal the whole-domain model step bit
+    for bit, two model steps in a row."""
+    from lisflood_amd import partition as P
+    from lisflood_amd import synthetic as syn
+    from lisflood_amd.kinematic_wave_parallel import kinematicWave
+    from lisflood_amd.routing_device import RoutingStepDevice
+    from test_full_size import model_step_values
+    H, W = 300, 280
+    N = H * W
+    nsteps = 24
+    mask = np.ones((H, W), bool)
+    codes = syn.make_ldd(family, H, W, 9).reshape(-1).astype(np.float64)
+    p = syn.router_params(N, seed=4)
+    vals, dt = model_step_values(N, p, np.random.default_rng(23))
+    side = [syn.lateral_inflow(N, s) * p["dx"] * dt for s in range(2)]
+    keys = ("ChanQ", "ChanQKin", "Chan2QKin", "ChanM3Kin", "Chan2M3Kin", "sumDisDay", "CrossSection2Area")
+
+    def run(c, m, ids):
+        kw = kinematicWave(c, m, p["alpha"][ids], p["beta"], p["dx"][ids], dt, alpha_floodplains=vals["ChannelAlpha2"][ids])
+        v = {k: (np.ascontiguousarray(x[ids]) if isinstance(x, np.ndarray) else x) for k, x in vals.items()}
+        v["SideflowChanM3"] = np.ascontiguousarray(side[0][ids])
+        st = RoutingStepDevice(kw, v, True, p["beta"], 1.0 / dt, dt * nsteps)
+        st.run_fused(nsteps)
+        st.dev["SideflowChanM3"].upload(np.ascontiguousarray(side[1][ids][st.perm]))
+        st.dev["sumDisDay"].zero()
+        st.run_fused(nsteps)
+        out = {k: st.download(k) for k in keys}
+        st.free(); kw.close()
+        return out
+
+    whole = run(codes, mask, np.arange(N))
+    parts, counts = P.catchment_partition(codes, mask, nparts)
+    assert counts.sum() == N and counts.min() > 0
+    got = {k: np.empty(N) for k in keys}
+    for c, m, ids in parts:
+        o = run(c, m, ids)
+        for k in keys:
+            got[k][ids] = o[k]
+    for k in keys:
+        assert np.array_equal(got[k], whole[k]), (family, k)
+
+
 def _model_var(N):
     """The slice of LisfloodModel_ini (Lisflood_initial.py:108-113, 272-345) the module classes read."""
     from collections import OrderedDict
