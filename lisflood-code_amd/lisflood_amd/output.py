@@ -143,11 +143,70 @@ def read_netcdf_classic(path, var_name):
         return a, np.array(f.variables[dx][:]), np.array(f.variables[dy][:]), t
 
 
-def write_state_maps(directory, maps, land_mask, x=None, y=None, time_value=None, **kw):
+def write_netcdf4(path, var_name, maps, x, y, time_values=None, time_units="days since 1990-01-01 00:00:00.0",
+                  calendar="proleptic_gregorian", dtype="f8", standard_name="", long_name="", units="",
+                  dims=("y", "x"), settings_path="", complevel=4, coord_attrs=None, projection=None,
+                  esri_pe_string=None):
+    """The reference's map writer (netcdf.py:432-583, `writenet`): a netCDF-4 (HDF5) file with dimensions x, y (, time),
+    coordinate variables, and the value variable `var_name` -- zlib (deflate `complevel`, shuffle), `_FillValue` -9999,
+    chunks (1, H, W) for a [T, H, W] stack (netcdf.py:559), one chunk for a single map.  Written by lisflood_amd.hdf5_min
+    (no HDF5 library in the image): old-style HDF5 structures, dimension scales with the netCDF-4 attributes.
+    `coord_attrs`: {dimension name: {attribute: value}} for x / y (the reference copies them from its template map),
+    `projection`: (variable name, {attributes}) for the scalar int grid-mapping variable (`laea`, netcdf.py:497-504)."""
+    from . import hdf5_min as H5
+    maps = np.asarray(maps, dtype=np.float64)
+    timed = maps.ndim == 3
+    if timed and (time_values is None or len(time_values) != maps.shape[0]):
+        raise ValueError("a [T, H, W] stack needs time_values[T]")
+    H, W = maps.shape[-2:]
+    if len(y) != H or len(x) != W:
+        raise ValueError("coordinate vectors do not match the map shape")
+    dy, dx = dims
+    coord_attrs = coord_attrs or {}
+    ds = []
+    if projection is not None:
+        ds.append(H5.Dataset(projection[0], np.array(0, np.int32), (), dict(projection[1])))
+    ds.append(H5.Dataset(dx, np.asarray(x, np.float64), (dx,), coord_attrs.get(dx, {})))
+    ds.append(H5.Dataset(dy, np.asarray(y, np.float64), (dy,), coord_attrs.get(dy, {})))
+    if timed:
+        ds.append(H5.Dataset("time", np.asarray(time_values, np.float64), ("time",),
+                             {"standard_name": "time", "calendar": calendar, "units": time_units}))
+    data = np.where(np.isnan(maps), FILL, maps).astype(dtype)
+    attrs = {"_FillValue": np.array([FILL], dtype=dtype), "standard_name": standard_name, "long_name": long_name,
+             "units": units}
+    if esri_pe_string:
+        attrs["esri_pe_string"] = esri_pe_string
+    ds.append(H5.Dataset(var_name, data, (("time",) if timed else ()) + (dy, dx), attrs,
+                         chunks=((1, H, W) if timed else (H, W)), deflate=complevel, shuffle=True,
+                         fill=np.array(FILL, dtype=dtype)))
+    H5.write(path, ds, {"settingsfile": settings_path, "date_created": time.ctime(time.time()),
+                        "Source_Software": "lisflood_amd", "source": "Lisflood output maps",
+                        "keywords": "Lisflood, EFAS, GLOFAS", "Conventions": "CF-1.6"})
+
+
+def read_netcdf4(path, var_name):
+    """-> (maps with NaN at _FillValue, x, y, time or None) of a file written by write_netcdf4 (or by libhdf5 with the
+    'earliest' format structures)"""
+    from . import hdf5_min as H5
+    r = H5.read(path)
+    a = r.dataset(var_name).astype(np.float64)
+    fv = r.attrs(var_name).get("_FillValue")
+    if fv is not None:
+        a[a == float(np.asarray(fv).reshape(-1)[0])] = np.nan
+    names = set(r.objects)
+    dx = "x" if "x" in names else "lon"
+    dy = "y" if "y" in names else "lat"
+    t = r.dataset("time") if "time" in names else None
+    return a, r.dataset(dx), r.dataset(dy), t
+
+
+def write_state_maps(directory, maps, land_mask, x=None, y=None, time_value=None, fmt="netcdf4", **kw):
     """One file per state map, named as the reference names it (`ChanQState.nc`, `Theta1ForestState.nc`, ...: the
     'repStateMaps' entries of default_options.py), each a [1, H, W] stack at the state step -- what a warm run reads back
-    through its *InitValue bindings.  `maps`: name -> compressed [N] vector (HotPathDevice.state_maps())."""
+    through its *InitValue bindings.  `maps`: name -> compressed [N] vector (HotPathDevice.state_maps()).
+    `fmt`: "netcdf4" (as the reference writes them) or "classic" (netCDF-3)."""
     import os
+    writer = {"netcdf4": write_netcdf4, "classic": write_netcdf_classic}[fmt]
     land_mask = np.asarray(land_mask, bool)
     H, W = land_mask.shape
     x = np.arange(W, dtype=np.float64) if x is None else x
@@ -155,8 +214,8 @@ def write_state_maps(directory, maps, land_mask, x=None, y=None, time_value=None
     os.makedirs(directory, exist_ok=True)
     for name, vec in maps.items():
         stack = decompress(vec, land_mask, fill=np.nan)[None]
-        write_netcdf_classic(os.path.join(directory, name + ".nc"), name, stack, x, y,
-                             time_values=[0.0 if time_value is None else float(time_value)], **kw)
+        writer(os.path.join(directory, name + ".nc"), name, stack, x, y,
+               time_values=[0.0 if time_value is None else float(time_value)], **kw)
 
 
 def read_state_maps(directory, land_mask, names=None):
@@ -169,7 +228,9 @@ def read_state_maps(directory, land_mask, names=None):
         name = os.path.splitext(os.path.basename(path))[0]
         if names is not None and name not in names:
             continue
-        a = read_netcdf_classic(path, name)[0]
+        with open(path, "rb") as f:
+            hdf5 = f.read(4) == b"\x89HDF"
+        a = (read_netcdf4 if hdf5 else read_netcdf_classic)(path, name)[0]
         v = a[-1][land_mask] if a.ndim == 3 else a[land_mask]
         out[name] = np.where(np.isnan(v), FILL, v)
     return out

@@ -1,0 +1,90 @@
+"""netCDF-4 (HDF5) map output without an HDF5 library: lisflood_amd.hdf5_min + output.write_netcdf4
+(reference: global_modules/netcdf.py:432-583, `writenet`: NETCDF4, zlib, _FillValue -9999, chunks (1, H, W)).
+
+The reader is pinned on a file written by libhdf5 itself (tests/golden/h5py_earliest.h5, made by
+tests/golden/make_hdf5_golden.py with h5py); the writer is pinned through the reader here and, in the container, by opening
+its files with h5py (`make_hdf5_golden.py check`, log in profiles/r02_netcdf4_h5py_check.txt)."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from lisflood_amd import hdf5_min as H5
+from lisflood_amd import output as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "h5py_earliest.h5")
+
+
+def test_reader_on_a_file_written_by_libhdf5():
+    r = H5.read(GOLD)
+    assert sorted(r.objects) == ["code", "dis", "time", "wide", "x", "y"]
+    rng = np.random.default_rng(11)                       # as make_hdf5_golden.py
+    a = rng.uniform(0.0, 250.0, (70, 5, 7))
+    a[:, 0, :2] = -9999.0
+    wide = rng.uniform(0, 1, (9, 11)).astype("f4")
+    assert np.array_equal(r.dataset("dis"), a)            # 70 chunks: a two-level chunk B-tree (K = 32), shuffle + deflate
+    assert np.array_equal(r.dataset("wide"), wide)        # 3 x 3 chunks of 4 x 4 with edge chunks, float32
+    assert np.array_equal(r.dataset("code"), np.arange(6, dtype="i4"))
+    assert np.array_equal(r.dataset("x"), np.arange(7) * 5000.0 + 2502500.0)
+    assert r.attrs()["Conventions"] == "CF-1.6"
+    t = r.attrs("time")
+    assert t["CLASS"] == "DIMENSION_SCALE" and t["NAME"] == "time" and int(t["_Netcdf4Dimid"]) == 2
+    assert t["units"] == "days since 2016-01-02 06:00:00.0"
+    assert float(r.attrs("dis")["_FillValue"][0]) == -9999.0
+
+
+@pytest.mark.parametrize("dtype", ["f8", "f4"])
+def test_map_stack_round_trip(tmp_path, dtype):
+    H, W, T = 23, 31, 130                                 # 130 chunks: more than the default node holds
+    rng = np.random.default_rng(3)
+    maps = rng.uniform(0, 500, (T, H, W))
+    maps[:, rng.uniform(size=(H, W)) < 0.3] = np.nan
+    x = np.arange(W) * 5000.0 + 2500.0
+    y = (np.arange(H) * 5000.0 + 2500.0)[::-1]
+    path = str(tmp_path / "dis.nc")
+    O.write_netcdf4(path, "dis", maps, x, y, time_values=np.arange(T) * 1.0, dtype=dtype, standard_name="DischargeMaps",
+                    long_name="ChanQAvg", units="m3/s", projection=("laea", {"grid_mapping_name": "lambert_azimuthal_equal_area"}),
+                    coord_attrs={"x": {"units": "Meter"}}, esri_pe_string="PROJCS[...]")
+    got, gx, gy, gt = O.read_netcdf4(path, "dis")
+    want = maps.astype(dtype).astype(np.float64)
+    assert np.array_equal(np.isnan(got), np.isnan(maps)) and np.array_equal(got[~np.isnan(got)], want[~np.isnan(maps)])
+    assert np.array_equal(gx, x) and np.array_equal(gy, y) and np.array_equal(gt, np.arange(T) * 1.0)
+    r = H5.read(path)
+    a = r.attrs("dis")
+    assert a["units"] == "m3/s" and a["long_name"] == "ChanQAvg" and list(a["_Netcdf4Coordinates"]) == [2, 1, 0]
+    assert [int(r.attrs(n)["_Netcdf4Dimid"]) for n in ("x", "y", "time")] == [0, 1, 2]
+    assert r.attrs("x")["units"] == "Meter" and r.attrs()["Conventions"] == "CF-1.6"
+    raw = open(path, "rb").read()
+    assert raw[:8] == H5.SIGNATURE and raw[8] == 1
+    assert struct.unpack_from("<Q", raw, 44)[0] == len(raw)               # end-of-file address of the superblock
+    # the references: REFERENCE_LIST of a scale points at the variable's object header, DIMENSION_LIST at the scales
+    kind, cls, shape, body = r.attrs("time")["REFERENCE_LIST"]
+    assert cls == 6 and shape == (1,) and struct.unpack_from("<Qi", body)[0] == r.objects["dis"] and struct.unpack_from("<Qi", body)[1] == 0
+    kind, cls, shape, body = a["DIMENSION_LIST"]
+    assert cls == 9 and shape == (3,)
+    gcol = struct.unpack_from("<IQI", body)[1]
+    assert raw[gcol:gcol + 4] == b"GCOL"
+    refs = [struct.unpack_from("<Q", raw, gcol + 16 + 24 * i + 16)[0] for i in range(3)]
+    assert refs == [r.objects["time"], r.objects["y"], r.objects["x"]]
+
+
+def test_single_map_and_state_maps(tmp_path):
+    H, W = 12, 9
+    rng = np.random.default_rng(8)
+    mask = rng.uniform(size=(H, W)) < 0.7
+    m = np.where(mask, rng.uniform(0, 3, (H, W)), np.nan)
+    path = str(tmp_path / "end.nc")
+    O.write_netcdf4(path, "ChanQEnd", m, np.arange(W, dtype=float), np.arange(H, dtype=float)[::-1])
+    got = O.read_netcdf4(path, "ChanQEnd")
+    assert got[3] is None and np.array_equal(np.isnan(got[0]), ~mask) and np.array_equal(got[0][mask], m[mask])
+    state = {"ChanQState": rng.uniform(0, 5, int(mask.sum())), "LakeLevelState": np.full(int(mask.sum()), -9999.0)}
+    for fmt in ("netcdf4", "classic"):
+        d = str(tmp_path / fmt)
+        O.write_state_maps(d, state, mask, fmt=fmt)
+        back = O.read_state_maps(d, mask)
+        assert sorted(back) == sorted(state)
+        for k in state:
+            assert np.array_equal(back[k], state[k]), (fmt, k)
+    with open(os.path.join(str(tmp_path / "netcdf4"), "ChanQState.nc"), "rb") as f:
+        assert f.read(8) == H5.SIGNATURE
