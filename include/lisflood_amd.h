@@ -161,6 +161,12 @@ int lf_router_route_host(lf_router *r, double *discharge_host, const double *lat
 /* Device-resident form: discharge_dev[N] (in/out) and lateral_dev[N] in pixel order, asynchronous on the
  * library stream. */
 int lf_router_route_device(lf_router *r, double *discharge_dev, const double *lateral_dev, int section);
+/* `count` (<= 4) routers built on ONE graph -- surface_routing.py:108-113 builds the direct / other / forest overland
+ * routers on the same LDD, and calls them one after the other (:151-153) -- swept together: one launch per level for
+ * all of them instead of one per router.  engine_order != 0: vectors in sweep order (lf_router_route_ordered).  Routers
+ * with different level schedules (or on the component layout) are simply swept one after the other. */
+int lf_router_route_device_multi(int count, lf_router **routers, double **discharge_dev, const double **lateral_dev,
+                                 int section, int engine_order);
 /* Engine-order form.  The engine's HBM layout of a per-pixel vector is "sweep order" (levels ascending,
  * breadth-first inside a level; lf_graph_get_layout's perm): in that layout every access of the sweep is
  * a coalesced stream and discharge is updated in place.  Element-wise work (routing.dynamic's fix-ups,

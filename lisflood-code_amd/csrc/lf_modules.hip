@@ -391,9 +391,12 @@ int lf_surface_step(lf_router *direct_router, lf_router *other_router, lf_router
     const dim3 grid(blocks_for(N)), block(kBlock);
     hipLaunchKernelGGL(k_surface_pre, grid, block, 0, c->stream, *a);
     // surface_routing.py:151-153 (section defaults to "main_channel")
-    LF_TRY(lf_router_route_device(direct_router, a->OFQDirect, a->scratch, LF_SECTION_MAIN));
-    LF_TRY(lf_router_route_device(other_router, a->OFQOther, a->scratch + N, LF_SECTION_MAIN));
-    LF_TRY(lf_router_route_device(forest_router, a->OFQForest, a->scratch + 2 * N, LF_SECTION_MAIN));
+    {   // the three routers share the LDD (surface_routing.py:108-113): one sweep for all of them
+        lf_router *rs[3] = {direct_router, other_router, forest_router};
+        double *q[3] = {a->OFQDirect, a->OFQOther, a->OFQForest};
+        const double *lat[3] = {a->scratch, a->scratch + N, a->scratch + 2 * N};
+        LF_TRY(lf_router_route_device_multi(3, rs, q, lat, LF_SECTION_MAIN, 0));
+    }
     hipLaunchKernelGGL(k_surface_post, grid, block, 0, c->stream, *a);
     LF_HIP(hipGetLastError());
     return LF_OK;

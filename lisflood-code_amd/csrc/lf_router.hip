@@ -249,18 +249,14 @@ struct lf_router {
 
 namespace {
 
-int enqueue_route(lf_router *r, double *q_dev, const double *lat_dev, int section, bool ordered)
+sweep_args make_sweep_args(lf_router *r, double *q_dev, const double *lat_dev, int section, bool ordered)
 {
-    hipStream_t s = r->ctx->stream;
-    const double *a = (section == LF_SECTION_MAIN) ? r->a1.p : r->a2.p;
-    const int n = (int)r->N;
-    int64_t launches = 0, wide = 0, narrow = 0;
     sweep_args A;
     A.ups_ptr = r->ups_ptr.p;
     A.ups_idx = nullptr;
     A.ups_base = nullptr;
     A.perm = r->perm.p;
-    A.a = a;
+    A.a = (section == LF_SECTION_MAIN) ? r->a1.p : r->a2.p;
     A.constant = r->constant.p;
     A.lat = lat_dev;
     A.dx = r->dx_per_pixel ? r->dx.p : nullptr;
@@ -271,6 +267,68 @@ int enqueue_route(lf_router *r, double *q_dev, const double *lat_dev, int sectio
     A.kmax = r->kmax;
     A.qord = ordered ? q_dev : r->qord.p;
     A.q_pix = ordered ? nullptr : q_dev;
+    return A;
+}
+
+// `count` routers built on the same graph (same level schedule), swept level by level with ONE launch per level
+int enqueue_route_multi(int count, lf_router **rs, double **q_dev, const double **lat_dev, int section, bool ordered)
+{
+    lf_router *r = rs[0];
+    hipStream_t s = r->ctx->stream;
+    const int n = (int)r->N;
+    sweep_args_multi M;
+    for (int i = 0; i < kMaxMulti; ++i) M.r[i] = make_sweep_args(rs[i < count ? i : 0], q_dev[i < count ? i : 0], lat_dev[i < count ? i : 0], section, ordered);
+    int64_t launches = 0, wide = 0, narrow = 0;
+    if (n > 0 && !r->fused)
+        for (int i = 0; i < count; ++i) {
+            hipLaunchKernelGGL(k_prep, dim3(blocks_for(n)), dim3(kBlock), 0, s, n, ordered ? nullptr : rs[i]->perm.p, q_dev[i],
+                               lat_dev[i], M.r[i].a, M.r[i].dx, rs[i]->dx_scalar, rs[i]->beta, rs[i]->constant.p);
+            ++launches;
+        }
+    for (const segment &g : r->schedule) {
+        if (g.wide) {
+            const int first = (int)r->h_level_start[g.k0];
+            const int cells = (int)(r->h_level_start[g.k1] - r->h_level_start[g.k0]);
+            const dim3 grid(blocks_for(cells), count), block(kBlock);
+            if (r->fused && ordered)
+                hipLaunchKernelGGL((k_level_multi<true, true>), grid, block, 0, s, first, cells, M);
+            else if (r->fused)
+                hipLaunchKernelGGL((k_level_multi<true, false>), grid, block, 0, s, first, cells, M);
+            else if (ordered)
+                hipLaunchKernelGGL((k_level_multi<false, true>), grid, block, 0, s, first, cells, M);
+            else
+                hipLaunchKernelGGL((k_level_multi<false, false>), grid, block, 0, s, first, cells, M);
+            ++wide;
+        } else {
+            const dim3 grid(count), block(kNarrowBlock);
+            if (r->fused && ordered)
+                hipLaunchKernelGGL((k_levels_narrow_multi<true, true>), grid, block, 0, s, g.k0, g.k1, r->level_start.p, M);
+            else if (r->fused)
+                hipLaunchKernelGGL((k_levels_narrow_multi<true, false>), grid, block, 0, s, g.k0, g.k1, r->level_start.p, M);
+            else if (ordered)
+                hipLaunchKernelGGL((k_levels_narrow_multi<false, true>), grid, block, 0, s, g.k0, g.k1, r->level_start.p, M);
+            else
+                hipLaunchKernelGGL((k_levels_narrow_multi<false, false>), grid, block, 0, s, g.k0, g.k1, r->level_start.p, M);
+            ++narrow;
+        }
+        ++launches;
+    }
+    for (int i = 0; i < count; ++i) {
+        rs[i]->last_stats[0] = launches;
+        rs[i]->last_stats[1] = wide;
+        rs[i]->last_stats[2] = narrow;
+        rs[i]->last_stats[3] = rs[i]->NL;
+    }
+    return LF_OK;
+}
+
+int enqueue_route(lf_router *r, double *q_dev, const double *lat_dev, int section, bool ordered)
+{
+    hipStream_t s = r->ctx->stream;
+    const int n = (int)r->N;
+    int64_t launches = 0, wide = 0, narrow = 0;
+    sweep_args A = make_sweep_args(r, q_dev, lat_dev, section, ordered);
+    const double *a = A.a;
     if (n > 0 && !r->fused) {
         LF_TRY(r->prof_begin(0, n));
         hipLaunchKernelGGL(k_prep, dim3(blocks_for(n)), dim3(kBlock), 0, s, n, ordered ? nullptr : r->perm.p, q_dev,
@@ -627,6 +685,36 @@ int lf_router_route_device(lf_router *r, double *discharge_dev, const double *la
 {
     if (!r || !discharge_dev || !lateral_dev) return lf_set_error(LF_E_INVALID, "null argument");
     return route_device(r, discharge_dev, lateral_dev, section);
+}
+
+// Several routers with the same level schedule (built on one lf_graph: e.g. the three overland routers of
+// surface_routing.py:108-113, which differ in alpha only) swept together, one launch per level for all of them.  Routers
+// whose schedules differ, or on the component layout, are swept one after the other.  engine_order != 0: the vectors
+// are resident in the routers' sweep order (lf_router_route_ordered), else in pixel order (lf_router_route_device).
+int lf_router_route_device_multi(int count, lf_router **routers, double **discharge_dev, const double **lateral_dev,
+                                 int section, int engine_order)
+{
+    if (count < 1 || !routers || !discharge_dev || !lateral_dev) return lf_set_error(LF_E_INVALID, "null argument");
+    for (int i = 0; i < count; ++i)
+        if (!routers[i] || !discharge_dev[i] || !lateral_dev[i]) return lf_set_error(LF_E_INVALID, "null argument");
+    if (section != LF_SECTION_MAIN && section != LF_SECTION_FLOODPLAINS)
+        return lf_set_error(LF_E_SECTION, "The section parameter must be either 'main_channel' or 'floodplain'!");
+    bool together = count > 1 && count <= kMaxMulti;
+    for (int i = 0; i < count && together; ++i) {
+        const lf_router *r = routers[i], *r0 = routers[0];
+        together = !r->comp && !r->linked.p && r->device == r0->device && r->ctx == r0->ctx && r->N == r0->N &&
+                   r->fused == r0->fused && r->h_level_start == r0->h_level_start && !r->profile &&
+                   (section == LF_SECTION_MAIN || r->has_floodplains);
+    }
+    if (!together) {
+        for (int i = 0; i < count; ++i)
+            LF_TRY(route_device(routers[i], discharge_dev[i], lateral_dev[i], section, engine_order != 0));
+        return LF_OK;
+    }
+    LF_HIP(hipSetDevice(routers[0]->device));
+    LF_TRY(enqueue_route_multi(count, routers, discharge_dev, lateral_dev, section, engine_order != 0));
+    LF_HIP(hipGetLastError());
+    return LF_OK;
 }
 
 int lf_router_route_ordered(lf_router *r, double *discharge_ord_dev, const double *lateral_ord_dev, int section)

@@ -350,6 +350,35 @@ __global__ void __launch_bounds__(kBlock) k_level(int first, int count, sweep_ar
     sweep_cell<FUSED, ORDERED, INDEXED>(first + i, A);
 }
 
+// Several routers on ONE graph (surface_routing.py:151-153: the direct / other / forest overland routers differ only in
+// alpha and in their vectors) swept together: blockIdx.y (wide levels) or blockIdx.x (narrow runs) picks the router, so a
+// level costs one launch for all of them.
+constexpr int kMaxMulti = 4;
+struct sweep_args_multi {
+    sweep_args r[kMaxMulti];
+};
+
+template <bool FUSED, bool ORDERED>
+__global__ void __launch_bounds__(kBlock) k_level_multi(int first, int count, sweep_args_multi M)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= count) return;
+    sweep_cell<FUSED, ORDERED, false>(first + i, M.r[blockIdx.y]);
+}
+
+template <bool FUSED, bool ORDERED>
+__global__ void __launch_bounds__(kNarrowBlock) k_levels_narrow_multi(int k0, int k1, const long long *__restrict__ level_start,
+                                                                      sweep_args_multi M)
+{
+    const sweep_args &A = M.r[blockIdx.x];
+    for (int k = k0; k < k1; ++k) {
+        const int first = (int)level_start[k], last = (int)level_start[k + 1];
+        for (int p = first + (int)threadIdx.x; p < last; p += kNarrowBlock) sweep_cell<FUSED, ORDERED, false>(p, A);
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
 // a run of narrow levels [k0, k1): one workgroup, barrier between levels
 template <bool FUSED, bool ORDERED, bool INDEXED = false>
 __global__ void __launch_bounds__(kNarrowBlock) k_levels_narrow(int k0, int k1, const long long *__restrict__ level_start,

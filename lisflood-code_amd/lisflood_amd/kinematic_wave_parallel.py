@@ -224,6 +224,18 @@ class kinematicWave:
         sec = self._section(section)
         check(lib().lf_router_route_ordered(self._h, discharge_ord_dev.ptr, lateral_ord_dev.ptr, C.c_int(sec)))
 
+    @staticmethod
+    def route_together(routers, discharge_devs, lateral_devs, section="main_channel", engine_order=False):
+        """Several routers built on the same graph (the direct / other / forest overland routers of
+        surface_routing.py:108-113) swept with one launch per level for all of them -- lf_router_route_device_multi.
+        DeviceArray vectors, pixel order unless engine_order."""
+        n = len(routers)
+        sec = kinematicWave._section(section)
+        hs = (C.c_void_p * n)(*[r._h for r in routers])
+        qs = (C.c_void_p * n)(*[q.ptr for q in discharge_devs])
+        ls = (C.c_void_p * n)(*[x.ptr for x in lateral_devs])
+        check(lib().lf_router_route_device_multi(C.c_int(n), hs, qs, ls, C.c_int(sec), C.c_int(1 if engine_order else 0)))
+
     def _warn(self):
         self.kinematic_wave_warning_printed = True
         warnings.warn(LisfloodWarning("Warning: NaN or Inf values after kinematicRouting module. Suggestion: please "

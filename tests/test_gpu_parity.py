@@ -1115,6 +1115,41 @@ def test_catchment_partition_routes_like_the_whole_domain(amd, family, nparts):
         assert np.array_equal(got, Qw), (family, s)
 
 
+@pytest.mark.parametrize("family", ["shallow", "deep", "river"])
+def test_routers_on_one_graph_swept_together(amd, solver, family):
+    """lf_router_route_device_multi: three routers on the same graph (different alpha, own vectors), one launch per level
+    for all of them -- bit-identical to three separate sweeps, in pixel order and in engine order, over 3 calls."""
+    from lisflood_amd import synthetic as syn
+    from lisflood_amd._lib import DeviceArray
+    from lisflood_amd.kinematic_wave_parallel import Graph, kinematicWave
+    H, W = 180, 140
+    N = H * W
+    codes = syn.make_ldd(family, H, W, 5)
+    p = syn.router_params(N, seed=3)
+    g = Graph(ldd_raster=codes)
+    rng = np.random.default_rng(9)
+    alphas = [p["alpha"] * f for f in (1.0, 0.6, 1.7)]
+    kws = [kinematicWave(None, None, a, p["beta"], p["dx"], p["dt"], graph=g) for a in alphas]
+    Q0 = [p["Q0"] * rng.uniform(0.5, 1.5, N) for _ in kws]
+    for ordered in (False, True):
+        qa = [DeviceArray.from_host(q) for q in Q0]
+        qb = [DeviceArray.from_host(q) for q in Q0]
+        for s in range(3):
+            lat = [DeviceArray.from_host(syn.lateral_inflow(N, s) * f) for f in (1.0, 2.0, 0.5)]
+            for kw, q, x in zip(kws, qa, lat):
+                (kw.route_ordered if ordered else kw.route_device)(q, x)
+            kinematicWave.route_together(kws, qb, lat, engine_order=ordered)
+            for i in range(3):
+                assert np.array_equal(qa[i].download(), qb[i].download()), (family, ordered, s, i)
+            for x in lat:
+                x.free()
+        assert kws[0].last_launches()["launches"] <= g.num_levels + 1
+        for d in qa + qb:
+            d.free()
+    for kw in kws:
+        kw.close()
+
+
 @pytest.mark.parametrize("family,nparts", [("deep", 3), ("river", 2)])      # (this river raster has two catchments)
 def test_catchment_partition_model_step_fused(amd, family, nparts):
     """configs[4]'s workload shape on a partition: every part runs the FUSED wavefront (24 split-routing sub-steps, level
