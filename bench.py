@@ -304,11 +304,15 @@ def model_step_bench(size=5000, nsteps=24, family="deep"):
     vals["Chan2QKin"] = (vals["Chan2M3Kin"] / length / alpha2) ** (1 / beta)
     out = {}
     ref = None
-    for mode in ("fused", "sequential", "sequential_single_sweep"):
-        st = RoutingStepDevice(kw, vals, True, beta, 1.0 / dt, dt * nsteps)
-        run = {"fused": st.run_fused, "sequential": st.run_sequential, "sequential_single_sweep": st.run_single_sweep}[mode]
-        reps = 3 if mode == "fused" else 1
-        if mode == "fused":
+    os.environ["LF_FUSED_LEVELS"] = "1"      # A/B: the wavefront one level per launch (the round-1 kernel)
+    kw1 = kinematicWave(None, None, alpha, beta, length, dt, alpha_floodplains=alpha2, graph=g)
+    del os.environ["LF_FUSED_LEVELS"]
+    for mode in ("fused", "fused_level_by_level", "sequential", "sequential_single_sweep"):
+        st = RoutingStepDevice(kw1 if mode == "fused_level_by_level" else kw, vals, True, beta, 1.0 / dt, dt * nsteps)
+        run = {"fused": st.run_fused, "fused_level_by_level": st.run_fused, "sequential": st.run_sequential,
+               "sequential_single_sweep": st.run_single_sweep}[mode]
+        reps = 3 if mode.startswith("fused") else 1
+        if mode.startswith("fused"):
             run(nsteps)                  # warm-up
         _lib.synchronize()
         t0 = time.perf_counter()
@@ -317,11 +321,15 @@ def model_step_bench(size=5000, nsteps=24, family="deep"):
         _lib.synchronize()
         ms = (time.perf_counter() - t0) * 1e3 / reps
         out[mode] = dict(ms_per_model_step=round(ms, 3), value=round(2 * nsteps * N / ms / 1e3, 2),
-                         unit="Mcell-steps/s", launches_per_model_step=kw.last_launches()["launches"] *
-                         {"fused": 1, "sequential": 2 * nsteps, "sequential_single_sweep": nsteps}[mode])
+                         unit="Mcell-steps/s",
+                         launches_per_model_step=(kw1 if mode == "fused_level_by_level" else kw).last_launches()["launches"] *
+                         {"fused": 1, "fused_level_by_level": 1, "sequential": 2 * nsteps, "sequential_single_sweep": nsteps}[mode])
         st.free()
     out["config"] = "%dx%d %s LDD (NL=%d), NoRoutSteps=%d, split routing: %d cell-steps per cell per model step" % (
         H, W, family, g.num_levels, nsteps, 2 * nsteps)
+    out["note"] = ("fused = lf_routing_substeps_fused: one wavefront over blocks of up to 16 levels, each block swept cone by "
+                   "cone through LDS (k_fused_cones); fused_level_by_level = the same call with LF_FUSED_LEVELS=1")
+    kw1.close()
     kw.close()
     return out
 

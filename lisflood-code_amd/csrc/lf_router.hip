@@ -186,7 +186,8 @@ struct lf_router {
     // one start per level and row
     std::vector<int> fb_level, fb_row;
     lf_dbuf<int> fb_level_dev, fb_row_dev, fb_cone;
-    lf_dbuf<int> fb_off_dev;
+    lf_dbuf<int> fb_off_dev, fb_lvl2blk_dev; // fb_lvl2blk: block of every level (the sites of the structures variant)
+    std::vector<int> fb_lvl2blk;
     int fb_lmax = 0;
     int64_t last_stats[4] = {0, 0, 0, 0};
     // profiling
@@ -516,6 +517,11 @@ static int build_level_blocks(lf_router *r, const lf_graph *g)
     LF_TRY(r->fb_row_dev.upload(row.data(), row.size(), r->ctx->stream));
     LF_TRY(r->fb_off_dev.upload(off.data(), off.size(), r->ctx->stream));
     LF_TRY(r->fb_cone.upload(cone.data(), cone.size(), r->ctx->stream));
+    std::vector<int> lvl2blk((size_t)NL, 0);
+    for (size_t b = 0; b + 1 < level.size(); ++b)
+        for (int k = level[b]; k < level[b + 1]; ++k) lvl2blk[k] = (int)b;
+    LF_TRY(r->fb_lvl2blk_dev.upload(lvl2blk.data(), lvl2blk.size(), r->ctx->stream));
+    r->fb_lvl2blk = lvl2blk;
     r->fb_level = level;
     r->fb_row = row;
     r->fb_lmax = lmax;
@@ -662,12 +668,12 @@ int lf_router_create(const lf_graph *g, const double *alpha, double beta, const 
             }
         }
     }
-    if (!g->has_links) {
-        rc = build_level_blocks(r, g);
-        if (rc != LF_OK) {
-            delete r;
-            return rc;
-        }
+    // (zero-length structure links need nothing special: such cells sit at the end of their level, inside the upstream
+    // range of the LAST cell of the next level -- which adds their 0.0 -- and so inside the last cone of a block)
+    rc = build_level_blocks(r, g);
+    if (rc != LF_OK) {
+        delete r;
+        return rc;
     }
     *out = r;
     return LF_OK;
@@ -1140,6 +1146,7 @@ struct fused_args {
     // level blocks (k_fused_blocked): t counts blocks instead of levels
     const int *__restrict__ fb_level, *__restrict__ fb_row, *__restrict__ fb_cone;
     const int *__restrict__ fb_off; // first entry of block b in fb_cone (rows of fb_level[b+1] - fb_level[b] starts)
+    const int *__restrict__ fb_lvl2blk; // block of every level
     int fb_nblocks;
     // k_fused_substeps beside k_fused_cones: the level of sub-step s at this wave time (-1: none) instead of t - s
     int use_lvl;
@@ -1180,6 +1187,16 @@ __global__ void __launch_bounds__(kBlock) k_sites_wave(fused_args F)
     const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (i >= F.I.n_lakes + F.I.n_res) return;
     const int s = F.t - F.site_level[i];
+    if (s < 0 || s >= F.nsteps) return;
+    lf_site_update(F.I, i);
+}
+
+// the same on level blocks (k_fused_cones): launch t works on (block t - s, sub-step s)
+__global__ void __launch_bounds__(kBlock) k_sites_blocks(fused_args F)
+{
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= F.I.n_lakes + F.I.n_res) return;
+    const int s = F.t - F.fb_lvl2blk[F.site_level[i]];
     if (s < 0 || s >= F.nsteps) return;
     lf_site_update(F.I, i);
 }
@@ -1394,13 +1411,15 @@ struct cone_cell { // what a cell's load phase leaves in registers: loaded value
                    // compare on a loaded value would make the wavefront wait for the loads right where they are issued)
     double dxp, inv_len, len, side_m3, ap1, qold, alpha1, inv_alpha1, sum_old;
     double m3, m3_2, start, m3limit, q2start, ap2, q2old, alpha2, inv_alpha2, qlimit, pix_area;
-    double chanq_old, csa_old, sf1_old; // only for the inert test
+    double chanq_old, csa_old, sf1_old; // the inert test; STRUCT: chanq_old = ChanQ before the sub-step (transmission loss)
+    // STRUCT: the terms of the sideflow assembly (routing.py:462-478), as k_inloop_dense / fused_cell read them
+    double eva, wuse, qin_old, qdelta, qin_added_old, transcum, lakeout, resout, polder;
     int u0, u1;
-    unsigned char chan_raw, inert_raw;
+    unsigned char chan_raw, inert_raw, uptrans_raw, cut_raw;
     bool active;
 };
 
-template <bool SPLIT>
+template <bool SPLIT, bool STRUCT>
 __device__ __forceinline__ void cone_load(const fused_args &F, long long p, int s, bool active, cone_cell &R)
 {
     const lf_substep_args &A = F.S;
@@ -1412,16 +1431,38 @@ __device__ __forceinline__ void cone_load(const fused_args &F, long long p, int 
     R.inv_len = A.InvChanLength[p];
     R.len = A.ChanLength[p];
     R.chan_raw = A.IsChannelKinematic[p];
-    R.side_m3 = A.SideflowChanM3[(long long)s * F.side_stride + p];
+    R.chanq_old = R.csa_old = R.sf1_old = 0;
+    R.inert_raw = R.uptrans_raw = R.cut_raw = 0;
+    R.eva = R.wuse = R.qin_old = R.qdelta = R.qin_added_old = R.transcum = R.lakeout = R.resout = R.polder = 0;
+    if (!STRUCT)
+        R.side_m3 = A.SideflowChanM3[(long long)s * F.side_stride + p];
+    else {
+        const lf_inloop_args &I = F.I;
+        R.side_m3 = I.ToChanM3RunoffDt[p];
+        if (I.EvaAddM3Dt) R.eva = I.EvaAddM3Dt[p];
+        if (I.WUseAddM3Dt) R.wuse = I.WUseAddM3Dt[p];
+        if (I.QInM3Old) {
+            R.qin_old = I.QInM3Old[p];
+            R.qdelta = I.QDelta[p];
+            R.qin_added_old = I.QinADDEDM3[p];
+        }
+        if (I.UpTrans) {
+            R.chanq_old = A.ChanQ[p];
+            R.uptrans_raw = I.UpTrans[p];
+            R.transcum = I.TransCum[p];
+        }
+        if (I.QLakeOutM3Dt) R.lakeout = I.QLakeOutM3Dt[p];
+        if (I.QResOutM3Dt) R.resout = I.QResOutM3Dt[p];
+        if (I.ChannelToPolderM3Dt) R.polder = I.ChannelToPolderM3Dt[p];
+    }
+    if (F.linked) R.cut_raw = F.linked[p]; // (also without STRUCT: a sub-step at a time on a graph with structure links)
     R.ap1 = F.a1[p];
     R.qold = A.ChanQKin[p];
     R.alpha1 = A.ChannelAlpha[p];
     R.inv_alpha1 = A.InvChannelAlpha[p];
     R.sum_old = A.sumDisDay[p];
     R.m3 = R.m3_2 = R.start = R.m3limit = R.q2start = R.ap2 = R.q2old = R.alpha2 = R.inv_alpha2 = R.qlimit = 0;
-    R.chanq_old = R.csa_old = R.sf1_old = 0;
-    R.inert_raw = 0;
-    const bool test_inert = F.inert && s != F.nsteps - 1; // see k_inert_flags / fused_cell (uniform)
+    const bool test_inert = !STRUCT && F.inert && s != F.nsteps - 1; // see k_inert_flags / fused_cell (uniform)
     if (SPLIT || test_inert) R.m3 = A.ChanM3Kin[p];
     if (SPLIT) {
         R.m3_2 = A.Chan2M3Kin[p];
@@ -1502,11 +1543,12 @@ __device__ __forceinline__ double cone_solve(double c, double ap, bool is35, con
 // registers (cone_out) and is stored one level later, so that the stores have a whole level's arithmetic to drain
 struct cone_out {
     double v, q, chanq, sum, s1, v2, csa, q2, vel, trav;
+    double qin, qin_added, loss, trans_cum, side_m3; // STRUCT
     long long p;
     bool valid;
 };
 
-template <bool SPLIT, bool ALL35>
+template <bool SPLIT, bool ALL35, bool STRUCT>
 __device__ __forceinline__ void cone_compute(const fused_args &F, const cone_cell &R, long long p, int s, double ups1,
                                              double ups2, double &qr_out, double &q2r_out, cone_out &O)
 {
@@ -1514,7 +1556,34 @@ __device__ __forceinline__ void cone_compute(const fused_args &F, const cone_cel
     const bool b35 = A.Beta == 0.6;
     const bool s35 = F.solve35 != 0;
     const bool last = s == F.nsteps - 1;
-    const double side = (R.chan_raw != 0) ? R.side_m3 * R.inv_len * A.InvDtRouting : 0.0;
+    double side_m3 = R.side_m3;
+    O.qin = O.qin_added = O.loss = O.trans_cum = 0.0;
+    if (STRUCT) { // inflow.py:142-144, transmission.py:76-87, sideflow assembly routing.py:462-478 -- as fused_cell
+        const lf_inloop_args &I = F.I;
+        if (I.EvaAddM3Dt) side_m3 -= R.eva;
+        if (I.WUseAddM3Dt) side_m3 -= R.wuse;
+        if (I.QInM3Old) {
+            O.qin = (R.qin_old + (s + 1) * R.qdelta) * I.InvNoRoutSteps;
+            O.qin_added = (s < 1 ? 0.0 : R.qin_added_old) + O.qin;
+            side_m3 += O.qin;
+        }
+        if (I.UpTrans) {
+            const double qc = R.chanq_old;
+            double tout = qc;
+            if (R.uptrans_raw) {
+                const double inner = (ALL35 ? cold_pow(qc, I.TransPower2) : pow(qc, I.TransPower2)) - I.TransSub;
+                tout = ALL35 ? cold_pow(inner, I.TransPower1) : pow(inner, I.TransPower1);
+            }
+            O.loss = (qc - tout) * I.DtRouting;
+            O.trans_cum = R.transcum + O.loss;
+            side_m3 -= O.loss;
+        }
+        if (I.QLakeOutM3Dt) side_m3 += R.lakeout;
+        if (I.QResOutM3Dt) side_m3 += R.resout;
+        if (I.ChannelToPolderM3Dt) side_m3 -= R.polder;
+    }
+    O.side_m3 = side_m3;
+    const double side = (R.chan_raw != 0) ? side_m3 * R.inv_len * A.InvDtRouting : 0.0;
     double s1 = side, s2 = 0.0;
     if (!SPLIT) {
         if (isnan(side)) s1 = 0.0;
@@ -1571,12 +1640,24 @@ __device__ __forceinline__ void cone_compute(const fused_args &F, const cone_cel
     }
 }
 
-template <bool SPLIT>
+template <bool SPLIT, bool STRUCT>
 __device__ __forceinline__ void cone_store(const fused_args &F, const cone_out &O, int s)
 {
     if (!O.valid) return;
     const lf_substep_args &A = F.S;
     const long long p = O.p;
+    if (STRUCT) {
+        const lf_inloop_args &I = F.I;
+        if (I.QInM3Old) {
+            I.QInDt[p] = O.qin;
+            I.QinADDEDM3[p] = O.qin_added;
+        }
+        if (I.UpTrans) {
+            I.TransLossM3Dt[p] = O.loss;
+            I.TransCum[p] = O.trans_cum;
+        }
+        I.SideflowChanM3[p] = O.side_m3;
+    }
     A.ChanM3Kin[p] = O.v;
     A.ChanQKin[p] = O.q;
     A.ChanQ[p] = O.chanq;
@@ -1599,7 +1680,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 #ifndef LF_CONES_WAVES
 #define LF_CONES_WAVES 2
 #endif
-template <bool SPLIT, bool ALL35>
+template <bool SPLIT, bool ALL35, bool STRUCT>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(LF_CONES_WAVES))) k_fused_cones(fused_args F)
 {
     __shared__ double x1[2][kBlock], x2[SPLIT ? 2 : 1][SPLIT ? kBlock : 1];
@@ -1638,12 +1719,12 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(LF_
         // Right behind the barrier: the state stores of level j-1 and the state loads of level j+1.  Both have the
         // arithmetic of level j to complete, so the wait at the end of this level finds them done (issued after the
         // arithmetic, the stores' acknowledgement would be waited for on every level).
-        cone_store<SPLIT>(F, pend, s);
+        cone_store<SPLIT, STRUCT>(F, pend, s);
         pend.valid = false;
         int nfirst = 0;
         if (j + 1 < nl) { // nothing of the next level's state depends on this launch
             nfirst = ld_table(c0, j + 1);
-            cone_load<SPLIT>(F, nfirst + tid, s, nfirst + tid < ld_table(c1, j + 1), nxt);
+            cone_load<SPLIT, STRUCT>(F, nfirst + tid, s, nfirst + tid < ld_table(c1, j + 1), nxt);
         }
         if (!cone_skip<SPLIT>(cur)) {
             double ups1, ups2 = 0.0;
@@ -1672,7 +1753,8 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(LF_
                 }
             }
             double qr, q2r;
-            cone_compute<SPLIT, ALL35>(F, cur, p, s, ups1, ups2, qr, q2r, pend);
+            cone_compute<SPLIT, ALL35, STRUCT>(F, cur, p, s, ups1, ups2, qr, q2r, pend);
+            if (cur.cut_raw) qr = q2r = 0.0; // zero-length structure links: their router output is stored as 0
             if (j + 1 < nl) {
                 x1[j & 1][tid] = qr;
                 if (SPLIT) x2[j & 1][tid] = q2r;
@@ -1689,13 +1771,13 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(LF_
     };
     cone_cell ra, rb;
     int first = ld_table(c0, 0);
-    cone_load<SPLIT>(F, first + tid, s, first + tid < ld_table(c1, 0), ra);
+    cone_load<SPLIT, STRUCT>(F, first + tid, s, first + tid < ld_table(c1, 0), ra);
     __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): inside the loop the current level's registers are always complete
     for (int j = 0; j < nl; j += 2) {
         first = level(j, ra, rb, first);
         if (j + 1 < nl) first = level(j + 1, rb, ra, first);
     }
-    cone_store<SPLIT>(F, pend, s);
+    cone_store<SPLIT, STRUCT>(F, pend, s);
 }
 
 // ---- the same wavefront INSIDE every bin of the component layout ---------------------------------------------------
@@ -1827,6 +1909,7 @@ int fused_impl(lf_router *r, const lf_substep_args *a, int nsteps, int64_t sidef
     F.site_level = nullptr;
     F.fb_level = F.fb_row = F.fb_cone = nullptr;
     F.fb_off = nullptr;
+    F.fb_lvl2blk = nullptr;
     F.fb_nblocks = 0;
     F.use_lvl = 0;
     std::memset(&F.I, 0, sizeof(F.I));
@@ -1958,13 +2041,16 @@ int fused_impl(lf_router *r, const lf_substep_args *a, int nsteps, int64_t sidef
             ++launches;
         }
     }
-    if (!in && r->fb_lmax > 1 && nsteps <= kMaxPackedSteps) { // several levels per launch (k_fused_cones)
+    if (r->fb_lmax > 1 && nsteps <= kMaxPackedSteps) { // several levels per launch (k_fused_cones)
         const int NB = (int)r->fb_level.size() - 1;
         F.fb_level = r->fb_level_dev.p;
         F.fb_row = r->fb_row_dev.p;
         F.fb_cone = r->fb_cone.p;
         F.fb_off = r->fb_off_dev.p;
+        F.fb_lvl2blk = r->fb_lvl2blk_dev.p;
         F.fb_nblocks = NB;
+        std::vector<int> site_blocks; // sorted blocks of the lakes and reservoirs
+        for (int lv : lv_sorted) site_blocks.push_back(r->fb_lvl2blk[lv]);
         auto cones = [&](int b) { return (int64_t)(r->fb_row[b + 1] - r->fb_row[b] - 1); };
         auto multi = [&](int b) { return r->fb_level[b + 1] - r->fb_level[b] > 1; };
         const bool all35 = r->fused && a->Beta == 0.6; // otherwise: run-time flags and inlined OCML pow, as fused_cell
@@ -1972,6 +2058,14 @@ int fused_impl(lf_router *r, const lf_substep_args *a, int nsteps, int64_t sidef
             // (block t - q, sub-step q), q = 0 .. nsteps-1, are independent of each other: the blocks of several levels go
             // to the cone kernel, the single (wide) levels to the level kernel, which streams them at full occupancy
             F.t = t;
+            if (nsites > 0) { // sites of the blocks [t - nsteps + 1, t]: sub-step t - block, before the cells of that block
+                const int b_lo = std::max(0, t - nsteps + 1), b_hi = std::min(NB - 1, t);
+                auto it = std::lower_bound(site_blocks.begin(), site_blocks.end(), b_lo);
+                if (it != site_blocks.end() && *it <= b_hi) {
+                    hipLaunchKernelGGL(k_sites_blocks, dim3(blocks_for(nsites)), dim3(kBlock), 0, s, F);
+                    ++launches;
+                }
+            }
             int64_t acc = 0;
             for (int q = 0; q < nsteps; ++q) {
                 F.blk_start[q] = (int)acc;
@@ -1984,14 +2078,22 @@ int fused_impl(lf_router *r, const lf_substep_args *a, int nsteps, int64_t sidef
                 F.packed = 1;
                 F.use_lvl = 0;
                 const dim3 grid((unsigned)acc);
-                if (a->split && all35)
-                    hipLaunchKernelGGL((k_fused_cones<true, true>), grid, dim3(kBlock), 0, s, F);
-                else if (a->split)
-                    hipLaunchKernelGGL((k_fused_cones<true, false>), grid, dim3(kBlock), 0, s, F);
-                else if (all35)
-                    hipLaunchKernelGGL((k_fused_cones<false, true>), grid, dim3(kBlock), 0, s, F);
+#define LF_CONES(ST)                                                                               \
+    do {                                                                                           \
+        if (a->split && all35)                                                                     \
+            hipLaunchKernelGGL((k_fused_cones<true, true, ST>), grid, dim3(kBlock), 0, s, F);      \
+        else if (a->split)                                                                         \
+            hipLaunchKernelGGL((k_fused_cones<true, false, ST>), grid, dim3(kBlock), 0, s, F);     \
+        else if (all35)                                                                            \
+            hipLaunchKernelGGL((k_fused_cones<false, true, ST>), grid, dim3(kBlock), 0, s, F);     \
+        else                                                                                       \
+            hipLaunchKernelGGL((k_fused_cones<false, false, ST>), grid, dim3(kBlock), 0, s, F);    \
+    } while (0)
+                if (in)
+                    LF_CONES(true);
                 else
-                    hipLaunchKernelGGL((k_fused_cones<false, false>), grid, dim3(kBlock), 0, s, F);
+                    LF_CONES(false);
+#undef LF_CONES
                 ++launches;
             }
             int64_t acc1 = 0, widest = 0;
@@ -2016,7 +2118,11 @@ int fused_impl(lf_router *r, const lf_substep_args *a, int nsteps, int64_t sidef
                     F.packed = 1; // as below: packed where it halves the grid
                     grid = dim3((unsigned)acc1, 1);
                 }
-                if (a->split)
+                if (in && a->split)
+                    hipLaunchKernelGGL((k_fused_substeps<true, true>), grid, dim3(kBlock), 0, s, F);
+                else if (in)
+                    hipLaunchKernelGGL((k_fused_substeps<false, true>), grid, dim3(kBlock), 0, s, F);
+                else if (a->split)
                     hipLaunchKernelGGL((k_fused_substeps<true, false>), grid, dim3(kBlock), 0, s, F);
                 else
                     hipLaunchKernelGGL((k_fused_substeps<false, false>), grid, dim3(kBlock), 0, s, F);

@@ -547,7 +547,8 @@ def test_structures_inside_the_fused_wavefront(amd, solver):
                              "ReservoirStorageM3", "LakeInflowCC", "ReservoirInflowCC"):
         assert np.array_equal(getattr(va, k), getattr(vb, k)), k
     fused = mb.river_router.last_launches()["launches"]
-    assert fused < 2 * (mb.river_router.graph.num_levels + va.NoRoutSteps) and seq_launches * va.NoRoutSteps > 5 * fused
+    # (both paths run on level blocks: ~NL / 16 + NoRoutSteps launches for the whole model step, ~NL / 16 per sub-step)
+    assert fused < 2 * (mb.river_router.graph.num_levels + va.NoRoutSteps) and seq_launches * va.NoRoutSteps > 2 * fused
     # a second model step continues from the state of the first
     for s in range(va.NoRoutSteps):
         ma.dynamic(s)
