@@ -11,6 +11,8 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 echo "== kernel trace of the default bench command"
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_kt -o kt -- python $ROOT/bench.py > $OUT/prof_${TAG}_kt.json 2> $OUT/prof_${TAG}_kt.err; echo rc=$?
+echo "== kernel trace of the headline workload alone (k_level mean for roofline.frac)"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}head_kt -o kt -- python $ROOT/bench.py --no-extra --no-cpu-baseline > $OUT/prof_${TAG}head_kt.json 2> $OUT/prof_${TAG}head_kt.err; echo rc=$?
 R="--size 10000 --steps 5 --warmup 1 --no-extra --no-cpu-baseline --calibrate"
 echo "== pmc FETCH_SIZE (routing)"; timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/prof_${TAG}_fetch -o pmc -- python $ROOT/bench.py $R > /dev/null 2> $OUT/prof_${TAG}_fetch.err; echo rc=$?
 echo "== pmc WRITE_SIZE (routing)"; timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/prof_${TAG}_write -o pmc -- python $ROOT/bench.py $R > /dev/null 2> $OUT/prof_${TAG}_write.err; echo rc=$?
@@ -21,6 +23,8 @@ echo "== soil WRITE_SIZE"; timeout 600 rocprofv3 --pmc WRITE_SIZE --output-forma
 cd $ROOT
 python tools/summarize_prof.py $TAG > $OUT/prof_${TAG}_summary.txt 2>&1
 python tools/summarize_prof.py ${TAG}soil > $OUT/prof_${TAG}soil_summary.txt 2>&1
+python tools/summarize_prof.py ${TAG}head > $OUT/prof_${TAG}head_summary.txt 2>&1
+head -12 $OUT/prof_${TAG}head_summary.txt
 tail -60 $OUT/prof_${TAG}soil_summary.txt
 find $OUT -name "*.db" -delete 2>/dev/null
 find $OUT -name "*_agent_info.csv" -delete 2>/dev/null
