@@ -1713,7 +1713,16 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(LF_
     int first_up = 0; // first position of the level above (LDS index 0)
     // One level of the cone: `cur` holds the loaded state of this thread's cell of level j, `nxt` receives that of level
     // j + 1.  The loop below calls it with the two register sets swapping roles (no copies).
+    // The ~45 array pointers of fused_args do not fit the scalar registers next to the loop's other state: left to itself
+    // the compiler loads them once and spills them to VGPR lanes (200 v_readlane per level).  Instead every level reads
+    // what it needs from the kernel-argument segment again (scalar loads from the constant cache, a handful per level):
+    // the pointer is laundered through an empty asm so that nothing is hoisted out of the level.
+    typedef const fused_args __attribute__((address_space(4))) *kargs_t;
+    const kargs_t K0 = (kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
     auto level = [&](int j, const cone_cell &cur, cone_cell &nxt, int first) {
+        kargs_t Kp = K0;
+        asm volatile("" : "+s"(Kp));
+        const fused_args &F = *(const fused_args *)Kp;
         const long long p = first + tid;
         if (j > 0) lds_barrier(); // level j-1 of this cone is in LDS
         // Right behind the barrier: the state stores of level j-1 and the state loads of level j+1.  Both have the
