@@ -1116,6 +1116,18 @@ def test_catchment_partition_routes_like_the_whole_domain(amd, family, nparts):
         assert np.array_equal(got, Qw), (family, s)
 
 
+def test_fused_cones_random_cases(amd):
+    """tools/stress_fused_cones.py: the wavefront on level blocks (cones, LDS exchange, deferred stores) against the
+    per-level wavefront on random rasters / sub-step counts / block lengths (incl. blocks that have to shrink): every
+    state vector bit-identical."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_fused_cones.py"), "16", "11"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "different 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("family", ["shallow", "deep", "river"])
 def test_routers_on_one_graph_swept_together(amd, solver, family):
     """lf_router_route_device_multi: three routers on the same graph (different alpha, own vectors), one launch per level
