@@ -133,6 +133,15 @@ def test_dis_series_round_trips_through_the_writers(tmp_path):
                              time_values=np.arange(dis.shape[0], dtype=float), units="m3/s")
     back, x, y, t = out.read_netcdf_classic(nc, "dis")
     assert np.array_equal(back[:, mask], dis) and np.isnan(back[:, ~mask]).all() and t.size == dis.shape[0]
+    # ... and as the reference writes dis.nc: netCDF-4, zlib, chunks (1, H, W), _FillValue -9999 (netcdf.py:432-583)
+    nc4 = str(tmp_path / "dis4.nc")
+    out.write_netcdf4(nc4, "dis", stack, x=np.arange(W) * 5000.0, y=np.arange(H)[::-1] * 5000.0,
+                      time_values=np.arange(dis.shape[0], dtype=float), time_units="days since 2016-01-02 06:00:00.0",
+                      standard_name="DischargeMaps", long_name="ChanQAvg", units="m3/s")
+    back, x, y, t = out.read_netcdf4(nc4, "dis")
+    assert np.array_equal(back[:, mask], dis) and np.isnan(back[:, ~mask]).all() and t.size == dis.shape[0]
+    import os
+    assert os.path.getsize(nc4) < 0.7 * os.path.getsize(nc)            # deflate + shuffle at work
 
 
 # ---------------------------------------------------------------------------------------------------------------
