@@ -161,6 +161,24 @@ def pmc_traffic(kernel_key, cells_per_launch):
     return d["hbm_read_bytes_per_launch"] + d["hbm_write_bytes_per_launch"], os.path.relpath(f, ROOT)
 
 
+def committed_rocprof_mean(cells_per_launch):
+    """Mean duration of the headline kernel in the newest committed rocprofv3 --kernel-trace --stats summary of this
+    same workload (profiles/*head_kernel_stats.csv, tools/gpu_profile_r02.sh): another box, another day -- reported
+    next to the live hipEvent figure so that the two can be compared (the boxes differ by up to ~8 % on this kernel)."""
+    import csv
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*head_kernel_stats.csv")), reverse=True):
+        try:
+            for r in csv.DictReader(open(f)):
+                if "k_level<true, true, false>" in r["Name"]:
+                    us = float(r["AverageNs"]) / 1e3
+                    return dict(file=os.path.relpath(f, ROOT), mean_launch_us=round(us, 3), calls=int(r["Calls"]),
+                                frac=round(B_ALG * cells_per_launch / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 6))
+        except Exception:
+            continue
+    return None
+
+
 def roofline_of(res, kernel_key=None):
     """Dominant sweep kernel: achieved algorithmic GB/s = 48 B x cells per launch / mean launch duration."""
     prof = res["prof"]
@@ -187,7 +205,9 @@ def roofline_of(res, kernel_key=None):
     ms_per_launch = dom["ms"] / dom["launches"]
     achieved = B_ALG * cells_per_launch / (ms_per_launch * 1e-3) / 1e9
     traffic, src = pmc_traffic(kernel_key, cells_per_launch) if kernel_key else (None, None)
+    check = committed_rocprof_mean(cells_per_launch) if (kernel_key and dom is wide) else None
     return dict(bound="hbm", kernel=name, achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit="GB/s",
+                committed_rocprof=check,
                 frac=round(achieved / HBM_PEAK_GBS, 6), traffic=traffic, traffic_unit="bytes per launch",
                 traffic_source=src, alg_bytes_per_launch=B_ALG * cells_per_launch,
                 launches_per_step=int(round(dom["launches"] / max(res.get("profile_steps", 1), 1))),
