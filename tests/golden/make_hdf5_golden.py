@@ -78,6 +78,16 @@ def check():
     print("laea", f["laea"].shape, f["laea"][()], dict(f["laea"].attrs))
     print("root attrs", {k: v for k, v in f.attrs.items() if k != "date_created"})
     assert np.array_equal(got, want)
+    # a long series: 400 chunks in ONE chunk B-tree node (the writer raises the superblock's indexed-storage K), float32
+    T2 = 400
+    m2 = rng.uniform(0.0, 5.0, (T2, 9, 13))
+    m2[:, 0, 0] = np.nan
+    path2 = os.path.join(os.path.dirname(path), "long.nc")
+    O.write_netcdf4(path2, "dis", m2, np.arange(13) * 1.0, np.arange(9)[::-1] * 1.0, time_values=np.arange(T2) * 1.0, dtype="f4")
+    d2 = h5py.File(path2, "r")["dis"]
+    ok = bool(np.array_equal(d2[...], np.where(np.isnan(m2), -9999.0, m2).astype("f4")))
+    print("long series", d2.shape, d2.dtype, "chunks", d2.chunks, d2.compression, "values identical:", ok)
+    assert ok
 
 
 if __name__ == "__main__":
