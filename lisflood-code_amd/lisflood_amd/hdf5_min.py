@@ -402,6 +402,29 @@ class _Reader:
             out[nm] = v
         return out
 
+    def info(self, name):
+        """-> dict(shape, dtype, chunks, filters [(id, values)], fill) of a dataset: the storage side of its header"""
+        d = self.d
+        out = dict(shape=None, dtype=None, chunks=None, filters=[], fill=None)
+        for t, body, _s in self.messages(self.objects[name]):
+            if t == 0x01:
+                out["shape"] = self._shape(body)
+            elif t == 0x03:
+                out["dtype"] = self._dtype(body, d)
+            elif t == 0x05 and d[body] == 2 and d[body + 3] == 1 and self.u(body + 4, 4) > 0 and out["dtype"] is not None:
+                out["fill"] = np.frombuffer(d, out["dtype"], 1, body + 8)[0]
+            elif t == 0x08 and d[body + 1] == 2:
+                rank1 = d[body + 2]
+                out["chunks"] = tuple(self.u(body + 11 + 4 * i, 4) for i in range(rank1 - 1))
+            elif t == 0x0B:
+                p = body + 8
+                for _ in range(d[body + 1]):
+                    fid, nlen, _fl, nv = (self.u(p + 2 * k, 2) for k in range(4))
+                    p += 8 + (nlen + 7) // 8 * 8
+                    out["filters"].append((fid, [self.u(p + 4 * k, 4) for k in range(nv)]))
+                    p += 4 * nv + (4 if nv % 2 else 0)
+        return out
+
     def dataset(self, name):
         d = self.d
         dt = shape = layout = None

@@ -90,5 +90,38 @@ def check():
     assert ok
 
 
+def refstruct():
+    """The STRUCTURE (no data) of the reference's own dis.nc -- variables, shapes, types, chunking, filters, fill values,
+    attribute names and the small attribute values -- as tests/golden/ref_disnc_structure.json: what `writenet` really
+    produces (netcdf.py:432-583), for the CPU test that compares write_netcdf4's files with it."""
+    import json
+    import h5py
+    src = "/root/reference/tests/data/LF_ETRS89_UseCase/reference/output_reference_daily/dis.nc"
+    f = h5py.File(src, "r")
+    skip = {"DIMENSION_LIST", "REFERENCE_LIST", "_Netcdf4Coordinates", "_Netcdf4Dimid", "CLASS", "NAME", "_NCProperties"}
+
+    def attrs(o):
+        out = {}
+        for k, v in o.attrs.items():
+            if k in skip:
+                continue
+            if isinstance(v, bytes):
+                out[k] = v.decode()
+            elif np.ndim(v) == 0:
+                out[k] = float(v) if np.asarray(v).dtype.kind == "f" else int(v)
+            else:
+                out[k] = np.asarray(v).tolist()
+        return out
+    out = {"source": "tests/data/LF_ETRS89_UseCase/reference/output_reference_daily/dis.nc", "root_attrs": sorted(attrs(f)),
+           "variables": {}}
+    for name, d in f.items():
+        out["variables"][name] = dict(shape=list(d.shape), dtype=str(d.dtype), chunks=list(d.chunks) if d.chunks else None,
+                                      compression=d.compression, compression_opts=d.compression_opts, shuffle=bool(d.shuffle),
+                                      fillvalue=float(d.fillvalue), dims=[s[0].name.strip("/") if len(s) else "" for s in d.dims],
+                                      attrs=attrs(d))
+    json.dump(out, open(os.path.join(HERE, "ref_disnc_structure.json"), "w"), indent=1, sort_keys=True)
+    print(json.dumps(out, indent=1, sort_keys=True)[:1500])
+
+
 if __name__ == "__main__":
-    {"make": make, "check": check}[sys.argv[1]]()
+    {"make": make, "check": check, "refstruct": refstruct}[sys.argv[1]]()

@@ -88,3 +88,45 @@ def test_single_map_and_state_maps(tmp_path):
             assert np.array_equal(back[k], state[k]), (fmt, k)
     with open(os.path.join(str(tmp_path / "netcdf4"), "ChanQState.nc"), "rb") as f:
         assert f.read(8) == H5.SIGNATURE
+
+
+def test_same_structure_as_the_reference_dis_nc(tmp_path):
+    """tests/golden/ref_disnc_structure.json: the structure of the dis.nc the reference itself wrote for LF_ETRS89_UseCase
+    (reference/output_reference_daily/dis.nc, extracted with h5py by make_hdf5_golden.py refstruct).  write_netcdf4 given
+    the same shapes and metadata must produce the same variables, dimensions, types, chunking, filters, fill value and
+    attributes (the global provenance attributes differ by design: no institution / creator_name of the JRC)."""
+    import json
+    ref = json.load(open(os.path.join(os.path.dirname(GOLD), "ref_disnc_structure.json")))
+    v = ref["variables"]
+    T, H, W = v["dis"]["shape"]
+    rng = np.random.default_rng(4)
+    maps = rng.uniform(0, 80, (T, H, W))
+    maps[:, rng.uniform(size=(H, W)) < 0.45] = np.nan
+    path = str(tmp_path / "dis.nc")
+    da = v["dis"]["attrs"]
+    O.write_netcdf4(path, "dis", maps, np.arange(W) * 5000.0, np.arange(H)[::-1] * 5000.0, time_values=np.arange(T) * 1.0,
+                    time_units=v["time"]["attrs"]["units"], calendar=v["time"]["attrs"]["calendar"],
+                    standard_name=da["standard_name"], long_name=da["long_name"], units=da["units"],
+                    esri_pe_string=da["esri_pe_string"], coord_attrs={"x": v["x"]["attrs"], "y": v["y"]["attrs"]})
+    r = H5.read(path)
+    assert sorted(r.objects) == sorted(v)
+    for name, want in v.items():
+        got = r.info(name)
+        assert list(got["shape"]) == want["shape"] and np.dtype(got["dtype"]) == np.dtype(want["dtype"]), name
+        assert (list(got["chunks"]) if got["chunks"] else None) == want["chunks"], name
+        filt = dict(got["filters"])
+        assert (1 in filt) == (want["compression"] == "gzip") and (2 in filt) == want["shuffle"], name
+        if want["compression"] == "gzip":
+            assert filt[1] == [want["compression_opts"]] and filt[2] == [8]
+        a = r.attrs(name)
+        for k, val in want["attrs"].items():
+            assert k in a, (name, k)
+            if isinstance(val, str):
+                assert a[k] == val, (name, k)
+            else:
+                assert np.allclose(np.asarray(a[k], float).reshape(-1), np.asarray(val, float).reshape(-1)), (name, k)
+    assert float(r.info("dis")["fill"]) == v["dis"]["fillvalue"] == -9999.0
+    # dimensions of the value variable, in the reference's order, through the netCDF-4 dimension ids
+    ids = {int(r.attrs(n)["_Netcdf4Dimid"]): n for n in ("x", "y", "time")}
+    assert [ids[i] for i in r.attrs("dis")["_Netcdf4Coordinates"]] == v["dis"]["dims"]
+    assert set(ref["root_attrs"]) - {"institution", "creator_name"} <= set(r.attrs())
