@@ -73,7 +73,8 @@ SEEDS = {"shallow": 1, "deep": 2, "river": 7}
 def build_case(family, H, W, layout="auto"):
     """layout: "levels" = one launch per level (wide levels: the HBM-bound regime), "components" = independent bins of
     the drainage forest, one wavefront each, one launch per tier (deep / dendritic networks: the launch-latency-bound
-    regime), "auto" = components when the network has more than 64 levels."""
+    regime; kept for A/B), "auto" = "levels": runs of narrow levels are swept in blocks of up to 16 levels, cone by cone
+    (k_sweep_cones), wide levels by k_level."""
     from lisflood_amd import synthetic as syn
     from lisflood_amd.kinematic_wave_parallel import Graph, kinematicWave
     t = time.time()
@@ -82,7 +83,7 @@ def build_case(family, H, W, layout="auto"):
     p = syn.router_params(N)
     g = Graph(ldd_raster=codes)
     levels = np.diff(g.layout()[2])
-    if layout == "components" or (layout == "auto" and g.num_levels > 64):
+    if layout == "components":      # ("auto" = "levels": since round 2 the level layout sweeps blocks of levels cone by cone)
         g.close()
         g = Graph(ldd_raster=codes, components=True)
     g.level_widths = levels
@@ -198,7 +199,7 @@ def roofline_of(res, kernel_key=None):
                     note="dependent chain of %d local levels (sum over tiers of the deepest bin): latency-bound, not "
                          "bandwidth-bound" % res["components"]["chain_levels"])
     dom = wide if wide["ms"] >= narrow["ms"] else narrow
-    name = "k_level" if dom is wide else "k_levels_narrow"
+    name = "k_level" if dom is wide else "k_sweep_cones / k_levels_narrow (runs of narrow levels)"
     if dom["launches"] == 0 or dom["ms"] == 0:
         return None
     cells_per_launch = dom["cells"] / dom["launches"]
@@ -535,23 +536,29 @@ def main():
     if not a.no_extra:
         extra = {}
         for other in [f for f in ("deep", "river", "shallow") if f != a.family]:
-            try:    # the other LDD families, each on the layout `auto` picks and -- for A/B -- on the level sweep
+            try:    # the other LDD families: level layout (blocks of levels cone by cone); for the deep ones, A/B against
+                    # one launch per level (LF_ROUTE_CONES=0, same router) and against the component layout
                 entry = {}
-                for layout in ("auto", "levels"):
-                    kw2, p2, g2 = build_case(other, H, W, layout)
-                    if layout == "levels" and "engine_layout" in entry and entry["engine_layout"] == "levels":
-                        kw2.close()
-                        break
-                    r2 = run_routing(kw2, p2, max(2, a.steps // 5), 1, nq=1, profile_steps=1)
-                    d = dict(value=round(kw2.num_pixels / r2["ms_per_step"] / 1e3, 2), unit="Mcell-steps/s",
-                             ms_per_step=round(r2["ms_per_step"], 3), launches_per_step=r2["stats"]["launches"],
-                             roofline=roofline_of(r2))
-                    if layout == "auto":
-                        entry.update(d, levels=g2.num_levels, level_sizes=level_sizes(g2),
-                                     engine_layout="components" if g2.components else "levels")
-                    else:
-                        entry["level_sweep"] = d
-                    kw2.close()
+
+                def leg(kw_, p_):
+                    r_ = run_routing(kw_, p_, max(2, a.steps // 5), 1, nq=1, profile_steps=1)
+                    return dict(value=round(kw_.num_pixels / r_["ms_per_step"] / 1e3, 2), unit="Mcell-steps/s",
+                                ms_per_step=round(r_["ms_per_step"], 3), launches_per_step=r_["stats"]["launches"],
+                                roofline=roofline_of(r_))
+                kw2, p2, g2 = build_case(other, H, W, "levels")
+                entry.update(leg(kw2, p2), levels=g2.num_levels, level_sizes=level_sizes(g2), engine_layout="levels")
+                deep_net = g2.num_levels > 64
+                if deep_net:
+                    os.environ["LF_ROUTE_CONES"] = "0"
+                    try:
+                        entry["level_sweep"] = leg(kw2, p2)
+                    finally:
+                        del os.environ["LF_ROUTE_CONES"]
+                kw2.close()
+                if deep_net:
+                    kw3, p3, g3 = build_case(other, H, W, "components")
+                    entry["component_layout"] = leg(kw3, p3)
+                    kw3.close()
                 extra[other] = entry
             except Exception as e:  # secondary numbers must never break the headline line
                 extra[other + "_error"] = repr(e)

@@ -184,7 +184,8 @@ struct lf_router {
     // cut into cones = the upstream ranges of chunks of its last level, no range wider than a workgroup; block b has
     // fb_row[b+1] - fb_row[b] - 1 cones and one more row (the end of every level) in fb_cone, from entry fb_off[b] on,
     // one start per level and row
-    std::vector<int> fb_level, fb_row;
+    std::vector<int> fb_level, fb_row, fb_off;
+    uint64_t topo_hash = 0; // of the graph's level table and (sampled) upstream ranges: same graph <=> same plan
     lf_dbuf<int> fb_level_dev, fb_row_dev, fb_cone;
     lf_dbuf<int> fb_off_dev, fb_lvl2blk_dev; // fb_lvl2blk: block of every level (the sites of the structures variant)
     std::vector<int> fb_lvl2blk;
@@ -271,6 +272,81 @@ sweep_args make_sweep_args(lf_router *r, double *q_dev, const double *lat_dev, i
     return A;
 }
 
+// A router call block by block (build_level_blocks): blocks of several levels cone by cone (k_sweep_cones), single wide
+// levels by the level kernel.  `count` routers of ONE graph share the launches.  LF_ROUTE_CONES=0: level by level.
+bool cones_enabled() // (read at every call: bench.py switches it for its A/B legs)
+{
+    const char *e = std::getenv("LF_ROUTE_CONES");
+    return !(e && e[0] == '0');
+}
+
+template <int NR>
+void launch_sweep_cones(bool fused, bool ordered, dim3 grid, hipStream_t s, const cone_plan_args &C, const sweep_args_multi &M)
+{
+    if (fused && ordered)
+        hipLaunchKernelGGL((k_sweep_cones<true, true, NR>), grid, dim3(kBlock), 0, s, C, M);
+    else if (fused)
+        hipLaunchKernelGGL((k_sweep_cones<true, false, NR>), grid, dim3(kBlock), 0, s, C, M);
+    else if (ordered)
+        hipLaunchKernelGGL((k_sweep_cones<false, true, NR>), grid, dim3(kBlock), 0, s, C, M);
+    else
+        hipLaunchKernelGGL((k_sweep_cones<false, false, NR>), grid, dim3(kBlock), 0, s, C, M);
+}
+
+int enqueue_blocks(int count, lf_router **rs, const sweep_args_multi &M, bool ordered, int64_t *launches, int64_t *wide,
+                   int64_t *narrow)
+{
+    lf_router *r = rs[0];
+    hipStream_t s = r->ctx->stream;
+    const int NB = (int)r->fb_level.size() - 1;
+    for (int b = 0; b < NB; ++b) {
+        const int k0 = r->fb_level[b], nl = r->fb_level[b + 1] - k0;
+        if (nl > 1) {
+            cone_plan_args C;
+            C.cone = r->fb_cone.p + r->fb_off[b];
+            C.nl = nl;
+            const dim3 grid((unsigned)(r->fb_row[b + 1] - r->fb_row[b] - 1));
+            LF_TRY(r->prof_begin(2, r->h_level_start[k0 + nl] - r->h_level_start[k0]));
+            if (count == 1)
+                launch_sweep_cones<1>(r->fused, ordered, grid, s, C, M);
+            else if (count == 2)
+                launch_sweep_cones<2>(r->fused, ordered, grid, s, C, M);
+            else if (count == 3)
+                launch_sweep_cones<3>(r->fused, ordered, grid, s, C, M);
+            else
+                launch_sweep_cones<4>(r->fused, ordered, grid, s, C, M);
+            LF_TRY(r->prof_end());
+            ++*narrow;
+        } else {
+            const int first = (int)r->h_level_start[k0];
+            const int cells = (int)(r->h_level_start[k0 + 1] - r->h_level_start[k0]);
+            const dim3 grid(blocks_for(cells), count), block(kBlock);
+            LF_TRY(r->prof_begin(1, cells));
+            if (count == 1) {
+                if (r->fused && ordered)
+                    hipLaunchKernelGGL((k_level<true, true>), grid, block, 0, s, first, cells, M.r[0]);
+                else if (r->fused)
+                    hipLaunchKernelGGL((k_level<true, false>), grid, block, 0, s, first, cells, M.r[0]);
+                else if (ordered)
+                    hipLaunchKernelGGL((k_level<false, true>), grid, block, 0, s, first, cells, M.r[0]);
+                else
+                    hipLaunchKernelGGL((k_level<false, false>), grid, block, 0, s, first, cells, M.r[0]);
+            } else if (r->fused && ordered)
+                hipLaunchKernelGGL((k_level_multi<true, true>), grid, block, 0, s, first, cells, M);
+            else if (r->fused)
+                hipLaunchKernelGGL((k_level_multi<true, false>), grid, block, 0, s, first, cells, M);
+            else if (ordered)
+                hipLaunchKernelGGL((k_level_multi<false, true>), grid, block, 0, s, first, cells, M);
+            else
+                hipLaunchKernelGGL((k_level_multi<false, false>), grid, block, 0, s, first, cells, M);
+            LF_TRY(r->prof_end());
+            ++*wide;
+        }
+        ++*launches;
+    }
+    return LF_OK;
+}
+
 // `count` routers built on the same graph (same level schedule), swept level by level with ONE launch per level
 int enqueue_route_multi(int count, lf_router **rs, double **q_dev, const double **lat_dev, int section, bool ordered)
 {
@@ -286,6 +362,18 @@ int enqueue_route_multi(int count, lf_router **rs, double **q_dev, const double 
                                lat_dev[i], M.r[i].a, M.r[i].dx, rs[i]->dx_scalar, rs[i]->beta, rs[i]->constant.p);
             ++launches;
         }
+    bool same_graph = r->fb_lmax > 1 && cones_enabled();
+    for (int i = 1; i < count; ++i) same_graph = same_graph && rs[i]->topo_hash == r->topo_hash && rs[i]->fb_lmax == r->fb_lmax;
+    if (same_graph) {
+        LF_TRY(enqueue_blocks(count, rs, M, ordered, &launches, &wide, &narrow));
+        for (int i = 0; i < count; ++i) {
+            rs[i]->last_stats[0] = launches;
+            rs[i]->last_stats[1] = wide;
+            rs[i]->last_stats[2] = narrow;
+            rs[i]->last_stats[3] = rs[i]->NL;
+        }
+        return LF_OK;
+    }
     for (const segment &g : r->schedule) {
         if (g.wide) {
             const int first = (int)r->h_level_start[g.k0];
@@ -374,6 +462,17 @@ int enqueue_route(lf_router *r, double *q_dev, const double *lat_dev, int sectio
         r->last_stats[0] = launches;
         r->last_stats[1] = wide;
         r->last_stats[2] = 0;
+        r->last_stats[3] = r->NL;
+        return LF_OK;
+    }
+    if (r->fb_lmax > 1 && cones_enabled()) {
+        sweep_args_multi M;
+        for (int i = 0; i < kMaxMulti; ++i) M.r[i] = A;
+        lf_router *one[1] = {r};
+        LF_TRY(enqueue_blocks(1, one, M, ordered, &launches, &wide, &narrow));
+        r->last_stats[0] = launches;
+        r->last_stats[1] = wide;
+        r->last_stats[2] = narrow;
         r->last_stats[3] = r->NL;
         return LF_OK;
     }
@@ -524,7 +623,14 @@ static int build_level_blocks(lf_router *r, const lf_graph *g)
     r->fb_lvl2blk = lvl2blk;
     r->fb_level = level;
     r->fb_row = row;
+    r->fb_off = off;
     r->fb_lmax = lmax;
+    uint64_t h = 1469598103934665603ull; // FNV-1a over the level table and every 61st upstream pointer
+    auto mix = [&](uint64_t v) { h = (h ^ v) * 1099511628211ull; };
+    for (int64_t v : g->level_start) mix((uint64_t)v);
+    for (size_t i = 0; i < g->ups_ptr.size(); i += 61) mix((uint64_t)g->ups_ptr[i]);
+    mix((uint64_t)g->ups_ptr.size());
+    r->topo_hash = h;
     return LF_OK;
 }
 

@@ -379,6 +379,123 @@ __global__ void __launch_bounds__(kNarrowBlock) k_levels_narrow_multi(int k0, in
     }
 }
 
+// One BLOCK of consecutive levels of a router call, cone by cone (the plan of lf_router.hip: build_level_blocks).  A
+// workgroup owns a chunk of the block's last level and the whole upstream cone above it -- level by level one contiguous
+// range of at most kBlock cells, the cones tile every level -- so the levels of a block need no synchronisation between
+// workgroups: the new discharges travel to the next level through LDS (two buffers by level parity; they are also
+// stored, the block after this one and later calls read them), the operands of the next level's cell are loaded before
+// the current level is solved.  NR routers of one graph (the overland routers of surface_routing.py:151-153) share the
+// cone and the barriers.  Arithmetic per cell = sweep_cell: bit-identical to the level sweep.
+struct cone_plan_args {
+    const int *__restrict__ cone; // starts of this block's cones, nl per cone, then the closing row (ends of the levels)
+    int nl;                       // levels of the block
+};
+
+template <bool FUSED, bool ORDERED, int NR>
+__global__ void __launch_bounds__(kBlock) k_sweep_cones(cone_plan_args C, sweep_args_multi M)
+{
+    __shared__ double x[NR][2][kBlock];
+    const int tid = threadIdx.x, nl = C.nl;
+    const int *c0 = C.cone + (size_t)blockIdx.x * nl, *c1 = c0 + nl;
+    struct cell {
+        int u0, u1, pix;
+        double ap[NR], lat[NR], qold[NR];
+        bool active;
+    };
+    auto load = [&](int p, bool active, cell &R) {
+        R.active = active;
+        if (!active) return;
+        R.u0 = M.r[0].ups_ptr[p];
+        R.u1 = M.r[0].ups_ptr[p + 1];
+        R.pix = ORDERED ? p : M.r[0].perm[p];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const sweep_args &A = M.r[r];
+            R.ap[r] = A.a[p];
+            if (FUSED) {
+                R.lat[r] = A.lat[R.pix] * (A.dx ? A.dx[p] : A.dx_scalar);
+                R.qold[r] = ORDERED ? A.qord[p] : A.q_pix[R.pix];
+            } else {
+                R.lat[r] = A.constant[p];
+                R.qold[r] = 0.0;
+            }
+        }
+    };
+    int first_up = 0;
+    // the stores of a level are issued one level later, right behind the barrier (with the next loads): then everything
+    // outstanding at the end of a level was issued before its arithmetic, and the wait there is short
+    double pend_q[NR];
+    int pend_p = 0, pend_pix = 0;
+    bool pend = false;
+    auto flush = [&]() {
+        if (!pend) return;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            M.r[r].qord[pend_p] = pend_q[r];
+            if (!ORDERED) M.r[r].q_pix[pend_pix] = pend_q[r];
+        }
+        pend = false;
+    };
+    auto level = [&](int j, const cell &cur, cell &nxt, int first) {
+        const int p = first + tid;
+        int nfirst = 0;
+        flush();
+        if (j + 1 < nl) { // the next level's operands: nothing of them depends on this launch
+            nfirst = ld_table(c0, j + 1);
+            load(nfirst + tid, nfirst + tid < ld_table(c1, j + 1), nxt);
+        }
+        if (j > 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // level j-1 of this cone is in LDS
+        if (cur.active) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const sweep_args &A = M.r[r];
+                double v[8];
+                if (j == 0) { // from the block before (previous launch)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = (k < A.kmax && cur.u0 + k < cur.u1) ? A.qord[cur.u0 + k] : 0.0;
+                } else {
+                    const double *y = &x[r][(j - 1) & 1][0];
+                    const int base = cur.u0 - first_up;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const bool have = k < A.kmax && cur.u0 + k < cur.u1;
+                        const double t = y[have ? base + k : 0];
+                        v[k] = have ? t : 0.0;
+                    }
+                }
+                double ups = 0.0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) ups += v[k];
+                const double ap = cur.ap[r];
+                const double cst = FUSED ? ap * lf_pow_3_5(cur.qold[r]) + cur.lat[r] : cur.lat[r];
+                const double c = ups + cst;
+                double q;
+                if (FUSED && lf_fast_range(c) && lf_fast_range(ap))
+                    q = (c <= LF_NEWTON_TOL) ? 0.0 : lf_solve_3_5(c, ap);
+                else
+                    q = lf_solve_cell(c, ap, A.beta * ap, A.beta, A.inv_beta, A.b_minus_1);
+                pend_q[r] = q;
+                if (j + 1 < nl) x[r][j & 1][tid] = q;
+            }
+            pend = true;
+            pend_p = p;
+            pend_pix = cur.pix;
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the next level's operands (issued before the arithmetic) are in
+        first_up = first;
+        return nfirst;
+    };
+    cell ra, rb;
+    int first = ld_table(c0, 0);
+    load(first + tid, first + tid < ld_table(c1, 0), ra);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    for (int j = 0; j < nl; j += 2) {
+        first = level(j, ra, rb, first);
+        if (j + 1 < nl) first = level(j + 1, rb, ra, first);
+    }
+    flush();
+}
+
 // a run of narrow levels [k0, k1): one workgroup, barrier between levels
 template <bool FUSED, bool ORDERED, bool INDEXED = false>
 __global__ void __launch_bounds__(kNarrowBlock) k_levels_narrow(int k0, int k1, const long long *__restrict__ level_start,
