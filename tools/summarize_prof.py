@@ -29,7 +29,7 @@ def short(name):
         f = [x.strip() == "true" for x in m.group(2).split(",")] + [False, False, False]
         tag = ("fused" if f[0] else "general") + ("+ordered" if f[1] else "+pixel") + ("+indexed" if f[2] else "")
         return "%s[%s]" % (m.group(1), tag)
-    m = re.search(r"(k_comp_bins|k_comp_fused|k_fused_cones|k_fused_substeps|k_level_multi|k_levels_narrow_multi)<([^>]*)>", name)
+    m = re.search(r"(k_comp_bins|k_comp_fused|k_fused_cones|k_fused_substeps|k_level_multi|k_levels_narrow_multi|k_sweep_cones)<([^>]*)>", name)
     if m:   # component layout: FUSED (quintic), ORDERED, TRUNK (index-list tier) / fused sub-steps: SPLIT, STRUCT
         return "%s<%s>" % (m.group(1), ",".join("1" if x.strip() == "true" else "0" if x.strip() == "false" else x.strip()
                                                  for x in m.group(2).split(",")))
