@@ -190,6 +190,11 @@ struct lf_router {
     lf_dbuf<int> fb_off_dev, fb_lvl2blk_dev; // fb_lvl2blk: block of every level (the sites of the structures variant)
     std::vector<int> fb_lvl2blk;
     int fb_lmax = 0;
+    // the same plan with longer blocks for plain router calls (k_sweep_cones: no sub-step dimension to fill the machine
+    // with, so fewer, longer launches pay): host tables + the cone starts on the device
+    std::vector<int> rb_level, rb_row, rb_off;
+    lf_dbuf<int> rb_cone;
+    int rb_lmax = 0;
     int64_t last_stats[4] = {0, 0, 0, 0};
     // profiling
     bool profile = false;
@@ -298,14 +303,14 @@ int enqueue_blocks(int count, lf_router **rs, const sweep_args_multi &M, bool or
 {
     lf_router *r = rs[0];
     hipStream_t s = r->ctx->stream;
-    const int NB = (int)r->fb_level.size() - 1;
+    const int NB = (int)r->rb_level.size() - 1;
     for (int b = 0; b < NB; ++b) {
-        const int k0 = r->fb_level[b], nl = r->fb_level[b + 1] - k0;
+        const int k0 = r->rb_level[b], nl = r->rb_level[b + 1] - k0;
         if (nl > 1) {
             cone_plan_args C;
-            C.cone = r->fb_cone.p + r->fb_off[b];
+            C.cone = r->rb_cone.p + r->rb_off[b];
             C.nl = nl;
-            const dim3 grid((unsigned)(r->fb_row[b + 1] - r->fb_row[b] - 1));
+            const dim3 grid((unsigned)(r->rb_row[b + 1] - r->rb_row[b] - 1));
             LF_TRY(r->prof_begin(2, r->h_level_start[k0 + nl] - r->h_level_start[k0]));
             if (count == 1)
                 launch_sweep_cones<1>(r->fused, ordered, grid, s, C, M);
@@ -362,8 +367,8 @@ int enqueue_route_multi(int count, lf_router **rs, double **q_dev, const double 
                                lat_dev[i], M.r[i].a, M.r[i].dx, rs[i]->dx_scalar, rs[i]->beta, rs[i]->constant.p);
             ++launches;
         }
-    bool same_graph = r->fb_lmax > 1 && cones_enabled();
-    for (int i = 1; i < count; ++i) same_graph = same_graph && rs[i]->topo_hash == r->topo_hash && rs[i]->fb_lmax == r->fb_lmax;
+    bool same_graph = r->rb_lmax > 1 && cones_enabled();
+    for (int i = 1; i < count; ++i) same_graph = same_graph && rs[i]->topo_hash == r->topo_hash && rs[i]->rb_lmax == r->rb_lmax;
     if (same_graph) {
         LF_TRY(enqueue_blocks(count, rs, M, ordered, &launches, &wide, &narrow));
         for (int i = 0; i < count; ++i) {
@@ -465,7 +470,7 @@ int enqueue_route(lf_router *r, double *q_dev, const double *lat_dev, int sectio
         r->last_stats[3] = r->NL;
         return LF_OK;
     }
-    if (r->fb_lmax > 1 && cones_enabled()) {
+    if (r->rb_lmax > 1 && cones_enabled()) {
         sweep_args_multi M;
         for (int i = 0; i < kMaxMulti; ++i) M.r[i] = A;
         lf_router *one[1] = {r};
@@ -535,14 +540,15 @@ int route_device(lf_router *r, double *q_dev, const double *lat_dev, int section
 } // namespace
 
 // Level blocks for the fused sub-step wavefront (k_fused_cones): runs of consecutive levels of at most `wide` cells are
-// cut into blocks of up to lmax levels (LF_FUSED_LEVELS, default 16; 1 = off); a wider level is a block of its own.  A
+// cut into blocks of up to lmax levels (fused wavefront: LF_FUSED_LEVELS, default 16; plain router calls, k_sweep_cones:
+// LF_ROUTE_LEVELS, default 64; 1 = off); a wider level is a block of its own.  A
 // block is cut into cones: chunks of its last level, as long as possible with no level of the cone wider than kBlock
 // cells; a block whose thinnest possible cone (one cell of the last level) is still too wide somewhere loses levels
 // until it fits (one level always does).  Nothing is built when no block holds more than one level.
-static int build_level_blocks(lf_router *r, const lf_graph *g)
+static int build_level_blocks(lf_router *r, const lf_graph *g, bool for_route)
 {
-    int lmax = 16;
-    if (const char *e = std::getenv("LF_FUSED_LEVELS")) lmax = std::atoi(e);
+    int lmax = for_route ? 64 : 16; // LF_ROUTE_LEVELS / LF_FUSED_LEVELS (measured: §4.1c / §4.3b of DESIGN.md)
+    if (const char *e = std::getenv(for_route ? "LF_ROUTE_LEVELS" : "LF_FUSED_LEVELS")) lmax = std::atoi(e);
     lmax = lmax < 1 ? 1 : (lmax > 64 ? 64 : lmax);
     int64_t wide = 262144;
     if (const char *e = std::getenv("LF_FUSED_WIDE")) wide = std::atoll(e);
@@ -612,6 +618,14 @@ static int build_level_blocks(lf_router *r, const lf_graph *g)
     }
     if (!any || cone.size() >= ((size_t)1 << 31)) return LF_OK;
     level.push_back((int)NL);
+    if (for_route) {
+        LF_TRY(r->rb_cone.upload(cone.data(), cone.size(), r->ctx->stream));
+        r->rb_level = level;
+        r->rb_row = row;
+        r->rb_off = off;
+        r->rb_lmax = lmax;
+        return LF_OK;
+    }
     LF_TRY(r->fb_level_dev.upload(level.data(), level.size(), r->ctx->stream));
     LF_TRY(r->fb_row_dev.upload(row.data(), row.size(), r->ctx->stream));
     LF_TRY(r->fb_off_dev.upload(off.data(), off.size(), r->ctx->stream));
@@ -776,7 +790,8 @@ int lf_router_create(const lf_graph *g, const double *alpha, double beta, const 
     }
     // (zero-length structure links need nothing special: such cells sit at the end of their level, inside the upstream
     // range of the LAST cell of the next level -- which adds their 0.0 -- and so inside the last cone of a block)
-    rc = build_level_blocks(r, g);
+    rc = build_level_blocks(r, g, false);
+    if (rc == LF_OK && !g->has_links) rc = build_level_blocks(r, g, true);
     if (rc != LF_OK) {
         delete r;
         return rc;
