@@ -1,0 +1,38 @@
+"""The shape of bench.py's JSON line, checked on the committed result of the last full run on an MI355X
+(profiles/r02_bench_final.json): the driver's contract (metric / value / unit / n_gpus / steps / warmup / ms_per_step /
+higher_is_better / scaling / vs_baseline / dtype / data / config.workload) plus the two objects of this tier, `roofline`
+and `cpu_baseline`, and the internal consistency of the numbers."""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_committed_bench_line_follows_the_contract():
+    line = open(os.path.join(ROOT, "profiles", "r02_bench_final.json")).read().strip().splitlines()[-1]
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["dtype"] == "f64" and d["data"] == "synthetic"
+    assert d["vs_baseline"] is None                      # BASELINE.md holds no published number for this metric
+    assert "workload" in d["config"] and "model" not in d["config"]
+    cells = d["config"]["cells"]
+    assert abs(d["value"] - cells / d["ms_per_step"] / 1e3) < 1e-3 * d["value"]      # Mcell-steps/s = cells per ms / 1e3
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-6
+    # achieved = algorithmic bytes per launch / mean launch duration of the dominant kernel
+    assert abs(r["achieved"] - r["alg_bytes_per_launch"] / (r["mean_launch_us"] * 1e-6) / 1e9) < 1e-3 * r["achieved"]
+    assert r["alg_bytes_per_cell_step"] == 48.0
+    if r["traffic"] is not None:                         # PMC bytes per launch: at least the algorithmic bytes, not 2x them
+        assert 1.0 <= r["traffic"] / r["alg_bytes_per_launch"] < 2.0
+        assert os.path.exists(os.path.join(ROOT, r["traffic_source"]))
+    # the whole step cannot be faster than its dominant kernel's launches
+    assert r["launches_per_step"] * r["mean_launch_us"] * 1e-3 <= d["ms_per_step"] * 1.02
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["unit"] == d["unit"]
