@@ -2,8 +2,8 @@
 
 The reference has no distributed code; this module is the host side of csrc/lf_dist.hip.  A transport is
 any object with `exchange_int32(top_send, bottom_send, n_top_recv, n_bottom_recv) -> (top_recv, bottom_recv)`
-and `allreduce_max(int) -> int`: `SocketTransport` (plain TCP, no PyTorch -- what bench.py uses) or `TorchTransport`
-(torch.distributed; gloo is enough: only the tiny phase vectors travel through it at set-up); `settle_phases_local` / `loopback_route` connect
+and `allreduce_max(int) -> int`: `SocketTransport` (plain TCP, no PyTorch -- what bench.py uses; a torch.distributed
+transport with the same two methods lives in tests/dist_worker_gloo.py); `settle_phases_local` / `loopback_route` connect
 several blocks living in one process (tests, single-GPU loopback).
 """
 import ctypes as C
@@ -155,41 +155,110 @@ def settle_phases_local(graphs):
     return nph
 
 
-class TorchTransport:
-    """torch.distributed transport for set-up (vertical neighbours = rank -/+ 1)."""
+# ---- wire format of SocketTransport: a fixed, typed encoding (no pickle -- nothing a peer sends is ever executed) ----------
+#   N                      None
+#   i <int64>              int            f <float64>   float          T / F   bool
+#   b <u64 n> <n bytes>    bytes          s <u64 n> <utf-8>  str
+#   a <u8 len><dtype str> <u8 ndim> <u64 shape...> <raw C-order bytes>    numpy array (numeric dtypes only)
+#   l <u64 n> items / t <u64 n> items                                     list / tuple
+_NUMERIC_KINDS = "biuf"
 
-    def __init__(self, dist):
-        self.dist = dist
-        self.rank, self.nranks = dist.get_rank(), dist.get_world_size()
 
-    def exchange_int32(self, top_send, bottom_send, n_top_recv, n_bottom_recv):
-        import torch
-        dist = self.dist
-        top_recv = torch.zeros(n_top_recv, dtype=torch.int32)
-        bot_recv = torch.zeros(n_bottom_recv, dtype=torch.int32)
-        ops = []
-        up, dn = self.rank - 1, self.rank + 1
-        # message sizes are known on both sides (export / ghost counts match by construction)
-        if up >= 0:
-            if len(top_send):
-                ops.append(dist.P2POp(dist.isend, torch.from_numpy(np.ascontiguousarray(top_send)), up))
-            if n_top_recv:
-                ops.append(dist.P2POp(dist.irecv, top_recv, up))
-        if dn < self.nranks:
-            if len(bottom_send):
-                ops.append(dist.P2POp(dist.isend, torch.from_numpy(np.ascontiguousarray(bottom_send)), dn))
-            if n_bottom_recv:
-                ops.append(dist.P2POp(dist.irecv, bot_recv, dn))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-        return top_recv.numpy(), bot_recv.numpy()
+def _encode(obj, out):
+    import struct
+    if obj is None:
+        out.append(b"N")
+    elif isinstance(obj, (bool, np.bool_)):
+        out.append(b"T" if obj else b"F")
+    elif isinstance(obj, (int, np.integer)):
+        out.append(b"i" + struct.pack("<q", int(obj)))
+    elif isinstance(obj, (float, np.floating)):
+        out.append(b"f" + struct.pack("<d", float(obj)))
+    elif isinstance(obj, (bytes, bytearray)):
+        out.append(b"b" + struct.pack("<Q", len(obj)) + bytes(obj))
+    elif isinstance(obj, str):
+        raw = obj.encode("utf-8")
+        out.append(b"s" + struct.pack("<Q", len(raw)) + raw)
+    elif isinstance(obj, np.ndarray):
+        if obj.dtype.kind not in _NUMERIC_KINDS:
+            raise TypeError("SocketTransport sends numeric arrays only, not dtype %r" % (obj.dtype,))
+        a = np.ascontiguousarray(obj)
+        dt = a.dtype.str.encode("ascii")
+        out.append(b"a" + struct.pack("<B", len(dt)) + dt + struct.pack("<B", a.ndim) +
+                   struct.pack("<%dQ" % a.ndim, *a.shape) + a.tobytes())
+    elif isinstance(obj, (list, tuple)):
+        out.append((b"l" if isinstance(obj, list) else b"t") + struct.pack("<Q", len(obj)))
+        for x in obj:
+            _encode(x, out)
+    else:
+        raise TypeError("SocketTransport cannot send %r" % (type(obj),))
 
-    def allreduce_max(self, value):
-        import torch
-        t = torch.tensor([int(value)], dtype=torch.int64)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        return int(t.item())
+
+def _decode(buf, pos=0, depth=0):
+    """-> (object, next position); raises ValueError on anything malformed"""
+    import struct
+    if depth > 16:
+        raise ValueError("message nested too deeply")
+    tag = buf[pos:pos + 1]
+    pos += 1
+    if tag == b"N":
+        return None, pos
+    if tag in (b"T", b"F"):
+        return tag == b"T", pos
+    if tag == b"i":
+        return struct.unpack_from("<q", buf, pos)[0], pos + 8
+    if tag == b"f":
+        return struct.unpack_from("<d", buf, pos)[0], pos + 8
+    if tag in (b"b", b"s"):
+        n, = struct.unpack_from("<Q", buf, pos)
+        pos += 8
+        if n > len(buf) - pos:
+            raise ValueError("truncated message")
+        raw = bytes(buf[pos:pos + n])
+        return (raw if tag == b"b" else raw.decode("utf-8")), pos + n
+    if tag == b"a":
+        ln, = struct.unpack_from("<B", buf, pos)
+        dt = np.dtype(bytes(buf[pos + 1:pos + 1 + ln]).decode("ascii"))
+        pos += 1 + ln
+        if dt.kind not in _NUMERIC_KINDS:
+            raise ValueError("refusing array dtype %r" % (dt,))
+        nd, = struct.unpack_from("<B", buf, pos)
+        shape = struct.unpack_from("<%dQ" % nd, buf, pos + 1)
+        pos += 1 + 8 * nd
+        count = 1
+        for d in shape:
+            count *= d
+        nbytes = count * dt.itemsize
+        if nbytes > len(buf) - pos:
+            raise ValueError("truncated message")
+        a = np.frombuffer(buf, dtype=dt, count=count, offset=pos).reshape(shape).copy()
+        return a, pos + nbytes
+    if tag in (b"l", b"t"):
+        n, = struct.unpack_from("<Q", buf, pos)
+        pos += 8
+        if n > len(buf):
+            raise ValueError("truncated message")
+        items = []
+        for _ in range(n):
+            x, pos = _decode(buf, pos, depth + 1)
+            items.append(x)
+        return (items if tag == b"l" else tuple(items)), pos
+    raise ValueError("unknown type tag %r" % (tag,))
+
+
+def _private_dir():
+    """a directory only this user can write: the rendezvous file must not be replaceable by another user of the node"""
+    import stat
+    import tempfile
+    d = os.path.join(tempfile.gettempdir(), "lisflood_amd_%d" % os.getuid())
+    try:
+        os.mkdir(d, 0o700)
+    except FileExistsError:
+        pass
+    st = os.lstat(d)
+    if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise PermissionError("%s is not a private directory of this user" % d)
+    return d
 
 
 class SocketTransport:
@@ -198,81 +267,130 @@ class SocketTransport:
     it (the phase fixpoint's int32 vectors, the 128-byte RCCL id, barriers and the max-over-ranks clock of the bench);
     the data path is RCCL.
 
-    Rendezvous on one node: rank 0 binds an ephemeral port and publishes it in a file named after MASTER_ADDR /
-    MASTER_PORT (+ torchrun's TORCHELASTIC_RUN_ID when present), so it works under `python -m torch.distributed.run`
-    -- whose agent owns MASTER_PORT itself -- as well as under any launcher that sets RANK / WORLD_SIZE."""
+    Rendezvous on one node: rank 0 binds an ephemeral port on 127.0.0.1 and publishes `port token` (a fresh random
+    token per run) in a 0600 file inside a 0700 per-user directory, named after MASTER_ADDR / MASTER_PORT (+ torchrun's
+    TORCHELASTIC_RUN_ID when present) -- so it works under `python -m torch.distributed.run`, whose agent owns
+    MASTER_PORT itself, as well as under any launcher that sets RANK / WORLD_SIZE.  A peer must present the token before
+    anything else it sends is looked at; a connection that does not is dropped.  Messages are a fixed typed encoding of
+    None / bool / int / float / bytes / str / numeric numpy arrays / lists / tuples (`_encode`): nothing received is
+    ever unpickled or evaluated.  A stale file of a crashed run is removed by rank 0 before it binds; the other ranks
+    re-read the file and reconnect until the timeout, so reading a dead port first is harmless."""
+
+    _MAGIC = b"LFAMD1"
+    _MAX_MESSAGE = 1 << 31
 
     def __init__(self, rank, nranks, rendezvous_file, timeout=300.0):
-        import pickle
+        import hmac
+        import secrets
         import socket
         import struct
         import time
-        self.rank, self.nranks, self._pickle, self._struct = rank, nranks, pickle, struct
+        self.rank, self.nranks, self._struct = rank, nranks, struct
         self.peers = {}
         if nranks == 1:
             return
+        deadline = time.time() + timeout
         if rank == 0:
-            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            srv.bind(("127.0.0.1", 0))
-            srv.listen(nranks)
-            srv.settimeout(timeout)
-            tmp = rendezvous_file + ".tmp%d" % os.getpid()
-            with open(tmp, "w") as f:
-                f.write(str(srv.getsockname()[1]))
-            os.replace(tmp, rendezvous_file)
-            for _ in range(nranks - 1):
-                c, _addr = srv.accept()
-                c.settimeout(timeout)
-                c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                self.peers[self._recv(c)] = c
-            srv.close()
             try:
-                os.unlink(rendezvous_file)
+                os.unlink(rendezvous_file)          # left behind by a crashed run: its port is dead
             except OSError:
                 pass
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.bind(("127.0.0.1", 0))
+            srv.listen(max(nranks, 8))
+            token = secrets.token_hex(16)
+            tmp = rendezvous_file + ".tmp%d" % os.getpid()
+            fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+            with os.fdopen(fd, "w") as f:
+                f.write("%d %s" % (srv.getsockname()[1], token))
+            os.replace(tmp, rendezvous_file)
+            try:
+                while len(self.peers) < nranks - 1:
+                    srv.settimeout(max(deadline - time.time(), 0.01))
+                    try:
+                        c, _addr = srv.accept()
+                    except socket.timeout:
+                        raise TimeoutError("only %d of %d ranks connected" % (len(self.peers) + 1, nranks))
+                    try:                               # handshake: magic, token, rank -- fixed 6 + 32 + 4 bytes
+                        c.settimeout(10.0)
+                        hello = self._exact(c, len(self._MAGIC) + 32 + 4)
+                        r, = struct.unpack("<i", hello[-4:])
+                        ok = (hello[:len(self._MAGIC)] == self._MAGIC and
+                              hmac.compare_digest(hello[len(self._MAGIC):-4], token.encode("ascii")) and
+                              0 < r < nranks and r not in self.peers)
+                    except (OSError, ConnectionError):
+                        ok = False
+                    if not ok:
+                        c.close()                      # not one of ours
+                        continue
+                    c.sendall(b"OK")
+                    c.settimeout(timeout)
+                    c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    self.peers[r] = c
+            finally:
+                srv.close()
+                try:
+                    os.unlink(rendezvous_file)
+                except OSError:
+                    pass
         else:
-            t0 = time.time()
-            port = None
-            while port is None:
+            c = None
+            while c is None:
+                if time.time() > deadline:
+                    raise TimeoutError("no rendezvous with rank 0 through %s" % rendezvous_file)
                 try:
                     with open(rendezvous_file) as f:
-                        port = int(f.read().strip())
-                except (OSError, ValueError):
-                    if time.time() - t0 > timeout:
-                        raise TimeoutError("rank 0 never published %s" % rendezvous_file)
+                        port_s, token = f.read().split()
+                    s = socket.create_connection(("127.0.0.1", int(port_s)), timeout=5.0)
+                    try:
+                        s.settimeout(10.0)
+                        s.sendall(self._MAGIC + token.encode("ascii") + struct.pack("<i", rank))
+                        if self._exact(s, 2) != b"OK":
+                            raise ConnectionError("handshake refused")
+                        c = s
+                    except (OSError, ConnectionError):
+                        s.close()
+                        raise
+                except (OSError, ValueError, ConnectionError):    # no file yet, a stale one, a dead port: look again
                     time.sleep(0.05)
-            c = socket.create_connection(("127.0.0.1", port), timeout=timeout)
             c.settimeout(timeout)
             c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-            self._send(c, rank)
             self.peers[0] = c
 
     @classmethod
     def from_env(cls, timeout=300.0):
         """RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT as torch.distributed.run (or any launcher) exports them"""
-        import tempfile
         rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
         tag = "%s_%s_%s" % (os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT", "29500"),
                             os.environ.get("TORCHELASTIC_RUN_ID", "none"))
-        path = os.path.join(tempfile.gettempdir(), "lisflood_amd_rdv_" + "".join(ch if ch.isalnum() else "_" for ch in tag))
-        return cls(rank, world, path, timeout)
+        name = "rdv_" + "".join(ch if ch.isalnum() else "_" for ch in tag)
+        return cls(rank, world, os.path.join(_private_dir(), name) if world > 1 else name, timeout)
+
+    @staticmethod
+    def _exact(sock, n):
+        buf = bytearray()
+        while len(buf) < n:
+            chunk = sock.recv(min(n - len(buf), 1 << 20))
+            if not chunk:
+                raise ConnectionError("peer closed the connection")
+            buf += chunk
+        return bytes(buf)
 
     def _send(self, sock, obj):
-        data = self._pickle.dumps(obj, protocol=4)
+        parts = []
+        _encode(obj, parts)
+        data = b"".join(parts)
         sock.sendall(self._struct.pack("<q", len(data)) + data)
 
     def _recv(self, sock):
-        def exact(n):
-            buf = bytearray()
-            while len(buf) < n:
-                chunk = sock.recv(min(n - len(buf), 1 << 20))
-                if not chunk:
-                    raise ConnectionError("peer closed the connection")
-                buf += chunk
-            return bytes(buf)
-        n, = self._struct.unpack("<q", exact(8))
-        return self._pickle.loads(exact(n))
+        n, = self._struct.unpack("<q", self._exact(sock, 8))
+        if n < 1 or n > self._MAX_MESSAGE:
+            raise ValueError("bad message length %d" % n)
+        buf = self._exact(sock, n)
+        obj, end = _decode(buf)
+        if end != n:
+            raise ValueError("trailing bytes in message")
+        return obj
 
     def allgather(self, obj):
         """-> [obj of rank 0, obj of rank 1, ...] on every rank"""

@@ -16,6 +16,41 @@ from lisflood_amd import synthetic as syn  # noqa: E402
 import dist_plan_exec as X  # noqa: E402
 
 
+class TorchTransport:
+    """torch.distributed transport for the set-up fixpoint (vertical neighbours = rank -/+ 1): the two methods
+    lisflood_amd.dist.settle_phases needs.  Test infrastructure -- the product's own transport is SocketTransport."""
+
+    def __init__(self, dist):
+        self.dist = dist
+        self.rank, self.nranks = dist.get_rank(), dist.get_world_size()
+
+    def exchange_int32(self, top_send, bottom_send, n_top_recv, n_bottom_recv):
+        dist = self.dist
+        top_recv = torch.zeros(n_top_recv, dtype=torch.int32)
+        bot_recv = torch.zeros(n_bottom_recv, dtype=torch.int32)
+        ops = []
+        up, dn = self.rank - 1, self.rank + 1
+        if up >= 0:
+            if len(top_send):
+                ops.append(dist.P2POp(dist.isend, torch.from_numpy(np.ascontiguousarray(top_send)), up))
+            if n_top_recv:
+                ops.append(dist.P2POp(dist.irecv, top_recv, up))
+        if dn < self.nranks:
+            if len(bottom_send):
+                ops.append(dist.P2POp(dist.isend, torch.from_numpy(np.ascontiguousarray(bottom_send)), dn))
+            if n_bottom_recv:
+                ops.append(dist.P2POp(dist.irecv, bot_recv, dn))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        return top_recv.numpy(), bot_recv.numpy()
+
+    def allreduce_max(self, value):
+        t = torch.tensor([int(value)], dtype=torch.int64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return int(t.item())
+
+
 def swap(dist, rank, world, j, rk):
     """halo values of round j with the vertical neighbours (gloo send/recv of float64)."""
     ops, bufs = [], {}
@@ -46,7 +81,7 @@ def main():
     r0, r1 = D.row_blocks(H, world)[rank]
     g = D.DistGraph(codes[r0:r1], mask[r0:r1], codes[r0 - 1] if r0 > 0 else None, None,
                     codes[r1] if r1 < H else None, None)
-    D.settle_phases(g, D.TorchTransport(dist))
+    D.settle_phases(g, TorchTransport(dist))
     sel = np.arange(r0 * W, r1 * W)
     rk = X.RankState(g, p["alpha"][sel], p["dx"][sel], p["dt"], p["beta"], p["Q0"][sel])
     outs = []

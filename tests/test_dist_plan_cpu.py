@@ -150,3 +150,82 @@ def test_bench_dist_leg_is_torch_free():
         assert not any(m.split(".")[0] == "torch" for m in mods), (name, mods)
     src = open(os.path.join(ROOT, "lisflood-code_amd", "lisflood_amd", "dist_bench.py")).read()
     assert "import torch" not in src
+
+
+def test_socket_transport_wire_format_is_typed_not_pickled():
+    """messages are a fixed typed encoding: round trip of everything the ranks send, and refusal of anything else
+    (object arrays, unknown tags, truncated input) -- nothing a peer sends is ever unpickled"""
+    from lisflood_amd import dist as D
+    msg = [None, True, 7, -3.5, b"\x00id", "txt", (np.arange(5, dtype=np.int32), np.zeros((2, 3))), [np.float64(2.0)]]
+    parts = []
+    D._encode(msg, parts)
+    back, end = D._decode(b"".join(parts))
+    assert end == len(b"".join(parts))
+    assert back[:6] == [None, True, 7, -3.5, b"\x00id", "txt"]
+    assert np.array_equal(back[6][0], msg[6][0]) and back[6][0].dtype == np.int32 and back[6][1].shape == (2, 3)
+    assert back[7] == [2.0]
+    with pytest.raises(TypeError):
+        D._encode(np.array([object()]), [])
+    with pytest.raises(TypeError):
+        D._encode({"a": 1}, [])
+    import pickle
+    for bad in (pickle.dumps([1, 2]), b"a\x03|O8\x01" + b"\x01" + b"\x00" * 7, b"b" + b"\xff" * 8, b"l" + b"\xff" * 8):
+        with pytest.raises((ValueError, struct_error())):
+            D._decode(bad)
+    assert "pickle" not in open(D.__file__).read().replace("no pickle", "").replace("unpickled", "")
+
+
+def struct_error():
+    import struct
+    return struct.error
+
+
+def test_socket_transport_rejects_strangers_and_survives_a_stale_file(tmp_path):
+    """rank 0 drops a connection that does not present the run's token (and still completes the rendezvous with the real
+    rank); a rendezvous file left behind by a crashed run (dead port) does not break the next run"""
+    import socket
+    import threading
+    from lisflood_amd import dist as D
+    rdv = str(tmp_path / "rdv")
+    dead = socket.socket()
+    dead.bind(("127.0.0.1", 0))
+    port = dead.getsockname()[1]
+    dead.close()
+    open(rdv, "w").write("%d %s" % (port, "0" * 32))         # stale: nobody listens there
+    res = {}
+
+    def rank0():
+        res[0] = D.SocketTransport(0, 2, rdv, timeout=30.0)
+
+    t0 = threading.Thread(target=rank0)
+    t0.start()
+    import time
+    deadline = time.time() + 20
+    live = None
+    while time.time() < deadline:                            # the file rank 0 publishes replaces the stale one
+        try:
+            ps, tok = open(rdv).read().split()
+            if int(ps) != port:
+                live = (int(ps), tok)
+                break
+        except (OSError, ValueError):
+            pass
+        time.sleep(0.02)
+    assert live is not None
+    s = socket.create_connection(("127.0.0.1", live[0]))     # a stranger: right port, wrong token
+    s.sendall(D.SocketTransport._MAGIC + b"f" * 32 + (1).to_bytes(4, "little"))
+    s.settimeout(10)
+    assert s.recv(2) == b""                                  # dropped without an answer
+    s.close()
+    t1 = D.SocketTransport(1, 2, rdv, timeout=30.0)
+    t0.join(30)
+    assert 0 in res
+    out = {}
+    th = threading.Thread(target=lambda: out.setdefault(0, res[0].allgather(np.arange(3))))
+    th.start()
+    got = t1.allgather(np.arange(3) + 10)
+    th.join(30)
+    assert np.array_equal(got[0], np.arange(3)) and np.array_equal(out[0][1], np.arange(3) + 10)
+    t1.close()
+    res[0].close()
+    assert not os.path.exists(rdv)
