@@ -92,6 +92,9 @@ int lf_timer_stop(int device, double *elapsed_ms);
 /* profiling aid: stream copy of n doubles with bytes_per_lane in {8, 16}; its HBM traffic is exactly
  * n*8 B read + n*8 B written, which calibrates rocprofv3's FETCH_SIZE / WRITE_SIZE on gfx950. */
 int lf_calibration_copy(int device, const double *src_dev, double *dst_dev, int64_t n, int bytes_per_lane);
+/* nread (1..8) read streams + one write stream of n doubles each (dst[i] = src_0[i] + ... ), 8 bytes per lane: the byte
+ * mix of the level sweep without its arithmetic -- the bandwidth ceiling of a kernel with that many streams. */
+int lf_calibration_streams(int device, int nread, const double *const *src_dev, double *dst_dev, int64_t n);
 
 /* ---------------------------------------------------------------------------------------------
  * graph: replaces rebuildFlowMatrix/decodeFlowMatrix/streamLookups/topoDistFromSea/_setRoutingOrders

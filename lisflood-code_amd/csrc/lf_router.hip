@@ -2349,6 +2349,49 @@ __global__ void __launch_bounds__(kBlock) k_calib_copy16(long long n2, const dou
 }
 } // namespace
 
+namespace {
+struct calib_streams {
+    const double *src[8];
+};
+template <int NS>
+__global__ void __launch_bounds__(kBlock) k_calib_streams(long long n, calib_streams S, double *__restrict__ dst)
+{
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    double v[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) v[k] = S.src[k][i];
+    double acc = v[0];
+#pragma unroll
+    for (int k = 1; k < NS; ++k) acc += v[k];
+    dst[i] = acc;
+}
+} // namespace
+
+// nread (1..8) read streams and one write stream of n doubles, one element per lane: the byte mix of the level sweep
+// without its arithmetic and without its gather -- what the memory system gives a kernel of that many 8-byte streams
+extern "C" int lf_calibration_streams(int device, int nread, const double *const *src_dev, double *dst_dev, int64_t n)
+{
+    lf_device_ctx *c;
+    LF_TRY(lf_ctx(device, &c));
+    if (!src_dev || !dst_dev || n <= 0 || nread < 1 || nread > 8) return lf_set_error(LF_E_INVALID, "bad argument");
+    calib_streams S;
+    for (int k = 0; k < 8; ++k) S.src[k] = src_dev[k < nread ? k : 0];
+    const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
+    switch (nread) {
+    case 1: hipLaunchKernelGGL(k_calib_streams<1>, grid, block, 0, c->stream, (long long)n, S, dst_dev); break;
+    case 2: hipLaunchKernelGGL(k_calib_streams<2>, grid, block, 0, c->stream, (long long)n, S, dst_dev); break;
+    case 3: hipLaunchKernelGGL(k_calib_streams<3>, grid, block, 0, c->stream, (long long)n, S, dst_dev); break;
+    case 4: hipLaunchKernelGGL(k_calib_streams<4>, grid, block, 0, c->stream, (long long)n, S, dst_dev); break;
+    case 5: hipLaunchKernelGGL(k_calib_streams<5>, grid, block, 0, c->stream, (long long)n, S, dst_dev); break;
+    case 6: hipLaunchKernelGGL(k_calib_streams<6>, grid, block, 0, c->stream, (long long)n, S, dst_dev); break;
+    case 7: hipLaunchKernelGGL(k_calib_streams<7>, grid, block, 0, c->stream, (long long)n, S, dst_dev); break;
+    default: hipLaunchKernelGGL(k_calib_streams<8>, grid, block, 0, c->stream, (long long)n, S, dst_dev); break;
+    }
+    LF_HIP(hipGetLastError());
+    return LF_OK;
+}
+
 extern "C" int lf_calibration_copy(int device, const double *src_dev, double *dst_dev, int64_t n, int bytes_per_lane)
 {
     lf_device_ctx *c;
