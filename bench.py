@@ -301,7 +301,7 @@ def model_step_bench(size=5000, nsteps=24, family="deep"):
     from lisflood_amd import _lib
     from lisflood_amd import synthetic as syn
     from lisflood_amd.kinematic_wave_parallel import Graph, kinematicWave
-    from lisflood_amd.routing_device import RoutingStepDevice
+    from bench_support import RoutingStepDevice
     H = W = size
     N = H * W
     codes = syn.make_ldd(family, H, W, SEEDS[family])
@@ -461,8 +461,8 @@ def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.gpus > 1 or world > 1 or a.force_dist:
-        from lisflood_amd import dist_bench
-        return dist_bench.main(a)
+        import bench_dist
+        return bench_dist.main(a)
     if a.only == "soil":
         print(json.dumps(soil_bench()), flush=True)
         return

@@ -31,10 +31,10 @@ def log(rank, *a):
 def catchment_leg(a, T, rank, world, device):
     """Same raster, same calls, ranks own whole catchments (lisflood_amd.partition): no halo, no collective on the data
     path.  Every rank derives the partition from the full LDD itself (set-up, untimed)."""
-    from . import _lib
-    from . import partition as P
-    from . import synthetic as syn
-    from .kinematic_wave_parallel import Graph, kinematicWave
+    from lisflood_amd import _lib
+    from lisflood_amd import partition as P
+    from lisflood_amd import synthetic as syn
+    from lisflood_amd.kinematic_wave_parallel import Graph, kinematicWave
     H = W = a.size
     N = H * W
     seed = {"shallow": 1, "deep": 2, "river": 7}[a.family]
@@ -98,7 +98,7 @@ def catchment_leg(a, T, rank, world, device):
     err = None
     nsteps = 24
     try:
-        from .routing_device import RoutingStepDevice
+        from bench_support import RoutingStepDevice
         p = syn.router_params(N)
         vals, dtr = syn.model_step_values(N, p, ids=ids)
         kw2 = kinematicWave(codes, mask.reshape(H, W), p["alpha"][ids], p["beta"], p["dx"][ids], dtr,
@@ -133,9 +133,9 @@ def catchment_leg(a, T, rank, world, device):
 
 
 def main(a):
-    from . import _lib
-    from . import dist as D
-    from . import synthetic as syn
+    from lisflood_amd import _lib
+    from lisflood_amd import dist as D
+    from lisflood_amd import synthetic as syn
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", str(a.gpus)))
@@ -155,8 +155,17 @@ def main(a):
     graph = D.DistGraph(local, None, top, None, bot, None)
     D.settle_phases(graph, T)
     uid = T.broadcast(D.Comm.unique_id() if rank == 0 else None, src=0)
-    comm = D.Comm(uid, world, rank, device)
-    _flush_c_stdio()        # RCCL announces its library path through C stdio: keep it out of the way of the JSON line
+    # RCCL announces its version / library path on stdout (C stdio) while the communicator is built: send that to stderr
+    # so that stdout carries the ONE JSON line and nothing else
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        comm = D.Comm(uid, world, rank, device)
+        _flush_c_stdio()
+    finally:
+        os.dup2(saved, 1)
+        os.close(saved)
     N = H * W
     i0, i1 = r0 * W, r1 * W
     p = syn.router_params_slice(N, i0, i1)

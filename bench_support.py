@@ -1,4 +1,5 @@
-"""Device-resident routing state for a whole model step (engine order).
+"""Bench / test helper (not part of the product package): device-resident routing state for a whole model step
+(engine order).
 
 `RoutingStepDevice` keeps every vector of routing.dynamic (routing.py:435-706) in HBM in the router's sweep
 order and runs the NoRoutSteps sub-steps either one by one (`run_sequential`, lf_routing_substep) or as one
@@ -8,8 +9,12 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import DeviceArray, check, f64, lib, u8
-from .routing import _OUT, _STATE, _STATIC, _SubstepArgs
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "lisflood-code_amd"))
+from lisflood_amd._lib import DeviceArray, check, f64, lib, u8  # noqa: E402
+from lisflood_amd.routing import _OUT, _STATE, _STATIC, _SubstepArgs  # noqa: E402
 
 
 class RoutingStepDevice:

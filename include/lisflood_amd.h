@@ -506,6 +506,24 @@ int lf_dist_router_route(lf_dist_router *r, lf_comm *comm, double *q_ord_dev, co
  * the rank's own N cells, each router call with its halo exchanges.  engine_order = 1 (the rank's engine order);
  * a->ChanQKin and a->Chan2QKin are state vectors (lf_dist_router_state_size entries), all others have N entries. */
 int lf_dist_routing_substep(lf_dist_router *r, lf_comm *comm, const lf_substep_args *a, int rank_top, int rank_bottom);
+/* nsteps x routing.dynamic() on the partition (= lf_routing_substeps_fused on the whole raster, bit for bit): a rank
+ * sweeps ONE PHASE for ALL sub-steps as a skewed wavefront over (level, sub-step); the router outputs that cross a
+ * phase or a rank boundary are kept per sub-step in slabs [slot][sub-step], so there is ONE halo exchange per phase and
+ * model step (RCCL Send/Recv of one contiguous block per neighbour and section) instead of one per phase, router call
+ * and sub-step.  Vectors as lf_dist_routing_substep; sideflow_stride = 0 or N (one SideflowChanM3 vector per sub-step). */
+int lf_dist_routing_substeps_fused(lf_dist_router *r, lf_comm *comm, const lf_substep_args *a, int nsteps,
+                                   int64_t sideflow_stride, int rank_top, int rank_bottom);
+/* its pieces (other transports, in-process loopback): allocate for nsteps; one phase; where a round's halo sits in the
+ * slab of a section -- out = {send offset, send count, recv offset, recv count} in doubles; the RCCL exchange */
+int lf_dist_fused_prepare(lf_dist_router *r, const lf_substep_args *a, int nsteps);
+int lf_dist_fused_phase(lf_dist_router *r, const lf_substep_args *a, int nsteps, int64_t sideflow_stride, int phase);
+int lf_dist_fused_halo_block(const lf_dist_router *r, int round, int side, int64_t out[4]);
+int lf_dist_fused_slab(const lf_dist_router *r, int section, void **slab_dev);
+int lf_dist_fused_exchange(lf_dist_router *r, lf_comm *comm, int round, int split, int rank_top, int rank_bottom);
+/* slab slots of the fused path: out[0] = slots, [1..2] first export slot top / bottom, [3..4] first ghost slot top /
+ * bottom, [5] first slot of the local cells that feed a later phase; and the tables by position (tests) */
+int lf_dist_graph_slab_layout(const lf_dist_graph *g, int64_t out[6]);
+int lf_dist_graph_get_fused_tables(const lf_dist_graph *g, int32_t *out_slot, int32_t *ups_idx_f);
 /* the pieces of a call, for transports other than RCCL and for tests */
 int lf_dist_router_compute_phase(lf_dist_router *r, double *q_ord_dev, const double *lat_ord_dev, int section,
                                  int phase);

@@ -24,7 +24,7 @@
 #include <cstdlib>
 #include <cstring>
 
-#include "lf_sweep.h"
+#include "lf_fused.h"
 
 // ------------------------------------------------------------------------------------------------
 // host: local graph with halos
@@ -55,6 +55,16 @@ struct lf_dist_graph {
     std::vector<int64_t> export_off[2];   // [nphases+1] offsets into export_pos per phase
     std::vector<int64_t> ghost_off[2];    // [nphases+1] offsets (within the side) of ghosts per phase
     int64_t ghost_base[2] = {0, 0};       // slot of the first ghost of each side (added to N)
+    // ---- fused sub-steps on the partition (lf_dist_routing_substeps_fused) ----
+    // A rank sweeps ONE PHASE for ALL sub-steps of a model step as a skewed wavefront over (level, sub-step), like the
+    // single-domain lf_routing_substeps_fused; what crosses a phase or a rank boundary -- the router outputs of cells
+    // whose downstream cell sits in a later phase or on another rank -- is kept for every sub-step in SLABS indexed
+    // [slot][sub-step], so a round's halo is one contiguous block per neighbour and section.  Slots:
+    //   [exports top | exports bottom | ghosts top | ghosts bottom | local cells feeding a later phase],
+    // exports and ghosts ordered (phase, column) as in the per-call exchange.
+    std::vector<int32_t> out_slot;        // [N] by position: slot the cell's router outputs are stored in, -1 none
+    std::vector<int32_t> ups_idx_f;       // as ups_idx: a same-phase local position, or -(slot) - 1
+    int64_t n_slots = 0, slot_export[2] = {0, 0}, slot_ghost[2] = {0, 0}, slot_xphase = 0;
 };
 
 namespace {
@@ -362,6 +372,40 @@ int lf_dist_graph_finalize(lf_dist_graph *g, int nphases)
         g->ups_base[p] = base;
         g->n_noncontiguous += base < 0;
     }
+    // ---- slab slots and upstream lists of the fused sub-step wavefront ----
+    {
+        const int64_t ne0 = (int64_t)g->export_pos[0].size(), ne1 = (int64_t)g->export_pos[1].size();
+        const int64_t ng0 = (int64_t)g->ghost_target[0].size(), ng1 = (int64_t)g->ghost_target[1].size();
+        g->slot_export[0] = 0;
+        g->slot_export[1] = ne0;
+        g->slot_ghost[0] = ne0 + ne1;
+        g->slot_ghost[1] = ne0 + ne1 + ng0;
+        g->slot_xphase = ne0 + ne1 + ng0 + ng1;
+        g->out_slot.assign(n, -1);
+        for (int side = 0; side < 2; ++side)
+            for (size_t i = 0; i < g->export_pos[side].size(); ++i)
+                g->out_slot[g->export_pos[side][i]] = (int32_t)(g->slot_export[side] + (int64_t)i);
+        int64_t x = g->slot_xphase;
+        for (int64_t p = 0; p < n; ++p) {
+            const int32_t c = g->perm[p], d = g->down[c];
+            if (d >= 0 && g->phase[d] > g->phase[c]) g->out_slot[p] = (int32_t)x++;
+        }
+        g->n_slots = x;
+        if (x >= ((int64_t)1 << 31)) return lf_set_error(LF_E_INVALID, "too many slab slots");
+        g->ups_idx_f.resize(g->ups_idx.size());
+        for (int64_t p = 0; p < n; ++p) {
+            const int32_t ph = g->phase[g->perm[p]];
+            for (int32_t k = g->ups_ptr[p]; k < g->ups_ptr[p + 1]; ++k) {
+                const int32_t e2 = g->ups_idx[k];
+                if (e2 >= n) // ghost: ups_idx holds n + ghost slot (side, phase, column)
+                    g->ups_idx_f[k] = -(int32_t)(g->slot_ghost[0] + (e2 - n)) - 1;
+                else if (g->phase[g->perm[e2]] == ph)
+                    g->ups_idx_f[k] = e2;
+                else
+                    g->ups_idx_f[k] = -g->out_slot[e2] - 1;
+            }
+        }
+    }
     g->finalized = true;
     return LF_OK;
 }
@@ -424,6 +468,28 @@ int lf_dist_graph_round_send_positions(const lf_dist_graph *g, int round, int si
     for (int64_t i = a; i < b; ++i) positions[i - a] = g->export_pos[side][i];
     return LF_OK;
 }
+// fused sub-steps: out[0] = slab slots, [1..2] first export slot top / bottom, [3..4] first ghost slot top / bottom,
+// [5] first slot of the local cells that feed a later phase
+int lf_dist_graph_slab_layout(const lf_dist_graph *g, int64_t out[6])
+{
+    if (!g || !g->finalized || !out) return lf_set_error(LF_E_INVALID, "graph not finalized");
+    out[0] = g->n_slots;
+    out[1] = g->slot_export[0];
+    out[2] = g->slot_export[1];
+    out[3] = g->slot_ghost[0];
+    out[4] = g->slot_ghost[1];
+    out[5] = g->slot_xphase;
+    return LF_OK;
+}
+// the fused path's tables by position: out_slot[N], ups_idx_f[n_edges] (either may be NULL)
+int lf_dist_graph_get_fused_tables(const lf_dist_graph *g, int32_t *out_slot, int32_t *ups_idx_f)
+{
+    if (!g || !g->finalized) return lf_set_error(LF_E_INVALID, "graph not finalized");
+    if (out_slot) std::memcpy(out_slot, g->out_slot.data(), sizeof(int32_t) * g->out_slot.size());
+    if (ups_idx_f) std::memcpy(ups_idx_f, g->ups_idx_f.data(), sizeof(int32_t) * g->ups_idx_f.size());
+    return LF_OK;
+}
+
 int64_t lf_dist_graph_round_recv_slot(const lf_dist_graph *g, int round, int side)
 {
     if (!g || !g->finalized || round < 0 || round >= g->nphases || side < 0 || side > 1) return -1;
@@ -570,6 +636,12 @@ struct lf_dist_router {
     std::vector<int64_t> export_off[2], ghost_off[2];
     int64_t ghost_base[2] = {0, 0};
     int64_t last_launches = 0;
+    // fused sub-steps (see lf_dist_graph): fused upstream lists, slab slot of every cell, router-output parity buffers,
+    // the slabs [slot][sub-step] of both sections, sized for slab_steps sub-steps
+    lf_dbuf<int32_t> ups_idx_f, out_slot;
+    lf_dbuf<double> fused_qr1, fused_qr2, slab1, slab2;
+    int64_t n_slots = 0, slab_steps = 0, slot_export[2] = {0, 0}, slot_ghost[2] = {0, 0};
+    std::vector<int32_t> phase_level; // [nphases + 1] first launch unit of every phase
 };
 
 namespace {
@@ -713,10 +785,18 @@ int lf_dist_router_create(const lf_dist_graph *g, const double *alpha, double be
         r->ghost_off[side] = g->ghost_off[side];
         r->ghost_base[side] = g->ghost_base[side];
     }
+    if (rc == LF_OK) rc = r->ups_idx_f.upload(g->ups_idx_f.data(), g->ups_idx_f.size());
+    if (rc == LF_OK) rc = r->out_slot.upload(g->out_slot.data(), g->out_slot.size());
     if (rc != LF_OK) {
         delete r;
         return rc;
     }
+    r->n_slots = g->n_slots;
+    for (int side = 0; side < 2; ++side) {
+        r->slot_export[side] = g->slot_export[side];
+        r->slot_ghost[side] = g->slot_ghost[side];
+    }
+    r->phase_level = g->phase_level;
     r->h_level_start = g->level_start;
     r->schedule.resize(g->nphases);
     for (int j = 0; j < g->nphases; ++j) {
@@ -876,6 +956,254 @@ int lf_dist_routing_substep(lf_dist_router *r, lf_comm *comm, const lf_substep_a
     if (a->split) {
         LF_TRY(lf_dist_router_route(r, comm, a->Chan2QKin, a->scratch1, LF_SECTION_FLOODPLAINS, rank_top, rank_bottom));
         LF_TRY(lf_substep_stage(r->device, 2, r->N, a));
+    }
+    return LF_OK;
+}
+
+} // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// fused sub-steps on the partition: a whole model step (nsteps x routing.dynamic, routing.py:512-603) per phase
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct dist_fused_args {
+    const int *__restrict__ ups_base; // [N] first upstream position if the upstream cells are consecutive (then: same phase)
+    const int *__restrict__ ups_idx;  // fused lists: same-phase position, or -(slab slot) - 1
+    const int *__restrict__ out_slot; // [N] slab slot of the cell's router outputs, -1 none
+    int unit0, nunits;                // launch units (levels) of the phase
+};
+
+// k_fused_substeps (lf_fused.h) on one phase of a rank's block: launch t works on (unit t - s, sub-step s).  A cell
+// reads the router outputs of its same-phase upstream cells from the parity buffers (previous unit, written at t - 1)
+// and those of earlier phases / other ranks from the slabs; cells feeding a later phase or another rank store theirs in
+// the slabs.  The per-cell arithmetic is fused_cell's: bit-identical to the single-domain wavefront.
+template <bool SPLIT>
+__global__ void __launch_bounds__(kBlock) k_fused_substeps_dist(fused_args F, dist_fused_args D)
+{
+    int s, blk;
+    if (F.packed) {
+        int cnt = 0, start = 0;
+        for (int q = 0; q < F.nsteps; ++q) {
+            const bool ge = (int)blockIdx.x >= F.blk_start[q];
+            cnt += ge ? 1 : 0;
+            start = ge ? F.blk_start[q] : start;
+        }
+        s = cnt - 1;
+        blk = (int)blockIdx.x - start;
+    } else {
+        s = blockIdx.y;
+        blk = blockIdx.x;
+    }
+    int k = F.t - s;
+    if (k < 0 || k >= D.nunits) return;
+    k += D.unit0;
+    const long long first = F.level_start[k];
+    const long long i = (long long)blk * kBlock + threadIdx.x;
+    if (i >= F.level_start[k + 1] - first) return;
+    const long long p = first + i;
+    const int u0 = F.ups_ptr[p], u1 = F.ups_ptr[p + 1];
+    const int base = D.ups_base[p];
+    const int kmax = F.kmax;
+    const long long slot = D.out_slot[p];
+    const int *idx = D.ups_idx;
+    const double *slab1 = F.root1, *slab2 = F.root2;
+    const long long ss = F.root_ss, off = (long long)s * F.root_st;
+    fused_cell<SPLIT, false>(F, p, s, [=](const double *q, int section) {
+        if (base >= 0) return upstream_sum8(q, base, base + (u1 - u0), kmax);
+        const double *slab = section ? slab2 : slab1;
+        double v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            double x = 0.0;
+            if (j < kmax && u0 + j < u1) {
+                const int e = idx[u0 + j];
+                x = e >= 0 ? q[e] : slab[(long long)(-(e + 1)) * ss + off];
+            }
+            v[j] = x;
+        }
+        double ups = 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ups += v[j];
+        return ups;
+    }, slot);
+}
+
+int dist_fused_prepare(lf_dist_router *r, const lf_substep_args *a, int nsteps)
+{
+    if (!r || !a || nsteps < 1) return lf_set_error(LF_E_INVALID, "bad argument");
+    if (!a->engine_order) return lf_set_error(LF_E_INVALID, "the partitioned sub-steps need engine-order vectors");
+    if (a->split && !r->has_floodplains)
+        return lf_set_error(LF_E_SECTION, "split routing requested but the router has no floodplain alpha");
+    LF_HIP(hipSetDevice(r->device));
+    const size_t n = (size_t)std::max<int64_t>(r->N, 1);
+    if (!r->fused_qr1.p) LF_TRY(r->fused_qr1.alloc(2 * n));
+    if (a->split && !r->fused_qr2.p) LF_TRY(r->fused_qr2.alloc(2 * n));
+    const size_t need = (size_t)std::max<int64_t>(r->n_slots, 1) * (size_t)nsteps;
+    if (r->slab_steps < nsteps || !r->slab1.p) {
+        LF_HIP(hipStreamSynchronize(r->ctx->stream)); // nobody may still read the old slabs
+        LF_TRY(r->slab1.alloc(need));
+        r->slab2.release();
+        r->slab_steps = nsteps;
+    }
+    if (a->split && !r->slab2.p) LF_TRY(r->slab2.alloc(need));
+    return LF_OK;
+}
+
+// every sub-step of one phase as a wavefront over (unit, sub-step): nunits + nsteps - 1 launches
+int dist_fused_phase(lf_dist_router *r, const lf_substep_args *a, int nsteps, int64_t sideflow_stride, int phase)
+{
+    if (phase < 0 || phase >= r->nphases) return lf_set_error(LF_E_INVALID, "phase %d out of range", phase);
+    if (sideflow_stride != 0 && sideflow_stride != r->N) return lf_set_error(LF_E_INVALID, "sideflow_stride must be 0 or N");
+    if (nsteps != r->slab_steps && nsteps > r->slab_steps) return lf_set_error(LF_E_INVALID, "lf_dist_fused_prepare first");
+    const int unit0 = r->phase_level[phase], nunits = r->phase_level[phase + 1] - unit0;
+    if (nunits <= 0 || r->N == 0) return LF_OK;
+    fused_args F;
+    std::memset(&F, 0, sizeof(F));
+    F.S = *a;
+    F.ups_ptr = r->ups_ptr.p;
+    F.a1 = r->a1.p;
+    F.a2 = r->a2.p;
+    F.dx = r->dx_per_pixel ? r->dx.p : nullptr;
+    F.level_start = r->level_start.p;
+    F.qr1 = r->fused_qr1.p;
+    F.qr2 = r->fused_qr2.p;
+    F.root1 = r->slab1.p;
+    F.root2 = r->slab2.p;
+    F.nroots = r->n_slots;
+    F.root_ss = r->slab_steps; // [slot][sub-step]
+    F.root_st = 1;
+    F.n = r->N;
+    F.side_stride = sideflow_stride;
+    F.dx_scalar = r->dx_scalar;
+    F.beta = r->beta;
+    F.inv_beta = r->inv_beta;
+    F.b_minus_1 = r->b_minus_1;
+    F.kmax = r->kmax;
+    F.nlevels = (int)r->h_level_start.size() - 1;
+    F.nsteps = nsteps;
+    F.solve35 = r->fused ? 1 : 0;
+    dist_fused_args D;
+    D.ups_base = r->ups_base.p;
+    D.ups_idx = r->ups_idx_f.p;
+    D.out_slot = r->out_slot.p;
+    D.unit0 = unit0;
+    D.nunits = nunits;
+    hipStream_t s = r->ctx->stream;
+    auto width = [&](int k) { return r->h_level_start[unit0 + k + 1] - r->h_level_start[unit0 + k]; };
+    for (int t = 0; t < nunits + nsteps - 1; ++t) {
+        const int k_lo = std::max(0, t - nsteps + 1), k_hi = std::min(nunits - 1, t);
+        int64_t widest = 0;
+        for (int k = k_lo; k <= k_hi; ++k) widest = std::max(widest, width(k));
+        F.t = t;
+        dim3 grid(blocks_for(widest), nsteps);
+        F.packed = 0;
+        if (nsteps <= kMaxPackedSteps) {
+            int64_t acc = 0;
+            for (int q = 0; q < nsteps; ++q) {
+                F.blk_start[q] = (int)acc;
+                const int k = t - q;
+                if (k >= 0 && k < nunits) acc += blocks_for(width(k));
+            }
+            F.blk_start[nsteps] = (int)acc;
+            if (2 * acc <= (int64_t)blocks_for(widest) * nsteps && acc < ((int64_t)1 << 31)) {
+                F.packed = 1;
+                grid = dim3((unsigned)std::max<int64_t>(acc, 1), 1);
+            }
+        }
+        if (a->split)
+            hipLaunchKernelGGL((k_fused_substeps_dist<true>), grid, dim3(kBlock), 0, s, F, D);
+        else
+            hipLaunchKernelGGL((k_fused_substeps_dist<false>), grid, dim3(kBlock), 0, s, F, D);
+        r->last_launches++;
+    }
+    LF_HIP(hipGetLastError());
+    return LF_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+// slabs and parity buffers for nsteps sub-steps (idempotent; lf_dist_routing_substeps_fused calls it itself)
+int lf_dist_fused_prepare(lf_dist_router *r, const lf_substep_args *a, int nsteps)
+{
+    LF_TRY(dist_fused_prepare(r, a, nsteps));
+    r->last_launches = 0;
+    return LF_OK;
+}
+
+// all nsteps sub-steps of the local cells of one phase (after lf_dist_fused_prepare and the halo of the phase before)
+int lf_dist_fused_phase(lf_dist_router *r, const lf_substep_args *a, int nsteps, int64_t sideflow_stride, int phase)
+{
+    if (!r || !a) return lf_set_error(LF_E_INVALID, "null argument");
+    LF_HIP(hipSetDevice(r->device));
+    return dist_fused_phase(r, a, nsteps, sideflow_stride, phase);
+}
+
+// halo of `round` in the slabs of `section`: out = {send offset, send count, recv offset, recv count} in doubles from
+// lf_dist_fused_slab (count = cells x slab sub-steps: a round's values of one neighbour are one contiguous block)
+int lf_dist_fused_halo_block(const lf_dist_router *r, int round, int side, int64_t out[4])
+{
+    if (!r || !out || round < 0 || round >= r->nphases || side < 0 || side > 1) return lf_set_error(LF_E_INVALID, "bad argument");
+    const int64_t S = r->slab_steps;
+    out[0] = (r->slot_export[side] + r->export_off[side][round]) * S;
+    out[1] = (r->export_off[side][round + 1] - r->export_off[side][round]) * S;
+    out[2] = (r->slot_ghost[side] + r->ghost_off[side][round]) * S;
+    out[3] = (r->ghost_off[side][round + 1] - r->ghost_off[side][round]) * S;
+    return LF_OK;
+}
+int lf_dist_fused_slab(const lf_dist_router *r, int section, void **slab_dev)
+{
+    if (!r || !slab_dev) return lf_set_error(LF_E_INVALID, "null argument");
+    *slab_dev = section == LF_SECTION_MAIN ? (void *)r->slab1.p : (void *)r->slab2.p;
+    return LF_OK;
+}
+
+// RCCL Send/Recv of the round's slab blocks with the rank above / below, both sections in one group
+int lf_dist_fused_exchange(lf_dist_router *r, lf_comm *comm, int round, int split, int rank_top, int rank_bottom)
+{
+    if (!r || round < 0 || round >= r->nphases) return lf_set_error(LF_E_INVALID, "bad argument");
+    LF_HIP(hipSetDevice(r->device));
+    const int peer[2] = {rank_top, rank_bottom};
+    int64_t blk[2][4];
+    bool any = false;
+    for (int side = 0; side < 2; ++side) {
+        LF_TRY(lf_dist_fused_halo_block(r, round, side, blk[side]));
+        if ((blk[side][1] > 0 || blk[side][3] > 0) && peer[side] < 0)
+            return lf_set_error(LF_E_INVALID, "halo traffic without a neighbour rank");
+        any = any || blk[side][1] > 0 || blk[side][3] > 0;
+    }
+    if (!any) return LF_OK;
+    if (!comm) return lf_set_error(LF_E_COMM, "halo exchange needed but no communicator given");
+    hipStream_t s = r->ctx->stream;
+    LF_NCCL(g_rccl.GroupStart());
+    for (int section = 0; section < (split ? 2 : 1); ++section) {
+        double *slab = section == 0 ? r->slab1.p : r->slab2.p;
+        for (int side = 0; side < 2; ++side) {
+            if (blk[side][1] > 0)
+                LF_NCCL(g_rccl.Send(slab + blk[side][0], (size_t)blk[side][1], kNcclFloat64, peer[side], comm->comm, s));
+            if (blk[side][3] > 0)
+                LF_NCCL(g_rccl.Recv(slab + blk[side][2], (size_t)blk[side][3], kNcclFloat64, peer[side], comm->comm, s));
+        }
+    }
+    LF_NCCL(g_rccl.GroupEnd());
+    return LF_OK;
+}
+
+// nsteps x routing.dynamic() on the partition (= lf_routing_substeps_fused on the whole raster, bit for bit): phase by
+// phase, every sub-step of a phase as one wavefront, ONE halo exchange per phase and model step (instead of one per
+// phase, router call and sub-step).  All vectors in the rank's engine order, N entries (ChanQKin / Chan2QKin may be the
+// state vectors of lf_dist_routing_substep: their ghost slots are not used here).  a->SideflowChanM3: sideflow_stride =
+// 0 (one vector for all sub-steps) or N.
+int lf_dist_routing_substeps_fused(lf_dist_router *r, lf_comm *comm, const lf_substep_args *a, int nsteps,
+                                   int64_t sideflow_stride, int rank_top, int rank_bottom)
+{
+    LF_TRY(dist_fused_prepare(r, a, nsteps));
+    r->last_launches = 0;
+    for (int j = 0; j < r->nphases; ++j) {
+        LF_TRY(dist_fused_phase(r, a, nsteps, sideflow_stride, j));
+        if (j + 1 < r->nphases) LF_TRY(lf_dist_fused_exchange(r, comm, j, a->split, rank_top, rank_bottom));
     }
     return LF_OK;
 }

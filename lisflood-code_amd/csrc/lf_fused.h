@@ -1,0 +1,682 @@
+// lf_fused.h -- device code of the fused multi-sub-step routing wavefront (routing.py:512-603, 693-703 around
+// kinematic_wave_parallel_tools.py:34-92), shared by the single-GPU router (lf_router.hip) and the row-block partition
+// (lf_dist.hip).  See the comment block above lf_routing_substeps_fused in lf_router.hip for the scheme.
+#pragma once
+#include "lf_structures.h"
+#include "lf_sweep.h"
+
+namespace {
+
+constexpr int kMaxPackedSteps = 128;
+
+struct fused_args {
+    lf_substep_args S;
+    const int *__restrict__ ups_ptr;
+    const double *__restrict__ a1, *__restrict__ a2, *__restrict__ dx;
+    const long long *__restrict__ level_start;
+    double *qr1, *qr2; // [2][N] router outputs by sub-step parity (main channel / floodplains)
+    // component layout: router outputs of the tree roots of every tier but the last, one slab per sub-step
+    // ([nsteps][nroots]): the next tier runs after this one has finished ALL its sub-steps
+    double *root1, *root2;
+    long long nroots;
+    long long root_ss, root_st; // slab index of (slot, sub-step) = slot * root_ss + sub-step * root_st
+    long long n, side_stride;
+    double dx_scalar, beta, inv_beta, b_minus_1;
+    int kmax, nlevels, nsteps, t;
+    int solve35; // router runs the beta = 3/5 quintic solve (false: general path, e.g. LF_GENERAL_POW=1)
+    const uint8_t *__restrict__ linked; // zero-length structure links: their router output is stored as 0
+    const uint8_t *__restrict__ inert;  // cells whose sub-step is the identity while their state is all +0.0
+    lf_inloop_args I;                   // STRUCT: lakes / reservoirs / inflow / transmission loss / sideflow assembly
+    const int *__restrict__ site_level; // STRUCT: level of every lake, then every reservoir cell
+    // 1-D grid packed by sub-step: blocks [blk_start[s], blk_start[s+1]) work on (level t - s, sub-step s), so no
+    // block is launched for the part of a narrow level that a 2-D grid sized by the widest level would cover
+    // (packed = 0: 2-D grid, blockIdx.y = sub-step; used when nsteps > kMaxPackedSteps)
+    int packed;
+    int blk_start[kMaxPackedSteps + 1];
+    // level blocks (k_fused_blocked): t counts blocks instead of levels
+    const int *__restrict__ fb_level, *__restrict__ fb_row, *__restrict__ fb_cone;
+    const int *__restrict__ fb_off; // first entry of block b in fb_cone (rows of fb_level[b+1] - fb_level[b] starts)
+    const int *__restrict__ fb_lvl2blk; // block of every level
+    int fb_nblocks;
+    // k_fused_substeps beside k_fused_cones: the level of sub-step s at this wave time (-1: none) instead of t - s
+    int use_lvl;
+    int lvl[kMaxPackedSteps];
+};
+
+__device__ __forceinline__ bool plus_zero(double x) { return __double_as_longlong(x) == 0; }
+
+// Non-channel land pixels sit in the channel router as isolated nodes without sideflow (routing.py:512): once their
+// state is zero, a sub-step leaves every vector as it is.  inert[p] marks the candidates (static part of the test);
+// the cell kernel then checks the state itself and returns early -- on real domains most land pixels are such cells,
+// and being outlets without upstream cells they lie side by side in the last level, so whole lines are skipped.
+// The parameters must be finite too: 0 * inf would turn the zero state into NaN, as it does in the reference.
+__global__ void __launch_bounds__(kBlock) k_inert_flags(long long n, lf_substep_args A, const uint8_t *__restrict__ isolated,
+                                                        const double *__restrict__ a1, const double *__restrict__ a2,
+                                                        const double *__restrict__ dx, uint8_t *__restrict__ inert)
+{
+    const long long p = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (p >= n) return;
+    bool f = isolated[p] && !A.IsChannelKinematic[p];
+    if (f) {
+        const double t = A.InvChanLength[p] * A.ChanLength[p] * A.ChannelAlpha[p] * A.InvChannelAlpha[p] * a1[p] *
+                         (dx ? dx[p] : 1.0);
+        f = isfinite(t) && A.InvChanLength[p] >= 0.0;
+    }
+    if (f && A.split) {
+        const double t = A.ChannelAlpha2[p] * A.InvChannelAlpha2[p] * a2[p];
+        f = isfinite(t) && plus_zero(A.QLimit[p]) && plus_zero(A.Chan2QStart[p]) && plus_zero(A.Chan2M3Start[p]);
+    }
+    inert[p] = f ? 1 : 0;
+}
+
+// Lakes and reservoirs inside the wavefront: site v handles sub-step s = t - level(v) right BEFORE launch t of the
+// cell kernel.  The cells that drain into v in the uncut LDD are zero-length links of the graph, i.e. on v's level:
+// their ChanQ of sub-step s-1 was stored by launch t-1 and is overwritten only by launch t.
+__global__ void __launch_bounds__(kBlock) k_sites_wave(fused_args F)
+{
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= F.I.n_lakes + F.I.n_res) return;
+    const int s = F.t - F.site_level[i];
+    if (s < 0 || s >= F.nsteps) return;
+    lf_site_update(F.I, i);
+}
+
+// the same on level blocks (k_fused_cones): launch t works on (block t - s, sub-step s)
+__global__ void __launch_bounds__(kBlock) k_sites_blocks(fused_args F)
+{
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= F.I.n_lakes + F.I.n_res) return;
+    const int s = F.t - F.fb_lvl2blk[F.site_level[i]];
+    if (s < 0 || s >= F.nsteps) return;
+    lf_site_update(F.I, i);
+}
+
+__device__ __forceinline__ double solve_any(double c, double ap, bool b35, const fused_args &F)
+{
+    if (b35 && lf_fast_range(c) && lf_fast_range(ap)) return (c <= LF_NEWTON_TOL) ? 0.0 : lf_solve_3_5(c, ap);
+    return lf_solve_cell(c, ap, F.beta * ap, F.beta, F.inv_beta, F.b_minus_1);
+}
+
+__device__ __forceinline__ double upstream_sum8(const double *q, int u0, int u1, int kmax)
+{
+    double v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = (k < kmax && u0 + k < u1) ? q[u0 + k] : 0.0;
+    double ups = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ups += v[k];
+    return ups;
+}
+
+// One (cell, sub-step) of the fused sub-steps: everything but the choice of the cell.  `UPS` sums the router outputs of
+// the upstream cells (ascending pixel id) from the parity buffer it is handed: the contiguous range of the level
+// layout, or the ranges / index lists of the component layout.
+template <bool SPLIT, bool STRUCT, class UPS>
+__device__ __forceinline__ void fused_cell(const fused_args &F, long long p, int s, const UPS &ups_of,
+                                           long long root_slot = -1)
+{
+    const lf_substep_args &A = F.S;
+    if (!STRUCT && F.inert && F.inert[p] && s != F.nsteps - 1) { // see k_inert_flags; the last sub-step also writes
+        bool zero = plus_zero(A.ChanQKin[p]) && plus_zero(A.ChanM3Kin[p]) && plus_zero(A.ChanQ[p]); // velocities
+        if (SPLIT && zero)
+            zero = plus_zero(A.Chan2QKin[p]) && plus_zero(A.Chan2M3Kin[p]) && plus_zero(A.CrossSection2Area[p]) &&
+                   plus_zero(A.Sideflow1Chan[p]);
+        if (zero) return;
+    }
+    const bool b35 = A.Beta == 0.6;     // fix-up round trips, as k_substep_main / k_substep_floodplain
+    const bool s35 = F.solve35 != 0;    // router solve + old-discharge term, as the router itself
+    const long long par = (long long)(s & 1) * F.n;
+    // ---- every load first: the argument pointers are not restrict-qualified, so a store in the middle of the
+    // ---- kernel would pin all later loads behind it (the kernel is a stream of ~30 vectors) -------------------
+    const double dxp = F.dx ? F.dx[p] : F.dx_scalar;
+    const double inv_len = A.InvChanLength[p], len = A.ChanLength[p];
+    const bool is_chan = A.IsChannelKinematic[p] != 0;
+    const bool cut = F.linked && F.linked[p];
+    double side_m3, qin = 0, qin_added = 0, loss = 0, trans_cum = 0;
+    if (!STRUCT)
+        side_m3 = A.SideflowChanM3[(long long)s * F.side_stride + p];
+    else { // inflow.py:142-144, transmission.py:76-87, sideflow assembly routing.py:462-478 -- as k_inloop_dense
+        const lf_inloop_args &I = F.I;
+        side_m3 = I.ToChanM3RunoffDt[p];
+        if (I.EvaAddM3Dt) side_m3 -= I.EvaAddM3Dt[p];
+        if (I.WUseAddM3Dt) side_m3 -= I.WUseAddM3Dt[p];
+        if (I.QInM3Old) {
+            qin = (I.QInM3Old[p] + (s + 1) * I.QDelta[p]) * I.InvNoRoutSteps;
+            qin_added = (s < 1 ? 0.0 : I.QinADDEDM3[p]) + qin;
+            side_m3 += qin;
+        }
+        if (I.UpTrans) {
+            const double qc = A.ChanQ[p];
+            const double tout = I.UpTrans[p] ? pow(pow(qc, I.TransPower2) - I.TransSub, I.TransPower1) : qc;
+            loss = (qc - tout) * I.DtRouting;
+            trans_cum = I.TransCum[p] + loss;
+            side_m3 -= loss;
+        }
+        if (I.QLakeOutM3Dt) side_m3 += I.QLakeOutM3Dt[p];
+        if (I.QResOutM3Dt) side_m3 += I.QResOutM3Dt[p];
+        if (I.ChannelToPolderM3Dt) side_m3 -= I.ChannelToPolderM3Dt[p];
+    }
+    const double ap1 = F.a1[p], qold = A.ChanQKin[p], alpha1 = A.ChannelAlpha[p], inv_alpha1 = A.InvChannelAlpha[p];
+    const double sum_old = A.sumDisDay[p];
+    const double ups1 = ups_of(F.qr1 + par, 0);
+    double m3 = 0, m3_2 = 0, start = 0, m3limit = 0, q2start = 0, ap2 = 0, q2old = 0, alpha2 = 0, inv_alpha2 = 0, qlimit = 0,
+           ups2 = 0;
+    if (SPLIT) {
+        m3 = A.ChanM3Kin[p];
+        m3_2 = A.Chan2M3Kin[p];
+        start = A.Chan2M3Start[p];
+        m3limit = A.M3Limit[p];
+        q2start = A.Chan2QStart[p];
+        ap2 = F.a2[p];
+        q2old = A.Chan2QKin[p];
+        alpha2 = A.ChannelAlpha2[p];
+        inv_alpha2 = A.InvChannelAlpha2[p];
+        qlimit = A.QLimit[p];
+        ups2 = ups_of(F.qr2 + par, 1);
+    }
+    const bool last = s == F.nsteps - 1;
+    double pix_area = 0;
+    if (last) pix_area = A.PixelArea[p];
+    // ---- sideflow (routing.py:512, 524 / 549-567) ----
+    const double side = is_chan ? side_m3 * inv_len * A.InvDtRouting : 0.0;
+    double s1 = side, s2 = 0.0;
+    if (!SPLIT) {
+        if (isnan(side)) s1 = 0.0;
+    } else {
+        const double tot = m3 + m3_2;
+        const double ratio = (tot > 0) ? m3 / tot : 0.0;
+        s1 = ((tot - start) > m3limit) ? ratio * side : side;
+        if (fabs(side) < 1e-7) s1 = side;
+        s2 = (side - s1) + q2start * inv_len;
+    }
+    // ---- main channel: router call + fix-up (routing.py:526-532 / 573-578) ----
+    const double cst = ap1 * (s35 ? lf_pow_3_5(qold) : pow(qold, F.beta)) + s1 * dxp;
+    const double c = ups1 + cst;
+    const double qr = solve_any(c, ap1, s35, F);
+    double v = len * alpha1 * (b35 ? lf_pow_3_5(qr) : pow(qr, A.Beta));
+    if (v < 0.0) v = 0.0;
+    const double x = v * inv_len * inv_alpha1;
+    const double q = b35 ? lf_pow_5_3(x) : pow(x, A.InvBeta);
+    double chanq = q, q2r = 0, v2 = 0, q2 = 0;
+    if (SPLIT) { // ---- floodplains (routing.py:583-603) ----
+        const double cst2 = ap2 * (s35 ? lf_pow_3_5(q2old) : pow(q2old, F.beta)) + s2 * dxp;
+        const double c2 = ups2 + cst2;
+        q2r = solve_any(c2, ap2, s35, F);
+        v2 = len * alpha2 * (b35 ? lf_pow_3_5(q2r) : pow(q2r, A.Beta));
+        if ((v2 - start) < 0.0) v2 = start;
+        const double x2 = v2 * inv_len * inv_alpha2;
+        q2 = b35 ? lf_pow_5_3(x2) : pow(x2, A.InvBeta);
+        chanq = q + q2 - qlimit;
+        if (chanq < 0.0) chanq = 0.0;
+    }
+    // ---- stores ----
+    if (STRUCT) {
+        const lf_inloop_args &I = F.I;
+        if (I.QInM3Old) {
+            I.QInDt[p] = qin;
+            I.QinADDEDM3[p] = qin_added;
+        }
+        if (I.UpTrans) {
+            I.TransLossM3Dt[p] = loss;
+            I.TransCum[p] = trans_cum;
+        }
+        I.SideflowChanM3[p] = side_m3;
+    }
+    F.qr1[par + p] = cut ? 0.0 : qr;
+    if (root_slot >= 0) F.root1[root_slot * F.root_ss + s * F.root_st] = qr; // kept for the next tier / phase / rank
+    A.ChanM3Kin[p] = v;
+    A.ChanQKin[p] = q;
+    A.ChanQ[p] = chanq;
+    A.sumDisDay[p] = sum_old + chanq;
+    if (SPLIT) {
+        A.Sideflow1Chan[p] = s1;
+        F.qr2[par + p] = cut ? 0.0 : q2r;
+        if (root_slot >= 0) F.root2[root_slot * F.root_ss + s * F.root_st] = q2r;
+        A.Chan2M3Kin[p] = v2;
+        A.CrossSection2Area[p] = (v2 - start) * inv_len;
+        A.Chan2QKin[p] = q2;
+    }
+    if (last) { // routing.py:693-703
+        double area = v * inv_len;
+        if (area < 0.01) area = 0.01;
+        const double v1 = q / area, vv2 = 0.36 * pow(q, 0.24);
+        double vel = (vv2 < v1) ? vv2 : v1;
+        if (isnan(vv2)) vel = vv2;
+        double sinu = sqrt(pix_area) * inv_len;
+        if (sinu > 1) sinu = 1;
+        vel *= sinu;
+        A.FlowVelocity[p] = vel;
+        A.TravelDistance[p] = vel * A.DtSec;
+    }
+}
+
+template <bool SPLIT, bool STRUCT>
+__global__ void __launch_bounds__(kBlock) k_fused_substeps(fused_args F)
+{
+    int s, blk;
+    if (F.packed) { // the last sub-step whose first block is <= blockIdx.x (starts are non-decreasing; independent
+                    // scalar loads and compares -- a binary search would chain its kernarg loads)
+        int cnt = 0, start = 0;
+        for (int q = 0; q < F.nsteps; ++q) {
+            const bool ge = (int)blockIdx.x >= F.blk_start[q];
+            cnt += ge ? 1 : 0;
+            start = ge ? F.blk_start[q] : start;
+        }
+        s = cnt - 1;
+        blk = (int)blockIdx.x - start;
+    } else {
+        s = blockIdx.y;
+        blk = blockIdx.x;
+    }
+    const int k = F.use_lvl ? F.lvl[s] : F.t - s; // level handled by this sub-step at wave time t
+    if (k < 0 || k >= F.nlevels) return;
+    const long long first = F.level_start[k];
+    const long long i = (long long)blk * kBlock + threadIdx.x;
+    if (i >= F.level_start[k + 1] - first) return;
+    const long long p = first + i;
+    const int u0 = F.ups_ptr[p], u1 = F.ups_ptr[p + 1];
+    const int kmax = F.kmax;
+    fused_cell<SPLIT, STRUCT>(F, p, s, [u0, u1, kmax](const double *q, int) { return upstream_sum8(q, u0, u1, kmax); });
+}
+
+// ---- several levels per launch: the wavefront over LEVEL BLOCKS, one workgroup per upstream cone --------------------
+// One (level, sub-step) of k_fused_substeps is a dependent chain of ~4 memory round trips (kernel arguments -> level
+// table -> upstream ranges -> router outputs and ~25 state vectors) plus the two closure solves: ~9 us of kernel and a
+// ~2.5 us boundary on a latency-bound network (deep 5000^2: 5024 launches, 58 ms per model step).  Grouping several
+// levels into one launch with a workgroup barrier between them does not help by itself (measured: 58 ms for 1, 2, 4 and
+// 8 levels per launch) -- the chain is the cost, not the boundary.  This kernel shortens the chain:
+//  * the levels are grouped into blocks of up to fb_lmax consecutive levels and launch t works on (block t - s,
+//    sub-step s).  Every cell below the last level has exactly one downstream cell, in the next level, and the upstream
+//    cells of a contiguous range of positions are a contiguous range of the level before (lf_common.h, sweep order): a
+//    workgroup that owns a chunk of the block's LAST level owns the whole cone above it, level by level one contiguous
+//    range (fb_cone: its starts, precomputed; chunks are cut so that no range exceeds the workgroup), and the cones tile
+//    every level of the block -- no synchronisation between workgroups inside a block;
+//  * inside a cone the router outputs travel through LDS (two buffers by level parity), so the barrier between two
+//    levels waits for LDS only -- not for the state stores, which drain behind it -- and only the block's last level
+//    writes its router outputs to the parity buffers in HBM (read by the next block in the next launch);
+//  * the state of the NEXT level's cell is loaded before the current level is solved (it does not depend on anything
+//    computed in this launch), so after a barrier a level costs: 8 LDS reads, the two solves, a few LDS writes.
+// The arithmetic of a cell is fused_cell's, operation by operation: results are bit-identical.
+struct cone_cell { // what a cell's load phase leaves in registers: loaded values only, nothing computed from them (a
+                   // compare on a loaded value would make the wavefront wait for the loads right where they are issued)
+    double dxp, inv_len, len, side_m3, ap1, qold, alpha1, inv_alpha1, sum_old;
+    double m3, m3_2, start, m3limit, q2start, ap2, q2old, alpha2, inv_alpha2, qlimit, pix_area;
+    double chanq_old, csa_old, sf1_old; // the inert test; STRUCT: chanq_old = ChanQ before the sub-step (transmission loss)
+    // STRUCT: the terms of the sideflow assembly (routing.py:462-478), as k_inloop_dense / fused_cell read them
+    double eva, wuse, qin_old, qdelta, qin_added_old, transcum, lakeout, resout, polder;
+    int u0, u1;
+    unsigned char chan_raw, inert_raw, uptrans_raw, cut_raw;
+    bool active;
+};
+
+template <bool SPLIT, bool STRUCT>
+__device__ __forceinline__ void cone_load(const fused_args &F, long long p, int s, bool active, cone_cell &R)
+{
+    const lf_substep_args &A = F.S;
+    R.active = active;
+    if (!active) return;
+    R.u0 = F.ups_ptr[p];
+    R.u1 = F.ups_ptr[p + 1];
+    R.dxp = F.dx ? F.dx[p] : F.dx_scalar;
+    R.inv_len = A.InvChanLength[p];
+    R.len = A.ChanLength[p];
+    R.chan_raw = A.IsChannelKinematic[p];
+    R.chanq_old = R.csa_old = R.sf1_old = 0;
+    R.inert_raw = R.uptrans_raw = R.cut_raw = 0;
+    R.eva = R.wuse = R.qin_old = R.qdelta = R.qin_added_old = R.transcum = R.lakeout = R.resout = R.polder = 0;
+    if (!STRUCT)
+        R.side_m3 = A.SideflowChanM3[(long long)s * F.side_stride + p];
+    else {
+        const lf_inloop_args &I = F.I;
+        R.side_m3 = I.ToChanM3RunoffDt[p];
+        if (I.EvaAddM3Dt) R.eva = I.EvaAddM3Dt[p];
+        if (I.WUseAddM3Dt) R.wuse = I.WUseAddM3Dt[p];
+        if (I.QInM3Old) {
+            R.qin_old = I.QInM3Old[p];
+            R.qdelta = I.QDelta[p];
+            R.qin_added_old = I.QinADDEDM3[p];
+        }
+        if (I.UpTrans) {
+            R.chanq_old = A.ChanQ[p];
+            R.uptrans_raw = I.UpTrans[p];
+            R.transcum = I.TransCum[p];
+        }
+        if (I.QLakeOutM3Dt) R.lakeout = I.QLakeOutM3Dt[p];
+        if (I.QResOutM3Dt) R.resout = I.QResOutM3Dt[p];
+        if (I.ChannelToPolderM3Dt) R.polder = I.ChannelToPolderM3Dt[p];
+    }
+    if (F.linked) R.cut_raw = F.linked[p]; // (also without STRUCT: a sub-step at a time on a graph with structure links)
+    R.ap1 = F.a1[p];
+    R.qold = A.ChanQKin[p];
+    R.alpha1 = A.ChannelAlpha[p];
+    R.inv_alpha1 = A.InvChannelAlpha[p];
+    R.sum_old = A.sumDisDay[p];
+    R.m3 = R.m3_2 = R.start = R.m3limit = R.q2start = R.ap2 = R.q2old = R.alpha2 = R.inv_alpha2 = R.qlimit = 0;
+    const bool test_inert = !STRUCT && F.inert && s != F.nsteps - 1; // see k_inert_flags / fused_cell (uniform)
+    if (SPLIT || test_inert) R.m3 = A.ChanM3Kin[p];
+    if (SPLIT) {
+        R.m3_2 = A.Chan2M3Kin[p];
+        R.start = A.Chan2M3Start[p];
+        R.m3limit = A.M3Limit[p];
+        R.q2start = A.Chan2QStart[p];
+        R.ap2 = F.a2[p];
+        R.q2old = A.Chan2QKin[p];
+        R.alpha2 = A.ChannelAlpha2[p];
+        R.inv_alpha2 = A.InvChannelAlpha2[p];
+        R.qlimit = A.QLimit[p];
+    }
+    R.pix_area = (s == F.nsteps - 1) ? A.PixelArea[p] : 0.0;
+    if (test_inert) {
+        R.inert_raw = F.inert[p];
+        R.chanq_old = A.ChanQ[p];
+        if (SPLIT) {
+            R.csa_old = A.CrossSection2Area[p];
+            R.sf1_old = A.Sideflow1Chan[p];
+        }
+    }
+}
+
+// the early return of fused_cell: an inert cell whose state is all +0.0 stays as it is
+template <bool SPLIT>
+__device__ __forceinline__ bool cone_skip(const cone_cell &R)
+{
+    if (!R.active) return true;
+    if (!R.inert_raw) return false;
+    bool zero = plus_zero(R.qold) && plus_zero(R.m3) && plus_zero(R.chanq_old);
+    if (SPLIT && zero) zero = plus_zero(R.q2old) && plus_zero(R.m3_2) && plus_zero(R.csa_old) && plus_zero(R.sf1_old);
+    return zero;
+}
+
+// The general-exponent paths (OCML pow: ~200 instructions per call site, ~25 call sites inlined into fused_cell) are
+// taken by single lanes with extreme arguments or not at all when beta = 3/5.  In the cone kernel's beta = 3/5 variant
+// they live out of line, one copy each, so that the loop over the levels of a cone is a few KB of straight code instead
+// of ~60 KB of mostly skipped blocks.  Same functions, same results.
+__device__ __attribute__((noinline)) double cold_pow(double x, double y) { return pow(x, y); }
+__device__ __attribute__((noinline)) double cold_solve(double c, double a, double ba, double beta, double inv_beta,
+                                                       double b_minus_1)
+{
+    return lf_solve_cell(c, a, ba, beta, inv_beta, b_minus_1);
+}
+// ALL35: beta == 3/5 for the fix-up round trips and for the router (both flags of fused_cell set), known on the host;
+// otherwise the flags are tested at run time exactly as fused_cell does
+template <bool ALL35>
+__device__ __forceinline__ double cone_pow_3_5(double x, double y, bool is35)
+{
+    if (!ALL35) return is35 ? lf_pow_3_5(x) : pow(x, y);
+    if (x == 0.0) return 0.0; // as lf_pow_3_5
+    if (lf_fast_range(x)) {
+        const double r = lf_root5(x);
+        return r * r * r;
+    }
+    return cold_pow(x, 0.6);
+}
+template <bool ALL35>
+__device__ __forceinline__ double cone_pow_5_3(double x, double y, bool is35)
+{
+    if (!ALL35) return is35 ? lf_pow_5_3(x) : pow(x, y);
+    if (x == 0.0) return 0.0; // as lf_pow_5_3
+    if (lf_fast_range(x)) {
+        const double r = lf_cbrt(x);
+        return x * (r * r);
+    }
+    return cold_pow(x, 1.0 / 0.6);
+}
+template <bool ALL35>
+__device__ __forceinline__ double cone_solve(double c, double ap, bool is35, const fused_args &F)
+{
+    if (!ALL35) return solve_any(c, ap, is35, F);
+    if (lf_fast_range(c) && lf_fast_range(ap)) return (c <= LF_NEWTON_TOL) ? 0.0 : lf_solve_3_5(c, ap);
+    return cold_solve(c, ap, F.beta * ap, F.beta, F.inv_beta, F.b_minus_1);
+}
+
+// everything after the loads of fused_cell<SPLIT, false>, in its order, up to the stores: the new state stays in
+// registers (cone_out) and is stored one level later, so that the stores have a whole level's arithmetic to drain
+struct cone_out {
+    double v, q, chanq, sum, s1, v2, csa, q2, vel, trav;
+    double qin, qin_added, loss, trans_cum, side_m3; // STRUCT
+    long long p;
+    bool valid;
+};
+
+template <bool SPLIT, bool ALL35, bool STRUCT>
+__device__ __forceinline__ void cone_compute(const fused_args &F, const cone_cell &R, long long p, int s, double ups1,
+                                             double ups2, double &qr_out, double &q2r_out, cone_out &O)
+{
+    const lf_substep_args &A = F.S;
+    const bool b35 = A.Beta == 0.6;
+    const bool s35 = F.solve35 != 0;
+    const bool last = s == F.nsteps - 1;
+    double side_m3 = R.side_m3;
+    O.qin = O.qin_added = O.loss = O.trans_cum = 0.0;
+    if (STRUCT) { // inflow.py:142-144, transmission.py:76-87, sideflow assembly routing.py:462-478 -- as fused_cell
+        const lf_inloop_args &I = F.I;
+        if (I.EvaAddM3Dt) side_m3 -= R.eva;
+        if (I.WUseAddM3Dt) side_m3 -= R.wuse;
+        if (I.QInM3Old) {
+            O.qin = (R.qin_old + (s + 1) * R.qdelta) * I.InvNoRoutSteps;
+            O.qin_added = (s < 1 ? 0.0 : R.qin_added_old) + O.qin;
+            side_m3 += O.qin;
+        }
+        if (I.UpTrans) {
+            const double qc = R.chanq_old;
+            double tout = qc;
+            if (R.uptrans_raw) {
+                const double inner = (ALL35 ? cold_pow(qc, I.TransPower2) : pow(qc, I.TransPower2)) - I.TransSub;
+                tout = ALL35 ? cold_pow(inner, I.TransPower1) : pow(inner, I.TransPower1);
+            }
+            O.loss = (qc - tout) * I.DtRouting;
+            O.trans_cum = R.transcum + O.loss;
+            side_m3 -= O.loss;
+        }
+        if (I.QLakeOutM3Dt) side_m3 += R.lakeout;
+        if (I.QResOutM3Dt) side_m3 += R.resout;
+        if (I.ChannelToPolderM3Dt) side_m3 -= R.polder;
+    }
+    O.side_m3 = side_m3;
+    const double side = (R.chan_raw != 0) ? side_m3 * R.inv_len * A.InvDtRouting : 0.0;
+    double s1 = side, s2 = 0.0;
+    if (!SPLIT) {
+        if (isnan(side)) s1 = 0.0;
+    } else {
+        const double tot = R.m3 + R.m3_2;
+        const double ratio = (tot > 0) ? R.m3 / tot : 0.0;
+        s1 = ((tot - R.start) > R.m3limit) ? ratio * side : side;
+        if (fabs(side) < 1e-7) s1 = side;
+        s2 = (side - s1) + R.q2start * R.inv_len;
+    }
+    const double cst = R.ap1 * cone_pow_3_5<ALL35>(R.qold, F.beta, s35) + s1 * R.dxp;
+    const double c = ups1 + cst;
+    const double qr = cone_solve<ALL35>(c, R.ap1, s35, F);
+    double v = R.len * R.alpha1 * cone_pow_3_5<ALL35>(qr, A.Beta, b35);
+    if (v < 0.0) v = 0.0;
+    const double x = v * R.inv_len * R.inv_alpha1;
+    const double q = cone_pow_5_3<ALL35>(x, A.InvBeta, b35);
+    double chanq = q, q2r = 0, v2 = 0, q2 = 0;
+    if (SPLIT) {
+        const double cst2 = R.ap2 * cone_pow_3_5<ALL35>(R.q2old, F.beta, s35) + s2 * R.dxp;
+        const double c2 = ups2 + cst2;
+        q2r = cone_solve<ALL35>(c2, R.ap2, s35, F);
+        v2 = R.len * R.alpha2 * cone_pow_3_5<ALL35>(q2r, A.Beta, b35);
+        if ((v2 - R.start) < 0.0) v2 = R.start;
+        const double x2 = v2 * R.inv_len * R.inv_alpha2;
+        q2 = cone_pow_5_3<ALL35>(x2, A.InvBeta, b35);
+        chanq = q + q2 - R.qlimit;
+        if (chanq < 0.0) chanq = 0.0;
+    }
+    qr_out = qr;
+    q2r_out = q2r;
+    O.valid = true;
+    O.p = p;
+    O.v = v;
+    O.q = q;
+    O.chanq = chanq;
+    O.sum = R.sum_old + chanq;
+    O.s1 = s1;
+    O.v2 = v2;
+    O.csa = (v2 - R.start) * R.inv_len;
+    O.q2 = q2;
+    O.vel = O.trav = 0.0;
+    if (last) { // routing.py:693-703
+        double area = v * R.inv_len;
+        if (area < 0.01) area = 0.01;
+        const double v1 = q / area, vv2 = 0.36 * (ALL35 ? cold_pow(q, 0.24) : pow(q, 0.24));
+        double vel = (vv2 < v1) ? vv2 : v1;
+        if (isnan(vv2)) vel = vv2;
+        double sinu = sqrt(R.pix_area) * R.inv_len;
+        if (sinu > 1) sinu = 1;
+        vel *= sinu;
+        O.vel = vel;
+        O.trav = vel * A.DtSec;
+    }
+}
+
+template <bool SPLIT, bool STRUCT>
+__device__ __forceinline__ void cone_store(const fused_args &F, const cone_out &O, int s)
+{
+    if (!O.valid) return;
+    const lf_substep_args &A = F.S;
+    const long long p = O.p;
+    if (STRUCT) {
+        const lf_inloop_args &I = F.I;
+        if (I.QInM3Old) {
+            I.QInDt[p] = O.qin;
+            I.QinADDEDM3[p] = O.qin_added;
+        }
+        if (I.UpTrans) {
+            I.TransLossM3Dt[p] = O.loss;
+            I.TransCum[p] = O.trans_cum;
+        }
+        I.SideflowChanM3[p] = O.side_m3;
+    }
+    A.ChanM3Kin[p] = O.v;
+    A.ChanQKin[p] = O.q;
+    A.ChanQ[p] = O.chanq;
+    A.sumDisDay[p] = O.sum;
+    if (SPLIT) {
+        A.Sideflow1Chan[p] = O.s1;
+        A.Chan2M3Kin[p] = O.v2;
+        A.CrossSection2Area[p] = O.csa;
+        A.Chan2QKin[p] = O.q2;
+    }
+    if (s == F.nsteps - 1) {
+        A.FlowVelocity[p] = O.vel;
+        A.TravelDistance[p] = O.trav;
+    }
+}
+
+// LDS barrier: the wavefronts of the workgroup have finished their LDS writes; global stores keep draining
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+#ifndef LF_CONES_WAVES
+#define LF_CONES_WAVES 2
+#endif
+template <bool SPLIT, bool ALL35, bool STRUCT>
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(LF_CONES_WAVES))) k_fused_cones(fused_args F)
+{
+    __shared__ double x1[2][kBlock], x2[SPLIT ? 2 : 1][SPLIT ? kBlock : 1];
+    int s, blk;
+    if (F.packed) {
+        int cnt = 0, start = 0;
+        for (int q = 0; q < F.nsteps; ++q) {
+            const bool ge = (int)blockIdx.x >= F.blk_start[q];
+            cnt += ge ? 1 : 0;
+            start = ge ? F.blk_start[q] : start;
+        }
+        s = cnt - 1;
+        blk = (int)blockIdx.x - start;
+    } else {
+        s = blockIdx.y;
+        blk = blockIdx.x;
+    }
+    const int b = F.t - s;
+    if (b < 0 || b >= F.fb_nblocks) return;
+    // the plan is read through the constant address space: scalar loads, no vector-memory wait on the way (ld_table)
+    const int row0 = ld_table(F.fb_row, b), ncones = ld_table(F.fb_row, b + 1) - row0 - 1;
+    if (blk >= ncones) return;
+    const int nl = ld_table(F.fb_level, b + 1) - ld_table(F.fb_level, b);
+    const int *c0 = F.fb_cone + (size_t)ld_table(F.fb_off, b) + (size_t)blk * nl, *c1 = c0 + nl; // this cone / the next
+    const int kmax = F.kmax;
+    const long long par = (long long)(s & 1) * F.n;
+    const int tid = threadIdx.x;
+    cone_out pend;
+    pend.valid = false;
+    int first_up = 0; // first position of the level above (LDS index 0)
+    // One level of the cone: `cur` holds the loaded state of this thread's cell of level j, `nxt` receives that of level
+    // j + 1.  The loop below calls it with the two register sets swapping roles (no copies).
+    // The ~45 array pointers of fused_args do not fit the scalar registers next to the loop's other state: left to itself
+    // the compiler loads them once and spills them to VGPR lanes (200 v_readlane per level).  Instead every level reads
+    // what it needs from the kernel-argument segment again (scalar loads from the constant cache, a handful per level):
+    // the pointer is laundered through an empty asm so that nothing is hoisted out of the level.
+    typedef const fused_args __attribute__((address_space(4))) *kargs_t;
+    const kargs_t K0 = (kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
+    auto level = [&](int j, const cone_cell &cur, cone_cell &nxt, int first) {
+        kargs_t Kp = K0;
+        asm volatile("" : "+s"(Kp));
+        const fused_args &F = *(const fused_args *)Kp;
+        const long long p = first + tid;
+        if (j > 0) lds_barrier(); // level j-1 of this cone is in LDS
+        // Right behind the barrier: the state stores of level j-1 and the state loads of level j+1.  Both have the
+        // arithmetic of level j to complete, so the wait at the end of this level finds them done (issued after the
+        // arithmetic, the stores' acknowledgement would be waited for on every level).
+        cone_store<SPLIT, STRUCT>(F, pend, s);
+        pend.valid = false;
+        int nfirst = 0;
+        if (j + 1 < nl) { // nothing of the next level's state depends on this launch
+            nfirst = ld_table(c0, j + 1);
+            cone_load<SPLIT, STRUCT>(F, nfirst + tid, s, nfirst + tid < ld_table(c1, j + 1), nxt);
+        }
+        if (!cone_skip<SPLIT>(cur)) {
+            double ups1, ups2 = 0.0;
+            if (j == 0) { // from the block before (previous launch) through the parity buffers
+                ups1 = upstream_sum8(F.qr1 + par, cur.u0, cur.u1, kmax);
+                if (SPLIT) ups2 = upstream_sum8(F.qr2 + par, cur.u0, cur.u1, kmax);
+            } else { // from LDS, branch-free: absent neighbours read slot 0 and add +0.0 (the sum as upstream_sum8)
+                const double *y1 = &x1[(j - 1) & 1][0], *y2 = &x2[SPLIT ? (j - 1) & 1 : 0][0];
+                const int base = cur.u0 - first_up;
+                double v1[8], v2[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const bool have = k < kmax && cur.u0 + k < cur.u1;
+                    const int idx = have ? base + k : 0;
+                    v1[k] = y1[idx];
+                    if (SPLIT) v2[k] = y2[idx];
+                    v1[k] = have ? v1[k] : 0.0;
+                    if (SPLIT) v2[k] = have ? v2[k] : 0.0;
+                }
+                ups1 = 0.0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) ups1 += v1[k];
+                if (SPLIT) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) ups2 += v2[k];
+                }
+            }
+            double qr, q2r;
+            cone_compute<SPLIT, ALL35, STRUCT>(F, cur, p, s, ups1, ups2, qr, q2r, pend);
+            if (cur.cut_raw) qr = q2r = 0.0; // zero-length structure links: their router output is stored as 0
+            if (j + 1 < nl) {
+                x1[j & 1][tid] = qr;
+                if (SPLIT) x2[j & 1][tid] = q2r;
+            } else { // the block's last level: read by the next block in the next launch
+                F.qr1[par + p] = qr;
+                if (SPLIT) F.qr2[par + p] = q2r;
+            }
+        }
+        // the loads of the next level (issued before this level's arithmetic) and the stores of the previous one: done
+        // by now.  Stated explicitly so that the compiler does not wait for `nxt` behind the NEXT level's stores.
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        first_up = first;
+        return nfirst;
+    };
+    cone_cell ra, rb;
+    int first = ld_table(c0, 0);
+    cone_load<SPLIT, STRUCT>(F, first + tid, s, first + tid < ld_table(c1, 0), ra);
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): inside the loop the current level's registers are always complete
+    for (int j = 0; j < nl; j += 2) {
+        first = level(j, ra, rb, first);
+        if (j + 1 < nl) first = level(j + 1, rb, ra, first);
+    }
+    cone_store<SPLIT, STRUCT>(F, pend, s);
+}
+
+} // namespace

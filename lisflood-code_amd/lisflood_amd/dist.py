@@ -113,6 +113,19 @@ class DistGraph:
     def round_recv_slot(self, rnd, side):
         return int(lib().lf_dist_graph_round_recv_slot(self._h, C.c_int(rnd), C.c_int(side)))
 
+    def slab_layout(self):
+        """slab slots of the fused sub-step path: dict(slots, export=(top, bottom), ghost=(top, bottom), xphase)"""
+        o = (C.c_int64 * 6)()
+        check(lib().lf_dist_graph_slab_layout(self._h, o))
+        return dict(slots=int(o[0]), export=(int(o[1]), int(o[2])), ghost=(int(o[3]), int(o[4])), xphase=int(o[5]))
+
+    def fused_tables(self):
+        """(out_slot[N] by position, ups_idx_f[n_edges]): see lf_dist_graph_get_fused_tables"""
+        out_slot = np.empty(self.num_pixels, np.int32)
+        idx = np.empty(self.csr()[1].size, np.int32)
+        check(lib().lf_dist_graph_get_fused_tables(self._h, ptr(out_slot), ptr(idx)))
+        return out_slot, idx
+
     def close(self):
         if self._h:
             lib().lf_dist_graph_destroy(self._h)
@@ -580,6 +593,31 @@ class DistRoutingStep:
     def stage(self, i):
         check(lib().lf_substep_stage(C.c_int(self.device), C.c_int(i), C.c_int64(self.N), C.byref(self.args)))
 
+    # --- a whole model step: every sub-step of a phase as one wavefront, one halo exchange per phase -----------------
+    def substeps_fused(self, nsteps):
+        """nsteps x routing.dynamic() = lf_routing_substeps_fused on the whole raster (lf_dist_routing_substeps_fused)"""
+        r = self.router
+        ch = r.comm._h if r.comm is not None else None
+        check(lib().lf_dist_routing_substeps_fused(r._h, ch, C.byref(self.args), C.c_int(nsteps), C.c_int64(0),
+                                                   C.c_int(r.rank_top), C.c_int(r.rank_bottom)))
+
+    def fused_prepare(self, nsteps):
+        check(lib().lf_dist_fused_prepare(self.router._h, C.byref(self.args), C.c_int(nsteps)))
+
+    def fused_phase(self, nsteps, phase):
+        check(lib().lf_dist_fused_phase(self.router._h, C.byref(self.args), C.c_int(nsteps), C.c_int64(0), C.c_int(phase)))
+
+    def fused_halo_block(self, rnd, side):
+        """(send offset, send count, recv offset, recv count) in doubles inside the slab of a section"""
+        o = (C.c_int64 * 4)()
+        check(lib().lf_dist_fused_halo_block(self.router._h, C.c_int(rnd), C.c_int(side), o))
+        return tuple(int(x) for x in o)
+
+    def fused_slab(self, section):
+        p = C.c_void_p()
+        check(lib().lf_dist_fused_slab(self.router._h, C.c_int(section), C.byref(p)))
+        return p.value or 0
+
     def download(self, name):
         out = np.empty(self.N)
         out[self.perm] = self.dev[name].download()[:self.N]
@@ -609,6 +647,35 @@ def loopback_substep(steps):
         loopback_route(routers, [s.dev["Chan2QKin"] for s in steps], [s.dev["scratch1"] for s in steps], "floodplains")
         for s in steps:
             s.stage(2)
+
+
+def loopback_substeps_fused(steps, nsteps):
+    """A whole model step (nsteps sub-steps) over blocks that all live on one GPU: lf_dist_fused_phase per block and phase,
+    the per-phase halo of the slabs as device-to-device copies -- the kernels and the plan of
+    lf_dist_routing_substeps_fused, only the transport differs."""
+    R = len(steps)
+    dev = steps[0].device
+    nph = steps[0].router.graph.num_phases
+    for s in steps:
+        s.fused_prepare(nsteps)
+    for j in range(nph):
+        for s in steps:
+            s.fused_phase(nsteps, j)
+        if j + 1 == nph:
+            break
+        for section in range(2 if steps[0].split else 1):
+            blocks = [[s.fused_halo_block(j, side) for side in (0, 1)] for s in steps]
+            slabs = [s.fused_slab(section) for s in steps]
+            for k in range(R):
+                # side 0: from the rank above (its bottom exports); side 1: from the rank below (its top exports)
+                for side, src_rank, src_side in ((0, k - 1, 1), (1, k + 1, 0)):
+                    _so, _sc, ro, rc = blocks[k][side]
+                    if rc == 0:
+                        continue
+                    so, sc, _ro, _rc = blocks[src_rank][src_side]
+                    assert sc == rc, (k, j, side, sc, rc)
+                    check(lib().lf_memcpy_d2d(C.c_int(dev), C.c_void_p(slabs[k] + 8 * ro),
+                                              C.c_void_p(slabs[src_rank] + 8 * so), C.c_size_t(8 * rc)))
 
 
 def loopback_route(routers, q_states, lat_states, section="main_channel"):

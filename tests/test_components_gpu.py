@@ -109,7 +109,7 @@ def test_components_fused_substeps_equal_the_level_wavefront(amd, family, shape,
     from lisflood_amd import ldd as L
     from lisflood_amd.kinematic_wave_parallel import kinematicWave
     from lisflood_amd.routing import _OUT, _STATE
-    from lisflood_amd.routing_device import RoutingStepDevice
+    from bench_support import RoutingStepDevice
     H, W = shape
     N = H * W
     mask = np.ones((H, W), bool)

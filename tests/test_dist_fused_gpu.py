@@ -1,0 +1,109 @@
+"""-m gpu: a whole model step of routing (NoRoutSteps x routing.dynamic, routing.py:512-603) on the row-block partition
+as lf_dist_routing_substeps_fused runs it -- phase by phase, every sub-step of a phase as one wavefront, one halo block
+per phase -- against lf_routing_substeps_fused on the whole raster: bit-identical.  The blocks live on ONE GPU and the
+halo travels by device copy (the test boxes have one GPU); kernels and plan are those of the RCCL path."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def amd():
+    from lisflood_amd import _lib
+    if _lib.device_count() == 0:
+        pytest.fail("no HIP device: the gpu tests must run on an MI355X box")
+    return _lib
+
+
+def _case(family, H, W, seed, channel_frac=0.9):
+    from lisflood_amd import synthetic as syn
+    N = H * W
+    codes = syn.make_ldd(family, H, W, seed)
+    p = syn.router_params(N, seed=6)
+    vals, dt = syn.model_step_values(N, p, seed=19)
+    if channel_frac < 1:
+        vals["IsChannelKinematic"] = np.random.default_rng(3).random(N) < channel_frac
+    return codes, p, vals, dt
+
+
+def _whole(codes, p, vals, dt, split, nsteps):
+    from lisflood_amd.kinematic_wave_parallel import Graph, kinematicWave
+    from bench_support import RoutingStepDevice
+    kw = kinematicWave(None, None, p["alpha"], p["beta"], p["dx"], dt,
+                       alpha_floodplains=vals["ChannelAlpha2"] if split else None, graph=Graph(ldd_raster=codes))
+    ref = RoutingStepDevice(kw, vals, split, p["beta"], 1 / dt, dt * nsteps)
+    return kw, ref
+
+
+def _blocks(codes, p, vals, dt, split, nsteps, nblocks):
+    from lisflood_amd import dist as D
+    H, W = codes.shape
+    blocks = D.row_blocks(H, nblocks)
+    graphs = [D.DistGraph(codes[r0:r1], None, codes[r0 - 1] if r0 > 0 else None, None,
+                          codes[r1] if r1 < H else None, None) for (r0, r1) in blocks]
+    nph = D.settle_phases_local(graphs)
+    sl = [slice(r0 * W, r1 * W) for (r0, r1) in blocks]
+    routers = [D.DistRouter(g, p["alpha"][s], p["beta"], p["dx"][s], dt,
+                            alpha_floodplains=vals["ChannelAlpha2"][s] if split else None) for g, s in zip(graphs, sl)]
+    steps = [D.DistRoutingStep(r, {k: (a[s] if isinstance(a, np.ndarray) else a) for k, a in vals.items()}, split,
+                               p["beta"], 1 / dt, dt * nsteps) for r, s in zip(routers, sl)]
+    return steps, nph
+
+
+def _same(steps, ref, split, what):
+    from lisflood_amd.routing import _OUT, _STATE
+    for k in _STATE + _OUT:
+        if not split and k in ("Chan2QKin", "Chan2M3Kin", "CrossSection2Area", "Sideflow1Chan"):
+            continue
+        got = np.concatenate([st.download(k) for st in steps])
+        assert np.array_equal(got, ref.download(k), equal_nan=True), (what, k)
+
+
+@pytest.mark.parametrize("split", [True, False])
+@pytest.mark.parametrize("family,seed,nblocks", [("deep", 2, 3), ("shallow", 1, 4), ("saddle", 6, 3), ("river", 7, 5)])
+def test_fused_model_step_on_row_blocks_small(amd, family, seed, nblocks, split):
+    """150 x 130, 7 sub-steps, two model steps in a row (the second starts from the first one's state); non-channel
+    pixels in the domain; flow crossing the cuts both ways (saddle)"""
+    from lisflood_amd import dist as D
+    nsteps = 7
+    codes, p, vals, dt = _case(family, 150, 130, seed)
+    kw, ref = _whole(codes, p, vals, dt, split, nsteps)
+    steps, nph = _blocks(codes, p, vals, dt, split, nsteps, nblocks)
+    for rep in range(2):
+        ref.run_fused(nsteps)
+        D.loopback_substeps_fused(steps, nsteps)
+        _same(steps, ref, split, (family, rep))
+    assert nph >= 2
+    # one block holding everything: the composite entry point, no communicator needed
+    one, _ = _blocks(codes, p, vals, dt, split, nsteps, 1)
+    one[0].substeps_fused(nsteps)
+    one[0].substeps_fused(nsteps)
+    _same(one, ref, split, (family, "one block"))
+    for st in steps + one:
+        st.free()
+    ref.free()
+    kw.close()
+
+
+@pytest.mark.parametrize("family,seed", [("deep", 2), ("river", 7)])
+def test_fused_model_step_on_row_blocks_config4_shape(amd, family, seed):
+    """BASELINE.json configs[4]'s shape on one GPU: 2000 x 2000, 8 row blocks, NoRoutSteps = 24, split routing -- state
+    after the model step bit-identical to the single-domain wavefront; the launch count shows the fused path ran
+    (per phase: levels + 23 launches, not 24 x 2 x levels)"""
+    from lisflood_amd import dist as D
+    nsteps, nblocks = 24, 8
+    codes, p, vals, dt = _case(family, 2000, 2000, seed, channel_frac=1.0)
+    kw, ref = _whole(codes, p, vals, dt, True, nsteps)
+    steps, nph = _blocks(codes, p, vals, dt, True, nsteps, nblocks)
+    ref.run_fused(nsteps)
+    D.loopback_substeps_fused(steps, nsteps)
+    _same(steps, ref, True, family)
+    for st in steps:
+        g = st.router.graph
+        assert st.router.last_launches() <= g.num_launch_units + nph * (nsteps - 1), (st.router.last_launches(),
+                                                                                      g.num_launch_units, nph)
+    for st in steps:
+        st.free()
+    ref.free()
+    kw.close()

@@ -142,13 +142,13 @@ def test_three_process_socket_run():
 def test_bench_dist_leg_is_torch_free():
     """the N > 1 bench leg and the transport it uses import no PyTorch (north_star: ctypes host code, no PyTorch)"""
     import ast
-    for name in ("dist_bench.py", "dist.py"):
-        tree = ast.parse(open(os.path.join(ROOT, "lisflood-code_amd", "lisflood_amd", name)).read())
+    for name in (os.path.join(ROOT, "bench_dist.py"), os.path.join(ROOT, "lisflood-code_amd", "lisflood_amd", "dist.py")):
+        tree = ast.parse(open(name).read())
         top = [n for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom))]
         mods = [a.name for n in top if isinstance(n, ast.Import) for a in n.names] + \
                [n.module or "" for n in top if isinstance(n, ast.ImportFrom)]
         assert not any(m.split(".")[0] == "torch" for m in mods), (name, mods)
-    src = open(os.path.join(ROOT, "lisflood-code_amd", "lisflood_amd", "dist_bench.py")).read()
+    src = open(os.path.join(ROOT, "bench_dist.py")).read()
     assert "import torch" not in src
 
 
@@ -229,3 +229,91 @@ def test_socket_transport_rejects_strangers_and_survives_a_stale_file(tmp_path):
     t1.close()
     res[0].close()
     assert not os.path.exists(rdv)
+
+
+def run_partitioned_phase_major(codes, mask, nranks, alpha, dx, dt, beta, Q0, qs):
+    """The schedule of lf_dist_routing_substeps_fused on the CPU, with a plain router call as the "sub-step": every rank
+    sweeps ONE phase for ALL calls before the next phase starts; what crosses a phase or a rank boundary travels through
+    the slabs [slot][call] (tables of lf_dist_graph_get_fused_tables), one halo block per phase and neighbour."""
+    import math
+    H, W = codes.shape
+    S = len(qs)
+    blocks, graphs = X.build_blocks(codes, mask, nranks)
+    nph = D.settle_phases_local(graphs)
+    ids = np.full((H, W), -1, np.int64)
+    ids[mask] = np.arange(int(mask.sum()))
+    sel = [ids[r0:r1][mask[r0:r1]] for (r0, r1) in blocks]
+    ranks = []
+    for g, s in zip(graphs, sel):
+        n = g.num_pixels
+        perm, _ = g.layout()
+        ups_ptr, _idx = g.csr()
+        out_slot, idx_f = g.fused_tables()
+        lay = g.slab_layout()
+        a = (alpha[s] * dx[s] / dt)[perm]
+        rk = dict(g=g, n=n, perm=perm, ups_ptr=ups_ptr, out_slot=out_slot, lay=lay, a=a, ba=beta * a, dx=dx[s][perm],
+                  idx=np.where(idx_f >= 0, idx_f, n + (-idx_f - 1)).astype(np.int32),
+                  # per call: [router outputs of the n local cells | slab column of that call]
+                  state=[np.zeros(n + lay["slots"]) for _ in range(S)], Q0=Q0[s][perm],
+                  lat=[q[s][perm] for q in qs])
+        assert (out_slot < lay["slots"]).all() and ((idx_f >= 0) | (-idx_f - 1 < lay["slots"])).all()
+        ranks.append(rk)
+    for j in range(nph):
+        for rk in ranks:
+            b, e = rk["g"].phase_range(j)
+            for s in range(S):
+                prev = rk["Q0"] if s == 0 else rk["state"][s - 1][:rk["n"]]
+                const = np.zeros(rk["n"])
+                const[b:e] = rk["a"][b:e] * np.array([math.pow(x, beta) for x in prev[b:e]]) + rk["lat"][s][b:e] * rk["dx"][b:e]
+                st = rk["state"][s]
+                oracle_mod().sweep_positions(st, const, rk["ups_ptr"], rk["idx"], rk["a"], rk["ba"], beta, b, e)
+                has = np.nonzero(rk["out_slot"][b:e] >= 0)[0] + b
+                st[rk["n"] + rk["out_slot"][has]] = st[has]
+        if j + 1 == nph:
+            break
+        for k, rk in enumerate(ranks):          # halo of round j: exports of the neighbour -> my ghost slots, every call
+            for side, src, src_side in ((0, k - 1, 1), (1, k + 1, 0)):
+                if not (0 <= src < nranks):
+                    continue
+                cnt = rk["g"].round_counts(j)["recv"][side]
+                if cnt == 0:
+                    continue
+                other = ranks[src]
+                assert other["g"].round_counts(j)["send"][src_side] == cnt
+                r_off = rk["lay"]["ghost"][side] + sum(rk["g"].round_counts(i)["recv"][side] for i in range(j))
+                s_off = other["lay"]["export"][src_side] + sum(other["g"].round_counts(i)["send"][src_side] for i in range(j))
+                for s in range(S):
+                    rk["state"][s][rk["n"] + r_off:rk["n"] + r_off + cnt] = \
+                        other["state"][s][other["n"] + s_off:other["n"] + s_off + cnt]
+    results = []
+    for s in range(S):
+        full = np.empty(int(mask.sum()))
+        for rk, ss in zip(ranks, sel):
+            loc = np.empty(rk["n"])
+            loc[rk["perm"]] = rk["state"][s][:rk["n"]]
+            full[ss] = loc
+        results.append(full)
+    return results, nph
+
+
+def oracle_mod():
+    import oracle
+    return oracle
+
+
+@pytest.mark.parametrize("family,seed,H,W", CASES + [("river", 7, 60, 56)])
+@pytest.mark.parametrize("nranks", [1, 3, 8])
+def test_phase_major_slab_plan_is_bit_identical_to_single_domain(oracle, family, seed, H, W, nranks):
+    """the fused sub-step schedule (phase-major, slabs, one halo block per phase) reproduces the call-by-call oracle"""
+    codes = syn.make_ldd(family, H, W, seed)
+    mask = np.ones((H, W), bool)
+    if family == "shallow":
+        mask[20:23, 10:30] = False
+        codes[~mask] = 0
+    N = int(mask.sum())
+    p = syn.router_params(N, seed=5)
+    qs = [syn.lateral_inflow(N, s) for s in range(4)]
+    ref = global_reference(oracle, codes, mask, p["alpha"], p["dx"], p["dt"], p["beta"], p["Q0"], qs)
+    got, nph = run_partitioned_phase_major(codes, mask, nranks, p["alpha"], p["dx"], p["dt"], p["beta"], p["Q0"], qs)
+    for a, b in zip(got, ref):
+        assert np.array_equal(a, b)

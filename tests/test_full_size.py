@@ -121,7 +121,7 @@ def run_config4(amd, oracle, size, tmp_path):
     from lisflood_amd import synthetic as syn
     from lisflood_amd.kinematic_wave_parallel import Graph, kinematicWave
     from lisflood_amd.routing import _STATE
-    from lisflood_amd.routing_device import RoutingStepDevice
+    from bench_support import RoutingStepDevice
     H = W = size
     N = H * W
     nsteps = 24

@@ -453,7 +453,7 @@ def test_fused_wavefront_skips_only_true_fixed_points(amd, monkeypatch):
     from lisflood_amd import synthetic as syn
     from lisflood_amd.kinematic_wave_parallel import kinematicWave
     from lisflood_amd.routing import _OUT, _STATE
-    from lisflood_amd.routing_device import RoutingStepDevice
+    from bench_support import RoutingStepDevice
     H, W = 60, 70
     N = H * W
     values, sc, mask, _, ldd_kin = syn.hotpath_scenario(H, W)
@@ -496,7 +496,7 @@ def test_fused_wavefront_equals_sequential_mid_size(amd, family, shape):
     from lisflood_amd import ldd as L
     from lisflood_amd.kinematic_wave_parallel import kinematicWave
     from lisflood_amd.routing import _OUT, _STATE
-    from lisflood_amd.routing_device import RoutingStepDevice
+    from bench_support import RoutingStepDevice
     H, W = shape
     N = H * W
     mask = np.ones((H, W), bool)
@@ -1042,7 +1042,7 @@ def test_row_block_routing_substep_loopback(amd, family, nblocks):
     from lisflood_amd import synthetic as syn
     from lisflood_amd.kinematic_wave_parallel import Graph, kinematicWave
     from lisflood_amd.routing import _OUT, _STATE
-    from lisflood_amd.routing_device import RoutingStepDevice
+    from bench_support import RoutingStepDevice
     H, W = 150, 130
     N = H * W
     codes = syn.make_ldd(family, H, W, 2 if family == "deep" else 1)
@@ -1174,7 +1174,7 @@ def test_catchment_partition_model_step_fused(amd, family, nparts):
     from lisflood_amd import partition as P
     from lisflood_amd import synthetic as syn
     from lisflood_amd.kinematic_wave_parallel import kinematicWave
-    from lisflood_amd.routing_device import RoutingStepDevice
+    from bench_support import RoutingStepDevice
     from test_full_size import model_step_values
     H, W = 300, 280
     N = H * W

@@ -6,9 +6,10 @@ import time
 import numpy as np
 
 sys.path.insert(0, "lisflood-code_amd")
+sys.path.insert(0, ".")
 from lisflood_amd import _lib, synthetic as syn          # noqa: E402
 from lisflood_amd.kinematic_wave_parallel import Graph, kinematicWave  # noqa: E402
-from lisflood_amd.routing_device import RoutingStepDevice  # noqa: E402
+from bench_support import RoutingStepDevice  # noqa: E402
 
 fam, size = sys.argv[1], int(sys.argv[2])
 configs = [None] + [tuple(int(x) for x in a.split(",")) if "," in a else True for a in sys.argv[3:]]

@@ -11,6 +11,7 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lisflood-code_amd"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lisflood_amd import _lib, synthetic as syn          # noqa: E402
 from lisflood_amd.kinematic_wave_parallel import Graph, kinematicWave  # noqa: E402
 
@@ -34,7 +35,7 @@ if mode == "route":
     _lib.synchronize()
     print("route", fam, size, "calls", reps, "launches/call", kw.last_launches()["launches"], "NL", g.num_levels, flush=True)
 else:
-    from lisflood_amd.routing_device import RoutingStepDevice
+    from bench_support import RoutingStepDevice
     nsteps = 24
     vals, dtr = syn.model_step_values(N, p)
     kw = kinematicWave(None, None, p["alpha"], p["beta"], p["dx"], dtr, alpha_floodplains=vals["ChannelAlpha2"], graph=g)

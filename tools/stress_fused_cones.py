@@ -7,9 +7,10 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lisflood-code_amd"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lisflood_amd import synthetic as syn          # noqa: E402
 from lisflood_amd.kinematic_wave_parallel import Graph, kinematicWave  # noqa: E402
-from lisflood_amd.routing_device import RoutingStepDevice  # noqa: E402
+from bench_support import RoutingStepDevice  # noqa: E402
 
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
