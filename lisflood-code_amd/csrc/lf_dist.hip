@@ -1003,7 +1003,10 @@ __global__ void __launch_bounds__(kBlock) k_fused_substeps_dist(fused_args F, di
     if (i >= F.level_start[k + 1] - first) return;
     const long long p = first + i;
     const int u0 = F.ups_ptr[p], u1 = F.ups_ptr[p + 1];
-    const int base = D.ups_base[p];
+    // ups_base also marks runs of GHOST slots (positions >= N of the per-call state vector) as consecutive: here those
+    // come from the slabs, so only a run inside the local cells -- then: same phase, previous unit -- takes the short way
+    const int base_raw = D.ups_base[p];
+    const int base = (base_raw >= 0 && (long long)base_raw + (u1 - u0) <= F.n) ? base_raw : -1;
     const int kmax = F.kmax;
     const long long slot = D.out_slot[p];
     const int *idx = D.ups_idx;
