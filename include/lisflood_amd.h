@@ -524,6 +524,9 @@ int lf_dist_fused_exchange(lf_dist_router *r, lf_comm *comm, int round, int spli
  * bottom, [5] first slot of the local cells that feed a later phase; and the tables by position (tests) */
 int lf_dist_graph_slab_layout(const lf_dist_graph *g, int64_t out[6]);
 int lf_dist_graph_get_fused_tables(const lf_dist_graph *g, int32_t *out_slot, int32_t *ups_idx_f);
+/* level blocks of the fused path (per phase, cone by cone): out = {blocks, blocks of more than one level, cones, entries
+ * of the cone table}; all 0 when no block holds more than one level (then: one launch per level and sub-step wave) */
+int lf_dist_graph_block_stats(const lf_dist_graph *g, int64_t out[4]);
 /* the pieces of a call, for transports other than RCCL and for tests */
 int lf_dist_router_compute_phase(lf_dist_router *r, double *q_ord_dev, const double *lat_ord_dev, int section,
                                  int phase);

@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#include "lf_blocks.h"
 #include "lf_fused.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -65,6 +66,9 @@ struct lf_dist_graph {
     std::vector<int32_t> out_slot;        // [N] by position: slot the cell's router outputs are stored in, -1 none
     std::vector<int32_t> ups_idx_f;       // as ups_idx: a same-phase local position, or -(slot) - 1
     int64_t n_slots = 0, slot_export[2] = {0, 0}, slot_ghost[2] = {0, 0}, slot_xphase = 0;
+    // level blocks and cones of every phase (lf_blocks.h; k_fused_cones<DIST>): blocks never span two phases
+    lf_block_plan fplan;
+    std::vector<int32_t> fplan_phase_block; // [nphases + 1] first block of every phase
 };
 
 namespace {
@@ -406,6 +410,52 @@ int lf_dist_graph_finalize(lf_dist_graph *g, int nphases)
             }
         }
     }
+    // ---- level blocks and cones of every phase ----
+    {
+        int lmax = 16;
+        if (const char *e = std::getenv("LF_FUSED_LEVELS")) lmax = std::atoi(e);
+        lmax = lmax < 1 ? 1 : (lmax > 64 ? 64 : lmax);
+        int64_t wide = 262144;
+        if (const char *e = std::getenv("LF_FUSED_WIDE")) wide = std::atoll(e);
+        g->fplan = lf_block_plan();
+        g->fplan_phase_block.assign(nphases + 1, 0);
+        try {
+            // child[a] = first position of the unit before whose SAME-PHASE downstream cell is at or behind a; cells that
+            // drain into a later phase or another rank sit between the runs and go with the run behind them
+            std::vector<int32_t> child((size_t)n, 0);
+            std::vector<int64_t> dfill;
+            for (int j = 0; j < nphases; ++j)
+                for (int64_t k = g->phase_level[j] + 1; k < g->phase_level[j + 1]; ++k) {
+                    const int64_t pb = g->level_start[k - 1], pe = g->level_start[k], e = g->level_start[k + 1];
+                    dfill.assign((size_t)(pe - pb), 0);
+                    int64_t nxt = e;
+                    for (int64_t u = pe - 1; u >= pb; --u) {
+                        const int32_t c = g->perm[u], d = g->down[c];
+                        if (d >= 0 && g->phase[d] == g->phase[c] && g->pos[d] >= pe && g->pos[d] < e) nxt = g->pos[d];
+                        dfill[(size_t)(u - pb)] = nxt;
+                    }
+                    int64_t u = pb;
+                    for (int64_t a = pe; a < e; ++a) {
+                        while (u < pe && dfill[(size_t)(u - pb)] < a) ++u;
+                        child[(size_t)a] = (int32_t)u;
+                    }
+                }
+            if (lmax > 1 && n < ((int64_t)1 << 31))
+                for (int j = 0; j < nphases; ++j) {
+                    g->fplan_phase_block[j] = (int32_t)g->fplan.level.size();
+                    lf_build_level_blocks(g->level_start, g->phase_level[j], g->phase_level[j + 1], lmax, wide, kBlock,
+                                          [&](int64_t pos) { return (int64_t)child[(size_t)pos]; }, g->fplan);
+                }
+        } catch (const std::bad_alloc &) {
+            return lf_set_error(LF_E_INVALID, "out of host memory while building the level blocks");
+        }
+        g->fplan_phase_block[nphases] = (int32_t)g->fplan.level.size();
+        g->fplan.level.push_back((int)(g->level_start.size() - 1));
+        if (!g->fplan.any_multi || g->fplan.cone.size() >= ((size_t)1 << 31)) { // nothing to gain: the per-unit wavefront
+            g->fplan = lf_block_plan();
+            g->fplan_phase_block.clear();
+        }
+    }
     g->finalized = true;
     return LF_OK;
 }
@@ -479,6 +529,21 @@ int lf_dist_graph_slab_layout(const lf_dist_graph *g, int64_t out[6])
     out[3] = g->slot_ghost[0];
     out[4] = g->slot_ghost[1];
     out[5] = g->slot_xphase;
+    return LF_OK;
+}
+// level blocks of the fused path: out = {blocks, blocks of more than one level, cones, entries of the cone table}
+int lf_dist_graph_block_stats(const lf_dist_graph *g, int64_t out[4])
+{
+    if (!g || !g->finalized || !out) return lf_set_error(LF_E_INVALID, "graph not finalized");
+    out[0] = out[1] = out[2] = out[3] = 0;
+    if (g->fplan_phase_block.empty()) return LF_OK;
+    const lf_block_plan &f = g->fplan;
+    out[0] = (int64_t)f.level.size() - 1;
+    for (size_t b = 0; b + 1 < f.level.size(); ++b) {
+        out[1] += f.level[b + 1] - f.level[b] > 1;
+        out[2] += f.row[b + 1] - f.row[b] - 1;
+    }
+    out[3] = (int64_t)f.cone.size();
     return LF_OK;
 }
 // the fused path's tables by position: out_slot[N], ups_idx_f[n_edges] (either may be NULL)
@@ -642,6 +707,10 @@ struct lf_dist_router {
     lf_dbuf<double> fused_qr1, fused_qr2, slab1, slab2;
     int64_t n_slots = 0, slab_steps = 0, slot_export[2] = {0, 0}, slot_ghost[2] = {0, 0};
     std::vector<int32_t> phase_level; // [nphases + 1] first launch unit of every phase
+    // level blocks + cones of every phase (empty: one launch per unit)
+    std::vector<int> fb_level, fb_row, fb_off;
+    std::vector<int32_t> fb_phase_block;
+    lf_dbuf<int> fb_level_dev, fb_row_dev, fb_off_dev, fb_cone;
 };
 
 namespace {
@@ -790,6 +859,20 @@ int lf_dist_router_create(const lf_dist_graph *g, const double *alpha, double be
     if (rc != LF_OK) {
         delete r;
         return rc;
+    }
+    if (!g->fplan_phase_block.empty()) {
+        rc = r->fb_level_dev.upload(g->fplan.level.data(), g->fplan.level.size());
+        if (rc == LF_OK) rc = r->fb_row_dev.upload(g->fplan.row.data(), g->fplan.row.size());
+        if (rc == LF_OK) rc = r->fb_off_dev.upload(g->fplan.off.data(), g->fplan.off.size());
+        if (rc == LF_OK) rc = r->fb_cone.upload(g->fplan.cone.data(), g->fplan.cone.size());
+        if (rc != LF_OK) {
+            delete r;
+            return rc;
+        }
+        r->fb_level = g->fplan.level;
+        r->fb_row = g->fplan.row;
+        r->fb_off = g->fplan.off;
+        r->fb_phase_block = g->fplan_phase_block;
     }
     r->n_slots = g->n_slots;
     for (int side = 0; side < 2; ++side) {
@@ -995,9 +1078,15 @@ __global__ void __launch_bounds__(kBlock) k_fused_substeps_dist(fused_args F, di
         s = blockIdx.y;
         blk = blockIdx.x;
     }
-    int k = F.t - s;
-    if (k < 0 || k >= D.nunits) return;
-    k += D.unit0;
+    int k;
+    if (F.use_lvl) { // beside k_fused_cones: the single (wide) level sub-step s works on at this wave time, -1 none
+        k = F.lvl[s];
+        if (k < 0) return;
+    } else {
+        k = F.t - s;
+        if (k < 0 || k >= D.nunits) return;
+        k += D.unit0;
+    }
     const long long first = F.level_start[k];
     const long long i = (long long)blk * kBlock + threadIdx.x;
     if (i >= F.level_start[k + 1] - first) return;
@@ -1093,6 +1182,76 @@ int dist_fused_phase(lf_dist_router *r, const lf_substep_args *a, int nsteps, in
     D.unit0 = unit0;
     D.nunits = nunits;
     hipStream_t s = r->ctx->stream;
+    F.d_ups_base = D.ups_base;
+    F.d_ups_idx = D.ups_idx;
+    F.d_out_slot = D.out_slot;
+    if (!r->fb_phase_block.empty() && nsteps <= kMaxPackedSteps) { // blocks of levels, cone by cone (k_fused_cones<DIST>)
+        const int b0 = r->fb_phase_block[phase], NB = r->fb_phase_block[phase + 1] - b0;
+        F.fb_level = r->fb_level_dev.p;
+        F.fb_row = r->fb_row_dev.p;
+        F.fb_cone = r->fb_cone.p;
+        F.fb_off = r->fb_off_dev.p;
+        F.fb_block0 = b0;
+        F.fb_nblocks = NB;
+        auto cones = [&](int b) { return (int64_t)(r->fb_row[b + 1] - r->fb_row[b] - 1); };
+        auto multi = [&](int b) { return r->fb_level[b + 1] - r->fb_level[b] > 1; };
+        const bool all35 = r->fused && a->Beta == 0.6;
+        for (int t = 0; t < NB + nsteps - 1; ++t) {
+            F.t = t;
+            int64_t acc = 0;
+            for (int q = 0; q < nsteps; ++q) {
+                F.blk_start[q] = (int)acc;
+                const int b = t - q;
+                if (b >= 0 && b < NB && multi(b0 + b)) acc += cones(b0 + b);
+            }
+            F.blk_start[nsteps] = (int)acc;
+            if (acc >= ((int64_t)1 << 31)) return lf_set_error(LF_E_INVALID, "fused sub-steps: grid too large");
+            if (acc > 0) {
+                F.packed = 1;
+                F.use_lvl = 0;
+                const dim3 grid((unsigned)acc);
+                if (a->split && all35)
+                    hipLaunchKernelGGL((k_fused_cones<true, true, false, true>), grid, dim3(kBlock), 0, s, F);
+                else if (a->split)
+                    hipLaunchKernelGGL((k_fused_cones<true, false, false, true>), grid, dim3(kBlock), 0, s, F);
+                else if (all35)
+                    hipLaunchKernelGGL((k_fused_cones<false, true, false, true>), grid, dim3(kBlock), 0, s, F);
+                else
+                    hipLaunchKernelGGL((k_fused_cones<false, false, false, true>), grid, dim3(kBlock), 0, s, F);
+                r->last_launches++;
+            }
+            int64_t acc1 = 0, widest = 0;
+            for (int q = 0; q < nsteps; ++q) {
+                F.blk_start[q] = (int)acc1;
+                F.lvl[q] = -1;
+                const int b = t - q;
+                if (b >= 0 && b < NB && !multi(b0 + b)) {
+                    const int k = r->fb_level[b0 + b];
+                    const int64_t w = r->h_level_start[k + 1] - r->h_level_start[k];
+                    F.lvl[q] = k;
+                    acc1 += blocks_for(w);
+                    widest = std::max(widest, w);
+                }
+            }
+            F.blk_start[nsteps] = (int)acc1;
+            if (acc1 > 0) {
+                F.use_lvl = 1;
+                F.packed = 0;
+                dim3 grid(blocks_for(widest), nsteps);
+                if (2 * acc1 <= (int64_t)blocks_for(widest) * nsteps && acc1 < ((int64_t)1 << 31)) {
+                    F.packed = 1;
+                    grid = dim3((unsigned)acc1, 1);
+                }
+                if (a->split)
+                    hipLaunchKernelGGL((k_fused_substeps_dist<true>), grid, dim3(kBlock), 0, s, F, D);
+                else
+                    hipLaunchKernelGGL((k_fused_substeps_dist<false>), grid, dim3(kBlock), 0, s, F, D);
+                r->last_launches++;
+            }
+        }
+        LF_HIP(hipGetLastError());
+        return LF_OK;
+    }
     auto width = [&](int k) { return r->h_level_start[unit0 + k + 1] - r->h_level_start[unit0 + k]; };
     for (int t = 0; t < nunits + nsteps - 1; ++t) {
         const int k_lo = std::max(0, t - nsteps + 1), k_hi = std::min(nunits - 1, t);

@@ -38,6 +38,11 @@ struct fused_args {
     const int *__restrict__ fb_off; // first entry of block b in fb_cone (rows of fb_level[b+1] - fb_level[b] starts)
     const int *__restrict__ fb_lvl2blk; // block of every level
     int fb_nblocks;
+    int fb_block0; // first block of this wavefront (row-block partition: the blocks of one phase), else 0
+    // row-block partition (DIST kernels): first upstream position when the upstream cells are a consecutive local run,
+    // the upstream lists (same-phase position, or -(slab slot) - 1) behind ups_ptr, the slab slot of a cell's own
+    // router outputs (-1 none); the slabs are root1 / root2
+    const int *__restrict__ d_ups_base, *__restrict__ d_ups_idx, *__restrict__ d_out_slot;
     // k_fused_substeps beside k_fused_cones: the level of sub-step s at this wave time (-1: none) instead of t - s
     int use_lvl;
     int lvl[kMaxPackedSteps];
@@ -305,18 +310,24 @@ struct cone_cell { // what a cell's load phase leaves in registers: loaded value
     // STRUCT: the terms of the sideflow assembly (routing.py:462-478), as k_inloop_dense / fused_cell read them
     double eva, wuse, qin_old, qdelta, qin_added_old, transcum, lakeout, resout, polder;
     int u0, u1;
+    int base, slot; // DIST: consecutive local run of upstream cells (else -1: the list ups_idx[u0 .. u1)); slab slot
     unsigned char chan_raw, inert_raw, uptrans_raw, cut_raw;
     bool active;
 };
 
-template <bool SPLIT, bool STRUCT>
+template <bool SPLIT, bool STRUCT, bool DIST = false>
 __device__ __forceinline__ void cone_load(const fused_args &F, long long p, int s, bool active, cone_cell &R)
 {
     const lf_substep_args &A = F.S;
     R.active = active;
+    R.base = R.slot = -1;
     if (!active) return;
     R.u0 = F.ups_ptr[p];
     R.u1 = F.ups_ptr[p + 1];
+    if (DIST) {
+        R.base = F.d_ups_base[p];
+        R.slot = F.d_out_slot[p];
+    }
     R.dxp = F.dx ? F.dx[p] : F.dx_scalar;
     R.inv_len = A.InvChanLength[p];
     R.len = A.ChanLength[p];
@@ -570,7 +581,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 #ifndef LF_CONES_WAVES
 #define LF_CONES_WAVES 2
 #endif
-template <bool SPLIT, bool ALL35, bool STRUCT>
+template <bool SPLIT, bool ALL35, bool STRUCT, bool DIST = false>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(LF_CONES_WAVES))) k_fused_cones(fused_args F)
 {
     __shared__ double x1[2][kBlock], x2[SPLIT ? 2 : 1][SPLIT ? kBlock : 1];
@@ -588,8 +599,9 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(LF_
         s = blockIdx.y;
         blk = blockIdx.x;
     }
-    const int b = F.t - s;
-    if (b < 0 || b >= F.fb_nblocks) return;
+    const int bi = F.t - s;
+    if (bi < 0 || bi >= F.fb_nblocks) return;
+    const int b = F.fb_block0 + bi;
     // the plan is read through the constant address space: scalar loads, no vector-memory wait on the way (ld_table)
     const int row0 = ld_table(F.fb_row, b), ncones = ld_table(F.fb_row, b + 1) - row0 - 1;
     if (blk >= ncones) return;
@@ -623,20 +635,55 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(LF_
         int nfirst = 0;
         if (j + 1 < nl) { // nothing of the next level's state depends on this launch
             nfirst = ld_table(c0, j + 1);
-            cone_load<SPLIT, STRUCT>(F, nfirst + tid, s, nfirst + tid < ld_table(c1, j + 1), nxt);
+            cone_load<SPLIT, STRUCT, DIST>(F, nfirst + tid, s, nfirst + tid < ld_table(c1, j + 1), nxt);
         }
         if (!cone_skip<SPLIT>(cur)) {
             double ups1, ups2 = 0.0;
-            if (j == 0) { // from the block before (previous launch) through the parity buffers
-                ups1 = upstream_sum8(F.qr1 + par, cur.u0, cur.u1, kmax);
-                if (SPLIT) ups2 = upstream_sum8(F.qr2 + par, cur.u0, cur.u1, kmax);
-            } else { // from LDS, branch-free: absent neighbours read slot 0 and add +0.0 (the sum as upstream_sum8)
+            // row-block partition: the upstream cells are the consecutive local run [base, base + count) -- a run of ghost
+            // slots is not one, see k_fused_substeps_dist -- or come from the list: same-phase cells (level before: LDS,
+            // or the parity buffers for the block's first level) and slab slots (earlier phases, other ranks)
+            const int cu0 = DIST ? cur.base : cur.u0, cu1 = DIST ? cur.base + (cur.u1 - cur.u0) : cur.u1;
+            if (DIST && (cur.base < 0 || (long long)cu1 > F.n)) {
                 const double *y1 = &x1[(j - 1) & 1][0], *y2 = &x2[SPLIT ? (j - 1) & 1 : 0][0];
-                const int base = cur.u0 - first_up;
+                const long long soff = (long long)s * F.root_st;
                 double v1[8], v2[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    const bool have = k < kmax && cur.u0 + k < cur.u1;
+                    double a1 = 0.0, a2 = 0.0;
+                    if (k < kmax && cur.u0 + k < cur.u1) {
+                        const int e = F.d_ups_idx[cur.u0 + k];
+                        if (e < 0) {
+                            const long long at = (long long)(-(e + 1)) * F.root_ss + soff;
+                            a1 = F.root1[at];
+                            if (SPLIT) a2 = F.root2[at];
+                        } else if (j == 0) {
+                            a1 = F.qr1[par + e];
+                            if (SPLIT) a2 = F.qr2[par + e];
+                        } else {
+                            a1 = y1[e - first_up];
+                            if (SPLIT) a2 = y2[e - first_up];
+                        }
+                    }
+                    v1[k] = a1;
+                    v2[k] = a2;
+                }
+                ups1 = 0.0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) ups1 += v1[k];
+                if (SPLIT) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) ups2 += v2[k];
+                }
+            } else if (j == 0) { // from the block before (previous launch) through the parity buffers
+                ups1 = upstream_sum8(F.qr1 + par, cu0, cu1, kmax);
+                if (SPLIT) ups2 = upstream_sum8(F.qr2 + par, cu0, cu1, kmax);
+            } else { // from LDS, branch-free: absent neighbours read slot 0 and add +0.0 (the sum as upstream_sum8)
+                const double *y1 = &x1[(j - 1) & 1][0], *y2 = &x2[SPLIT ? (j - 1) & 1 : 0][0];
+                const int base = cu0 - first_up;
+                double v1[8], v2[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const bool have = k < kmax && cu0 + k < cu1;
                     const int idx = have ? base + k : 0;
                     v1[k] = y1[idx];
                     if (SPLIT) v2[k] = y2[idx];
@@ -653,6 +700,11 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(LF_
             }
             double qr, q2r;
             cone_compute<SPLIT, ALL35, STRUCT>(F, cur, p, s, ups1, ups2, qr, q2r, pend);
+            if (DIST && cur.slot >= 0) { // feeds a later phase or another rank: kept for every sub-step
+                const long long at = (long long)cur.slot * F.root_ss + (long long)s * F.root_st;
+                F.root1[at] = qr;
+                if (SPLIT) F.root2[at] = q2r;
+            }
             if (cur.cut_raw) qr = q2r = 0.0; // zero-length structure links: their router output is stored as 0
             if (j + 1 < nl) {
                 x1[j & 1][tid] = qr;
@@ -670,7 +722,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(LF_
     };
     cone_cell ra, rb;
     int first = ld_table(c0, 0);
-    cone_load<SPLIT, STRUCT>(F, first + tid, s, first + tid < ld_table(c1, 0), ra);
+    cone_load<SPLIT, STRUCT, DIST>(F, first + tid, s, first + tid < ld_table(c1, 0), ra);
     __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): inside the loop the current level's registers are always complete
     for (int j = 0; j < nl; j += 2) {
         first = level(j, ra, rb, first);

@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#include "lf_blocks.h"
 #include "lf_structures.h"
 #include "lf_sweep.h"
 
@@ -554,68 +555,17 @@ static int build_level_blocks(lf_router *r, const lf_graph *g, bool for_route)
     if (const char *e = std::getenv("LF_FUSED_WIDE")) wide = std::atoll(e);
     const int64_t NL = g->NL;
     if (lmax <= 1 || NL < 2 || g->N >= ((int64_t)1 << 31)) return LF_OK;
-    const std::vector<int64_t> &ls = g->level_start;
-    auto width = [&](int64_t k) { return ls[k + 1] - ls[k]; };
-    std::vector<int> level, row(1, 0), cone, off;
-    std::vector<int64_t> st(lmax), en(lmax);
-    // starts of the cone above last-level position `pos` of the block [k0, k0 + nl): st[nl-1] = pos, st[j] = first
-    // upstream position of st[j+1] (the end of level j when st[j+1] is the end of level j+1)
-    auto chain = [&](int k0, int nl, int64_t pos, std::vector<int64_t> &out) {
-        out[nl - 1] = pos;
-        for (int j = nl - 2; j >= 0; --j) {
-            pos = (pos < ls[k0 + j + 2]) ? (int64_t)g->ups_ptr[pos] : ls[k0 + j + 1];
-            out[j] = pos;
-        }
-    };
-    bool any = false;
+    lf_block_plan plan;
     try {
-        for (int64_t k = 0; k < NL;) {
-            int nl = 1;
-            if (width(k) <= wide)
-                while (k + nl < NL && nl < lmax && width(k + nl) <= wide) ++nl;
-            std::vector<int> rows; // starts, nl per cone, then the closing row
-            for (;; --nl) {        // shrink until every cone fits a workgroup
-                rows.clear();
-                const int k0 = (int)k;
-                const int64_t lo = ls[k0 + nl - 1], hi = ls[k0 + nl];
-                bool fits = true;
-                for (int64_t a = lo; a < hi && fits;) {
-                    chain(k0, nl, a, st);
-                    auto ok = [&](int64_t e) { // cone [a, e) of the last level: every level's range <= kBlock?
-                        chain(k0, nl, e, en);
-                        for (int j = 0; j < nl; ++j)
-                            if (en[j] - st[j] > kBlock) return false;
-                        return true;
-                    };
-                    int64_t e = std::min<int64_t>(a + kBlock, hi);
-                    if (!ok(e)) { // largest e in (a, a + kBlock) that fits: the widths grow with e
-                        int64_t good = a, bad = e;
-                        while (bad - good > 1) {
-                            const int64_t mid = good + (bad - good) / 2;
-                            if (ok(mid)) good = mid; else bad = mid;
-                        }
-                        e = good;
-                    }
-                    if (e == a) { // even one cell of the last level has too wide a cone
-                        fits = false;
-                        break;
-                    }
-                    for (int j = 0; j < nl; ++j) rows.push_back((int)st[j]);
-                    a = e;
-                }
-                if (fits || nl == 1) break;
-            }
-            for (int j = 0; j < nl; ++j) rows.push_back((int)ls[k + j + 1]); // closing row: the end of every level
-            level.push_back((int)k);
-            off.push_back((int)cone.size());
-            row.push_back(row.back() + (int)(rows.size() / nl));
-            cone.insert(cone.end(), rows.begin(), rows.end());
-            any = any || nl > 1;
-            k += nl;
-        }
+        // every cell below the last level drains into the next level, so the upstream ranges tile the level before:
+        // the first position draining at or behind `pos` is the first upstream position of `pos`
+        lf_build_level_blocks(g->level_start, 0, NL, lmax, wide, kBlock, [&](int64_t pos) { return (int64_t)g->ups_ptr[pos]; },
+                              plan);
     } catch (const std::bad_alloc &) {
         return lf_set_error(LF_E_INVALID, "out of host memory while building the level blocks");
     }
+    const bool any = plan.any_multi;
+    std::vector<int> &level = plan.level, &row = plan.row, &cone = plan.cone, &off = plan.off;
     if (!any || cone.size() >= ((size_t)1 << 31)) return LF_OK;
     level.push_back((int)NL);
     if (for_route) {
@@ -1374,6 +1324,8 @@ int fused_impl(lf_router *r, const lf_substep_args *a, int nsteps, int64_t sidef
     F.fb_off = nullptr;
     F.fb_lvl2blk = nullptr;
     F.fb_nblocks = 0;
+    F.fb_block0 = 0;
+    F.d_ups_base = F.d_ups_idx = F.d_out_slot = nullptr;
     F.use_lvl = 0;
     std::memset(&F.I, 0, sizeof(F.I));
     hipStream_t s = r->ctx->stream;
