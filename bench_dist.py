@@ -132,6 +132,48 @@ def catchment_leg(a, T, rank, world, device):
     return out
 
 
+def row_block_model_step(a, T, rank, world, device, graph, comm, N, i0, i1, nsteps=24, reps=2):
+    """lf_dist_routing_substeps_fused on this rank's row block: NoRoutSteps = 24, split routing (2 router calls per
+    sub-step = 48 cell-steps per cell and model step)."""
+    from lisflood_amd import _lib
+    from lisflood_amd import dist as D
+    from lisflood_amd import synthetic as syn
+    err = None
+    try:
+        ps = syn.router_params_slice(N, i0, i1)
+        vals, dtr = syn.model_step_values_slice(N, i0, i1, ps)
+        router = D.DistRouter(graph, ps["alpha"], ps["beta"], ps["dx"], dtr, alpha_floodplains=vals["ChannelAlpha2"],
+                              device=device, comm=comm, rank_top=rank - 1 if rank > 0 else -1,
+                              rank_bottom=rank + 1 if rank + 1 < world else -1)
+        st = D.DistRoutingStep(router, vals, True, ps["beta"], 1.0 / dtr, dtr * nsteps)
+        del vals, ps
+    except Exception as e:
+        err = repr(e)
+    if int(T.allreduce(0 if err else 1, "min")) == 0:       # all ranks take the same branch (RCCL calls must pair up)
+        return {"error": err or "set-up failed on another rank"}
+    st.substeps_fused(nsteps)                                 # warm-up (allocates the slabs)
+    _lib.synchronize(device)
+    T.barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        st.substeps_fused(nsteps)
+    _lib.synchronize(device)
+    dt_local = time.perf_counter() - t0
+    T.barrier()
+    ms = float(T.allreduce(dt_local, "max")) * 1e3 / reps
+    q = st.download("ChanQ")
+    chk = T.allreduce(np.array([float(q.sum()), float(np.isfinite(q).all() and (q >= 0).all())]), "sum")
+    launches = int(T.allreduce(int(router.last_launches()), "max"))
+    st.free()
+    router.close()
+    return {"ms_per_model_step": round(ms, 3), "value": round(2 * nsteps * N / ms / 1e3, 2), "unit": "Mcell-steps/s",
+            "max_launches_per_model_step": launches, "halo_exchanges_per_model_step": graph.num_phases - 1,
+            "checksum_sumChanQ": float(chk[0]), "finite": bool(chk[1] == world),
+            "note": "lf_dist_routing_substeps_fused: per phase one wavefront over (level block, sub-step), slabs "
+                    "[slot][sub-step] for what crosses a phase or rank boundary, one RCCL Send/Recv block per phase, "
+                    "neighbour and section"}
+
+
 def main(a):
     from lisflood_amd import _lib
     from lisflood_amd import dist as D
@@ -192,6 +234,14 @@ def main(a):
     Qh = router.download_pix(Q)
     chk = T.allreduce(np.array([float(Qh.sum()), float(np.isfinite(Qh).all() and (Qh >= 0).all())]), "sum")
     launches = int(T.allreduce(int(router.last_launches()), "max"))
+    # configs[4]'s workload shape on the SAME row blocks: a model step of 24 split-routing sub-steps, every sub-step of a
+    # phase as one wavefront (level blocks + cones), ONE RCCL halo block per phase and model step
+    row_step = None
+    if not getattr(a, "no_extra", False):
+        try:
+            row_step = row_block_model_step(a, T, rank, world, device, graph, comm, N, i0, i1)
+        except Exception as e:
+            row_step = {"error": repr(e)}
     # secondary: the same raster partitioned by whole catchments -- no exchange, every rank runs the single-GPU engine
     catch = None
     if not getattr(a, "no_extra", False):
@@ -222,6 +272,8 @@ def main(a):
                          "traffic": None},
             "checksum_sumQ": float(chk[0]), "finite": bool(chk[1] == world),
         }
+        if row_step is not None:
+            out["model_step_24_substeps_split_row_blocks"] = row_step
         if catch is not None:
             out["catchment_partition"] = catch
     T.barrier()

@@ -263,6 +263,13 @@ int lf_catchments(lf_router *r, const int64_t *points_host, int64_t *labels_host
  * the total of w over its whole tree (routing.py:483-499, 645-691; equal to rounding, the summation order differs) */
 int lf_catchment_totals_device(lf_router *r, const double *w_pix_dev, double *out_pix_dev);
 int lf_catchment_totals_host(lf_router *r, const double *w_host, double *out_host);
+/* nv (<= 4) weight vectors in ONE sweep (the mass-balance terms of routing.py:645-691 come several at a time): the
+ * device form is asynchronous on the library stream and, after a router's first call (which finds every cell's outlet
+ * once, by pointer jumping), neither allocates nor synchronises; the host form takes nv vectors of N doubles back to
+ * back.  accuflux runs on the router's block plan (blocks of levels cone by cone), like a router call. */
+int lf_catchment_totals_multi_device(lf_router *r, int nv, const double *const *w_pix_dev, double *const *out_pix_dev);
+int lf_catchment_totals_multi_host(lf_router *r, int nv, const double *w_host, double *out_host);
+int lf_accuflux_ordered_multi_device(lf_router *r, int nv, const double *const *x_ord_dev, double *const *acc_ord_dev);
 
 /* ---------------------------------------------------------------------------------------------
  * soil: replaces interception_water_balance (soilloop.py:27-70) and soilColumnsWaterBalance

@@ -24,10 +24,14 @@ struct lf_router_view {
     int64_t trunk_first;                     // component layout: first tier >= 1 position, else N
     const int32_t *t_ptr, *t_idx;
     int32_t **parent_slot;                   // lazily built parent array, owned by the router
+    int32_t **root_slot;                     // lazily built outlet-of-every-cell array, owned by the router
 };
 int lf_router_view_of(lf_router *r, lf_router_view *v);
 int lf_router_alloc_parent(lf_router *r);    // allocates *parent_slot (N int32)
+int lf_router_alloc_root(lf_router *r);      // allocates *root_slot (N int32)
+int lf_router_totals_scratch(lf_router *r, size_t count, double **p);
 int lf_accuflux_ordered_device(lf_router *r, const double *x_ord_dev, double *acc_ord_dev);
+int lf_accuflux_ordered_multi_device(lf_router *r, int nv, const double *const *x_ord_dev, double *const *acc_ord_dev);
 
 namespace {
 
@@ -139,6 +143,29 @@ __global__ void __launch_bounds__(kBlock) k_take_root(long long n, const int *__
     const long long p = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (p >= n) return;
     out_pix[perm[p]] = acc_ord[jump[p]];
+}
+
+constexpr int kMaxTotals = 4;
+struct totals_multi {
+    const double *w_pix[kMaxTotals];
+    double *w_ord[kMaxTotals];
+    const double *acc_ord[kMaxTotals];
+    double *out_pix[kMaxTotals];
+};
+__global__ void __launch_bounds__(kBlock) k_totals_gather(long long n, int nv, const int *__restrict__ perm, totals_multi T)
+{
+    const long long p = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (p >= n) return;
+    const int pix = perm[p];
+    for (int v = 0; v < nv; ++v) T.w_ord[v][p] = T.w_pix[v][pix];
+}
+__global__ void __launch_bounds__(kBlock) k_totals_take(long long n, int nv, const int *__restrict__ perm,
+                                                        const int *__restrict__ root, totals_multi T)
+{
+    const long long p = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (p >= n) return;
+    const int pix = perm[p], o = root[p];
+    for (int v = 0; v < nv; ++v) T.out_pix[v][pix] = T.acc_ord[v][o];
 }
 
 int ensure_parent(lf_router *r, lf_router_view *V)
@@ -299,41 +326,78 @@ int lf_catchments(lf_router *r, const int64_t *points_host, int64_t *labels_host
 // 483-499): every cell gets the total of w over its whole tree.  accuflux carries the tree's total to its outlet
 // (upstream first, then the cell: not np.bincount's ascending-pixel order -- equal to rounding, not to the bit), every
 // cell then reads the outlet its walk downstream ends in.  Device vectors in pixel order.
-int lf_catchment_totals_device(lf_router *r, const double *w_pix_dev, double *out_pix_dev)
+int lf_catchment_totals_multi_device(lf_router *r, int nv, const double *const *w_pix_dev, double *const *out_pix_dev)
 {
-    if (!r || !w_pix_dev || !out_pix_dev) return lf_set_error(LF_E_INVALID, "null argument");
+    if (!r || !w_pix_dev || !out_pix_dev || nv < 1 || nv > kMaxTotals) return lf_set_error(LF_E_INVALID, "bad argument");
+    for (int v = 0; v < nv; ++v)
+        if (!w_pix_dev[v] || !out_pix_dev[v]) return lf_set_error(LF_E_INVALID, "null argument");
     lf_router_view V;
     LF_TRY(ensure_parent(r, &V));
     const int64_t n = V.N;
     if (n == 0) return LF_OK;
     hipStream_t s = V.ctx->stream;
-    lf_dbuf<double> w_ord, acc;
-    LF_TRY(w_ord.alloc((size_t)n));
-    LF_TRY(acc.alloc((size_t)n));
-    LF_TRY(lf_router_to_engine_order(r, w_pix_dev, w_ord.p));
-    LF_TRY(lf_accuflux_ordered_device(r, w_ord.p, acc.p));
-    lf_dbuf<int> a, b;
-    int *jump = nullptr;
-    LF_TRY(converge_jumps(V, nullptr, a, b, &jump));
-    hipLaunchKernelGGL(k_take_root, dim3(blocks_for(n)), dim3(kBlock), 0, s, (long long)n, V.perm, jump, acc.p, out_pix_dev);
+    if (!*V.root_slot) { // once per router: the outlet of every cell, by pointer jumping (the only synchronising part)
+        lf_dbuf<int> a, b;
+        int *jump = nullptr;
+        LF_TRY(converge_jumps(V, nullptr, a, b, &jump));
+        LF_TRY(lf_router_alloc_root(r));
+        LF_TRY(lf_router_view_of(r, &V));
+        LF_HIP(hipMemcpyAsync(*V.root_slot, jump, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, s));
+        LF_HIP(hipStreamSynchronize(s)); // a, b go out of scope
+    }
+    double *scratch = nullptr;
+    LF_TRY(lf_router_totals_scratch(r, (size_t)(2 * nv) * (size_t)n, &scratch));
+    totals_multi T;
+    const double *x[kMaxTotals];
+    double *acc[kMaxTotals];
+    for (int v = 0; v < kMaxTotals; ++v) {
+        const int u = v < nv ? v : 0;
+        T.w_pix[v] = w_pix_dev[u];
+        T.out_pix[v] = out_pix_dev[u];
+        T.w_ord[v] = scratch + (size_t)(2 * u) * (size_t)n;
+        T.acc_ord[v] = acc[v] = scratch + (size_t)(2 * u + 1) * (size_t)n;
+        x[v] = T.w_ord[v];
+    }
+    hipLaunchKernelGGL(k_totals_gather, dim3(blocks_for(n)), dim3(kBlock), 0, s, (long long)n, nv, V.perm, T);
+    LF_TRY(lf_accuflux_ordered_multi_device(r, nv, x, acc));
+    hipLaunchKernelGGL(k_totals_take, dim3(blocks_for(n)), dim3(kBlock), 0, s, (long long)n, nv, V.perm, *V.root_slot, T);
     LF_HIP(hipGetLastError());
-    LF_HIP(hipStreamSynchronize(s));
+    return LF_OK; // asynchronous on the library stream: no allocation, no synchronisation after the first call
+}
+
+int lf_catchment_totals_device(lf_router *r, const double *w_pix_dev, double *out_pix_dev)
+{
+    const double *w[1] = {w_pix_dev};
+    double *o[1] = {out_pix_dev};
+    return lf_catchment_totals_multi_device(r, 1, w, o);
+}
+
+// nv vectors of N doubles back to back, host memory
+int lf_catchment_totals_multi_host(lf_router *r, int nv, const double *w_host, double *out_host)
+{
+    if (!r || !w_host || !out_host || nv < 1 || nv > kMaxTotals) return lf_set_error(LF_E_INVALID, "bad argument");
+    lf_router_view V;
+    LF_TRY(lf_router_view_of(r, &V));
+    const size_t n = (size_t)V.N;
+    if (n == 0) return LF_OK;
+    lf_dbuf<double> a, b;
+    LF_TRY(a.upload(w_host, n * (size_t)nv, V.ctx->stream));
+    LF_TRY(b.alloc(n * (size_t)nv));
+    const double *w[kMaxTotals];
+    double *o[kMaxTotals];
+    for (int v = 0; v < nv; ++v) {
+        w[v] = a.p + (size_t)v * n;
+        o[v] = b.p + (size_t)v * n;
+    }
+    LF_TRY(lf_catchment_totals_multi_device(r, nv, w, o));
+    LF_HIP(hipMemcpyAsync(out_host, b.p, sizeof(double) * n * (size_t)nv, hipMemcpyDeviceToHost, V.ctx->stream));
+    LF_HIP(hipStreamSynchronize(V.ctx->stream));
     return LF_OK;
 }
 
 int lf_catchment_totals_host(lf_router *r, const double *w_host, double *out_host)
 {
-    if (!r || !w_host || !out_host) return lf_set_error(LF_E_INVALID, "null argument");
-    lf_router_view V;
-    LF_TRY(lf_router_view_of(r, &V));
-    if (V.N == 0) return LF_OK;
-    lf_dbuf<double> a, b;
-    LF_TRY(a.upload(w_host, (size_t)V.N, V.ctx->stream));
-    LF_TRY(b.alloc((size_t)V.N));
-    LF_TRY(lf_catchment_totals_device(r, a.p, b.p));
-    LF_HIP(hipMemcpyAsync(out_host, b.p, sizeof(double) * (size_t)V.N, hipMemcpyDeviceToHost, V.ctx->stream));
-    LF_HIP(hipStreamSynchronize(V.ctx->stream));
-    return LF_OK;
+    return lf_catchment_totals_multi_host(r, 1, w_host, out_host);
 }
 
 } // extern "C"

@@ -96,31 +96,116 @@ __global__ void __launch_bounds__(64) k_comp_accu(int bin0, comp_args C, const i
     }
 }
 
-// accuflux: acc[p] = x[p] + sum over upstream acc (upstream first, ascending pixel id, then the cell itself)
-__global__ void __launch_bounds__(kBlock) k_accu_level(int first, int count, const int *__restrict__ ups_ptr,
-                                                       const double *__restrict__ x_ord, double *acc)
+// accuflux: acc[p] = x[p] + sum over upstream acc (upstream first, ascending pixel id, then the cell itself); up to
+// kMaxAccu vectors share a sweep (the catchment totals of routing.py:645-691 come four at a time)
+constexpr int kMaxAccu = 4;
+struct accu_multi {
+    const double *x[kMaxAccu];
+    double *acc[kMaxAccu];
+};
+
+template <int NV>
+__global__ void __launch_bounds__(kBlock) k_accu_level(int first, int count, const int *__restrict__ ups_ptr, accu_multi M)
 {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= count) return;
     const int p = first + i;
-    double s = 0.0;
-    for (int e = ups_ptr[p]; e < ups_ptr[p + 1]; ++e) s += acc[e];
-    acc[p] = s + x_ord[p];
+    const int u0 = ups_ptr[p], u1 = ups_ptr[p + 1];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        double s = 0.0;
+        for (int e = u0; e < u1; ++e) s += M.acc[v][e];
+        M.acc[v][p] = s + M.x[v][p];
+    }
 }
 
+template <int NV>
 __global__ void __launch_bounds__(kNarrowBlock) k_accu_narrow(int k0, int k1, const long long *__restrict__ level_start,
-                                                              const int *__restrict__ ups_ptr,
-                                                              const double *__restrict__ x_ord, double *acc)
+                                                              const int *__restrict__ ups_ptr, accu_multi M)
 {
     for (int k = k0; k < k1; ++k) {
         const int first = (int)level_start[k], last = (int)level_start[k + 1];
         for (int p = first + (int)threadIdx.x; p < last; p += kNarrowBlock) {
-            double s = 0.0;
-            for (int e = ups_ptr[p]; e < ups_ptr[p + 1]; ++e) s += acc[e];
-            acc[p] = s + x_ord[p];
+            const int u0 = ups_ptr[p], u1 = ups_ptr[p + 1];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                double s = 0.0;
+                for (int e = u0; e < u1; ++e) s += M.acc[v][e];
+                M.acc[v][p] = s + M.x[v][p];
+            }
         }
         __threadfence_block();
         __syncthreads();
+    }
+}
+
+// One block of consecutive levels of the router's plan (build_level_blocks, the plan of k_sweep_cones), cone by cone:
+// the sums travel to the next level through LDS, the operands of the next level's cell are loaded before the current
+// level is added up.  Same additions in the same order as k_accu_level.
+template <int NV>
+__global__ void __launch_bounds__(kBlock) k_accu_cones(cone_plan_args C, const int *__restrict__ ups_ptr, accu_multi M)
+{
+    __shared__ double y[NV][2][kBlock];
+    const int tid = threadIdx.x, nl = C.nl;
+    const int *c0 = C.cone + (size_t)blockIdx.x * nl, *c1 = c0 + nl;
+    struct cell {
+        int u0, u1;
+        double x[NV];
+        bool active;
+    };
+    auto load = [&](int p, bool active, cell &R) {
+        R.active = active;
+        if (!active) return;
+        R.u0 = ups_ptr[p];
+        R.u1 = ups_ptr[p + 1];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) R.x[v] = M.x[v][p];
+    };
+    int first_up = 0;
+    auto level = [&](int j, const cell &cur, cell &nxt, int first) {
+        const int p = first + tid;
+        int nfirst = 0;
+        if (j + 1 < nl) {
+            nfirst = ld_table(c0, j + 1);
+            load(nfirst + tid, nfirst + tid < ld_table(c1, j + 1), nxt);
+        }
+        if (j > 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (cur.active) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                double t[8];
+                if (j == 0) { // from the block before (previous launch)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) t[k] = (cur.u0 + k < cur.u1) ? M.acc[v][cur.u0 + k] : 0.0;
+                } else {
+                    const double *z = &y[v][(j - 1) & 1][0];
+                    const int base = cur.u0 - first_up;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const bool have = cur.u0 + k < cur.u1;
+                        const double w = z[have ? base + k : 0];
+                        t[k] = have ? w : 0.0;
+                    }
+                }
+                double sum = 0.0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) sum += t[k];
+                const double a = sum + cur.x[v];
+                M.acc[v][p] = a;
+                if (j + 1 < nl) y[v][j & 1][tid] = a;
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the next level's operands are in
+        first_up = first;
+        return nfirst;
+    };
+    cell ra, rb;
+    int first = ld_table(c0, 0);
+    load(first + tid, first + tid < ld_table(c1, 0), ra);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    for (int j = 0; j < nl; j += 2) {
+        first = level(j, ra, rb, first);
+        if (j + 1 < nl) first = level(j + 1, rb, ra, first);
     }
 }
 
@@ -172,6 +257,8 @@ struct lf_router {
     lf_dbuf<unsigned long long> counter;
     lf_dbuf<uint8_t> linked; // zero-length structure links (lf_graph_create_ex); null without them
     lf_dbuf<int32_t> parent; // [N] downstream position of every position, -1 = outlet (lf_ldd.hip builds it on demand)
+    lf_dbuf<int32_t> root;   // [N] position of the outlet every position drains to (lf_ldd.hip, on demand: catchment totals)
+    lf_dbuf<double> totals_scratch; // catchment totals: engine-order copies of the weights and their accuflux
     lf_dbuf<uint8_t> isolated; // [N] by position: 1 = no upstream and no downstream cell (e.g. non-channel land pixels)
     lf_dbuf<uint8_t> inert;    // [N] per fused call: isolated, not a channel, zero split-routing thresholds
     int64_t n_isolated = 0;
@@ -944,10 +1031,14 @@ int lf_upstream_sum_host(lf_router *r, const double *w_host, double *out_host)
     return LF_OK;
 }
 
-// accuflux over engine-order device vectors: acc[p] = x[p] + sum of acc over the upstream cells
-int lf_accuflux_ordered_device(lf_router *r, const double *x_ord_dev, double *acc_ord_dev)
+// accuflux over engine-order device vectors: acc[p] = x[p] + sum of acc over the upstream cells; nv (<= 4) vectors in
+// one sweep.  On the level layout it runs on the router's block plan (blocks of up to 64 levels cone by cone through
+// LDS, single wide levels one launch each), like a router call.
+int lf_accuflux_ordered_multi_device(lf_router *r, int nv, const double *const *x_ord_dev, double *const *acc_ord_dev)
 {
-    if (!r || !x_ord_dev || !acc_ord_dev) return lf_set_error(LF_E_INVALID, "null argument");
+    if (!r || !x_ord_dev || !acc_ord_dev || nv < 1 || nv > kMaxAccu) return lf_set_error(LF_E_INVALID, "bad argument");
+    for (int v = 0; v < nv; ++v)
+        if (!x_ord_dev[v] || !acc_ord_dev[v]) return lf_set_error(LF_E_INVALID, "null argument");
     if (r->linked.p) return lf_set_error(LF_E_INVALID, "accuflux is not defined on a graph with structure links");
     LF_HIP(hipSetDevice(r->device));
     hipStream_t s = r->ctx->stream;
@@ -961,30 +1052,78 @@ int lf_accuflux_ordered_device(lf_router *r, const double *x_ord_dev, double *ac
         C.t_idx = r->c_t_idx.p;
         C.trunk_first = (int)r->c_trunk_first;
         const int T = (int)r->c_tier_bin_start.size() - 1;
-        for (int t = 0; t < T; ++t) {
-            const int b0 = r->c_tier_bin_start[t], nb = r->c_tier_bin_start[t + 1] - b0;
-            if (nb <= 0) continue;
-            if (t == 0)
-                hipLaunchKernelGGL(k_comp_accu<false>, dim3(nb), dim3(64), 0, s, b0, C, r->ups_ptr.p, x_ord_dev, acc_ord_dev);
-            else
-                hipLaunchKernelGGL(k_comp_accu<true>, dim3(nb), dim3(64), 0, s, b0, C, r->ups_ptr.p, x_ord_dev, acc_ord_dev);
-        }
-    }
-    for (const segment &g : r->schedule) {
-        if (g.wide) {
-            for (int k = g.k0; k < g.k1; ++k) {
-                const int first = (int)r->h_level_start[k];
-                const int count = (int)(r->h_level_start[k + 1] - r->h_level_start[k]);
-                hipLaunchKernelGGL(k_accu_level, dim3(blocks_for(count)), dim3(kBlock), 0, s, first, count, r->ups_ptr.p,
-                                   x_ord_dev, acc_ord_dev);
+        for (int v = 0; v < nv; ++v)
+            for (int t = 0; t < T; ++t) {
+                const int b0 = r->c_tier_bin_start[t], nb = r->c_tier_bin_start[t + 1] - b0;
+                if (nb <= 0) continue;
+                if (t == 0)
+                    hipLaunchKernelGGL(k_comp_accu<false>, dim3(nb), dim3(64), 0, s, b0, C, r->ups_ptr.p, x_ord_dev[v],
+                                       acc_ord_dev[v]);
+                else
+                    hipLaunchKernelGGL(k_comp_accu<true>, dim3(nb), dim3(64), 0, s, b0, C, r->ups_ptr.p, x_ord_dev[v],
+                                       acc_ord_dev[v]);
             }
-        } else {
-            hipLaunchKernelGGL(k_accu_narrow, dim3(1), dim3(kNarrowBlock), 0, s, g.k0, g.k1, r->level_start.p,
-                               r->ups_ptr.p, x_ord_dev, acc_ord_dev);
+        LF_HIP(hipGetLastError());
+        return LF_OK;
+    }
+    accu_multi M;
+    for (int v = 0; v < kMaxAccu; ++v) {
+        M.x[v] = x_ord_dev[v < nv ? v : 0];
+        M.acc[v] = acc_ord_dev[v < nv ? v : 0];
+    }
+    int64_t launches = 0;
+#define LF_ACCU(KERNEL, GRID, BLOCK, ...)                                                      \
+    do {                                                                                       \
+        if (nv == 1)                                                                           \
+            hipLaunchKernelGGL(KERNEL<1>, GRID, BLOCK, 0, s, __VA_ARGS__);                     \
+        else if (nv == 2)                                                                      \
+            hipLaunchKernelGGL(KERNEL<2>, GRID, BLOCK, 0, s, __VA_ARGS__);                     \
+        else if (nv == 3)                                                                      \
+            hipLaunchKernelGGL(KERNEL<3>, GRID, BLOCK, 0, s, __VA_ARGS__);                     \
+        else                                                                                   \
+            hipLaunchKernelGGL(KERNEL<4>, GRID, BLOCK, 0, s, __VA_ARGS__);                     \
+        ++launches;                                                                            \
+    } while (0)
+    if (r->rb_lmax > 1 && cones_enabled()) {
+        const int NB = (int)r->rb_level.size() - 1;
+        for (int b = 0; b < NB; ++b) {
+            const int k0 = r->rb_level[b], nl = r->rb_level[b + 1] - k0;
+            if (nl > 1) {
+                cone_plan_args C;
+                C.cone = r->rb_cone.p + r->rb_off[b];
+                C.nl = nl;
+                const dim3 grid((unsigned)(r->rb_row[b + 1] - r->rb_row[b] - 1));
+                LF_ACCU(k_accu_cones, grid, dim3(kBlock), C, r->ups_ptr.p, M);
+            } else {
+                const int first = (int)r->h_level_start[k0];
+                const int count = (int)(r->h_level_start[k0 + 1] - r->h_level_start[k0]);
+                LF_ACCU(k_accu_level, dim3(blocks_for(count)), dim3(kBlock), first, count, r->ups_ptr.p, M);
+            }
+        }
+    } else {
+        for (const segment &g : r->schedule) {
+            if (g.wide) {
+                const int first = (int)r->h_level_start[g.k0];
+                const int count = (int)(r->h_level_start[g.k0 + 1] - r->h_level_start[g.k0]);
+                LF_ACCU(k_accu_level, dim3(blocks_for(count)), dim3(kBlock), first, count, r->ups_ptr.p, M);
+            } else {
+                LF_ACCU(k_accu_narrow, dim3(1), dim3(kNarrowBlock), g.k0, g.k1, r->level_start.p, r->ups_ptr.p, M);
+            }
         }
     }
+#undef LF_ACCU
+    r->last_stats[0] = launches;
+    r->last_stats[1] = r->last_stats[2] = 0;
+    r->last_stats[3] = r->NL;
     LF_HIP(hipGetLastError());
     return LF_OK;
+}
+
+int lf_accuflux_ordered_device(lf_router *r, const double *x_ord_dev, double *acc_ord_dev)
+{
+    const double *x[1] = {x_ord_dev};
+    double *acc[1] = {acc_ord_dev};
+    return lf_accuflux_ordered_multi_device(r, 1, x, acc);
 }
 
 int lf_accuflux_host(lf_router *r, const double *x_host, double *out_host)
@@ -1021,6 +1160,7 @@ struct lf_router_view {
     int64_t trunk_first;
     const int32_t *t_ptr, *t_idx;
     int32_t **parent_slot;
+    int32_t **root_slot;
 };
 
 int lf_router_view_of(lf_router *r, lf_router_view *v)
@@ -1038,6 +1178,25 @@ int lf_router_view_of(lf_router *r, lf_router_view *v)
     v->t_ptr = r->c_t_ptr.p;
     v->t_idx = r->c_t_idx.p;
     v->parent_slot = &r->parent.p;
+    v->root_slot = &r->root.p;
+    return LF_OK;
+}
+
+int lf_router_alloc_root(lf_router *r)
+{
+    if (!r) return lf_set_error(LF_E_INVALID, "null argument");
+    return r->root.p ? LF_OK : r->root.alloc((size_t)r->N);
+}
+
+// grow-only scratch of the catchment totals (count doubles)
+int lf_router_totals_scratch(lf_router *r, size_t count, double **p)
+{
+    if (!r || !p) return lf_set_error(LF_E_INVALID, "null argument");
+    if (r->totals_scratch.n < count) {
+        LF_HIP(hipStreamSynchronize(r->ctx->stream));
+        LF_TRY(r->totals_scratch.alloc(count));
+    }
+    *p = r->totals_scratch.p;
     return LF_OK;
 }
 

@@ -41,7 +41,9 @@ def lddmask(codes, land_mask, keep):
     keep = np.asarray(keep, bool)
     down = downstream_index(codes, land_mask)
     out = np.asarray(codes).copy()
-    lost = (down < 0) | ~keep[np.maximum(down, 0)]      # drains off the map / into a missing value / out of `keep`
+    known = np.isin(out, (1, 2, 3, 4, 5, 6, 7, 8, 9))   # any other value is a missing value of the ldd map
+    # drains off the map / into a missing value (incl. a land pixel with an unknown code) / out of `keep`
+    lost = (down < 0) | ~keep[np.maximum(down, 0)] | ~known[np.maximum(down, 0)]
     out[lost & np.isin(out, (1, 2, 3, 4, 6, 7, 8, 9))] = PIT
     sub = land_mask.copy()
     sub[land_mask] = keep
@@ -49,11 +51,15 @@ def lddmask(codes, land_mask, keep):
 
 
 def lddrepair(codes, land_mask):
-    """PCRaster lddrepair: cells draining to a missing value or off the map become pits (routing.py:125)."""
+    """PCRaster lddrepair: cells draining to a missing value or off the map become pits (routing.py:125).  A land pixel
+    whose code is not a keypad code is a missing value of the ldd map: cells draining into it become pits, and -- a
+    compressed vector has no missing values -- so does the pixel itself (the device form does the same).  PCRaster's
+    lddrepair also breaks cycles; here a cyclic LDD is an error when the graph is built (LF_E_CYCLE), never repaired."""
     c = np.asarray(codes).copy()
     down = downstream_index(c, land_mask)
     valid = np.isin(c, (1, 2, 3, 4, 6, 7, 8, 9))
-    c[(down < 0) | ~valid] = PIT
+    known = valid | (c == PIT)
+    c[(down < 0) | ~valid | ~known[np.maximum(down, 0)]] = PIT
     return c
 
 
@@ -209,11 +215,19 @@ class LddDevice:
 
     def catchment_totals(self, w):
         """np.take(np.bincount(Catchments, weights=w), Catchments) for Catchments = catchment(ldd, pit(ldd))"""
+        return self.catchment_totals_multi([w])[0]
+
+    def catchment_totals_multi(self, ws):
+        """the same for several weight vectors at once: one upload, accuflux sweeps of up to four vectors, one download"""
         from ._lib import check, f64, lib, ptr
-        w = f64(np.broadcast_to(w, (self.N,)))
-        out = np.empty(self.N)
-        if self.N:
-            check(lib().lf_catchment_totals_host(self.kw._h, ptr(w), ptr(out)))
+        ws = [np.broadcast_to(np.asarray(w, np.float64), (self.N,)) for w in ws]
+        out = []
+        for i in range(0, len(ws), 4):
+            chunk = f64(np.stack(ws[i:i + 4])) if self.N else np.zeros((len(ws[i:i + 4]), 0))
+            res = np.empty_like(chunk)
+            if self.N:
+                check(lib().lf_catchment_totals_multi_host(self.kw._h, C.c_int(chunk.shape[0]), ptr(chunk), ptr(res)))
+            out.extend(res[k] for k in range(chunk.shape[0]))
         return out
 
     def upstream(self, w):

@@ -307,13 +307,20 @@ class routing(HydroModule):
         if self.options.get("repMBTs"):
             self._mbts_initial()
 
-    def _catchment_totals(self, w):
-        """np.take(np.bincount(Catchments, weights=w), Catchments): totals over the trees of the full LDD, on the device"""
+    def _ldd_device(self):
         d = getattr(self, "_ldd_all", None)
         if d is None:
             from . import ldd as L
             d = self._ldd_all = L.LddDevice(self.var.Ldd, self._land_mask, self.device)
-        return d.catchment_totals(w)
+        return d
+
+    def _catchment_totals(self, w):
+        """np.take(np.bincount(Catchments, weights=w), Catchments): totals over the trees of the full LDD, on the device"""
+        return self._ldd_device().catchment_totals(w)
+
+    def _catchment_totals_multi(self, ws):
+        """several totals in one device pass (lf_catchment_totals_multi_host)"""
+        return self._ldd_device().catchment_totals_multi(ws)
 
     def _mbts_added(self, s, nsub=1, qin=None):
         """AddedTRUN (routing.py:483-499): water added to the channels, summed per catchment and over the sub-steps.
@@ -338,20 +345,29 @@ class routing(HydroModule):
         N = self._nfull
         at_last = np.asarray(v.AtLastPointC).astype(bool)
         avg = v.sumDisDay / v.NoRoutSteps
-        out_step = self._catchment_totals(np.where(at_last, avg, 0.0) * v.DtSec)                          # :649-651
+        # the up to four catchment totals of this block (:649-683) in ONE device pass
+        terms = [np.where(at_last, avg, 0.0) * v.DtSec]                                                   # :649-651
         storage = v.ChanM3Kin + v.Chan2M3Kin - v.Chan2M3Start                                             # :654
         ups = np.asarray(getattr(v, "IsUpsOfStructureKinematicC", np.zeros(N))) > 0
-        r = np.zeros(N)
-        if o.get('simulateReservoirs'):
+        res_on, lakes_on = bool(o.get('simulateReservoirs')), bool(o.get('simulateLakes'))
+        if res_on:
             storage = storage + v.ReservoirStorageM3                                                      # :664
-            r = self._catchment_totals(np.where(ups, v.ChanQ * v.DtRouting, 0.0)) - v.DischargeM3StructuresIni
-        if o.get('simulateLakes'):
+        if lakes_on:
             storage = storage + v.LakeStorageM3Balance                                                    # :672
-            r = self._catchment_totals(np.where(ups, v.ChanQ * v.DtRouting, 0.0))
+        terms.append(storage)
+        if res_on or lakes_on:
+            terms.append(np.where(ups, v.ChanQ * v.DtRouting, 0.0))                                       # :666 / :674
+        if lakes_on:
             lake = np.zeros(N)
             lake[np.asarray(v.LakeIndex)] = 0.5 * np.asarray(v.LakeInflowCC) * v.DtRouting                # :676
-            r = r + self._catchment_totals(lake) - v.DischargeM3StructuresIni
-        storage1 = self._catchment_totals(storage)                                                        # :683
+            terms.append(lake)
+        tot = self._catchment_totals_multi(terms)
+        out_step, storage1 = tot[0], tot[1]                                                               # :651, :683
+        r = np.zeros(N)
+        if lakes_on:                    # (the lake branch overwrites the reservoir one, as in the reference)
+            r = tot[2] + tot[3] - v.DischargeM3StructuresIni                                              # :674-679
+        elif res_on:
+            r = tot[2] - v.DischargeM3StructuresIni                                                       # :666-668
         v.MBErrorSplitRoutingM3 = -storage1 + v.StorageStepINIT - out_step - r + v.AddedTRUN              # :685
         corr = np.where(at_last, v.MBErrorSplitRoutingM3 / v.DtRouting, 0.0)                              # :687-688
         v.OutletDischargeErrorSplitRouting = self._catchment_totals(corr)

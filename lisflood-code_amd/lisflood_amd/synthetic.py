@@ -114,6 +114,25 @@ def lateral_inflow(N, step, seed=4, hi=2e-4):
     return np.random.default_rng(seed + step).uniform(0.0, hi, N)
 
 
+def model_step_values_slice(N, i0, i1, p_slice, seed=17):
+    """Elements [i0, i1) of model_step_values(N, router_params(N), seed)[0] without generating the rest
+    (`p_slice` = router_params_slice(N, i0, i1)): what one rank of a row-block partition needs."""
+    n = i1 - i0
+    beta, dt = p_slice["beta"], 3600.0
+    alpha, length, q0 = p_slice["alpha"], p_slice["dx"], p_slice["Q0"]
+    alpha2 = alpha * (1.2 + (2.0 - 1.2) * _stream_slice(seed, i0, n))
+    qlimit = 2.0 * q0 * (0.3 + (1.2 - 0.3) * _stream_slice(seed, N + i0, n))
+    vals = dict(ChanLength=length, InvChanLength=1 / length, ChannelAlpha=alpha, InvChannelAlpha=1 / alpha,
+                ChannelAlpha2=alpha2, InvChannelAlpha2=1 / alpha2, QLimit=qlimit, M3Limit=alpha * length * qlimit ** beta,
+                Chan2M3Start=alpha2 * length * qlimit ** beta, Chan2QStart=qlimit * 0.1, PixelArea=np.full(n, 2.5e7),
+                IsChannelKinematic=np.ones(n, bool), SideflowChanM3=lateral_inflow_slice(N, 0, i0, i1) * length * dt)
+    vals["Chan2M3Kin"] = vals["Chan2M3Start"].copy()
+    vals["ChanM3Kin"] = alpha * length * q0 ** beta
+    vals["ChanQKin"] = q0.copy()
+    vals["Chan2QKin"] = (vals["Chan2M3Kin"] / length / alpha2) ** (1 / beta)
+    return vals, dt
+
+
 def _stream_slice(seed, offset, count):
     """`count` uniform(0,1) doubles starting at element `offset` of default_rng(seed)'s stream (PCG64 jump-ahead:
     one 64-bit draw per double), so a rank can draw exactly its slice of a global vector."""

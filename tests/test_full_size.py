@@ -169,6 +169,10 @@ def run_config4(amd, oracle, size, tmp_path):
         v.sumDisDay = np.zeros(pix.size)
         for s in range(nsteps):
             sub.dynamic(split=True, sideflow_m3=np.ascontiguousarray(side[step][pix]))
+    # tolerance: the engine's closed-form beta = 3/5 solve and the oracle's Newton iteration agree to ~1e-12 per call
+    # (tests/test_gpu_parity.py holds 1e-9 on single calls and sub-steps); here 2 x 24 sub-steps with two Q -> V -> Q
+    # round trips each feed one another, and the split-routing threshold (routing.py:557-563) amplifies a last-place
+    # difference where the volume sits on it -- 1e-8 after 96 router calls, still 100x inside the 1e-6 bar
     for k in ("ChanQ", "ChanQKin", "Chan2QKin", "ChanM3Kin", "sumDisDay"):
         want = getattr(v, k)
         np.testing.assert_allclose(second[k][pix], want, rtol=1e-8, atol=1e-9 * max(1.0, float(np.abs(want).max())),
@@ -181,7 +185,19 @@ def test_config4_workload_8000(amd, oracle, tmp_path):
     run_config4(amd, oracle, 8000, tmp_path)
 
 
-@pytest.mark.skipif(os.environ.get("LF_FULL_SIZE") != "1", reason="20000^2 needs ~40 GB of host memory and several minutes: "
-                    "LF_FULL_SIZE=1 (run once per round, log under profiles/)")
+def _host_memory_gb():
+    """MemAvailable of /proc/meminfo (falls back to the physical memory)"""
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                return int(line.split()[1]) / 1e6
+    except OSError:
+        pass
+    return os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE") / 1e9
+
+
+@pytest.mark.skipif(_host_memory_gb() < 64 and os.environ.get("LF_FULL_SIZE") != "1",
+                    reason="BASELINE.json configs[4] at its full 20000^2 size needs ~40 GB of host memory (and ~2.5 minutes)")
 def test_config4_workload_20000(amd, oracle, tmp_path):
+    """configs[4] at the size BASELINE.json names, on one GPU (4e8 cells, ~26 GB of device vectors)"""
     run_config4(amd, oracle, 20000, tmp_path)

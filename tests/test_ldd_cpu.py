@@ -62,6 +62,16 @@ def test_lddmask_and_repair_make_pits_at_the_cut():
     bad = codes.copy(); bad[3] = 0; bad[5] = 77
     rep = L.lddrepair(bad, mask)
     assert rep[3] == L.PIT and rep[5] == L.PIT
+    # a land pixel with an unknown code is a missing value of the ldd map: what drains INTO it becomes a pit as well
+    target = int(down_full[down_full >= 0][7])
+    feeders = np.nonzero(down_full == target)[0]
+    bad2 = codes.copy(); bad2[target] = 77
+    rep2 = L.lddrepair(bad2, mask)
+    assert rep2[target] == L.PIT and (rep2[feeders] == L.PIT).all()
+    others = np.setdiff1d(np.arange(N), np.append(feeders, target))
+    assert np.array_equal(rep2[others], L.lddrepair(codes, mask)[others])
+    m2, _ = L.lddmask(bad2, mask, np.ones(N, bool))
+    assert (m2[feeders] == L.PIT).all()
     assert (L.pit(rep) > 0).sum() == (rep == L.PIT).sum() and L.pit(rep).max() == (rep == L.PIT).sum()
 
 

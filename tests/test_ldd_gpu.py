@@ -61,7 +61,40 @@ def test_downstream_catchment_totals_vs_walks(amd, components):
     tot = d.catchment_totals(w)
     want = np.bincount(root, weights=w, minlength=N)[root]                          # routing.py:483-499
     np.testing.assert_allclose(tot, want, rtol=1e-13)
+    # several weight vectors in one sweep (the mass-balance terms of routing.py:645-691): each equals its own call
+    ws = [np.random.default_rng(40 + i).uniform(0, 5, N) for i in range(6)]
+    for a, w1 in zip(d.catchment_totals_multi(ws), ws):
+        assert np.array_equal(a, d.catchment_totals(w1))
     d.close()
+
+
+@pytest.mark.parametrize("family,seed", [("deep", 2), ("river", 7), ("shallow", 1)])
+def test_accuflux_on_level_blocks_equals_the_level_schedule(amd, family, seed, monkeypatch):
+    """accuflux runs on the router's block plan (blocks of up to 64 levels cone by cone through LDS, k_accu_cones): the
+    same additions in the same order as one launch per level (LF_ROUTE_CONES=0) -- bit-identical, and equal to the
+    brute-force sum over every cell's upstream tree"""
+    from lisflood_amd import synthetic as syn
+    from lisflood_amd.kinematic_wave_parallel import Graph, kinematicWave
+    H, W = 700, 600
+    N = H * W
+    codes = syn.make_ldd(family, H, W, seed)
+    kw = kinematicWave(None, None, np.ones(N), 0.6, 1.0, 1.0, graph=Graph(ldd_raster=codes))
+    x = np.random.default_rng(8).uniform(0, 3, N)
+    got = kw.accuflux(x)
+    launches = kw.last_launches()["launches"]
+    monkeypatch.setenv("LF_ROUTE_CONES", "0")
+    ref = kw.accuflux(x)
+    assert np.array_equal(got, ref)
+    assert family == "shallow" or launches < kw.last_launches()["launches"] / 8
+    down = kw.graph.lookups()[0].astype(np.int64)
+    po, ss = kw.graph.orders()
+    acc = x.copy()                                             # level by level from the headwaters (float order differs)
+    for k in range(ss.shape[0]):
+        cells = po[ss[k, 0]:ss[k, 1]]
+        d = down[cells]
+        np.add.at(acc, d[d >= 0], acc[cells[d >= 0]])
+    np.testing.assert_allclose(got, acc, rtol=1e-12)
+    kw.close()
 
 
 def test_lddrepair_and_lddmask_device_equal_the_host_helpers(amd):
@@ -70,6 +103,14 @@ def test_lddrepair_and_lddmask_device_equal_the_host_helpers(amd):
     N = codes.size
     bad = codes.copy(); bad[3] = 0; bad[5] = 77; bad[9] = 2.5
     assert np.array_equal(L.lddrepair_device(bad, mask), L.lddrepair(bad, mask))
+    down = L.downstream_index(codes, mask)
+    target = int(down[down >= 0][7])                      # an unknown code on a pixel that HAS inflow: its feeders become pits
+    bad2 = codes.copy(); bad2[target] = 77
+    assert np.array_equal(L.lddrepair_device(bad2, mask), L.lddrepair(bad2, mask))
+    assert (L.lddrepair_device(bad2, mask)[down == target] == L.PIT).all()
+    a2, _ = L.lddmask_device(bad2, mask, np.ones(N, bool))
+    b2, _ = L.lddmask(bad2, mask, np.ones(N, bool))
+    assert np.array_equal(np.where(np.isin(a2, range(1, 10)), a2, 0), np.where(np.isin(b2, range(1, 10)), b2, 0))
     keep = np.random.default_rng(5).random(N) < 0.6
     a, am = L.lddmask_device(codes, mask, keep)
     b, bm = L.lddmask(codes, mask, keep)
