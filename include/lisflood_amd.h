@@ -330,6 +330,14 @@ typedef struct lf_canopy_args {
     const int64_t *index_landuse; /* [V], host */
     double LeafDrainageK, DtDay, InvDtDay;
     int64_t V, L, N;
+    /* option branches of the method, each switched on by a non-NULL output:
+     *   repStressDays (soilloop.py:597-598): SoilMoistureStressDays[V,N] = DtDay where RWS < 1, else 0
+     *   wateruse      (soilloop.py:582-587): WFilla[N] / WFillb[N] = min(WCrit1a / WCrit1b, WPF3a / WPF3b) of the land-use
+     *                 row of vegetation row `irrigated_veg` (the "Irrigated" fraction; < 0: none); WPF3a / WPF3b [L,N] */
+    double *SoilMoistureStressDays;
+    double *WFilla, *WFillb;
+    const double *WPF3a, *WPF3b;
+    int64_t irrigated_veg;
 } lf_canopy_args;
 int lf_canopy_device(int device, const lf_canopy_args *a);
 

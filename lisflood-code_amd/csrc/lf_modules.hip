@@ -86,6 +86,11 @@ __global__ void __launch_bounds__(kBlock) k_canopy(lf_canopy_args A, veg_map M)
         double rws = ((wcrit1 - wwp1) > 0) ? (w1 - wwp1) / (wcrit1 - wwp1) : 1.;
         rws = npmax(npmin(rws, 1.), 0.);
         A.RWS[i] = rws;
+        if (A.SoilMoistureStressDays) A.SoilMoistureStressDays[i] = (rws < 1) ? A.DtDay : 0.; // :597-598 (repStressDays)
+        if (A.WFilla && veg == (int)A.irrigated_veg) {                                          // :582-587 (wateruse)
+            A.WFilla[pix] = npmin(wcrit1a, A.WPF3a[j]);
+            A.WFillb[pix] = npmin(wcrit1b, A.WPF3b[j]);
+        }
         const double transpirable = npmax(w1 - wwp1, 0.);
         double ta = npmin(rws * pot, transpirable);
         if (frozen) ta = 0.;
@@ -354,6 +359,8 @@ int lf_canopy_device(int device, const lf_canopy_args *a)
 {
     if (!a || !a->index_landuse) return lf_set_error(LF_E_INVALID, "null argument");
     if (a->V > kMaxVeg) return lf_set_error(LF_E_INVALID, "V exceeds %d", kMaxVeg);
+    if ((a->WFilla || a->WFillb) && (!a->WFilla || !a->WFillb || !a->WPF3a || !a->WPF3b))
+        return lf_set_error(LF_E_INVALID, "wateruse: WFilla, WFillb, WPF3a and WPF3b are needed together");
     lf_device_ctx *c;
     LF_TRY(lf_ctx(device, &c));
     veg_map M;

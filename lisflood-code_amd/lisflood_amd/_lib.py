@@ -163,10 +163,41 @@ class BufferCache:
             host = host.view(np.uint8)
         return self.get(name, host.shape, host.dtype).upload(host)
 
+    @staticmethod
+    def _fingerprint(host):
+        """cheap identity of a host array's CONTENT: where it lives, its shape, and a strided sample of <= 4096 elements
+        (a parameter map that was recomputed, reloaded or rescaled changes it; a single edited element may not -- call
+        invalidate_static() after such an edit)"""
+        flat = host.reshape(-1)
+        step = max(1, flat.size // 4096)
+        sample = flat[::step]
+        return (host.__array_interface__["data"][0], host.shape, host.dtype.str, sample.tobytes())
+
+    def put_static(self, name, host):
+        """`put` for parameters that do not change between calls (soil and crop parameter maps): the upload is skipped
+        while the array's fingerprint is the one of the last upload.  static_uploads = False switches the check off."""
+        host = np.ascontiguousarray(host)
+        if host.dtype == np.bool_:
+            host = host.view(np.uint8)
+        if not getattr(self, "static_uploads", True):
+            return self.put(name, host)
+        fp = self._fingerprint(host)
+        seen = self.__dict__.setdefault("_static_fp", {})
+        d = self.buf.get(name)
+        if d is not None and seen.get(name) == fp and d.shape == host.shape and d.dtype == host.dtype:
+            return d
+        d = self.put(name, host)
+        seen[name] = fp
+        return d
+
+    def invalidate_static(self):
+        self.__dict__["_static_fp"] = {}
+
     def free(self):
         for d in self.buf.values():
             d.free()
         self.buf = {}
+        self.invalidate_static()
 
 
 def synchronize(device=0):

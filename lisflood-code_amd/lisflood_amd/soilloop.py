@@ -168,7 +168,9 @@ _CANOPY_N_IN = "Rain EWRef ETRef isFrozenSoil".split()
 class _CanopyArgs(C.Structure):  # lf_canopy_args
     _fields_ = ([(k, C.c_void_p) for k in _CANOPY_IO + _CANOPY_V_IN + _CANOPY_L_IN + _CANOPY_N_IN] +
                 [("index_landuse", C.c_void_p), ("LeafDrainageK", C.c_double), ("DtDay", C.c_double),
-                 ("InvDtDay", C.c_double), ("V", C.c_int64), ("L", C.c_int64), ("N", C.c_int64)])
+                 ("InvDtDay", C.c_double), ("V", C.c_int64), ("L", C.c_int64), ("N", C.c_int64),
+                 ("SoilMoistureStressDays", C.c_void_p), ("WFilla", C.c_void_p), ("WFillb", C.c_void_p),
+                 ("WPF3a", C.c_void_p), ("WPF3b", C.c_void_p), ("irrigated_veg", C.c_int64)])
 
 
 def _values(x):
@@ -179,14 +181,14 @@ def _values(x):
 class soilloop(HydroModule):
     """Soil/vegetation loop for the three prescribed fractions.  `dynamic_canopy()` and `dynamic_soil()` read and
     write the same `var` attributes as the reference methods; each is one device pass.
-    Option-gated extras of the reference that need other modules are not produced here: `cropsEPIC` rows (the
-    EPIC module is not part of the reference checkout), `SoilMoistureStressDays` (repStressDays), `WFilla/WFillb`
-    (wateruse).  `pF0..2` are produced with options={"simulatePF": True}."""
+    Option branches: options={"repStressDays": True} writes `SoilMoistureStressDays` (soilloop.py:597-598),
+    {"wateruse": True} sets `WFilla` / `WFillb` of the irrigated fraction (:582-587), {"simulatePF": True} produces
+    `pF0..2`.  Not produced: the `cropsEPIC` rows (the EPIC module is not part of the reference checkout)."""
     input_files_keys = {'wateruse': []}
     module_name = 'SoilLoop'
 
     def __init__(self, soilloop_variable, device=0, options=None):
-        """options: the reference's option switches this module reads (`simulatePF`)"""
+        """options: the reference's option switches this module reads (`simulatePF`, `wateruse`, `repStressDays`)"""
         self.var = soilloop_variable
         self.device = device
         self.options = dict(options or {})
@@ -216,8 +218,10 @@ class soilloop(HydroModule):
         for k in _CANOPY_IO:
             host[k] = self._inplace_rows(k)
             dev[k] = put("canopy." + k, host[k])
-        for k in _CANOPY_V_IN + _CANOPY_L_IN:
+        for k in _CANOPY_V_IN:
             dev[k] = put("canopy." + k, f64(_values(getattr(v, k))))
+        for k in _CANOPY_L_IN:          # crop / soil parameter maps: uploaded once (fingerprint check, BufferCache.put_static)
+            dev[k] = self._cache.put_static("canopy." + k, f64(_values(getattr(v, k))))
         for k in _CANOPY_N_IN:
             x = _values(getattr(v, k))
             dev[k] = put("canopy." + k, u8(x) if k == "isFrozenSoil" else f64(np.broadcast_to(x, (N,))))
@@ -227,9 +231,26 @@ class soilloop(HydroModule):
         a.index_landuse = idx.ctypes.data
         a.LeafDrainageK, a.DtDay, a.InvDtDay = float(v.LeafDrainageK), float(v.DtDay), float(v.InvDtDay)
         a.V, a.L, a.N = V, _values(v.WFC1).shape[0], N
+        a.irrigated_veg = -1
+        stress = fill = None
+        if self.options.get("repStressDays"):                  # soilloop.py:597-598
+            stress = self._inplace_rows("SoilMoistureStressDays")
+            a.SoilMoistureStressDays = self._cache.get("canopy.SoilMoistureStressDays", (V, N)).ptr.value
+        if self.options.get("wateruse"):                       # soilloop.py:582-587: the "Irrigated" fraction
+            irrigated = [i for i, veg in enumerate(v.prescribed_vegetation) if v.VEGETATION_LANDUSE[veg] == "Irrigated"]
+            if irrigated:
+                a.irrigated_veg = irrigated[-1]
+                fill = (self._cache.get("canopy.WFilla", (N,)), self._cache.get("canopy.WFillb", (N,)))
+                a.WFilla, a.WFillb = fill[0].ptr.value, fill[1].ptr.value
+                a.WPF3a = self._cache.put_static("canopy.WPF3a", f64(_values(v.WPF3a))).ptr.value
+                a.WPF3b = self._cache.put_static("canopy.WPF3b", f64(_values(v.WPF3b))).ptr.value
         check(lib().lf_canopy_device(C.c_int(self.device), C.byref(a)))
         for k in _CANOPY_IO:
             dev[k].download(host[k])
+        if stress is not None:
+            self._cache.buf["canopy.SoilMoistureStressDays"].download(stress)
+        if fill is not None:
+            v.WFilla, v.WFillb = fill[0].download(), fill[1].download()
 
     def dynamic_soil(self):
         v = self.var
@@ -240,23 +261,36 @@ class soilloop(HydroModule):
         V = _values(v.LAITerm).shape[0]
         out = self._cache.get("soil.ESMax", (V, N))
         check(lib().lf_scale_rows_device(C.c_int(self.device), es.ptr, lt.ptr, out.ptr, C.c_int64(V), C.c_int64(N)))
-        ESMax = out.download()
-        paddy_inactive = np.zeros(N, bool)[None]           # soilloop.py:644
+        # soilColumnsWaterBalance (soilloop.py:645-665) on cached device buffers: the static parameter maps ([L,N] soil
+        # hydraulic parameters and the five [N] constants) are uploaded once, the state and forcing every call -- other
+        # modules may have changed them on `var` --, the 22 written arrays come back in place
         g = lambda k: _values(getattr(v, k))
-        soilColumnsWaterBalance(
-            self.index_landuse_all, self.is_irrigated, self.is_paddy_irrig, paddy_inactive, v.DtDay,
-            g("AvailableWaterForInfiltration"), g("Rain"), g("SnowMelt"), g("LeafDrainage"), g("Interception"),
-            g("DSLR"), v.AvWaterThreshold, g("ESAct"), ESMax, g("isFrozenSoil"), g("b_Xinanjiang"),
-            g("StoreMaxPervious"), g("PowerInfPot"), g("PrefFlow"), g("PowerPrefFlow"), g("Infiltration"),
-            v.CourantCrit, g("PoreSpaceNotZero1a"), g("PoreSpaceNotZero1b"), g("PoreSpaceNotZero2"),
-            g("KSat1a"), g("KSat1b"), g("KSat2"), g("GenuInvM1a"), g("GenuInvM1b"), g("GenuInvM2"),
-            g("GenuM1a"), g("GenuM1b"), g("GenuM2"), g("W1a"), g("W1b"), g("W1"), g("W2"),
-            g("Theta1a"), g("Theta1b"), g("Theta2"), g("Sat1a"), g("Sat1b"), g("Sat1"), g("Sat2"),
-            g("SeepTopToSubA"), g("SeepTopToSubB"), g("SeepSubToGW"),
-            g("WRes1a"), g("WRes1b"), g("WRes1"), g("WRes2"), g("WWP1a"), g("WWP1b"), g("WWP1"), g("WWP2"),
-            g("WFC1a"), g("WFC1b"), g("WFC1"), g("WFC2"), g("SoilDepth1a"), g("SoilDepth1b"), g("SoilDepth2"),
-            g("WS1a"), g("WS1b"), g("WS1"), g("WS2"), g("UpperZoneK"), v.DrainedFraction, g("GwPercStep"),
-            g("UZOutflow"), g("UZ"), g("GwPercUZLZ"), device=self.device)
+        a = _SoilArgs()
+        cache = self._cache
+        written = {}
+        for k in _V_IO:
+            written[k] = _inplace(g(k), k)
+            setattr(a, k, cache.put("soil." + k, written[k]).ptr.value)
+        static_n = ("b_Xinanjiang", "PowerInfPot", "PowerPrefFlow", "UpperZoneK", "GwPercStep")
+        for k in _L_FIELDS + _N_FIELDS:
+            x = g(k)
+            if k in _N_FIELDS:
+                x = np.broadcast_to(x, (N,))
+            x = u8(x) if k in _BOOL else f64(x)
+            d = cache.put_static("soil." + k, x) if (k in _L_FIELDS or k in static_n) else cache.put("soil." + k, x)
+            setattr(a, k, d.ptr.value)
+        a.LeafDrainage = cache.put("soil.LeafDrainage", f64(g("LeafDrainage"))).ptr.value
+        a.Interception = cache.put("soil.Interception", f64(g("Interception"))).ptr.value
+        a.ESMax = out.ptr.value                              # already on the device
+        keep = []
+        _fill_small(a, keep, dict(index_landuse_all=self.index_landuse_all, is_irrigated=self.is_irrigated,
+                                  is_paddy_irrig=self.is_paddy_irrig), V)      # no paddy rows: paddy_inactive unused (:644)
+        a.DtDay, a.AvWaterThreshold = float(v.DtDay), float(v.AvWaterThreshold)
+        a.CourantCrit, a.DrainedFraction = float(v.CourantCrit), float(v.DrainedFraction)
+        a.V, a.L, a.N = V, g("WS1a").shape[0], N
+        check(lib().lf_soil_columns_device(C.c_int(self.device), C.byref(a)))
+        for k, host in written.items():
+            cache.buf["soil." + k].download(host)
         if self.options.get("simulatePF"):
             self.soil_pf()
 

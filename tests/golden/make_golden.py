@@ -534,6 +534,62 @@ def gen_canopy_soil_step():
          **{"init_" + k: a for k, a in before.items()}, **{"static_" + k: a for k, a in static.items()}, **forc, **outs)
 
 
+def gen_canopy_options():
+    """soilloop.dynamic_canopy with the option branches `wateruse` (WFilla / WFillb, soilloop.py:582-587) and
+    `repStressDays` (SoilMoistureStressDays, :597-598) switched on: same seeded inputs as canopy_soil_step's first
+    step (asserted), only the extra outputs are stored."""
+    soil = REF["soilloop"]
+    N = 600
+    rng = np.random.default_rng(51)
+    p = syn.soil_params(N, seed=52)
+    v = model_var(N)
+    REF["MaskInfo"].n = N
+    REF["LisSettings"].options.clear()
+    REF["LisSettings"].options.update(wateruse=True, repStressDays=True)
+    REF["LisSettings"].soil_uses = SOIL_USES[:]
+    REF["LisSettings"].vegetation_landuse = dict(zip(PRESCRIBED, SOIL_USES))
+    vn, ln = ["vegetation", "pixel"], ["landuse", "pixel"]
+    L_KEYS = [k for k in syn.SOIL_ARG_ORDER if np.ndim(p[k]) == 2 and k not in syn.SOIL_WRITTEN and
+              k not in ("LeafDrainage", "Interception", "ESMax", "paddy_inactive")]
+    for k in L_KEYS:
+        setattr(v, k, VA(p[k].copy(), ln))
+    for k in syn.SOIL_WRITTEN + ["LeafDrainage", "Interception"]:
+        setattr(v, k, VA(p[k].copy(), vn))
+    for k in ("Rain", "SnowMelt", "isFrozenSoil", "b_Xinanjiang", "PowerInfPot", "PowerPrefFlow", "UpperZoneK",
+              "GwPercStep"):
+        setattr(v, k, p[k].copy())
+    for k in ("DtDay", "AvWaterThreshold", "CourantCrit", "DrainedFraction"):
+        setattr(v, k, p[k])
+    v.InvDtDay = 1 / v.DtDay
+    ip = syn.interception_params(N, seed=53)
+    v.LAI = VA(ip["LAI"], vn)
+    v.CumInterception = VA(ip["CumInterception"], vn)
+    v.TaInterception = VA(np.zeros((3, N)), vn)
+    v.LAITerm = VA(np.exp(-0.5 * ip["LAI"]), vn)
+    v.LeafDrainageK = 0.25
+    v.EWRef, v.ETRef, v.ESRef = rng.uniform(0, 6, N), rng.uniform(0, 5, N), rng.uniform(0, 4, N)
+    v.CropCoef = VA(rng.uniform(0.6, 1.2, (3, N)), ln)
+    v.CropGroupNumber = VA(np.stack([rng.uniform(1, 5, N), rng.uniform(1, 5, N), np.full(N, 2.0)]), ln)
+    v.WPF3a = VA(p["WWP1a"] + 0.6 * (p["WFC1a"] - p["WWP1a"]), ln)
+    v.WPF3b = VA(p["WWP1b"] + 0.6 * (p["WFC1b"] - p["WWP1b"]), ln)
+    v.potential_transpiration = VA(np.zeros((3, N)), vn)
+    v.RWS = VA(np.zeros((3, N)), vn)
+    v.Ta = VA(np.zeros((3, N)), vn)
+    v.SoilMoistureStressDays = VA(np.full((3, N), -1.0), vn)
+    m = soil.soilloop(v)
+    m.initial()
+    with np.errstate(all="ignore"):
+        v.Rain = rng.uniform(0, 25, N) * (rng.random(N) < 0.6)
+        v.EWRef, v.ETRef, v.ESRef = rng.uniform(0, 6, N), rng.uniform(0, 5, N), rng.uniform(0, 4, N)
+        m.dynamic_canopy()
+    base = np.load(os.path.join(HERE, "canopy_soil_step.npz"))
+    assert np.array_equal(base["forc0_Rain"], v.Rain) and np.array_equal(base["canopy0_RWS"], np.array(v.RWS))
+    assert np.array_equal(base["canopy0_W1a"], np.array(v.W1a))
+    save("canopy_options", WFilla=np.asarray(v.WFilla), WFillb=np.asarray(v.WFillb),
+         SoilMoistureStressDays=np.array(v.SoilMoistureStressDays), DtDay=v.DtDay)
+    REF["LisSettings"].options.clear()
+
+
 PIXEL_V_IN = ("SoilFraction TaInterception Ta ESAct PrefFlow Infiltration SeepTopToSubA SeepTopToSubB SeepSubToGW "
               "Theta1a Theta1b Theta2 W1a W1b W2 UZOutflow GwPercUZLZ").split()
 PIXEL_N_IN = ("Rain SnowMelt EWRef SMaxSealed DirectRunoffFraction WaterFraction LowerZoneK LZThreshold "
@@ -1154,11 +1210,71 @@ def gen_initial():
     S.options.clear()
 
 
+def gen_prerun():
+    """InitLisflood pre-run (the run that produces avgdis for split routing): the reference's OWN routing.initial /
+    initialSecond with option InitLisflood -- NoRoutSteps forced to 1 (routing.py:78-79), no split branch -- on
+    cold.xml's channel maps, then six model steps of routing.dynamic(0) (single branch, routing.py:518-538) with seeded
+    runoff.  After each step the generator applies the five post-loop lines of Lisflood_dynamic.py:194-226 that the
+    pre-run needs (ChanM3, TotalCrossSectionArea, sumDis, ChanQAvg, CumQ / avgdis) -- restated here, they live in the
+    model class, which cannot be instantiated without the rest of the model."""
+    mask, maps, tables, scal = initial_inputs()
+    N = int(mask.sum())
+    import importlib
+    st_mod = importlib.import_module("lisflood.hydrological_modules.structures")
+    rout, lakes, res = REF["routing"], REF["lakes"], REF["reservoir"]
+    emu = PcrEmu(mask, maps, tables)
+    emu.install(rout, lakes, res, st_mod)
+    S = REF["LisSettings"]
+    S.options.clear()
+    S.options.update(InitLisflood=True, SplitRouting=True, simulateLakes=True, simulateReservoirs=True)
+    S.flags = {"nancheck": False}
+    M = REF["MaskInfo"]
+    M.n = N
+    M.info = types.SimpleNamespace(mask=~mask, mapC=(N,))
+    v = types.SimpleNamespace(DtSec=scal["DtSec"], DtSecChannel=scal["DtSecChannel"], MaskMap=np.ones(N, bool),
+                              PixelAreaPcr=maps["PixelArea"], PixelArea=maps["PixelArea"])
+    m = rout.routing(v)
+    rng = np.random.default_rng(77)
+    steps = 6
+    out = {k: [] for k in ("ChanQ", "ChanQKin", "ChanM3Kin", "sumDisDay", "ChanM3", "ChanQAvg", "avgdis")}
+    runoff = []
+    with np.errstate(all="ignore"):
+        m.initial()
+        lakes.lakes(v).initial()                # both return at once under InitLisflood (lakes.py / reservoir.py)
+        res.reservoir(v).initial()
+        st_mod.structures(v).initial()
+        m.initialSecond()
+        assert v.NoRoutSteps == 1 and v.DtRouting == v.DtSec
+        noop = types.SimpleNamespace(dynamic_inloop=lambda *a, **k: None)
+        m.lakes_module = m.reservoir_module = m.polder_module = m.inflow_module = m.transmission_module = noop
+        init = {k: np.array(getattr(v, k), dtype=np.float64).copy() for k in ("ChanQKin", "ChanM3Kin", "ChanQ")}
+        v.sumDis = np.zeros(N)
+        for step in range(steps):
+            v.ToChanM3RunoffDt = rng.uniform(0.0, 6.0e5, N) * (rng.random(N) < 0.8)
+            runoff.append(v.ToChanM3RunoffDt.copy())
+            v.TimeSinceStart = float(step + 1)
+            v.sumDisDay = np.zeros(N)                                       # Lisflood_dynamic.py:177
+            for s in range(v.NoRoutSteps):
+                m.dynamic(s)                                                # :179-180
+            v.ChanM3 = v.ChanM3Kin.copy()                                   # :197
+            v.TotalCrossSectionArea = v.ChanM3 * v.InvChanLength            # :206
+            v.sumDis += v.sumDisDay                                         # :208
+            v.ChanQAvg = v.sumDisDay / v.NoRoutSteps                        # :209
+            v.CumQ += v.ChanQ                                               # :225
+            v.avgdis = v.CumQ / v.TimeSinceStart                            # :226
+            for k in out:
+                out[k].append(np.array(getattr(v, k), dtype=np.float64).copy())
+    save("initlisflood_prerun", mask=mask, NoRoutSteps=v.NoRoutSteps, DtRouting=v.DtRouting, Beta=v.Beta,
+         LddKinematic=np.asarray(v.LddKinematic, np.float64), ToChanM3RunoffDt=np.array(runoff),
+         **{"init_" + k: a for k, a in init.items()}, **{"out_" + k: np.array(a) for k, a in out.items()})
+    S.options.clear()
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["graphs", "routes", "edge", "substeps", "upsum", "interception", "soil", "surface",
-                             "canopy", "inloop", "pixel", "chain", "pf", "initial"]
+                             "canopy", "canopy_options", "inloop", "pixel", "chain", "pf", "initial", "prerun"]
     fns = dict(graphs=gen_graphs, routes=gen_routes, edge=gen_route_edge, substeps=gen_substeps,
                upsum=gen_upstream_sum, interception=gen_interception, soil=gen_soil_columns,
-               surface=gen_surface_step, canopy=gen_canopy_soil_step, inloop=gen_inloop, pixel=gen_pixel_aggregates, chain=gen_chain, pf=gen_soil_pf, initial=gen_initial)
+               surface=gen_surface_step, canopy=gen_canopy_soil_step, canopy_options=gen_canopy_options, inloop=gen_inloop, pixel=gen_pixel_aggregates, chain=gen_chain, pf=gen_soil_pf, initial=gen_initial, prerun=gen_prerun)
     for w in which:
         fns[w]()

@@ -1284,6 +1284,117 @@ def test_soilloop_module_golden(amd, solver):
             np.testing.assert_allclose(getattr(v, k), g["soil%d_%s" % (s, k)], rtol=1e-9, atol=1e-11, err_msg=(s, k))
 
 
+def test_soilloop_option_branches_golden(amd):
+    """dynamic_canopy's option branches against the reference's own method with the options switched on
+    (tests/golden/make_golden.py canopy_options): `wateruse` -> WFilla / WFillb of the irrigated fraction
+    (soilloop.py:582-587), `repStressDays` -> SoilMoistureStressDays (:597-598); same inputs as canopy_soil_step's
+    first step"""
+    from lisflood_amd.soilloop import soilloop
+    g, o = golden("canopy_soil_step"), golden("canopy_options")
+    N = g["init_W1a"].shape[1]
+    v = _model_var(N)
+    for k in g.files:
+        if k.startswith("static_"):
+            setattr(v, k[7:], g[k].copy())
+        elif k.startswith("init_"):
+            setattr(v, k[5:], g[k].copy())
+    v.LeafDrainageK, v.DtDay = float(g["LeafDrainageK"]), float(g["DtDay"])
+    v.InvDtDay = 1 / v.DtDay
+    v.SoilMoistureStressDays = np.full((3, N), -1.0)
+    for k in ("Rain", "EWRef", "ETRef", "ESRef"):
+        setattr(v, k, g["forc0_" + k])
+    m = soilloop(v, options={"wateruse": True, "repStressDays": True})
+    m.initial()
+    m.dynamic_canopy()
+    np.testing.assert_allclose(v.RWS, g["canopy0_RWS"], rtol=1e-9, atol=1e-11)
+    assert np.array_equal(v.SoilMoistureStressDays, o["SoilMoistureStressDays"])
+    assert v.WFilla.shape == (N,) and v.WFillb.shape == (N,)
+    np.testing.assert_allclose(v.WFilla, o["WFilla"], rtol=1e-12)
+    np.testing.assert_allclose(v.WFillb, o["WFillb"], rtol=1e-12)
+    # without the options nothing of the kind is touched
+    v2 = _model_var(N)
+    for k in g.files:
+        if k.startswith("static_"):
+            setattr(v2, k[7:], g[k].copy())
+        elif k.startswith("init_"):
+            setattr(v2, k[5:], g[k].copy())
+    v2.LeafDrainageK, v2.DtDay, v2.InvDtDay = v.LeafDrainageK, v.DtDay, v.InvDtDay
+    v2.SoilMoistureStressDays = np.full((3, N), -1.0)
+    for k in ("Rain", "EWRef", "ETRef", "ESRef"):
+        setattr(v2, k, g["forc0_" + k])
+    m2 = soilloop(v2)
+    m2.initial()
+    m2.dynamic_canopy()
+    assert (v2.SoilMoistureStressDays == -1.0).all() and not hasattr(v2, "WFilla")
+
+
+def test_soilloop_static_parameter_maps_are_uploaded_once_and_followed_when_they_change(amd):
+    """the module classes keep the static [L,N] parameter maps on the device between calls (fingerprint check,
+    BufferCache.put_static): a second call uploads none of them, a map that is recomputed is picked up"""
+    from lisflood_amd import synthetic as syn
+    from lisflood_amd import _lib
+    from lisflood_amd.soilloop import soilloop
+    g = golden("canopy_soil_step")
+    N = g["init_W1a"].shape[1]
+
+    def fresh():
+        v = _model_var(N)
+        for k in g.files:
+            if k.startswith("static_"):
+                setattr(v, k[7:], g[k].copy())
+            elif k.startswith("init_"):
+                setattr(v, k[5:], g[k].copy())
+        v.LeafDrainageK, v.DtDay = float(g["LeafDrainageK"]), float(g["DtDay"])
+        v.InvDtDay = 1 / v.DtDay
+        v.AvWaterThreshold, v.CourantCrit, v.DrainedFraction = (float(g["AvWaterThreshold"]), float(g["CourantCrit"]),
+                                                               float(g["DrainedFraction"]))
+        for k in ("Rain", "EWRef", "ETRef", "ESRef"):
+            setattr(v, k, g["forc0_" + k])
+        m = soilloop(v)
+        m.initial()
+        return v, m
+    v, m = fresh()
+    uploads = []
+    orig = _lib.DeviceArray.upload
+
+    def counting(self, host):
+        uploads.append(host.nbytes)
+        return orig(self, host)
+    _lib.DeviceArray.upload = counting
+    try:
+        m.dynamic_canopy(); m.dynamic_soil()
+        first = sum(uploads)
+        uploads.clear()
+        m.dynamic_canopy(); m.dynamic_soil()
+        second = sum(uploads)
+    finally:
+        _lib.DeviceArray.upload = orig
+    assert second < 0.62 * first, (first, second)        # 40 of the ~75 staged arrays are parameter maps
+    # a recomputed map is followed: KSat1a x 3 in place == a fresh module on the changed map
+    v.KSat1a *= 3.0
+    v3, m3 = fresh()
+    m3.dynamic_canopy(); m3.dynamic_soil()
+    m3.dynamic_canopy(); m3.dynamic_soil()
+    v3.KSat1a *= 3.0
+    m3._cache.static_uploads = False                      # the reference path: everything staged on every call
+    m.dynamic_canopy(); m.dynamic_soil()
+    m3.dynamic_canopy(); m3.dynamic_soil()
+    for k in syn.SOIL_WRITTEN:
+        assert np.array_equal(getattr(v, k), getattr(v3, k)), k
+
+
+def test_handles_created_after_a_fork():
+    """SURVEY 8(b) threading row: the reference forks its Monte-Carlo / EnKF members (main.py:104-106); handles created
+    in forked children (library loaded before the fork) and in the parent afterwards all work -- run in a fresh
+    interpreter, this process has touched the device already"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fork_worker.py")], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "FORK_OK members=3" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
 def test_empty_inputs(amd):
     mask = np.zeros((3, 4), bool)
     kw = amd.kw.kinematicWave(np.zeros(0), mask, np.zeros(0), 0.6, 1000.0, 3600.0)

@@ -81,11 +81,10 @@ def test_accuflux_on_level_blocks_equals_the_level_schedule(amd, family, seed, m
     kw = kinematicWave(None, None, np.ones(N), 0.6, 1.0, 1.0, graph=Graph(ldd_raster=codes))
     x = np.random.default_rng(8).uniform(0, 3, N)
     got = kw.accuflux(x)
-    launches = kw.last_launches()["launches"]
+    assert kw.last_launches()["launches"] <= kw.graph.num_levels // 32 + 8      # blocks of up to 64 levels, not levels
     monkeypatch.setenv("LF_ROUTE_CONES", "0")
     ref = kw.accuflux(x)
     assert np.array_equal(got, ref)
-    assert family == "shallow" or launches < kw.last_launches()["launches"] / 8
     down = kw.graph.lookups()[0].astype(np.int64)
     po, ss = kw.graph.orders()
     acc = x.copy()                                             # level by level from the headwaters (float order differs)
@@ -200,3 +199,36 @@ def test_channel_initialisation_reproduces_the_reference_on_cold_xml_inputs(amd)
     # the router initialSecond built sweeps the cut LDD exactly like the reference's
     assert np.array_equal(m.river_router.pixels_ordered, g["router_pixels_ordered"])
     assert np.array_equal(m.river_router.order_start_stop, g["router_order_start_stop"])
+
+
+def test_initlisflood_prerun_reproduces_the_reference(amd):
+    """The pre-run that produces avgdis (option InitLisflood): routing.initial forces NoRoutSteps = 1 (routing.py:78-79),
+    initialSecond builds no split branch, routing.dynamic(0) takes the single branch even with SplitRouting on
+    (:518-538), and the post-loop lines give ChanM3 / ChanQAvg / CumQ / avgdis (Lisflood_dynamic.py:194-226) -- against
+    tests/golden/initlisflood_prerun.npz, six model steps driven by the reference's OWN routing.initial /
+    initialSecond / dynamic on cold.xml's channel maps (make_golden.py gen_prerun)."""
+    import types
+    from lisflood_amd import structures as ST
+    g0 = golden("etrs89_initial")
+    g = golden("initlisflood_prerun")
+    mask = g["mask"]
+    maps = {k[4:]: (g0[k] if g0[k].ndim else float(g0[k])) for k in g0.files if k.startswith("map_")}
+    opts = dict(InitLisflood=True, SplitRouting=True, simulateLakes=True, simulateReservoirs=True)
+    v = types.SimpleNamespace(DtSec=float(g0["DtSec"]), DtSecChannel=float(g0["DtSecChannel"]))
+    m = amd.routing.routing(v, options=opts)
+    m.initial(maps, mask)
+    assert v.NoRoutSteps == 1 == int(g["NoRoutSteps"]) and v.DtRouting == v.DtSec == float(g["DtRouting"])
+    ST.structures(v, opts).initial(mask)          # (lakes / reservoirs are switched off by InitLisflood)
+    m.initialSecond()
+    assert np.array_equal(np.asarray(v.LddKinematic, np.float64), g["LddKinematic"])
+    for k in ("ChanQKin", "ChanM3Kin", "ChanQ"):
+        np.testing.assert_allclose(getattr(v, k), g["init_" + k], rtol=1e-14, err_msg=k)
+    assert not hasattr(v, "Chan2QKin") or not m._split()
+    for step in range(g["ToChanM3RunoffDt"].shape[0]):
+        v.ToChanM3RunoffDt = g["ToChanM3RunoffDt"][step].copy()
+        v.sumDisDay = np.zeros(v.ChanQKin.size)
+        for s in range(v.NoRoutSteps):
+            m.dynamic(s)
+        m.step_end(time_since_start=float(step + 1))
+        for k in ("ChanQ", "ChanQKin", "ChanM3Kin", "sumDisDay", "ChanM3", "ChanQAvg", "avgdis"):
+            np.testing.assert_allclose(getattr(v, k), g["out_" + k][step], rtol=1e-9, atol=1e-12, err_msg=(step, k))
