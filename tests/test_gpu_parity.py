@@ -1380,7 +1380,7 @@ def test_soilloop_static_parameter_maps_are_uploaded_once_and_followed_when_they
     m.dynamic_canopy(); m.dynamic_soil()
     m3.dynamic_canopy(); m3.dynamic_soil()
     for k in syn.SOIL_WRITTEN:
-        assert np.array_equal(getattr(v, k), getattr(v3, k)), k
+        assert np.array_equal(getattr(v, k), getattr(v3, k), equal_nan=True), k
 
 
 def test_handles_created_after_a_fork():

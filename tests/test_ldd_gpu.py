@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def amd():
     import lisflood_amd
-    from lisflood_amd import _lib
+    from lisflood_amd import _lib, routing  # noqa: F401  (the tests reach the module class through the package)
     if _lib.device_count() < 1:
         pytest.fail("no HIP device visible: the -m gpu tests need an MI355X")
     return lisflood_amd
@@ -230,5 +230,9 @@ def test_initlisflood_prerun_reproduces_the_reference(amd):
         for s in range(v.NoRoutSteps):
             m.dynamic(s)
         m.step_end(time_since_start=float(step + 1))
-        for k in ("ChanQ", "ChanQKin", "ChanM3Kin", "sumDisDay", "ChanM3", "ChanQAvg", "avgdis"):
+        # discharges: rtol 1e-9 + the reference's own Newton tolerance (1e-12 m3/s, kinematic_wave_parallel_tools.py:26);
+        # volumes V = L alpha Q^0.6 carry that absolute tolerance of Q relatively (dV/V = 0.6 dQ/Q): 1e-8 on nearly dry cells
+        for k in ("ChanQ", "ChanQKin", "sumDisDay", "ChanQAvg", "avgdis"):
             np.testing.assert_allclose(getattr(v, k), g["out_" + k][step], rtol=1e-9, atol=1e-12, err_msg=(step, k))
+        for k in ("ChanM3Kin", "ChanM3"):
+            np.testing.assert_allclose(getattr(v, k), g["out_" + k][step], rtol=1e-8, atol=1e-9, err_msg=(step, k))
