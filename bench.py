@@ -162,6 +162,26 @@ def pmc_traffic(kernel_key, cells_per_launch):
     return d["hbm_read_bytes_per_launch"] + d["hbm_write_bytes_per_launch"], os.path.relpath(f, ROOT)
 
 
+def pmc_traffic_r03(workload, kernel_substr):
+    """HBM bytes per launch of `kernel_substr` in the newest committed profiles/*_pmc_digest.json (tools/pmc_r03.sh:
+    separate --pmc passes of tools/pmc_route.py on this workload, FETCH_SIZE x 2 + WRITE_SIZE) -> (bytes, source, extra)"""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_digest.json")), reverse=True):
+        try:
+            w = json.load(open(f))["workloads"].get(workload)
+        except Exception:
+            continue
+        if not w:
+            continue
+        for name, k in w["kernels"].items():
+            if kernel_substr in name and "hbm_read_bytes_per_launch" in k:
+                extra = {x: round(k[x], 1) for x in ("waves_per_launch", "sq_wave_cycles_per_wave", "sq_wait_any_per_wave",
+                                                     "sq_wait_inst_any_per_wave", "sq_active_inst_valu_per_wave",
+                                                     "sq_insts_valu_per_wave") if x in k}
+                return k["hbm_read_bytes_per_launch"] + k["hbm_write_bytes_per_launch"], w["source"], extra
+    return None, None, None
+
+
 def committed_rocprof_mean(cells_per_launch):
     """Mean duration of the headline kernel in the newest committed rocprofv3 --kernel-trace --stats summary of this
     same workload (profiles/*head_kernel_stats.csv, tools/gpu_profile_r02.sh): another box, another day -- reported
@@ -180,8 +200,9 @@ def committed_rocprof_mean(cells_per_launch):
     return None
 
 
-def roofline_of(res, kernel_key=None):
-    """Dominant sweep kernel: achieved algorithmic GB/s = 48 B x cells per launch / mean launch duration."""
+def roofline_of(res, kernel_key=None, workload=None):
+    """Dominant sweep kernel: achieved algorithmic GB/s = 48 B x cells per launch / mean launch duration.
+    workload: key of the committed PMC digest (e.g. "route_deep_10000") for roofline.traffic."""
     prof = res["prof"]
     wide, narrow = prof["wide_level"], prof["narrow_run"]
     if res.get("components"):       # component layout: the tier launches together sweep every cell once per call
@@ -206,9 +227,14 @@ def roofline_of(res, kernel_key=None):
     ms_per_launch = dom["ms"] / dom["launches"]
     achieved = B_ALG * cells_per_launch / (ms_per_launch * 1e-3) / 1e9
     traffic, src = pmc_traffic(kernel_key, cells_per_launch) if kernel_key else (None, None)
+    counters = None
+    if workload:        # round-3 digests: per workload, the dominant kernel by name
+        t3, s3, counters = pmc_traffic_r03(workload, "k_level<true, true, false>" if dom is wide else "k_sweep_cones")
+        if t3 is not None:
+            traffic, src = t3, s3
     check = committed_rocprof_mean(cells_per_launch) if (kernel_key and dom is wide) else None
     return dict(bound="hbm", kernel=name, achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit="GB/s",
-                committed_rocprof=check,
+                committed_rocprof=check, pmc_per_wavefront=counters,
                 frac=round(achieved / HBM_PEAK_GBS, 6), traffic=traffic, traffic_unit="bytes per launch",
                 traffic_source=src, alg_bytes_per_launch=B_ALG * cells_per_launch,
                 launches_per_step=int(round(dom["launches"] / max(res.get("profile_steps", 1), 1))),
@@ -217,27 +243,43 @@ def roofline_of(res, kernel_key=None):
                 prep_ms_per_step=round(prof["prep"]["ms"] / max(prof["prep"]["launches"], 1), 4))
 
 
-def cpu_baseline(family, sample, steps=2):
-    """The oracle (C restatement of the reference algorithm, OpenMP level-parallel like numba prange)
-    timed on this host on a bounded sample of the same workload."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or "unknown"
+
+
+def cpu_baseline(family, sample, steps=2, full=10000, budget_s=45.0):
+    """The oracle (C restatement of the reference algorithm, OpenMP level-parallel like numba prange) timed on this
+    host: first on a sample x sample raster over several team sizes, then -- with the best team -- on the largest raster
+    up to the bench's own size whose graph build + 3 calls fit `budget_s` (estimated from the sample; the oracle's
+    graph build is single-threaded host code and dominates).  `value` is the larger leg's rate."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle
     from lisflood_amd import synthetic as syn
     oracle.build()
-    H = W = sample
-    codes = syn.make_ldd(family, H, W, SEEDS[family])
-    mask = np.ones((H, W), bool)
-    N = H * W
-    p = syn.router_params(N)
-    kw = oracle.kinematicWave(codes.reshape(-1).astype(np.float64), mask, p["alpha"], p["beta"], p["dx"], p["dt"])
-    Q = p["Q0"].copy()
-    q = syn.lateral_inflow(N, 0)
-    kw.kinematicWaveRouting(Q, q)    # warm
     ncpu = os.cpu_count() or 1
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = ncpu
+
+    def case(size):
+        H = W = size
+        t0 = time.perf_counter()
+        codes = syn.make_ldd(family, H, W, SEEDS[family])
+        mask = np.ones((H, W), bool)
+        N = H * W
+        p = syn.router_params(N)
+        kw = oracle.kinematicWave(codes.reshape(-1).astype(np.float64), mask, p["alpha"], p["beta"], p["dx"], p["dt"])
+        return kw, p["Q0"].copy(), syn.lateral_inflow(N, 0), N, time.perf_counter() - t0
+    kw, Q, q, N, t_build = case(sample)
+    kw.kinematicWaveRouting(Q, q)    # warm
     rates = {}
     for threads in sorted({1, 8, 32, avail}):
         if threads > avail:
@@ -248,14 +290,33 @@ def cpu_baseline(family, sample, steps=2):
             kw.kinematicWaveRouting(Q, q)
         rates[threads] = N * steps / (time.perf_counter() - t0) / 1e6
     cores = max(rates, key=rates.get)
-    dt_all = N / rates[cores] / 1e6
-    dt_one = N / rates[1] / 1e6
-    return dict(value=round(N / dt_all / 1e6, 3), unit="Mcell-steps/s", cores=cores, kind="port",
-                sample="%dx%d %s raster, %d calls per thread count; best of OpenMP teams %s = %d threads "
-                       "(1 thread: %.3f Mcell-steps/s; host reports %d cpus, %d usable); C restatement of the "
-                       "reference algorithm (oracle/lf_oracle.c), not numba"
-                       % (H, W, family, steps, sorted(rates), cores, N / dt_one / 1e6, ncpu, avail),
-                newton_iters_mean=round(kw.last_iters[0] / N, 3), newton_iters_max=kw.last_iters[1])
+    out = dict(value=round(rates[cores], 3), unit="Mcell-steps/s", cores=cores, kind="port", cpu_model=cpu_model(),
+               host_cpus=ncpu, usable_cpus=avail,
+               sample="%dx%d %s raster, %d calls per thread count; best of OpenMP teams %s = %d threads "
+                      "(1 thread: %.3f Mcell-steps/s); C restatement of the reference algorithm (oracle/lf_oracle.c), "
+                      "not numba" % (sample, sample, family, steps, sorted(rates), cores, rates[1]),
+               newton_iters_mean=round(kw.last_iters[0] / N, 3), newton_iters_max=kw.last_iters[1])
+    # the bench's own size, or the largest that fits the budget
+    per_cell = (t_build + 3.0 * N / rates[cores] / 1e6) / N
+    size = int(min(full, (budget_s / per_cell) ** 0.5))
+    size -= size % 100
+    if size > sample * 1.2:
+        del kw, Q, q
+        kw, Q, q, N2, t_b2 = case(size)
+        oracle.set_threads(cores)
+        kw.kinematicWaveRouting(Q, q)
+        t0 = time.perf_counter()
+        for s in range(steps):
+            kw.kinematicWaveRouting(Q, q)
+        rate = N2 * steps / (time.perf_counter() - t0) / 1e6
+        out["sample_leg"] = dict(value=out["value"], size=sample)
+        out["value"] = round(rate, 3)
+        out["sample"] = ("%dx%d %s raster (largest up to the bench's %d^2 whose oracle set-up + calls fit %.0f s: set-up "
+                         "took %.1f s), %d calls with %d OpenMP threads; team size chosen on a %dx%d sample among %s "
+                         "(1 thread there: %.3f Mcell-steps/s); C restatement of the reference algorithm "
+                         "(oracle/lf_oracle.c), not numba"
+                         % (size, size, family, full, budget_s, t_b2, steps, cores, sample, sample, sorted(rates), rates[1]))
+    return out
 
 
 def soil_bench(N=4_000_000, steps=10):
@@ -348,6 +409,18 @@ def model_step_bench(size=5000, nsteps=24, family="deep"):
         st.free()
     out["config"] = "%dx%d %s LDD (NL=%d), NoRoutSteps=%d, split routing: %d cell-steps per cell per model step" % (
         H, W, family, g.num_levels, nsteps, 2 * nsteps)
+    t3, s3, counters = pmc_traffic_r03("fused_%s_%d" % (family, size), "k_fused_cones")
+    if t3 is not None:      # committed counter passes of this workload: HBM bytes of the cone launches per (cell, sub-step)
+        launches = out["fused"]["launches_per_model_step"]
+        per = t3 * launches / (N * nsteps)
+        ms = out["fused"]["ms_per_model_step"]
+        out["fused"]["roofline"] = dict(bound="hbm", kernel="k_fused_cones", traffic=round(t3, 1), traffic_unit="bytes per launch",
+                                        traffic_source=s3, hbm_bytes_per_cell_substep=round(per, 1),
+                                        achieved=round(2 * B_ALG * N * nsteps / (ms * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS,
+                                        unit="GB/s", frac=round(2 * B_ALG * N * nsteps / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                        moved_GBs=round(per * N * nsteps / (ms * 1e-3) / 1e9, 1), pmc_per_wavefront=counters,
+                                        note="frac by the 48 B per router call measure (2 calls per sub-step); moved_GBs = "
+                                             "counter traffic / time: the step is bound by its own ~25 state vectors")
     out["note"] = ("fused = lf_routing_substeps_fused: one wavefront over blocks of up to 16 levels, each block swept cone by "
                    "cone through LDS (k_fused_cones); fused_level_by_level = the same call with LF_FUSED_LEVELS=1")
     kw1.close()
@@ -510,7 +583,7 @@ def main():
         "hbm_frac_whole_step": round(B_ALG * N / (res["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
         "finite": res["finite"],
     }
-    out["roofline"] = roofline_of(res, "k_level[fused+ordered]")
+    out["roofline"] = roofline_of(res, "k_level[fused+ordered]", workload="route_%s_%d" % (a.family, a.size))
     try:
         rp = run_routing(kw, p, max(3, a.steps // 3), 1, nq=2, profile_steps=1, ordered=False)
         out["pixel_order_call"] = dict(value=round(N / rp["ms_per_step"] / 1e3, 2), unit="Mcell-steps/s",
@@ -540,13 +613,13 @@ def main():
                     # one launch per level (LF_ROUTE_CONES=0, same router) and against the component layout
                 entry = {}
 
-                def leg(kw_, p_):
+                def leg(kw_, p_, wl=None):
                     r_ = run_routing(kw_, p_, max(2, a.steps // 5), 1, nq=1, profile_steps=1)
                     return dict(value=round(kw_.num_pixels / r_["ms_per_step"] / 1e3, 2), unit="Mcell-steps/s",
                                 ms_per_step=round(r_["ms_per_step"], 3), launches_per_step=r_["stats"]["launches"],
-                                roofline=roofline_of(r_))
+                                roofline=roofline_of(r_, workload=wl))
                 kw2, p2, g2 = build_case(other, H, W, "levels")
-                entry.update(leg(kw2, p2), levels=g2.num_levels, level_sizes=level_sizes(g2), engine_layout="levels")
+                entry.update(leg(kw2, p2, "route_%s_%d" % (other, H)), levels=g2.num_levels, level_sizes=level_sizes(g2), engine_layout="levels")
                 deep_net = g2.num_levels > 64
                 if deep_net:
                     os.environ["LF_ROUTE_CONES"] = "0"
@@ -580,7 +653,7 @@ def main():
             extra["resident_hot_path_error"] = repr(e)
         out["other_workloads"] = extra
     if not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(a.family, a.cpu_sample)
+        out["cpu_baseline"] = cpu_baseline(a.family, a.cpu_sample, full=a.size)
     print(json.dumps(out), flush=True)
 
 
