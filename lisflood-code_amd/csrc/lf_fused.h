@@ -24,6 +24,12 @@ struct fused_args {
     double dx_scalar, beta, inv_beta, b_minus_1;
     int kmax, nlevels, nsteps, t;
     int solve35; // router runs the beta = 3/5 quintic solve (false: general path, e.g. LF_GENERAL_POW=1)
+    // *recompute != 0 (device flag, written by k_check_derived before the wavefront): for every cell InvChanLength ==
+    // 1 / ChanLength, InvChannelAlpha(2) == 1 / ChannelAlpha(2) and the router's alpha*dx/dt == ChannelAlpha(2) * dx / dt
+    // bit for bit -- as routing.initial computes them (routing.py:70, 236, 361; kinematic_wave_parallel.py:127) -- so the
+    // five vectors are recomputed (IEEE division) instead of streamed: 40 of ~235 bytes per cell and sub-step
+    const unsigned int *__restrict__ recompute;
+    double dt; // the router's time step (a = alpha * dx / dt)
     const uint8_t *__restrict__ linked; // zero-length structure links: their router output is stored as 0
     const uint8_t *__restrict__ inert;  // cells whose sub-step is the identity while their state is all +0.0
     lf_inloop_args I;                   // STRUCT: lakes / reservoirs / inflow / transmission loss / sideflow assembly
@@ -49,6 +55,27 @@ struct fused_args {
 };
 
 __device__ __forceinline__ bool plus_zero(double x) { return __double_as_longlong(x) == 0; }
+__device__ __forceinline__ bool same_bits(double a, double b) { return __double_as_longlong(a) == __double_as_longlong(b); }
+
+// see fused_args::recompute; *flag is preset to 1
+__global__ void __launch_bounds__(kBlock) k_check_derived(long long n, lf_substep_args A, const double *__restrict__ a1,
+                                                          const double *__restrict__ a2, const double *__restrict__ dx,
+                                                          double dx_scalar, double dt, unsigned int *flag)
+{
+    const long long p = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (p >= n) return;
+    const double dxp = dx ? dx[p] : dx_scalar;
+    bool ok = same_bits(A.InvChanLength[p], 1.0 / A.ChanLength[p]) && same_bits(A.InvChannelAlpha[p], 1.0 / A.ChannelAlpha[p]) &&
+              same_bits(a1[p], A.ChannelAlpha[p] * dxp / dt);
+    if (ok && A.split)
+        ok = same_bits(A.InvChannelAlpha2[p], 1.0 / A.ChannelAlpha2[p]) && same_bits(a2[p], A.ChannelAlpha2[p] * dxp / dt);
+    if (!ok) *flag = 0u; // benign race: every writer stores the same value
+}
+__device__ __forceinline__ bool derived_recomputable(const fused_args &F)
+{
+    typedef const unsigned int __attribute__((address_space(4))) *cptr; // scalar load (nothing in the wavefront writes it)
+    return F.recompute != nullptr && ((cptr)(unsigned long long)F.recompute)[0] != 0u;
+}
 
 // Non-channel land pixels sit in the channel router as isolated nodes without sideflow (routing.py:512): once their
 // state is zero, a sub-step leaves every vector as it is.  inert[p] marks the candidates (static part of the test);
@@ -133,8 +160,10 @@ __device__ __forceinline__ void fused_cell(const fused_args &F, long long p, int
     const long long par = (long long)(s & 1) * F.n;
     // ---- every load first: the argument pointers are not restrict-qualified, so a store in the middle of the
     // ---- kernel would pin all later loads behind it (the kernel is a stream of ~30 vectors) -------------------
+    const bool rc = derived_recomputable(F); // (uniform)
     const double dxp = F.dx ? F.dx[p] : F.dx_scalar;
-    const double inv_len = A.InvChanLength[p], len = A.ChanLength[p];
+    const double len = A.ChanLength[p];
+    const double inv_len = rc ? 1.0 / len : A.InvChanLength[p];
     const bool is_chan = A.IsChannelKinematic[p] != 0;
     const bool cut = F.linked && F.linked[p];
     double side_m3, qin = 0, qin_added = 0, loss = 0, trans_cum = 0;
@@ -161,7 +190,8 @@ __device__ __forceinline__ void fused_cell(const fused_args &F, long long p, int
         if (I.QResOutM3Dt) side_m3 += I.QResOutM3Dt[p];
         if (I.ChannelToPolderM3Dt) side_m3 -= I.ChannelToPolderM3Dt[p];
     }
-    const double ap1 = F.a1[p], qold = A.ChanQKin[p], alpha1 = A.ChannelAlpha[p], inv_alpha1 = A.InvChannelAlpha[p];
+    const double qold = A.ChanQKin[p], alpha1 = A.ChannelAlpha[p];
+    const double inv_alpha1 = rc ? 1.0 / alpha1 : A.InvChannelAlpha[p], ap1 = rc ? alpha1 * dxp / F.dt : F.a1[p];
     const double sum_old = A.sumDisDay[p];
     const double ups1 = ups_of(F.qr1 + par, 0);
     double m3 = 0, m3_2 = 0, start = 0, m3limit = 0, q2start = 0, ap2 = 0, q2old = 0, alpha2 = 0, inv_alpha2 = 0, qlimit = 0,
@@ -172,10 +202,10 @@ __device__ __forceinline__ void fused_cell(const fused_args &F, long long p, int
         start = A.Chan2M3Start[p];
         m3limit = A.M3Limit[p];
         q2start = A.Chan2QStart[p];
-        ap2 = F.a2[p];
         q2old = A.Chan2QKin[p];
         alpha2 = A.ChannelAlpha2[p];
-        inv_alpha2 = A.InvChannelAlpha2[p];
+        ap2 = rc ? alpha2 * dxp / F.dt : F.a2[p];
+        inv_alpha2 = rc ? 1.0 / alpha2 : A.InvChannelAlpha2[p];
         qlimit = A.QLimit[p];
         ups2 = ups_of(F.qr2 + par, 1);
     }
@@ -229,16 +259,20 @@ __device__ __forceinline__ void fused_cell(const fused_args &F, long long p, int
     }
     F.qr1[par + p] = cut ? 0.0 : qr;
     if (root_slot >= 0) F.root1[root_slot * F.root_ss + s * F.root_st] = qr; // kept for the next tier / phase / rank
+    // ChanQ, Sideflow1Chan and CrossSection2Area are results of a sub-step that no later sub-step reads (routing.py:557-603
+    // recomputes them from the volumes) -- only the structures of the loop read ChanQ (STRUCT): without them the
+    // intermediate values are not stored, the last sub-step's are (what the sub-step-by-sub-step sequence leaves behind)
+    const bool keep = STRUCT || last;
     A.ChanM3Kin[p] = v;
     A.ChanQKin[p] = q;
-    A.ChanQ[p] = chanq;
+    if (keep) A.ChanQ[p] = chanq;
     A.sumDisDay[p] = sum_old + chanq;
     if (SPLIT) {
-        A.Sideflow1Chan[p] = s1;
+        if (keep) A.Sideflow1Chan[p] = s1;
         F.qr2[par + p] = cut ? 0.0 : q2r;
         if (root_slot >= 0) F.root2[root_slot * F.root_ss + s * F.root_st] = q2r;
         A.Chan2M3Kin[p] = v2;
-        A.CrossSection2Area[p] = (v2 - start) * inv_len;
+        if (keep) A.CrossSection2Area[p] = (v2 - start) * inv_len;
         A.Chan2QKin[p] = q2;
     }
     if (last) { // routing.py:693-703
@@ -316,7 +350,7 @@ struct cone_cell { // what a cell's load phase leaves in registers: loaded value
 };
 
 template <bool SPLIT, bool STRUCT, bool DIST = false>
-__device__ __forceinline__ void cone_load(const fused_args &F, long long p, int s, bool active, cone_cell &R)
+__device__ __forceinline__ void cone_load(const fused_args &F, long long p, int s, bool active, cone_cell &R, bool rc = false)
 {
     const lf_substep_args &A = F.S;
     R.active = active;
@@ -329,7 +363,7 @@ __device__ __forceinline__ void cone_load(const fused_args &F, long long p, int 
         R.slot = F.d_out_slot[p];
     }
     R.dxp = F.dx ? F.dx[p] : F.dx_scalar;
-    R.inv_len = A.InvChanLength[p];
+    R.inv_len = rc ? 0.0 : A.InvChanLength[p]; // rc: cone_derive fills the five derived values in from len / alpha / dx
     R.len = A.ChanLength[p];
     R.chan_raw = A.IsChannelKinematic[p];
     R.chanq_old = R.csa_old = R.sf1_old = 0;
@@ -357,10 +391,10 @@ __device__ __forceinline__ void cone_load(const fused_args &F, long long p, int 
         if (I.ChannelToPolderM3Dt) R.polder = I.ChannelToPolderM3Dt[p];
     }
     if (F.linked) R.cut_raw = F.linked[p]; // (also without STRUCT: a sub-step at a time on a graph with structure links)
-    R.ap1 = F.a1[p];
+    R.ap1 = rc ? 0.0 : F.a1[p];
     R.qold = A.ChanQKin[p];
     R.alpha1 = A.ChannelAlpha[p];
-    R.inv_alpha1 = A.InvChannelAlpha[p];
+    R.inv_alpha1 = rc ? 0.0 : A.InvChannelAlpha[p];
     R.sum_old = A.sumDisDay[p];
     R.m3 = R.m3_2 = R.start = R.m3limit = R.q2start = R.ap2 = R.q2old = R.alpha2 = R.inv_alpha2 = R.qlimit = 0;
     const bool test_inert = !STRUCT && F.inert && s != F.nsteps - 1; // see k_inert_flags / fused_cell (uniform)
@@ -370,10 +404,10 @@ __device__ __forceinline__ void cone_load(const fused_args &F, long long p, int 
         R.start = A.Chan2M3Start[p];
         R.m3limit = A.M3Limit[p];
         R.q2start = A.Chan2QStart[p];
-        R.ap2 = F.a2[p];
+        R.ap2 = rc ? 0.0 : F.a2[p];
         R.q2old = A.Chan2QKin[p];
         R.alpha2 = A.ChannelAlpha2[p];
-        R.inv_alpha2 = A.InvChannelAlpha2[p];
+        R.inv_alpha2 = rc ? 0.0 : A.InvChannelAlpha2[p];
         R.qlimit = A.QLimit[p];
     }
     R.pix_area = (s == F.nsteps - 1) ? A.PixelArea[p] : 0.0;
@@ -384,6 +418,20 @@ __device__ __forceinline__ void cone_load(const fused_args &F, long long p, int 
             R.csa_old = A.CrossSection2Area[p];
             R.sf1_old = A.Sideflow1Chan[p];
         }
+    }
+}
+
+// fused_args::recompute: the five derived statics from the three loaded ones (same operations as the host's)
+template <bool SPLIT>
+__device__ __forceinline__ void cone_derive(const fused_args &F, cone_cell &R)
+{
+    if (!R.active) return;
+    R.inv_len = 1.0 / R.len;
+    R.inv_alpha1 = 1.0 / R.alpha1;
+    R.ap1 = R.alpha1 * R.dxp / F.dt;
+    if (SPLIT) {
+        R.inv_alpha2 = 1.0 / R.alpha2;
+        R.ap2 = R.alpha2 * R.dxp / F.dt;
     }
 }
 
@@ -559,14 +607,15 @@ __device__ __forceinline__ void cone_store(const fused_args &F, const cone_out &
         }
         I.SideflowChanM3[p] = O.side_m3;
     }
+    const bool keep = STRUCT || s == F.nsteps - 1; // see fused_cell: intermediate values nobody reads are not stored
     A.ChanM3Kin[p] = O.v;
     A.ChanQKin[p] = O.q;
-    A.ChanQ[p] = O.chanq;
+    if (keep) A.ChanQ[p] = O.chanq;
     A.sumDisDay[p] = O.sum;
     if (SPLIT) {
-        A.Sideflow1Chan[p] = O.s1;
+        if (keep) A.Sideflow1Chan[p] = O.s1;
         A.Chan2M3Kin[p] = O.v2;
-        A.CrossSection2Area[p] = O.csa;
+        if (keep) A.CrossSection2Area[p] = O.csa;
         A.Chan2QKin[p] = O.q2;
     }
     if (s == F.nsteps - 1) {
@@ -610,6 +659,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(LF_
     const int kmax = F.kmax;
     const long long par = (long long)(s & 1) * F.n;
     const int tid = threadIdx.x;
+    const bool rc = derived_recomputable(F);
     cone_out pend;
     pend.valid = false;
     int first_up = 0; // first position of the level above (LDS index 0)
@@ -635,7 +685,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(LF_
         int nfirst = 0;
         if (j + 1 < nl) { // nothing of the next level's state depends on this launch
             nfirst = ld_table(c0, j + 1);
-            cone_load<SPLIT, STRUCT, DIST>(F, nfirst + tid, s, nfirst + tid < ld_table(c1, j + 1), nxt);
+            cone_load<SPLIT, STRUCT, DIST>(F, nfirst + tid, s, nfirst + tid < ld_table(c1, j + 1), nxt, rc);
         }
         if (!cone_skip<SPLIT>(cur)) {
             double ups1, ups2 = 0.0;
@@ -717,13 +767,15 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(LF_
         // the loads of the next level (issued before this level's arithmetic) and the stores of the previous one: done
         // by now.  Stated explicitly so that the compiler does not wait for `nxt` behind the NEXT level's stores.
         __builtin_amdgcn_s_waitcnt(0x0F70);
+        if (rc && j + 1 < nl) cone_derive<SPLIT>(F, nxt); // off the next level's chain: before its barrier
         first_up = first;
         return nfirst;
     };
     cone_cell ra, rb;
     int first = ld_table(c0, 0);
-    cone_load<SPLIT, STRUCT, DIST>(F, first + tid, s, first + tid < ld_table(c1, 0), ra);
+    cone_load<SPLIT, STRUCT, DIST>(F, first + tid, s, first + tid < ld_table(c1, 0), ra, rc);
     __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): inside the loop the current level's registers are always complete
+    if (rc) cone_derive<SPLIT>(F, ra);
     for (int j = 0; j < nl; j += 2) {
         first = level(j, ra, rb, first);
         if (j + 1 < nl) first = level(j + 1, rb, ra, first);

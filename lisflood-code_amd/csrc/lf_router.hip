@@ -237,8 +237,9 @@ struct lf_router {
     int device = 0;
     lf_device_ctx *ctx = nullptr;
     int64_t N = 0, NL = 0;
-    double beta = 0, inv_beta = 0, b_minus_1 = 0, dx_scalar = 0;
+    double beta = 0, inv_beta = 0, b_minus_1 = 0, dx_scalar = 0, dt = 0;
     bool has_floodplains = false, dx_per_pixel = false;
+    lf_dbuf<unsigned int> derived_ok; // fused sub-steps: flag of k_check_derived (fused_args::recompute)
     int kmax = 8;
     bool fused = false; // beta == 3/5: prep fused into the sweep, polynomial closure solve (lf_math.h)
     lf_dbuf<int32_t> perm, ups_ptr;
@@ -703,6 +704,7 @@ int lf_router_create(const lf_graph *g, const double *alpha, double beta, const 
     r->inv_beta = 1 / beta;      // kinematic_wave_parallel.py:125
     r->b_minus_1 = beta - 1;     // :126
     r->dx_scalar = dx_scalar;
+    r->dt = dt;
     r->dx_per_pixel = dx != nullptr;
     r->has_floodplains = alpha_floodplains != nullptr;
     // beta == 3/5 (every LISFLOOD setting): fused prep + polynomial solve.  LF_GENERAL_POW=1 forces the
@@ -1485,6 +1487,8 @@ int fused_impl(lf_router *r, const lf_substep_args *a, int nsteps, int64_t sidef
     F.fb_nblocks = 0;
     F.fb_block0 = 0;
     F.d_ups_base = F.d_ups_idx = F.d_out_slot = nullptr;
+    F.recompute = nullptr;
+    F.dt = r->dt;
     F.use_lvl = 0;
     std::memset(&F.I, 0, sizeof(F.I));
     hipStream_t s = r->ctx->stream;
@@ -1614,6 +1618,17 @@ int fused_impl(lf_router *r, const lf_substep_args *a, int nsteps, int64_t sidef
             hipLaunchKernelGGL(k_inert_flags, dim3(blocks_for(n)), dim3(kBlock), 0, s, (long long)n, *a, r->isolated.p,
                                r->a1.p, r->a2.p, F.dx, r->inert.p);
             F.inert = r->inert.p;
+            ++launches;
+        }
+    }
+    {
+        const char *e = std::getenv("LF_NO_RECOMPUTE"); // A/B switch: stream the derived statics as given
+        if (!(e && e[0] == '1') && nsteps > 1) {
+            if (!r->derived_ok.p) LF_TRY(r->derived_ok.alloc(1));
+            LF_HIP(hipMemsetD32Async((hipDeviceptr_t)r->derived_ok.p, 1, 1, s));
+            hipLaunchKernelGGL(k_check_derived, dim3(blocks_for(n)), dim3(kBlock), 0, s, (long long)n, *a, r->a1.p, r->a2.p,
+                               F.dx, r->dx_scalar, r->dt, r->derived_ok.p);
+            F.recompute = r->derived_ok.p;
             ++launches;
         }
     }
