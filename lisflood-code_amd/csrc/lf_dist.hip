@@ -691,8 +691,9 @@ struct lf_dist_router {
     lf_device_ctx *ctx = nullptr;
     int64_t N = 0, state_size = 0;
     int nphases = 1, kmax = 8;
-    double beta = 0, inv_beta = 0, b_minus_1 = 0, dx_scalar = 0;
+    double beta = 0, inv_beta = 0, b_minus_1 = 0, dx_scalar = 0, dt = 0;
     bool has_floodplains = false, dx_per_pixel = false, fused = false;
+    lf_dbuf<unsigned int> derived_ok; // fused sub-steps: flags of k_check_derived (fused_args::recompute)
     lf_dbuf<int32_t> perm, ups_ptr, ups_idx, ups_base, export_pos[2];
     lf_dbuf<long long> level_start;
     lf_dbuf<double> a1, a2, dx, constant, sendbuf[2];
@@ -806,6 +807,7 @@ int lf_dist_router_create(const lf_dist_graph *g, const double *alpha, double be
     r->inv_beta = 1 / beta;
     r->b_minus_1 = beta - 1;
     r->dx_scalar = dx_scalar;
+    r->dt = dt;
     r->dx_per_pixel = dx != nullptr;
     r->has_floodplains = alpha_floodplains != nullptr;
     const char *force_general = std::getenv("LF_GENERAL_POW");
@@ -1139,6 +1141,18 @@ int dist_fused_prepare(lf_dist_router *r, const lf_substep_args *a, int nsteps)
         r->slab_steps = nsteps;
     }
     if (a->split && !r->slab2.p) LF_TRY(r->slab2.alloc(need));
+    // which derived statics the wavefront may recompute instead of streaming (fused_args::recompute)
+    const char *e = std::getenv("LF_NO_RECOMPUTE");
+    if (r->N > 0 && !(e && e[0] == '1')) {
+        if (!r->derived_ok.p) LF_TRY(r->derived_ok.alloc(1));
+        hipStream_t s = r->ctx->stream;
+        LF_HIP(hipMemsetD32Async((hipDeviceptr_t)r->derived_ok.p, 3, 1, s));
+        hipLaunchKernelGGL(k_check_derived, dim3(blocks_for(r->N)), dim3(kBlock), 0, s, (long long)r->N, *a, r->a1.p, r->a2.p,
+                           r->dx_per_pixel ? r->dx.p : nullptr, r->dx_scalar, r->dt, r->derived_ok.p);
+        LF_HIP(hipGetLastError());
+    } else {
+        r->derived_ok.release();
+    }
     return LF_OK;
 }
 
@@ -1175,6 +1189,8 @@ int dist_fused_phase(lf_dist_router *r, const lf_substep_args *a, int nsteps, in
     F.nlevels = (int)r->h_level_start.size() - 1;
     F.nsteps = nsteps;
     F.solve35 = r->fused ? 1 : 0;
+    F.recompute = r->derived_ok.p;
+    F.dt = r->dt;
     dist_fused_args D;
     D.ups_base = r->ups_base.p;
     D.ups_idx = r->ups_idx_f.p;

@@ -69,13 +69,17 @@ __global__ void __launch_bounds__(kBlock) k_check_derived(long long n, lf_subste
               same_bits(a1[p], A.ChannelAlpha[p] * dxp / dt);
     if (ok && A.split)
         ok = same_bits(A.InvChannelAlpha2[p], 1.0 / A.ChannelAlpha2[p]) && same_bits(a2[p], A.ChannelAlpha2[p] * dxp / dt);
-    if (!ok) *flag = 0u; // benign race: every writer stores the same value
+    if (!ok) atomicAnd(flag, ~1u);
+    // bit 1: the router's space step IS the channel length (kinematicWave(..., ChanLength, ...), routing.py:401-403)
+    if (!dx || !same_bits(dx[p], A.ChanLength[p])) atomicAnd(flag, ~2u);
 }
-__device__ __forceinline__ bool derived_recomputable(const fused_args &F)
+// bit 0: the five derived vectors are recomputed; bit 1: dx is read from ChanLength
+__device__ __forceinline__ unsigned int derived_flags(const fused_args &F)
 {
     typedef const unsigned int __attribute__((address_space(4))) *cptr; // scalar load (nothing in the wavefront writes it)
-    return F.recompute != nullptr && ((cptr)(unsigned long long)F.recompute)[0] != 0u;
+    return F.recompute != nullptr ? ((cptr)(unsigned long long)F.recompute)[0] : 0u;
 }
+__device__ __forceinline__ bool derived_recomputable(const fused_args &F) { return (derived_flags(F) & 1u) != 0u; }
 
 // Non-channel land pixels sit in the channel router as isolated nodes without sideflow (routing.py:512): once their
 // state is zero, a sub-step leaves every vector as it is.  inert[p] marks the candidates (static part of the test);
@@ -160,9 +164,10 @@ __device__ __forceinline__ void fused_cell(const fused_args &F, long long p, int
     const long long par = (long long)(s & 1) * F.n;
     // ---- every load first: the argument pointers are not restrict-qualified, so a store in the middle of the
     // ---- kernel would pin all later loads behind it (the kernel is a stream of ~30 vectors) -------------------
-    const bool rc = derived_recomputable(F); // (uniform)
-    const double dxp = F.dx ? F.dx[p] : F.dx_scalar;
+    const unsigned int dflags = derived_flags(F); // (uniform)
+    const bool rc = (dflags & 1u) != 0u;
     const double len = A.ChanLength[p];
+    const double dxp = (dflags & 2u) ? len : (F.dx ? F.dx[p] : F.dx_scalar);
     const double inv_len = rc ? 1.0 / len : A.InvChanLength[p];
     const bool is_chan = A.IsChannelKinematic[p] != 0;
     const bool cut = F.linked && F.linked[p];
@@ -350,7 +355,8 @@ struct cone_cell { // what a cell's load phase leaves in registers: loaded value
 };
 
 template <bool SPLIT, bool STRUCT, bool DIST = false>
-__device__ __forceinline__ void cone_load(const fused_args &F, long long p, int s, bool active, cone_cell &R, bool rc = false)
+__device__ __forceinline__ void cone_load(const fused_args &F, long long p, int s, bool active, cone_cell &R, bool rc = false,
+                                          bool dx_is_len = false)
 {
     const lf_substep_args &A = F.S;
     R.active = active;
@@ -362,9 +368,10 @@ __device__ __forceinline__ void cone_load(const fused_args &F, long long p, int 
         R.base = F.d_ups_base[p];
         R.slot = F.d_out_slot[p];
     }
-    R.dxp = F.dx ? F.dx[p] : F.dx_scalar;
+    R.dxp = (F.dx && !dx_is_len) ? F.dx[p] : F.dx_scalar; // dx_is_len: taken from ChanLength below (same bits)
     R.inv_len = rc ? 0.0 : A.InvChanLength[p]; // rc: cone_derive fills the five derived values in from len / alpha / dx
     R.len = A.ChanLength[p];
+    if (dx_is_len) R.dxp = R.len;
     R.chan_raw = A.IsChannelKinematic[p];
     R.chanq_old = R.csa_old = R.sf1_old = 0;
     R.inert_raw = R.uptrans_raw = R.cut_raw = 0;
@@ -659,7 +666,8 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(LF_
     const int kmax = F.kmax;
     const long long par = (long long)(s & 1) * F.n;
     const int tid = threadIdx.x;
-    const bool rc = derived_recomputable(F);
+    const unsigned int dflags = derived_flags(F);
+    const bool rc = (dflags & 1u) != 0u, dx_is_len = (dflags & 2u) != 0u;
     cone_out pend;
     pend.valid = false;
     int first_up = 0; // first position of the level above (LDS index 0)
@@ -685,7 +693,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(LF_
         int nfirst = 0;
         if (j + 1 < nl) { // nothing of the next level's state depends on this launch
             nfirst = ld_table(c0, j + 1);
-            cone_load<SPLIT, STRUCT, DIST>(F, nfirst + tid, s, nfirst + tid < ld_table(c1, j + 1), nxt, rc);
+            cone_load<SPLIT, STRUCT, DIST>(F, nfirst + tid, s, nfirst + tid < ld_table(c1, j + 1), nxt, rc, dx_is_len);
         }
         if (!cone_skip<SPLIT>(cur)) {
             double ups1, ups2 = 0.0;
@@ -773,7 +781,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(LF_
     };
     cone_cell ra, rb;
     int first = ld_table(c0, 0);
-    cone_load<SPLIT, STRUCT, DIST>(F, first + tid, s, first + tid < ld_table(c1, 0), ra, rc);
+    cone_load<SPLIT, STRUCT, DIST>(F, first + tid, s, first + tid < ld_table(c1, 0), ra, rc, dx_is_len);
     __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): inside the loop the current level's registers are always complete
     if (rc) cone_derive<SPLIT>(F, ra);
     for (int j = 0; j < nl; j += 2) {

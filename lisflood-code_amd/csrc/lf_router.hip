@@ -1625,7 +1625,7 @@ int fused_impl(lf_router *r, const lf_substep_args *a, int nsteps, int64_t sidef
         const char *e = std::getenv("LF_NO_RECOMPUTE"); // A/B switch: stream the derived statics as given
         if (!(e && e[0] == '1') && nsteps > 1) {
             if (!r->derived_ok.p) LF_TRY(r->derived_ok.alloc(1));
-            LF_HIP(hipMemsetD32Async((hipDeviceptr_t)r->derived_ok.p, 1, 1, s));
+            LF_HIP(hipMemsetD32Async((hipDeviceptr_t)r->derived_ok.p, 3, 1, s));
             hipLaunchKernelGGL(k_check_derived, dim3(blocks_for(n)), dim3(kBlock), 0, s, (long long)n, *a, r->a1.p, r->a2.p,
                                F.dx, r->dx_scalar, r->dt, r->derived_ok.p);
             F.recompute = r->derived_ok.p;
