@@ -545,6 +545,12 @@ int lf_dist_graph_block_stats(const lf_dist_graph *g, int64_t out[4]);
 /* the pieces of a call, for transports other than RCCL and for tests */
 int lf_dist_router_compute_phase(lf_dist_router *r, double *q_ord_dev, const double *lat_ord_dev, int section,
                                  int phase);
+/* one part of a phase: 0 = its boundary-critical cells (the exports of the phase and what drains into them inside the
+ * phase), 1 = the rest; the parts are independent, so lf_dist_router_route runs round j's halo exchange on a second
+ * stream beside part 1 of phase j (LF_DIST_OVERLAP=0: one stream).  part_range: positions [begin, end) of a part. */
+int lf_dist_router_compute_part(lf_dist_router *r, double *q_ord_dev, const double *lat_ord_dev, int section, int phase,
+                                int part);
+int lf_dist_graph_part_range(const lf_dist_graph *g, int phase, int part, int64_t out[2]);
 int lf_dist_router_pack(lf_dist_router *r, const double *q_ord_dev, int round, void *send_ptr[2], int64_t send_count[2]);
 int lf_dist_router_recv_slots(const lf_dist_router *r, int round, int64_t slot[2], int64_t count[2]);
 int lf_dist_router_exchange(lf_dist_router *r, lf_comm *comm, double *q_ord_dev, int round, int rank_top,

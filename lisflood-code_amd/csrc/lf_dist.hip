@@ -52,6 +52,13 @@ struct lf_dist_graph {
     int64_t n_noncontiguous = 0;
     std::vector<int64_t> level_start;     // launch units: runs of equal (phase, height)
     std::vector<int32_t> phase_level;     // [nphases+1] first launch unit of each phase
+    // Inside a phase the cells that some export of the phase depends on (the exports and their same-phase upstream
+    // closure: "boundary-critical") come FIRST, the rest ("bulk") after them.  The two parts are independent of each
+    // other -- a cell has one downstream cell, so nothing outside the closure drains into it and nothing inside it
+    // drains out except through the export -- which lets the halo exchange of round j start after part 0 of phase j
+    // and run beside part 1 (lf_dist_router_route, second stream).  stage = 2 * phase + part.
+    std::vector<uint8_t> crit;            // [N] by local id: 1 = boundary-critical
+    std::vector<int32_t> stage_level;     // [2 * nphases + 1] first launch unit of every stage
     std::vector<int32_t> export_pos[2];   // positions of exports sorted by (phase, column)
     std::vector<int64_t> export_off[2];   // [nphases+1] offsets into export_pos per phase
     std::vector<int64_t> ghost_off[2];    // [nphases+1] offsets (within the side) of ghosts per phase
@@ -283,35 +290,49 @@ int lf_dist_graph_finalize(lf_dist_graph *g, int nphases)
     if (nphases < lf_dist_graph_local_num_phases(g)) return lf_set_error(LF_E_INVALID, "nphases too small");
     const int64_t n = g->N;
     g->nphases = nphases;
-    // order by (phase, level, breadth-first rank): `topo` is already sorted by level with siblings adjacent, a stable
-    // counting sort by phase on top of it keeps that inside every phase (upstream gathers stay nearly contiguous)
+    // boundary-critical cells: the exports and everything of their own phase that drains into them
+    g->crit.assign(n, 0);
+    for (int side = 0; side < 2; ++side)
+        for (int32_t c : g->export_cell[side]) g->crit[c] = 1;
+    for (int64_t t = n - 1; t >= 0; --t) { // downstream before upstream
+        const int32_t c = g->topo[t], d = g->down[c];
+        if (d >= 0 && g->crit[d] && g->phase[d] == g->phase[c]) g->crit[c] = 1;
+    }
+    auto stage_of = [&](int32_t c) { return 2 * g->phase[c] + (g->crit[c] ? 0 : 1); };
+    const int nstages = 2 * nphases;
+    // order by (stage, level, breadth-first rank): `topo` is already sorted by level with siblings adjacent, a stable
+    // counting sort by stage on top of it keeps that inside every stage (the same-stage children of a cell stay one
+    // ascending run: a cell's same-phase children are in its own part)
     const std::vector<int32_t> &tmp = g->topo;
     g->perm.resize(n);
     {
-        std::vector<int64_t> cnt(nphases + 1, 0);
-        for (int64_t p = 0; p < n; ++p) cnt[g->phase[p] + 1]++;
-        for (int j = 0; j < nphases; ++j) cnt[j + 1] += cnt[j];
-        for (int64_t i = 0; i < n; ++i) g->perm[cnt[g->phase[tmp[i]]]++] = tmp[i];
+        std::vector<int64_t> cnt(nstages + 1, 0);
+        for (int64_t p = 0; p < n; ++p) cnt[stage_of((int32_t)p) + 1]++;
+        for (int j = 0; j < nstages; ++j) cnt[j + 1] += cnt[j];
+        for (int64_t i = 0; i < n; ++i) g->perm[cnt[stage_of(tmp[i])]++] = tmp[i];
     }
     g->pos.resize(n);
     for (int64_t p = 0; p < n; ++p) g->pos[g->perm[p]] = (int32_t)p;
-    // launch units and phase boundaries
+    // launch units (runs of equal stage and level), stage and phase boundaries
     g->level_start.clear();
-    g->phase_level.assign(nphases + 1, 0);
+    g->stage_level.assign(nstages + 1, 0);
     {
-        int cur_phase = -1, cur_h = -1;
+        int cur_stage = -1, cur_h = -1;
         for (int64_t p = 0; p < n; ++p) {
             const int32_t c = g->perm[p];
-            if (g->phase[c] != cur_phase || g->height[c] != cur_h) {
-                for (int j = cur_phase + 1; j <= g->phase[c]; ++j) g->phase_level[j] = (int32_t)g->level_start.size();
+            const int st = stage_of(c);
+            if (st != cur_stage || g->height[c] != cur_h) {
+                for (int j = cur_stage + 1; j <= st; ++j) g->stage_level[j] = (int32_t)g->level_start.size();
                 g->level_start.push_back(p);
-                cur_phase = g->phase[c];
+                cur_stage = st;
                 cur_h = g->height[c];
             }
         }
-        for (int j = cur_phase + 1; j <= nphases; ++j) g->phase_level[j] = (int32_t)g->level_start.size();
+        for (int j = cur_stage + 1; j <= nstages; ++j) g->stage_level[j] = (int32_t)g->level_start.size();
         g->level_start.push_back(n);
     }
+    g->phase_level.assign(nphases + 1, 0);
+    for (int j = 0; j <= nphases; ++j) g->phase_level[j] = g->stage_level[2 * j];
     // ghost slots ordered (side, phase, column); exports ordered (phase, column)
     std::vector<int32_t> ghost_slot[2];
     int64_t slot = 0;
@@ -494,6 +515,15 @@ int lf_dist_graph_phase_range(const lf_dist_graph *g, int phase, int64_t out[2])
     if (!g || !g->finalized || phase < 0 || phase >= g->nphases) return lf_set_error(LF_E_INVALID, "bad argument");
     out[0] = g->level_start[g->phase_level[phase]];
     out[1] = g->level_start[g->phase_level[phase + 1]];
+    return LF_OK;
+}
+
+// position range [begin, end) of one part of a phase (0 = boundary-critical, 1 = bulk)
+int lf_dist_graph_part_range(const lf_dist_graph *g, int phase, int part, int64_t out[2])
+{
+    if (!g || !g->finalized || phase < 0 || phase >= g->nphases || part < 0 || part > 1) return lf_set_error(LF_E_INVALID, "bad argument");
+    out[0] = g->level_start[g->stage_level[2 * phase + part]];
+    out[1] = g->level_start[g->stage_level[2 * phase + part + 1]];
     return LF_OK;
 }
 
@@ -698,7 +728,10 @@ struct lf_dist_router {
     lf_dbuf<long long> level_start;
     lf_dbuf<double> a1, a2, dx, constant, sendbuf[2];
     std::vector<int64_t> h_level_start;
-    std::vector<std::vector<dsegment>> schedule; // per phase
+    std::vector<std::vector<dsegment>> schedule; // per stage (2 * phase + part, see lf_dist_graph::crit)
+    // halo exchange beside the bulk part of a phase: second stream + events (lf_dist_router_route)
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_part0 = nullptr, ev_halo = nullptr;
     std::vector<int64_t> export_off[2], ghost_off[2];
     int64_t ghost_base[2] = {0, 0};
     int64_t last_launches = 0;
@@ -716,7 +749,8 @@ struct lf_dist_router {
 
 namespace {
 
-int dist_compute_phase(lf_dist_router *r, double *q, const double *lat, int section, int phase)
+// part: 0 = the boundary-critical cells of the phase, 1 = the rest, -1 = both
+int dist_compute_phase(lf_dist_router *r, double *q, const double *lat, int section, int phase, int part = -1)
 {
     if (section != LF_SECTION_MAIN && section != LF_SECTION_FLOODPLAINS)
         return lf_set_error(LF_E_SECTION, "The section parameter must be either 'main_channel' or 'floodplain'!");
@@ -740,13 +774,14 @@ int dist_compute_phase(lf_dist_router *r, double *q, const double *lat, int sect
     A.kmax = r->kmax;
     A.qord = q;
     A.q_pix = nullptr;
-    if (!r->fused && phase == 0 && r->N > 0) { // general beta: constant for ALL local cells from the old discharge
+    if (!r->fused && phase == 0 && part != 1 && r->N > 0) { // general beta: constant for ALL local cells from the old discharge
         const int n = (int)r->N;
         hipLaunchKernelGGL(k_prep, dim3(blocks_for(n)), dim3(kBlock), 0, s, n, (const int *)nullptr, q, lat, A.a, A.dx,
                            r->dx_scalar, r->beta, r->constant.p);
         r->last_launches++;
     }
-    for (const dsegment &g : r->schedule[phase]) {
+    for (int st = 2 * phase + (part == 1 ? 1 : 0); st <= 2 * phase + (part == 0 ? 0 : 1); ++st)
+    for (const dsegment &g : r->schedule[st]) {
         if (g.wide) {
             const int first = (int)r->h_level_start[g.k0];
             const int count = (int)(r->h_level_start[g.k1] - r->h_level_start[g.k0]);
@@ -770,9 +805,9 @@ int dist_compute_phase(lf_dist_router *r, double *q, const double *lat, int sect
     return LF_OK;
 }
 
-int dist_pack(lf_dist_router *r, const double *q, int round)
+int dist_pack(lf_dist_router *r, const double *q, int round, hipStream_t s = nullptr)
 {
-    hipStream_t s = r->ctx->stream;
+    if (!s) s = r->ctx->stream;
     for (int side = 0; side < 2; ++side) {
         const int64_t a = r->export_off[side][round], b = r->export_off[side][round + 1];
         if (b > a) {
@@ -883,10 +918,10 @@ int lf_dist_router_create(const lf_dist_graph *g, const double *alpha, double be
     }
     r->phase_level = g->phase_level;
     r->h_level_start = g->level_start;
-    r->schedule.resize(g->nphases);
-    for (int j = 0; j < g->nphases; ++j) {
-        const int64_t k_end = g->phase_level[j + 1];
-        for (int64_t k = g->phase_level[j]; k < k_end;) {
+    r->schedule.resize(2 * (size_t)g->nphases);
+    for (int j = 0; j < 2 * g->nphases; ++j) {
+        const int64_t k_end = g->stage_level[j + 1];
+        for (int64_t k = g->stage_level[j]; k < k_end;) {
             const int64_t size = g->level_start[k + 1] - g->level_start[k];
             if (size > kNarrowMax) {
                 r->schedule[j].push_back({(int)k, (int)k + 1, true});
@@ -908,6 +943,12 @@ void lf_dist_router_destroy(lf_dist_router *r)
     if (!r) return;
     (void)hipSetDevice(r->device);
     (void)hipStreamSynchronize(r->ctx->stream);
+    if (r->comm_stream) {
+        (void)hipStreamSynchronize(r->comm_stream);
+        (void)hipStreamDestroy(r->comm_stream);
+    }
+    if (r->ev_part0) (void)hipEventDestroy(r->ev_part0);
+    if (r->ev_halo) (void)hipEventDestroy(r->ev_halo);
     delete r;
 }
 
@@ -946,6 +987,16 @@ int lf_dist_router_compute_phase(lf_dist_router *r, double *q_ord_dev, const dou
     return dist_compute_phase(r, q_ord_dev, lat_ord_dev, section, phase);
 }
 
+// one part of a phase: 0 = the boundary-critical cells (the exports of the phase and what drains into them inside the
+// phase), 1 = the rest; the two are independent of each other
+int lf_dist_router_compute_part(lf_dist_router *r, double *q_ord_dev, const double *lat_ord_dev, int section, int phase,
+                                int part)
+{
+    if (!r || !q_ord_dev || !lat_ord_dev || part < 0 || part > 1) return lf_set_error(LF_E_INVALID, "bad argument");
+    LF_HIP(hipSetDevice(r->device));
+    return dist_compute_phase(r, q_ord_dev, lat_ord_dev, section, phase, part);
+}
+
 // gathers the boundary cells of `round` into the two send buffers; returns their device addresses / counts
 int lf_dist_router_pack(lf_dist_router *r, const double *q_ord_dev, int round, void *send_ptr[2], int64_t send_count[2])
 {
@@ -971,11 +1022,12 @@ int lf_dist_router_recv_slots(const lf_dist_router *r, int round, int64_t slot[2
 }
 
 // pack + RCCL Send/Recv with the rank above (rank_top) and below (rank_bottom); -1 = no neighbour
-int lf_dist_router_exchange(lf_dist_router *r, lf_comm *comm, double *q_ord_dev, int round, int rank_top, int rank_bottom)
+static int dist_exchange(lf_dist_router *r, lf_comm *comm, double *q_ord_dev, int round, int rank_top, int rank_bottom,
+                         hipStream_t s)
 {
     if (!r || !comm || !q_ord_dev || round < 0 || round >= r->nphases) return lf_set_error(LF_E_INVALID, "bad argument");
     LF_HIP(hipSetDevice(r->device));
-    LF_TRY(dist_pack(r, q_ord_dev, round));
+    LF_TRY(dist_pack(r, q_ord_dev, round, s));
     const int peer[2] = {rank_top, rank_bottom};
     bool any = false;
     for (int side = 0; side < 2; ++side) {
@@ -985,7 +1037,6 @@ int lf_dist_router_exchange(lf_dist_router *r, lf_comm *comm, double *q_ord_dev,
         any = any || ns > 0 || nr > 0;
     }
     if (!any) return LF_OK;
-    hipStream_t s = r->ctx->stream;
     LF_NCCL(g_rccl.GroupStart());
     for (int side = 0; side < 2; ++side) {
         const int64_t ns = r->export_off[side][round + 1] - r->export_off[side][round];
@@ -1001,6 +1052,12 @@ int lf_dist_router_exchange(lf_dist_router *r, lf_comm *comm, double *q_ord_dev,
     return LF_OK;
 }
 
+int lf_dist_router_exchange(lf_dist_router *r, lf_comm *comm, double *q_ord_dev, int round, int rank_top, int rank_bottom)
+{
+    if (!r) return lf_set_error(LF_E_INVALID, "null argument");
+    return dist_exchange(r, comm, q_ord_dev, round, rank_top, rank_bottom, r->ctx->stream);
+}
+
 // one kinematicWaveRouting call on the partitioned raster (asynchronous on the library stream)
 int lf_dist_router_route(lf_dist_router *r, lf_comm *comm, double *q_ord_dev, const double *lat_ord_dev, int section,
                          int rank_top, int rank_bottom)
@@ -1008,18 +1065,38 @@ int lf_dist_router_route(lf_dist_router *r, lf_comm *comm, double *q_ord_dev, co
     if (!r || !q_ord_dev || !lat_ord_dev) return lf_set_error(LF_E_INVALID, "null argument");
     LF_HIP(hipSetDevice(r->device));
     r->last_launches = 0;
+    // Two streams (LF_DIST_OVERLAP=0: one): the boundary-critical part of phase j runs first, the round-j halo (pack +
+    // RCCL Send/Recv) then goes to the communication stream and runs BESIDE the bulk part of the phase; phase j + 1 waits
+    // for it.  The packs read export cells (part 0, final), the receives write ghost slots of round j that only later
+    // phases read: no buffer is touched by both streams at once.
+    const char *e = std::getenv("LF_DIST_OVERLAP");
+    const bool overlap = comm && !(e && e[0] == '0');
+    if (overlap && !r->comm_stream) {
+        LF_HIP(hipStreamCreateWithFlags(&r->comm_stream, hipStreamNonBlocking));
+        LF_HIP(hipEventCreateWithFlags(&r->ev_part0, hipEventDisableTiming));
+        LF_HIP(hipEventCreateWithFlags(&r->ev_halo, hipEventDisableTiming));
+    }
+    hipStream_t s = r->ctx->stream;
     for (int j = 0; j < r->nphases; ++j) {
-        LF_TRY(dist_compute_phase(r, q_ord_dev, lat_ord_dev, section, j));
-        if (j + 1 < r->nphases) {
-            if (!comm) {
-                bool any = false;
-                for (int side = 0; side < 2; ++side)
-                    any = any || r->export_off[side][j + 1] > r->export_off[side][j] ||
-                          r->ghost_off[side][j + 1] > r->ghost_off[side][j];
-                if (any) return lf_set_error(LF_E_COMM, "halo exchange needed but no communicator given");
-            } else {
-                LF_TRY(lf_dist_router_exchange(r, comm, q_ord_dev, j, rank_top, rank_bottom));
-            }
+        bool any = false;
+        if (j + 1 < r->nphases)
+            for (int side = 0; side < 2; ++side)
+                any = any || r->export_off[side][j + 1] > r->export_off[side][j] ||
+                      r->ghost_off[side][j + 1] > r->ghost_off[side][j];
+        if (any && !comm) return lf_set_error(LF_E_COMM, "halo exchange needed but no communicator given");
+        if (!any) {
+            LF_TRY(dist_compute_phase(r, q_ord_dev, lat_ord_dev, section, j));
+        } else if (!overlap) {
+            LF_TRY(dist_compute_phase(r, q_ord_dev, lat_ord_dev, section, j));
+            LF_TRY(dist_exchange(r, comm, q_ord_dev, j, rank_top, rank_bottom, s));
+        } else {
+            LF_TRY(dist_compute_phase(r, q_ord_dev, lat_ord_dev, section, j, 0));
+            LF_HIP(hipEventRecord(r->ev_part0, s));
+            LF_HIP(hipStreamWaitEvent(r->comm_stream, r->ev_part0, 0));
+            LF_TRY(dist_exchange(r, comm, q_ord_dev, j, rank_top, rank_bottom, r->comm_stream));
+            LF_HIP(hipEventRecord(r->ev_halo, r->comm_stream));
+            LF_TRY(dist_compute_phase(r, q_ord_dev, lat_ord_dev, section, j, 1));
+            LF_HIP(hipStreamWaitEvent(s, r->ev_halo, 0));
         }
     }
     return LF_OK;

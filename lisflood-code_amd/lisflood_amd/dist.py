@@ -99,6 +99,13 @@ class DistGraph:
         check(lib().lf_dist_graph_phase_range(self._h, C.c_int(phase), o))
         return int(o[0]), int(o[1])
 
+    def part_range(self, phase, part):
+        """positions [begin, end) of a phase's boundary-critical cells (part 0: its exports and what drains into them
+        inside the phase) or of the rest (part 1); the two parts are independent of each other"""
+        o = (C.c_int64 * 2)()
+        check(lib().lf_dist_graph_part_range(self._h, C.c_int(phase), C.c_int(part), o))
+        return int(o[0]), int(o[1])
+
     def round_counts(self, rnd):
         o = (C.c_int64 * 4)()
         check(lib().lf_dist_graph_round_counts(self._h, C.c_int(rnd), o))
@@ -524,6 +531,10 @@ class DistRouter:
         check(lib().lf_dist_router_compute_phase(self._h, q_state.ptr, lat_state.ptr, C.c_int(_lib.SECTION[section]),
                                                  C.c_int(phase)))
 
+    def compute_part(self, q_state, lat_state, phase, part, section="main_channel"):
+        check(lib().lf_dist_router_compute_part(self._h, q_state.ptr, lat_state.ptr, C.c_int(_lib.SECTION[section]),
+                                                C.c_int(phase), C.c_int(part)))
+
     def pack(self, q_state, rnd):
         ptrs = (C.c_void_p * 2)()
         cnt = (C.c_int64 * 2)()
@@ -678,17 +689,28 @@ def loopback_substeps_fused(steps, nsteps):
                                               C.c_void_p(slabs[src_rank] + 8 * so), C.c_size_t(8 * rc)))
 
 
-def loopback_route(routers, q_states, lat_states, section="main_channel"):
+def loopback_route(routers, q_states, lat_states, section="main_channel", overlap_order=False):
     """One call over blocks that all live on ONE GPU in ONE process: the halo exchange is a device-to-device
-    copy instead of RCCL Send/Recv.  Exercises exactly the kernels and the plan of the multi-GPU path."""
+    copy instead of RCCL Send/Recv.  Exercises exactly the kernels and the plan of the multi-GPU path.
+    overlap_order: the order lf_dist_router_route's two streams allow -- a phase's boundary-critical part, the round's
+    packs, then the bulk part, then the copies into the ghost slots."""
     R = len(routers)
     nph = routers[0].graph.num_phases
     dev = routers[0].device
     for j in range(nph):
-        for k in range(R):
-            routers[k].compute_phase(q_states[k], lat_states[k], j, section)
-        if j + 1 < nph:
+        sends = None
+        if overlap_order and j + 1 < nph:
+            for k in range(R):
+                routers[k].compute_part(q_states[k], lat_states[k], j, 0, section)
             sends = [routers[k].pack(q_states[k], j) for k in range(R)]
+            for k in range(R):
+                routers[k].compute_part(q_states[k], lat_states[k], j, 1, section)
+        else:
+            for k in range(R):
+                routers[k].compute_phase(q_states[k], lat_states[k], j, section)
+        if j + 1 < nph:
+            if sends is None:
+                sends = [routers[k].pack(q_states[k], j) for k in range(R)]
             for k in range(R):
                 slots = routers[k].recv_slots(j)
                 # side 0: from the rank above (its bottom send buffer); side 1: from the rank below (its top buffer)

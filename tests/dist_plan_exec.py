@@ -47,6 +47,10 @@ class RankState:
         b, e = self.g.phase_range(j)
         oracle.sweep_positions(self.state, self.constant, self.ups_ptr, self.ups_idx, self.a, self.ba, self.beta, b, e)
 
+    def compute_part(self, j, part):
+        b, e = self.g.part_range(j, part)
+        oracle.sweep_positions(self.state, self.constant, self.ups_ptr, self.ups_idx, self.a, self.ba, self.beta, b, e)
+
     def send_values(self, j, side):
         return self.state[self.g.round_send_positions(j, side)].copy()
 

@@ -107,3 +107,39 @@ def test_fused_model_step_on_row_blocks_config4_shape(amd, family, seed):
         st.free()
     ref.free()
     kw.close()
+
+
+@pytest.mark.parametrize("family,seed,nblocks", [("deep", 2, 3), ("shallow", 1, 4), ("saddle", 6, 3), ("river", 7, 4)])
+def test_router_call_in_the_order_the_two_streams_allow(amd, oracle, family, seed, nblocks):
+    """lf_dist_router_route runs a phase's boundary-critical part, hands the round's halo to a second stream and sweeps
+    the bulk part beside it: the same order on one GPU (packs taken right after part 0, ghost slots filled after part 1)
+    gives the single-domain oracle's discharge, three calls"""
+    from lisflood_amd import dist as D
+    from lisflood_amd import synthetic as syn
+    H, W = 300, 260
+    N = H * W
+    codes = syn.make_ldd(family, H, W, seed)
+    mask = np.ones((H, W), bool)
+    p = syn.router_params(N, seed=6)
+    cpu = oracle.kinematicWave(codes.reshape(-1).astype(np.float64), mask, p["alpha"], p["beta"], p["dx"], p["dt"])
+    blocks = D.row_blocks(H, nblocks)
+    graphs = [D.DistGraph(codes[r0:r1], None, codes[r0 - 1] if r0 > 0 else None, None,
+                          codes[r1] if r1 < H else None, None) for (r0, r1) in blocks]
+    D.settle_phases_local(graphs)
+    sl = [slice(r0 * W, r1 * W) for (r0, r1) in blocks]
+    routers = [D.DistRouter(g, p["alpha"][s], p["beta"], p["dx"][s], p["dt"]) for g, s in zip(graphs, sl)]
+    Qs = [r.new_state(p["Q0"][s]) for r, s in zip(routers, sl)]
+    Qs2 = [r.new_state(p["Q0"][s]) for r, s in zip(routers, sl)]
+    Qc = p["Q0"].copy()
+    for step in range(3):
+        q = syn.lateral_inflow(N, step)
+        lats = [r.new_state(q[s]) for r, s in zip(routers, sl)]
+        D.loopback_route(routers, Qs, lats, overlap_order=True)
+        D.loopback_route(routers, Qs2, lats)
+        cpu.kinematicWaveRouting(Qc, q)
+        got = np.concatenate([r.download_pix(Q) for r, Q in zip(routers, Qs)])
+        got2 = np.concatenate([r.download_pix(Q) for r, Q in zip(routers, Qs2)])
+        assert np.array_equal(got, got2)
+        np.testing.assert_allclose(got, Qc, rtol=1e-9, atol=1e-12)
+        for d in lats:
+            d.free()

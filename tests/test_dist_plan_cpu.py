@@ -317,3 +317,52 @@ def test_phase_major_slab_plan_is_bit_identical_to_single_domain(oracle, family,
     got, nph = run_partitioned_phase_major(codes, mask, nranks, p["alpha"], p["dx"], p["dt"], p["beta"], p["Q0"], qs)
     for a, b in zip(got, ref):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("family,seed,H,W", CASES + [("river", 7, 60, 56)])
+def test_boundary_critical_part_is_independent_of_the_bulk(oracle, family, seed, H, W):
+    """inside a phase the exports and what drains into them (part 0) and the rest (part 1) do not depend on each other:
+    the halo of a round is final after part 0, and the bulk part may run before, beside or after it -- what lets
+    lf_dist_router_route exchange on a second stream beside the bulk of the phase"""
+    nranks = 4
+    codes = syn.make_ldd(family, H, W, seed)
+    mask = np.ones((H, W), bool)
+    N = H * W
+    p = syn.router_params(N, seed=5)
+    qs = [syn.lateral_inflow(N, s) for s in range(2)]
+    ref = global_reference(oracle, codes, mask, p["alpha"], p["dx"], p["dt"], p["beta"], p["Q0"], qs)
+    blocks, graphs = X.build_blocks(codes, mask, nranks)
+    nph = D.settle_phases_local(graphs)
+    sel = [np.arange(r0 * W, r1 * W) for (r0, r1) in blocks]
+    for g in graphs:
+        perm, _ph = g.layout()
+        for j in range(nph):
+            a0, a1 = g.part_range(j, 0)
+            b0, b1 = g.part_range(j, 1)
+            assert (a0, b1) == g.phase_range(j) and a1 == b0
+            for side in (0, 1):                                  # every export of the phase is boundary-critical
+                sp = g.round_send_positions(j, side)
+                assert ((sp >= a0) & (sp < a1)).all()
+    ranks = [X.RankState(g, p["alpha"][s], p["dx"][s], p["dt"], p["beta"], p["Q0"][s]) for g, s in zip(graphs, sel)]
+    for step, q in enumerate(qs):
+        for rk, s in zip(ranks, sel):
+            rk.begin_call(q[s])
+        for j in range(nph):
+            order = (1, 0) if (step + j) % 2 else (0, 1)         # bulk first on odd turns
+            sends = {}
+            for rk_i, rk in enumerate(ranks):
+                for part in order:
+                    rk.compute_part(j, part)
+                    if part == 0 and j + 1 < nph:                # the halo as it is right after part 0
+                        sends[rk_i] = [rk.send_values(j, side) for side in (0, 1)]
+            if j + 1 < nph:
+                for k, rk in enumerate(ranks):
+                    assert all(np.array_equal(sends[k][side], rk.send_values(j, side)) for side in (0, 1))
+                    if k > 0:
+                        rk.recv_values(j, 0, sends[k - 1][1])
+                    if k + 1 < nranks:
+                        rk.recv_values(j, 1, sends[k + 1][0])
+        full = np.empty(N)
+        for rk, s in zip(ranks, sel):
+            full[s] = rk.pixel_values()
+        assert np.array_equal(full, ref[step])
