@@ -35,9 +35,6 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=10000, help="raster is size x size cells")
     ap.add_argument("--family", default="shallow", choices=["shallow", "deep", "river"])
-    ap.add_argument("--layout", default="auto", choices=["auto", "levels", "components"],
-                    help="engine layout of the router: level sweep (one launch per level), component layout (one launch "
-                         "per tier, one wavefront per bin), auto = components when the raster has more than 64 levels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads / soil kernel")
     ap.add_argument("--cpu-sample", type=int, default=2000, help="CPU baseline raster is sample x sample")
@@ -70,11 +67,9 @@ def level_sizes(g):
 SEEDS = {"shallow": 1, "deep": 2, "river": 7}
 
 
-def build_case(family, H, W, layout="auto"):
-    """layout: "levels" = one launch per level (wide levels: the HBM-bound regime), "components" = independent bins of
-    the drainage forest, one wavefront each, one launch per tier (deep / dendritic networks: the launch-latency-bound
-    regime; kept for A/B), "auto" = "levels": runs of narrow levels are swept in blocks of up to 16 levels, cone by cone
-    (k_sweep_cones), wide levels by k_level."""
+def build_case(family, H, W):
+    """the synthetic raster of `family` with a router on it: runs of narrow levels are swept in blocks of up to 64 levels,
+    cone by cone (k_sweep_cones), wide levels one launch each (k_level)"""
     from lisflood_amd import synthetic as syn
     from lisflood_amd.kinematic_wave_parallel import Graph, kinematicWave
     t = time.time()
@@ -82,15 +77,9 @@ def build_case(family, H, W, layout="auto"):
     N = H * W
     p = syn.router_params(N)
     g = Graph(ldd_raster=codes)
-    levels = np.diff(g.layout()[2])
-    if layout == "components":      # ("auto" = "levels": since round 2 the level layout sweeps blocks of levels cone by cone)
-        g.close()
-        g = Graph(ldd_raster=codes, components=True)
-    g.level_widths = levels
+    g.level_widths = np.diff(g.layout()[2])
     kw = kinematicWave(None, None, p["alpha"], p["beta"], p["dx"], p["dt"], graph=g)
-    log("[bench] %s %dx%d: N=%d NL=%d K=%d layout=%s built in %.1f s" % (
-        family, H, W, N, g.num_levels, g.max_upstream, "components %s" % g.components if g.components else "levels",
-        time.time() - t))
+    log("[bench] %s %dx%d: N=%d NL=%d K=%d built in %.1f s" % (family, H, W, N, g.num_levels, g.max_upstream, time.time() - t))
     return kw, p, g
 
 
@@ -140,7 +129,7 @@ def run_routing(kw, p, steps, warmup, nq=3, profile_steps=2, ordered=True):
     for d in qs + [Q]:
         d.free()
     return dict(ms_per_step=(t1 - t0) * 1e3 / steps, event_ms_per_step=ev_ms / steps, prof=prof, stats=stats,
-                finite=ok, profile_steps=profile_steps, components=kw.graph.components, cells=N)
+                finite=ok, profile_steps=profile_steps, cells=N)
 
 
 def pmc_traffic(kernel_key, cells_per_launch):
@@ -205,20 +194,6 @@ def roofline_of(res, kernel_key=None, workload=None):
     workload: key of the committed PMC digest (e.g. "route_deep_10000") for roofline.traffic."""
     prof = res["prof"]
     wide, narrow = prof["wide_level"], prof["narrow_run"]
-    if res.get("components"):       # component layout: the tier launches together sweep every cell once per call
-        ms = wide["ms"] + narrow["ms"]
-        calls = max(res.get("profile_steps", 1), 1)
-        if ms == 0:
-            return None
-        achieved = B_ALG * res["cells"] * calls / (ms * 1e-3) / 1e9
-        return dict(bound="hbm", kernel="k_comp_bins (all tiers of a call)", achieved=round(achieved, 3), peak=HBM_PEAK_GBS,
-                    unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 6), traffic=None, traffic_unit="bytes per call",
-                    traffic_source=None, alg_bytes_per_launch=B_ALG * res["cells"],
-                    launches_per_step=int(round((wide["launches"] + narrow["launches"]) / calls)),
-                    mean_launch_us=round(ms * 1e3 / calls, 3), cells_per_launch=float(res["cells"]),
-                    alg_bytes_per_cell_step=B_ALG, components=res["components"],
-                    note="dependent chain of %d local levels (sum over tiers of the deepest bin): latency-bound, not "
-                         "bandwidth-bound" % res["components"]["chain_levels"])
     dom = wide if wide["ms"] >= narrow["ms"] else narrow
     name = "k_level" if dom is wide else "k_sweep_cones / k_levels_narrow (runs of narrow levels)"
     if dom["launches"] == 0 or dom["ms"] == 0:
@@ -562,7 +537,7 @@ def main():
                 _lib.check(_lib.lib().lf_calibration_copy(C.c_int(0), src.ptr, dst.ptr, C.c_int64(n), C.c_int(width)))
         _lib.synchronize()
         src.free(); dst.free()
-    kw, p, g = build_case(a.family, H, W, a.layout)
+    kw, p, g = build_case(a.family, H, W)
     res = run_routing(kw, p, a.steps, a.warmup)
     N = kw.num_pixels
     value = N / res["ms_per_step"] / 1e3          # Mcell-steps/s
@@ -573,7 +548,7 @@ def main():
         "config": {"workload": "%dx%d fp64 raster, %s LDD (seed %d), all land, beta=0.6, 1 router call per step"
                                % (H, W, {"shallow": "random ('shallow')", "deep": "sheet-flow ('deep')",
                                          "river": "dendritic ('river')"}[a.family], SEEDS[a.family]),
-                   "engine_layout": "components %s" % g.components if g.components else "levels",
+                   "engine_layout": "levels (blocks of levels cone by cone + single wide levels)",
                    "cells": N, "levels": g.num_levels, "level_sizes": level_sizes(g),
                    "launches_per_step": res["stats"]["launches"],
                    "layout": "discharge and lateral inflow resident in HBM in the engine's sweep order "
@@ -609,8 +584,7 @@ def main():
     if not a.no_extra:
         extra = {}
         for other in [f for f in ("deep", "river", "shallow") if f != a.family]:
-            try:    # the other LDD families: level layout (blocks of levels cone by cone); for the deep ones, A/B against
-                    # one launch per level (LF_ROUTE_CONES=0, same router) and against the component layout
+            try:    # the other LDD families
                 entry = {}
 
                 def leg(kw_, p_, wl=None):
@@ -618,20 +592,15 @@ def main():
                     return dict(value=round(kw_.num_pixels / r_["ms_per_step"] / 1e3, 2), unit="Mcell-steps/s",
                                 ms_per_step=round(r_["ms_per_step"], 3), launches_per_step=r_["stats"]["launches"],
                                 roofline=roofline_of(r_, workload=wl))
-                kw2, p2, g2 = build_case(other, H, W, "levels")
-                entry.update(leg(kw2, p2, "route_%s_%d" % (other, H)), levels=g2.num_levels, level_sizes=level_sizes(g2), engine_layout="levels")
-                deep_net = g2.num_levels > 64
-                if deep_net:
+                kw2, p2, g2 = build_case(other, H, W)
+                entry.update(leg(kw2, p2, "route_%s_%d" % (other, H)), levels=g2.num_levels, level_sizes=level_sizes(g2))
+                if g2.num_levels > 64:      # deep networks: A/B against one launch per level (same router)
                     os.environ["LF_ROUTE_CONES"] = "0"
                     try:
                         entry["level_sweep"] = leg(kw2, p2)
                     finally:
                         del os.environ["LF_ROUTE_CONES"]
                 kw2.close()
-                if deep_net:
-                    kw3, p3, g3 = build_case(other, H, W, "components")
-                    entry["component_layout"] = leg(kw3, p3)
-                    kw3.close()
                 extra[other] = entry
             except Exception as e:  # secondary numbers must never break the headline line
                 extra[other + "_error"] = repr(e)

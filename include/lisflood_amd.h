@@ -115,26 +115,6 @@ int lf_graph_create_ex(const double *ldd_codes, const uint8_t *land_mask, int H,
 int lf_graph_get_links(const lf_graph *g, uint8_t *linked);
 /* raster form for large domains: H*W uint8 codes; land_mask may be NULL (= all land). */
 int lf_graph_create_raster(const uint8_t *ldd_raster, const uint8_t *land_mask, int H, int W, lf_graph **out);
-/* Component layout (optional; call before creating routers on the graph).  The cells are regrouped into independent
- * components: tier 0 = every cell whose upstream tree holds <= cap cells, tier 1 = the same rule on what is left, ...
- * The trees of a tier are packed into bins of ~bin_cells cells, a bin is swept by ONE wavefront level after level, all
- * bins of a tier concurrently: a kinematicWaveRouting call is one launch per tier instead of one per level -- what a
- * deep / dendritic network needs.  Routers created afterwards use this layout (lf_graph_get_layout returns its
- * permutation); results are identical to the level layout (same upstream summation order).  cap, bin_cells <= 0:
- * defaults (cap = N/1024 rounded down to a power of two within [2048, 32768], bin_cells = 2048).  Not available for graphs with structure links; the fused sub-step wavefront needs the level
- * layout. */
-int lf_graph_build_components(lf_graph *g, int64_t cap, int64_t bin_cells);
-/* [0] tiers, [1] bins, [2] cells of tier >= 1, [3] most local levels of a bin, [4] sum over tiers of the deepest bin,
- * [5] cap, [6] bin_cells */
-int lf_graph_component_stats(const lf_graph *g, int64_t stats[7]);
-/* the tables of the component layout, for tests and for callers that schedule their own per-bin work: sizes[0] =
- * tiers + 1, [1] = bins, [2] = entries of lvl, [3] = entries of t_ptr, [4] = entries of t_idx.  Bins of tier t are
- * [tier_bin_start[t], tier_bin_start[t+1]); bin b covers positions lvl[bin_lvl_off[b]] .. lvl[bin_lvl_off[b] +
- * bin_nl[b]] with one entry per local level; cells at positions >= trunk_first (tier >= 1) list their upstream
- * positions in t_idx[t_ptr[p - trunk_first] .. t_ptr[p - trunk_first + 1]). */
-int lf_graph_component_sizes(const lf_graph *g, int64_t sizes[5]);
-int lf_graph_get_components(const lf_graph *g, int32_t *tier_bin_start, int32_t *bin_lvl_off, int32_t *bin_nl, int32_t *lvl,
-                            int32_t *t_ptr, int32_t *t_idx, int64_t *trunk_first);
 void lf_graph_destroy(lf_graph *g);
 int64_t lf_graph_num_pixels(const lf_graph *g);   /* N  */
 int64_t lf_graph_num_levels(const lf_graph *g);   /* NL = order_start_stop.shape[0] */
@@ -167,7 +147,7 @@ int lf_router_route_device(lf_router *r, double *discharge_dev, const double *la
 /* `count` (<= 4) routers built on ONE graph -- surface_routing.py:108-113 builds the direct / other / forest overland
  * routers on the same LDD, and calls them one after the other (:151-153) -- swept together: one launch per level for
  * all of them instead of one per router.  engine_order != 0: vectors in sweep order (lf_router_route_ordered).  Routers
- * with different level schedules (or on the component layout) are simply swept one after the other. */
+ * with different level schedules are simply swept one after the other. */
 int lf_router_route_device_multi(int count, lf_router **routers, double **discharge_dev, const double **lateral_dev,
                                  int section, int engine_order);
 /* Engine-order form.  The engine's HBM layout of a per-pixel vector is "sweep order" (levels ascending,

@@ -57,7 +57,6 @@ int lf_ctx(int device, lf_device_ctx **out); // makes `device` current, creates 
 // ascending (level = max distance to outlet - distance, as kinematic_wave_parallel.py:148-149),
 // breadth-first from the outlets inside a level, which makes the upstream cells of position p the
 // contiguous positions [ups_ptr[p], ups_ptr[p+1]) in ascending pixel id.
-struct lf_comp_plan;
 struct lf_graph {
     int H = 0, W = 0;
     int64_t N = 0, NL = 0;
@@ -72,34 +71,9 @@ struct lf_graph {
     // (the fused sub-step wavefront, which stores 0 for them) may run on such a graph.
     std::vector<uint8_t> linked;
     bool has_links = false;
-    lf_comp_plan *comp = nullptr; // component layout (lf_graph_build_components); replaces perm / ups_ptr for routers
-    ~lf_graph();
     lf_graph() = default;
     lf_graph(const lf_graph &) = delete;
     lf_graph &operator=(const lf_graph &) = delete;
-};
-
-// Component layout (lf_graph_build_components): the cells are regrouped into independent COMPONENTS so that a sweep
-// needs no synchronisation between levels other than inside one wavefront.
-//   tier 0    : every cell whose upstream tree holds <= cap cells.  Their trees hang on cells of higher tiers (or end
-//               in an outlet) and are mutually independent.
-//   tier t>0  : the same rule applied to what is left (the "trunk": main stems), counting only cells still left.
-// The trees of a tier are packed into BINS of ~bin_cells cells (deepest trees first); a bin is swept by ONE wavefront,
-// level after level (local level = bin depth - 1 - distance to the tree's root), all bins of a tier concurrently, one
-// launch per tier.  Positions: tier-major, bin-major, local level ascending, breadth-first inside a level -- inside a
-// bin the same-tier upstream cells of position p are again the contiguous range [ups_ptr[p], min(ups_ptr[p+1], first
-// position of the bin's last level)).  Cells of tier > 0 also drain lower-tier roots: their upstream positions come
-// from the index list t_idx[t_ptr[p - trunk_first] .. t_ptr[p - trunk_first + 1]) in ascending pixel id.
-struct lf_comp_plan {
-    int64_t cap = 0, bin_cells = 0;
-    std::vector<int32_t> perm;           // [N] position -> pixel
-    std::vector<int32_t> ups_ptr;        // [N+1] first same-tier upstream position (see above)
-    std::vector<int32_t> tier_bin_start; // [T+1] bins of tier t = [tier_bin_start[t], tier_bin_start[t+1])
-    std::vector<int32_t> bin_lvl_off;    // [B] first entry of the bin in `lvl`
-    std::vector<int32_t> bin_nl;         // [B] number of local levels
-    std::vector<int32_t> lvl;            // per bin nl+1 positions: start of every local level, then the bin's end
-    int64_t trunk_first = 0;             // first position of tier >= 1
-    std::vector<int32_t> t_ptr, t_idx;   // upstream index list of the cells of tier >= 1
 };
 
 template <typename T>

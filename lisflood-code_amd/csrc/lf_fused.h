@@ -15,8 +15,8 @@ struct fused_args {
     const double *__restrict__ a1, *__restrict__ a2, *__restrict__ dx;
     const long long *__restrict__ level_start;
     double *qr1, *qr2; // [2][N] router outputs by sub-step parity (main channel / floodplains)
-    // component layout: router outputs of the tree roots of every tier but the last, one slab per sub-step
-    // ([nsteps][nroots]): the next tier runs after this one has finished ALL its sub-steps
+    // slabs of router outputs kept for EVERY sub-step (row-block partition: what crosses a phase or a rank boundary, see
+    // lf_dist.hip): the value of (slot, sub-step) sits at slot * root_ss + sub-step * root_st
     double *root1, *root2;
     long long nroots;
     long long root_ss, root_st; // slab index of (slot, sub-step) = slot * root_ss + sub-step * root_st
@@ -146,7 +146,7 @@ __device__ __forceinline__ double upstream_sum8(const double *q, int u0, int u1,
 
 // One (cell, sub-step) of the fused sub-steps: everything but the choice of the cell.  `UPS` sums the router outputs of
 // the upstream cells (ascending pixel id) from the parity buffer it is handed: the contiguous range of the level
-// layout, or the ranges / index lists of the component layout.
+// layout, or the index lists and slabs of the row-block partition.
 template <bool SPLIT, bool STRUCT, class UPS>
 __device__ __forceinline__ void fused_cell(const fused_args &F, long long p, int s, const UPS &ups_of,
                                            long long root_slot = -1)

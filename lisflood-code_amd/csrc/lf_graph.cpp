@@ -251,221 +251,6 @@ int lf_graph_create_raster(const uint8_t *ldd_raster, const uint8_t *land_mask, 
     return build(H, W, code, land, true, out);
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// Component layout: see lf_comp_plan in lf_common.h.  Host side, O(N * tiers) with the alive list compacted per tier.
-// ------------------------------------------------------------------------------------------------------------------
-int lf_graph_build_components(lf_graph *g, int64_t cap, int64_t bin_cells)
-{
-    if (!g) return lf_set_error(LF_E_INVALID, "null argument");
-    if (g->has_links)
-        return lf_set_error(LF_E_INVALID, "the component layout is not defined on a graph with structure links");
-    // defaults from A/B runs on MI355X (deep 4000^2 / 10000^2, shallow 4000^2 / 10000^2): a tree bound that grows with
-    // the domain (fewer tiers: the tiers run one after the other) and small bins (more wavefronts in flight)
-    if (cap <= 0) {
-        const int64_t want = std::min<int64_t>(std::max<int64_t>(g->N / 1024, 2048), 32768);
-        cap = 2048;
-        while (cap * 2 <= want) cap *= 2;
-    }
-    if (bin_cells <= 0) bin_cells = 2048;
-    if (cap > (int64_t)1 << 30) cap = (int64_t)1 << 30;
-    const int64_t n = g->N;
-    lf_comp_plan *cp = new (std::nothrow) lf_comp_plan();
-    if (!cp) return lf_set_error(LF_E_INVALID, "out of memory");
-    try {
-        cp->cap = cap;
-        cp->bin_cells = bin_cells;
-        cp->perm.resize(n);
-        cp->ups_ptr.assign(n + 1, 0);
-        cp->tier_bin_start.push_back(0);
-        // upstream adjacency in pixel space, ascending source id
-        std::vector<int32_t> uptr(n + 1, 0);
-        for (int64_t p = 0; p < n; ++p)
-            if (g->down[p] >= 0) uptr[g->down[p] + 1]++;
-        for (int64_t p = 0; p < n; ++p) uptr[p + 1] += uptr[p];
-        std::vector<int32_t> uidx(std::max<int64_t>(uptr[n], 1));
-        {
-            std::vector<int32_t> fill(uptr.begin(), uptr.end() - 1);
-            for (int64_t p = 0; p < n; ++p)
-                if (g->down[p] >= 0) uidx[fill[g->down[p]]++] = (int32_t)p;
-        }
-        std::vector<int16_t> tier(n, -1);
-        std::vector<int32_t> size(n, 0), depth(n, 0), pos(n, -1);
-        std::vector<int32_t> alive(g->perm.begin(), g->perm.end()); // topological order: upstream first
-        std::vector<int32_t> roots, queue, next_alive;
-        std::vector<int64_t> gen_start;
-        int64_t cursor = 0; // next free position
-        int t = 0;
-        while (!alive.empty()) {
-            if (t >= 32000) {
-                delete cp;
-                return lf_set_error(LF_E_INVALID, "component layout: more than 32000 tiers (cap too small for this LDD)");
-            }
-            // 1. sizes and depths of the trees of the cells still alive; tier t = the cells with <= cap alive cells upstream
-            roots.clear();
-            next_alive.clear();
-            for (int32_t pix : alive) {
-                int64_t s = 1;
-                int32_t d = 1;
-                for (int32_t e = uptr[pix]; e < uptr[pix + 1]; ++e) {
-                    const int32_t c = uidx[e];
-                    if (tier[c] >= 0 && tier[c] < t) continue; // an earlier tier: not part of this tree
-                    s += size[c];
-                    if (tier[c] == t && depth[c] + 1 > d) d = depth[c] + 1;
-                }
-                if (s > cap) s = cap + 1;
-                size[pix] = (int32_t)s;
-                depth[pix] = d;
-                if (s <= cap)
-                    tier[pix] = (int16_t)t;
-                else
-                    next_alive.push_back(pix);
-            }
-            for (int32_t pix : alive)
-                if (tier[pix] == t && (g->down[pix] < 0 || tier[g->down[pix]] != t)) roots.push_back(pix);
-            // 2. deepest trees first (counting sort by depth, ties in topological order)
-            {
-                int32_t dmax = 0;
-                for (int32_t r : roots) dmax = std::max(dmax, depth[r]);
-                std::vector<int64_t> cnt((size_t)dmax + 2, 0);
-                for (int32_t r : roots) cnt[dmax - depth[r] + 1]++;
-                for (int32_t d = 0; d <= dmax; ++d) cnt[d + 1] += cnt[d];
-                std::vector<int32_t> sorted(roots.size());
-                for (int32_t r : roots) sorted[cnt[dmax - depth[r]]++] = r;
-                roots.swap(sorted);
-            }
-            if (t == 1) cp->trunk_first = cursor;
-            // 3. bins: consecutive trees until bin_cells cells; layout by breadth-first generations from the roots
-            size_t ri = 0;
-            while (ri < roots.size()) {
-                size_t rj = ri;
-                int64_t cells = 0;
-                while (rj < roots.size() && (cells == 0 || cells + size[roots[rj]] <= bin_cells)) cells += size[roots[rj++]];
-                queue.clear();
-                gen_start.clear();
-                for (size_t i = ri; i < rj; ++i) queue.push_back(roots[i]);
-                gen_start.push_back(0);
-                size_t head = 0;
-                while (head < queue.size()) {
-                    const size_t gen_end = queue.size();
-                    for (; head < gen_end; ++head) {
-                        const int32_t pix = queue[head];
-                        for (int32_t e = uptr[pix]; e < uptr[pix + 1]; ++e)
-                            if (tier[uidx[e]] == t) queue.push_back(uidx[e]);
-                    }
-                    gen_start.push_back((int64_t)gen_end);
-                }
-                const int nl = (int)gen_start.size() - 1; // generations = local levels
-                cp->bin_lvl_off.push_back((int32_t)cp->lvl.size());
-                cp->bin_nl.push_back(nl);
-                int64_t at = cursor;
-                for (int k = 0; k < nl; ++k) { // level k = generation nl-1-k
-                    const int gen = nl - 1 - k;
-                    cp->lvl.push_back((int32_t)at);
-                    for (int64_t i = gen_start[gen]; i < gen_start[gen + 1]; ++i) {
-                        cp->perm[at] = queue[i];
-                        pos[queue[i]] = (int32_t)at;
-                        ++at;
-                    }
-                }
-                cp->lvl.push_back((int32_t)at);
-                // same-tier upstream ranges tile [bin start, start of the last level) in position order
-                int64_t acc = cursor;
-                for (int64_t p = cursor; p < at; ++p) {
-                    cp->ups_ptr[p] = (int32_t)acc;
-                    const int32_t pix = cp->perm[p];
-                    for (int32_t e = uptr[pix]; e < uptr[pix + 1]; ++e) acc += tier[uidx[e]] == t;
-                }
-                cursor = at;
-                ri = rj;
-            }
-            cp->tier_bin_start.push_back((int32_t)cp->bin_nl.size());
-            alive.swap(next_alive);
-            ++t;
-        }
-        cp->ups_ptr[n] = (int32_t)n;
-        if (t <= 1) cp->trunk_first = n;
-        // upstream index lists of the cells of tier >= 1 (all their upstream cells, ascending pixel id)
-        const int64_t nt = n - cp->trunk_first;
-        cp->t_ptr.assign(nt + 1, 0);
-        for (int64_t q = 0; q < nt; ++q) {
-            const int32_t pix = cp->perm[cp->trunk_first + q];
-            cp->t_ptr[q + 1] = cp->t_ptr[q] + (uptr[pix + 1] - uptr[pix]);
-        }
-        cp->t_idx.resize(std::max<int64_t>(cp->t_ptr[nt], 1));
-        for (int64_t q = 0; q < nt; ++q) {
-            const int32_t pix = cp->perm[cp->trunk_first + q];
-            int32_t o = cp->t_ptr[q];
-            for (int32_t e = uptr[pix]; e < uptr[pix + 1]; ++e) cp->t_idx[o++] = pos[uidx[e]];
-        }
-    } catch (const std::bad_alloc &) {
-        delete cp;
-        return lf_set_error(LF_E_INVALID, "out of host memory while building the component layout");
-    }
-    delete g->comp;
-    g->comp = cp;
-    return LF_OK;
-}
-
-/* stats[0] tiers, [1] bins, [2] cells of tier >= 1, [3] largest number of local levels of a bin, [4] sum over tiers of
- * the deepest bin (the dependent chain of a sweep), [5] cap, [6] bin_cells */
-int lf_graph_component_stats(const lf_graph *g, int64_t stats[7])
-{
-    if (!g || !stats) return lf_set_error(LF_E_INVALID, "null argument");
-    if (!g->comp) return lf_set_error(LF_E_INVALID, "the graph has no component layout");
-    const lf_comp_plan &c = *g->comp;
-    const int T = (int)c.tier_bin_start.size() - 1;
-    stats[0] = T;
-    stats[1] = (int64_t)c.bin_nl.size();
-    stats[2] = g->N - c.trunk_first;
-    int64_t deepest = 0, chain = 0;
-    for (int t = 0; t < T; ++t) {
-        int64_t d = 0;
-        for (int32_t b = c.tier_bin_start[t]; b < c.tier_bin_start[t + 1]; ++b) d = std::max<int64_t>(d, c.bin_nl[b]);
-        deepest = std::max(deepest, d);
-        chain += d;
-    }
-    stats[3] = deepest;
-    stats[4] = chain;
-    stats[5] = c.cap;
-    stats[6] = c.bin_cells;
-    return LF_OK;
-}
-
-/* sizes[0] = tiers + 1, [1] = bins, [2] = entries of lvl, [3] = entries of t_ptr, [4] = entries of t_idx: the lengths
- * of the arrays lf_graph_get_components fills (any pointer may be NULL) */
-int lf_graph_component_sizes(const lf_graph *g, int64_t sizes[5])
-{
-    if (!g || !sizes) return lf_set_error(LF_E_INVALID, "null argument");
-    if (!g->comp) return lf_set_error(LF_E_INVALID, "the graph has no component layout");
-    const lf_comp_plan &c = *g->comp;
-    sizes[0] = (int64_t)c.tier_bin_start.size();
-    sizes[1] = (int64_t)c.bin_nl.size();
-    sizes[2] = (int64_t)c.lvl.size();
-    sizes[3] = (int64_t)c.t_ptr.size();
-    sizes[4] = (int64_t)c.t_idx.size();
-    return LF_OK;
-}
-
-int lf_graph_get_components(const lf_graph *g, int32_t *tier_bin_start, int32_t *bin_lvl_off, int32_t *bin_nl, int32_t *lvl,
-                            int32_t *t_ptr, int32_t *t_idx, int64_t *trunk_first)
-{
-    if (!g) return lf_set_error(LF_E_INVALID, "null argument");
-    if (!g->comp) return lf_set_error(LF_E_INVALID, "the graph has no component layout");
-    const lf_comp_plan &c = *g->comp;
-    auto put = [](int32_t *dst, const std::vector<int32_t> &v) {
-        if (dst && !v.empty()) std::memcpy(dst, v.data(), sizeof(int32_t) * v.size());
-    };
-    put(tier_bin_start, c.tier_bin_start);
-    put(bin_lvl_off, c.bin_lvl_off);
-    put(bin_nl, c.bin_nl);
-    put(lvl, c.lvl);
-    put(t_ptr, c.t_ptr);
-    put(t_idx, c.t_idx);
-    if (trunk_first) *trunk_first = c.trunk_first;
-    return LF_OK;
-}
-
-lf_graph::~lf_graph() { delete comp; }
 
 void lf_graph_destroy(lf_graph *g) { delete g; }
 int64_t lf_graph_num_pixels(const lf_graph *g) { return g ? g->N : -1; }
@@ -505,12 +290,6 @@ int lf_graph_get_orders(const lf_graph *g, int64_t *pixels_ordered, int64_t *ord
 int lf_graph_get_layout(const lf_graph *g, int32_t *perm, int32_t *ups_ptr, int64_t *level_start)
 {
     if (!g) return lf_set_error(LF_E_INVALID, "null argument");
-    if (g->comp) { // component layout: the engine order routers on this graph use (level_start stays the reference's)
-        if (perm) std::memcpy(perm, g->comp->perm.data(), sizeof(int32_t) * g->comp->perm.size());
-        if (ups_ptr) std::memcpy(ups_ptr, g->comp->ups_ptr.data(), sizeof(int32_t) * g->comp->ups_ptr.size());
-        if (level_start) std::memcpy(level_start, g->level_start.data(), sizeof(int64_t) * g->level_start.size());
-        return LF_OK;
-    }
     if (perm) std::memcpy(perm, g->perm.data(), sizeof(int32_t) * g->perm.size());
     if (ups_ptr) std::memcpy(ups_ptr, g->ups_ptr.data(), sizeof(int32_t) * g->ups_ptr.size());
     if (level_start) std::memcpy(level_start, g->level_start.data(), sizeof(int64_t) * g->level_start.size());

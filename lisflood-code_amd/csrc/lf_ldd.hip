@@ -19,10 +19,8 @@ struct lf_router_view {
     int device;
     lf_device_ctx *ctx;
     int64_t N;
-    const int32_t *perm, *ups_ptr, *ups_end; // ups_end: component layout only (else ups_ptr[p + 1])
+    const int32_t *perm, *ups_ptr;
     const uint8_t *linked;
-    int64_t trunk_first;                     // component layout: first tier >= 1 position, else N
-    const int32_t *t_ptr, *t_idx;
     int32_t **parent_slot;                   // lazily built parent array, owned by the router
     int32_t **root_slot;                     // lazily built outlet-of-every-cell array, owned by the router
 };
@@ -86,14 +84,8 @@ __global__ void __launch_bounds__(kBlock) k_parents(lf_router_view V, int *__res
 {
     const long long p = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (p >= V.N) return;
-    if (p < V.trunk_first) {
-        const int u1 = V.ups_end ? V.ups_end[p] : V.ups_ptr[p + 1];
-        for (int e = V.ups_ptr[p]; e < u1; ++e)
-            if (!V.linked || !V.linked[e]) parent[e] = (int)p;
-    } else {
-        const long long q = p - V.trunk_first;
-        for (int e = V.t_ptr[q]; e < V.t_ptr[q + 1]; ++e) parent[V.t_idx[e]] = (int)p;
-    }
+    for (int e = V.ups_ptr[p]; e < V.ups_ptr[p + 1]; ++e)
+        if (!V.linked || !V.linked[e]) parent[e] = (int)p;
 }
 
 // out[pixel(p)] = x[pixel(parent(p))], pits keep their own value (PCRaster downstream)

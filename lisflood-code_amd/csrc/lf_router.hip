@@ -51,51 +51,6 @@ __global__ void __launch_bounds__(kBlock) k_upstream_sum(int n, const int *__res
     out_pix[perm[p]] = s;
 }
 
-// the same on the component layout: same-tier range [ups_ptr[p], ups_end[p]) for tier 0, the index list for tier >= 1
-__global__ void __launch_bounds__(kBlock) k_upstream_sum_comp(int n, const int *__restrict__ perm,
-                                                              const int *__restrict__ ups_ptr,
-                                                              const int *__restrict__ ups_end, int trunk_first,
-                                                              const int *__restrict__ t_ptr, const int *__restrict__ t_idx,
-                                                              const double *__restrict__ w_pix, double *__restrict__ out_pix)
-{
-    const int p = blockIdx.x * kBlock + threadIdx.x;
-    if (p >= n) return;
-    double s = 0.0;
-    if (p < trunk_first) {
-        for (int e = ups_ptr[p]; e < ups_end[p]; ++e) s += w_pix[perm[e]];
-    } else {
-        for (int e = t_ptr[p - trunk_first]; e < t_ptr[p - trunk_first + 1]; ++e) s += w_pix[perm[t_idx[e]]];
-    }
-    out_pix[perm[p]] = s;
-}
-
-// accuflux on the component layout: one wavefront per bin, as k_comp_bins
-template <bool TRUNK>
-__global__ void __launch_bounds__(64) k_comp_accu(int bin0, comp_args C, const int *__restrict__ ups_ptr,
-                                                  const double *__restrict__ x_ord, double *acc)
-{
-    const int b = bin0 + (int)blockIdx.x;
-    const int l0 = C.bin_lvl_off[b], nl = C.bin_nl[b];
-    const int lls = C.lvl[l0 + nl - 1];
-    for (int k = 0; k < nl; ++k) {
-        const int first = C.lvl[l0 + k], last = C.lvl[l0 + k + 1];
-        for (int p = first + (int)threadIdx.x; p < last; p += 64) {
-            double s = 0.0;
-            if (TRUNK) {
-                const int q = p - C.trunk_first;
-                for (int e = C.t_ptr[q]; e < C.t_ptr[q + 1]; ++e) s += acc[C.t_idx[e]];
-            } else {
-                int u1 = ups_ptr[p + 1];
-                u1 = u1 < lls ? u1 : lls;
-                for (int e = ups_ptr[p]; e < u1; ++e) s += acc[e];
-            }
-            acc[p] = s + x_ord[p];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    }
-}
-
 // accuflux: acc[p] = x[p] + sum over upstream acc (upstream first, ascending pixel id, then the cell itself); up to
 // kMaxAccu vectors share a sweep (the catchment totals of routing.py:645-691 come four at a time)
 constexpr int kMaxAccu = 4;
@@ -245,16 +200,6 @@ struct lf_router {
     lf_dbuf<int32_t> perm, ups_ptr;
     lf_dbuf<long long> level_start;
     lf_dbuf<double> a1, a2, dx, constant, qord, io_q, io_lat, tmp_ord, fused_qr1, fused_qr2;
-    // component layout (lf_graph_build_components): one launch per tier, one wavefront per bin
-    bool comp = false;
-    lf_dbuf<int32_t> c_bin_lvl_off, c_bin_nl, c_lvl, c_t_ptr, c_t_idx, c_ups_end;
-    // fused sub-steps on the component layout: slot of every bin's last level in the root slabs, the tier >= 1 index
-    // list with lower-tier tributaries as -(slot) - 1, the slabs themselves ([nsteps][nroots] per section)
-    lf_dbuf<int32_t> c_root_base, c_t_idx_fused;
-    lf_dbuf<double> c_root1, c_root2;
-    int64_t c_nroots = 0, c_root_steps = 0;
-    std::vector<int32_t> c_tier_bin_start;
-    int64_t c_trunk_first = 0;
     lf_dbuf<unsigned long long> counter;
     lf_dbuf<uint8_t> linked; // zero-length structure links (lf_graph_create_ex); null without them
     lf_dbuf<int32_t> parent; // [N] downstream position of every position, -1 = outlet (lf_ldd.hip builds it on demand)
@@ -519,46 +464,6 @@ int enqueue_route(lf_router *r, double *q_dev, const double *lat_dev, int sectio
         LF_TRY(r->prof_end());
         ++launches;
     }
-    if (r->comp) {
-        comp_args C;
-        C.bin_lvl_off = r->c_bin_lvl_off.p;
-        C.bin_nl = r->c_bin_nl.p;
-        C.lvl = r->c_lvl.p;
-        C.t_ptr = r->c_t_ptr.p;
-        C.t_idx = r->c_t_idx.p;
-        C.trunk_first = (int)r->c_trunk_first;
-        const int T = (int)r->c_tier_bin_start.size() - 1;
-        for (int t = 0; t < T; ++t) {
-            const int b0 = r->c_tier_bin_start[t], nb = r->c_tier_bin_start[t + 1] - b0;
-            if (nb <= 0) continue;
-            LF_TRY(r->prof_begin(t == 0 ? 1 : 2, 0));
-            const dim3 grid(nb), block(64);
-#define LF_COMP_LAUNCH(TR)                                                                               \
-    do {                                                                                                 \
-        if (r->fused && ordered)                                                                         \
-            hipLaunchKernelGGL((k_comp_bins<true, true, TR>), grid, block, 0, s, b0, C, A);              \
-        else if (r->fused)                                                                               \
-            hipLaunchKernelGGL((k_comp_bins<true, false, TR>), grid, block, 0, s, b0, C, A);             \
-        else if (ordered)                                                                                \
-            hipLaunchKernelGGL((k_comp_bins<false, true, TR>), grid, block, 0, s, b0, C, A);             \
-        else                                                                                             \
-            hipLaunchKernelGGL((k_comp_bins<false, false, TR>), grid, block, 0, s, b0, C, A);            \
-    } while (0)
-            if (t == 0)
-                LF_COMP_LAUNCH(false);
-            else
-                LF_COMP_LAUNCH(true);
-#undef LF_COMP_LAUNCH
-            LF_TRY(r->prof_end());
-            ++launches;
-            ++wide;
-        }
-        r->last_stats[0] = launches;
-        r->last_stats[1] = wide;
-        r->last_stats[2] = 0;
-        r->last_stats[3] = r->NL;
-        return LF_OK;
-    }
     if (r->rb_lmax > 1 && cones_enabled()) {
         sweep_args_multi M;
         for (int i = 0; i < kMaxMulti; ++i) M.r[i] = A;
@@ -713,9 +618,8 @@ int lf_router_create(const lf_graph *g, const double *alpha, double beta, const 
     r->fused = (beta == 0.6) && !(force_general && force_general[0] == '1');
     const int64_t n = g->N;
     int rc = LF_OK;
-    r->comp = g->comp != nullptr;
-    const std::vector<int32_t> &g_perm = g->comp ? g->comp->perm : g->perm;
-    const std::vector<int32_t> &g_ups_ptr = g->comp ? g->comp->ups_ptr : g->ups_ptr;
+    const std::vector<int32_t> &g_perm = g->perm;
+    const std::vector<int32_t> &g_ups_ptr = g->ups_ptr;
     {
         // a_dx_div_dt = alpha * dx / dt, evaluated left to right (:127), permuted into sweep order
         std::vector<double> h(n);
@@ -738,51 +642,6 @@ int lf_router_create(const lf_graph *g, const double *alpha, double beta, const 
     }
     if (rc == LF_OK) rc = r->perm.upload(g_perm.data(), n, ctx->stream);
     if (rc == LF_OK) rc = r->ups_ptr.upload(g_ups_ptr.data(), n + 1, ctx->stream);
-    if (rc == LF_OK && g->comp) {
-        const lf_comp_plan &c = *g->comp;
-        r->c_tier_bin_start = c.tier_bin_start;
-        r->c_trunk_first = c.trunk_first;
-        rc = r->c_bin_lvl_off.upload(c.bin_lvl_off.data(), c.bin_lvl_off.size(), ctx->stream);
-        if (rc == LF_OK) rc = r->c_bin_nl.upload(c.bin_nl.data(), c.bin_nl.size(), ctx->stream);
-        if (rc == LF_OK) rc = r->c_lvl.upload(c.lvl.data(), c.lvl.size(), ctx->stream);
-        if (rc == LF_OK) rc = r->c_t_ptr.upload(c.t_ptr.data(), c.t_ptr.size(), ctx->stream);
-        if (rc == LF_OK) rc = r->c_t_idx.upload(c.t_idx.data(), c.t_idx.size(), ctx->stream);
-        if (rc == LF_OK && c.tier_bin_start.size() > 2) { // more than one tier: root slots for the fused sub-steps
-            const int T = (int)c.tier_bin_start.size() - 1;
-            const size_t B = c.bin_nl.size();
-            std::vector<int32_t> root_base(B, -1), slot_of(n, -1);
-            int64_t slots = 0;
-            for (int t = 0; t + 1 < T; ++t)
-                for (int32_t b = c.tier_bin_start[t]; b < c.tier_bin_start[t + 1]; ++b) {
-                    const int32_t l0 = c.bin_lvl_off[b], nl = c.bin_nl[b];
-                    root_base[b] = (int32_t)slots;
-                    for (int32_t p = c.lvl[l0 + nl - 1]; p < c.lvl[l0 + nl]; ++p) slot_of[p] = (int32_t)slots++;
-                }
-            r->c_nroots = slots;
-            std::vector<int32_t> tf(c.t_idx.size());
-            for (int t = 1; t < T; ++t)
-                for (int32_t b = c.tier_bin_start[t]; b < c.tier_bin_start[t + 1]; ++b) {
-                    const int32_t l0 = c.bin_lvl_off[b], nl = c.bin_nl[b];
-                    const int32_t b_first = c.lvl[l0], b_end = c.lvl[l0 + nl];
-                    for (int32_t p = b_first; p < b_end; ++p)
-                        for (int32_t e = c.t_ptr[p - c.trunk_first]; e < c.t_ptr[p - c.trunk_first + 1]; ++e) {
-                            const int32_t u = c.t_idx[e];
-                            tf[e] = (u >= b_first && u < b_end) ? u : -(slot_of[u] + 1);
-                        }
-                }
-            rc = r->c_root_base.upload(root_base.data(), B, ctx->stream);
-            if (rc == LF_OK) rc = r->c_t_idx_fused.upload(tf.data(), tf.size(), ctx->stream);
-        }
-        if (rc == LF_OK) { // end of every cell's same-tier upstream range (the one-hop reductions read it)
-            std::vector<int32_t> ends(n);
-            for (size_t b = 0; b < c.bin_nl.size(); ++b) {
-                const int32_t l0 = c.bin_lvl_off[b], nl = c.bin_nl[b];
-                const int32_t lls = c.lvl[l0 + nl - 1];
-                for (int32_t p = c.lvl[l0]; p < c.lvl[l0 + nl]; ++p) ends[p] = std::min(c.ups_ptr[p + 1], lls);
-            }
-            rc = r->c_ups_end.upload(ends.data(), n, ctx->stream);
-        }
-    }
     if (rc == LF_OK && g->has_links) rc = r->linked.upload(g->linked.data(), n, ctx->stream);
     if (rc == LF_OK && n > 0) {
         std::vector<uint8_t> has_up(n, 0), iso(n, 0);
@@ -807,10 +666,6 @@ int lf_router_create(const lf_graph *g, const double *alpha, double beta, const 
         return rc;
     }
     r->h_level_start = g->level_start;
-    if (r->comp) { // no level schedule: the sweep runs tier by tier over the bins
-        *out = r;
-        return LF_OK;
-    }
     // launch schedule: runs of narrow levels -> one single-workgroup launch each; wide levels -> one launch per level
     {
         const int64_t NL = g->NL;
@@ -855,7 +710,7 @@ int lf_router_route_device(lf_router *r, double *discharge_dev, const double *la
 
 // Several routers with the same level schedule (built on one lf_graph: e.g. the three overland routers of
 // surface_routing.py:108-113, which differ in alpha only) swept together, one launch per level for all of them.  Routers
-// whose schedules differ, or on the component layout, are swept one after the other.  engine_order != 0: the vectors
+// whose schedules differ are swept one after the other.  engine_order != 0: the vectors
 // are resident in the routers' sweep order (lf_router_route_ordered), else in pixel order (lf_router_route_device).
 int lf_router_route_device_multi(int count, lf_router **routers, double **discharge_dev, const double **lateral_dev,
                                  int section, int engine_order)
@@ -868,7 +723,7 @@ int lf_router_route_device_multi(int count, lf_router **routers, double **discha
     bool together = count > 1 && count <= kMaxMulti;
     for (int i = 0; i < count && together; ++i) {
         const lf_router *r = routers[i], *r0 = routers[0];
-        together = !r->comp && !r->linked.p && r->device == r0->device && r->ctx == r0->ctx && r->N == r0->N &&
+        together = !r->linked.p && r->device == r0->device && r->ctx == r0->ctx && r->N == r0->N &&
                    r->fused == r0->fused && r->h_level_start == r0->h_level_start && !r->profile &&
                    (section == LF_SECTION_MAIN || r->has_floodplains);
     }
@@ -1008,10 +863,7 @@ int lf_upstream_sum_device(lf_router *r, const double *w_dev, double *out_dev)
     if (!r || !w_dev || !out_dev) return lf_set_error(LF_E_INVALID, "null argument");
     LF_HIP(hipSetDevice(r->device));
     const int n = (int)r->N;
-    if (n > 0 && r->comp)
-        hipLaunchKernelGGL(k_upstream_sum_comp, dim3(blocks_for(n)), dim3(kBlock), 0, r->ctx->stream, n, r->perm.p,
-                           r->ups_ptr.p, r->c_ups_end.p, (int)r->c_trunk_first, r->c_t_ptr.p, r->c_t_idx.p, w_dev, out_dev);
-    else if (n > 0)
+    if (n > 0)
         hipLaunchKernelGGL(k_upstream_sum, dim3(blocks_for(n)), dim3(kBlock), 0, r->ctx->stream, n, r->perm.p,
                            r->ups_ptr.p, w_dev, out_dev, (const uint8_t *)r->linked.p);
     LF_HIP(hipGetLastError());
@@ -1045,29 +897,6 @@ int lf_accuflux_ordered_multi_device(lf_router *r, int nv, const double *const *
     LF_HIP(hipSetDevice(r->device));
     hipStream_t s = r->ctx->stream;
     if (r->N == 0) return LF_OK;
-    if (r->comp) {
-        comp_args C;
-        C.bin_lvl_off = r->c_bin_lvl_off.p;
-        C.bin_nl = r->c_bin_nl.p;
-        C.lvl = r->c_lvl.p;
-        C.t_ptr = r->c_t_ptr.p;
-        C.t_idx = r->c_t_idx.p;
-        C.trunk_first = (int)r->c_trunk_first;
-        const int T = (int)r->c_tier_bin_start.size() - 1;
-        for (int v = 0; v < nv; ++v)
-            for (int t = 0; t < T; ++t) {
-                const int b0 = r->c_tier_bin_start[t], nb = r->c_tier_bin_start[t + 1] - b0;
-                if (nb <= 0) continue;
-                if (t == 0)
-                    hipLaunchKernelGGL(k_comp_accu<false>, dim3(nb), dim3(64), 0, s, b0, C, r->ups_ptr.p, x_ord_dev[v],
-                                       acc_ord_dev[v]);
-                else
-                    hipLaunchKernelGGL(k_comp_accu<true>, dim3(nb), dim3(64), 0, s, b0, C, r->ups_ptr.p, x_ord_dev[v],
-                                       acc_ord_dev[v]);
-            }
-        LF_HIP(hipGetLastError());
-        return LF_OK;
-    }
     accu_multi M;
     for (int v = 0; v < kMaxAccu; ++v) {
         M.x[v] = x_ord_dev[v < nv ? v : 0];
@@ -1157,10 +986,8 @@ struct lf_router_view {
     int device;
     lf_device_ctx *ctx;
     int64_t N;
-    const int32_t *perm, *ups_ptr, *ups_end;
+    const int32_t *perm, *ups_ptr;
     const uint8_t *linked;
-    int64_t trunk_first;
-    const int32_t *t_ptr, *t_idx;
     int32_t **parent_slot;
     int32_t **root_slot;
 };
@@ -1174,11 +1001,7 @@ int lf_router_view_of(lf_router *r, lf_router_view *v)
     v->N = r->N;
     v->perm = r->perm.p;
     v->ups_ptr = r->ups_ptr.p;
-    v->ups_end = r->comp ? r->c_ups_end.p : nullptr;
     v->linked = r->linked.p;
-    v->trunk_first = r->comp ? r->c_trunk_first : r->N;
-    v->t_ptr = r->c_t_ptr.p;
-    v->t_idx = r->c_t_idx.p;
     v->parent_slot = &r->parent.p;
     v->root_slot = &r->root.p;
     return LF_OK;
@@ -1352,101 +1175,10 @@ extern "C" int lf_routing_substep(lf_router *r, const lf_substep_args *a)
 
 namespace {
 
-// ---- the same wavefront INSIDE every bin of the component layout ---------------------------------------------------
-// One workgroup (4 wavefronts) per bin walks t = local level + sub-step; the items (level t - s, sub-step s) of one t
-// are packed over its lanes (a thin level has a few cells, but there are up to nsteps of them per t).  Cells read the router
-// outputs of their upstream cells from the parity buffers (same bin, one level up, written at t - 1) or, for the
-// tributaries of a tier >= 1 cell, from the root slabs the lower tiers left behind.  Arithmetic = fused_cell.
-struct comp_fused_args {
-    comp_args C;
-    const int *__restrict__ root_base; // [B] slot of the first cell of the bin's last level in the root slabs, -1 = none
-    int bin0;
-};
-
-constexpr int kCompFusedBlock = 256; // 4 wavefronts share the items of a t: a thin level x 24 sub-steps is one pass
-
-template <bool SPLIT, bool TRUNK>
-__global__ void __launch_bounds__(kCompFusedBlock) k_comp_fused(comp_fused_args G, fused_args F)
-{
-    const comp_args &C = G.C;
-    const int lane = (int)threadIdx.x & 63; // every wavefront lays the items of a t out for itself (same result)
-    const int b = G.bin0 + (int)blockIdx.x;
-    const int l0 = ld_table(C.bin_lvl_off, b), nl = ld_table(C.bin_nl, b);
-    const int lls = ld_table(C.lvl, l0 + nl - 1);
-    const int rbase = G.root_base ? ld_table(G.root_base, b) : -1;
-    const int S = F.nsteps; // <= 64: lane s owns sub-step s while the items of a t are laid out
-    for (int t = 0; t < nl + S - 1; ++t) {
-        // lane s: the level of sub-step s at this t, its first position and width; exclusive prefix = item offset
-        const int k = t - lane;
-        const bool valid = lane < S && k >= 0 && k < nl;
-        const int first = valid ? C.lvl[l0 + k] : 0;
-        const int width = valid ? C.lvl[l0 + k + 1] - first : 0;
-        int incl = width;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int up = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += up;
-        }
-        const int excl = incl - width;
-        const int total = __shfl(incl, 63, 64);
-        for (int base = 0; base < total; base += kCompFusedBlock) {
-            const int i = base + (int)threadIdx.x;
-            // sub-step of item i: the last s whose items start at or before i (empty levels own no item)
-            int s = 0;
-            for (int q = 0; q < S; ++q) {
-                const int eq = __builtin_amdgcn_readlane(excl, q), wq = __builtin_amdgcn_readlane(width, q);
-                s = (wq > 0 && i >= eq) ? q : s;
-            }
-            const int f = __shfl(first, s, 64), e = __shfl(excl, s, 64);
-            if (i < total) {
-                const int p = f + (i - e);
-                const int kmax = F.kmax;
-                const long long slot = (rbase >= 0 && p >= lls) ? (long long)rbase + (p - lls) : -1;
-                if (TRUNK) {
-                    const int q = p - C.trunk_first;
-                    const int u0 = C.t_ptr[q], u1 = C.t_ptr[q + 1];
-                    const int *idx = C.t_idx;
-                    const double *r1 = F.root1 + (long long)s * F.nroots, *r2 = F.root2 + (long long)s * F.nroots;
-                    fused_cell<SPLIT, false>(F, p, s, [=](const double *qr, int section) {
-                        double v[8];
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            double x = 0.0;
-                            if (j < kmax && u0 + j < u1) {
-                                const int src = idx[u0 + j]; // >= 0: position in this bin; < 0: -(root slot) - 1
-                                x = src >= 0 ? qr[src] : (section ? r2 : r1)[-(src + 1)];
-                            }
-                            v[j] = x;
-                        }
-                        double ups = 0.0;
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) ups += v[j];
-                        return ups;
-                    }, slot);
-                } else {
-                    const int u0 = F.ups_ptr[p];
-                    int u1 = F.ups_ptr[p + 1];
-                    u1 = u1 < lls ? u1 : lls;
-                    fused_cell<SPLIT, false>(F, p, s, [=](const double *qr, int) { return upstream_sum8(qr, u0, u1, kmax); },
-                                             slot);
-                }
-            }
-        }
-        __syncthreads(); // workgroup-scope fence + barrier: t + 1 reads what t wrote
-    }
-}
-
-} // namespace
-
-namespace {
-
 int fused_impl(lf_router *r, const lf_substep_args *a, int nsteps, int64_t sideflow_stride, const lf_inloop_args *in)
 {
     if (!r || !a || nsteps < 1) return lf_set_error(LF_E_INVALID, "bad argument");
     if (!a->engine_order) return lf_set_error(LF_E_INVALID, "the fused sub-step wavefront needs engine-order vectors");
-    if (r->comp && (in || nsteps > 64))
-        return lf_set_error(LF_E_INVALID, "on the component layout the fused sub-steps run without structures and with at "
-                            "most 64 sub-steps");
     if (a->split && !r->has_floodplains)
         return lf_set_error(LF_E_SECTION, "split routing requested but the router has no floodplain alpha");
     if (sideflow_stride != 0 && sideflow_stride != r->N) return lf_set_error(LF_E_INVALID, "sideflow_stride must be 0 or N");
@@ -1556,58 +1288,6 @@ int fused_impl(lf_router *r, const lf_substep_args *a, int nsteps, int64_t sidef
         }
     }
     int64_t launches = 0;
-    if (r->comp) { // one launch per tier, one wavefront per bin (k_comp_fused)
-        const char *e = std::getenv("LF_NO_INERT_SKIP");
-        if (r->n_isolated > 0 && nsteps > 1 && !(e && e[0] == '1')) {
-            if (!r->inert.p) LF_TRY(r->inert.alloc(n));
-            hipLaunchKernelGGL(k_inert_flags, dim3(blocks_for(n)), dim3(kBlock), 0, s, (long long)n, *a, r->isolated.p,
-                               r->a1.p, r->a2.p, F.dx, r->inert.p);
-            F.inert = r->inert.p;
-            ++launches;
-        }
-        const int T = (int)r->c_tier_bin_start.size() - 1;
-        if (T > 1 && (r->c_root_steps < nsteps || !r->c_root1.p || (a->split && !r->c_root2.p))) {
-            LF_TRY(r->c_root1.alloc((size_t)nsteps * (size_t)r->c_nroots));
-            if (a->split) LF_TRY(r->c_root2.alloc((size_t)nsteps * (size_t)r->c_nroots));
-            r->c_root_steps = nsteps;
-        }
-        F.root1 = r->c_root1.p;
-        F.root2 = r->c_root2.p;
-        F.nroots = r->c_nroots;
-        F.root_ss = 1;
-        F.root_st = r->c_nroots;
-        F.packed = 0;
-        F.t = 0;
-        comp_fused_args G;
-        G.C.bin_lvl_off = r->c_bin_lvl_off.p;
-        G.C.bin_nl = r->c_bin_nl.p;
-        G.C.lvl = r->c_lvl.p;
-        G.C.t_ptr = r->c_t_ptr.p;
-        G.C.t_idx = r->c_t_idx_fused.p;
-        G.C.trunk_first = (int)r->c_trunk_first;
-        for (int t = 0; t < T; ++t) {
-            const int b0 = r->c_tier_bin_start[t], nb = r->c_tier_bin_start[t + 1] - b0;
-            if (nb <= 0) continue;
-            G.bin0 = b0;
-            G.root_base = (t + 1 < T) ? r->c_root_base.p : nullptr;
-            const dim3 grid(nb), block(kCompFusedBlock);
-            if (t == 0 && a->split)
-                hipLaunchKernelGGL((k_comp_fused<true, false>), grid, block, 0, s, G, F);
-            else if (t == 0)
-                hipLaunchKernelGGL((k_comp_fused<false, false>), grid, block, 0, s, G, F);
-            else if (a->split)
-                hipLaunchKernelGGL((k_comp_fused<true, true>), grid, block, 0, s, G, F);
-            else
-                hipLaunchKernelGGL((k_comp_fused<false, true>), grid, block, 0, s, G, F);
-            ++launches;
-        }
-        LF_HIP(hipGetLastError());
-        r->last_stats[0] = launches;
-        r->last_stats[1] = launches;
-        r->last_stats[2] = 0;
-        r->last_stats[3] = r->NL;
-        return LF_OK;
-    }
     bool grid2d = false;
     {
         const char *e2 = std::getenv("LF_FUSED_2D_GRID"); // A/B switch: one grid row per sub-step, sized by the widest

@@ -122,223 +122,13 @@ __device__ __forceinline__ void sweep_cell(int p, const sweep_args &A)
     if (!ORDERED) A.q_pix[pix] = q;
 }
 
-// ---- component layout (lf_comp_plan, lf_common.h): one wavefront sweeps one bin, level after level --------------
-struct comp_args {
-    const int *__restrict__ bin_lvl_off; // [B]
-    const int *__restrict__ bin_nl;      // [B]
-    const int *__restrict__ lvl;         // level starts of every bin (nl + 1 entries per bin)
-    const int *__restrict__ t_ptr;       // upstream index list of the cells of tier >= 1
-    const int *__restrict__ t_idx;
-    int trunk_first;
-};
-
-// one cell with its upstream positions given explicitly: the contiguous range [u0, u1) (TRUNK = false) or the index
-// list idx[u0 .. u1) (TRUNK = true); otherwise exactly sweep_cell
-template <bool FUSED, bool ORDERED, bool TRUNK>
-__device__ __forceinline__ void sweep_cell_at(int p, int u0, int u1, const int *__restrict__ idx, const sweep_args &A)
-{
-    const int pix = ORDERED ? p : A.perm[p];
-    const double ap = A.a[p];
-    double cst;
-    if (FUSED) {
-        const double lateral = A.lat[pix] * (A.dx ? A.dx[p] : A.dx_scalar);
-        const double qold = ORDERED ? A.qord[p] : A.q_pix[pix];
-        cst = ap * lf_pow_3_5(qold) + lateral;
-    } else {
-        cst = A.constant[p];
-    }
-    double v[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const bool on = k < A.kmax && u0 + k < u1;
-        v[k] = on ? A.qord[TRUNK ? idx[u0 + k] : u0 + k] : 0.0;
-    }
-    double ups = 0.0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) ups += v[k];
-    const double c = ups + cst;
-    double q;
-    if (FUSED && lf_fast_range(c) && lf_fast_range(ap))
-        q = (c <= LF_NEWTON_TOL) ? 0.0 : lf_solve_3_5(c, ap);
-    else
-        q = lf_solve_cell(c, ap, A.beta * ap, A.beta, A.inv_beta, A.b_minus_1);
-    A.qord[p] = q;
-    if (!ORDERED) A.q_pix[pix] = q;
-}
-
-// Read of a table that no kernel of this library ever writes (level tables of the component layout) through the
+// Read of a table that no kernel of this library ever writes (the cone plans of the level blocks) through the
 // constant address space: with a wavefront-uniform index it becomes a scalar load (s_load) instead of a vector load that
 // the compiler, fearing an alias with the discharge stores, would wait for together with every store in flight.
 __device__ __forceinline__ int ld_table(const int *p, int i)
 {
     typedef const int __attribute__((address_space(4))) *const_int_ptr;
     return ((const_int_ptr)(unsigned long long)p)[i];
-}
-
-// The bins [bin0, bin0 + gridDim.x) of one tier: block = one wavefront = one bin, so the levels of a bin depend on
-// each other only through this wavefront's own results and there is nobody to wait for.
-//   * THIN levels (<= 64 cells: one pass of the wavefront; deep and dendritic networks are almost entirely such levels)
-//     never touch memory on their dependent chain: the operands of the bin's cells -- everything that does not depend
-//     on the upstream cells, i.e. alpha*dx/dt, the old-discharge term + lateral inflow, the upstream ranges, for tier
-//     >= 1 also the discharge of lower-tier tributaries -- are prepared 64 POSITIONS at a time (full lanes, coalesced,
-//     independent of the level structure: a bin's positions are consecutive) into an LDS ring indexed by position, the
-//     new discharge goes into a second ring from which the next level reads its upstream cells.  Chain per level:
-//     LDS reads + closure solve + LDS write; the stores to memory are fire-and-forget.
-//   * wider levels run cell by cell from memory behind a workgroup-scope fence (they are throughput work).
-template <bool FUSED, bool ORDERED, bool TRUNK>
-__global__ void __launch_bounds__(64) k_comp_bins(int bin0, comp_args C, sweep_args A)
-{
-    constexpr int R = 128; // ring size in positions: a level and the one before it span < 128 positions
-    __shared__ double s_ap[R], s_cst[R], s_q[R];
-    __shared__ int s_u0[R], s_u1[R];
-    __shared__ int s_src[TRUNK ? 8 : 1][TRUNK ? R : 1];      // tier >= 1: upstream position, -1 none, -2 value below
-    __shared__ double s_val[TRUNK ? 8 : 1][TRUNK ? R : 1];   // tier >= 1: discharge of a lower-tier upstream cell
-    const int lane = (int)threadIdx.x;
-    const int b = bin0 + (int)blockIdx.x;
-    const int l0 = ld_table(C.bin_lvl_off, b), nl = ld_table(C.bin_nl, b);
-    const int bin_first = ld_table(C.lvl, l0), bin_end = ld_table(C.lvl, l0 + nl);
-    const int lls = ld_table(C.lvl, l0 + nl - 1); // first position of the last level: same-tier upstream ranges end here
-    // the level table travels 64 entries at a time in one register per lane (lane j: entry tbase + j) and is read with
-    // v_readlane: no memory operation on the dependent chain of a level
-    int tbase = 0;
-    int tab = C.lvl[l0 + (lane < nl + 1 ? lane : nl)];
-    auto entry = [&](int i) -> int { // i in [tbase, tbase + 64)
-        return __builtin_amdgcn_readlane(tab, i - tbase);
-    };
-    int first = bin_first;
-    bool prev_thin = false; // the level before the current one went through the rings
-    int hi = bin_first;     // operands of the positions below hi are in the ring
-    for (int k = 0; k < nl; ++k) {
-        if (k + 2 >= tbase + 64) { // entries k+1, k+2 are needed below: reload so that they are inside the window
-            tbase = k;
-            const int i = k + lane;
-            tab = C.lvl[l0 + (i < nl + 1 ? i : nl)];
-        }
-        const int last = entry(k + 1);
-        const int next_last = (k + 1 < nl) ? entry(k + 2) : last;
-        if (last - first <= 64) {
-            while (hi < last) { // prepare the next 64 positions of the bin
-                const int p = hi + lane;
-                if (p < bin_end) {
-                    const int slot = p & (R - 1);
-                    const int pix = ORDERED ? p : A.perm[p];
-                    const double ap = A.a[p];
-                    double cst;
-                    if (FUSED) {
-                        const double lateral = A.lat[pix] * (A.dx ? A.dx[p] : A.dx_scalar);
-                        const double qold = ORDERED ? A.qord[p] : A.q_pix[pix];
-                        cst = ap * lf_pow_3_5(qold) + lateral;
-                    } else {
-                        cst = A.constant[p];
-                    }
-                    s_ap[slot] = ap;
-                    s_cst[slot] = cst;
-                    if (TRUNK) {
-                        const int q = p - C.trunk_first;
-                        const int u0 = C.t_ptr[q], u1 = C.t_ptr[q + 1];
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const bool on = j < A.kmax && u0 + j < u1;
-                            const int e = on ? C.t_idx[u0 + j] : 0;
-                            const bool inbin = e >= bin_first && e < bin_end;
-                            s_src[j][slot] = on ? (inbin ? e : -2) : -1;
-                            s_val[j][slot] = (on && !inbin) ? A.qord[e] : 0.0;
-                        }
-                    } else {
-                        const int u1 = A.ups_ptr[p + 1];
-                        s_u0[slot] = A.ups_ptr[p];
-                        s_u1[slot] = u1 < lls ? u1 : lls;
-                    }
-                }
-                hi = (hi + 64 < bin_end) ? hi + 64 : bin_end;
-            }
-            // the block is ONE wavefront and the LDS unit serves a wavefront's operations in issue order: no barrier
-            __builtin_amdgcn_wave_barrier();
-            const bool active = lane < last - first;
-            const int p = first + lane;
-            const int slot = p & (R - 1);
-            const double ap = s_ap[slot], cst = s_cst[slot];
-            // upstream inflow, ascending pixel id; cells of the previous level from the discharge ring, or from memory
-            // if that level was a wide one.  Two separate code paths, each summing inside its own branch: the ring path
-            // must not contain a single memory load, or the compiler parks a wait for every store in flight on it.
-            double ups = 0.0;
-            if (prev_thin) {
-                double v[8];
-                if (TRUNK) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int src = (active && j < A.kmax) ? s_src[j][slot] : -1;
-                        const double val = s_val[j][slot];
-                        const double ring = s_q[(src >= 0 ? src : 0) & (R - 1)];
-                        v[j] = src >= 0 ? ring : (src == -2 ? val : 0.0);
-                    }
-                } else {
-                    const int u0 = s_u0[slot], u1 = s_u1[slot];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const double ring = s_q[(u0 + j) & (R - 1)];
-                        v[j] = (active && j < A.kmax && u0 + j < u1) ? ring : 0.0;
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) ups += v[j];
-            } else {
-                double v[8];
-                if (TRUNK) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int src = (active && j < A.kmax) ? s_src[j][slot] : -1;
-                        double x = 0.0;
-                        if (src >= 0)
-                            x = A.qord[src];
-                        else if (src == -2)
-                            x = s_val[j][slot];
-                        v[j] = x;
-                    }
-                } else {
-                    const int u0 = s_u0[slot], u1 = s_u1[slot];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = (active && j < A.kmax && u0 + j < u1) ? A.qord[u0 + j] : 0.0;
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) ups += v[j];
-            }
-            const double c = ups + cst;
-            double q = 0.0;
-            if (active) {
-                if (FUSED && lf_fast_range(c) && lf_fast_range(ap))
-                    q = (c <= LF_NEWTON_TOL) ? 0.0 : lf_solve_3_5(c, ap);
-                else
-                    q = lf_solve_cell(c, ap, A.beta * ap, A.beta, A.inv_beta, A.b_minus_1);
-                s_q[slot] = q;
-                A.qord[p] = q;
-                if (!ORDERED) A.q_pix[A.perm[p]] = q;
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (k + 1 < nl && next_last - last > 64) { // a wide level reads this one from memory
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            }
-            prev_thin = true;
-        } else {
-            for (int p = first + lane; p < last; p += 64) {
-                if (TRUNK) {
-                    const int q = p - C.trunk_first;
-                    sweep_cell_at<FUSED, ORDERED, true>(p, C.t_ptr[q], C.t_ptr[q + 1], C.t_idx, A);
-                } else {
-                    const int u0 = A.ups_ptr[p];
-                    int u1 = A.ups_ptr[p + 1];
-                    u1 = u1 < lls ? u1 : lls;
-                    sweep_cell_at<FUSED, ORDERED, false>(p, u0, u1, nullptr, A);
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            prev_thin = false;
-            hi = last; // the ring restarts behind a wide level
-        }
-        first = last;
-    }
 }
 
 // one wide level: one cell per lane

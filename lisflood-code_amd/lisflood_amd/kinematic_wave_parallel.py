@@ -25,7 +25,7 @@ except Exception:  # stand-alone
 class Graph:
     """LDD -> adjacency -> routing orders (lf_graph); host memory only."""
 
-    def __init__(self, compressed_encoded_ldd=None, land_mask=None, ldd_raster=None, virtual_down=None, components=None):
+    def __init__(self, compressed_encoded_ldd=None, land_mask=None, ldd_raster=None, virtual_down=None):
         """virtual_down ([N] int, -1 = none; compressed form only): for the pits that structures.py:44-61 cut just
         upstream of a lake / reservoir, the pixel they drain into in the uncut LDD -- they are put on that pixel's
         level (lf_graph_create_ex), which the fused sub-step wavefront with structures needs."""
@@ -49,11 +49,6 @@ class Graph:
                 raise ValueError("virtual_down needs one entry per land pixel")
             check(lib().lf_graph_create_ex(ptr(codes), ptr(m), C.c_int(H), C.c_int(W), ptr(vd), C.byref(self._h)))
         self.shape = (H, W)
-        self.components = None
-        if components:      # True or (cap, bin_cells): the component layout (lf_graph_build_components)
-            cap, bin_cells = (0, 0) if components is True else (int(components[0]), int(components[1]))
-            check(lib().lf_graph_build_components(self._h, C.c_int64(cap), C.c_int64(bin_cells)))
-            self.components = self.component_stats()
         self.num_pixels = int(lib().lf_graph_num_pixels(self._h))
         self.num_levels = int(lib().lf_graph_num_levels(self._h))
         self.max_upstream = int(lib().lf_graph_max_upstream(self._h))
@@ -85,24 +80,6 @@ class Graph:
         check(lib().lf_graph_get_layout(self._h, ptr(perm), ptr(ups_ptr), ptr(level_start)))
         return perm, ups_ptr, level_start
 
-    def component_stats(self):
-        s = (C.c_int64 * 7)()
-        check(lib().lf_graph_component_stats(self._h, s))
-        return dict(tiers=s[0], bins=s[1], trunk_cells=s[2], deepest_bin=s[3], chain_levels=s[4], cap=s[5], bin_cells=s[6])
-
-    def component_tables(self):
-        """dict of the component layout's tables (include/lisflood_amd.h: lf_graph_get_components)"""
-        n = (C.c_int64 * 5)()
-        check(lib().lf_graph_component_sizes(self._h, n))
-        names = ("tier_bin_start", "bin_lvl_off", "bin_nl", "lvl", "t_ptr", "t_idx")
-        sizes = (n[0], n[1], n[1], n[2], n[3], n[4])
-        out = {k: np.zeros(max(int(m), 1), np.int32) for k, m in zip(names, sizes)}
-        tf = C.c_int64(0)
-        check(lib().lf_graph_get_components(self._h, *[ptr(out[k]) for k in names], C.byref(tf)))
-        out = {k: out[k][:int(m)] for k, m in zip(names, sizes)}
-        out["trunk_first"] = tf.value
-        return out
-
     def close(self):
         if self._h:
             lib().lf_graph_destroy(self._h)
@@ -119,7 +96,7 @@ class kinematicWave:
     """See module docstring.  Extra keyword `device` selects the GPU (default 0)."""
 
     def __init__(self, compressed_encoded_ldd, land_mask, alpha_channel, beta, space_delta, time_delta,
-                 alpha_floodplains=None, flagnancheck=False, device=0, graph=None, components=None):
+                 alpha_floodplains=None, flagnancheck=False, device=0, graph=None):
         self.kinematic_wave_warning_printed = False
         self.flagnancheck = flagnancheck
         self.device = device
@@ -127,9 +104,7 @@ class kinematicWave:
         self.beta = beta
         self.inv_beta = 1 / beta
         self.b_minus_1 = beta - 1
-        # components: True / (cap, bin_cells) sweeps independent components instead of global levels (one launch per
-        # tier instead of one per level: deep and dendritic networks); identical results
-        self.graph = graph if graph is not None else Graph(compressed_encoded_ldd, land_mask, components=components)
+        self.graph = graph if graph is not None else Graph(compressed_encoded_ldd, land_mask)
         N = self.graph.num_pixels
         self.num_pixels = N
         alpha = f64(np.broadcast_to(alpha_channel, (N,)))

@@ -191,11 +191,10 @@ class LddDevice:
     """The downstream / catchment operations of one LDD on the device: a router on the LDD's graph with unit parameters
     (kinematicWave also carries upstream_sum and accuflux)."""
 
-    def __init__(self, codes, land_mask, device=0, components=None):
+    def __init__(self, codes, land_mask, device=0):
         from .kinematic_wave_parallel import kinematicWave
         self.N = int(np.asarray(land_mask, bool).sum())
-        self.kw = kinematicWave(np.asarray(codes, np.float64), land_mask, np.ones(self.N), 0.6, 1.0, 1.0, device=device,
-                                components=components)
+        self.kw = kinematicWave(np.asarray(codes, np.float64), land_mask, np.ones(self.N), 0.6, 1.0, 1.0, device=device)
 
     def downstream(self, x):
         from ._lib import check, f64, lib, ptr

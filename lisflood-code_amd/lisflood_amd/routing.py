@@ -202,7 +202,7 @@ class routing(HydroModule):
         feeds = site[ds] & (ds < N)
         return np.where(feeds, ds, -1)
 
-    def attach_router(self, compressed_ldd_kinematic, land_mask, flagnancheck=False, components=None):
+    def attach_router(self, compressed_ldd_kinematic, land_mask, flagnancheck=False):
         """The router construction of initialSecond (routing.py:401-403).  In engine order with lakes or reservoirs
         switched on, the graph also carries their uncut links (Graph(virtual_down=...)), so that dynamic_fused()
         can run the structures inside the wavefront."""
@@ -232,11 +232,6 @@ class routing(HydroModule):
             mask = np.zeros(land_mask.shape, bool)
             mask[land_mask] = keep
         graph = None
-        if components:       # the component layout (lf_graph_build_components); structures need the level layout
-            if self.engine_order and structures:
-                raise ValueError("lakes / reservoirs inside the wavefront need the level layout (components=None)")
-            from .kinematic_wave_parallel import Graph
-            graph = Graph(codes[ids], mask, components=components)
         if self.engine_order and structures:
             from .kinematic_wave_parallel import Graph
             vd = self.structure_links(codes)

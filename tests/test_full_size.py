@@ -55,9 +55,8 @@ def sub_domain(codes_raster, pix, W):
     return codes_raster[r, c].astype(np.float64), mask
 
 
-@pytest.mark.parametrize("family,size,layout", [("shallow", 10000, None), ("deep", 10000, True), ("river", 6000, True),
-                                                ("shallow", 5000, True)])
-def test_catchments_of_the_full_raster_vs_oracle(amd, oracle, family, size, layout):
+@pytest.mark.parametrize("family,size", [("shallow", 10000), ("deep", 10000), ("river", 6000), ("shallow", 5000)])
+def test_catchments_of_the_full_raster_vs_oracle(amd, oracle, family, size):
     from lisflood_amd import synthetic as syn
     from lisflood_amd._lib import DeviceArray
     from lisflood_amd.kinematic_wave_parallel import Graph, kinematicWave
@@ -66,10 +65,10 @@ def test_catchments_of_the_full_raster_vs_oracle(amd, oracle, family, size, layo
     seed = {"shallow": 1, "deep": 2, "river": 7}[family]
     codes = syn.make_ldd(family, H, W, seed)
     p = syn.router_params(N)
-    g = Graph(ldd_raster=codes, components=layout)
+    g = Graph(ldd_raster=codes)
     kw = kinematicWave(None, None, p["alpha"], p["beta"], p["dx"], p["dt"], graph=g)
     perm = g.layout()[0].astype(np.int64)
-    pix, ncatch = pick_catchments(Graph(ldd_raster=codes) if layout else g, np.random.default_rng(5),
+    pix, ncatch = pick_catchments(g, np.random.default_rng(5),
                                   want_cells=150_000 if family != "deep" else 400_000)
     sub_codes, sub_mask = sub_domain(codes, pix, W)
     cpu = oracle.kinematicWave(sub_codes, sub_mask, p["alpha"][pix], p["beta"], p["dx"][pix], p["dt"])

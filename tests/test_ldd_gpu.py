@@ -31,13 +31,12 @@ def case(H=61, W=47):
     return codes, mask
 
 
-@pytest.mark.parametrize("components", [None, (32, 64)])
-def test_downstream_catchment_totals_vs_walks(amd, components):
+def test_downstream_catchment_totals_vs_walks(amd):
     from lisflood_amd import ldd as L
     codes, mask = case()
     N = codes.size
     down = L.downstream_index(codes, mask)
-    d = L.LddDevice(codes, mask, components=components)
+    d = L.LddDevice(codes, mask)
     x = np.random.default_rng(3).uniform(0, 9, N)
     assert np.array_equal(d.downstream(x), np.where(down >= 0, x[np.maximum(down, 0)], x))
     assert np.array_equal(d.downstream(x), L.downstream(codes, mask, x))

@@ -29,15 +29,15 @@ def short(name):
         f = [x.strip() == "true" for x in m.group(2).split(",")] + [False, False, False]
         tag = ("fused" if f[0] else "general") + ("+ordered" if f[1] else "+pixel") + ("+indexed" if f[2] else "")
         return "%s[%s]" % (m.group(1), tag)
-    m = re.search(r"(k_comp_bins|k_comp_fused|k_fused_cones|k_fused_substeps|k_level_multi|k_levels_narrow_multi|k_sweep_cones)<([^>]*)>", name)
-    if m:   # component layout: FUSED (quintic), ORDERED, TRUNK (index-list tier) / fused sub-steps: SPLIT, STRUCT
+    m = re.search(r"(k_fused_cones|k_fused_substeps|k_level_multi|k_levels_narrow_multi|k_sweep_cones)<([^>]*)>", name)
+    if m:   # template flags as 0 / 1 (fused sub-steps: SPLIT, ALL35, STRUCT, DIST; sweeps: FUSED, ORDERED, NR)
         return "%s<%s>" % (m.group(1), ",".join("1" if x.strip() == "true" else "0" if x.strip() == "false" else x.strip()
                                                  for x in m.group(2).split(",")))
     m = re.search(r"k_soil_columns<([^>]*)>", name)
     if m:   # FASTPOW, STAGE
         f = [x.strip() == "true" for x in m.group(1).split(",")] + [False, False]
         return "k_soil_columns[%s]" % ("staging" if f[1] else "plain")
-    for k in ("k_soil_columns_deferred", "k_upstream_sum_comp", "k_comp_accu", "k_jump_init", "k_jump_step", "k_labels",
+    for k in ("k_soil_columns_deferred", "k_accu_cones", "k_jump_init", "k_jump_step", "k_labels",
               "k_take_root", "k_lddrepair", "k_lddmask", "k_parents", "k_downstream", "k_soil_pf", "k_soil_hist", "k_soil_scatter", "k_fused_substeps", "k_canopy", "k_surface_pre",
               "k_surface_post", "k_calib_copy8", "k_calib_copy16", "k_prep", "k_levels_narrow", "k_level", "k_soil_columns", "k_interception", "k_substep",
               "k_halo", "k_gather", "k_scatter"):
