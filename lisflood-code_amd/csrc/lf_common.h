@@ -71,6 +71,7 @@ struct lf_graph {
     // (the fused sub-step wavefront, which stores 0 for them) may run on such a graph.
     std::vector<uint8_t> linked;
     bool has_links = false;
+    uint64_t serial = 0; // identity of this graph object (unique per process): routers swept together must share it
     lf_graph() = default;
     lf_graph(const lf_graph &) = delete;
     lf_graph &operator=(const lf_graph &) = delete;

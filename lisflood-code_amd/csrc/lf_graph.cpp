@@ -6,6 +6,7 @@
 // per level (O(N*NL)); here a single breadth-first pass from the outlets yields the distances, the
 // level sets and the engine's sweep layout at once.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <new>
@@ -45,6 +46,8 @@ int build(int H, int W, CodeAt codes_at, IsLand is_land, bool all_land, lf_graph
     if (H <= 0 || W <= 0) return lf_set_error(LF_E_INVALID, "bad raster shape %d x %d", H, W);
     const int64_t HW = (int64_t)H * W;
     lf_graph *g = new (std::nothrow) lf_graph();
+    static std::atomic<uint64_t> next_serial{1};
+    if (g) g->serial = next_serial.fetch_add(1);
     if (!g) return lf_set_error(LF_E_INVALID, "out of memory");
     g->H = H;
     g->W = W;

@@ -219,7 +219,7 @@ struct lf_router {
     // fb_row[b+1] - fb_row[b] - 1 cones and one more row (the end of every level) in fb_cone, from entry fb_off[b] on,
     // one start per level and row
     std::vector<int> fb_level, fb_row, fb_off;
-    uint64_t topo_hash = 0; // of the graph's level table and (sampled) upstream ranges: same graph <=> same plan
+    uint64_t graph_serial = 0; // lf_graph::serial of the graph the router was built on: same object <=> same plan
     lf_dbuf<int> fb_level_dev, fb_row_dev, fb_cone;
     lf_dbuf<int> fb_off_dev, fb_lvl2blk_dev; // fb_lvl2blk: block of every level (the sites of the structures variant)
     std::vector<int> fb_lvl2blk;
@@ -402,7 +402,7 @@ int enqueue_route_multi(int count, lf_router **rs, double **q_dev, const double 
             ++launches;
         }
     bool same_graph = r->rb_lmax > 1 && cones_enabled();
-    for (int i = 1; i < count; ++i) same_graph = same_graph && rs[i]->topo_hash == r->topo_hash && rs[i]->rb_lmax == r->rb_lmax;
+    for (int i = 1; i < count; ++i) same_graph = same_graph && rs[i]->graph_serial == r->graph_serial && r->graph_serial != 0 && rs[i]->rb_lmax == r->rb_lmax;
     if (same_graph) {
         LF_TRY(enqueue_blocks(count, rs, M, ordered, &launches, &wide, &narrow));
         for (int i = 0; i < count; ++i) {
@@ -582,12 +582,6 @@ static int build_level_blocks(lf_router *r, const lf_graph *g, bool for_route)
     r->fb_row = row;
     r->fb_off = off;
     r->fb_lmax = lmax;
-    uint64_t h = 1469598103934665603ull; // FNV-1a over the level table and every 61st upstream pointer
-    auto mix = [&](uint64_t v) { h = (h ^ v) * 1099511628211ull; };
-    for (int64_t v : g->level_start) mix((uint64_t)v);
-    for (size_t i = 0; i < g->ups_ptr.size(); i += 61) mix((uint64_t)g->ups_ptr[i]);
-    mix((uint64_t)g->ups_ptr.size());
-    r->topo_hash = h;
     return LF_OK;
 }
 
@@ -604,6 +598,7 @@ int lf_router_create(const lf_graph *g, const double *alpha, double beta, const 
     r->ctx = ctx;
     r->N = g->N;
     r->NL = g->NL;
+    r->graph_serial = g->serial; // routers swept together (cone plan and upstream ranges of router 0) must share the graph
     r->kmax = g->K;
     r->beta = beta;
     r->inv_beta = 1 / beta;      // kinematic_wave_parallel.py:125
