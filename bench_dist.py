@@ -83,7 +83,7 @@ def catchment_leg(a, T, rank, world, device):
     T.barrier()
     dt_max = float(T.allreduce(dt_local, "max"))
     Qh = Q.download()
-    ok = T.allreduce(np.array([float(np.isfinite(Qh).all() and (Qh >= 0).all()), float(n)]), "sum")
+    ok = T.allreduce(np.array([float(np.isfinite(Qh).all() and (Qh >= 0).all()), float(n), float(Qh.sum())]), "sum")
     cells = T.allgather(int(n))
     for d in qs + [Q]:
         d.free()
@@ -92,6 +92,7 @@ def catchment_leg(a, T, rank, world, device):
     out = {"value": round(N / ms / 1e3, 2), "unit": "Mcell-steps/s", "ms_per_step": round(ms, 4),
            "cells_per_rank": [int(x) for x in cells], "catchments": int(sizes.size),
            "largest_catchment": int(sizes.max()), "finite": bool(ok[0] == world and int(ok[1]) == N),
+           "checksum_sumQ": float(ok[2]),
            "note": "ranks own whole catchments (no exchange on the data path); engine-order vectors as in the N = 1 run"}
     # configs[4]'s workload shape on the same partition: a model step of 24 split-routing sub-steps as ONE fused wavefront
     # per rank (level blocks + cones), no exchange
@@ -175,6 +176,7 @@ def row_block_model_step(a, T, rank, world, device, graph, comm, N, i0, i1, nste
 
 
 def main(a):
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on these hosts (before HIP starts)
     from lisflood_amd import _lib
     from lisflood_amd import dist as D
     from lisflood_amd import synthetic as syn
@@ -276,6 +278,12 @@ def main(a):
             out["model_step_24_substeps_split_row_blocks"] = row_step
         if catch is not None:
             out["catchment_partition"] = catch
+            if "checksum_sumQ" in catch and catch["checksum_sumQ"]:
+                # the two partitions route the same raster through the same calls and are both bit-identical to the single
+                # domain: their discharge sums agree to summation order -- a halo exchange that lost or misplaced a value
+                # would show here
+                out["row_block_vs_catchment_partition_sumQ_rel_diff"] = abs(float(chk[0]) - catch["checksum_sumQ"]) / abs(
+                    catch["checksum_sumQ"])
     T.barrier()
     comm.close()
     T.close()
