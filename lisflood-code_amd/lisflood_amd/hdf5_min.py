@@ -452,7 +452,12 @@ class _Reader:
         rank1 = d[layout + 2]
         bt = self.u(layout + 3, 8)
         cdims = tuple(self.u(layout + 11 + 4 * i, 4) for i in range(rank1 - 1))
-        out = np.zeros(shape, dt)
+        # chunks that were never written (libhdf5's incremental allocation) have no entry in the B-tree: they read as the
+        # dataset's fill value -- -9999 in LISFLOOD's maps, the cold-start marker of read_state_maps -- not as zeros
+        fill = self.info(name)["fill"]
+        out = np.zeros(shape, dt) if fill is None else np.full(shape, fill, dt)
+        if bt == 0xFFFFFFFFFFFFFFFF:      # undefined address: no chunk allocated at all
+            return out
 
         def walk(node):
             level, used = d[node + 5], self.u(node + 6, 2)

@@ -43,6 +43,18 @@ def make():
     f.close()
 
 
+def make_sparse():
+    """tests/golden/h5py_sparse.h5: a chunked variable with a fill value of which libhdf5 allocated only SOME chunks
+    (incremental allocation: steps 1 and 3 of 4 were never written) and one of which nothing was written at all"""
+    import h5py
+    f = h5py.File(os.path.join(HERE, "h5py_sparse.h5"), "w", libver="earliest")
+    d = f.create_dataset("state", shape=(4, 3, 5), dtype="f8", chunks=(1, 3, 5), fillvalue=-9999.0, compression="gzip")
+    d[0] = np.arange(15, dtype="f8").reshape(3, 5)
+    d[2] = np.arange(15, dtype="f8").reshape(3, 5) * 2.0
+    f.create_dataset("never", shape=(2, 3), dtype="f4", chunks=(1, 3), fillvalue=-1.5)
+    f.close()
+
+
 def check():
     import tempfile
     import h5py
@@ -124,4 +136,4 @@ def refstruct():
 
 
 if __name__ == "__main__":
-    {"make": make, "check": check, "refstruct": refstruct}[sys.argv[1]]()
+    {"make": make, "sparse": make_sparse, "check": check, "refstruct": refstruct}[sys.argv[1]]()

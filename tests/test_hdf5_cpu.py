@@ -130,3 +130,15 @@ def test_same_structure_as_the_reference_dis_nc(tmp_path):
     ids = {int(r.attrs(n)["_Netcdf4Dimid"]): n for n in ("x", "y", "time")}
     assert [ids[i] for i in r.attrs("dis")["_Netcdf4Coordinates"]] == v["dis"]["dims"]
     assert set(ref["root_attrs"]) - {"institution", "creator_name"} <= set(r.attrs())
+
+
+def test_chunks_libhdf5_never_allocated_read_as_the_fill_value():
+    """a file written by libhdf5 (tests/golden/make_hdf5_golden.py sparse) in which two of four chunks of a variable and
+    all chunks of another were never written: they read as the fill value (-9999 = LISFLOOD's cold-start marker), not 0"""
+    r = H5.read(os.path.join(os.path.dirname(GOLD), "h5py_sparse.h5"))
+    a = r.dataset("state")
+    base = np.arange(15, dtype="f8").reshape(3, 5)
+    assert np.array_equal(a[0], base) and np.array_equal(a[2], base * 2.0)
+    assert (a[1] == -9999.0).all() and (a[3] == -9999.0).all()
+    n = r.dataset("never")
+    assert n.shape == (2, 3) and n.dtype == np.float32 and (n == np.float32(-1.5)).all()
