@@ -222,13 +222,14 @@ def main(a):
     log(rank, "rows [%d,%d) cells=%d phases=%d launch_units=%d ghosts=%s exports=%s non-contiguous inflow: %d cells; "
         "setup %.1f s" % (r0, r1, graph.num_pixels, graph.num_phases, graph.num_launch_units, graph.n_ghost,
                           graph.n_export, graph.num_noncontiguous, time.time() - t_setup))
-    for s in range(a.warmup):
-        router.route(Q, qs[s % nq])
+    # the K calls as ONE pipelined sequence (lf_dist_router_route_many: phase 0 of call s + 1 beside the later halo rounds
+    # of call s, alternating state vectors); LF_DIST_OVERLAP=0 or a single phase: call by call
+    if a.warmup:
+        router.route_many(Q, [qs[s % nq] for s in range(a.warmup)])
     _lib.synchronize(device)
     T.barrier()
     t0 = time.perf_counter()
-    for s in range(a.steps):
-        router.route(Q, qs[s % nq])
+    router.route_many(Q, [qs[s % nq] for s in range(a.steps)])
     _lib.synchronize(device)
     dt_local = time.perf_counter() - t0
     T.barrier()
@@ -263,8 +264,9 @@ def main(a):
                                              "river": "dendritic ('river')"}[a.family], seed),
                        "cells": N, "phases": graph.num_phases, "max_launches_per_step": launches,
                        "layout": "engine sweep order per rank, ghost slots appended",
-                       "parallelism": "row-block x%d, RCCL Send/Recv halo per phase; rendezvous over TCP sockets "
-                                      "(no PyTorch in the ranks)" % world},
+                       "parallelism": "row-block x%d, RCCL Send/Recv halo per phase on a second stream, calls pipelined "
+                                      "on alternating state vectors; rendezvous over TCP sockets (no PyTorch in the "
+                                      "ranks)" % world},
             "hbm_frac_whole_step": round(B_ALG * N / (ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), 6),
             # per-GPU algorithmic bandwidth over the WHOLE step (sweeps + packs + RCCL halo rounds), not a
             # per-kernel hipEvent figure: the per-kernel roofline is reported by the N = 1 run

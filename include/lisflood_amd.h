@@ -497,6 +497,15 @@ int lf_dist_router_from_engine_order(lf_dist_router *r, const double *src_ord_de
  * rank_bottom = -1 at the raster's edge.  Asynchronous on the library stream. */
 int lf_dist_router_route(lf_dist_router *r, lf_comm *comm, double *q_ord_dev, const double *lat_ord_dev, int section,
                          int rank_top, int rank_bottom);
+/* ncalls calls in a row (lat_ord_dev[s]: lateral inflow of call s), software-pipelined across calls: successive calls
+ * alternate between the caller's state vector and a second one of the router, so phase 0 of call s + 1 runs beside the
+ * later halo rounds of call s (second stream).  Same result as ncalls calls of lf_dist_router_route, in q_ord_dev.
+ * lf_dist_router_compute_part_io is its building block: one part of a phase with the old discharge read from q_in and
+ * everything else (new discharge, upstream values, ghost slots) in q_out. */
+int lf_dist_router_route_many(lf_dist_router *r, lf_comm *comm, double *q_ord_dev, const double *const *lat_ord_dev, int ncalls,
+                              int section, int rank_top, int rank_bottom);
+int lf_dist_router_compute_part_io(lf_dist_router *r, const double *q_in_dev, double *q_out_dev, const double *lat_ord_dev,
+                                   int section, int phase, int part);
 /* One routing.dynamic() sub-step on the partition (= lf_routing_substep on the whole raster): element-wise stages on
  * the rank's own N cells, each router call with its halo exchanges.  engine_order = 1 (the rank's engine order);
  * a->ChanQKin and a->Chan2QKin are state vectors (lf_dist_router_state_size entries), all others have N entries. */

@@ -732,6 +732,9 @@ struct lf_dist_router {
     // halo exchange beside the bulk part of a phase: second stream + events (lf_dist_router_route)
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_part0 = nullptr, ev_halo = nullptr;
+    // pipelined calls (lf_dist_router_route_many): second state vector, events per (call parity, round)
+    lf_dbuf<double> pp_state;
+    std::vector<hipEvent_t> pp_crit, pp_halo; // [2 * nphases]
     std::vector<int64_t> export_off[2], ghost_off[2];
     int64_t ghost_base[2] = {0, 0};
     int64_t last_launches = 0;
@@ -750,7 +753,8 @@ struct lf_dist_router {
 namespace {
 
 // part: 0 = the boundary-critical cells of the phase, 1 = the rest, -1 = both
-int dist_compute_phase(lf_dist_router *r, double *q, const double *lat, int section, int phase, int part = -1)
+int dist_compute_phase(lf_dist_router *r, double *q, const double *lat, int section, int phase, int part = -1,
+                       const double *q_in = nullptr)
 {
     if (section != LF_SECTION_MAIN && section != LF_SECTION_FLOODPLAINS)
         return lf_set_error(LF_E_SECTION, "The section parameter must be either 'main_channel' or 'floodplain'!");
@@ -774,6 +778,8 @@ int dist_compute_phase(lf_dist_router *r, double *q, const double *lat, int sect
     A.kmax = r->kmax;
     A.qord = q;
     A.q_pix = nullptr;
+    A.qold_src = q_in; // pipelined calls: old discharge from the other state vector (beta = 3/5 path only)
+    if (q_in && !r->fused) return lf_set_error(LF_E_INVALID, "separate input discharge needs the beta = 3/5 path");
     if (!r->fused && phase == 0 && part != 1 && r->N > 0) { // general beta: constant for ALL local cells from the old discharge
         const int n = (int)r->N;
         hipLaunchKernelGGL(k_prep, dim3(blocks_for(n)), dim3(kBlock), 0, s, n, (const int *)nullptr, q, lat, A.a, A.dx,
@@ -949,6 +955,8 @@ void lf_dist_router_destroy(lf_dist_router *r)
     }
     if (r->ev_part0) (void)hipEventDestroy(r->ev_part0);
     if (r->ev_halo) (void)hipEventDestroy(r->ev_halo);
+    for (hipEvent_t e : r->pp_crit) (void)hipEventDestroy(e);
+    for (hipEvent_t e : r->pp_halo) (void)hipEventDestroy(e);
     delete r;
 }
 
@@ -1099,6 +1107,105 @@ int lf_dist_router_route(lf_dist_router *r, lf_comm *comm, double *q_ord_dev, co
             LF_HIP(hipStreamWaitEvent(s, r->ev_halo, 0));
         }
     }
+    return LF_OK;
+}
+
+// one part of a phase with the old discharge read from q_in and everything else (new discharge, upstream values, ghost
+// slots) in q_out: the building block of the pipelined calls, exposed for tests and other transports
+int lf_dist_router_compute_part_io(lf_dist_router *r, const double *q_in_dev, double *q_out_dev, const double *lat_ord_dev,
+                                   int section, int phase, int part)
+{
+    if (!r || !q_in_dev || !q_out_dev || !lat_ord_dev || part < 0 || part > 1) return lf_set_error(LF_E_INVALID, "bad argument");
+    LF_HIP(hipSetDevice(r->device));
+    return dist_compute_phase(r, q_out_dev, lat_ord_dev, section, phase, part, q_in_dev == q_out_dev ? nullptr : q_in_dev);
+}
+
+// ncalls kinematicWaveRouting calls in a row (lat_ord_dev[s] = lateral inflow of call s), software-pipelined: call s
+// reads the old discharge from one state vector and writes the other (the caller's and a second one of the router,
+// alternating), so phase 0 of call s + 1 -- nearly all of the work on a raster with short flow paths -- does not have to
+// wait for the later phases of call s and runs beside their halo rounds.  Order on the compute stream per call s:
+//     [part 0 of phase 0 of call s+1 -> round 0 of call s+1 to the communication stream]
+//     part 0 of phase 1 of call s -> round 1 of call s to the communication stream
+//     [bulk of phase 0 of call s+1]            <- hides both rounds
+//     bulk of phase 1 of call s, phases 2.. of call s (each: wait for the round before, part 0, its round, bulk)
+// Every kernel runs on the compute stream in this order; only the exchanges run beside them, and each touches ghost slots
+// (or export cells) that no kernel between its issue and its wait reads (or writes).  The result -- identical to ncalls
+// calls of lf_dist_router_route -- ends in q_ord_dev.  beta = 3/5 path with a communicator; otherwise call by call.
+int lf_dist_router_route_many(lf_dist_router *r, lf_comm *comm, double *q_ord_dev, const double *const *lat_ord_dev, int ncalls,
+                              int section, int rank_top, int rank_bottom)
+{
+    if (!r || !q_ord_dev || !lat_ord_dev || ncalls < 0) return lf_set_error(LF_E_INVALID, "bad argument");
+    for (int s = 0; s < ncalls; ++s)
+        if (!lat_ord_dev[s]) return lf_set_error(LF_E_INVALID, "null argument");
+    const char *e = std::getenv("LF_DIST_OVERLAP");
+    const bool pipelined = comm && r->fused && r->nphases > 1 && ncalls > 1 && !(e && e[0] == '0');
+    if (!pipelined) {
+        for (int s = 0; s < ncalls; ++s)
+            LF_TRY(lf_dist_router_route(r, comm, q_ord_dev, lat_ord_dev[s], section, rank_top, rank_bottom));
+        return LF_OK;
+    }
+    LF_HIP(hipSetDevice(r->device));
+    const int P = r->nphases;
+    if (!r->comm_stream) LF_HIP(hipStreamCreateWithFlags(&r->comm_stream, hipStreamNonBlocking));
+    if (r->pp_crit.empty()) {
+        r->pp_crit.assign(2 * (size_t)P, nullptr);
+        r->pp_halo.assign(2 * (size_t)P, nullptr);
+        for (size_t i = 0; i < r->pp_crit.size(); ++i) {
+            LF_HIP(hipEventCreateWithFlags(&r->pp_crit[i], hipEventDisableTiming));
+            LF_HIP(hipEventCreateWithFlags(&r->pp_halo[i], hipEventDisableTiming));
+        }
+    }
+    if (!r->pp_state.p) {
+        LF_TRY(r->pp_state.alloc((size_t)std::max<int64_t>(r->state_size, 1)));
+        LF_HIP(hipMemsetAsync(r->pp_state.p, 0, sizeof(double) * (size_t)std::max<int64_t>(r->state_size, 1), r->ctx->stream));
+    }
+    hipStream_t s0 = r->ctx->stream;
+    double *B[2] = {q_ord_dev, r->pp_state.p};
+    r->last_launches = 0;
+    auto traffic = [&](int j) {
+        if (j + 1 >= P) return false;
+        for (int side = 0; side < 2; ++side)
+            if (r->export_off[side][j + 1] > r->export_off[side][j] || r->ghost_off[side][j + 1] > r->ghost_off[side][j]) return true;
+        return false;
+    };
+    // call c: in = B[c & 1], out = B[(c + 1) & 1]
+    auto part = [&](int c, int j, int pt) {
+        return dist_compute_phase(r, B[(c + 1) & 1], lat_ord_dev[c], section, j, pt, B[c & 1]);
+    };
+    auto issue_round = [&](int c, int j) -> int { // after part 0 of phase j of call c
+        if (!traffic(j)) return LF_OK;
+        hipEvent_t ec = r->pp_crit[(size_t)(c & 1) * P + j], eh = r->pp_halo[(size_t)(c & 1) * P + j];
+        LF_HIP(hipEventRecord(ec, s0));
+        LF_HIP(hipStreamWaitEvent(r->comm_stream, ec, 0));
+        LF_TRY(dist_exchange(r, comm, B[(c + 1) & 1], j, rank_top, rank_bottom, r->comm_stream));
+        LF_HIP(hipEventRecord(eh, r->comm_stream));
+        return LF_OK;
+    };
+    auto wait_round = [&](int c, int j) -> int { // before phase j + 1 of call c
+        if (!traffic(j)) return LF_OK;
+        LF_HIP(hipStreamWaitEvent(s0, r->pp_halo[(size_t)(c & 1) * P + j], 0));
+        return LF_OK;
+    };
+    LF_TRY(part(0, 0, 0));
+    LF_TRY(issue_round(0, 0));
+    LF_TRY(part(0, 0, 1));
+    for (int c = 0; c < ncalls; ++c) {
+        const bool next = c + 1 < ncalls;
+        if (next) {
+            LF_TRY(part(c + 1, 0, 0));
+            LF_TRY(issue_round(c + 1, 0));
+        }
+        for (int j = 1; j < P; ++j) {
+            LF_TRY(wait_round(c, j - 1));
+            LF_TRY(part(c, j, 0));
+            LF_TRY(issue_round(c, j));
+            if (j == 1 && next) LF_TRY(part(c + 1, 0, 1));
+            LF_TRY(part(c, j, 1));
+        }
+    }
+    if (ncalls & 1) // the last call wrote the router's vector: hand the result back in the caller's
+        LF_HIP(hipMemcpyAsync(q_ord_dev, r->pp_state.p, sizeof(double) * (size_t)r->N, hipMemcpyDeviceToDevice, s0));
+    LF_HIP(hipGetLastError());
     return LF_OK;
 }
 

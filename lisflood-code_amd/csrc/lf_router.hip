@@ -308,6 +308,7 @@ sweep_args make_sweep_args(lf_router *r, double *q_dev, const double *lat_dev, i
     A.kmax = r->kmax;
     A.qord = ordered ? q_dev : r->qord.p;
     A.q_pix = ordered ? nullptr : q_dev;
+    A.qold_src = nullptr;
     return A;
 }
 

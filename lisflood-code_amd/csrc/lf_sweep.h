@@ -70,6 +70,10 @@ struct sweep_args {
     int kmax;     // max in-degree of the graph (<= 8)
     double *qord; // discharge in sweep order: upstream values are read from it, the new value is written to it
     double *q_pix; // pixel-order I/O: caller's discharge vector (old value in, new value out); unused if ORDERED
+    // INDEXED only (row-block partition, pipelined calls): the old discharge is read from here instead of qord when not
+    // null -- successive calls ping-pong between two state vectors so that a call may start before the one before it has
+    // finished its later phases (lf_dist_router_route_many)
+    const double *qold_src;
 };
 
 // One cell of the implicit sweep.
@@ -91,7 +95,7 @@ __device__ __forceinline__ void sweep_cell(int p, const sweep_args &A)
     double cst;
     if (FUSED) {
         const double lateral = A.lat[pix] * (A.dx ? A.dx[p] : A.dx_scalar);
-        const double qold = ORDERED ? A.qord[p] : A.q_pix[pix];
+        const double qold = ORDERED ? ((INDEXED && A.qold_src) ? A.qold_src[p] : A.qord[p]) : A.q_pix[pix];
         cst = ap * lf_pow_3_5(qold) + lateral;
     } else {
         cst = A.constant[p];

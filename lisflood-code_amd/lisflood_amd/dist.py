@@ -526,6 +526,19 @@ class DistRouter:
         check(lib().lf_dist_router_route(self._h, ch, q_state.ptr, lat_state.ptr, C.c_int(sec), C.c_int(self.rank_top),
                                          C.c_int(self.rank_bottom)))
 
+    def route_many(self, q_state, lat_states, section="main_channel"):
+        """len(lat_states) calls in a row, pipelined across calls (lf_dist_router_route_many); result in q_state"""
+        sec = _lib.SECTION[section]
+        ch = self.comm._h if self.comm is not None else None
+        n = len(lat_states)
+        arr = (C.c_void_p * max(n, 1))(*[d.ptr.value for d in lat_states])
+        check(lib().lf_dist_router_route_many(self._h, ch, q_state.ptr, arr, C.c_int(n), C.c_int(sec),
+                                              C.c_int(self.rank_top), C.c_int(self.rank_bottom)))
+
+    def compute_part_io(self, q_in, q_out, lat_state, phase, part, section="main_channel"):
+        check(lib().lf_dist_router_compute_part_io(self._h, q_in.ptr, q_out.ptr, lat_state.ptr,
+                                                   C.c_int(_lib.SECTION[section]), C.c_int(phase), C.c_int(part)))
+
     # pieces, for the in-process loopback
     def compute_phase(self, q_state, lat_state, phase, section="main_channel"):
         check(lib().lf_dist_router_compute_phase(self._h, q_state.ptr, lat_state.ptr, C.c_int(_lib.SECTION[section]),
@@ -687,6 +700,75 @@ def loopback_substeps_fused(steps, nsteps):
                     assert sc == rc, (k, j, side, sc, rc)
                     check(lib().lf_memcpy_d2d(C.c_int(dev), C.c_void_p(slabs[k] + 8 * ro),
                                               C.c_void_p(slabs[src_rank] + 8 * so), C.c_size_t(8 * rc)))
+
+
+def loopback_route_many(routers, q_states, lat_lists, late_halo=False, section="main_channel"):
+    """lf_dist_router_route_many's schedule over blocks that live on one GPU: the same kernels in the same order on the
+    two alternating state vectors, every halo round as a device copy -- performed right where the communication stream
+    could first run it (late_halo=False) or right where the compute stream waits for it (late_halo=True): the two ends of
+    the window in which the real exchange may land.  lat_lists[k] = the lateral inflow vectors of block k, one per call.
+    The result ends in q_states (as the C function leaves it)."""
+    R = len(routers)
+    P = routers[0].graph.num_phases
+    K = len(lat_lists[0])
+    dev = routers[0].device
+    if P < 2 or K < 2:
+        for c in range(K):
+            loopback_route(routers, q_states, [l[c] for l in lat_lists], section)
+        return
+    second = [DeviceArray(max(r.state_size, 1), np.float64, dev).zero() for r in routers]
+    B = [q_states, second]
+    pending = {}
+
+    def part(c, j, pt):
+        for k in range(R):
+            routers[k].compute_part_io(B[c & 1][k], B[(c + 1) & 1][k], lat_lists[k][c], j, pt, section)
+
+    def do_round(c, j):
+        out = B[(c + 1) & 1]
+        sends = [routers[k].pack(out[k], j) for k in range(R)]
+        for k in range(R):
+            slots = routers[k].recv_slots(j)
+            for side, src_rank, src_side in ((0, k - 1, 1), (1, k + 1, 0)):
+                slot, n = slots[side]
+                if n == 0:
+                    continue
+                sp, sn = sends[src_rank][src_side]
+                assert sn == n
+                check(lib().lf_memcpy_d2d(C.c_int(dev), C.c_void_p(out[k].ptr.value + 8 * slot), C.c_void_p(sp),
+                                          C.c_size_t(8 * n)))
+
+    def issue_round(c, j):
+        if j + 1 >= P:
+            return
+        if late_halo:
+            pending[(c, j)] = True
+        else:
+            do_round(c, j)
+
+    def wait_round(c, j):
+        if pending.pop((c, j), False):
+            do_round(c, j)
+
+    part(0, 0, 0); issue_round(0, 0); part(0, 0, 1)
+    for c in range(K):
+        nxt = c + 1 < K
+        if nxt:
+            part(c + 1, 0, 0); issue_round(c + 1, 0)
+        for j in range(1, P):
+            wait_round(c, j - 1)
+            part(c, j, 0); issue_round(c, j)
+            if j == 1 and nxt:
+                part(c + 1, 0, 1)
+            part(c, j, 1)
+    if K & 1:
+        for k in range(R):
+            n = routers[k].num_pixels
+            if n:
+                check(lib().lf_memcpy_d2d(C.c_int(dev), q_states[k].ptr, second[k].ptr, C.c_size_t(8 * n)))
+    _lib.synchronize(dev)
+    for d in second:
+        d.free()
 
 
 def loopback_route(routers, q_states, lat_states, section="main_channel", overlap_order=False):

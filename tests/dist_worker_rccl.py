@@ -36,6 +36,14 @@ def main():
         _lib.synchronize(device)
         lat.free()
         outs.append(router.download_pix(Q))
+    # four more calls as one pipelined sequence (lf_dist_router_route_many: alternating state vectors, halo rounds on the
+    # second stream beside the next call's phase 0)
+    lats = [router.new_state(syn.lateral_inflow(N, s)[sel]) for s in range(4, 8)]
+    router.route_many(Q, lats)
+    _lib.synchronize(device)
+    outs.append(router.download_pix(Q))
+    for d in lats:
+        d.free()
     gathered = T.allgather(outs)
     if rank == 0:
         kw = oracle.kinematicWave(codes.reshape(-1).astype(np.float64), np.ones((H, W), bool), p["alpha"], p["beta"], p["dx"],
@@ -45,6 +53,10 @@ def main():
             kw.kinematicWaveRouting(Qo, syn.lateral_inflow(N, s))
             full = np.concatenate([gathered[k][s] for k in range(world)])
             np.testing.assert_allclose(full, Qo, rtol=1e-9, atol=1e-12, err_msg="call %d" % s)
+        for s in range(4, 8):
+            kw.kinematicWaveRouting(Qo, syn.lateral_inflow(N, s))
+        full = np.concatenate([gathered[k][4] for k in range(world)])
+        np.testing.assert_allclose(full, Qo, rtol=1e-9, atol=1e-12, err_msg="pipelined calls 4..7")
         print("DIST_RCCL_OK phases=%d ranks=%d" % (g.num_phases, world))
     T.barrier()
     comm.close()

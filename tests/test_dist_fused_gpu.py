@@ -143,3 +143,36 @@ def test_router_call_in_the_order_the_two_streams_allow(amd, oracle, family, see
         np.testing.assert_allclose(got, Qc, rtol=1e-9, atol=1e-12)
         for d in lats:
             d.free()
+
+
+@pytest.mark.parametrize("late", [False, True])
+@pytest.mark.parametrize("family,seed,nblocks,ncalls", [("shallow", 1, 4, 5), ("saddle", 6, 3, 4), ("river", 7, 4, 3),
+                                                        ("deep", 2, 3, 2)])
+def test_pipelined_router_calls_on_alternating_state_vectors(amd, family, seed, nblocks, ncalls, late):
+    """lf_dist_router_route_many starts phase 0 of call s + 1 before the later phases of call s by alternating between two
+    state vectors.  Its kernel order on one GPU, with every halo round landing at the earliest or at the latest moment the
+    real exchange may (late), gives bit for bit what call-by-call routing gives; with one block the C function itself
+    (no communicator: call by call) agrees too."""
+    from lisflood_amd import dist as D
+    from lisflood_amd import synthetic as syn
+    H, W = 300, 260
+    N = H * W
+    codes = syn.make_ldd(family, H, W, seed)
+    p = syn.router_params(N, seed=6)
+    blocks = D.row_blocks(H, nblocks)
+    graphs = [D.DistGraph(codes[r0:r1], None, codes[r0 - 1] if r0 > 0 else None, None,
+                          codes[r1] if r1 < H else None, None) for (r0, r1) in blocks]
+    D.settle_phases_local(graphs)
+    sl = [slice(r0 * W, r1 * W) for (r0, r1) in blocks]
+    routers = [D.DistRouter(g, p["alpha"][s], p["beta"], p["dx"][s], p["dt"]) for g, s in zip(graphs, sl)]
+    Qa = [r.new_state(p["Q0"][s]) for r, s in zip(routers, sl)]
+    Qb = [r.new_state(p["Q0"][s]) for r, s in zip(routers, sl)]
+    lats = [[r.new_state(syn.lateral_inflow(N, c)[s]) for c in range(ncalls)] for r, s in zip(routers, sl)]
+    for c in range(ncalls):
+        D.loopback_route(routers, Qa, [l[c] for l in lats])
+    D.loopback_route_many(routers, Qb, lats, late_halo=late)
+    for r, a, b in zip(routers, Qa, Qb):
+        assert np.array_equal(r.download_pix(a), r.download_pix(b))
+    for l in lats:
+        for d in l:
+            d.free()
