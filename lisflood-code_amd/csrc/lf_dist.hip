@@ -791,7 +791,7 @@ int dist_compute_phase(lf_dist_router *r, double *q, const double *lat, int sect
         if (g.wide) {
             const int first = (int)r->h_level_start[g.k0];
             const int count = (int)(r->h_level_start[g.k1] - r->h_level_start[g.k0]);
-            const dim3 grid(blocks_for(count)), block(kBlock);
+            const dim3 grid(level_blocks_for(count)), block(kLevelBlock);
             if (r->fused)
                 hipLaunchKernelGGL((k_level<true, true, true>), grid, block, 0, s, first, count, A);
             else

@@ -361,16 +361,17 @@ int enqueue_blocks(int count, lf_router **rs, const sweep_args_multi &M, bool or
             const int first = (int)r->h_level_start[k0];
             const int cells = (int)(r->h_level_start[k0 + 1] - r->h_level_start[k0]);
             const dim3 grid(blocks_for(cells), count), block(kBlock);
+            const dim3 grid1(level_blocks_for(cells)), block1(kLevelBlock);
             LF_TRY(r->prof_begin(1, cells));
             if (count == 1) {
                 if (r->fused && ordered)
-                    hipLaunchKernelGGL((k_level<true, true>), grid, block, 0, s, first, cells, M.r[0]);
+                    hipLaunchKernelGGL((k_level<true, true>), grid1, block1, 0, s, first, cells, M.r[0]);
                 else if (r->fused)
-                    hipLaunchKernelGGL((k_level<true, false>), grid, block, 0, s, first, cells, M.r[0]);
+                    hipLaunchKernelGGL((k_level<true, false>), grid1, block1, 0, s, first, cells, M.r[0]);
                 else if (ordered)
-                    hipLaunchKernelGGL((k_level<false, true>), grid, block, 0, s, first, cells, M.r[0]);
+                    hipLaunchKernelGGL((k_level<false, true>), grid1, block1, 0, s, first, cells, M.r[0]);
                 else
-                    hipLaunchKernelGGL((k_level<false, false>), grid, block, 0, s, first, cells, M.r[0]);
+                    hipLaunchKernelGGL((k_level<false, false>), grid1, block1, 0, s, first, cells, M.r[0]);
             } else if (r->fused && ordered)
                 hipLaunchKernelGGL((k_level_multi<true, true>), grid, block, 0, s, first, cells, M);
             else if (r->fused)
@@ -481,7 +482,7 @@ int enqueue_route(lf_router *r, double *q_dev, const double *lat_dev, int sectio
             const int first = (int)r->h_level_start[g.k0];
             const int count = (int)(r->h_level_start[g.k1] - r->h_level_start[g.k0]);
             LF_TRY(r->prof_begin(1, count));
-            const dim3 grid(blocks_for(count)), block(kBlock);
+            const dim3 grid(level_blocks_for(count)), block(kLevelBlock);
             if (r->fused && ordered)
                 hipLaunchKernelGGL((k_level<true, true>), grid, block, 0, s, first, count, A);
             else if (r->fused)
