@@ -1,5 +1,5 @@
 """The shape of bench.py's JSON line, checked on the committed result of the last full run on an MI355X
-(profiles/r02_bench_final.json): the driver's contract (metric / value / unit / n_gpus / steps / warmup / ms_per_step /
+(profiles/r03_bench_final.json): the driver's contract (metric / value / unit / n_gpus / steps / warmup / ms_per_step /
 higher_is_better / scaling / vs_baseline / dtype / data / config.workload) plus the two objects of this tier, `roofline`
 and `cpu_baseline`, and the internal consistency of the numbers."""
 import json
@@ -9,8 +9,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_follows_the_contract():
-    line = open(os.path.join(ROOT, "profiles", "r02_bench_final.json")).read().strip().splitlines()[-1]
-    d = json.loads(line)
+    text = open(os.path.join(ROOT, "profiles", "r03_bench_final.json")).read().strip().splitlines()
+    assert len(text) == 1                                # ONE JSON line on stdout
+    d = json.loads(text[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -36,3 +37,23 @@ def test_committed_bench_line_follows_the_contract():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["unit"] == d["unit"]
+    assert c.get("cpu_model") and c.get("host_cpus", 0) >= c["cores"]      # core count and CPU model stated
+    # every routing leg of the line carries its counter traffic with the file it came from
+    for fam in ("deep", "river"):
+        rl = d["other_workloads"][fam]["roofline"]
+        assert rl["traffic"] and os.path.exists(os.path.join(ROOT, rl["traffic_source"])), fam
+    fr = d["other_workloads"]["model_step_24_substeps_split"]["fused"]["roofline"]
+    assert fr["hbm_bytes_per_cell_substep"] < 200 and os.path.exists(os.path.join(ROOT, fr["traffic_source"]))
+
+
+def test_committed_force_dist_line_is_one_json_line_with_both_partitions():
+    """the N > 1 code path run with one rank on an MI355X box (profiles/r03_force_dist_1rank.json): stdout is the ONE JSON
+    line (RCCL's banner goes to stderr), it carries the row-block model step and the catchment partition, and the two
+    partitions' discharge sums agree"""
+    text = open(os.path.join(ROOT, "profiles", "r03_force_dist_1rank.json")).read().strip().splitlines()
+    assert len(text) == 1
+    d = json.loads(text[0])
+    assert d["n_gpus"] == 1 and d["finite"] and d["scaling"] == "strong"
+    assert d["model_step_24_substeps_split_row_blocks"]["finite"]
+    assert d["catchment_partition"]["finite"]
+    assert d["row_block_vs_catchment_partition_sumQ_rel_diff"] < 1e-12
