@@ -166,7 +166,7 @@ struct sweep_args_multi {
 };
 
 template <bool FUSED, bool ORDERED>
-__global__ void __launch_bounds__(kBlock) k_level_multi(int first, int count, sweep_args_multi M)
+__global__ void __launch_bounds__(kBlock) LF_LEVEL_ATTR k_level_multi(int first, int count, sweep_args_multi M)
 {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= count) return;
