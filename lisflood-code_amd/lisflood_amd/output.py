@@ -153,35 +153,77 @@ def write_netcdf4(path, var_name, maps, x, y, time_values=None, time_units="days
     (no HDF5 library in the image): old-style HDF5 structures, dimension scales with the netCDF-4 attributes.
     `coord_attrs`: {dimension name: {attribute: value}} for x / y (the reference copies them from its template map),
     `projection`: (variable name, {attributes}) for the scalar int grid-mapping variable (`laea`, netcdf.py:497-504)."""
-    from . import hdf5_min as H5
     maps = np.asarray(maps, dtype=np.float64)
     timed = maps.ndim == 3
     if timed and (time_values is None or len(time_values) != maps.shape[0]):
         raise ValueError("a [T, H, W] stack needs time_values[T]")
-    H, W = maps.shape[-2:]
-    if len(y) != H or len(x) != W:
+    w = NetCDF4MapWriter(path, var_name, x, y, time_values if timed else None, time_units, calendar, dtype, standard_name,
+                         long_name, units, dims, settings_path, complevel, coord_attrs, projection, esri_pe_string)
+    if maps.shape[-2:] != (len(y), len(x)):
+        w.close()
         raise ValueError("coordinate vectors do not match the map shape")
-    dy, dx = dims
-    coord_attrs = coord_attrs or {}
-    ds = []
-    if projection is not None:
-        ds.append(H5.Dataset(projection[0], np.array(0, np.int32), (), dict(projection[1])))
-    ds.append(H5.Dataset(dx, np.asarray(x, np.float64), (dx,), coord_attrs.get(dx, {})))
-    ds.append(H5.Dataset(dy, np.asarray(y, np.float64), (dy,), coord_attrs.get(dy, {})))
-    if timed:
-        ds.append(H5.Dataset("time", np.asarray(time_values, np.float64), ("time",),
-                             {"standard_name": "time", "calendar": calendar, "units": time_units}))
-    data = np.where(np.isnan(maps), FILL, maps).astype(dtype)
-    attrs = {"_FillValue": np.array([FILL], dtype=dtype), "standard_name": standard_name, "long_name": long_name,
-             "units": units}
-    if esri_pe_string:
-        attrs["esri_pe_string"] = esri_pe_string
-    ds.append(H5.Dataset(var_name, data, (("time",) if timed else ()) + (dy, dx), attrs,
-                         chunks=((1, H, W) if timed else (H, W)), deflate=complevel, shuffle=True,
-                         fill=np.array(FILL, dtype=dtype)))
-    H5.write(path, ds, {"settingsfile": settings_path, "date_created": time.ctime(time.time()),
-                        "Source_Software": "lisflood_amd", "source": "Lisflood output maps",
-                        "keywords": "Lisflood, EFAS, GLOFAS", "Conventions": "CF-1.6"})
+    for t, m in enumerate(maps if timed else [maps]):
+        w.write_step(t, m)
+    w.close()
+
+
+class NetCDF4MapWriter:
+    """write_netcdf4 one map at a time: the file's metadata (dimensions, coordinate variables, all `time_values`) goes to
+    disk when the writer is made, write_step(t, map) appends that step's compressed chunk, close() completes the chunk
+    index -- a [T, H, W] output stack never sits in memory (the reference appends to its open netCDF4 dataset the same
+    way, netcdf.py:540-583 with `flag_time`).  Steps not written read back as `_FillValue`.  `time_values` None: one map."""
+
+    def __init__(self, path, var_name, x, y, time_values=None, time_units="days since 1990-01-01 00:00:00.0",
+                 calendar="proleptic_gregorian", dtype="f8", standard_name="", long_name="", units="", dims=("y", "x"),
+                 settings_path="", complevel=4, coord_attrs=None, projection=None, esri_pe_string=None):
+        from . import hdf5_min as H5
+        timed = time_values is not None
+        H, W = len(y), len(x)
+        dy, dx = dims
+        coord_attrs = coord_attrs or {}
+        ds = []
+        if projection is not None:
+            ds.append(H5.Dataset(projection[0], np.array(0, np.int32), (), dict(projection[1])))
+        ds.append(H5.Dataset(dx, np.asarray(x, np.float64), (dx,), coord_attrs.get(dx, {})))
+        ds.append(H5.Dataset(dy, np.asarray(y, np.float64), (dy,), coord_attrs.get(dy, {})))
+        if timed:
+            ds.append(H5.Dataset("time", np.asarray(time_values, np.float64), ("time",),
+                                 {"standard_name": "time", "calendar": calendar, "units": time_units}))
+        attrs = {"_FillValue": np.array([FILL], dtype=dtype), "standard_name": standard_name, "long_name": long_name,
+                 "units": units}
+        if esri_pe_string:
+            attrs["esri_pe_string"] = esri_pe_string
+        T = len(time_values) if timed else 0
+        ds.append(H5.Dataset(var_name, None, (("time",) if timed else ()) + (dy, dx), attrs,
+                             chunks=((1, H, W) if timed else (H, W)), deflate=complevel, shuffle=True,
+                             fill=np.array(FILL, dtype=dtype), shape=((T, H, W) if timed else (H, W)), dtype=dtype))
+        self._timed, self._name, self._shape, self._dtype = timed, var_name, (H, W), np.dtype(dtype)
+        self._w = H5.Writer(path, ds, {"settingsfile": settings_path, "date_created": time.ctime(time.time()),
+                                       "Source_Software": "lisflood_amd", "source": "Lisflood output maps",
+                                       "keywords": "Lisflood, EFAS, GLOFAS", "Conventions": "CF-1.6"})
+
+    def write_step(self, t, map2d):
+        """`map2d` [H, W] (NaN = missing) as step `t` of the stack (t is ignored for a single map)"""
+        m = np.asarray(map2d, dtype=np.float64)
+        if m.shape != self._shape:
+            raise ValueError("map shape %s, file %s" % (m.shape, self._shape))
+        block = np.where(np.isnan(m), FILL, m).astype(self._dtype)
+        if self._timed:
+            self._w.write_chunk(self._name, (t, 0, 0), block[None])
+        else:
+            self._w.write_chunk(self._name, (0, 0), block)
+
+    def flush(self):
+        self._w.flush()
+
+    def close(self):
+        self._w.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
 
 def read_netcdf4(path, var_name):

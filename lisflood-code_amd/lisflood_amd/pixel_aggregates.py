@@ -36,10 +36,13 @@ def dynamic(var, device=0):
     cache = getattr(v, "_lf_pixel_buffers", None)       # device buffers live as long as `var` does
     if cache is None or cache.device != device:
         cache = v._lf_pixel_buffers = BufferCache(device)
+    static = ("SoilFraction", "SoilDepthTotal", "SMaxSealed", "DirectRunoffFraction", "WaterFraction", "LowerZoneK",
+              "LZThreshold", "GwLossStep")       # parameter maps: uploaded once (BufferCache.put_static)
     for k in _V_IN:
-        dev[k] = cache.put(k, f64(_values(getattr(v, k))))
+        dev[k] = (cache.put_static if k in static else cache.put)(k, f64(_values(getattr(v, k))))
     for k in _N_IN + _STATE:
-        dev[k] = cache.put(k, f64(np.broadcast_to(_values(getattr(v, k)), (N,))))
+        x = f64(np.broadcast_to(_values(getattr(v, k)), (N,)))
+        dev[k] = (cache.put_static if (k in static and np.ndim(_values(getattr(v, k))) == 1) else cache.put)(k, x)
     for k in _OUT:
         dev[k] = cache.get(k, N)
     dev["Theta"] = cache.get("Theta", (3, N))

@@ -87,11 +87,12 @@ class surface_routing(HydroModule):
         if getattr(self, "_cache", None) is None:        # device buffers live as long as the module
             self._cache = BufferCache(self.device)
         put, get = self._cache.put, self._cache.get
+        static = ("SoilFraction", "OFAlpha", "IsChannel")   # parameter maps: uploaded once (BufferCache.put_static)
         for k in _V_IN:
-            dev[k] = put(k, f64(_values(getattr(v, k))))
+            dev[k] = (self._cache.put_static if k in static else put)(k, f64(_values(getattr(v, k))))
         for k in _N_IN:
             x = _values(getattr(v, k))
-            dev[k] = put(k, u8(x) if k == "IsChannel" else f64(np.broadcast_to(x, (N,))))
+            dev[k] = (self._cache.put_static if k in static else put)(k, u8(x) if k == "IsChannel" else f64(np.broadcast_to(x, (N,))))
         host_state = {}
         for k in _STATE:
             host_state[k] = np.ascontiguousarray(getattr(v, k), dtype=np.float64)

@@ -100,6 +100,27 @@ def check():
     ok = bool(np.array_equal(d2[...], np.where(np.isnan(m2), -9999.0, m2).astype("f4")))
     print("long series", d2.shape, d2.dtype, "chunks", d2.chunks, d2.compression, "values identical:", ok)
     assert ok
+    # the streamed writer: steps appended out of order, two of them never written (libhdf5 returns the fill value there),
+    # the file opened by libhdf5 after a flush() in the middle and after close()
+    path3 = os.path.join(os.path.dirname(path), "stream.nc")
+    w = O.NetCDF4MapWriter(path3, "dis", x, y, time_values=np.arange(T, dtype=float), units="m3/s")
+    order = [3, 0, 1, 7, 2, 11, 5, 6, 4, 9]
+    want3 = np.full((T, H, W), -9999.0)
+    for i, t in enumerate(order):
+        w.write_step(t, maps[t])
+        want3[t] = want[t]
+        if i == 4:
+            w.flush()
+            part = h5py.File(path3, "r")["dis"][...]
+            okp = bool(np.array_equal(part[[3, 0, 1, 7, 2]], want[[3, 0, 1, 7, 2]]) and (part[[4, 5, 6, 8, 9, 10, 11]] == -9999.0).all())
+            print("streamed, after flush() at 5 of 12 steps: libhdf5 reads the written steps and the fill value elsewhere:", okp)
+            assert okp
+    w.close()
+    f3 = h5py.File(path3, "r")
+    ok3 = bool(np.array_equal(f3["dis"][...], want3))
+    print("streamed", f3["dis"].shape, "10 of 12 steps written out of order: values identical, unwritten steps = fill:", ok3,
+          "| scales attached:", [[s.name for s in dim.values()] for dim in f3["dis"].dims])
+    assert ok3
 
 
 def refstruct():

@@ -142,3 +142,65 @@ def test_chunks_libhdf5_never_allocated_read_as_the_fill_value():
     assert (a[1] == -9999.0).all() and (a[3] == -9999.0).all()
     n = r.dataset("never")
     assert n.shape == (2, 3) and n.dtype == np.float32 and (n == np.float32(-1.5)).all()
+
+
+def test_streamed_map_stack_equals_the_one_written_at_once(tmp_path, monkeypatch):
+    """output.NetCDF4MapWriter appends one step's chunk at a time (the stack is never in memory): with every step written
+    in order the file is byte for byte the one write_netcdf4 makes from the whole stack"""
+    import time
+    monkeypatch.setattr(time, "ctime", lambda *a: "Thu Jan  1 00:00:00 1970")
+    H, W, T = 19, 27, 40
+    rng = np.random.default_rng(8)
+    maps = rng.uniform(0, 500, (T, H, W))
+    maps[:, rng.uniform(size=(H, W)) < 0.3] = np.nan
+    x, y, tv = np.arange(W) * 1.0, np.arange(H)[::-1] * 1.0, np.arange(T) * 1.0
+    kw = dict(dtype="f4", units="m3/s", projection=("laea", {"grid_mapping_name": "lambert_azimuthal_equal_area"}))
+    O.write_netcdf4(str(tmp_path / "a.nc"), "dis", maps, x, y, time_values=tv, **kw)
+    with O.NetCDF4MapWriter(str(tmp_path / "b.nc"), "dis", x, y, time_values=tv, **kw) as w:
+        for t in range(T):
+            w.write_step(t, maps[t])
+    assert open(tmp_path / "a.nc", "rb").read() == open(tmp_path / "b.nc", "rb").read()
+    # a single map (no time axis)
+    O.write_netcdf4(str(tmp_path / "c.nc"), "dis", maps[0], x, y, **kw)
+    with O.NetCDF4MapWriter(str(tmp_path / "d.nc"), "dis", x, y, **kw) as w:
+        w.write_step(0, maps[0])
+    assert open(tmp_path / "c.nc", "rb").read() == open(tmp_path / "d.nc", "rb").read()
+
+
+def test_streamed_map_stack_out_of_order_flush_and_missing_steps(tmp_path):
+    H, W, T = 11, 13, 9
+    rng = np.random.default_rng(2)
+    maps = rng.uniform(0, 5, (T, H, W))
+    x, y = np.arange(W) * 1.0, np.arange(H)[::-1] * 1.0
+    path = str(tmp_path / "s.nc")
+    w = O.NetCDF4MapWriter(path, "dis", x, y, time_values=np.arange(T) * 1.0)
+    for t in (4, 0, 8):
+        w.write_step(t, maps[t])
+    w.flush()                                                              # readable while still open
+    got = O.read_netcdf4(path, "dis")[0]
+    assert np.array_equal(got[[4, 0, 8]], maps[[4, 0, 8]]) and np.isnan(got[[1, 2, 3, 5, 6, 7]]).all()
+    raw = open(path, "rb").read()
+    assert struct.unpack_from("<Q", raw, 44)[0] == len(raw)
+    for t in (2, 1, 7):
+        w.write_step(t, maps[t])
+    with pytest.raises(ValueError):
+        w.write_step(2, maps[2])                                           # a chunk is written once
+    with pytest.raises(IndexError):
+        w.write_step(T, maps[0])
+    with pytest.raises(ValueError):
+        w.write_step(3, maps[3][:, :5])
+    w.close()
+    w.close()                                                              # idempotent
+    got = O.read_netcdf4(path, "dis")[0]
+    done = [0, 1, 2, 4, 7, 8]
+    assert np.array_equal(got[done], maps[done]) and np.isnan(got[[3, 5, 6]]).all()
+    with pytest.raises(ValueError):
+        H5.write(str(tmp_path / "x.h5"), [H5.Dataset("v", None, chunks=(1, 2), shape=(3, 2), dtype="f8")])
+    # a streamed dataset whose edge chunks are partial blocks
+    d = H5.Dataset("v", None, chunks=(4, 4), shape=(6, 7), dtype="f4", fill=np.float32(-1))
+    a = rng.uniform(0, 1, (6, 7)).astype("f4")
+    with H5.Writer(str(tmp_path / "e.h5"), [d]) as hw:
+        for i in range(2):
+            for j in range(2):
+                hw.write_chunk("v", (i, j), a[4 * i:4 * i + 4, 4 * j:4 * j + 4])
+    assert np.array_equal(H5.read(str(tmp_path / "e.h5")).dataset("v"), a)
