@@ -1,0 +1,97 @@
+"""-m gpu: the row-block partition as an N-GPU job runs it -- one PROCESS per rank, socket rendezvous, the product's own
+sequence of group calls / sends / receives / streams / events -- on the ONE GPU a test box has.
+
+RCCL refuses two ranks on one device, so the workers find tests/fake_rccl/librccl.so.1 first on LD_LIBRARY_PATH: a test
+stand-in for the eight RCCL entry points csrc/lf_dist.hip binds, moving the messages between processes through hipIpc
+mailboxes with RCCL's semantics (asynchronous on the caller's stream, grouped operations progress together, messages
+matched per (source, destination) in order, byte counts checked, every wait bounded).  What these tests prove is the
+product's side of the protocol between real processes: who sends what to whom in which order, that every receive has
+its send, that kernels wait for the halo they read.  The wire itself (RCCL over xGMI) is covered by
+test_gpu_parity.py::test_two_rank_rccl_halo_exchange on boxes with two devices."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FAKE = os.path.join(ROOT, "tests", "fake_rccl")
+_PORT = [29700]
+
+
+@pytest.fixture(scope="module")
+def fake_rccl():
+    from lisflood_amd import _lib
+    if _lib.device_count() == 0:
+        pytest.fail("no HIP device: the gpu tests must run on an MI355X box")
+    src, so = os.path.join(FAKE, "fake_rccl.hip"), os.path.join(FAKE, "librccl.so.1")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.run(["hipcc", "-O2", "-shared", "-fPIC", "--offload-arch=gfx950", "-o", so, src, "-lrt"], check=True,
+                       timeout=300)
+    return FAKE
+
+
+def run_ranks(fake, world, script, extra_env, args=(), timeout=600):
+    """`world` processes of `script`, all on device 0, rendezvous on a fresh port; -> [(stdout, stderr)] per rank"""
+    _PORT[0] += 1
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(_PORT[0]), TORCHELASTIC_RUN_ID="fake%d_%d" % (os.getpid(), _PORT[0]),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", FAKE_RCCL_TIMEOUT_S="60",
+                   LD_LIBRARY_PATH=fake + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""))
+        env.update(extra_env)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, script)] + list(args), env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=timeout))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    if any(p.returncode != 0 for p in procs):
+        pytest.fail("\n".join("--- rank %d rc=%s\n%s\n%s" % (rank, p.returncode, o[-1500:], e[-2500:])
+                              for rank, (p, (o, e)) in enumerate(zip(procs, outs))))
+    return outs
+
+
+@pytest.mark.parametrize("family,world", [("saddle", 2), ("saddle", 3), ("shallow", 4), ("deep", 3), ("river", 4)])
+def test_router_calls_between_processes(fake_rccl, family, world):
+    """lf_dist_router_route (boundary-critical part, halo on the second stream beside the bulk) and
+    lf_dist_router_route_many (calls pipelined on alternating state vectors) with `world` ranks: the single-domain
+    oracle's discharge after 4 + 4 calls"""
+    outs = run_ranks(fake_rccl, world, "tests/dist_worker_rccl.py", {"LF_TEST_FAMILY": family})
+    assert "DIST_RCCL_OK" in outs[0][0] and "ranks=%d" % world in outs[0][0]
+
+
+@pytest.mark.parametrize("family,world,split", [("saddle", 2, True), ("saddle", 3, False), ("shallow", 4, True),
+                                                ("deep", 3, True), ("river", 4, True)])
+def test_fused_model_step_between_processes(fake_rccl, family, world, split):
+    """lf_dist_routing_substeps_fused with `world` ranks, two model steps of 7 sub-steps: bit-identical to the whole
+    raster's lf_routing_substeps_fused"""
+    outs = run_ranks(fake_rccl, world, "tests/dist_worker_fused.py",
+                     {"LF_TEST_FAMILY": family, "LF_TEST_SPLIT": "1" if split else "0"})
+    assert "DIST_FUSED_OK" in outs[0][0]
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_line_of_a_multi_rank_job(fake_rccl, world):
+    """`bench.py --gpus N` as the driver launches it (one process per rank, RANK / WORLD_SIZE / MASTER_* from the
+    environment) at a reduced raster: ONE JSON line on rank 0's stdout, finite, and the row-block partition's discharge
+    sum equal to the catchment partition's (both bit-identical to the single domain) to summation order"""
+    import json
+    outs = run_ranks(fake_rccl, world, "bench.py", {},
+                     args=["--gpus", str(world), "--size", "1600", "--steps", "4", "--warmup", "1"], timeout=900)
+    lines = [l for l in outs[0][0].splitlines() if l.strip()]
+    assert len(lines) == 1, outs[0][0][-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == world and d["finite"] and d["value"] > 0
+    assert d["row_block_vs_catchment_partition_sumQ_rel_diff"] < 1e-12
+    step = d["model_step_24_substeps_split_row_blocks"]
+    assert step.get("finite") is True, step
+    for rank in range(1, world):
+        assert outs[rank][0].strip() == ""
