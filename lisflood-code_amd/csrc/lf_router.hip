@@ -228,7 +228,7 @@ struct lf_router {
     // with, so fewer, longer launches pay): host tables + the cone starts on the device
     std::vector<int> rb_level, rb_row, rb_off;
     lf_dbuf<int> rb_cone;
-    int rb_lmax = 0;
+    int rb_lmax = 0, rb_cw = kBlock; // levels per block, cells per level of a cone (LF_ROUTE_CONE_WIDTH: 64 or 256)
     int64_t last_stats[4] = {0, 0, 0, 0};
     // profiling
     bool profile = false;
@@ -320,17 +320,27 @@ bool cones_enabled() // (read at every call: bench.py switches it for its A/B le
     return !(e && e[0] == '0');
 }
 
-template <int NR>
-void launch_sweep_cones(bool fused, bool ordered, dim3 grid, hipStream_t s, const cone_plan_args &C, const sweep_args_multi &M)
+template <int NR, int CW>
+void launch_sweep_cones_cw(bool fused, bool ordered, dim3 grid, hipStream_t s, const cone_plan_args &C,
+                           const sweep_args_multi &M)
 {
     if (fused && ordered)
-        hipLaunchKernelGGL((k_sweep_cones<true, true, NR>), grid, dim3(kBlock), 0, s, C, M);
+        hipLaunchKernelGGL((k_sweep_cones<true, true, NR, CW>), grid, dim3(CW), 0, s, C, M);
     else if (fused)
-        hipLaunchKernelGGL((k_sweep_cones<true, false, NR>), grid, dim3(kBlock), 0, s, C, M);
+        hipLaunchKernelGGL((k_sweep_cones<true, false, NR, CW>), grid, dim3(CW), 0, s, C, M);
     else if (ordered)
-        hipLaunchKernelGGL((k_sweep_cones<false, true, NR>), grid, dim3(kBlock), 0, s, C, M);
+        hipLaunchKernelGGL((k_sweep_cones<false, true, NR, CW>), grid, dim3(CW), 0, s, C, M);
     else
-        hipLaunchKernelGGL((k_sweep_cones<false, false, NR>), grid, dim3(kBlock), 0, s, C, M);
+        hipLaunchKernelGGL((k_sweep_cones<false, false, NR, CW>), grid, dim3(CW), 0, s, C, M);
+}
+template <int NR>
+void launch_sweep_cones(int cw, bool fused, bool ordered, dim3 grid, hipStream_t s, const cone_plan_args &C,
+                        const sweep_args_multi &M)
+{
+    if (cw == 64)
+        launch_sweep_cones_cw<NR, 64>(fused, ordered, grid, s, C, M);
+    else
+        launch_sweep_cones_cw<NR, kBlock>(fused, ordered, grid, s, C, M);
 }
 
 int enqueue_blocks(int count, lf_router **rs, const sweep_args_multi &M, bool ordered, int64_t *launches, int64_t *wide,
@@ -348,13 +358,13 @@ int enqueue_blocks(int count, lf_router **rs, const sweep_args_multi &M, bool or
             const dim3 grid((unsigned)(r->rb_row[b + 1] - r->rb_row[b] - 1));
             LF_TRY(r->prof_begin(2, r->h_level_start[k0 + nl] - r->h_level_start[k0]));
             if (count == 1)
-                launch_sweep_cones<1>(r->fused, ordered, grid, s, C, M);
+                launch_sweep_cones<1>(r->rb_cw, r->fused, ordered, grid, s, C, M);
             else if (count == 2)
-                launch_sweep_cones<2>(r->fused, ordered, grid, s, C, M);
+                launch_sweep_cones<2>(r->rb_cw, r->fused, ordered, grid, s, C, M);
             else if (count == 3)
-                launch_sweep_cones<3>(r->fused, ordered, grid, s, C, M);
+                launch_sweep_cones<3>(r->rb_cw, r->fused, ordered, grid, s, C, M);
             else
-                launch_sweep_cones<4>(r->fused, ordered, grid, s, C, M);
+                launch_sweep_cones<4>(r->rb_cw, r->fused, ordered, grid, s, C, M);
             LF_TRY(r->prof_end());
             ++*narrow;
         } else {
@@ -404,7 +414,7 @@ int enqueue_route_multi(int count, lf_router **rs, double **q_dev, const double 
             ++launches;
         }
     bool same_graph = r->rb_lmax > 1 && cones_enabled();
-    for (int i = 1; i < count; ++i) same_graph = same_graph && rs[i]->graph_serial == r->graph_serial && r->graph_serial != 0 && rs[i]->rb_lmax == r->rb_lmax;
+    for (int i = 1; i < count; ++i) same_graph = same_graph && rs[i]->graph_serial == r->graph_serial && r->graph_serial != 0 && rs[i]->rb_lmax == r->rb_lmax && rs[i]->rb_cw == r->rb_cw;
     if (same_graph) {
         LF_TRY(enqueue_blocks(count, rs, M, ordered, &launches, &wide, &narrow));
         for (int i = 0; i < count; ++i) {
@@ -543,18 +553,23 @@ int route_device(lf_router *r, double *q_dev, const double *lat_dev, int section
 // until it fits (one level always does).  Nothing is built when no block holds more than one level.
 static int build_level_blocks(lf_router *r, const lf_graph *g, bool for_route)
 {
-    int lmax = for_route ? 64 : 16; // LF_ROUTE_LEVELS / LF_FUSED_LEVELS (measured: §4.1c / §4.3b of DESIGN.md)
+    int lmax = for_route ? 256 : 16; // LF_ROUTE_LEVELS / LF_FUSED_LEVELS (measured: §4.1c / §4.3b of DESIGN.md)
     if (const char *e = std::getenv(for_route ? "LF_ROUTE_LEVELS" : "LF_FUSED_LEVELS")) lmax = std::atoi(e);
-    lmax = lmax < 1 ? 1 : (lmax > 64 ? 64 : lmax);
+    lmax = lmax < 1 ? 1 : (lmax > (for_route ? 512 : 64) ? (for_route ? 512 : 64) : lmax);
     int64_t wide = 262144;
     if (const char *e = std::getenv("LF_FUSED_WIDE")) wide = std::atoll(e);
     const int64_t NL = g->NL;
     if (lmax <= 1 || NL < 2 || g->N >= ((int64_t)1 << 31)) return LF_OK;
+    int cw = kBlock;
+    if (for_route) { // one wavefront per cone: no barrier between the levels (deep 10 000^2: 11.3 -> 10.1 ms per call)
+        cw = 64;
+        if (const char *e = std::getenv("LF_ROUTE_CONE_WIDTH")) cw = std::atoi(e) == 64 ? 64 : kBlock;
+    }
     lf_block_plan plan;
     try {
         // every cell below the last level drains into the next level, so the upstream ranges tile the level before:
         // the first position draining at or behind `pos` is the first upstream position of `pos`
-        lf_build_level_blocks(g->level_start, 0, NL, lmax, wide, kBlock, [&](int64_t pos) { return (int64_t)g->ups_ptr[pos]; },
+        lf_build_level_blocks(g->level_start, 0, NL, lmax, wide, cw, [&](int64_t pos) { return (int64_t)g->ups_ptr[pos]; },
                               plan);
     } catch (const std::bad_alloc &) {
         return lf_set_error(LF_E_INVALID, "out of host memory while building the level blocks");
@@ -569,6 +584,7 @@ static int build_level_blocks(lf_router *r, const lf_graph *g, bool for_route)
         r->rb_row = row;
         r->rb_off = off;
         r->rb_lmax = lmax;
+        r->rb_cw = cw;
         return LF_OK;
     }
     LF_TRY(r->fb_level_dev.upload(level.data(), level.size(), r->ctx->stream));

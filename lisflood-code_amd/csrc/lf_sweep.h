@@ -198,32 +198,36 @@ struct cone_plan_args {
     int nl;                       // levels of the block
 };
 
-template <bool FUSED, bool ORDERED, int NR>
-__global__ void __launch_bounds__(kBlock) k_sweep_cones(cone_plan_args C, sweep_args_multi M)
+// CW: cells per level of a cone = threads of the workgroup (64: one wavefront, no barrier between the levels)
+template <bool FUSED, bool ORDERED, int NR, int CW = kBlock>
+__global__ void __launch_bounds__(CW) k_sweep_cones(cone_plan_args C, sweep_args_multi M)
 {
-    __shared__ double x[NR][2][kBlock];
+    __shared__ double x[NR][2][CW];
     const int tid = threadIdx.x, nl = C.nl;
     const int *c0 = C.cone + (size_t)blockIdx.x * nl, *c1 = c0 + nl;
-    struct cell {
+    struct cell { // the operands of one cell as loaded: no arithmetic before the level that solves it (a product here
+                  // would make the loads wait where they are issued)
         int u0, u1, pix;
-        double ap[NR], lat[NR], qold[NR];
+        double ap[NR], lat[NR], dx[NR], qold[NR];
         bool active;
     };
     auto load = [&](int p, bool active, cell &R) {
         R.active = active;
-        if (!active) return;
-        R.u0 = M.r[0].ups_ptr[p];
-        R.u1 = M.r[0].ups_ptr[p + 1];
-        R.pix = ORDERED ? p : M.r[0].perm[p];
+        const int pc = active ? p : 0; // lanes beyond the cone's range load cell 0: no branch around the loads
+        R.u0 = M.r[0].ups_ptr[pc];
+        R.u1 = M.r[0].ups_ptr[pc + 1];
+        R.pix = ORDERED ? pc : M.r[0].perm[pc];
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             const sweep_args &A = M.r[r];
-            R.ap[r] = A.a[p];
+            R.ap[r] = A.a[pc];
             if (FUSED) {
-                R.lat[r] = A.lat[R.pix] * (A.dx ? A.dx[p] : A.dx_scalar);
-                R.qold[r] = ORDERED ? A.qord[p] : A.q_pix[R.pix];
+                R.lat[r] = A.lat[R.pix];
+                R.dx[r] = A.dx ? A.dx[pc] : A.dx_scalar;
+                R.qold[r] = ORDERED ? A.qord[pc] : A.q_pix[R.pix];
             } else {
-                R.lat[r] = A.constant[p];
+                R.lat[r] = A.constant[pc];
+                R.dx[r] = 1.0;
                 R.qold[r] = 0.0;
             }
         }
@@ -243,15 +247,20 @@ __global__ void __launch_bounds__(kBlock) k_sweep_cones(cone_plan_args C, sweep_
         }
         pend = false;
     };
-    auto level = [&](int j, const cell &cur, cell &nxt, int first) {
+    // Software pipeline of depth 2: level j is solved from operands loaded while level j - 2 was solved, so a load has two
+    // level times to arrive (one level of a cone takes about as long as one trip to memory: with depth 1 every level
+    // waited for its own loads).  Three operand sets rotate; the waits are the compiler's (vmcnt counts the loads and
+    // stores issued since, nothing is waited for that is not needed).
+    auto level = [&](int j, const cell &cur, cell &nn, int first, int fn2, int ln2) {
         const int p = first + tid;
-        int nfirst = 0;
         flush();
-        if (j + 1 < nl) { // the next level's operands: nothing of them depends on this launch
-            nfirst = ld_table(c0, j + 1);
-            load(nfirst + tid, nfirst + tid < ld_table(c1, j + 1), nxt);
+        load(fn2 + tid, fn2 + tid < ln2, nn); // nothing of them depends on this launch; beyond the block: bounds 0, 0
+        if (j > 0) { // level j-1 of this cone is in LDS
+            if (CW > 64)
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // one wavefront: its LDS operations complete in order
         }
-        if (j > 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // level j-1 of this cone is in LDS
         if (cur.active) {
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
@@ -274,7 +283,7 @@ __global__ void __launch_bounds__(kBlock) k_sweep_cones(cone_plan_args C, sweep_
 #pragma unroll
                 for (int k = 0; k < 8; ++k) ups += v[k];
                 const double ap = cur.ap[r];
-                const double cst = FUSED ? ap * lf_pow_3_5(cur.qold[r]) + cur.lat[r] : cur.lat[r];
+                const double cst = FUSED ? ap * lf_pow_3_5(cur.qold[r]) + cur.lat[r] * cur.dx[r] : cur.lat[r];
                 const double c = ups + cst;
                 double q;
                 if (FUSED && lf_fast_range(c) && lf_fast_range(ap))
@@ -288,17 +297,26 @@ __global__ void __launch_bounds__(kBlock) k_sweep_cones(cone_plan_args C, sweep_
             pend_p = p;
             pend_pix = cur.pix;
         }
-        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the next level's operands (issued before the arithmetic) are in
         first_up = first;
-        return nfirst;
     };
-    cell ra, rb;
-    int first = ld_table(c0, 0);
-    load(first + tid, first + tid < ld_table(c1, 0), ra);
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    for (int j = 0; j < nl; j += 2) {
-        first = level(j, ra, rb, first);
-        if (j + 1 < nl) first = level(j + 1, rb, ra, first);
+    auto bound = [&](const int *t, int k) { return k < nl ? ld_table(t, k) : 0; };
+    cell r0, r1, r2;
+    int f0 = ld_table(c0, 0), f1 = bound(c0, 1), f2 = bound(c0, 2), l2 = bound(c1, 2);
+    load(f0 + tid, f0 + tid < ld_table(c1, 0), r0);
+    load(f1 + tid, f1 + tid < bound(c1, 1), r1);
+    // three levels per trip, no branch around a level or its loads (the wait counts stay exact): a level beyond the block
+    // has the bounds 0, 0 -- no active cell, only its barrier
+    for (int j = 0; j < nl; j += 3) {
+        // bounds of the levels whose operands this round of three requests
+        const int f3 = bound(c0, j + 3), l3 = bound(c1, j + 3), f4 = bound(c0, j + 4), l4 = bound(c1, j + 4);
+        const int f5 = bound(c0, j + 5), l5 = bound(c1, j + 5);
+        level(j, r0, r2, f0, f2, l2);
+        level(j + 1, r1, r0, f1, f3, l3);
+        level(j + 2, r2, r1, f2, f4, l4);
+        f0 = f3;
+        f1 = f4;
+        f2 = f5;
+        l2 = l5;
     }
     flush();
 }
