@@ -637,10 +637,11 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 #ifndef LF_CONES_WAVES
 #define LF_CONES_WAVES 2
 #endif
-template <bool SPLIT, bool ALL35, bool STRUCT, bool DIST = false>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(LF_CONES_WAVES))) k_fused_cones(fused_args F)
+// CW: cells per level of a cone = threads of the workgroup (64: one wavefront per cone, no barrier between the levels)
+template <bool SPLIT, bool ALL35, bool STRUCT, bool DIST = false, int CW = kBlock>
+__global__ void __launch_bounds__(CW) __attribute__((amdgpu_waves_per_eu(LF_CONES_WAVES))) k_fused_cones(fused_args F)
 {
-    __shared__ double x1[2][kBlock], x2[SPLIT ? 2 : 1][SPLIT ? kBlock : 1];
+    __shared__ double x1[2][CW], x2[SPLIT ? 2 : 1][SPLIT ? CW : 1];
     int s, blk;
     if (F.packed) {
         int cnt = 0, start = 0;
@@ -684,7 +685,12 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(LF_
         asm volatile("" : "+s"(Kp));
         const fused_args &F = *(const fused_args *)Kp;
         const long long p = first + tid;
-        if (j > 0) lds_barrier(); // level j-1 of this cone is in LDS
+        if (j > 0) { // level j-1 of this cone is in LDS
+            if (CW > 64)
+                lds_barrier();
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // one wavefront: its LDS operations complete in order
+        }
         // Right behind the barrier: the state stores of level j-1 and the state loads of level j+1.  Both have the
         // arithmetic of level j to complete, so the wait at the end of this level finds them done (issued after the
         // arithmetic, the stores' acknowledgement would be waited for on every level).

@@ -64,6 +64,35 @@ __device__ __forceinline__ double lf_pow_3_5(double x)
     return pow(x, 0.6);
 }
 
+// N independent x^0.6 in lockstep (stage by stage for all arguments, so the N dependent chains interleave in the
+// instruction stream); element by element the operations of lf_pow_3_5
+template <int N>
+__device__ __forceinline__ void lf_pow_3_5_n(const double (&x)[N], double (&out)[N])
+{
+    bool fast[N];
+    double xs[N], r[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        fast[i] = lf_fast_range(x[i]);
+        xs[i] = fast[i] ? x[i] : 1.0;
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = (double)__builtin_amdgcn_exp2f(0.2f * __builtin_amdgcn_logf((float)xs[i]));
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const double r2 = r[i] * r[i], r4 = r2 * r2;
+            r[i] = fma(-fma(r4, r[i], -xs[i]), lf_rcp(5.0 * r4), r[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) out[i] = r[i] * r[i] * r[i];
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        if (!fast[i]) out[i] = (x[i] == 0.0) ? 0.0 : pow(x[i], 0.6); // zero, or beyond the fast range (rare)
+}
+
 // x^(1/0.6) = x^(5/3) = x * cbrt(x)^2
 __device__ __forceinline__ double lf_pow_5_3(double x)
 {

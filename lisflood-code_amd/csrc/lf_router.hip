@@ -94,50 +94,53 @@ __global__ void __launch_bounds__(kNarrowBlock) k_accu_narrow(int k0, int k1, co
     }
 }
 
-// One block of consecutive levels of the router's plan (build_level_blocks, the plan of k_sweep_cones), cone by cone:
-// the sums travel to the next level through LDS, the operands of the next level's cell are loaded before the current
-// level is added up.  Same additions in the same order as k_accu_level.
-template <int NV>
-__global__ void __launch_bounds__(kBlock) k_accu_cones(cone_plan_args C, const int *__restrict__ ups_ptr, accu_multi M)
+// One block of consecutive levels of the router's plan (build_level_blocks, the plan of k_sweep_cones), cone by cone.
+// An accumulation level is a handful of additions, far shorter than a trip to memory, so the cone is worked through in
+// CHUNKS of LC levels: all operands of a chunk (upstream ranges, x) are requested at once and parked in LDS -- one memory
+// latency per chunk instead of one per level --, the levels of the chunk are then added up from LDS alone (the sums
+// replace x in place and are the next level's inflow), and the chunk's sums leave with one burst of stores that nothing
+// waits for.  CW = cells per level of a cone = threads (64: one wavefront, whose LDS operations complete in order -- no
+// barrier).  Same additions in the same order as k_accu_level.
+template <int NV, int CW>
+__global__ void __launch_bounds__(CW) k_accu_cones(cone_plan_args C, const int *__restrict__ ups_ptr, accu_multi M)
 {
-    __shared__ double y[NV][2][kBlock];
+    constexpr int LC0 = 49152 / (CW * (8 + 8 * NV)), LC = LC0 < 2 ? 2 : (LC0 > 64 ? 64 : LC0);
+    __shared__ int U0[LC][CW], U1[LC][CW];
+    __shared__ double X[NV][LC][CW], PREV[NV][CW];
     const int tid = threadIdx.x, nl = C.nl;
     const int *c0 = C.cone + (size_t)blockIdx.x * nl, *c1 = c0 + nl;
-    struct cell {
-        int u0, u1;
-        double x[NV];
-        bool active;
-    };
-    auto load = [&](int p, bool active, cell &R) {
-        R.active = active;
-        if (!active) return;
-        R.u0 = ups_ptr[p];
-        R.u1 = ups_ptr[p + 1];
-#pragma unroll
-        for (int v = 0; v < NV; ++v) R.x[v] = M.x[v][p];
-    };
     int first_up = 0;
-    auto level = [&](int j, const cell &cur, cell &nxt, int first) {
-        const int p = first + tid;
-        int nfirst = 0;
-        if (j + 1 < nl) {
-            nfirst = ld_table(c0, j + 1);
-            load(nfirst + tid, nfirst + tid < ld_table(c1, j + 1), nxt);
+    for (int j0 = 0; j0 < nl; j0 += LC) {
+        const int L = nl - j0 < LC ? nl - j0 : LC;
+        // ---- every operand of the chunk: independent loads, all in flight together ----
+#pragma unroll 8
+        for (int jj = 0; jj < L; ++jj) {
+            const int p = ld_table(c0, j0 + jj) + tid;
+            const bool act = p < ld_table(c1, j0 + jj);
+            const int pc = act ? p : 0;
+            const int u0 = ups_ptr[pc], u1 = ups_ptr[pc + 1];
+            U0[jj][tid] = u0;
+            U1[jj][tid] = act ? u1 : u0; // a lane beyond the cone's range: no upstream cells, its sum is never stored
+#pragma unroll
+            for (int v = 0; v < NV; ++v) X[v][jj][tid] = M.x[v][pc];
         }
-        if (j > 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (cur.active) {
+        cone_sync<CW>();
+        // ---- the levels of the chunk, from LDS ----
+        for (int jj = 0; jj < L; ++jj) {
+            const int first = ld_table(c0, j0 + jj);
+            const int u0 = U0[jj][tid], u1 = U1[jj][tid];
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 double t[8];
-                if (j == 0) { // from the block before (previous launch)
+                if (j0 + jj == 0) { // from the block before (previous launch)
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) t[k] = (cur.u0 + k < cur.u1) ? M.acc[v][cur.u0 + k] : 0.0;
+                    for (int k = 0; k < 8; ++k) t[k] = (u0 + k < u1) ? M.acc[v][u0 + k] : 0.0;
                 } else {
-                    const double *z = &y[v][(j - 1) & 1][0];
-                    const int base = cur.u0 - first_up;
+                    const double *z = jj == 0 ? &PREV[v][0] : &X[v][jj - 1][0];
+                    const int base = u0 - first_up;
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
-                        const bool have = cur.u0 + k < cur.u1;
+                        const bool have = u0 + k < u1;
                         const double w = z[have ? base + k : 0];
                         t[k] = have ? w : 0.0;
                     }
@@ -145,22 +148,23 @@ __global__ void __launch_bounds__(kBlock) k_accu_cones(cone_plan_args C, const i
                 double sum = 0.0;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) sum += t[k];
-                const double a = sum + cur.x[v];
-                M.acc[v][p] = a;
-                if (j + 1 < nl) y[v][j & 1][tid] = a;
+                const double a = sum + X[v][jj][tid];
+                X[v][jj][tid] = a;
+            }
+            cone_sync<CW>();
+            first_up = first;
+        }
+        // ---- the chunk's sums: one burst of stores; the last level stays behind for the next chunk ----
+        for (int jj = 0; jj < L; ++jj) {
+            const int p = ld_table(c0, j0 + jj) + tid;
+            if (p < ld_table(c1, j0 + jj)) {
+#pragma unroll
+                for (int v = 0; v < NV; ++v) M.acc[v][p] = X[v][jj][tid];
             }
         }
-        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the next level's operands are in
-        first_up = first;
-        return nfirst;
-    };
-    cell ra, rb;
-    int first = ld_table(c0, 0);
-    load(first + tid, first + tid < ld_table(c1, 0), ra);
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    for (int j = 0; j < nl; j += 2) {
-        first = level(j, ra, rb, first);
-        if (j + 1 < nl) first = level(j + 1, rb, ra, first);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) PREV[v][tid] = X[v][L - 1][tid];
+        cone_sync<CW>();
     }
 }
 
@@ -223,7 +227,7 @@ struct lf_router {
     lf_dbuf<int> fb_level_dev, fb_row_dev, fb_cone;
     lf_dbuf<int> fb_off_dev, fb_lvl2blk_dev; // fb_lvl2blk: block of every level (the sites of the structures variant)
     std::vector<int> fb_lvl2blk;
-    int fb_lmax = 0;
+    int fb_lmax = 0, fb_cw = kBlock;
     // the same plan with longer blocks for plain router calls (k_sweep_cones: no sub-step dimension to fill the machine
     // with, so fewer, longer launches pay): host tables + the cone starts on the device
     std::vector<int> rb_level, rb_row, rb_off;
@@ -564,7 +568,8 @@ static int build_level_blocks(lf_router *r, const lf_graph *g, bool for_route)
     if (for_route) { // one wavefront per cone: no barrier between the levels (deep 10 000^2: 11.3 -> 10.1 ms per call)
         cw = 64;
         if (const char *e = std::getenv("LF_ROUTE_CONE_WIDTH")) cw = std::atoi(e) == 64 ? 64 : kBlock;
-    }
+    } else if (const char *e = std::getenv("LF_FUSED_CONE_WIDTH"))
+        cw = std::atoi(e) == 64 ? 64 : kBlock;
     lf_block_plan plan;
     try {
         // every cell below the last level drains into the next level, so the upstream ranges tile the level before:
@@ -600,6 +605,7 @@ static int build_level_blocks(lf_router *r, const lf_graph *g, bool for_route)
     r->fb_row = row;
     r->fb_off = off;
     r->fb_lmax = lmax;
+    r->fb_cw = cw;
     return LF_OK;
 }
 
@@ -928,6 +934,25 @@ int lf_accuflux_ordered_multi_device(lf_router *r, int nv, const double *const *
             hipLaunchKernelGGL(KERNEL<4>, GRID, BLOCK, 0, s, __VA_ARGS__);                     \
         ++launches;                                                                            \
     } while (0)
+#define LF_ACCU_CW(NVV, GRID, ...)                                                            \
+    do {                                                                                       \
+        if (r->rb_cw == 64)                                                                    \
+            hipLaunchKernelGGL((k_accu_cones<NVV, 64>), GRID, dim3(64), 0, s, __VA_ARGS__);    \
+        else                                                                                   \
+            hipLaunchKernelGGL((k_accu_cones<NVV, kBlock>), GRID, dim3(kBlock), 0, s, __VA_ARGS__); \
+    } while (0)
+#define LF_ACCU_CONES(GRID, ...)                                                               \
+    do {                                                                                       \
+        if (nv == 1)                                                                           \
+            LF_ACCU_CW(1, GRID, __VA_ARGS__);                                                  \
+        else if (nv == 2)                                                                      \
+            LF_ACCU_CW(2, GRID, __VA_ARGS__);                                                  \
+        else if (nv == 3)                                                                      \
+            LF_ACCU_CW(3, GRID, __VA_ARGS__);                                                  \
+        else                                                                                   \
+            LF_ACCU_CW(4, GRID, __VA_ARGS__);                                                  \
+        ++launches;                                                                            \
+    } while (0)
     if (r->rb_lmax > 1 && cones_enabled()) {
         const int NB = (int)r->rb_level.size() - 1;
         for (int b = 0; b < NB; ++b) {
@@ -937,7 +962,7 @@ int lf_accuflux_ordered_multi_device(lf_router *r, int nv, const double *const *
                 C.cone = r->rb_cone.p + r->rb_off[b];
                 C.nl = nl;
                 const dim3 grid((unsigned)(r->rb_row[b + 1] - r->rb_row[b] - 1));
-                LF_ACCU(k_accu_cones, grid, dim3(kBlock), C, r->ups_ptr.p, M);
+                LF_ACCU_CONES(grid, C, r->ups_ptr.p, M);
             } else {
                 const int first = (int)r->h_level_start[k0];
                 const int count = (int)(r->h_level_start[k0 + 1] - r->h_level_start[k0]);
@@ -956,6 +981,8 @@ int lf_accuflux_ordered_multi_device(lf_router *r, int nv, const double *const *
         }
     }
 #undef LF_ACCU
+#undef LF_ACCU_CONES
+#undef LF_ACCU_CW
     r->last_stats[0] = launches;
     r->last_stats[1] = r->last_stats[2] = 0;
     r->last_stats[3] = r->NL;
@@ -1362,21 +1389,29 @@ int fused_impl(lf_router *r, const lf_substep_args *a, int nsteps, int64_t sidef
                 F.packed = 1;
                 F.use_lvl = 0;
                 const dim3 grid((unsigned)acc);
-#define LF_CONES(ST)                                                                               \
-    do {                                                                                           \
-        if (a->split && all35)                                                                     \
-            hipLaunchKernelGGL((k_fused_cones<true, true, ST>), grid, dim3(kBlock), 0, s, F);      \
-        else if (a->split)                                                                         \
-            hipLaunchKernelGGL((k_fused_cones<true, false, ST>), grid, dim3(kBlock), 0, s, F);     \
-        else if (all35)                                                                            \
-            hipLaunchKernelGGL((k_fused_cones<false, true, ST>), grid, dim3(kBlock), 0, s, F);     \
-        else                                                                                       \
-            hipLaunchKernelGGL((k_fused_cones<false, false, ST>), grid, dim3(kBlock), 0, s, F);    \
+#define LF_CONES_CW(ST, CW)                                                                                  \
+    do {                                                                                                     \
+        if (a->split && all35)                                                                               \
+            hipLaunchKernelGGL((k_fused_cones<true, true, ST, false, CW>), grid, dim3(CW), 0, s, F);         \
+        else if (a->split)                                                                                   \
+            hipLaunchKernelGGL((k_fused_cones<true, false, ST, false, CW>), grid, dim3(CW), 0, s, F);        \
+        else if (all35)                                                                                      \
+            hipLaunchKernelGGL((k_fused_cones<false, true, ST, false, CW>), grid, dim3(CW), 0, s, F);        \
+        else                                                                                                 \
+            hipLaunchKernelGGL((k_fused_cones<false, false, ST, false, CW>), grid, dim3(CW), 0, s, F);       \
+    } while (0)
+#define LF_CONES(ST)                                                                                         \
+    do {                                                                                                     \
+        if (r->fb_cw == 64)                                                                                  \
+            LF_CONES_CW(ST, 64);                                                                             \
+        else                                                                                                 \
+            LF_CONES_CW(ST, kBlock);                                                                         \
     } while (0)
                 if (in)
                     LF_CONES(true);
                 else
                     LF_CONES(false);
+#undef LF_CONES_CW
 #undef LF_CONES
                 ++launches;
             }

@@ -42,6 +42,25 @@ __device__ __forceinline__ double lf_solve_cell(double c, double a, double ba, d
     return q;
 }
 
+// The same out of line: inside the cone kernel's level loop the general path is taken by single lanes with extreme
+// arguments or not at all when beta = 3/5 -- one copy to jump to instead of ~1500 instructions to jump over per level
+__device__ __attribute__((noinline)) double lf_solve_cell_cold(double c, double a, double ba, double beta, double inv_beta,
+                                                               double b_minus_1)
+{
+    return lf_solve_cell(c, a, ba, beta, inv_beta, b_minus_1);
+}
+__device__ __attribute__((noinline)) double lf_pow_cold(double x, double y) { return pow(x, y); }
+// lf_pow_3_5 with the OCML fallback (arguments beyond the fast range) out of line
+__device__ __forceinline__ double lf_pow_3_5_hot(double x)
+{
+    if (x == 0.0) return 0.0;
+    if (lf_fast_range(x)) {
+        const double r = lf_root5(x);
+        return r * r * r;
+    }
+    return lf_pow_cold(x, 0.6);
+}
+
 // constant = a*Qold^beta + q*dx (kinematic_wave_parallel.py:163,175), gathered into sweep order
 __global__ void __launch_bounds__(kBlock) k_prep(int n, const int *__restrict__ perm, const double *__restrict__ q_pix,
                                                  const double *__restrict__ lat_pix, const double *__restrict__ a,
@@ -198,6 +217,15 @@ struct cone_plan_args {
     int nl;                       // levels of the block
 };
 
+template <int CW>
+__device__ __forceinline__ void cone_sync() // between the levels of a cone: workgroup barrier, or nothing for one wavefront
+{
+    if (CW > 64)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else
+        asm volatile("" ::: "memory"); // its LDS operations complete in order
+}
+
 // CW: cells per level of a cone = threads of the workgroup (64: one wavefront, no barrier between the levels)
 template <bool FUSED, bool ORDERED, int NR, int CW = kBlock>
 __global__ void __launch_bounds__(CW) k_sweep_cones(cone_plan_args C, sweep_args_multi M)
@@ -261,42 +289,53 @@ __global__ void __launch_bounds__(CW) k_sweep_cones(cone_plan_args C, sweep_args
             else
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // one wavefront: its LDS operations complete in order
         }
-        if (cur.active) {
+        // every lane runs the level's arithmetic (a lane beyond the cone's range: on cell 0, nothing of it is kept), the
+        // quintic path without a branch on sanitised arguments -- the loop over the levels is straight code but for the
+        // block's first level and the out-of-line general path (single lanes with extreme arguments, or beta != 3/5)
 #pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                const sweep_args &A = M.r[r];
-                double v[8];
-                if (j == 0) { // from the block before (previous launch)
+        for (int r = 0; r < NR; ++r) {
+            const sweep_args &A = M.r[r];
+            double v[8];
+            if (j == 0) { // from the block before (previous launch)
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = (k < A.kmax && cur.u0 + k < cur.u1) ? A.qord[cur.u0 + k] : 0.0;
-                } else {
-                    const double *y = &x[r][(j - 1) & 1][0];
-                    const int base = cur.u0 - first_up;
+                for (int k = 0; k < 8; ++k) v[k] = (k < A.kmax && cur.u0 + k < cur.u1) ? A.qord[cur.u0 + k] : 0.0;
+            } else {
+                const double *y = &x[r][(j - 1) & 1][0];
+                const int base = cur.u0 - first_up;
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const bool have = k < A.kmax && cur.u0 + k < cur.u1;
-                        const double t = y[have ? base + k : 0];
-                        v[k] = have ? t : 0.0;
-                    }
+                for (int k = 0; k < 8; ++k) {
+                    const bool have = k < A.kmax && cur.u0 + k < cur.u1;
+                    const double t = y[have ? base + k : 0];
+                    v[k] = have ? t : 0.0;
                 }
-                double ups = 0.0;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) ups += v[k];
-                const double ap = cur.ap[r];
-                const double cst = FUSED ? ap * lf_pow_3_5(cur.qold[r]) + cur.lat[r] * cur.dx[r] : cur.lat[r];
-                const double c = ups + cst;
-                double q;
-                if (FUSED && lf_fast_range(c) && lf_fast_range(ap))
-                    q = (c <= LF_NEWTON_TOL) ? 0.0 : lf_solve_3_5(c, ap);
-                else
-                    q = lf_solve_cell(c, ap, A.beta * ap, A.beta, A.inv_beta, A.b_minus_1);
-                pend_q[r] = q;
-                if (j + 1 < nl) x[r][j & 1][tid] = q;
             }
-            pend = true;
-            pend_p = p;
-            pend_pix = cur.pix;
+            double ups = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) ups += v[k];
+            const double ap = cur.ap[r];
+            double q;
+            if (FUSED) {
+                const double qo = cur.qold[r];
+                const bool fq = lf_fast_range(qo);
+                const double rt = lf_root5(fq ? qo : 1.0);
+                double pw = fq ? rt * rt * rt : 0.0;                  // lf_pow_3_5: +-0 -> +0
+                if (!fq && qo != 0.0) pw = lf_pow_cold(qo, 0.6);      // beyond the fast range, NaN
+                const double c = ups + (ap * pw + cur.lat[r] * cur.dx[r]);
+                const bool fc = lf_fast_range(c) && lf_fast_range(ap);
+                const bool solve = fc && !(c <= LF_NEWTON_TOL);
+                q = lf_solve_3_5(solve ? c : 1.0, solve ? ap : 1.0);
+                q = solve ? q : 0.0;                                   // fast range and c <= NEWTON_TOL: 0
+                if (!fc) q = lf_solve_cell_cold(c, ap, A.beta * ap, A.beta, A.inv_beta, A.b_minus_1);
+            } else {
+                const double c = ups + cur.lat[r];
+                q = lf_solve_cell(c, ap, A.beta * ap, A.beta, A.inv_beta, A.b_minus_1);
+            }
+            pend_q[r] = q;
+            if (j + 1 < nl) x[r][j & 1][tid] = q;
         }
+        pend = cur.active;
+        pend_p = p;
+        pend_pix = cur.pix;
         first_up = first;
     };
     auto bound = [&](const int *t, int k) { return k < nl ? ld_table(t, k) : 0; };
