@@ -68,8 +68,8 @@ SEEDS = {"shallow": 1, "deep": 2, "river": 7}
 
 
 def build_case(family, H, W):
-    """the synthetic raster of `family` with a router on it: runs of narrow levels are swept in blocks of up to 64 levels,
-    cone by cone (k_sweep_cones), wide levels one launch each (k_level)"""
+    """the synthetic raster of `family` with a router on it: runs of narrow levels are swept in blocks of up to 256 levels,
+    cone by cone (k_sweep_cones, one wavefront per cone), wide levels one launch each (k_level)"""
     from lisflood_amd import synthetic as syn
     from lisflood_amd.kinematic_wave_parallel import Graph, kinematicWave
     t = time.time()
@@ -177,7 +177,9 @@ def committed_rocprof_mean(cells_per_launch):
     next to the live hipEvent figure so that the two can be compared (the boxes differ by up to ~8 % on this kernel)."""
     import csv
     import glob
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*head_kernel_stats.csv")), reverse=True):
+    # newest first by its tag (r02c < r03 < r03d: the text before "head")
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*head_kernel_stats.csv")),
+                    key=lambda f: os.path.basename(f).split("head")[0], reverse=True):
         try:
             for r in csv.DictReader(open(f)):
                 if "k_level<true, true, false>" in r["Name"]:
