@@ -76,6 +76,10 @@ struct lf_dist_graph {
     // level blocks and cones of every phase (lf_blocks.h; k_fused_cones<DIST>): blocks never span two phases
     lf_block_plan fplan;
     std::vector<int32_t> fplan_phase_block; // [nphases + 1] first block of every phase
+    // the same for single router calls (k_sweep_cones<DIST>): blocks never span two STAGES (a phase's boundary-critical
+    // part and its bulk are swept separately), one wavefront per cone, blocks of up to LF_ROUTE_LEVELS (256) units
+    lf_block_plan rplan;
+    std::vector<int32_t> rplan_stage_block; // [2 * nphases + 1] first block of every stage
 };
 
 namespace {
@@ -467,6 +471,23 @@ int lf_dist_graph_finalize(lf_dist_graph *g, int nphases)
                     lf_build_level_blocks(g->level_start, g->phase_level[j], g->phase_level[j + 1], lmax, wide, kBlock,
                                           [&](int64_t pos) { return (int64_t)child[(size_t)pos]; }, g->fplan);
                 }
+            int rmax = 256;
+            if (const char *e = std::getenv("LF_ROUTE_LEVELS")) rmax = std::atoi(e);
+            rmax = rmax < 1 ? 1 : (rmax > 512 ? 512 : rmax);
+            g->rplan = lf_block_plan();
+            g->rplan_stage_block.assign(nstages + 1, 0);
+            if (rmax > 1 && n < ((int64_t)1 << 31))
+                for (int st = 0; st < nstages; ++st) {
+                    g->rplan_stage_block[st] = (int32_t)g->rplan.level.size();
+                    lf_build_level_blocks(g->level_start, g->stage_level[st], g->stage_level[st + 1], rmax, wide, 64,
+                                          [&](int64_t pos) { return (int64_t)child[(size_t)pos]; }, g->rplan);
+                }
+            g->rplan_stage_block[nstages] = (int32_t)g->rplan.level.size();
+            g->rplan.level.push_back((int)(g->level_start.size() - 1));
+            if (!g->rplan.any_multi || g->rplan.cone.size() >= ((size_t)1 << 31)) { // one launch per unit it is
+                g->rplan = lf_block_plan();
+                g->rplan_stage_block.clear();
+            }
         } catch (const std::bad_alloc &) {
             return lf_set_error(LF_E_INVALID, "out of host memory while building the level blocks");
         }
@@ -748,6 +769,10 @@ struct lf_dist_router {
     std::vector<int> fb_level, fb_row, fb_off;
     std::vector<int32_t> fb_phase_block;
     lf_dbuf<int> fb_level_dev, fb_row_dev, fb_off_dev, fb_cone;
+    // level blocks + cones of every stage for single router calls (lf_dist_graph::rplan; empty: the segment schedule)
+    std::vector<int> rb_level, rb_row, rb_off;
+    std::vector<int32_t> rb_stage_block;
+    lf_dbuf<int> rb_cone;
 };
 
 namespace {
@@ -786,7 +811,37 @@ int dist_compute_phase(lf_dist_router *r, double *q, const double *lat, int sect
                            r->dx_scalar, r->beta, r->constant.p);
         r->last_launches++;
     }
-    for (int st = 2 * phase + (part == 1 ? 1 : 0); st <= 2 * phase + (part == 0 ? 0 : 1); ++st)
+    const char *cones_env = std::getenv("LF_ROUTE_CONES"); // (read at every call, as the single-domain router does)
+    const bool cones = !r->rb_stage_block.empty() && !(cones_env && cones_env[0] == '0');
+    for (int st = 2 * phase + (part == 1 ? 1 : 0); st <= 2 * phase + (part == 0 ? 0 : 1); ++st) {
+        if (cones) { // blocks of units cone by cone (k_sweep_cones<DIST>), single wide units by the level kernel
+            sweep_args_multi M;
+            M.r[0] = A;
+            for (int b = r->rb_stage_block[st]; b < r->rb_stage_block[st + 1]; ++b) {
+                const int k0 = r->rb_level[b], nl = r->rb_level[b + 1] - k0;
+                if (nl > 1) {
+                    cone_plan_args C;
+                    C.cone = r->rb_cone.p + r->rb_off[b];
+                    C.nl = nl;
+                    const dim3 grid((unsigned)(r->rb_row[b + 1] - r->rb_row[b] - 1)), block(64);
+                    if (r->fused)
+                        hipLaunchKernelGGL((k_sweep_cones<true, true, 1, 64, true>), grid, block, 0, s, C, M);
+                    else
+                        hipLaunchKernelGGL((k_sweep_cones<false, true, 1, 64, true>), grid, block, 0, s, C, M);
+                } else {
+                    const int first = (int)r->h_level_start[k0];
+                    const int count = (int)(r->h_level_start[k0 + 1] - r->h_level_start[k0]);
+                    if (count <= 0) continue;
+                    const dim3 grid(level_blocks_for(count)), block(kLevelBlock);
+                    if (r->fused)
+                        hipLaunchKernelGGL((k_level<true, true, true>), grid, block, 0, s, first, count, A);
+                    else
+                        hipLaunchKernelGGL((k_level<false, true, true>), grid, block, 0, s, first, count, A);
+                }
+                r->last_launches++;
+            }
+            continue;
+        }
     for (const dsegment &g : r->schedule[st]) {
         if (g.wide) {
             const int first = (int)r->h_level_start[g.k0];
@@ -806,6 +861,7 @@ int dist_compute_phase(lf_dist_router *r, double *q, const double *lat, int sect
                                    r->level_start.p, A);
         }
         r->last_launches++;
+    }
     }
     LF_HIP(hipGetLastError());
     return LF_OK;
@@ -916,6 +972,17 @@ int lf_dist_router_create(const lf_dist_graph *g, const double *alpha, double be
         r->fb_row = g->fplan.row;
         r->fb_off = g->fplan.off;
         r->fb_phase_block = g->fplan_phase_block;
+    }
+    if (!g->rplan_stage_block.empty()) {
+        const int rc2 = r->rb_cone.upload(g->rplan.cone.data(), g->rplan.cone.size());
+        if (rc2 != LF_OK) {
+            delete r;
+            return rc2;
+        }
+        r->rb_level = g->rplan.level;
+        r->rb_row = g->rplan.row;
+        r->rb_off = g->rplan.off;
+        r->rb_stage_block = g->rplan_stage_block;
     }
     r->n_slots = g->n_slots;
     for (int side = 0; side < 2; ++side) {

@@ -227,7 +227,11 @@ __device__ __forceinline__ void cone_sync() // between the levels of a cone: wor
 }
 
 // CW: cells per level of a cone = threads of the workgroup (64: one wavefront, no barrier between the levels)
-template <bool FUSED, bool ORDERED, int NR, int CW = kBlock>
+// DIST (row-block partition, lf_dist.hip: NR = 1, ORDERED): a cell's upstream cells are the consecutive run starting at
+// ups_base or come from the list ups_idx; those in the level above of this cone are read from LDS, all others (ghost slots,
+// earlier phases, the block before) are final in the state vector.  The old discharge may come from a second state vector
+// (qold_src: pipelined calls).
+template <bool FUSED, bool ORDERED, int NR, int CW = kBlock, bool DIST = false>
 __global__ void __launch_bounds__(CW) k_sweep_cones(cone_plan_args C, sweep_args_multi M)
 {
     __shared__ double x[NR][2][CW];
@@ -235,15 +239,17 @@ __global__ void __launch_bounds__(CW) k_sweep_cones(cone_plan_args C, sweep_args
     const int *c0 = C.cone + (size_t)blockIdx.x * nl, *c1 = c0 + nl;
     struct cell { // the operands of one cell as loaded: no arithmetic before the level that solves it (a product here
                   // would make the loads wait where they are issued)
-        int u0, u1, pix;
+        int u0, u1, pix, base;
         double ap[NR], lat[NR], dx[NR], qold[NR];
         bool active;
     };
+    const double *qold_from = (DIST && M.r[0].qold_src) ? M.r[0].qold_src : M.r[0].qord;
     auto load = [&](int p, bool active, cell &R) {
         R.active = active;
         const int pc = active ? p : 0; // lanes beyond the cone's range load cell 0: no branch around the loads
         R.u0 = M.r[0].ups_ptr[pc];
         R.u1 = M.r[0].ups_ptr[pc + 1];
+        R.base = DIST ? M.r[0].ups_base[pc] : 0;
         R.pix = ORDERED ? pc : M.r[0].perm[pc];
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
@@ -252,7 +258,7 @@ __global__ void __launch_bounds__(CW) k_sweep_cones(cone_plan_args C, sweep_args
             if (FUSED) {
                 R.lat[r] = A.lat[R.pix];
                 R.dx[r] = A.dx ? A.dx[pc] : A.dx_scalar;
-                R.qold[r] = ORDERED ? A.qord[pc] : A.q_pix[R.pix];
+                R.qold[r] = DIST ? qold_from[pc] : (ORDERED ? A.qord[pc] : A.q_pix[R.pix]);
             } else {
                 R.lat[r] = A.constant[pc];
                 R.dx[r] = 1.0;
@@ -260,7 +266,7 @@ __global__ void __launch_bounds__(CW) k_sweep_cones(cone_plan_args C, sweep_args
             }
         }
     };
-    int first_up = 0;
+    int first_up = 0, last_up = 0;
     // the stores of a level are issued one level later, right behind the barrier (with the next loads): then everything
     // outstanding at the end of a level was issued before its arithmetic, and the wait there is short
     double pend_q[NR];
@@ -279,7 +285,7 @@ __global__ void __launch_bounds__(CW) k_sweep_cones(cone_plan_args C, sweep_args
     // level times to arrive (one level of a cone takes about as long as one trip to memory: with depth 1 every level
     // waited for its own loads).  Three operand sets rotate; the waits are the compiler's (vmcnt counts the loads and
     // stores issued since, nothing is waited for that is not needed).
-    auto level = [&](int j, const cell &cur, cell &nn, int first, int fn2, int ln2) {
+    auto level = [&](int j, const cell &cur, cell &nn, int first, int last, int fn2, int ln2) {
         const int p = first + tid;
         flush();
         load(fn2 + tid, fn2 + tid < ln2, nn); // nothing of them depends on this launch; beyond the block: bounds 0, 0
@@ -296,7 +302,20 @@ __global__ void __launch_bounds__(CW) k_sweep_cones(cone_plan_args C, sweep_args
         for (int r = 0; r < NR; ++r) {
             const sweep_args &A = M.r[r];
             double v[8];
-            if (j == 0) { // from the block before (previous launch)
+            if (DIST) {
+                const double *y = &x[r][(j - 1) & 1][0];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const bool have = k < A.kmax && cur.u0 + k < cur.u1;
+                    int e = cur.base + k;
+                    if (cur.base < 0) e = have ? A.ups_idx[cur.u0 + k] : 0; // ghost or cross-phase inflow: from the list
+                    const bool above = j > 0 && e >= first_up && e < last_up; // in the level above of this cone: LDS
+                    const double t = y[above ? e - first_up : 0];
+                    double gq = 0.0;
+                    if (have && !above) gq = A.qord[e]; // final: ghost slot, earlier phase, the block before
+                    v[k] = have ? (above ? t : gq) : 0.0;
+                }
+            } else if (j == 0) { // from the block before (previous launch)
 #pragma unroll
                 for (int k = 0; k < 8; ++k) v[k] = (k < A.kmax && cur.u0 + k < cur.u1) ? A.qord[cur.u0 + k] : 0.0;
             } else {
@@ -337,24 +356,27 @@ __global__ void __launch_bounds__(CW) k_sweep_cones(cone_plan_args C, sweep_args
         pend_p = p;
         pend_pix = cur.pix;
         first_up = first;
+        last_up = last;
     };
     auto bound = [&](const int *t, int k) { return k < nl ? ld_table(t, k) : 0; };
     cell r0, r1, r2;
-    int f0 = ld_table(c0, 0), f1 = bound(c0, 1), f2 = bound(c0, 2), l2 = bound(c1, 2);
-    load(f0 + tid, f0 + tid < ld_table(c1, 0), r0);
-    load(f1 + tid, f1 + tid < bound(c1, 1), r1);
+    int f0 = ld_table(c0, 0), f1 = bound(c0, 1), f2 = bound(c0, 2), l0 = ld_table(c1, 0), l1 = bound(c1, 1), l2 = bound(c1, 2);
+    load(f0 + tid, f0 + tid < l0, r0);
+    load(f1 + tid, f1 + tid < l1, r1);
     // three levels per trip, no branch around a level or its loads (the wait counts stay exact): a level beyond the block
     // has the bounds 0, 0 -- no active cell, only its barrier
     for (int j = 0; j < nl; j += 3) {
         // bounds of the levels whose operands this round of three requests
         const int f3 = bound(c0, j + 3), l3 = bound(c1, j + 3), f4 = bound(c0, j + 4), l4 = bound(c1, j + 4);
         const int f5 = bound(c0, j + 5), l5 = bound(c1, j + 5);
-        level(j, r0, r2, f0, f2, l2);
-        level(j + 1, r1, r0, f1, f3, l3);
-        level(j + 2, r2, r1, f2, f4, l4);
+        level(j, r0, r2, f0, l0, f2, l2);
+        level(j + 1, r1, r0, f1, l1, f3, l3);
+        level(j + 2, r2, r1, f2, l2, f4, l4);
         f0 = f3;
         f1 = f4;
         f2 = f5;
+        l0 = l3;
+        l1 = l4;
         l2 = l5;
     }
     flush();
