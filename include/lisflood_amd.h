@@ -531,6 +531,11 @@ int lf_dist_graph_get_fused_tables(const lf_dist_graph *g, int32_t *out_slot, in
 /* level blocks of the fused path (per phase, cone by cone): out = {blocks, blocks of more than one level, cones, entries
  * of the cone table}; all 0 when no block holds more than one level (then: one launch per level and sub-step wave) */
 int lf_dist_graph_block_stats(const lf_dist_graph *g, int64_t out[4]);
+/* the block plan of single router calls on the partition (one plan per stage = phase x {boundary-critical part, bulk};
+ * blocks of launch units, each cut into cones of at most 64 cells per unit; see lf_blocks.h for the table layout):
+ * sizes = {stages + 1, blocks + 1, rows, entries of the cone table, launch units + 1}; arrays may be NULL (sizes only) */
+int lf_dist_graph_get_route_plan(const lf_dist_graph *g, int64_t sizes[5], int32_t *stage_block, int32_t *level,
+                                 int32_t *row, int32_t *off, int32_t *cone, int64_t *level_start);
 /* the pieces of a call, for transports other than RCCL and for tests */
 int lf_dist_router_compute_phase(lf_dist_router *r, double *q_ord_dev, const double *lat_ord_dev, int section,
                                  int phase);

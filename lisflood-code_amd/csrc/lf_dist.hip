@@ -597,6 +597,29 @@ int lf_dist_graph_block_stats(const lf_dist_graph *g, int64_t out[4])
     out[3] = (int64_t)f.cone.size();
     return LF_OK;
 }
+// the block plan of single router calls (k_sweep_cones<DIST>), for tests: sizes = {stages + 1, blocks + 1, rows (= blocks
+// + 1 entries), entries of the cone table, launch units + 1}; with the arrays NULL only the sizes are returned.  All sizes 0
+// when no block holds more than one unit.
+int lf_dist_graph_get_route_plan(const lf_dist_graph *g, int64_t sizes[5], int32_t *stage_block, int32_t *level, int32_t *row,
+                                 int32_t *off, int32_t *cone, int64_t *level_start)
+{
+    if (!g || !g->finalized || !sizes) return lf_set_error(LF_E_INVALID, "graph not finalized");
+    sizes[0] = sizes[1] = sizes[2] = sizes[3] = 0;
+    sizes[4] = (int64_t)g->level_start.size();
+    if (level_start) std::memcpy(level_start, g->level_start.data(), sizeof(int64_t) * g->level_start.size());
+    if (g->rplan_stage_block.empty()) return LF_OK;
+    const lf_block_plan &f = g->rplan;
+    sizes[0] = (int64_t)g->rplan_stage_block.size();
+    sizes[1] = (int64_t)f.level.size();
+    sizes[2] = (int64_t)f.row.size();
+    sizes[3] = (int64_t)f.cone.size();
+    if (stage_block) std::memcpy(stage_block, g->rplan_stage_block.data(), sizeof(int32_t) * g->rplan_stage_block.size());
+    if (level) std::memcpy(level, f.level.data(), sizeof(int32_t) * f.level.size());
+    if (row) std::memcpy(row, f.row.data(), sizeof(int32_t) * f.row.size());
+    if (off) std::memcpy(off, f.off.data(), sizeof(int32_t) * f.off.size());
+    if (cone) std::memcpy(cone, f.cone.data(), sizeof(int32_t) * f.cone.size());
+    return LF_OK;
+}
 // the fused path's tables by position: out_slot[N], ups_idx_f[n_edges] (either may be NULL)
 int lf_dist_graph_get_fused_tables(const lf_dist_graph *g, int32_t *out_slot, int32_t *ups_idx_f)
 {

@@ -126,6 +126,21 @@ class DistGraph:
         check(lib().lf_dist_graph_slab_layout(self._h, o))
         return dict(slots=int(o[0]), export=(int(o[1]), int(o[2])), ghost=(int(o[3]), int(o[4])), xphase=int(o[5]))
 
+    def route_plan(self):
+        """the block plan of single router calls (lf_dist_graph_get_route_plan): dict(stage_block, level, row, off, cone,
+        level_start) or None when no block holds more than one launch unit"""
+        sizes = (C.c_int64 * 5)()
+        check(lib().lf_dist_graph_get_route_plan(self._h, sizes, None, None, None, None, None, None))
+        ls = np.empty(int(sizes[4]), np.int64)
+        if sizes[0] == 0:
+            check(lib().lf_dist_graph_get_route_plan(self._h, sizes, None, None, None, None, None, ptr(ls)))
+            return None
+        sb, lv, row = (np.empty(int(sizes[i]), np.int32) for i in range(3))
+        off = np.empty(int(sizes[1]) - 1, np.int32)
+        cone = np.empty(int(sizes[3]), np.int32)
+        check(lib().lf_dist_graph_get_route_plan(self._h, sizes, ptr(sb), ptr(lv), ptr(row), ptr(off), ptr(cone), ptr(ls)))
+        return dict(stage_block=sb, level=lv, row=row, off=off, cone=cone, level_start=ls)
+
     def fused_tables(self):
         """(out_slot[N] by position, ups_idx_f[n_edges]): see lf_dist_graph_get_fused_tables"""
         out_slot = np.empty(self.num_pixels, np.int32)

@@ -51,6 +51,42 @@ class RankState:
         b, e = self.g.part_range(j, part)
         oracle.sweep_positions(self.state, self.constant, self.ups_ptr, self.ups_idx, self.a, self.ba, self.beta, b, e)
 
+    def compute_stage_cones(self, st, plan, reverse=False):
+        """Stage `st` (= 2 * phase + part) as k_sweep_cones<DIST> runs it on the block plan `plan` (DistGraph.route_plan):
+        block after block; the cones of a block in any order; inside a cone unit by unit, where ONLY the unit just solved
+        is visible as new (the kernel's LDS row) -- every other cell of the block still shows its old value until the
+        whole block is done (what the kernel may read from the state vector must be final before the launch).  A plan
+        whose cones did not hold everything a unit needs from the unit above would read stale values here."""
+        ls = plan["level_start"]
+        for b in range(plan["stage_block"][st], plan["stage_block"][st + 1]):
+            k0 = int(plan["level"][b])
+            nl = int(plan["level"][b + 1]) - k0
+            ncones = int(plan["row"][b + 1] - plan["row"][b]) - 1
+            rows = plan["cone"][plan["off"][b]:plan["off"][b] + (ncones + 1) * nl].reshape(ncones + 1, nl)
+            for j in range(nl):                                  # the cones tile every unit of the block
+                assert rows[0, j] == ls[k0 + j] and rows[ncones, j] == ls[k0 + j + 1] and (np.diff(rows[:, j]) >= 0).all()
+            if nl == 1:                                          # a single (wide) unit: the level kernel
+                self._sweep(int(ls[k0]), int(ls[k0 + 1]))
+                continue
+            done = []
+            for c in (range(ncones - 1, -1, -1) if reverse else range(ncones)):
+                prev = None
+                for j in range(nl):
+                    lo, hi = int(rows[c, j]), int(rows[c + 1, j])
+                    assert hi - lo <= 64
+                    old = self.state[lo:hi].copy()
+                    self._sweep(lo, hi)
+                    done.append((lo, hi, self.state[lo:hi].copy()))
+                    if prev is not None:                         # the unit above is not visible any longer
+                        self.state[prev[0]:prev[1]] = prev[2]
+                    prev = (lo, hi, old)
+                self.state[prev[0]:prev[1]] = prev[2]
+            for lo, hi, new in done:                             # the block's discharges: visible to the next launch
+                self.state[lo:hi] = new
+
+    def _sweep(self, b, e):
+        oracle.sweep_positions(self.state, self.constant, self.ups_ptr, self.ups_idx, self.a, self.ba, self.beta, b, e)
+
     def send_values(self, j, side):
         return self.state[self.g.round_send_positions(j, side)].copy()
 

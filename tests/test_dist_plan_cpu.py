@@ -366,3 +366,55 @@ def test_boundary_critical_part_is_independent_of_the_bulk(oracle, family, seed,
         for rk, s in zip(ranks, sel):
             full[s] = rk.pixel_values()
         assert np.array_equal(full, ref[step])
+
+
+@pytest.mark.parametrize("family,seed,H,W,nranks", [("deep", 2, 90, 70, 3), ("saddle", 6, 80, 64, 4), ("river", 7, 120, 90, 3),
+                                                    ("shallow", 1, 64, 48, 8)])
+def test_block_plan_of_single_router_calls(oracle, family, seed, H, W, nranks):
+    """lf_dist_graph's plan for k_sweep_cones<DIST> (one plan per stage: blocks of launch units, cones of <= 64 cells per
+    unit), executed on the CPU the way the kernel may see memory -- inside a cone only the unit just solved is new, the
+    rest of the block shows old values until the block is complete, the cones of a block run in either order --: the
+    single-domain oracle's discharge bit for bit, two calls.  LF_ROUTE_LEVELS=4 in a second pass cuts the blocks short."""
+    codes = syn.make_ldd(family, H, W, seed)
+    mask = np.ones((H, W), bool)
+    N = H * W
+    p = syn.router_params(N, seed=5)
+    qs = [syn.lateral_inflow(N, s) for s in range(2)]
+    ref = global_reference(oracle, codes, mask, p["alpha"], p["dx"], p["dt"], p["beta"], p["Q0"], qs)
+    for lmax in (None, "4"):
+        if lmax:
+            os.environ["LF_ROUTE_LEVELS"] = lmax
+        try:
+            blocks, graphs = X.build_blocks(codes, mask, nranks)
+            nph = D.settle_phases_local(graphs)
+        finally:
+            os.environ.pop("LF_ROUTE_LEVELS", None)
+        plans = [g.route_plan() for g in graphs]
+        assert any(pl is not None for pl in plans)
+        sel = [np.arange(r0 * W, r1 * W) for (r0, r1) in blocks]
+        ranks = [X.RankState(g, p["alpha"][s], p["dx"][s], p["dt"], p["beta"], p["Q0"][s]) for g, s in zip(graphs, sel)]
+        multi = 0
+        for step, q in enumerate(qs):
+            for rk, s in zip(ranks, sel):
+                rk.begin_call(q[s])
+            for j in range(nph):
+                for rk, pl in zip(ranks, plans):
+                    for part in (0, 1):
+                        if pl is None:
+                            rk.compute_part(j, part)
+                        else:
+                            assert len(pl["stage_block"]) == 2 * nph + 1
+                            rk.compute_stage_cones(2 * j + part, pl, reverse=bool((step + j + part) % 2))
+                            multi += int((np.diff(pl["level"]) > 1).sum())
+                if j + 1 < nph:
+                    sends = [[rk.send_values(j, side) for side in (0, 1)] for rk in ranks]
+                    for k, rk in enumerate(ranks):
+                        if k > 0:
+                            rk.recv_values(j, 0, sends[k - 1][1])
+                        if k + 1 < nranks:
+                            rk.recv_values(j, 1, sends[k + 1][0])
+            full = np.empty(N)
+            for rk, s in zip(ranks, sel):
+                full[s] = rk.pixel_values()
+            assert np.array_equal(full, ref[step]), (family, lmax, step)
+        assert multi > 0                                          # blocks of several units did occur
