@@ -838,8 +838,6 @@ int dist_compute_phase(lf_dist_router *r, double *q, const double *lat, int sect
     const bool cones = !r->rb_stage_block.empty() && !(cones_env && cones_env[0] == '0');
     for (int st = 2 * phase + (part == 1 ? 1 : 0); st <= 2 * phase + (part == 0 ? 0 : 1); ++st) {
         if (cones) { // blocks of units cone by cone (k_sweep_cones<DIST>), single wide units by the level kernel
-            sweep_args_multi M;
-            M.r[0] = A;
             for (int b = r->rb_stage_block[st]; b < r->rb_stage_block[st + 1]; ++b) {
                 const int k0 = r->rb_level[b], nl = r->rb_level[b + 1] - k0;
                 if (nl > 1) {
@@ -848,9 +846,9 @@ int dist_compute_phase(lf_dist_router *r, double *q, const double *lat, int sect
                     C.nl = nl;
                     const dim3 grid((unsigned)(r->rb_row[b + 1] - r->rb_row[b] - 1)), block(64);
                     if (r->fused)
-                        hipLaunchKernelGGL((k_sweep_cones<true, true, 1, 64, true>), grid, block, 0, s, C, M);
+                        hipLaunchKernelGGL((k_sweep_cones_dist<true>), grid, block, 0, s, C, A);
                     else
-                        hipLaunchKernelGGL((k_sweep_cones<false, true, 1, 64, true>), grid, block, 0, s, C, M);
+                        hipLaunchKernelGGL((k_sweep_cones_dist<false>), grid, block, 0, s, C, A);
                 } else {
                     const int first = (int)r->h_level_start[k0];
                     const int count = (int)(r->h_level_start[k0 + 1] - r->h_level_start[k0]);

@@ -227,11 +227,7 @@ __device__ __forceinline__ void cone_sync() // between the levels of a cone: wor
 }
 
 // CW: cells per level of a cone = threads of the workgroup (64: one wavefront, no barrier between the levels)
-// DIST (row-block partition, lf_dist.hip: NR = 1, ORDERED): a cell's upstream cells are the consecutive run starting at
-// ups_base or come from the list ups_idx; those in the level above of this cone are read from LDS, all others (ghost slots,
-// earlier phases, the block before) are final in the state vector.  The old discharge may come from a second state vector
-// (qold_src: pipelined calls).
-template <bool FUSED, bool ORDERED, int NR, int CW = kBlock, bool DIST = false>
+template <bool FUSED, bool ORDERED, int NR, int CW = kBlock>
 __global__ void __launch_bounds__(CW) k_sweep_cones(cone_plan_args C, sweep_args_multi M)
 {
     __shared__ double x[NR][2][CW];
@@ -239,17 +235,15 @@ __global__ void __launch_bounds__(CW) k_sweep_cones(cone_plan_args C, sweep_args
     const int *c0 = C.cone + (size_t)blockIdx.x * nl, *c1 = c0 + nl;
     struct cell { // the operands of one cell as loaded: no arithmetic before the level that solves it (a product here
                   // would make the loads wait where they are issued)
-        int u0, u1, pix, base;
+        int u0, u1, pix;
         double ap[NR], lat[NR], dx[NR], qold[NR];
         bool active;
     };
-    const double *qold_from = (DIST && M.r[0].qold_src) ? M.r[0].qold_src : M.r[0].qord;
     auto load = [&](int p, bool active, cell &R) {
         R.active = active;
         const int pc = active ? p : 0; // lanes beyond the cone's range load cell 0: no branch around the loads
         R.u0 = M.r[0].ups_ptr[pc];
         R.u1 = M.r[0].ups_ptr[pc + 1];
-        R.base = DIST ? M.r[0].ups_base[pc] : 0;
         R.pix = ORDERED ? pc : M.r[0].perm[pc];
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
@@ -258,7 +252,7 @@ __global__ void __launch_bounds__(CW) k_sweep_cones(cone_plan_args C, sweep_args
             if (FUSED) {
                 R.lat[r] = A.lat[R.pix];
                 R.dx[r] = A.dx ? A.dx[pc] : A.dx_scalar;
-                R.qold[r] = DIST ? qold_from[pc] : (ORDERED ? A.qord[pc] : A.q_pix[R.pix]);
+                R.qold[r] = ORDERED ? A.qord[pc] : A.q_pix[R.pix];
             } else {
                 R.lat[r] = A.constant[pc];
                 R.dx[r] = 1.0;
@@ -302,20 +296,7 @@ __global__ void __launch_bounds__(CW) k_sweep_cones(cone_plan_args C, sweep_args
         for (int r = 0; r < NR; ++r) {
             const sweep_args &A = M.r[r];
             double v[8];
-            if (DIST) {
-                const double *y = &x[r][(j - 1) & 1][0];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const bool have = k < A.kmax && cur.u0 + k < cur.u1;
-                    int e = cur.base + k;
-                    if (cur.base < 0) e = have ? A.ups_idx[cur.u0 + k] : 0; // ghost or cross-phase inflow: from the list
-                    const bool above = j > 0 && e >= first_up && e < last_up; // in the level above of this cone: LDS
-                    const double t = y[above ? e - first_up : 0];
-                    double gq = 0.0;
-                    if (have && !above) gq = A.qord[e]; // final: ghost slot, earlier phase, the block before
-                    v[k] = have ? (above ? t : gq) : 0.0;
-                }
-            } else if (j == 0) { // from the block before (previous launch)
+            if (j == 0) { // from the block before (previous launch)
 #pragma unroll
                 for (int k = 0; k < 8; ++k) v[k] = (k < A.kmax && cur.u0 + k < cur.u1) ? A.qord[cur.u0 + k] : 0.0;
             } else {
@@ -380,6 +361,151 @@ __global__ void __launch_bounds__(CW) k_sweep_cones(cone_plan_args C, sweep_args
         l2 = l5;
     }
     flush();
+}
+
+// The same on the row-block partition (lf_dist.hip; one router, sweep-order vectors, one wavefront per cone).  A cell's
+// upstream cells are the consecutive run starting at ups_base or come from the list ups_idx; those in the unit above of
+// this cone are new this launch and come from LDS, all others -- ghost slots, earlier phases, the block before -- are
+// final in the state vector.  Reading those inside the level would cost two dependent trips to memory on every level that
+// has one such cell, so the prefetch has THREE stages over five rotating register sets:
+//   A  four units ahead: upstream range, run start and the operands;
+//   B  two units ahead:  the upstream positions (run start + k, or the list entries -- needs A);
+//   C  one unit ahead:   the discharges of the positions that are not in the unit above (needs B; usually L2 hits);
+// the level itself touches LDS and registers only.  qold_src: the old discharge from a second state vector (pipelined calls).
+template <bool FUSED>
+__global__ void __launch_bounds__(64) k_sweep_cones_dist(cone_plan_args C, sweep_args A)
+{
+    __shared__ double x[2][64];
+    const int tid = threadIdx.x, nl = C.nl;
+    const int *c0 = C.cone + (size_t)blockIdx.x * nl, *c1 = c0 + nl;
+    const double *qold_from = A.qold_src ? A.qold_src : A.qord;
+    const int kmax = A.kmax;
+    struct cell {
+        int u0, u1, base, p;
+        double ap, lat, dx, qold;
+        int e[8];
+        double gq[8];
+        bool active;
+    };
+    auto stage_a = [&](int first, int last, cell &R) {
+        const int p = first + tid;
+        R.active = p < last;
+        const int pc = R.active ? p : 0; // a lane beyond the cone's range: cell 0, nothing of it is kept
+        R.p = p;
+        R.u0 = A.ups_ptr[pc];
+        R.u1 = A.ups_ptr[pc + 1];
+        R.base = A.ups_base[pc];
+        R.ap = A.a[pc];
+        if (FUSED) {
+            R.lat = A.lat[pc];
+            R.dx = A.dx ? A.dx[pc] : A.dx_scalar;
+            R.qold = qold_from[pc];
+        } else {
+            R.lat = A.constant[pc];
+            R.dx = 1.0;
+            R.qold = 0.0;
+        }
+    };
+    auto stage_b = [&](cell &R) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const bool have = k < kmax && R.u0 + k < R.u1;
+            int e = R.base + k;
+            if (R.base < 0) e = have ? A.ups_idx[R.u0 + k] : 0; // ghost or cross-phase inflow: from the list
+            R.e[k] = have ? e : -1;
+        }
+    };
+    // [fa, la): the cone's range in the unit above (empty for the block's first unit: everything comes from memory)
+    auto stage_c = [&](cell &R, int fa, int la) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int e = R.e[k];
+            const bool ext = e >= 0 && !(e >= fa && e < la);
+            R.gq[k] = 0.0;
+            if (ext) R.gq[k] = A.qord[e];
+        }
+    };
+    double pend_q = 0.0;
+    int pend_p = 0;
+    bool pend = false;
+    auto level = [&](int j, const cell &cur, cell &n1, cell &n2, cell &n4, int first, int last, int fa, int la, int f4,
+                     int l4) {
+        if (pend) A.qord[pend_p] = pend_q;
+        stage_a(f4, l4, n4);
+        stage_b(n2);
+        stage_c(n1, first, last);
+        if (j > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // one wavefront: its LDS operations complete in order
+        const double *y = &x[(j - 1) & 1][0];
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int e = cur.e[k];
+            const bool above = e >= fa && e < la;
+            const double t = y[above ? e - fa : 0];
+            v[k] = above ? t : cur.gq[k]; // (no upstream cell k: gq = 0)
+        }
+        double ups = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ups += v[k];
+        const double ap = cur.ap;
+        double q;
+        if (FUSED) {
+            const double qo = cur.qold;
+            const bool fq = lf_fast_range(qo);
+            const double rt = lf_root5(fq ? qo : 1.0);
+            double pw = fq ? rt * rt * rt : 0.0;
+            if (!fq && qo != 0.0) pw = lf_pow_cold(qo, 0.6);
+            const double c = ups + (ap * pw + cur.lat * cur.dx);
+            const bool fc = lf_fast_range(c) && lf_fast_range(ap);
+            const bool solve = fc && !(c <= LF_NEWTON_TOL);
+            q = lf_solve_3_5(solve ? c : 1.0, solve ? ap : 1.0);
+            q = solve ? q : 0.0;
+            if (!fc) q = lf_solve_cell_cold(c, ap, A.beta * ap, A.beta, A.inv_beta, A.b_minus_1);
+        } else {
+            q = lf_solve_cell(ups + cur.lat, ap, A.beta * ap, A.beta, A.inv_beta, A.b_minus_1);
+        }
+        x[j & 1][tid] = q;
+        pend = cur.active;
+        pend_p = cur.p;
+        pend_q = q;
+    };
+    auto bound = [&](const int *t, int k) { return k < nl ? ld_table(t, k) : 0; };
+    cell s0, s1, s2, s3, s4;
+    int f[5], l[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        f[i] = bound(c0, i);
+        l[i] = bound(c1, i);
+    }
+    stage_a(f[0], l[0], s0);
+    stage_a(f[1], l[1], s1);
+    stage_a(f[2], l[2], s2);
+    stage_a(f[3], l[3], s3);
+    stage_b(s0);
+    stage_b(s1);
+    stage_c(s0, 0, 0);
+    int fa = 0, la = 0; // the cone's range in the unit above the current one
+    for (int j = 0; j < nl; j += 5) {
+        int fn[5], ln[5]; // bounds of the units j + 5 .. j + 9
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            fn[i] = bound(c0, j + 5 + i);
+            ln[i] = bound(c1, j + 5 + i);
+        }
+        level(j, s0, s1, s2, s4, f[0], l[0], fa, la, f[4], l[4]);
+        level(j + 1, s1, s2, s3, s0, f[1], l[1], f[0], l[0], fn[0], ln[0]);
+        level(j + 2, s2, s3, s4, s1, f[2], l[2], f[1], l[1], fn[1], ln[1]);
+        level(j + 3, s3, s4, s0, s2, f[3], l[3], f[2], l[2], fn[2], ln[2]);
+        level(j + 4, s4, s0, s1, s3, f[4], l[4], f[3], l[3], fn[3], ln[3]);
+        fa = f[4];
+        la = l[4];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            f[i] = fn[i];
+            l[i] = ln[i];
+        }
+    }
+    if (pend) A.qord[pend_p] = pend_q;
 }
 
 // a run of narrow levels [k0, k1): one workgroup, barrier between levels
