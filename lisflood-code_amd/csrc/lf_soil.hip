@@ -372,7 +372,10 @@ __device__ __forceinline__ long long soil_column(const lf_soil_args &A, const ve
 // floor(log2(nsub)) as before -- A/B switch).  With the inputs staged per column, the order inside the pool no longer
 // changes which lines a wavefront touches, so the finer the sort the closer the lanes of a wavefront finish together.
 constexpr int kClasses = 128;
-constexpr int kGroup = 16;  // tiles per pass-2 workgroup (a pool of 4096 columns: enough deferred columns to fill
+#ifndef LF_SOIL_GROUP
+#define LF_SOIL_GROUP 16
+#endif
+constexpr int kGroup = LF_SOIL_GROUP;  // tiles per pass-2 workgroup (a pool of 4096 columns: enough deferred columns to fill
                             // wavefronts with similar trip counts even when the sub-step distribution has a long tail)
 
 #ifndef LF_SOIL_P1_WAVES
