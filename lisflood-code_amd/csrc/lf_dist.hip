@@ -740,11 +740,15 @@ struct dsegment {
     bool wide;
 };
 
-__global__ void __launch_bounds__(kBlock) k_pack(int n, const int *__restrict__ positions, const double *__restrict__ q,
-                                                 double *__restrict__ buf)
+__global__ void __launch_bounds__(kBlock) k_pack2(int n0, int n1, const int *__restrict__ pos0, const int *__restrict__ pos1,
+                                                  const double *__restrict__ q, double *__restrict__ buf0,
+                                                  double *__restrict__ buf1)
 {
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i < n) buf[i] = q[positions[i]];
+    if (i < n0)
+        buf0[i] = q[pos0[i]];
+    else if (i < n0 + n1)
+        buf1[i - n0] = q[pos1[i - n0]];
 }
 __global__ void __launch_bounds__(kBlock) k_dgather(int n, const int *__restrict__ perm, const double *__restrict__ src,
                                                     double *__restrict__ dst)
@@ -891,13 +895,14 @@ int dist_compute_phase(lf_dist_router *r, double *q, const double *lat, int sect
 int dist_pack(lf_dist_router *r, const double *q, int round, hipStream_t s = nullptr)
 {
     if (!s) s = r->ctx->stream;
-    for (int side = 0; side < 2; ++side) {
-        const int64_t a = r->export_off[side][round], b = r->export_off[side][round + 1];
-        if (b > a) {
-            hipLaunchKernelGGL(k_pack, dim3(blocks_for(b - a)), dim3(kBlock), 0, s, (int)(b - a),
-                               r->export_pos[side].p + a, q, r->sendbuf[side].p + a);
-            r->last_launches++;
-        }
+    // both neighbours' send buffers in ONE launch (a launch boundary of the tail phases is worth more than the kernel)
+    const int64_t a0 = r->export_off[0][round], n0 = r->export_off[0][round + 1] - a0;
+    const int64_t a1 = r->export_off[1][round], n1 = r->export_off[1][round + 1] - a1;
+    if (n0 + n1 > 0) {
+        hipLaunchKernelGGL(k_pack2, dim3(blocks_for(n0 + n1)), dim3(kBlock), 0, s, (int)n0, (int)n1,
+                           r->export_pos[0].p + a0, r->export_pos[1].p + a1, q, r->sendbuf[0].p + a0,
+                           r->sendbuf[1].p + a1);
+        r->last_launches++;
     }
     LF_HIP(hipGetLastError());
     return LF_OK;
