@@ -41,6 +41,7 @@ def run_ranks(fake, world, script, extra_env, args=(), timeout=600):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(_PORT[0]), TORCHELASTIC_RUN_ID="fake%d_%d" % (os.getpid(), _PORT[0]),
                    HSA_ENABLE_IPC_MODE_LEGACY="0", FAKE_RCCL_TIMEOUT_S="60",
+                   HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", "0").split(",")[0],  # ONE device, whatever the box
                    LD_LIBRARY_PATH=fake + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""))
         env.update(extra_env)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, script)] + list(args), env=env,
