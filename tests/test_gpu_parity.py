@@ -1131,6 +1131,54 @@ def test_fused_cones_random_cases(amd):
     assert r.returncode == 0 and "different 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("family,seed", [("deep", 2), ("river", 7), ("shallow", 1)])
+def test_cone_shapes_of_the_block_plan_agree(amd, monkeypatch, family, seed):
+    """The switches of the level-block plan -- cells per level of a cone (one wavefront / a workgroup of four), levels per
+    block (default, 7, one launch per level), for router calls, accuflux and the fused model step -- change the schedule,
+    never a bit of the result.  (The defaults run everywhere else; this is where the other shapes run.)"""
+    from lisflood_amd import synthetic as syn
+    from lisflood_amd._lib import DeviceArray
+    from lisflood_amd.kinematic_wave_parallel import Graph, kinematicWave
+    from bench_support import RoutingStepDevice
+    H, W = 330, 290
+    N = H * W
+    codes = syn.make_ldd(family, H, W, seed)
+    p = syn.router_params(N, seed=3)
+    vals, dt = syn.model_step_values(N, p, seed=11)
+    x = np.random.default_rng(4).uniform(0, 2, N)
+
+    def run(env):
+        for k in ("LF_ROUTE_CONE_WIDTH", "LF_ROUTE_LEVELS", "LF_FUSED_CONE_WIDTH", "LF_FUSED_LEVELS", "LF_ROUTE_CONES"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        g = Graph(ldd_raster=codes)
+        kw = kinematicWave(None, None, p["alpha"], p["beta"], p["dx"], p["dt"], graph=g)
+        perm = g.layout()[0].astype(np.int64)
+        q = DeviceArray.from_host(np.ascontiguousarray(p["Q0"][perm]))
+        for s in range(3):
+            lat = DeviceArray.from_host(np.ascontiguousarray(syn.lateral_inflow(N, s)[perm]))
+            kw.route_ordered(q, lat)
+            lat.free()
+        out = {"Q": q.download(), "launches": kw.last_launches()["launches"], "accu": kw.accuflux(x)}
+        q.free()
+        kw2 = kinematicWave(None, None, p["alpha"], p["beta"], p["dx"], dt, alpha_floodplains=vals["ChannelAlpha2"], graph=g)
+        st = RoutingStepDevice(kw2, vals, True, p["beta"], 1 / dt, dt * 5)
+        st.run_fused(5)
+        out.update({k: st.download(k) for k in ("ChanQ", "ChanQKin", "Chan2QKin", "ChanM3Kin", "sumDisDay")})
+        st.free(); kw2.close(); kw.close()
+        return out
+
+    ref = run({})
+    for env in ({"LF_ROUTE_CONE_WIDTH": "256", "LF_FUSED_CONE_WIDTH": "64"}, {"LF_ROUTE_LEVELS": "7", "LF_FUSED_LEVELS": "5"},
+                {"LF_ROUTE_CONES": "0", "LF_FUSED_LEVELS": "1"}):
+        got = run(env)
+        for k, a in ref.items():
+            if k != "launches":
+                assert np.array_equal(a, got[k], equal_nan=True), (family, env, k)
+    monkeypatch.delenv("LF_ROUTE_CONES", raising=False)
+
+
 @pytest.mark.parametrize("family", ["shallow", "deep", "river"])
 def test_routers_on_one_graph_swept_together(amd, solver, family):
     """lf_router_route_device_multi: three routers on the same graph (different alpha, own vectors), one launch per level
