@@ -394,17 +394,19 @@ def model_step_values(N, p, seed=17, ids=None):
     dict `RoutingStepDevice` / `routing.var_from_values` take; `p` = router_params(N); `ids`: only these pixels."""
     rng = np.random.default_rng(seed)
     beta, dt = p["beta"], 3600.0
-    alpha, length = p["alpha"], p["dx"]
-    alpha2 = alpha * rng.uniform(1.2, 2.0, N)
-    qlimit = 2.0 * p["Q0"] * rng.uniform(0.3, 1.2, N)
+    # `ids`: every full-length vector is cut to the selection as soon as it is drawn (one or two of them alive at a time:
+    # a rank of the catchment partition at 10 000^2 would otherwise hold ~17 vectors of 0.8 GB)
+    cut = (lambda v: v) if ids is None else (lambda v: np.ascontiguousarray(v[ids]))
+    n = N if ids is None else int(np.asarray(ids).size)
+    alpha, length, q0 = cut(p["alpha"]), cut(p["dx"]), cut(p["Q0"])
+    alpha2 = alpha * cut(rng.uniform(1.2, 2.0, N))
+    qlimit = 2.0 * q0 * cut(rng.uniform(0.3, 1.2, N))
     vals = dict(ChanLength=length, InvChanLength=1 / length, ChannelAlpha=alpha, InvChannelAlpha=1 / alpha,
                 ChannelAlpha2=alpha2, InvChannelAlpha2=1 / alpha2, QLimit=qlimit, M3Limit=alpha * length * qlimit ** beta,
-                Chan2M3Start=alpha2 * length * qlimit ** beta, Chan2QStart=qlimit * 0.1, PixelArea=np.full(N, 2.5e7),
-                IsChannelKinematic=np.ones(N, bool), SideflowChanM3=lateral_inflow(N, 0) * length * dt)
+                Chan2M3Start=alpha2 * length * qlimit ** beta, Chan2QStart=qlimit * 0.1, PixelArea=np.full(n, 2.5e7),
+                IsChannelKinematic=np.ones(n, bool), SideflowChanM3=cut(lateral_inflow(N, 0)) * length * dt)
     vals["Chan2M3Kin"] = vals["Chan2M3Start"].copy()
-    vals["ChanM3Kin"] = alpha * length * p["Q0"] ** beta
-    vals["ChanQKin"] = p["Q0"].copy()
+    vals["ChanM3Kin"] = alpha * length * q0 ** beta
+    vals["ChanQKin"] = q0.copy()
     vals["Chan2QKin"] = (vals["Chan2M3Kin"] / length / alpha2) ** (1 / beta)
-    if ids is not None:
-        vals = {k: np.ascontiguousarray(v[ids]) for k, v in vals.items()}
     return vals, dt
