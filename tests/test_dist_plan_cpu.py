@@ -418,3 +418,12 @@ def test_block_plan_of_single_router_calls(oracle, family, seed, H, W, nranks):
                 full[s] = rk.pixel_values()
             assert np.array_equal(full, ref[step]), (family, lmax, step)
         assert multi > 0                                          # blocks of several units did occur
+
+
+def test_block_plan_switched_off(monkeypatch):
+    """LF_ROUTE_LEVELS=1: no block holds more than one launch unit -> no plan, the per-unit schedule is what runs"""
+    monkeypatch.setenv("LF_ROUTE_LEVELS", "1")
+    codes = syn.make_ldd("river", 60, 50, 7)
+    blocks, graphs = X.build_blocks(codes, np.ones((60, 50), bool), 3)
+    D.settle_phases_local(graphs)
+    assert all(g.route_plan() is None for g in graphs)

@@ -204,3 +204,25 @@ def test_streamed_map_stack_out_of_order_flush_and_missing_steps(tmp_path):
             for j in range(2):
                 hw.write_chunk("v", (i, j), a[4 * i:4 * i + 4, 4 * j:4 * j + 4])
     assert np.array_equal(H5.read(str(tmp_path / "e.h5")).dataset("v"), a)
+
+
+def test_two_streamed_datasets_in_one_file(tmp_path):
+    """chunks of several streamed datasets interleave behind the metadata; each keeps its own chunk index"""
+    rng = np.random.default_rng(5)
+    a = rng.uniform(0, 1, (5, 6, 7))
+    b = rng.integers(0, 100, (3, 4)).astype(np.int32)
+    ds = [H5.Dataset("t", np.arange(5.0), ("t",)),
+          H5.Dataset("a", None, chunks=(1, 6, 7), deflate=4, shuffle=True, fill=np.float64(-1), shape=a.shape, dtype="f8"),
+          H5.Dataset("b", None, chunks=(1, 4), shape=b.shape, dtype="i4"),
+          H5.Dataset("c", np.arange(4, dtype=np.float32))]
+    path = str(tmp_path / "two.h5")
+    with H5.Writer(path, ds) as w:
+        for i in range(5):
+            w.write_chunk("a", (i, 0, 0), a[i][None])
+            if i < 3:
+                w.write_chunk("b", (i, 0), b[i][None])
+    r = H5.read(path)
+    assert np.array_equal(r.dataset("a"), a) and np.array_equal(r.dataset("b"), b)
+    assert np.array_equal(r.dataset("c"), np.arange(4, dtype=np.float32)) and np.array_equal(r.dataset("t"), np.arange(5.0))
+    with pytest.raises(KeyError):
+        H5.Writer(str(tmp_path / "x.h5"), ds[:1]).write_chunk("a", (0, 0, 0), a[0][None])
