@@ -207,11 +207,14 @@ __global__ void __launch_bounds__(kNarrowBlock) k_levels_narrow_multi(int k0, in
 
 // One BLOCK of consecutive levels of a router call, cone by cone (the plan of lf_router.hip: build_level_blocks).  A
 // workgroup owns a chunk of the block's last level and the whole upstream cone above it -- level by level one contiguous
-// range of at most kBlock cells, the cones tile every level -- so the levels of a block need no synchronisation between
+// range of at most CW cells, the cones tile every level -- so the levels of a block need no synchronisation between
 // workgroups: the new discharges travel to the next level through LDS (two buffers by level parity; they are also
-// stored, the block after this one and later calls read them), the operands of the next level's cell are loaded before
-// the current level is solved.  NR routers of one graph (the overland routers of surface_routing.py:151-153) share the
-// cone and the barriers.  Arithmetic per cell = sweep_cell: bit-identical to the level sweep.
+// stored, the block after this one and later calls read them).  One level of a cone is a dependent chain about as long
+// as one trip to memory and nothing else runs on its SIMD, so the operands of a level are requested TWO levels ahead
+// (three rotating register sets), the request holds loaded values only and sits behind no branch, the stores of a level
+// leave one level later, and the rarely taken general-exponent paths live out of line.  NR
+// routers of one graph (the overland routers of surface_routing.py:151-153) share the cone.  Arithmetic per cell =
+// sweep_cell: bit-identical to the level sweep.
 struct cone_plan_args {
     const int *__restrict__ cone; // starts of this block's cones, nl per cone, then the closing row (ends of the levels)
     int nl;                       // levels of the block
