@@ -495,10 +495,15 @@ __global__ void __launch_bounds__(64) k_sweep_cones_dist(cone_plan_args C, sweep
             fn[i] = bound(c0, j + 5 + i);
             ln[i] = bound(c1, j + 5 + i);
         }
+        // (the exits leave the trip straight code: a stage of three units -- the tail phases -- does not pay for five)
         level(j, s0, s1, s2, s4, f[0], l[0], fa, la, f[4], l[4]);
+        if (j + 1 >= nl) break;
         level(j + 1, s1, s2, s3, s0, f[1], l[1], f[0], l[0], fn[0], ln[0]);
+        if (j + 2 >= nl) break;
         level(j + 2, s2, s3, s4, s1, f[2], l[2], f[1], l[1], fn[1], ln[1]);
+        if (j + 3 >= nl) break;
         level(j + 3, s3, s4, s0, s2, f[3], l[3], f[2], l[2], fn[2], ln[2]);
+        if (j + 4 >= nl) break;
         level(j + 4, s4, s0, s1, s3, f[4], l[4], f[3], l[3], fn[3], ln[3]);
         fa = f[4];
         la = l[4];
