@@ -191,6 +191,8 @@ class Writer:
     def write_chunk(self, name, index, block):
         """chunk `index` (chunk coordinates, e.g. (t, 0, 0)) of the streamed dataset `name`; `block`: the chunk's shape
         (smaller at the upper edges of the dataset: the rest is the fill value)"""
+        if self._f is None:
+            raise ValueError("the file is closed")
         d = self._streamed[name]
         index = tuple(int(i) for i in index)
         if len(index) != len(d.chunks) or any(i < 0 or i >= n for i, n in zip(index, d.chunk_counts)):
@@ -212,6 +214,8 @@ class Writer:
 
     def flush(self):
         """B-tree nodes and end-of-file address as of now: the file on disk is complete up to the chunks written so far"""
+        if self._f is None:
+            return
         for name, d in self._streamed.items():
             ent = [(tuple(i * c for i, c in zip(idx, d.chunks)), size, at)
                    for idx, (size, at) in sorted(self._entries[name].items())]
