@@ -27,10 +27,13 @@ def global_reference(oracle, codes, mask, alpha, dx, dt, beta, Q0, qs):
     return out
 
 
-def run_partitioned(codes, mask, nranks, alpha, dx, dt, beta, Q0, qs):
+def run_partitioned(codes, mask, nranks, alpha, dx, dt, beta, Q0, qs, cones=False):
+    """cones: every stage through the block plan of single router calls (RankState.compute_stage_cones), the cones of a
+    block in alternating order"""
     H, W = codes.shape
     blocks, graphs = X.build_blocks(codes, mask, nranks)
     nph = D.settle_phases_local(graphs)
+    plans = [g.route_plan() if cones else None for g in graphs]
     ids = np.full((H, W), -1, np.int64)
     ids[mask] = np.arange(int(mask.sum()))
     sel = [ids[r0:r1][mask[r0:r1]] for (r0, r1) in blocks]     # global pixel ids of each rank's local pixels
@@ -40,8 +43,12 @@ def run_partitioned(codes, mask, nranks, alpha, dx, dt, beta, Q0, qs):
         for rk, s in zip(ranks, sel):
             rk.begin_call(q[s])
         for j in range(nph):
-            for rk in ranks:
-                rk.compute_phase(j)
+            for rk, pl in zip(ranks, plans):
+                if pl is None:
+                    rk.compute_phase(j)
+                else:
+                    for part in (0, 1):
+                        rk.compute_stage_cones(2 * j + part, pl, reverse=bool((j + part + len(results)) % 2))
             if j + 1 < nph:
                 for k, rk in enumerate(ranks):
                     if k > 0:
@@ -83,10 +90,33 @@ def test_partition_real_ldd_with_mask(oracle):
     qs = [g["q"][s] for s in range(4)]
     ref = [g["Q"][s] for s in range(4)]      # reference-captured vectors (main channel)
     for nranks in (2, 5):
-        got, nph, _ = run_partitioned(codes, mask, nranks, g["alpha"], g["dx"], float(g["dt"]), float(g["beta"]),
-                                      g["Q0"], qs)
-        for a, b in zip(got, ref):
-            assert np.array_equal(a, b)
+        for cones in (False, True):          # (True: the block plan of single router calls on the real, masked LDD)
+            got, nph, graphs = run_partitioned(codes, mask, nranks, g["alpha"], g["dx"], float(g["dt"]), float(g["beta"]),
+                                               g["Q0"], qs, cones=cones)
+            for a, b in zip(got, ref):
+                assert np.array_equal(a, b)
+            assert not cones or any(gr.route_plan() is not None for gr in graphs)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_block_plan_on_random_masked_rasters(oracle, seed):
+    """random family / shape / rank count / land mask with holes and missing rows at the cuts: the block plan of single
+    router calls executed under the kernel's visibility rules equals the single domain bit for bit"""
+    rng = np.random.default_rng(100 + seed)
+    family = ["shallow", "deep", "saddle", "river"][seed % 4]
+    H, W = int(rng.integers(40, 110)), int(rng.integers(30, 90))
+    nranks = int(rng.integers(2, 7))
+    codes = syn.make_ldd(family, H, W, seed)
+    mask = rng.random((H, W)) < 0.9
+    r0 = int(rng.integers(3, H - 6))
+    mask[r0:r0 + 2, int(rng.integers(0, W // 2)):int(rng.integers(W // 2, W))] = False       # a gap that may sit on a cut
+    n = int(mask.sum())
+    p = syn.router_params(n, seed=seed)
+    qs = [syn.lateral_inflow(n, s) for s in range(2)]
+    ref = global_reference(oracle, codes, mask, p["alpha"], p["dx"], p["dt"], p["beta"], p["Q0"], qs)
+    got, nph, graphs = run_partitioned(codes, mask, nranks, p["alpha"], p["dx"], p["dt"], p["beta"], p["Q0"], qs, cones=True)
+    for a, b in zip(got, ref):
+        assert np.array_equal(a, b), (family, H, W, nranks)
 
 
 def test_plan_invariants():
