@@ -536,6 +536,10 @@ int lf_dist_graph_block_stats(const lf_dist_graph *g, int64_t out[4]);
  * sizes = {stages + 1, blocks + 1, rows, entries of the cone table, launch units + 1}; arrays may be NULL (sizes only) */
 int lf_dist_graph_get_route_plan(const lf_dist_graph *g, int64_t sizes[5], int32_t *stage_block, int32_t *level,
                                  int32_t *row, int32_t *off, int32_t *cone, int64_t *level_start);
+/* the same for the block plan of the fused sub-step path (one plan per phase): sizes = {phases + 1, blocks + 1, rows,
+ * entries of the cone table} */
+int lf_dist_graph_get_fused_plan(const lf_dist_graph *g, int64_t sizes[4], int32_t *phase_block, int32_t *level,
+                                 int32_t *row, int32_t *off, int32_t *cone);
 /* the pieces of a call, for transports other than RCCL and for tests */
 int lf_dist_router_compute_phase(lf_dist_router *r, double *q_ord_dev, const double *lat_ord_dev, int section,
                                  int phase);

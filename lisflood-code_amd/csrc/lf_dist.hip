@@ -620,6 +620,26 @@ int lf_dist_graph_get_route_plan(const lf_dist_graph *g, int64_t sizes[5], int32
     if (cone) std::memcpy(cone, f.cone.data(), sizeof(int32_t) * f.cone.size());
     return LF_OK;
 }
+// the block plan of the fused sub-step path (one plan per phase, cones of <= 256 cells per unit), same layout and calling
+// convention; sizes = {phases + 1, blocks + 1, rows, entries of the cone table}
+int lf_dist_graph_get_fused_plan(const lf_dist_graph *g, int64_t sizes[4], int32_t *phase_block, int32_t *level, int32_t *row,
+                                 int32_t *off, int32_t *cone)
+{
+    if (!g || !g->finalized || !sizes) return lf_set_error(LF_E_INVALID, "graph not finalized");
+    sizes[0] = sizes[1] = sizes[2] = sizes[3] = 0;
+    if (g->fplan_phase_block.empty()) return LF_OK;
+    const lf_block_plan &f = g->fplan;
+    sizes[0] = (int64_t)g->fplan_phase_block.size();
+    sizes[1] = (int64_t)f.level.size();
+    sizes[2] = (int64_t)f.row.size();
+    sizes[3] = (int64_t)f.cone.size();
+    if (phase_block) std::memcpy(phase_block, g->fplan_phase_block.data(), sizeof(int32_t) * g->fplan_phase_block.size());
+    if (level) std::memcpy(level, f.level.data(), sizeof(int32_t) * f.level.size());
+    if (row) std::memcpy(row, f.row.data(), sizeof(int32_t) * f.row.size());
+    if (off) std::memcpy(off, f.off.data(), sizeof(int32_t) * f.off.size());
+    if (cone) std::memcpy(cone, f.cone.data(), sizeof(int32_t) * f.cone.size());
+    return LF_OK;
+}
 // the fused path's tables by position: out_slot[N], ups_idx_f[n_edges] (either may be NULL)
 int lf_dist_graph_get_fused_tables(const lf_dist_graph *g, int32_t *out_slot, int32_t *ups_idx_f)
 {

@@ -141,6 +141,23 @@ class DistGraph:
         check(lib().lf_dist_graph_get_route_plan(self._h, sizes, ptr(sb), ptr(lv), ptr(row), ptr(off), ptr(cone), ptr(ls)))
         return dict(stage_block=sb, level=lv, row=row, off=off, cone=cone, level_start=ls)
 
+    def fused_plan(self):
+        """the block plan of the fused sub-step path, one plan per PHASE (lf_dist_graph_get_fused_plan), in the layout of
+        route_plan() with `stage_block` = first block of every phase; None when no block holds more than one unit"""
+        sizes = (C.c_int64 * 4)()
+        check(lib().lf_dist_graph_get_fused_plan(self._h, sizes, None, None, None, None, None))
+        if sizes[0] == 0:
+            return None
+        pb, lv, row = (np.empty(int(sizes[i]), np.int32) for i in range(3))
+        off = np.empty(int(sizes[1]) - 1, np.int32)
+        cone = np.empty(int(sizes[3]), np.int32)
+        check(lib().lf_dist_graph_get_fused_plan(self._h, sizes, ptr(pb), ptr(lv), ptr(row), ptr(off), ptr(cone)))
+        rp_sizes = (C.c_int64 * 5)()
+        check(lib().lf_dist_graph_get_route_plan(self._h, rp_sizes, None, None, None, None, None, None))
+        ls = np.empty(int(rp_sizes[4]), np.int64)
+        check(lib().lf_dist_graph_get_route_plan(self._h, rp_sizes, None, None, None, None, None, ptr(ls)))
+        return dict(stage_block=pb, level=lv, row=row, off=off, cone=cone, level_start=ls)
+
     def fused_tables(self):
         """(out_slot[N] by position, ups_idx_f[n_edges]): see lf_dist_graph_get_fused_tables"""
         out_slot = np.empty(self.num_pixels, np.int32)

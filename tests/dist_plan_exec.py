@@ -51,8 +51,10 @@ class RankState:
         b, e = self.g.part_range(j, part)
         oracle.sweep_positions(self.state, self.constant, self.ups_ptr, self.ups_idx, self.a, self.ba, self.beta, b, e)
 
-    def compute_stage_cones(self, st, plan, reverse=False):
-        """Stage `st` (= 2 * phase + part) as k_sweep_cones<DIST> runs it on the block plan `plan` (DistGraph.route_plan):
+    def compute_stage_cones(self, st, plan, reverse=False, max_cone=64):
+        """Stage `st` (= 2 * phase + part) as k_sweep_cones_dist runs it on the block plan `plan` (DistGraph.route_plan) --
+        or phase `st` on the fused path's plan (DistGraph.fused_plan, max_cone = 256: what k_fused_cones<DIST> may read
+        of a sub-step's router outputs) --:
         block after block; the cones of a block in any order; inside a cone unit by unit, where ONLY the unit just solved
         is visible as new (the kernel's LDS row) -- every other cell of the block still shows its old value until the
         whole block is done (what the kernel may read from the state vector must be final before the launch).  A plan
@@ -73,7 +75,7 @@ class RankState:
                 prev = None
                 for j in range(nl):
                     lo, hi = int(rows[c, j]), int(rows[c + 1, j])
-                    assert hi - lo <= 64
+                    assert hi - lo <= max_cone
                     old = self.state[lo:hi].copy()
                     self._sweep(lo, hi)
                     done.append((lo, hi, self.state[lo:hi].copy()))

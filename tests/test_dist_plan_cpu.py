@@ -457,3 +457,45 @@ def test_block_plan_switched_off(monkeypatch):
     blocks, graphs = X.build_blocks(codes, np.ones((60, 50), bool), 3)
     D.settle_phases_local(graphs)
     assert all(g.route_plan() is None for g in graphs)
+
+
+@pytest.mark.parametrize("family,seed,H,W,nranks", [("deep", 2, 90, 70, 3), ("river", 7, 130, 100, 4), ("saddle", 6, 80, 64, 4)])
+def test_block_plan_of_the_fused_path(oracle, family, seed, H, W, nranks):
+    """the fused sub-step path's plan (one per phase, cones of <= 256 cells) under the same visibility rules: what a cone
+    of k_fused_cones<DIST> reads of the router outputs of a sub-step is either its own unit above or final"""
+    codes = syn.make_ldd(family, H, W, seed)
+    mask = np.ones((H, W), bool)
+    N = H * W
+    p = syn.router_params(N, seed=5)
+    qs = [syn.lateral_inflow(N, s) for s in range(2)]
+    ref = global_reference(oracle, codes, mask, p["alpha"], p["dx"], p["dt"], p["beta"], p["Q0"], qs)
+    os.environ["LF_FUSED_LEVELS"] = "6"
+    try:
+        blocks, graphs = X.build_blocks(codes, mask, nranks)
+        nph = D.settle_phases_local(graphs)
+    finally:
+        os.environ.pop("LF_FUSED_LEVELS", None)
+    plans = [g.fused_plan() for g in graphs]
+    assert any(pl is not None and len(pl["stage_block"]) == nph + 1 for pl in plans)
+    sel = [np.arange(r0 * W, r1 * W) for (r0, r1) in blocks]
+    ranks = [X.RankState(g, p["alpha"][s], p["dx"][s], p["dt"], p["beta"], p["Q0"][s]) for g, s in zip(graphs, sel)]
+    for step, q in enumerate(qs):
+        for rk, s in zip(ranks, sel):
+            rk.begin_call(q[s])
+        for j in range(nph):
+            for rk, pl in zip(ranks, plans):
+                if pl is None:
+                    rk.compute_phase(j)
+                else:
+                    rk.compute_stage_cones(j, pl, reverse=bool((step + j) % 2), max_cone=256)
+            if j + 1 < nph:
+                sends = [[rk.send_values(j, side) for side in (0, 1)] for rk in ranks]
+                for k, rk in enumerate(ranks):
+                    if k > 0:
+                        rk.recv_values(j, 0, sends[k - 1][1])
+                    if k + 1 < nranks:
+                        rk.recv_values(j, 1, sends[k + 1][0])
+        full = np.empty(N)
+        for rk, s in zip(ranks, sel):
+            full[s] = rk.pixel_values()
+        assert np.array_equal(full, ref[step]), (family, step)
