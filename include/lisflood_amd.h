@@ -166,6 +166,10 @@ int lf_count_nonfinite(int device, const double *x_dev, int64_t n, int64_t *coun
 /* launch statistics of the last route call: [0] kernel launches, [1] wide-level launches,
  * [2] narrow-run launches, [3] levels */
 int lf_router_last_launches(const lf_router *r, int64_t stats[4]);
+/* shape of the block plan of single router calls: [0] blocks, [1] blocks of more than one level (swept cone by cone),
+ * and over those: [2] cones, [3] cone levels (one wavefront-level each: 64 lanes), [4] cells, [5] most cones in one launch.
+ * [4] / (64 * [3]) = lane use of the cone sweep. */
+int lf_router_route_plan_stats(const lf_router *r, int64_t out[6]);
 /* per-kernel hipEvent profiling: when enabled every sweep launch is bracketed by an event pair.
  * lf_router_profile_read returns accumulated {launches, milliseconds, cells} per kernel class
  * (0 = prep, 1 = wide level, 2 = narrow run) since the last reset. */

@@ -868,6 +868,7 @@ int dist_compute_phase(lf_dist_router *r, double *q, const double *lat, int sect
                     cone_plan_args C;
                     C.cone = r->rb_cone.p + r->rb_off[b];
                     C.nl = nl;
+                    C.n_cells = 0; // (unused by k_sweep_cones_dist)
                     const dim3 grid((unsigned)(r->rb_row[b + 1] - r->rb_row[b] - 1)), block(64);
                     if (r->fused)
                         hipLaunchKernelGGL((k_sweep_cones_dist<true>), grid, block, 0, s, C, A);

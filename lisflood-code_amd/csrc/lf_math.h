@@ -104,30 +104,46 @@ __device__ __forceinline__ double lf_pow_5_3(double x)
     return pow(x, 1.0 / 0.6);
 }
 
-// Root of Q + a*Q^(3/5) = c for c > 1e-12, a > 0 (both finite, in the fast range): returns Q >= 0.
-// Mirrors the reference's floor: a root at or below NEWTON_TOL = 1e-12 is reported as 0
-// (kinematic_wave_parallel_tools.py:77,81-82).
-__device__ __forceinline__ double lf_solve_3_5(double c, double a)
+// Newton steps of lf_solve_3_5 behind its seed: 1 in fp32 + 2 in fp64 (rounds 1-3: 4 + 3 from a seed up to 19 % off).
+// A relative error e becomes <= 2 e^2 per step (g''/(2 g') * r is in [1, 2]), so the seed's <= 0.2 % gives 8e-6 -> 1.3e-10
+// -> 3e-20: rounding.  tools/solve_steps_check.py replays the scheme in numpy against a long-double root.
+#ifndef LF_SOLVE_F32_STEPS
+#define LF_SOLVE_F32_STEPS 1
+#endif
+#ifndef LF_SOLVE_F64_STEPS
+#define LF_SOLVE_F64_STEPS 2
+#endif
+
+// Seed of the root of r^5 + a r^3 = c from cf = (float)c, af = (float)a, laf = log2(af).  ra = c^(1/5) and rb = (c/a)^(1/3)
+// are both upper bounds of the root r*; with r = sqrt(a) y the equation is y^5 + y^3 = c a^(-5/2), a ONE-parameter family,
+// so r* / min(ra, rb) is a function of d = log2(ra / rb) alone: 1 at both ends, 0.838 at its lowest.  It is fitted by
+// 1 - x (A + B x), x = 2^(-p |d|) with one rate p per sign of d, to 0.2 % (max over the whole family:
+// tools/solve_steps_check.py); the upper bound itself is up to 19 % off.
+__device__ __forceinline__ float lf_solve_3_5_seed(float cf, float laf)
 {
-    // upper bounds of the root r*: r*^5 <= c and a r*^3 <= c
-    const float cf = (float)c, af = (float)a;
     const float lc = __builtin_amdgcn_logf(cf);
-    const float ra = __builtin_amdgcn_exp2f(0.2f * lc);
-    const float rb = __builtin_amdgcn_exp2f(0.33333334f * (lc - __builtin_amdgcn_logf(af)));
-    float rf = fminf(ra, rb) * 1.000001f;
-    // fp32 Newton: from <= 15 % above the root to ~1e-7
+    const float la = 0.2f * lc, lb = 0.33333334f * (lc - laf);
+    const float d = la - lb;
+    const float x = __builtin_amdgcn_exp2f(fminf(-4.16617164f * d, 3.23546616f * d)); // 2^(-p |d|)
+    const float corr = fmaf(-x, fmaf(-0.05679083f, x, 0.21762144f), 1.0f);
+    return __builtin_amdgcn_exp2f(fminf(la, lb)) * corr;
+}
+
+// r >= LF_ROOT_FLOOR  <=>  fl(fl(fl(r r)^2) r) > 1e-12 (the product is monotone in r; the threshold is the smallest
+// double whose fifth power, rounded as computed below, exceeds 1e-12 -- tests/test_host_cpu.py checks both neighbours)
+#define LF_ROOT_FLOOR 0x1.04e74cc73ee88p-8
+
+// the Newton steps and the floor of lf_solve_3_5, from the seed on
+__device__ __forceinline__ double lf_solve_3_5_from(float rf, double c, double a, float cf, float af)
+{
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < LF_SOLVE_F32_STEPS; ++i) {
         const float r2 = rf * rf, r3 = r2 * rf;
         const float g = fmaf(r3, r2, fmaf(af, r3, -cf));
         const float gp = r2 * fmaf(5.0f, r2, 3.0f * af);
         rf = fmaf(-g, __builtin_amdgcn_rcpf(gp), rf);
     }
     double r = (double)rf;
-    // fp64 Newton: 1e-7 -> 2e-14 -> rounding (third step is insurance for the worst start)
-#ifndef LF_SOLVE_F64_STEPS
-#define LF_SOLVE_F64_STEPS 3
-#endif
 #pragma unroll
     for (int i = 0; i < LF_SOLVE_F64_STEPS; ++i) {
         const double r2 = r * r, r3 = r2 * r;
@@ -137,7 +153,23 @@ __device__ __forceinline__ double lf_solve_3_5(double c, double a)
     }
     const double r2 = r * r;
     const double q = (r2 * r2) * r;
-    return (q > 1e-12) ? q : 0.0;
+    return (r >= LF_ROOT_FLOOR) ? q : 0.0; // q > 1e-12, decided beside the products instead of behind them
+}
+
+// Root of Q + a*Q^(3/5) = c for c > 1e-12, a > 0 (both finite, in the fast range): returns Q >= 0.
+// Mirrors the reference's floor: a root at or below NEWTON_TOL = 1e-12 is reported as 0
+// (kinematic_wave_parallel_tools.py:77,81-82).
+__device__ __forceinline__ double lf_solve_3_5(double c, double a)
+{
+    const float cf = (float)c, af = (float)a;
+    return lf_solve_3_5_from(lf_solve_3_5_seed(cf, __builtin_amdgcn_logf(af)), c, a, cf, af);
+}
+
+// the same with the a-only part of the seed supplied (af = (float)a, laf = log2(af)): the same operations
+__device__ __forceinline__ double lf_solve_3_5_pre(double c, double a, float af, float laf)
+{
+    const float cf = (float)c;
+    return lf_solve_3_5_from(lf_solve_3_5_seed(cf, laf), c, a, cf, af);
 }
 
 

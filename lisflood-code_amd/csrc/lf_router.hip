@@ -337,11 +337,30 @@ void launch_sweep_cones_cw(bool fused, bool ordered, dim3 grid, hipStream_t s, c
     else
         hipLaunchKernelGGL((k_sweep_cones<false, false, NR, CW>), grid, dim3(CW), 0, s, C, M);
 }
+bool cone_split_enabled() // LF_ROUTE_SPLIT=0: one wavefront per cone does everything (the round-3 kernel; A/B switch)
+{
+    const char *e = std::getenv("LF_ROUTE_SPLIT");
+    return !(e && e[0] == '0');
+}
+template <int NR>
+constexpr int split_threads() // one chain wavefront + the supply wavefronts of k_sweep_cones_split's default arguments
+{
+    return 64 * (1 + cone_split_cfg<NR>::NS);
+}
 template <int NR>
 void launch_sweep_cones(int cw, bool fused, bool ordered, dim3 grid, hipStream_t s, const cone_plan_args &C,
                         const sweep_args_multi &M)
 {
-    if (cw == 64)
+    if (cw == 64 && cone_split_enabled() && C.n_cells < (1 << 29)) { // (byte offsets of the buffer stores: 32 bits)
+        if (fused && ordered)
+            hipLaunchKernelGGL((k_sweep_cones_split<true, true, NR>), grid, dim3(split_threads<NR>()), 0, s, C, M);
+        else if (fused)
+            hipLaunchKernelGGL((k_sweep_cones_split<true, false, NR>), grid, dim3(split_threads<NR>()), 0, s, C, M);
+        else if (ordered)
+            hipLaunchKernelGGL((k_sweep_cones_split<false, true, NR>), grid, dim3(split_threads<NR>()), 0, s, C, M);
+        else
+            hipLaunchKernelGGL((k_sweep_cones_split<false, false, NR>), grid, dim3(split_threads<NR>()), 0, s, C, M);
+    } else if (cw == 64)
         launch_sweep_cones_cw<NR, 64>(fused, ordered, grid, s, C, M);
     else
         launch_sweep_cones_cw<NR, kBlock>(fused, ordered, grid, s, C, M);
@@ -359,6 +378,7 @@ int enqueue_blocks(int count, lf_router **rs, const sweep_args_multi &M, bool or
             cone_plan_args C;
             C.cone = r->rb_cone.p + r->rb_off[b];
             C.nl = nl;
+            C.n_cells = (int)r->N;
             const dim3 grid((unsigned)(r->rb_row[b + 1] - r->rb_row[b] - 1));
             LF_TRY(r->prof_begin(2, r->h_level_start[k0 + nl] - r->h_level_start[k0]));
             if (count == 1)
@@ -850,6 +870,26 @@ int lf_router_last_launches(const lf_router *r, int64_t stats[4])
     return LF_OK;
 }
 
+// Shape of the block plan of single router calls (build_level_blocks): how full the cone wavefronts are.
+int lf_router_route_plan_stats(const lf_router *r, int64_t out[6])
+{
+    if (!r || !out) return lf_set_error(LF_E_INVALID, "null argument");
+    for (int i = 0; i < 6; ++i) out[i] = 0;
+    const int NB = r->rb_level.empty() ? 0 : (int)r->rb_level.size() - 1;
+    out[0] = NB;
+    for (int b = 0; b < NB; ++b) {
+        const int k0 = r->rb_level[b], nl = r->rb_level[b + 1] - k0;
+        if (nl < 2) continue;
+        const int64_t cones = r->rb_row[b + 1] - r->rb_row[b] - 1;
+        out[1] += 1;
+        out[2] += cones;
+        out[3] += cones * nl;
+        out[4] += r->h_level_start[k0 + nl] - r->h_level_start[k0];
+        out[5] = cones > out[5] ? cones : out[5];
+    }
+    return LF_OK;
+}
+
 // The fused-with-structures call validates the levels of the site lists once per set of device pointers; a caller
 // that rebuilds its site lists (possibly at the same addresses) drops that cache here.
 int lf_router_reset_site_cache(lf_router *r)
@@ -961,6 +1001,7 @@ int lf_accuflux_ordered_multi_device(lf_router *r, int nv, const double *const *
                 cone_plan_args C;
                 C.cone = r->rb_cone.p + r->rb_off[b];
                 C.nl = nl;
+                C.n_cells = (int)r->N;
                 const dim3 grid((unsigned)(r->rb_row[b + 1] - r->rb_row[b] - 1));
                 LF_ACCU_CONES(grid, C, r->ups_ptr.p, M);
             } else {

@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "lf_common.h"
 #include "lf_math.h"
 
@@ -218,6 +220,7 @@ __global__ void __launch_bounds__(kNarrowBlock) k_levels_narrow_multi(int k0, in
 struct cone_plan_args {
     const int *__restrict__ cone; // starts of this block's cones, nl per cone, then the closing row (ends of the levels)
     int nl;                       // levels of the block
+    int n_cells;                  // cells of the graph (k_sweep_cones_split: extent of the state vectors, < 2^29)
 };
 
 template <int CW>
@@ -364,6 +367,315 @@ __global__ void __launch_bounds__(CW) k_sweep_cones(cone_plan_args C, sweep_args
         l2 = l5;
     }
     flush();
+}
+
+// The cone sweep with the work split between TWO wavefronts of a 128-thread workgroup (round 4).  One level of a cone is
+// a dependent chain that a single wavefront issues in order; on chain-bound networks three quarters of the SIMDs idle while
+// that wavefront also works out everything that does NOT depend on the level above (operand addresses and loads, the
+// old-discharge term a*Qold^0.6 + q*dx, the stores).  Here
+//   * the SUPPLY wavefront (threads 64..127) runs a chunk of KC levels ahead: it requests every operand of the chunk at
+//     once, works out the constant term of every cell (kinematic_wave_parallel.py:163,175) and parks it in LDS together
+//     with a and the cell's upstream range as (first slot, count) in the level above; one chunk later it takes the chunk's
+//     new discharges out of LDS and stores them;
+//   * the CHAIN wavefront (threads 0..63) touches LDS and registers only: gather the level above -> sum in ascending
+//     pixel id (kinematic_wave_parallel_tools.py:57-58) -> closure solve -> LDS.
+// The two meet at one workgroup barrier per chunk; operand and result buffers alternate by chunk parity.  The upstream
+// discharges of the block's first level are final in memory (the block before): the supply wavefront adds them up and
+// hands the chain wavefront c = ups + constant with an empty range (0.0 + c == c for every c that is solved; c == -0.0
+// gives 0 either way).  Arithmetic per cell = sweep_cell: bit-identical to the level sweep.
+#ifndef LF_CONE_KC
+#define LF_CONE_KC 8
+#endif
+#ifndef LF_CONE_NS
+#define LF_CONE_NS 2
+#endif
+template <int NR>
+struct cone_split_cfg {
+    static constexpr int KC = NR == 1 ? LF_CONE_KC : 4;                   // levels per chunk
+    static constexpr int NS = KC % LF_CONE_NS == 0 ? LF_CONE_NS : 1;      // supply wavefronts
+};
+constexpr int kConeSlots = 65;           // a level's 64 discharges + one slot holding 0.0 ("no such upstream cell" reads it)
+constexpr int kConeRow = kConeSlots * 8; // bytes of a row
+
+// What the supply wavefronts park for a chunk of KC levels, per lane in 16-byte records (one ds_read_b128 each).
+struct cone_rec_ca {
+    double cst; // a*Qold^beta + q*dx (first level of the block: + the inflow from the block before)
+    double ap;  // a, 1.0 where a is outside the fast range (the cold path reads the true value from memory)
+};
+struct cone_rec_fl {
+    float af, laf; // (float)a and log2 of it: the part of lf_solve_3_5's seed that does not depend on c
+    int fast_a;    // a in the fast range
+    int pad;
+};
+struct cone_rec_ad {
+    int ad[4]; // byte offsets (in the result rows) of four reads of the level above: slot first + k, or the 0.0 in slot 64
+};
+template <int NR, int KC>
+struct cone_chunk_ops {
+    cone_rec_ca ca[KC][NR][64];
+    cone_rec_fl fl[KC][NR][64];
+    cone_rec_ad ad[KC][2][64]; // reads 0..3 and 4..7 of router 0 (router r: + r rows)
+};
+template <int NR, int KC>
+struct cone_lds {
+    double xr[2 * KC * NR][kConeSlots]; // row (chunk parity * KC + level of the chunk) * NR + router; first: small offsets
+    cone_chunk_ops<NR, KC> ops[2];
+};
+
+// The chain wavefront's loop over the chunks, for a graph of at most KM upstream cells per cell: LDS and registers only.
+template <bool FUSED, int NR, int KC, int KM>
+__device__ __forceinline__ void cone_chain(cone_lds<NR, KC> &S, int tid, int nl, const int *c0, const sweep_args_multi &M)
+{
+    const int nch = (nl + KC - 1) / KC;
+    const char *xb = (const char *)&S.xr[0][0];
+    struct operands {
+        cone_rec_ca ca[NR];
+        cone_rec_fl fl[NR];
+        cone_rec_ad a0, a1;
+    };
+    auto request = [&](const cone_chunk_ops<NR, KC> &O, int jj, operands &P) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            P.ca[r] = O.ca[jj][r][tid];
+            P.fl[r] = O.fl[jj][r][tid];
+        }
+        P.a0 = O.ad[jj][0][tid];
+        if (KM > 4) P.a1 = O.ad[jj][1][tid];
+    };
+    for (int ch = 0; ch < nch; ++ch) {
+        const int ob = ch & 1, L = nl - ch * KC < KC ? nl - ch * KC : KC;
+        const cone_chunk_ops<NR, KC> &O = S.ops[ob];
+        operands cur, nxt;
+        request(O, 0, cur); // the chunk's first level; inside the chunk the operands are requested one level ahead
+#ifdef LF_EXP_NOCHAIN
+        for (int jj = 0; jj < L; ++jj) S.xr[(ob * KC + jj) * NR][tid] = 1.0;
+        for (int jj = 0; jj < 0; ++jj) {
+#else
+        for (int jj = 0; jj < L; ++jj) {
+#endif
+            // the level above, all reads in flight together
+            double t[NR][KM];
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+#pragma unroll
+                for (int k = 0; k < KM; ++k) // (router r: r rows on; slot 64 of EVERY row holds 0.0)
+                    t[r][k] = *(const double *)(xb + (k < 4 ? cur.a0.ad[k & 3] : cur.a1.ad[k & 3]) + r * kConeRow);
+            request(O, jj + 1 < L ? jj + 1 : jj, nxt); // (the chunk's last level: its own again)
+            const int row = (ob * KC + jj) * NR;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                // ascending pixel id (kinematic_wave_parallel_tools.py:57-58); the reference starts from 0.0, and 0.0 + x
+                // is x bit for bit unless x is -0.0, which no discharge written to LDS is (0.0, a positive root, or NaN)
+                double ups = t[r][0];
+#pragma unroll
+                for (int k = 1; k < KM; ++k) ups += t[r][k];
+                const double c = ups + cur.ca[r].cst;
+                double q;
+                if (FUSED) {
+                    // c <= NEWTON_TOL: 0 on every path; else the quintic when c and a are in its range, else the general
+                    // path (c beyond 1e30, NaN, a outside the fast range: kinematic_wave_parallel_tools.py:59-82)
+                    const bool le = c <= LF_NEWTON_TOL;
+                    const bool quintic = c <= LF_FAST_MAX && cur.fl[r].fast_a != 0;
+#ifdef LF_EXP_NOSOLVE
+                    q = c * 0.5;
+#else
+                    q = lf_solve_3_5_pre(c, cur.ca[r].ap, cur.fl[r].af, cur.fl[r].laf); // (lanes not selected: garbage)
+#endif
+                    q = (le || !quintic) ? 0.0 : q;
+                    if (!le && !quintic) {
+                        const sweep_args &A = M.r[r];
+                        const double at = A.a[ld_table(c0, ch * KC + jj) + tid]; // (a lane beyond the cone's range: any cell)
+                        q = lf_solve_cell_cold(c, at, A.beta * at, A.beta, A.inv_beta, A.b_minus_1);
+                    }
+                } else {
+                    const sweep_args &A = M.r[r];
+                    q = lf_solve_cell(c, cur.ca[r].ap, A.beta * cur.ca[r].ap, A.beta, A.inv_beta, A.b_minus_1);
+                }
+                S.xr[row + r][tid] = q;
+            }
+            cur = nxt;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+}
+
+// NS supply wavefronts share a chunk level by level (wavefront s: levels s, s + NS, ... of every chunk); each keeps the
+// operands of its levels of the NEXT chunk in flight while it works out the current one (two register sets).
+template <bool FUSED, bool ORDERED, int NR, int KC = cone_split_cfg<NR>::KC, int NS = cone_split_cfg<NR>::NS>
+__global__ void __launch_bounds__(64 * (1 + NS)) k_sweep_cones_split(cone_plan_args C, sweep_args_multi M)
+{
+    __shared__ cone_lds<NR, KC> S;
+    static_assert(2 * KC * NR <= 64, "one lane per row");
+    static_assert(KC % NS == 0, "every supply wavefront takes KC / NS levels of a chunk");
+    constexpr int KS = KC / NS;
+    const int tid = threadIdx.x & 63, nl = C.nl;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // 0 = chain, 1.. = supply (uniform: scalar table reads)
+    const int nch = (nl + KC - 1) / KC;
+    const int *c0 = C.cone + (size_t)blockIdx.x * nl, *c1 = c0 + nl;
+    if (wave == 0) {
+        if (tid < 2 * KC * NR) S.xr[tid][64] = 0.0; // the zero slot of every row
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // chunk 0 is in LDS
+        switch (M.r[0].kmax) {
+        case 0:
+        case 1: cone_chain<FUSED, NR, KC, 1>(S, tid, nl, c0, M); break;
+        case 2: cone_chain<FUSED, NR, KC, 2>(S, tid, nl, c0, M); break;
+        case 3: cone_chain<FUSED, NR, KC, 3>(S, tid, nl, c0, M); break;
+        case 4: cone_chain<FUSED, NR, KC, 4>(S, tid, nl, c0, M); break;
+        case 5: cone_chain<FUSED, NR, KC, 5>(S, tid, nl, c0, M); break;
+        case 6: cone_chain<FUSED, NR, KC, 6>(S, tid, nl, c0, M); break;
+        case 7: cone_chain<FUSED, NR, KC, 7>(S, tid, nl, c0, M); break;
+        default: cone_chain<FUSED, NR, KC, 8>(S, tid, nl, c0, M); break;
+        }
+        return;
+    }
+    // ---- a supply wavefront ----
+    // Its loop over the chunks is straight code but for the out-of-line pow of an extreme old discharge: no branch around
+    // a load or a store (lanes beyond the cone's range load cell 0 and store beyond the end of a buffer resource, which the
+    // hardware drops; phases beyond the block work on empty levels), so the compiler's wait counts stay exact and the
+    // operands requested during one phase are not waited for before the next.
+    const int sw = wave - 1;
+    typedef int v2i __attribute__((ext_vector_type(2)));
+    __amdgpu_buffer_rsrc_t q_rsrc[NR], qpix_rsrc[NR];
+    const double *dxp[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        q_rsrc[r] = __builtin_amdgcn_make_buffer_rsrc(M.r[r].qord, 0, (int)((unsigned)C.n_cells * 8u), 0x00020000);
+        qpix_rsrc[r] = __builtin_amdgcn_make_buffer_rsrc(ORDERED ? M.r[r].qord : M.r[r].q_pix, 0, (int)((unsigned)C.n_cells * 8u), 0x00020000);
+        dxp[r] = M.r[r].dx ? M.r[r].dx : M.r[r].a; // (no per-pixel dx: any valid stream, the scalar is selected)
+    }
+    auto lbound = [&](const int *t, int k) { // entry k of a cone's row of the plan, 0 outside the block: an unconditional
+        const bool in = (unsigned)k < (unsigned)nl; // scalar load and a select, no branch in the load step
+        const int v = ld_table(t, in ? k : 0);
+        return in ? v : 0;
+    };
+    struct opset { // the operands of this wavefront's KS levels of a chunk, as loaded
+        int u0[KS], u1[KS], pix[KS];
+        double ap[KS][NR], lat[KS][NR], dx[KS][NR], qo[KS][NR];
+        bool act[KS];
+    };
+    auto issue = [&](int ph, opset &P) { // independent loads, all in flight together
+#pragma unroll
+        for (int i = 0; i < KS; ++i) {
+            const int j = ph * KC + sw + i * NS;
+            const int p = lbound(c0, j) + tid;
+            P.act[i] = p < lbound(c1, j);    // a level beyond the block: bounds 0, 0
+            const int pc = P.act[i] ? p : 0; // lanes beyond the cone's range load cell 0: no branch around the loads
+            P.u0[i] = M.r[0].ups_ptr[pc];
+            P.u1[i] = M.r[0].ups_ptr[pc + 1];
+            P.pix[i] = ORDERED ? pc : M.r[0].perm[pc];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const sweep_args &A = M.r[r];
+                P.ap[i][r] = A.a[pc];
+                if (FUSED) {
+                    P.lat[i][r] = A.lat[P.pix[i]];
+                    P.dx[i][r] = dxp[r][pc];
+                    P.qo[i][r] = ORDERED ? A.qord[pc] : A.q_pix[P.pix[i]];
+                } else {
+                    P.lat[i][r] = A.constant[pc];
+                    P.dx[i][r] = 1.0;
+                    P.qo[i][r] = 0.0;
+                }
+            }
+        }
+    };
+    auto store = [&](int ph) { // results of chunk ph - 2: out of LDS, into the state vector
+        const int ob = ph & 1;
+#pragma unroll
+        for (int i = 0; i < KS; ++i) {
+            const int jj = sw + i * NS, j = (ph - 2) * KC + jj;
+            const int p = lbound(c0, j) + tid;
+            const bool act = p < lbound(c1, j);
+            const unsigned off = act ? (unsigned)p * 8u : 0xffffffffu; // beyond the buffer: dropped
+            unsigned off_pix = off;
+            if (!ORDERED) {
+                const int pix = M.r[0].perm[act ? p : 0];
+                off_pix = act ? (unsigned)pix * 8u : 0xffffffffu;
+            }
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const double q = S.xr[(ob * KC + jj) * NR + r][tid];
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, q), q_rsrc[r], off, 0, 0);
+                if (!ORDERED) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, q), qpix_rsrc[r], off_pix, 0, 0);
+            }
+        }
+    };
+    auto finish = [&](int ph, const opset &P, auto first_chunk) { // constant terms of chunk ph
+        const int ob = ph & 1;
+        cone_chunk_ops<NR, KC> &O = S.ops[ob];
+#pragma unroll
+        for (int i = 0; i < KS; ++i) {
+            const int jj = sw + i * NS, j = ph * KC + jj;
+            const bool block_top = decltype(first_chunk)::value && i == 0 && sw == 0; // the block's first level
+            // the reads of the level above: its rows are those of level jj - 1 of this chunk or the last of the chunk before
+            const int above = jj > 0 ? (ob * KC + jj - 1) * NR : ((ob ^ 1) * KC + KC - 1) * NR;
+            int cnt = P.act[i] ? P.u1[i] - P.u0[i] : 0;
+            const int ab = above * kConeRow + (((P.u0[i] - lbound(c0, j - 1)) & 0xff) << 3);
+            cone_rec_ad a0, a1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                a0.ad[k] = (k < cnt && !block_top) ? ab + 8 * k : 64 * 8;
+                a1.ad[k] = (k + 4 < cnt && !block_top) ? ab + 8 * (k + 4) : 64 * 8;
+            }
+            O.ad[jj][0][tid] = a0;
+            O.ad[jj][1][tid] = a1;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const sweep_args &A = M.r[r];
+                double cst;
+                if (FUSED) {
+                    const double q = P.qo[i][r];
+                    const bool fq = lf_fast_range(q);
+                    const double rt = lf_root5(fq ? q : 1.0);
+                    double pw = fq ? rt * rt * rt : 0.0;           // lf_pow_3_5: +-0 -> +0
+                    if (!fq && q != 0.0) pw = lf_pow_cold(q, 0.6); // beyond the fast range, NaN
+                    cst = P.ap[i][r] * pw + P.lat[i][r] * (A.dx ? P.dx[i][r] : A.dx_scalar);
+                } else {
+                    cst = P.lat[i][r];
+                }
+                if (decltype(first_chunk)::value && i == 0) {
+                    if (block_top) { // its upstream cells are final in memory (the block before)
+                        double v[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] = (k < A.kmax && k < cnt) ? A.qord[P.u0[i] + k] : 0.0;
+                        double ups = 0.0;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) ups += v[k];
+                        cst = ups + cst;
+                    }
+                }
+                const bool fast_a = lf_fast_range(P.ap[i][r]);
+                cone_rec_ca ca;
+                ca.cst = cst;
+                ca.ap = (fast_a || !FUSED) ? P.ap[i][r] : 1.0;
+                cone_rec_fl fl;
+                fl.af = (float)ca.ap;
+                fl.laf = __builtin_amdgcn_logf(fl.af);
+                fl.fast_a = fast_a;
+                fl.pad = 0;
+                O.ca[jj][r][tid] = ca;
+                O.fl[jj][r][tid] = fl;
+            }
+        }
+    };
+    // phase ph: request chunk ph + 1, store chunk ph - 2, work out chunk ph; barriers behind the phases 0 .. nch
+    opset SA, SB;
+    issue(0, SA);
+    issue(1, SB);
+    finish(0, SA, std::true_type());
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int ph = 1; ph <= nch; ph += 2) {
+        issue(ph + 1, SA);
+        store(ph);
+        finish(ph, SB, std::false_type());
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (ph + 1 > nch) break;
+        issue(ph + 2, SB);
+        store(ph + 1);
+        finish(ph + 1, SA, std::false_type());
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    store(nch + 1);
 }
 
 // The same on the row-block partition (lf_dist.hip; one router, sweep-order vectors, one wavefront per cone).  A cell's

@@ -241,6 +241,13 @@ class kinematicWave:
         check(lib().lf_router_last_launches(self._h, s))
         return dict(launches=s[0], wide=s[1], narrow=s[2], levels=s[3])
 
+    def route_plan_stats(self):
+        """shape of the block plan of single router calls; lane_use = cells per 64-lane cone level"""
+        s = (C.c_int64 * 6)()
+        check(lib().lf_router_route_plan_stats(self._h, s))
+        return dict(blocks=s[0], cone_blocks=s[1], cones=s[2], cone_levels=s[3], cells=s[4], max_cones_per_launch=s[5],
+                    lane_use=(s[4] / (64.0 * s[3]) if s[3] else 0.0))
+
     def profile(self, on):
         check(lib().lf_router_profile_enable(self._h, C.c_int(1 if on else 0)))
 

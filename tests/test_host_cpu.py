@@ -295,3 +295,22 @@ def test_inert_pixels_and_subdomain_renumbering():
     ds = sub["downstruct"]
     assert ds.size == ids.size and ((ds == ids.size) | (ids[np.minimum(ds, ids.size - 1)] == st["downstruct"][ids])).all()
     assert sub["QInM3Old"].size == ids.size and sub["QInM3Old"].sum() == 5.0
+
+
+def test_root_floor_constant_is_the_exact_threshold_of_the_fifth_power():
+    """lf_math.h decides `root^5 > 1e-12` (kinematic_wave_parallel_tools.py:77,81-82) on the root itself:
+    LF_ROOT_FLOOR must be the smallest double whose fifth power -- rounded product by product as the kernel forms it --
+    exceeds 1e-12, so that the two tests agree for every double (the product is monotone in r)."""
+    import re
+    src = open(os.path.join(ROOT, "lisflood-code_amd", "csrc", "lf_math.h")).read()
+    floor = float.fromhex(re.search(r"#define LF_ROOT_FLOOR (\S+)", src).group(1))
+
+    def q(r):
+        r = np.float64(r)
+        r2 = np.float64(r * r)
+        return np.float64(np.float64(r2 * r2) * r)
+    assert q(floor) > 1e-12 and not q(np.nextafter(floor, 0.0)) > 1e-12
+    r = np.sort(np.concatenate([np.random.default_rng(1).uniform(0.5 * floor, 2 * floor, 200000),
+                                floor * (1 + np.arange(-2000, 2000) * 2.0 ** -52)]))
+    r2 = r * r
+    np.testing.assert_array_equal(r >= floor, (r2 * r2) * r > 1e-12)
