@@ -170,6 +170,9 @@ int lf_router_last_launches(const lf_router *r, int64_t stats[4]);
  * and over those: [2] cones, [3] cone levels (one wavefront-level each: 64 lanes), [4] cells, [5] most cones in one launch.
  * [4] / (64 * [3]) = lane use of the cone sweep. */
 int lf_router_route_plan_stats(const lf_router *r, int64_t out[6]);
+/* the same figures for the plan a router WOULD build on a graph with blocks of up to lmax levels of at most `wide` cells
+ * and cones of at most max_cone cells per level (host only: plan shapes can be studied without a device) */
+int lf_graph_block_plan_stats(const lf_graph *g, int lmax, int64_t wide, int max_cone, int64_t out[6]);
 /* per-kernel hipEvent profiling: when enabled every sweep launch is bracketed by an event pair.
  * lf_router_profile_read returns accumulated {launches, milliseconds, cells} per kernel class
  * (0 = prep, 1 = wide level, 2 = narrow run) since the last reset. */

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <new>
 
+#include "lf_blocks.h"
 #include "lf_common.h"
 
 namespace {
@@ -259,6 +260,36 @@ void lf_graph_destroy(lf_graph *g) { delete g; }
 int64_t lf_graph_num_pixels(const lf_graph *g) { return g ? g->N : -1; }
 int64_t lf_graph_num_levels(const lf_graph *g) { return g ? g->NL : -1; }
 int lf_graph_max_upstream(const lf_graph *g) { return g ? g->K : -1; }
+
+// Shape of the block plan a router would sweep this graph with (lf_blocks.h; host only, no device needed): blocks of up
+// to lmax consecutive levels of at most `wide` cells, cones of at most max_cone cells per level.
+int lf_graph_block_plan_stats(const lf_graph *g, int lmax, int64_t wide, int max_cone, int64_t out[6])
+{
+    if (!g || !out || lmax < 1 || max_cone < 1) return lf_set_error(LF_E_INVALID, "bad argument");
+    for (int i = 0; i < 6; ++i) out[i] = 0;
+    if (g->NL < 1) return LF_OK;
+    lf_block_plan plan;
+    try {
+        lf_build_level_blocks(g->level_start, 0, g->NL, lmax, wide, max_cone,
+                              [&](int64_t pos) { return (int64_t)g->ups_ptr[pos]; }, plan);
+    } catch (const std::bad_alloc &) {
+        return lf_set_error(LF_E_INVALID, "out of host memory while building the level blocks");
+    }
+    plan.level.push_back((int)g->NL);
+    const int NB = (int)plan.level.size() - 1;
+    out[0] = NB;
+    for (int b = 0; b < NB; ++b) {
+        const int k0 = plan.level[b], nl = plan.level[b + 1] - k0;
+        if (nl < 2) continue;
+        const int64_t cones = plan.row[b + 1] - plan.row[b] - 1;
+        out[1] += 1;
+        out[2] += cones;
+        out[3] += cones * nl;
+        out[4] += g->level_start[k0 + nl] - g->level_start[k0];
+        out[5] = cones > out[5] ? cones : out[5];
+    }
+    return LF_OK;
+}
 
 int lf_graph_get_lookups(const lf_graph *g, double *downstream, int64_t *upstream, int64_t *num_upstream)
 {

@@ -342,10 +342,33 @@ bool cone_split_enabled() // LF_ROUTE_SPLIT=0: one wavefront per cone does every
     const char *e = std::getenv("LF_ROUTE_SPLIT");
     return !(e && e[0] == '0');
 }
-template <int NR>
-constexpr int split_threads() // one chain wavefront + the supply wavefronts of k_sweep_cones_split's default arguments
+// k_sweep_cones_split comes in two shapes for a single router.  FEW cones per launch (at most about one per CU: the
+// chain-bound networks) -> chunks of 8 levels and four supply wavefronts, 72 KB of LDS per cone; MANY cones (several per
+// CU: their wavefronts share the SIMDs, the launch is throughput-bound) -> chunks of 4 levels and two supply wavefronts,
+// 37 KB.  Several routers on one graph: chunks of 4 levels, two supply wavefronts.  LF_ROUTE_SPLIT_SHAPE=few|many forces
+// one shape (A/B switch); LF_ROUTE_SPLIT_FEW is the threshold in cones per launch.
+template <bool FUSED, bool ORDERED, int NR, int KC, int NS>
+void launch_split(dim3 grid, hipStream_t s, const cone_plan_args &C, const sweep_args_multi &M)
 {
-    return 64 * (1 + cone_split_cfg<NR>::NS);
+    hipLaunchKernelGGL((k_sweep_cones_split<FUSED, ORDERED, NR, KC, NS>), grid, dim3(64 * (1 + NS)), 0, s, C, M);
+}
+template <bool FUSED, bool ORDERED, int NR>
+void launch_split_shape(dim3 grid, hipStream_t s, const cone_plan_args &C, const sweep_args_multi &M)
+{
+    if (NR > 1) {
+        launch_split<FUSED, ORDERED, NR, 4, 2>(grid, s, C, M);
+        return;
+    }
+    static const int few_limit = [] {
+        const char *e = std::getenv("LF_ROUTE_SPLIT_FEW");
+        return e ? std::atoi(e) : 384;
+    }();
+    const char *shape = std::getenv("LF_ROUTE_SPLIT_SHAPE"); // (read at every call: A/B legs switch it)
+    const bool few = shape ? shape[0] == 'f' : (int)grid.x <= few_limit;
+    if (few)
+        launch_split<FUSED, ORDERED, 1, LF_CONE_KC, LF_CONE_NS>(grid, s, C, M);
+    else
+        launch_split<FUSED, ORDERED, 1, 4, 2>(grid, s, C, M);
 }
 template <int NR>
 void launch_sweep_cones(int cw, bool fused, bool ordered, dim3 grid, hipStream_t s, const cone_plan_args &C,
@@ -353,13 +376,13 @@ void launch_sweep_cones(int cw, bool fused, bool ordered, dim3 grid, hipStream_t
 {
     if (cw == 64 && cone_split_enabled() && C.n_cells < (1 << 29)) { // (byte offsets of the buffer stores: 32 bits)
         if (fused && ordered)
-            hipLaunchKernelGGL((k_sweep_cones_split<true, true, NR>), grid, dim3(split_threads<NR>()), 0, s, C, M);
+            launch_split_shape<true, true, NR>(grid, s, C, M);
         else if (fused)
-            hipLaunchKernelGGL((k_sweep_cones_split<true, false, NR>), grid, dim3(split_threads<NR>()), 0, s, C, M);
+            launch_split_shape<true, false, NR>(grid, s, C, M);
         else if (ordered)
-            hipLaunchKernelGGL((k_sweep_cones_split<false, true, NR>), grid, dim3(split_threads<NR>()), 0, s, C, M);
+            launch_split_shape<false, true, NR>(grid, s, C, M);
         else
-            hipLaunchKernelGGL((k_sweep_cones_split<false, false, NR>), grid, dim3(split_threads<NR>()), 0, s, C, M);
+            launch_split_shape<false, false, NR>(grid, s, C, M);
     } else if (cw == 64)
         launch_sweep_cones_cw<NR, 64>(fused, ordered, grid, s, C, M);
     else

@@ -384,16 +384,11 @@ __global__ void __launch_bounds__(CW) k_sweep_cones(cone_plan_args C, sweep_args
 // hands the chain wavefront c = ups + constant with an empty range (0.0 + c == c for every c that is solved; c == -0.0
 // gives 0 either way).  Arithmetic per cell = sweep_cell: bit-identical to the level sweep.
 #ifndef LF_CONE_KC
-#define LF_CONE_KC 8
+#define LF_CONE_KC 8 /* levels per chunk and supply wavefronts of the few-cones shape (lf_router.hip: launch_split_shape) */
 #endif
 #ifndef LF_CONE_NS
-#define LF_CONE_NS 2
+#define LF_CONE_NS 4
 #endif
-template <int NR>
-struct cone_split_cfg {
-    static constexpr int KC = NR == 1 ? LF_CONE_KC : 4;                   // levels per chunk
-    static constexpr int NS = KC % LF_CONE_NS == 0 ? LF_CONE_NS : 1;      // supply wavefronts
-};
 constexpr int kConeSlots = 65;           // a level's 64 discharges + one slot holding 0.0 ("no such upstream cell" reads it)
 constexpr int kConeRow = kConeSlots * 8; // bytes of a row
 
@@ -445,14 +440,8 @@ __device__ __forceinline__ void cone_chain(cone_lds<NR, KC> &S, int tid, int nl,
     for (int ch = 0; ch < nch; ++ch) {
         const int ob = ch & 1, L = nl - ch * KC < KC ? nl - ch * KC : KC;
         const cone_chunk_ops<NR, KC> &O = S.ops[ob];
-        operands cur, nxt;
-        request(O, 0, cur); // the chunk's first level; inside the chunk the operands are requested one level ahead
-#ifdef LF_EXP_NOCHAIN
-        for (int jj = 0; jj < L; ++jj) S.xr[(ob * KC + jj) * NR][tid] = 1.0;
-        for (int jj = 0; jj < 0; ++jj) {
-#else
-        for (int jj = 0; jj < L; ++jj) {
-#endif
+        // one level: `cur` holds its operands, those of the next level are requested into `nxt` behind the gather
+        auto level = [&](int jj, const operands &cur, operands &nxt) {
             // the level above, all reads in flight together
             double t[NR][KM];
 #pragma unroll
@@ -477,7 +466,7 @@ __device__ __forceinline__ void cone_chain(cone_lds<NR, KC> &S, int tid, int nl,
                     const bool le = c <= LF_NEWTON_TOL;
                     const bool quintic = c <= LF_FAST_MAX && cur.fl[r].fast_a != 0;
 #ifdef LF_EXP_NOSOLVE
-                    q = c * 0.5;
+                    q = c * 1e-3 + 0.5 * cur.ca[r].cst;
 #else
                     q = lf_solve_3_5_pre(c, cur.ca[r].ap, cur.fl[r].af, cur.fl[r].laf); // (lanes not selected: garbage)
 #endif
@@ -493,7 +482,18 @@ __device__ __forceinline__ void cone_chain(cone_lds<NR, KC> &S, int tid, int nl,
                 }
                 S.xr[row + r][tid] = q;
             }
-            cur = nxt;
+        };
+        operands pa, pb; // two sets, swapping roles level by level (no copies)
+        request(O, 0, pa); // the chunk's first level; inside the chunk the operands are requested one level ahead
+#ifdef LF_EXP_NOCHAIN
+        for (int jj = 0; jj < L; ++jj) S.xr[(ob * KC + jj) * NR][tid] = 1.0;
+        for (int jj = 0; jj < 0; jj += 2) {
+#else
+        for (int jj = 0; jj < L; jj += 2) {
+#endif
+            level(jj, pa, pb);
+            if (jj + 1 >= L) break;
+            level(jj + 1, pb, pa);
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
@@ -501,7 +501,7 @@ __device__ __forceinline__ void cone_chain(cone_lds<NR, KC> &S, int tid, int nl,
 
 // NS supply wavefronts share a chunk level by level (wavefront s: levels s, s + NS, ... of every chunk); each keeps the
 // operands of its levels of the NEXT chunk in flight while it works out the current one (two register sets).
-template <bool FUSED, bool ORDERED, int NR, int KC = cone_split_cfg<NR>::KC, int NS = cone_split_cfg<NR>::NS>
+template <bool FUSED, bool ORDERED, int NR, int KC, int NS>
 __global__ void __launch_bounds__(64 * (1 + NS)) k_sweep_cones_split(cone_plan_args C, sweep_args_multi M)
 {
     __shared__ cone_lds<NR, KC> S;
