@@ -248,6 +248,7 @@ int lf_catchments_device(lf_router *r, const int32_t *points_pix_dev, int32_t *l
 int lf_catchments(lf_router *r, const int64_t *points_host, int64_t *labels_host);
 /* np.take(np.bincount(Catchments, weights=w), Catchments) for Catchments = catchment(ldd, pit(ldd)): every cell gets
  * the total of w over its whole tree (routing.py:483-499, 645-691; equal to rounding, the summation order differs) */
+/* (synchronous: the totals are complete when it returns; the asynchronous form is the multi-vector one below) */
 int lf_catchment_totals_device(lf_router *r, const double *w_pix_dev, double *out_pix_dev);
 int lf_catchment_totals_host(lf_router *r, const double *w_host, double *out_host);
 /* nv (<= 4) weight vectors in ONE sweep (the mass-balance terms of routing.py:645-691 come several at a time): the

@@ -1174,6 +1174,16 @@ static int dist_exchange(lf_dist_router *r, lf_comm *comm, double *q_ord_dev, in
     return LF_OK;
 }
 
+// The halo stream and the two events the overlapped route call orders it with, each created once whichever entry point
+// comes first (a pipelined route_many before the first plain route used to leave the events null)
+static int ensure_comm_stream(lf_dist_router *r)
+{
+    if (!r->comm_stream) LF_HIP(hipStreamCreateWithFlags(&r->comm_stream, hipStreamNonBlocking));
+    if (!r->ev_part0) LF_HIP(hipEventCreateWithFlags(&r->ev_part0, hipEventDisableTiming));
+    if (!r->ev_halo) LF_HIP(hipEventCreateWithFlags(&r->ev_halo, hipEventDisableTiming));
+    return LF_OK;
+}
+
 int lf_dist_router_exchange(lf_dist_router *r, lf_comm *comm, double *q_ord_dev, int round, int rank_top, int rank_bottom)
 {
     if (!r) return lf_set_error(LF_E_INVALID, "null argument");
@@ -1193,11 +1203,7 @@ int lf_dist_router_route(lf_dist_router *r, lf_comm *comm, double *q_ord_dev, co
     // phases read: no buffer is touched by both streams at once.
     const char *e = std::getenv("LF_DIST_OVERLAP");
     const bool overlap = comm && !(e && e[0] == '0');
-    if (overlap && !r->comm_stream) {
-        LF_HIP(hipStreamCreateWithFlags(&r->comm_stream, hipStreamNonBlocking));
-        LF_HIP(hipEventCreateWithFlags(&r->ev_part0, hipEventDisableTiming));
-        LF_HIP(hipEventCreateWithFlags(&r->ev_halo, hipEventDisableTiming));
-    }
+    if (overlap) LF_TRY(ensure_comm_stream(r));
     hipStream_t s = r->ctx->stream;
     for (int j = 0; j < r->nphases; ++j) {
         bool any = false;
@@ -1260,7 +1266,7 @@ int lf_dist_router_route_many(lf_dist_router *r, lf_comm *comm, double *q_ord_de
     }
     LF_HIP(hipSetDevice(r->device));
     const int P = r->nphases;
-    if (!r->comm_stream) LF_HIP(hipStreamCreateWithFlags(&r->comm_stream, hipStreamNonBlocking));
+    LF_TRY(ensure_comm_stream(r));
     if (r->pp_crit.empty()) {
         r->pp_crit.assign(2 * (size_t)P, nullptr);
         r->pp_halo.assign(2 * (size_t)P, nullptr);

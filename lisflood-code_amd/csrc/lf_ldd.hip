@@ -27,6 +27,7 @@ struct lf_router_view {
 int lf_router_view_of(lf_router *r, lf_router_view *v);
 int lf_router_alloc_parent(lf_router *r);    // allocates *parent_slot (N int32)
 int lf_router_alloc_root(lf_router *r);      // allocates *root_slot (N int32)
+int lf_router_drop_root(lf_router *r);       // frees it again (its contents did not arrive)
 int lf_router_totals_scratch(lf_router *r, size_t count, double **p);
 int lf_accuflux_ordered_device(lf_router *r, const double *x_ord_dev, double *acc_ord_dev);
 int lf_accuflux_ordered_multi_device(lf_router *r, int nv, const double *const *x_ord_dev, double *const *acc_ord_dev);
@@ -334,8 +335,12 @@ int lf_catchment_totals_multi_device(lf_router *r, int nv, const double *const *
         LF_TRY(converge_jumps(V, nullptr, a, b, &jump));
         LF_TRY(lf_router_alloc_root(r));
         LF_TRY(lf_router_view_of(r, &V));
-        LF_HIP(hipMemcpyAsync(*V.root_slot, jump, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, s));
-        LF_HIP(hipStreamSynchronize(s)); // a, b go out of scope
+        hipError_t e = hipMemcpyAsync(*V.root_slot, jump, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s); // a, b go out of scope
+        if (e != hipSuccess) { // the table is published only complete: later calls trust a non-null slot
+            (void)lf_router_drop_root(r);
+            return lf_set_error(LF_E_HIP, "outlet table of the catchment totals: %s", hipGetErrorString(e));
+        }
     }
     double *scratch = nullptr;
     LF_TRY(lf_router_totals_scratch(r, (size_t)(2 * nv) * (size_t)n, &scratch));
@@ -361,7 +366,13 @@ int lf_catchment_totals_device(lf_router *r, const double *w_pix_dev, double *ou
 {
     const double *w[1] = {w_pix_dev};
     double *o[1] = {out_pix_dev};
-    return lf_catchment_totals_multi_device(r, 1, w, o);
+    LF_TRY(lf_catchment_totals_multi_device(r, 1, w, o));
+    // synchronous, as it has been since round 1: C callers read out_pix_dev from the host or from another stream right
+    // after the call (the asynchronous form is lf_catchment_totals_multi_device with nv = 1)
+    lf_router_view V;
+    LF_TRY(lf_router_view_of(r, &V));
+    LF_HIP(hipStreamSynchronize(V.ctx->stream));
+    return LF_OK;
 }
 
 // nv vectors of N doubles back to back, host memory

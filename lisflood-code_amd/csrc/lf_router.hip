@@ -1117,6 +1117,14 @@ int lf_router_alloc_root(lf_router *r)
     return r->root.p ? LF_OK : r->root.alloc((size_t)r->N);
 }
 
+// (a root table whose contents never arrived must not be trusted by later calls)
+int lf_router_drop_root(lf_router *r)
+{
+    if (!r) return lf_set_error(LF_E_INVALID, "null argument");
+    r->root.release();
+    return LF_OK;
+}
+
 // grow-only scratch of the catchment totals (count doubles)
 int lf_router_totals_scratch(lf_router *r, size_t count, double **p)
 {

@@ -165,17 +165,21 @@ class BufferCache:
 
     @staticmethod
     def _fingerprint(host):
-        """cheap identity of a host array's CONTENT: where it lives, its shape, and a strided sample of <= 4096 elements
-        (a parameter map that was recomputed, reloaded or rescaled changes it; a single edited element may not -- call
-        invalidate_static() after such an edit)"""
-        flat = host.reshape(-1)
-        step = max(1, flat.size // 4096)
-        sample = flat[::step]
-        return (host.__array_interface__["data"][0], host.shape, host.dtype.str, sample.tobytes())
+        """identity of a host array's CONTENT: shape, dtype and two checksums over EVERY byte (wrap-around sum and xor of
+        the buffer read as 64-bit words, plus the odd bytes) -- one pass at memory speed, cheaper than the staging copy and
+        the PCIe transfer it saves.  An in-place edit of any element changes it (a strided sample, as rounds 2-3 used,
+        did not see edits between its sample points)."""
+        b = host.reshape(-1).view(np.uint8)
+        n8 = b.size // 8 * 8
+        w = b[:n8].view(np.uint64)
+        return (host.shape, host.dtype.str, int(w.sum(dtype=np.uint64)) if w.size else 0,
+                int(np.bitwise_xor.reduce(w)) if w.size else 0, b[n8:].tobytes())
 
     def put_static(self, name, host):
-        """`put` for parameters that do not change between calls (soil and crop parameter maps): the upload is skipped
-        while the array's fingerprint is the one of the last upload.  static_uploads = False switches the check off."""
+        """`put` for parameters that do not change between calls (soil and crop parameter maps, calibration constants):
+        the upload is skipped while the array's content checksum is the one of the last upload.  Maps the reference
+        itself rewrites during a run (the land-use fractions: landusechange.py:107-139, evapowater.py:108-119) do not
+        come through here at all.  static_uploads = False switches the check off."""
         host = np.ascontiguousarray(host)
         if host.dtype == np.bool_:
             host = host.view(np.uint8)

@@ -320,13 +320,14 @@ class SocketTransport:
     the data path is RCCL.
 
     Rendezvous on one node: rank 0 binds an ephemeral port on 127.0.0.1 and publishes `port token` (a fresh random
-    token per run) in a 0600 file inside a 0700 per-user directory, named after MASTER_ADDR / MASTER_PORT (+ torchrun's
-    TORCHELASTIC_RUN_ID when present) -- so it works under `python -m torch.distributed.run`, whose agent owns
+    token per run, and its own pid) in a 0600 file inside a 0700 per-user directory, named after MASTER_ADDR / MASTER_PORT,
+    the world size (+ torchrun's TORCHELASTIC_RUN_ID and LF_JOB_ID when present) -- so it works under `python -m torch.distributed.run`, whose agent owns
     MASTER_PORT itself, as well as under any launcher that sets RANK / WORLD_SIZE.  A peer must present the token before
     anything else it sends is looked at; a connection that does not is dropped.  Messages are a fixed typed encoding of
     None / bool / int / float / bytes / str / numeric numpy arrays / lists / tuples (`_encode`): nothing received is
-    ever unpickled or evaluated.  A stale file of a crashed run is removed by rank 0 before it binds; the other ranks
-    re-read the file and reconnect until the timeout, so reading a dead port first is harmless."""
+    ever unpickled or evaluated.  A stale file of a crashed run (its rank 0's pid is gone) is removed by rank 0 before it
+    binds, a file whose rank 0 is alive is a concurrent job's and is refused; the other ranks re-read the file and
+    reconnect until the timeout, so reading a dead port first is harmless.  The handshake carries the world size."""
 
     _MAGIC = b"LFAMD1"
     _MAX_MESSAGE = 1 << 31
@@ -343,8 +344,24 @@ class SocketTransport:
             return
         deadline = time.time() + timeout
         if rank == 0:
+            try:                                    # a file left behind by a crashed run (its rank 0 is gone) is removed;
+                with open(rendezvous_file) as f:    # one whose rank 0 is alive belongs to a concurrent job with the same
+                    owner = int(f.read().split()[2])  # MASTER_ADDR / MASTER_PORT / world size: refuse, do not clobber it
+                alive = owner != os.getpid()
+                if alive:
+                    try:
+                        os.kill(owner, 0)
+                    except ProcessLookupError:
+                        alive = False
+                    except OSError:
+                        pass
+                if alive:
+                    raise RuntimeError("rendezvous file %s belongs to a running job (pid %d): give this job its own "
+                                       "MASTER_PORT or LF_JOB_ID" % (rendezvous_file, owner))
+            except (OSError, ValueError, IndexError):
+                pass
             try:
-                os.unlink(rendezvous_file)          # left behind by a crashed run: its port is dead
+                os.unlink(rendezvous_file)
             except OSError:
                 pass
             srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
@@ -354,7 +371,7 @@ class SocketTransport:
             tmp = rendezvous_file + ".tmp%d" % os.getpid()
             fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
             with os.fdopen(fd, "w") as f:
-                f.write("%d %s" % (srv.getsockname()[1], token))
+                f.write("%d %s %d" % (srv.getsockname()[1], token, os.getpid()))
             os.replace(tmp, rendezvous_file)
             try:
                 while len(self.peers) < nranks - 1:
@@ -363,19 +380,20 @@ class SocketTransport:
                         c, _addr = srv.accept()
                     except socket.timeout:
                         raise TimeoutError("only %d of %d ranks connected" % (len(self.peers) + 1, nranks))
-                    try:                               # handshake: magic, token, rank -- fixed 6 + 32 + 4 bytes
-                        c.settimeout(10.0)
-                        hello = self._exact(c, len(self._MAGIC) + 32 + 4)
-                        r, = struct.unpack("<i", hello[-4:])
+                    try:                               # handshake: magic, token, rank, world size -- 6 + 32 + 4 + 4 bytes,
+                        c.settimeout(1.0)              # sent at once by a real peer (an idle connection must not stall
+                        hello = self._exact(c, len(self._MAGIC) + 32 + 8)     # the others for long)
+                        r, w = struct.unpack("<ii", hello[-8:])
                         ok = (hello[:len(self._MAGIC)] == self._MAGIC and
-                              hmac.compare_digest(hello[len(self._MAGIC):-4], token.encode("ascii")) and
-                              0 < r < nranks and r not in self.peers)
-                    except (OSError, ConnectionError):
+                              hmac.compare_digest(hello[len(self._MAGIC):-8], token.encode("ascii")) and
+                              w == nranks and 0 < r < nranks and r not in self.peers)
+                        if ok:
+                            c.sendall(b"OK")
+                    except (OSError, ConnectionError):  # (a peer that dies mid-handshake is dropped, the loop goes on)
                         ok = False
                     if not ok:
                         c.close()                      # not one of ours
                         continue
-                    c.sendall(b"OK")
                     c.settimeout(timeout)
                     c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                     self.peers[r] = c
@@ -392,11 +410,11 @@ class SocketTransport:
                     raise TimeoutError("no rendezvous with rank 0 through %s" % rendezvous_file)
                 try:
                     with open(rendezvous_file) as f:
-                        port_s, token = f.read().split()
+                        port_s, token = f.read().split()[:2]
                     s = socket.create_connection(("127.0.0.1", int(port_s)), timeout=5.0)
                     try:
                         s.settimeout(10.0)
-                        s.sendall(self._MAGIC + token.encode("ascii") + struct.pack("<i", rank))
+                        s.sendall(self._MAGIC + token.encode("ascii") + struct.pack("<ii", rank, nranks))
                         if self._exact(s, 2) != b"OK":
                             raise ConnectionError("handshake refused")
                         c = s
@@ -413,8 +431,8 @@ class SocketTransport:
     def from_env(cls, timeout=300.0):
         """RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT as torch.distributed.run (or any launcher) exports them"""
         rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-        tag = "%s_%s_%s" % (os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT", "29500"),
-                            os.environ.get("TORCHELASTIC_RUN_ID", "none"))
+        tag = "%s_%s_%s_%s_w%d" % (os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT", "29500"),
+                                   os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.environ.get("LF_JOB_ID", "none"), world)
         name = "rdv_" + "".join(ch if ch.isalnum() else "_" for ch in tag)
         return cls(rank, world, os.path.join(_private_dir(), name) if world > 1 else name, timeout)
 

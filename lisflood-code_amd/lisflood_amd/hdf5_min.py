@@ -241,6 +241,12 @@ class Writer:
     def __exit__(self, *exc):
         self.close()
 
+    def __del__(self):   # a writer dropped without close() (an exception in the caller's step loop): the chunk index and
+        try:             # the end-of-file address still reach the file, the steps written so far stay readable
+            self.close()
+        except Exception:
+            pass
+
     def _layout(self, path, datasets, root_attrs):
         names = [d.name for d in datasets]
         if len(set(names)) != len(names):

@@ -157,14 +157,12 @@ def write_netcdf4(path, var_name, maps, x, y, time_values=None, time_units="days
     timed = maps.ndim == 3
     if timed and (time_values is None or len(time_values) != maps.shape[0]):
         raise ValueError("a [T, H, W] stack needs time_values[T]")
-    w = NetCDF4MapWriter(path, var_name, x, y, time_values if timed else None, time_units, calendar, dtype, standard_name,
-                         long_name, units, dims, settings_path, complevel, coord_attrs, projection, esri_pe_string)
-    if maps.shape[-2:] != (len(y), len(x)):
-        w.close()
+    if maps.shape[-2:] != (len(y), len(x)):      # (before the file is created or truncated)
         raise ValueError("coordinate vectors do not match the map shape")
-    for t, m in enumerate(maps if timed else [maps]):
-        w.write_step(t, m)
-    w.close()
+    with NetCDF4MapWriter(path, var_name, x, y, time_values if timed else None, time_units, calendar, dtype, standard_name,
+                          long_name, units, dims, settings_path, complevel, coord_attrs, projection, esri_pe_string) as w:
+        for t, m in enumerate(maps if timed else [maps]):
+            w.write_step(t, m)
 
 
 class NetCDF4MapWriter:
@@ -214,10 +212,18 @@ class NetCDF4MapWriter:
             self._w.write_chunk(self._name, (0, 0), block)
 
     def flush(self):
+        """chunk index and end-of-file address as of now: a reader sees every step written so far (call it every few
+        steps of a long run; close() -- also on garbage collection -- does it once more)"""
         self._w.flush()
 
     def close(self):
         self._w.close()
+
+    def __del__(self):
+        try:
+            self._w.close()
+        except Exception:
+            pass
 
     def __enter__(self):
         return self

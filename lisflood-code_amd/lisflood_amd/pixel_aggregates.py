@@ -36,8 +36,10 @@ def dynamic(var, device=0):
     cache = getattr(v, "_lf_pixel_buffers", None)       # device buffers live as long as `var` does
     if cache is None or cache.device != device:
         cache = v._lf_pixel_buffers = BufferCache(device)
-    static = ("SoilFraction", "SoilDepthTotal", "SMaxSealed", "DirectRunoffFraction", "WaterFraction", "LowerZoneK",
-              "LZThreshold", "GwLossStep")       # parameter maps: uploaded once (BufferCache.put_static)
+    # parameter maps: uploaded once (BufferCache.put_static, content checksum).  NOT the land-use fractions
+    # (SoilFraction, DirectRunoffFraction, WaterFraction): the reference rewrites them during a run
+    # (landusechange.py:107-139, evapowater.py:108-119), they are staged on every call
+    static = ("SoilDepthTotal", "SMaxSealed", "LowerZoneK", "LZThreshold", "GwLossStep")
     for k in _V_IN:
         dev[k] = (cache.put_static if k in static else cache.put)(k, f64(_values(getattr(v, k))))
     for k in _N_IN + _STATE:

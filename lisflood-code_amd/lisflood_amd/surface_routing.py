@@ -87,7 +87,8 @@ class surface_routing(HydroModule):
         if getattr(self, "_cache", None) is None:        # device buffers live as long as the module
             self._cache = BufferCache(self.device)
         put, get = self._cache.put, self._cache.get
-        static = ("SoilFraction", "OFAlpha", "IsChannel")   # parameter maps: uploaded once (BufferCache.put_static)
+        static = ("OFAlpha", "IsChannel")   # parameter maps: uploaded once (BufferCache.put_static); SoilFraction is not
+        #                                     one (landusechange.py:107-139 rewrites it during a run)
         for k in _V_IN:
             dev[k] = (self._cache.put_static if k in static else put)(k, f64(_values(getattr(v, k))))
         for k in _N_IN:

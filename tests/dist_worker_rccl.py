@@ -29,34 +29,46 @@ def main():
     router = D.DistRouter(g, p["alpha"][sel], p["beta"], p["dx"][sel], p["dt"], device=device, comm=comm,
                           rank_top=rank - 1 if rank > 0 else -1, rank_bottom=rank + 1 if rank + 1 < world else -1)
     Q = router.new_state(p["Q0"][sel])
+    # four calls one by one and four as one pipelined sequence (lf_dist_router_route_many: alternating state vectors,
+    # halo rounds on the second stream beside the next call's phase 0); LF_TEST_MANY_FIRST=1: the pipelined four first
+    # (the halo stream and its events are then created by route_many, and the plain calls must find them)
+    many_first = os.environ.get("LF_TEST_MANY_FIRST", "0") == "1"
     outs = []
-    for s in range(4):
-        lat = router.new_state(syn.lateral_inflow(N, s)[sel])
-        router.route(Q, lat)
+
+    def plain(steps):
+        for s in steps:
+            lat = router.new_state(syn.lateral_inflow(N, s)[sel])
+            router.route(Q, lat)
+            _lib.synchronize(device)
+            lat.free()
+            outs.append((s, router.download_pix(Q)))
+
+    def pipelined(steps):
+        lats = [router.new_state(syn.lateral_inflow(N, s)[sel]) for s in steps]
+        router.route_many(Q, lats)
         _lib.synchronize(device)
-        lat.free()
-        outs.append(router.download_pix(Q))
-    # four more calls as one pipelined sequence (lf_dist_router_route_many: alternating state vectors, halo rounds on the
-    # second stream beside the next call's phase 0)
-    lats = [router.new_state(syn.lateral_inflow(N, s)[sel]) for s in range(4, 8)]
-    router.route_many(Q, lats)
-    _lib.synchronize(device)
-    outs.append(router.download_pix(Q))
-    for d in lats:
-        d.free()
+        outs.append((steps[-1], router.download_pix(Q)))
+        for d in lats:
+            d.free()
+
+    if many_first:
+        pipelined(range(0, 4))
+        plain(range(4, 8))
+    else:
+        plain(range(0, 4))
+        pipelined(range(4, 8))
     gathered = T.allgather(outs)
     if rank == 0:
         kw = oracle.kinematicWave(codes.reshape(-1).astype(np.float64), np.ones((H, W), bool), p["alpha"], p["beta"], p["dx"],
                                   p["dt"])
         Qo = p["Q0"].copy()
-        for s in range(4):
+        want = {}
+        for s in range(8):
             kw.kinematicWaveRouting(Qo, syn.lateral_inflow(N, s))
-            full = np.concatenate([gathered[k][s] for k in range(world)])
-            np.testing.assert_allclose(full, Qo, rtol=1e-9, atol=1e-12, err_msg="call %d" % s)
-        for s in range(4, 8):
-            kw.kinematicWaveRouting(Qo, syn.lateral_inflow(N, s))
-        full = np.concatenate([gathered[k][4] for k in range(world)])
-        np.testing.assert_allclose(full, Qo, rtol=1e-9, atol=1e-12, err_msg="pipelined calls 4..7")
+            want[s] = Qo.copy()
+        for i, (s, _) in enumerate(outs):
+            full = np.concatenate([gathered[k][i][1] for k in range(world)])
+            np.testing.assert_allclose(full, want[s], rtol=1e-9, atol=1e-12, err_msg="after call %d" % s)
         print("DIST_RCCL_OK phases=%d ranks=%d" % (g.num_phases, world))
     T.barrier()
     comm.close()

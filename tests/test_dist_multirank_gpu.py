@@ -69,6 +69,13 @@ def test_router_calls_between_processes(fake_rccl, family, world):
     assert "DIST_RCCL_OK" in outs[0][0] and "ranks=%d" % world in outs[0][0]
 
 
+def test_plain_router_call_after_a_pipelined_sequence(fake_rccl):
+    """the order nothing else runs: lf_dist_router_route_many first (it creates the halo stream), plain
+    lf_dist_router_route calls -- which order the halo stream by two events -- after it"""
+    outs = run_ranks(fake_rccl, 2, "tests/dist_worker_rccl.py", {"LF_TEST_FAMILY": "saddle", "LF_TEST_MANY_FIRST": "1"})
+    assert "DIST_RCCL_OK" in outs[0][0]
+
+
 @pytest.mark.parametrize("family,world,split", [("saddle", 2, True), ("saddle", 3, False), ("shallow", 4, True),
                                                 ("deep", 3, True), ("river", 4, True)])
 def test_fused_model_step_between_processes(fake_rccl, family, world, split):

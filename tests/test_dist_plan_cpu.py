@@ -221,7 +221,11 @@ def test_socket_transport_rejects_strangers_and_survives_a_stale_file(tmp_path):
     dead.bind(("127.0.0.1", 0))
     port = dead.getsockname()[1]
     dead.close()
-    open(rdv, "w").write("%d %s" % (port, "0" * 32))         # stale: nobody listens there
+    gone = os.fork()                                          # a pid that no longer exists: the crashed run's rank 0
+    if gone == 0:
+        os._exit(0)
+    os.waitpid(gone, 0)
+    open(rdv, "w").write("%d %s %d" % (port, "0" * 32, gone))   # stale: nobody listens there, its owner is gone
     res = {}
 
     def rank0():
@@ -234,7 +238,7 @@ def test_socket_transport_rejects_strangers_and_survives_a_stale_file(tmp_path):
     live = None
     while time.time() < deadline:                            # the file rank 0 publishes replaces the stale one
         try:
-            ps, tok = open(rdv).read().split()
+            ps, tok = open(rdv).read().split()[:2]
             if int(ps) != port:
                 live = (int(ps), tok)
                 break
@@ -243,10 +247,23 @@ def test_socket_transport_rejects_strangers_and_survives_a_stale_file(tmp_path):
         time.sleep(0.02)
     assert live is not None
     s = socket.create_connection(("127.0.0.1", live[0]))     # a stranger: right port, wrong token
-    s.sendall(D.SocketTransport._MAGIC + b"f" * 32 + (1).to_bytes(4, "little"))
+    s.sendall(D.SocketTransport._MAGIC + b"f" * 32 + (1).to_bytes(4, "little") + (2).to_bytes(4, "little"))
     s.settimeout(10)
     assert s.recv(2) == b""                                  # dropped without an answer
     s.close()
+    s = socket.create_connection(("127.0.0.1", live[0]))     # a rank of a job of another size: right token, wrong world
+    s.sendall(D.SocketTransport._MAGIC + live[1].encode("ascii") + (1).to_bytes(4, "little") + (3).to_bytes(4, "little"))
+    s.settimeout(10)
+    assert s.recv(2) == b""
+    s.close()
+    idle = socket.create_connection(("127.0.0.1", live[0]))  # says nothing: costs the others one second, not the run
+    # a second job's rank 0 on the same file while the first lives
+    probe = ("import sys; sys.path.insert(0, %r); from lisflood_amd import dist as D\n"
+             "try:\n    D.SocketTransport(0, 2, %r, timeout=5.0)\nexcept RuntimeError as e:\n    print('REFUSED', e)\n"
+             % (os.path.join(ROOT, "lisflood-code_amd"), rdv))
+    out = subprocess.run([sys.executable, "-c", probe], capture_output=True, text=True, timeout=60)
+    assert "REFUSED" in out.stdout, out.stdout + out.stderr
+    assert os.path.exists(rdv)                               # (and it did not clobber the live file)
     t1 = D.SocketTransport(1, 2, rdv, timeout=30.0)
     t0.join(30)
     assert 0 in res
@@ -258,6 +275,7 @@ def test_socket_transport_rejects_strangers_and_survives_a_stale_file(tmp_path):
     assert np.array_equal(got[0], np.arange(3)) and np.array_equal(out[0][1], np.arange(3) + 10)
     t1.close()
     res[0].close()
+    idle.close()
     assert not os.path.exists(rdv)
 
 

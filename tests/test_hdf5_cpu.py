@@ -226,3 +226,25 @@ def test_two_streamed_datasets_in_one_file(tmp_path):
     assert np.array_equal(r.dataset("c"), np.arange(4, dtype=np.float32)) and np.array_equal(r.dataset("t"), np.arange(5.0))
     with pytest.raises(KeyError):
         H5.Writer(str(tmp_path / "x.h5"), ds[:1]).write_chunk("a", (0, 0, 0), a[0][None])
+
+
+def test_shape_error_leaves_no_file_and_a_dropped_writer_keeps_its_steps(tmp_path):
+    """write_netcdf4 checks the map shape before it creates (or truncates) the file; a NetCDF4MapWriter that is dropped
+    without close() -- an exception in the caller's step loop -- still completes the chunk index on garbage collection"""
+    import gc
+    from lisflood_amd import output
+    x, y = np.arange(5.0), np.arange(4.0)
+    path = str(tmp_path / "bad.nc")
+    with pytest.raises(ValueError):
+        output.write_netcdf4(path, "dis", np.zeros((4, 6)), x, y)
+    assert not os.path.exists(path)
+    path = str(tmp_path / "dropped.nc")
+    maps = np.random.default_rng(3).random((3, 4, 5))
+    w = output.NetCDF4MapWriter(path, "dis", x, y, time_values=[0.0, 1.0, 2.0])
+    w.write_step(0, maps[0])
+    w.write_step(1, maps[1])
+    del w
+    gc.collect()
+    got = output.read_netcdf4(path, "dis")[0]
+    np.testing.assert_array_equal(got[:2], maps[:2])
+    assert np.isnan(got[2]).all()

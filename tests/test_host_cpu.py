@@ -314,3 +314,25 @@ def test_root_floor_constant_is_the_exact_threshold_of_the_fifth_power():
                                 floor * (1 + np.arange(-2000, 2000) * 2.0 ** -52)]))
     r2 = r * r
     np.testing.assert_array_equal(r >= floor, (r2 * r2) * r > 1e-12)
+
+
+def test_static_upload_fingerprint_sees_every_element():
+    """BufferCache.put_static skips an upload while the content checksum of the host array is unchanged: an in-place edit
+    of ANY element must change it (rounds 2-3 fingerprinted a strided sample of 4096 elements and missed edits between
+    the sample points), also in the odd bytes of a buffer that is not a multiple of 8 bytes long"""
+    fp = _lib.BufferCache._fingerprint
+    rng = np.random.default_rng(5)
+    x = rng.random(2_000_003)
+    f0 = fp(x)
+    assert fp(x.copy()) == f0                       # content, not address
+    for i in rng.integers(0, x.size, 50):
+        old = x[i]
+        x[i] = np.nextafter(old, 2.0)
+        assert fp(x) != f0, i
+        x[i] = old
+    assert fp(x) == f0
+    b = np.ones(1003, np.uint8)
+    f1 = fp(b)
+    b[1002] = 0
+    assert fp(b) != f1
+    assert fp(x.reshape(-1, 1)) != f0               # shape is part of it
