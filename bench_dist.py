@@ -28,6 +28,11 @@ def log(rank, *a):
     print("[bench rank %d]" % rank, *a, file=sys.stderr, flush=True)
 
 
+def peak_rss_gb():
+    import resource
+    return resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6
+
+
 def catchment_leg(a, T, rank, world, device):
     """Same raster, same calls, ranks own whole catchments (lisflood_amd.partition): no halo, no collective on the data
     path.  Every rank derives the partition from the full LDD itself (set-up, untimed)."""
@@ -43,9 +48,9 @@ def catchment_leg(a, T, rank, world, device):
     err = None
     try:
         raster = syn.make_ldd(a.family, H, W, seed)
-        g = Graph(ldd_raster=raster)
-        roots = P.catchment_roots(g)
-        g.close()
+        # the outlet of every pixel straight from the 1-byte LDD (pointer jumping on one int32 vector): no whole-raster
+        # graph in any rank -- round 3 built one per rank, ~20 GB of host memory each at 10000^2
+        roots = P.catchment_roots_of_raster(raster)
         pix_rank, sizes = P.split_catchments(roots, world)
         del roots
         ids = np.nonzero(pix_rank == rank)[0]
@@ -65,7 +70,8 @@ def catchment_leg(a, T, rank, world, device):
             d.copy_from(tmp)
         _lib.synchronize(device)
         tmp.free()
-        log(rank, "catchment partition: %d cells in %d levels, set-up %.1f s" % (n, kw.graph.num_levels, time.time() - t0))
+        log(rank, "catchment partition: %d cells in %d levels, set-up %.1f s, peak host memory so far %.1f GB"
+            % (n, kw.graph.num_levels, time.time() - t0, peak_rss_gb()))
     except Exception as e:
         err = repr(e)
     # all ranks take the same branch: a rank that failed its set-up must not leave the others in a barrier
@@ -220,8 +226,9 @@ def main(a):
     qs = [router.new_state(syn.lateral_inflow_slice(N, s, i0, i1)) for s in range(nq)]
     _lib.synchronize(device)
     log(rank, "rows [%d,%d) cells=%d phases=%d launch_units=%d ghosts=%s exports=%s non-contiguous inflow: %d cells; "
-        "setup %.1f s" % (r0, r1, graph.num_pixels, graph.num_phases, graph.num_launch_units, graph.n_ghost,
-                          graph.n_export, graph.num_noncontiguous, time.time() - t_setup))
+        "setup %.1f s, peak host memory %.1f GB" % (r0, r1, graph.num_pixels, graph.num_phases, graph.num_launch_units,
+                                                     graph.n_ghost, graph.n_export, graph.num_noncontiguous,
+                                                     time.time() - t_setup, peak_rss_gb()))
     # the K calls as ONE pipelined sequence (lf_dist_router_route_many: phase 0 of call s + 1 beside the later halo rounds
     # of call s, alternating state vectors); LF_DIST_OVERLAP=0 or a single phase: call by call
     if a.warmup:
@@ -237,22 +244,8 @@ def main(a):
     Qh = router.download_pix(Q)
     chk = T.allreduce(np.array([float(Qh.sum()), float(np.isfinite(Qh).all() and (Qh >= 0).all())]), "sum")
     launches = int(T.allreduce(int(router.last_launches()), "max"))
-    # configs[4]'s workload shape on the SAME row blocks: a model step of 24 split-routing sub-steps, every sub-step of a
-    # phase as one wavefront (level blocks + cones), ONE RCCL halo block per phase and model step
-    row_step = None
-    if not getattr(a, "no_extra", False):
-        try:
-            row_step = row_block_model_step(a, T, rank, world, device, graph, comm, N, i0, i1)
-        except Exception as e:
-            row_step = {"error": repr(e)}
-    # secondary: the same raster partitioned by whole catchments -- no exchange, every rank runs the single-GPU engine
-    catch = None
-    if not getattr(a, "no_extra", False):
-        try:
-            catch = catchment_leg(a, T, rank, world, device)
-        except Exception as e:  # must never cost the headline line
-            catch = {"error": repr(e)}
-    if rank == 0:
+    out = None
+    if rank == 0:           # the headline first: nothing a secondary leg does below can cost it
         ms = dt_max * 1e3 / a.steps
         value = N / ms / 1e3
         out = {
@@ -276,6 +269,22 @@ def main(a):
                          "traffic": None},
             "checksum_sumQ": float(chk[0]), "finite": bool(chk[1] == world),
         }
+    # configs[4]'s workload shape on the SAME row blocks: a model step of 24 split-routing sub-steps, every sub-step of a
+    # phase as one wavefront (level blocks + cones), ONE RCCL halo block per phase and model step
+    row_step = None
+    if not getattr(a, "no_extra", False):
+        try:
+            row_step = row_block_model_step(a, T, rank, world, device, graph, comm, N, i0, i1)
+        except Exception as e:
+            row_step = {"error": repr(e)}
+    # secondary: the same raster partitioned by whole catchments -- no exchange, every rank runs the single-GPU engine
+    catch = None
+    if not getattr(a, "no_extra", False):
+        try:
+            catch = catchment_leg(a, T, rank, world, device)
+        except Exception as e:  # must never cost the headline line
+            catch = {"error": repr(e)}
+    if rank == 0:
         if row_step is not None:
             out["model_step_24_substeps_split_row_blocks"] = row_step
         if catch is not None:
@@ -286,9 +295,13 @@ def main(a):
                 # would show here
                 out["row_block_vs_catchment_partition_sumQ_rel_diff"] = abs(float(chk[0]) - catch["checksum_sumQ"]) / abs(
                     catch["checksum_sumQ"])
-    T.barrier()
-    comm.close()
-    T.close()
+    try:                    # (a secondary leg that lost a rank leaves the transport unusable: the line below still goes out)
+        T.barrier()
+        comm.close()
+        T.close()
+    except Exception as e:
+        log(rank, "shutdown: %r" % (e,))
     _flush_c_stdio()
     if rank == 0:           # the ONE JSON line, last on stdout
+        out["peak_host_memory_gb_rank0"] = round(peak_rss_gb(), 2)
         print(json.dumps(out), flush=True)

@@ -604,6 +604,13 @@ class DistRouter:
         check(lib().lf_dist_router_pack(self._h, q_state.ptr, C.c_int(rnd), ptrs, cnt))
         return [(ptrs[i], int(cnt[i])) for i in range(2)]
 
+    def exchange(self, q_state, rnd):
+        """halo round `rnd` of a router call alone (lf_dist_router_exchange: pack, one grouped RCCL Send/Recv per neighbour
+        on the library stream) -- what route() issues after part 0 of phase `rnd`"""
+        ch = self.comm._h if self.comm is not None else None
+        check(lib().lf_dist_router_exchange(self._h, ch, q_state.ptr, C.c_int(rnd), C.c_int(self.rank_top),
+                                            C.c_int(self.rank_bottom)))
+
     def recv_slots(self, rnd):
         slot = (C.c_int64 * 2)()
         cnt = (C.c_int64 * 2)()

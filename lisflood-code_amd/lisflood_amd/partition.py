@@ -27,6 +27,42 @@ def catchment_roots(graph):
     return out
 
 
+def catchment_roots_of_raster(ldd_raster, land_mask=None):
+    """catchment_roots without building a graph: the outlet of every land pixel (compressed pixel ids, as catchment_roots
+    returns them) straight from the uint8 LDD raster by pointer jumping -- every pixel's pointer doubles its reach per pass,
+    log2(longest flow path) passes over one int32 vector (the device form is lf_ldd.hip's k_jump_step).  Peak host memory
+    ~3 int32 vectors of the raster's size: what a rank of a many-rank job can afford where a whole-raster Graph (20 GB at
+    10000^2) is not.  Codes follow kinematic_wave_parallel.py:49-51; a pixel pointing off the raster, at a missing value
+    or at non-land is a pit, as lddrepair leaves it (routing.py:125)."""
+    from .synthetic import FLOW_CODE, IX_ADDS
+    ldd = np.asarray(ldd_raster)
+    H, W = ldd.shape
+    land = (ldd != 0) if land_mask is None else (np.asarray(land_mask, bool) & (ldd != 0))
+    if land_mask is not None and (np.asarray(land_mask, bool) & (ldd == 0)).any():
+        raise ValueError("LDD code 0 on a land pixel")
+    n = H * W
+    parent = np.arange(n, dtype=np.int32).reshape(H, W)           # raster index of the downstream pixel (pits: itself)
+    rows = np.arange(H, dtype=np.int32)[:, None]
+    cols = np.arange(W, dtype=np.int32)[None, :]
+    for k, (dr, dc) in enumerate(IX_ADDS):
+        sel = ldd == FLOW_CODE[k]
+        r2, c2 = rows + dr, cols + dc
+        ok = sel & (r2 >= 0) & (r2 < H) & (c2 >= 0) & (c2 < W)
+        tgt = (np.clip(r2, 0, H - 1) * W + np.clip(c2, 0, W - 1)).astype(np.int32)
+        ok &= land.reshape(-1)[tgt]                               # a link into non-land is cut
+        parent[ok] = tgt[ok]
+        del sel, ok, tgt
+    parent = parent.reshape(-1)
+    while True:                                                   # parent <- parent o parent until nothing moves
+        nxt = parent[parent]
+        if np.array_equal(nxt, parent):
+            break
+        parent = nxt
+    landf = land.reshape(-1)
+    comp = np.cumsum(landf, dtype=np.int64).astype(np.int32) - 1  # raster index -> compressed pixel id
+    return comp[parent[landf]]
+
+
 def split_catchments(roots, nparts):
     """rank of every pixel: catchments ordered by outlet pixel id, cut where the running cell count passes k*N/nparts
     (whole catchments only; the imbalance is bounded by the largest catchment)."""

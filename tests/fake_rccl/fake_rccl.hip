@@ -65,6 +65,17 @@ struct comm {
     unsigned long long sent[kMaxRanks] = {}, rcvd[kMaxRanks] = {}; // chunks issued per pair
     unsigned int *err = nullptr;        // pinned host word the kernels raise
     long long timeout_ticks = 0;
+    // FAKE_RCCL_LOG_DIR: every operation in host issue order -- group number, send / receive, peer, bytes -- written to
+    // <dir>/rank<r>.log when the communicator is destroyed.  RCCL matches the operations of a pair of ranks in issue
+    // order, so for every pair (a, b) a's sends to b and b's receives from a must be the same sequence of sizes
+    // (tests/test_dist_multirank_gpu.py: check_issue_order); a mailbox with equal sizes would not notice a swap.
+    struct logged {
+        long long group;
+        int send, peer;
+        unsigned long long bytes;
+    };
+    std::vector<logged> log;
+    long long groups = 0;
 };
 
 struct op {
@@ -214,6 +225,7 @@ int enqueue(comm *c, int send, void *buf, size_t count, int dtype, int peer, hip
     if (bytes % 8 != 0 || ((uintptr_t)buf & 7)) return kInvalidArgument; // the shim moves 8-byte words
     if (int e = check_error(c)) return e;
     if (bytes == 0) return kSuccess;
+    c->log.push_back({t_depth == 0 ? c->groups++ : c->groups, send, peer, bytes});
     op o;
     o.send = send;
     o.user = (char *)buf;
@@ -324,6 +336,15 @@ int ncclCommDestroy(void *p)
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     const int e = check_error(c);
+    if (const char *dir = std::getenv("FAKE_RCCL_LOG_DIR")) {
+        char path[512];
+        std::snprintf(path, sizeof path, "%s/rank%d.log", dir, c->rank);
+        if (FILE *f = std::fopen(path, "a")) { // (a process may make several communicators in a row)
+            for (const comm::logged &l : c->log)
+                std::fprintf(f, "%lld %s %d %llu\n", l.group, l.send ? "send" : "recv", l.peer, l.bytes);
+            std::fclose(f);
+        }
+    }
     if (c->nranks > 1) { // nobody unmaps a mailbox a peer may still be writing to
         c->ctl->leaving.fetch_add(1);
         spin_until(c->ctl->leaving, c->nranks, 60.0);
@@ -358,7 +379,10 @@ int ncclGroupEnd()
     if (t_depth <= 0) return kInvalidUsage;
     if (--t_depth > 0) return kSuccess;
     int e = kSuccess;
-    if (!t_ops.empty()) e = launch(t_comm, t_stream, t_ops.data(), (int)t_ops.size());
+    if (!t_ops.empty()) {
+        e = launch(t_comm, t_stream, t_ops.data(), (int)t_ops.size());
+        ++t_comm->groups;
+    }
     t_ops.clear();
     t_comm = nullptr;
     t_have_stream = false;

@@ -33,10 +33,37 @@ def fake_rccl():
     return FAKE
 
 
-def run_ranks(fake, world, script, extra_env, args=(), timeout=600):
-    """`world` processes of `script`, all on device 0, rendezvous on a fresh port; -> [(stdout, stderr)] per rank"""
+def check_issue_order(log_dir, world):
+    """RCCL pairs the operations of two ranks in host issue order: for every pair (a, b) the sizes of a's sends to b and of
+    b's receives from a, each in the order its rank issued them, must be the same sequence -- whatever streams, groups
+    and events lie between (every rank walks the same sequence of (call, round) pairs).  -> the
+    number of operations checked; raises AssertionError naming the first pair and position that differ."""
+    ops = {}
+    for r in range(world):
+        path = os.path.join(log_dir, "rank%d.log" % r)
+        rows = [l.split() for l in open(path)] if os.path.exists(path) else []
+        ops[r] = [(int(g), kind, int(peer), int(nbytes)) for g, kind, peer, nbytes in rows]
+    n = 0
+    for a in range(world):
+        for b in range(world):
+            if a == b:
+                continue
+            sends = [x[3] for x in ops[a] if x[1] == "send" and x[2] == b]
+            recvs = [x[3] for x in ops[b] if x[1] == "recv" and x[2] == a]
+            assert sends == recvs, "ranks %d -> %d: %d sends %s..., %d receives %s..." % (
+                a, b, len(sends), sends[:8], len(recvs), recvs[:8])
+            n += len(sends)
+    return n
+
+
+def run_ranks(fake, world, script, extra_env, args=(), timeout=600, expect_failure=False):
+    """`world` processes of `script`, all on device 0, rendezvous on a fresh port; -> [(stdout, stderr)] per rank.  Every
+    run also checks the issue order the stand-in recorded (check_issue_order)."""
+    import tempfile
     _PORT[0] += 1
     procs = []
+    log_dir = tempfile.mkdtemp(prefix="fake_rccl_order_")
+    extra_env = dict(extra_env, FAKE_RCCL_LOG_DIR=log_dir)
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(_PORT[0]), TORCHELASTIC_RUN_ID="fake%d_%d" % (os.getpid(), _PORT[0]),
@@ -54,9 +81,12 @@ def run_ranks(fake, world, script, extra_env, args=(), timeout=600):
         for p in procs:
             if p.poll() is None:
                 p.kill()
+    if expect_failure:
+        return outs, log_dir, [p.returncode for p in procs]
     if any(p.returncode != 0 for p in procs):
         pytest.fail("\n".join("--- rank %d rc=%s\n%s\n%s" % (rank, p.returncode, o[-1500:], e[-2500:])
                               for rank, (p, (o, e)) in enumerate(zip(procs, outs))))
+    check_issue_order(log_dir, world)
     return outs
 
 
@@ -67,6 +97,21 @@ def test_router_calls_between_processes(fake_rccl, family, world):
     oracle's discharge after 4 + 4 calls"""
     outs = run_ranks(fake_rccl, world, "tests/dist_worker_rccl.py", {"LF_TEST_FAMILY": family})
     assert "DIST_RCCL_OK" in outs[0][0] and "ranks=%d" % world in outs[0][0]
+
+
+def test_a_misordered_rank_is_caught(fake_rccl):
+    """the check of the check: three ranks exchange their halo rounds through the product's own lf_dist_router_exchange,
+    rank 1 in REVERSE round order.  The stand-in's issue log must show the mismatch (and the run itself must not pass: the
+    byte counts of the rounds differ, or a receive waits for a send that comes later)"""
+    (outs, log_dir, rcs) = run_ranks(fake_rccl, 3, "tests/dist_worker_order.py",
+                                     {"LF_TEST_FAMILY": "saddle", "LF_TEST_REVERSED_RANK": "1", "FAKE_RCCL_TIMEOUT_S": "5"},
+                                     timeout=300, expect_failure=True)
+    with pytest.raises(AssertionError):
+        check_issue_order(log_dir, 3)
+    assert any(rc != 0 for rc in rcs) or not any("ORDER_WORKER_OK" in o for o, _ in outs)
+    # ... and the same worker with every rank in round order is clean
+    outs = run_ranks(fake_rccl, 3, "tests/dist_worker_order.py", {"LF_TEST_FAMILY": "saddle"}, timeout=300)
+    assert all("ORDER_WORKER_OK" in o for o, _ in outs)
 
 
 def test_plain_router_call_after_a_pipelined_sequence(fake_rccl):
