@@ -797,4 +797,320 @@ __global__ void __launch_bounds__(CW) __attribute__((amdgpu_waves_per_eu(LF_CONE
     cone_store<SPLIT, STRUCT>(F, pend, s);
 }
 
+// ---- the cone kernel of a model step with the work split between a chain wavefront and supply wavefronts (round 4) ----
+// k_fused_cones makes ONE wavefront (or four, with a barrier per level) do everything a (cell, sub-step) needs: ~25 state
+// loads, the sideflow split, two old-discharge terms, two closure solves, the Q -> V -> Q fix-ups, nine stores -- ~650
+// instructions of mostly dependent fp64 arithmetic per level, during which the level below waits.  With ~2 wavefronts
+// per SIMD (5000 cells per level x 24 sub-steps is all the parallelism a `deep` 5000^2 raster has) nothing hides those
+// chains: VALU busy 29 % (profiles/pmc_r03a_fused_deep_5000.txt).  Only gather -> sum -> solve feeds the level below.
+// So, as in k_sweep_cones_split (lf_sweep.h), per cone of at most 64 cells per level:
+//   * the CHAIN wavefront runs the two routers of the cell (main channel, floodplains) from LDS records: gather the level
+//     above, add, solve, put the router outputs back into LDS -- nothing else (cone_chain<true, NR = 2>);
+//   * KC = 4 SUPPLY wavefronts, one per level of a chunk, work two chunks ahead and two chunks behind it:
+//       phase ph:   request the state of chunk ph + 1                          (pre-loads)
+//                   request what the fix-ups of chunk ph - 1 need again          (post-loads: 7 streams, L2 hits mostly)
+//                   fix-ups and stores of chunk ph - 2 from its router outputs  (routing.py:526-532, 573-603)
+//                   sideflow split, constant terms, gather addresses of chunk ph (routing.py:512-567) -> LDS
+//     the two meet at one workgroup barrier per chunk.  Loads and stores sit behind no branch (lanes beyond the cone's
+//     range load cell 0 and store beyond the end of a buffer resource; the outputs only the last sub-step keeps are
+//     stored beyond the end on the others), so the compiler's wait counts stay exact.
+// Arithmetic per cell = fused_cell's, operation by operation (cone_compute's beta = 3/5 forms): bit-identical.
+// For: beta = 3/5 router and fix-ups, no structures, no zero-length links, no inert-pixel test (a compact channel domain
+// has none), the single-domain plan with cones of <= 64 cells; every other case keeps k_fused_cones.
+constexpr int kFusedKC = 4;
+
+template <bool SPLIT>
+__global__ void __launch_bounds__(64 * (1 + kFusedKC)) k_fused_cones_split(fused_args F)
+{
+    constexpr int NR = SPLIT ? 2 : 1, KC = kFusedKC;
+    __shared__ cone_lds<NR, KC> S;
+    __shared__ double s1buf[3][KC][64]; // Sideflow1Chan of a cell from its constant terms to its stores (two chunks later)
+    int s, blk;
+    {
+        int cnt = 0, start = 0;
+        for (int q = 0; q < F.nsteps; ++q) {
+            const bool ge = (int)blockIdx.x >= F.blk_start[q];
+            cnt += ge ? 1 : 0;
+            start = ge ? F.blk_start[q] : start;
+        }
+        s = cnt - 1;
+        blk = (int)blockIdx.x - start;
+    }
+    const int bi = F.t - s;
+    if (bi < 0 || bi >= F.fb_nblocks) return;
+    const int b = F.fb_block0 + bi;
+    const int row0 = ld_table(F.fb_row, b), ncones = ld_table(F.fb_row, b + 1) - row0 - 1;
+    if (blk >= ncones) return;
+    const int nl = ld_table(F.fb_level, b + 1) - ld_table(F.fb_level, b);
+    const int *c0 = F.fb_cone + (size_t)ld_table(F.fb_off, b) + (size_t)blk * nl, *c1 = c0 + nl; // this cone / the next
+    const int tid = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // 0 = chain, 1 .. KC = supply
+    const int nch = (nl + KC - 1) / KC;
+    if (wave == 0) {
+        if (tid < 2 * KC * NR) S.xr[tid][64] = 0.0; // the zero slot of every row
+        sweep_args_multi M;                          // (the chain's cold path: a outside the fast range, c beyond 1e30)
+        for (int r = 0; r < kMaxMulti; ++r) {
+            M.r[r].a = (r == 1 && SPLIT) ? F.a2 : F.a1;
+            M.r[r].beta = F.beta;
+            M.r[r].inv_beta = F.inv_beta;
+            M.r[r].b_minus_1 = F.b_minus_1;
+        }
+        lds_barrier(); // chunk 0 is in LDS
+        switch (F.kmax) {
+        case 0:
+        case 1: cone_chain<true, NR, KC, 1>(S, tid, nl, c0, M); break;
+        case 2: cone_chain<true, NR, KC, 2>(S, tid, nl, c0, M); break;
+        case 3: cone_chain<true, NR, KC, 3>(S, tid, nl, c0, M); break;
+        case 4: cone_chain<true, NR, KC, 4>(S, tid, nl, c0, M); break;
+        case 5: cone_chain<true, NR, KC, 5>(S, tid, nl, c0, M); break;
+        case 6: cone_chain<true, NR, KC, 6>(S, tid, nl, c0, M); break;
+        case 7: cone_chain<true, NR, KC, 7>(S, tid, nl, c0, M); break;
+        default: cone_chain<true, NR, KC, 8>(S, tid, nl, c0, M); break;
+        }
+        return;
+    }
+    // ---- a supply wavefront: level sw of every chunk ----
+    const int sw = wave - 1;
+    const unsigned int dflags = derived_flags(F);
+    const bool dx_is_len = (dflags & 2u) != 0u;
+    const bool last = s == F.nsteps - 1;
+    const long long par = (long long)(s & 1) * F.n;
+    const unsigned nbytes = (unsigned)F.n * 8u;
+    typedef int v2i __attribute__((ext_vector_type(2)));
+    typedef const fused_args __attribute__((address_space(4))) *kargs_t;
+    const kargs_t K0 = (kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
+    auto lbound = [&](const int *t, int k) { // entry k of a cone's row of the plan, 0 outside the block
+        const bool in = (unsigned)k < (unsigned)nl;
+        const int v = ld_table(t, in ? k : 0);
+        return in ? v : 0;
+    };
+    struct pre_t { // what the constant terms of a cell need, as loaded
+        int u0, u1, p;
+        double len, side_m3, qold, alpha1, m3, m3_2, start, m3limit, q2start, q2old, alpha2, inv_len, ap1, ap2, dxv;
+        unsigned char chan;
+        bool act;
+    };
+    struct post_t { // what its fix-ups need again two chunks later
+        int p;
+        double len, alpha1, inv_len, inv_alpha1, start, alpha2, inv_alpha2, qlimit, sum_old, pix_area;
+        bool act;
+    };
+    auto body = [&](auto rc_tag) {
+        constexpr bool RC = decltype(rc_tag)::value; // the five derived statics are recomputed (fused_args::recompute)
+        auto issue_pre = [&](int ph, pre_t &P) {
+            kargs_t Kp = K0; // (the ~40 array pointers: re-read from the kernel-argument segment per phase, see k_fused_cones)
+            asm volatile("" : "+s"(Kp));
+            const fused_args &G = *(const fused_args *)Kp;
+            const lf_substep_args &A = G.S;
+            const int j = ph * KC + sw;
+            const int p = lbound(c0, j) + tid;
+            P.act = p < lbound(c1, j);
+            P.p = p;
+            const int pc = P.act ? p : 0;
+            P.u0 = G.ups_ptr[pc];
+            P.u1 = G.ups_ptr[pc + 1];
+            P.len = A.ChanLength[pc];
+            P.chan = A.IsChannelKinematic[pc];
+            P.side_m3 = A.SideflowChanM3[(long long)s * G.side_stride + pc];
+            P.qold = A.ChanQKin[pc];
+            P.alpha1 = A.ChannelAlpha[pc];
+            P.dxv = (G.dx ? G.dx : A.ChanLength)[pc]; // (no per-pixel dx: any valid stream, the scalar is selected)
+            P.inv_len = RC ? 0.0 : A.InvChanLength[pc];
+            P.ap1 = RC ? 0.0 : G.a1[pc];
+            P.m3 = P.m3_2 = P.start = P.m3limit = P.q2start = P.q2old = P.alpha2 = P.ap2 = 0.0;
+            if (SPLIT) {
+                P.m3 = A.ChanM3Kin[pc];
+                P.m3_2 = A.Chan2M3Kin[pc];
+                P.start = A.Chan2M3Start[pc];
+                P.m3limit = A.M3Limit[pc];
+                P.q2start = A.Chan2QStart[pc];
+                P.q2old = A.Chan2QKin[pc];
+                P.alpha2 = A.ChannelAlpha2[pc];
+                P.ap2 = RC ? 0.0 : G.a2[pc];
+            }
+        };
+        auto finish_pre = [&](int ph, const pre_t &P, auto first_chunk) {
+            kargs_t Kp = K0;
+            asm volatile("" : "+s"(Kp));
+            const fused_args &G = *(const fused_args *)Kp;
+            const lf_substep_args &A = G.S;
+            const int ob = ph & 1, jj = sw, j = ph * KC + jj;
+            cone_chunk_ops<NR, KC> &O = S.ops[ob];
+            const bool block_top = decltype(first_chunk)::value && sw == 0; // the block's first level
+            // ---- the reads of the level above ----
+            const int above = jj > 0 ? (ob * KC + jj - 1) * NR : ((ob ^ 1) * KC + KC - 1) * NR;
+            const int cnt = P.act ? P.u1 - P.u0 : 0;
+            const int ab = above * kConeRow + (((P.u0 - lbound(c0, j - 1)) & 0xff) << 3);
+            cone_rec_ad a0, a1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                a0.ad[k] = (k < cnt && !block_top) ? ab + 8 * k : 64 * 8;
+                a1.ad[k] = (k + 4 < cnt && !block_top) ? ab + 8 * (k + 4) : 64 * 8;
+            }
+            O.ad[jj][0][tid] = a0;
+            O.ad[jj][1][tid] = a1;
+            // ---- sideflow (routing.py:512, 524 / 549-567), as cone_compute ----
+            const double dxp = dx_is_len ? P.len : (G.dx ? P.dxv : G.dx_scalar);
+            const double inv_len = RC ? 1.0 / P.len : P.inv_len;
+            const double ap1 = RC ? P.alpha1 * dxp / G.dt : P.ap1;
+            const double side = (P.chan != 0) ? P.side_m3 * inv_len * A.InvDtRouting : 0.0;
+            double s1 = side, s2 = 0.0;
+            if (!SPLIT) {
+                if (isnan(side)) s1 = 0.0;
+            } else {
+                const double tot = P.m3 + P.m3_2;
+                const double ratio = (tot > 0) ? P.m3 / tot : 0.0;
+                s1 = ((tot - P.start) > P.m3limit) ? ratio * side : side;
+                if (fabs(side) < 1e-7) s1 = side;
+                s2 = (side - s1) + P.q2start * inv_len;
+            }
+            s1buf[(ph + 3) % 3][jj][tid] = s1;
+            // ---- constant terms of the two routers (kinematic_wave_parallel.py:163,175) ----
+            double cst[2], apv[2];
+            cst[0] = ap1 * cone_pow_3_5<true>(P.qold, G.beta, true) + s1 * dxp;
+            apv[0] = ap1;
+            if (SPLIT) {
+                const double ap2 = RC ? P.alpha2 * dxp / G.dt : P.ap2;
+                cst[1] = ap2 * cone_pow_3_5<true>(P.q2old, G.beta, true) + s2 * dxp;
+                apv[1] = ap2;
+            }
+            if (decltype(first_chunk)::value) {
+                if (block_top) { // from the block before (previous launch) through the parity buffers
+                    cst[0] = upstream_sum8(G.qr1 + par, P.u0, P.u0 + cnt, G.kmax) + cst[0];
+                    if (SPLIT) cst[1] = upstream_sum8(G.qr2 + par, P.u0, P.u0 + cnt, G.kmax) + cst[1];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const bool fast_a = lf_fast_range(apv[r]);
+                cone_rec_ca ca;
+                ca.cst = cst[r];
+                ca.ap = fast_a ? apv[r] : 1.0;
+                cone_rec_fl fl;
+                fl.af = (float)ca.ap;
+                fl.laf = __builtin_amdgcn_logf(fl.af);
+                fl.fast_a = fast_a;
+                fl.pad = 0;
+                O.ca[jj][r][tid] = ca;
+                O.fl[jj][r][tid] = fl;
+            }
+        };
+        auto issue_post = [&](int ph, post_t &R) {
+            kargs_t Kp = K0;
+            asm volatile("" : "+s"(Kp));
+            const fused_args &G = *(const fused_args *)Kp;
+            const lf_substep_args &A = G.S;
+            const int j = ph * KC + sw;
+            const int p = lbound(c0, j) + tid;
+            R.act = p < lbound(c1, j);
+            R.p = p;
+            const int pc = R.act ? p : 0;
+            R.len = A.ChanLength[pc];
+            R.alpha1 = A.ChannelAlpha[pc];
+            R.sum_old = A.sumDisDay[pc];
+            R.inv_len = RC ? 0.0 : A.InvChanLength[pc];
+            R.inv_alpha1 = RC ? 0.0 : A.InvChannelAlpha[pc];
+            R.pix_area = A.PixelArea[last ? pc : 0]; // (read by the last sub-step only: one line on the others)
+            R.start = R.alpha2 = R.inv_alpha2 = R.qlimit = 0.0;
+            if (SPLIT) {
+                R.start = A.Chan2M3Start[pc];
+                R.alpha2 = A.ChannelAlpha2[pc];
+                R.qlimit = A.QLimit[pc];
+                R.inv_alpha2 = RC ? 0.0 : A.InvChannelAlpha2[pc];
+            }
+        };
+        auto finish_post = [&](int ph, const post_t &R) { // fix-ups and stores of chunk ph (routing.py:526-532, 573-603, 693-703)
+            kargs_t Kp = K0;
+            asm volatile("" : "+s"(Kp));
+            const fused_args &G = *(const fused_args *)Kp;
+            const lf_substep_args &A = G.S;
+            const int ob = ph & 1, jj = sw, j = ph * KC + jj;
+            const double qr = S.xr[(ob * KC + jj) * NR][tid];
+            const double q2r = SPLIT ? S.xr[(ob * KC + jj) * NR + (NR - 1)][tid] : 0.0;
+            const double s1 = s1buf[(ph + 3) % 3][jj][tid];
+            const double inv_len = RC ? 1.0 / R.len : R.inv_len;
+            const double inv_alpha1 = RC ? 1.0 / R.alpha1 : R.inv_alpha1;
+            double v = R.len * R.alpha1 * cone_pow_3_5<true>(qr, A.Beta, true);
+            if (v < 0.0) v = 0.0;
+            const double x = v * inv_len * inv_alpha1;
+            const double q = cone_pow_5_3<true>(x, A.InvBeta, true);
+            double chanq = q, v2 = 0, q2 = 0;
+            if (SPLIT) {
+                const double inv_alpha2 = RC ? 1.0 / R.alpha2 : R.inv_alpha2;
+                v2 = R.len * R.alpha2 * cone_pow_3_5<true>(q2r, A.Beta, true);
+                if ((v2 - R.start) < 0.0) v2 = R.start;
+                const double x2 = v2 * inv_len * inv_alpha2;
+                q2 = cone_pow_5_3<true>(x2, A.InvBeta, true);
+                chanq = q + q2 - R.qlimit;
+                if (chanq < 0.0) chanq = 0.0;
+            }
+            double vel = 0.0;
+            if (last) { // routing.py:693-703
+                double area = v * inv_len;
+                if (area < 0.01) area = 0.01;
+                const double v1 = q / area, vv2 = 0.36 * cold_pow(q, 0.24);
+                vel = (vv2 < v1) ? vv2 : v1;
+                if (isnan(vv2)) vel = vv2;
+                double sinu = sqrt(R.pix_area) * inv_len;
+                if (sinu > 1) sinu = 1;
+                vel *= sinu;
+            }
+            const unsigned off = R.act ? (unsigned)R.p * 8u : 0xffffffffu; // beyond the buffer: dropped
+            const unsigned off_last = last ? off : 0xffffffffu;           // what only the last sub-step leaves behind
+            const unsigned off_out = (j == nl - 1) ? off : 0xffffffffu;   // the block's last level: read by the next block
+            auto put = [&](double *base, unsigned o, double val) {
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, val),
+                                                      __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)nbytes, 0x00020000), o, 0, 0);
+            };
+            put(G.qr1 + par, off_out, qr);
+            put(A.ChanM3Kin, off, v);
+            put(A.ChanQKin, off, q);
+            put(A.ChanQ, off_last, chanq);
+            put(A.sumDisDay, off, R.sum_old + chanq);
+            if (SPLIT) {
+                put(G.qr2 + par, off_out, q2r);
+                put(A.Sideflow1Chan, off_last, s1);
+                put(A.Chan2M3Kin, off, v2);
+                put(A.CrossSection2Area, off_last, (v2 - R.start) * inv_len);
+                put(A.Chan2QKin, off, q2);
+            }
+            put(A.FlowVelocity, off_last, vel);
+            put(A.TravelDistance, off_last, vel * A.DtSec);
+        };
+        // phase ph: pre-loads of chunk ph + 1, post-loads of chunk ph - 1, fix-ups of chunk ph - 2, constant terms of chunk
+        // ph; barriers behind the phases 0 .. nch.  Chunks of even / odd number use the register sets A / B.
+        pre_t PA, PB;
+        post_t RA, RB;
+        RB.act = false; // (the first trip runs the fix-ups of a chunk -1: nothing of it is stored)
+        RB.p = 0;
+        RB.len = RB.alpha1 = RB.inv_len = RB.inv_alpha1 = RB.start = RB.alpha2 = RB.inv_alpha2 = RB.qlimit = RB.sum_old =
+            RB.pix_area = 1.0;
+        issue_pre(0, PA);
+        issue_pre(1, PB);
+        finish_pre(0, PA, std::true_type());
+        lds_barrier();
+        for (int ph = 1; ph <= nch; ph += 2) {
+            issue_pre(ph + 1, PA);
+            issue_post(ph - 1, RA);
+            finish_post(ph - 2, RB);
+            finish_pre(ph, PB, std::false_type());
+            lds_barrier();
+            if (ph + 1 > nch) break;
+            issue_pre(ph + 2, PB);
+            issue_post(ph, RB);
+            finish_post(ph - 1, RA);
+            finish_pre(ph + 1, PA, std::false_type());
+            lds_barrier();
+        }
+        if ((nch - 1) & 1)
+            finish_post(nch - 1, RB);
+        else
+            finish_post(nch - 1, RA);
+    };
+    if (dflags & 1u)
+        body(std::true_type());
+    else
+        body(std::false_type());
+}
+
 } // namespace

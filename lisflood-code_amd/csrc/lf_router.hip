@@ -611,8 +611,12 @@ static int build_level_blocks(lf_router *r, const lf_graph *g, bool for_route)
     if (for_route) { // one wavefront per cone: no barrier between the levels (deep 10 000^2: 11.3 -> 10.1 ms per call)
         cw = 64;
         if (const char *e = std::getenv("LF_ROUTE_CONE_WIDTH")) cw = std::atoi(e) == 64 ? 64 : kBlock;
-    } else if (const char *e = std::getenv("LF_FUSED_CONE_WIDTH"))
-        cw = std::atoi(e) == 64 ? 64 : kBlock;
+    } else {
+        // fused wavefront: one wavefront per cone on graphs without structure links (the chain / supply kernel needs it;
+        // k_fused_cones itself measured the same at 64 and 256: DESIGN.md section 8b), 256 with links
+        cw = g->has_links ? kBlock : 64;
+        if (const char *e = std::getenv("LF_FUSED_CONE_WIDTH")) cw = std::atoi(e) == 64 ? 64 : kBlock;
+    }
     lf_block_plan plan;
     try {
         // every cell below the last level drains into the next level, so the upstream ranges tile the level before:
@@ -1479,7 +1483,22 @@ int fused_impl(lf_router *r, const lf_substep_args *a, int nsteps, int64_t sidef
         else                                                                                                 \
             LF_CONES_CW(ST, kBlock);                                                                         \
     } while (0)
-                if (in)
+                // The chain / supply form (lf_fused.h: k_fused_cones_split) where it applies and where the launch is
+                // chain-bound: up to ~800 cones in flight (24 sub-steps x 2000 cells per level) it is 1.1 - 1.8 x faster,
+                // beyond that the launch is bound by throughput and by LDS space (62 KB per cone: two per CU) and the
+                // one-wavefront kernel wins.  LF_FUSED_SPLIT=0 / 1: never / always (A/B switch).
+                static const int64_t split_max = [] {
+                    const char *e = std::getenv("LF_FUSED_SPLIT_MAX");
+                    return e ? std::atoll(e) : (long long)800;
+                }();
+                const char *es = std::getenv("LF_FUSED_SPLIT");
+                const bool split_form = !in && all35 && !F.inert && !F.linked && r->fb_cw == 64 && n < ((int64_t)1 << 29) &&
+                                        (es ? es[0] != '0' : acc <= split_max);
+                if (split_form && a->split)
+                    hipLaunchKernelGGL((k_fused_cones_split<true>), grid, dim3(64 * (1 + kFusedKC)), 0, s, F);
+                else if (split_form)
+                    hipLaunchKernelGGL((k_fused_cones_split<false>), grid, dim3(64 * (1 + kFusedKC)), 0, s, F);
+                else if (in)
                     LF_CONES(true);
                 else
                     LF_CONES(false);

@@ -266,7 +266,7 @@ __global__ void __launch_bounds__(CW) k_sweep_cones(cone_plan_args C, sweep_args
             }
         }
     };
-    int first_up = 0, last_up = 0;
+    int first_up = 0;
     // the stores of a level are issued one level later, right behind the barrier (with the next loads): then everything
     // outstanding at the end of a level was issued before its arithmetic, and the wait there is short
     double pend_q[NR];
@@ -343,7 +343,7 @@ __global__ void __launch_bounds__(CW) k_sweep_cones(cone_plan_args C, sweep_args
         pend_p = p;
         pend_pix = cur.pix;
         first_up = first;
-        last_up = last;
+        (void)last;
     };
     auto bound = [&](const int *t, int k) { return k < nl ? ld_table(t, k) : 0; };
     cell r0, r1, r2;
