@@ -50,13 +50,72 @@ def lddmask(codes, land_mask, keep):
     return out[keep], sub
 
 
-def lddrepair(codes, land_mask):
+def _down_no_graph(codes, land_mask):
+    """downstream_index without building a graph (a graph refuses a cyclic LDD): -1 for pits, unknown codes and links
+    that leave the map or the mask"""
+    land_mask = np.asarray(land_mask, bool)
+    c = np.asarray(codes)
+    H, W = land_mask.shape
+    ids = np.full((H, W), -1, np.int64)
+    ids[land_mask] = np.arange(c.size)
+    rr, cc = np.nonzero(land_mask)
+    down = np.full(c.size, -1, np.int64)
+    for code in _ROW:
+        sel = c == code
+        r2, c2 = rr[sel] + _ROW[code], cc[sel] + _COL[code]
+        ok = (r2 >= 0) & (r2 < H) & (c2 >= 0) & (c2 < W)
+        t = np.full(int(sel.sum()), -1, np.int64)
+        t[ok] = ids[r2[ok], c2[ok]]
+        down[sel] = t
+    return down
+
+
+def break_cycles(codes, land_mask):
+    """-> (codes with every cycle of the LDD broken, number of cycles).  PCRaster's lddrepair makes a cyclic ldd sound by
+    turning a cell of the cycle into a pit; its manual does not say which one, so this is a CHOICE, not a restatement:
+    the cell of the cycle that comes first in row-major order (lowest pixel id) becomes the pit.  Every other cell keeps
+    its direction, so the trees hanging on the cycle and the rest of the cycle drain to the new pit.  Host, init-time:
+    pointer doubling finds the cells that lie on cycles (the image of the N-fold downstream map minus the pits)."""
+    c = np.asarray(codes).copy()
+    down = _down_no_graph(c, land_mask)
+    n = c.size
+    if n == 0:
+        return c, 0
+    p = np.where(down >= 0, down, np.arange(n))            # pits point at themselves
+    hop = p.copy()
+    reach = 1
+    while reach < n:                                       # hop = p^(2^k), 2^k >= n: every cell lands on a cycle or a pit
+        hop = hop[hop]
+        reach *= 2
+    on_cycle = np.zeros(n, bool)
+    on_cycle[np.unique(hop)] = True
+    on_cycle &= down >= 0                                  # (a pit is a fixed point, not a cycle)
+    cyc = np.nonzero(on_cycle)[0]
+    if cyc.size == 0:
+        return c, 0
+    lowest = np.arange(n)
+    while True:                                            # the lowest id along each cycle, passed round until it settles
+        nxt = np.minimum(lowest[cyc], lowest[p[cyc]])
+        if np.array_equal(nxt, lowest[cyc]):
+            break
+        lowest[cyc] = nxt
+    heads = cyc[lowest[cyc] == cyc]
+    c[heads] = PIT
+    return c, int(heads.size)
+
+
+def lddrepair(codes, land_mask, break_cycles_too=False):
     """PCRaster lddrepair: cells draining to a missing value or off the map become pits (routing.py:125).  A land pixel
     whose code is not a keypad code is a missing value of the ldd map: cells draining into it become pits, and -- a
     compressed vector has no missing values -- so does the pixel itself (the device form does the same).  PCRaster's
-    lddrepair also breaks cycles; here a cyclic LDD is an error when the graph is built (LF_E_CYCLE), never repaired."""
+    lddrepair also breaks cycles.  By default a cyclic LDD is NOT repaired here: building the graph on it raises
+    LF_E_CYCLE (the reference's own graph builder would hang on it, kinematic_wave_parallel.py:99, were it not for
+    PCRaster's repair) -- which cell of a cycle PCRaster turns into a pit is not documented, and a silent choice would
+    move an outlet.  break_cycles_too=True makes that choice explicit (break_cycles: the first cell in row-major order)."""
     c = np.asarray(codes).copy()
-    down = downstream_index(c, land_mask)
+    if break_cycles_too:
+        c, _ = break_cycles(c, land_mask)
+    down = _down_no_graph(c, land_mask) if break_cycles_too else downstream_index(c, land_mask)
     valid = np.isin(c, (1, 2, 3, 4, 6, 7, 8, 9))
     known = valid | (c == PIT)
     c[(down < 0) | ~valid | ~known[np.maximum(down, 0)]] = PIT
@@ -234,6 +293,11 @@ class LddDevice:
 
     def accuflux(self, x):
         return self.kw.accuflux(x)
+
+    def water_use_sum(self, withdrawal_m3, inv_dt_sec):
+        """self.var.WUseSumM3 of waterabstraction.py:533: accuflux(Ldd, withdrawal_CH_actual_M3 * InvDtSec), the channel
+        withdrawal of a model step accumulated downstream as a flow [m3/s] -- one device sweep on the LDD's block plan"""
+        return self.kw.accuflux(np.asarray(withdrawal_m3, np.float64) * inv_dt_sec)
 
     def close(self):
         self.kw.close()

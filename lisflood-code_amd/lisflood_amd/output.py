@@ -64,12 +64,30 @@ class TssWriter:
     """Collects one row per model step and writes the file at the end, like TimeoutputTimeseries.sample() /
     _writeTssFile (zusatz.py:246-290)."""
 
-    def __init__(self, path, ids, pixel_index, first_timestep=1, **header_kw):
+    def __init__(self, path, ids, pixel_index, first_timestep=1, how="", router=None, pixel_area=None, inv_up_area=None,
+                 **header_kw):
+        """`how`: the `operation` of the reference's time-series definitions (global_modules/output.py:568-575):
+        ""            the value at the gauge pixels;
+        "mapmaximum"  the maximum of the map at every gauge;
+        "total"       catchmenttotal(x * PixelArea, Ldd) * InvUpArea -- the area-weighted mean of x over everything
+                      upstream of the gauge.  PCRaster's catchmenttotal is the accumulation over all upstream cells incl.
+                      the cell: `router.accuflux` (a kinematicWave or anything with accuflux(x) over the same pixels; the
+                      device sweep of lf_accuflux), `pixel_area` and `inv_up_area` as self.var.PixelArea / InvUpArea."""
+        if how not in ("", "mapmaximum", "total"):
+            raise ValueError("unknown time-series operation %r" % (how,))
+        if how == "total" and (router is None or pixel_area is None or inv_up_area is None):
+            raise ValueError("how='total' needs router, pixel_area and inv_up_area")
         self.path, self.ids, self.pix, self.first = path, list(ids), np.asarray(pixel_index, np.int64), first_timestep
+        self.how, self.router, self.pixel_area, self.inv_up_area = how, router, pixel_area, inv_up_area
         self.rows, self.header_kw = [], header_kw
 
     def sample(self, vector):
-        self.rows.append(sample(vector, self.pix))
+        v = np.asarray(vector, dtype=np.float64)
+        if self.how == "mapmaximum":
+            v = np.full(v.shape, np.nanmax(v) if v.size else np.nan)
+        elif self.how == "total":
+            v = self.router.accuflux(v * self.pixel_area) * self.inv_up_area
+        self.rows.append(sample(v, self.pix))
 
     def close(self):
         write_tss(self.path, self.ids, self.first, np.array(self.rows).reshape(len(self.rows), len(self.ids)),

@@ -336,3 +336,38 @@ def test_static_upload_fingerprint_sees_every_element():
     b[1002] = 0
     assert fp(b) != f1
     assert fp(x.reshape(-1, 1)) != f0               # shape is part of it
+
+
+def test_tss_writer_operations_total_and_mapmaximum(tmp_path):
+    """the `operation` of the reference's time-series definitions (global_modules/output.py:568-575): 'total' samples
+    catchmenttotal(x * PixelArea, Ldd) * InvUpArea, 'mapmaximum' the map's maximum.  CPU: the accumulation is a plain
+    walk over a 7-pixel chain with one tributary (the device sweep is tied to it in tests/test_ldd_gpu.py)"""
+    from lisflood_amd import output as O
+    #   0 -> 1 -> 2 -> 3 (outlet), 4 -> 5 -> 2, 6 isolated
+    down = np.array([1, 2, 3, -1, 5, 2, -1])
+
+    class Walk:
+        @staticmethod
+        def accuflux(x):
+            out = np.array(x, dtype=np.float64)
+            for start in range(down.size):
+                p = down[start]
+                while p >= 0:
+                    out[p] += x[start]
+                    p = down[p]
+            return out
+    area = np.array([1.0, 2.0, 1.0, 4.0, 1.0, 1.0, 3.0])
+    up_area = Walk.accuflux(area)
+    x1, x2 = np.arange(7.0), np.array([5.0, 0, 0, 1, 2, 2, 9])
+    w = O.TssWriter(str(tmp_path / "t.tss"), [11, 12, 13], [3, 2, 6], how="total", router=Walk, pixel_area=area,
+                    inv_up_area=1 / up_area, date="D")
+    w.sample(x1); w.sample(x2); w.close()
+    vals = O.read_tss(str(tmp_path / "t.tss"))[3]
+    for row, x in zip(vals, (x1, x2)):
+        want = [(x * area).sum() - x[6] * area[6], (x * area)[[0, 1, 2, 4, 5]].sum(), x[6] * area[6]]
+        np.testing.assert_allclose(row, np.array(want) / up_area[[3, 2, 6]], rtol=5e-6)      # (%14g keeps 6 digits)
+    m = O.TssWriter(str(tmp_path / "m.tss"), [1, 2], [0, 4], how="mapmaximum", date="D")
+    m.sample(x2); m.close()
+    assert (O.read_tss(str(tmp_path / "m.tss"))[3] == 9.0).all()
+    with pytest.raises(ValueError):
+        O.TssWriter(str(tmp_path / "e.tss"), [1], [0], how="total")

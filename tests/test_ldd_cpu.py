@@ -1,6 +1,7 @@
 """LDD operations restated from PCRaster's documented semantics (lisflood_amd/ldd.py), checked against brute
 force walks on small catchments.  CPU only (host-side, init-time code)."""
 import numpy as np
+import pytest
 
 from lisflood_amd import ldd as L
 from lisflood_amd import synthetic as syn
@@ -107,3 +108,37 @@ def test_host_catchment_reproduces_the_pcraster_masks_of_the_use_case():
         assert outlet.size == 1
         pts = np.zeros(codes.size, np.int64); pts[outlet[0]] = 1
         assert np.array_equal(L.catchment(codes, land, pts) == 1, m), key
+
+
+def test_cyclic_ldd_is_an_error_by_default_and_can_be_broken_explicitly():
+    """routing.py:125 relies on PCRaster's lddrepair to make a cyclic ldd sound.  Here: the graph builder refuses the
+    cycle with LF_E_CYCLE and a message that names the repair (the documented deviation); ldd.break_cycles /
+    lddrepair(..., break_cycles_too=True) turn the FIRST cell of every cycle in row-major order into a pit, after which
+    the graph builds, every other cell keeps its direction and all of them drain to the new pit"""
+    from lisflood_amd import _lib
+    from lisflood_amd import ldd as L
+    from lisflood_amd.kinematic_wave_parallel import Graph
+    # 4 x 5 raster: a 4-cycle (cells 6 -> 7 -> 12 -> 11 -> 6), a 2-cycle (3 <-> 4), two trees hanging on the 4-cycle,
+    # the rest draining to the pit in the lower right corner
+    codes = np.array([[6, 2, 4, 6, 4],
+                      [6, 6, 2, 2, 2],
+                      [6, 8, 4, 6, 2],
+                      [6, 6, 6, 6, 5]], np.float64)
+    mask = np.ones(codes.shape, bool)
+    flat = codes.reshape(-1)
+    with pytest.raises(_lib.LisfloodAmdError) as e:
+        Graph(flat, mask)
+    assert e.value.code == _lib.LF_E_CYCLE
+    fixed, ncycles = L.break_cycles(flat, mask)
+    assert ncycles == 2
+    assert np.array_equal(np.nonzero(fixed != flat)[0], [3, 6]) and (fixed[[3, 6]] == L.PIT).all()
+    np.testing.assert_array_equal(L.lddrepair(flat, mask, break_cycles_too=True), fixed)
+    g = Graph(fixed, mask)
+    roots_of = L.catchment(fixed, mask, L.pit(fixed))
+    pits = L.pit(fixed)
+    assert roots_of[4] == pits[3] and roots_of[3] == pits[3]                          # the 2-cycle drains to cell 3
+    for cell in (0, 1, 5, 6, 7, 10, 11, 12):                                          # the 4-cycle and its trees: to cell 6
+        assert roots_of[cell] == pits[6], cell
+    assert roots_of[15] == pits[19] and roots_of[2] == pits[6]
+    g.close()
+    assert L.break_cycles(fixed, mask)[1] == 0                                        # sound now: nothing to break

@@ -235,3 +235,45 @@ def test_initlisflood_prerun_reproduces_the_reference(amd):
             np.testing.assert_allclose(getattr(v, k), g["out_" + k][step], rtol=1e-9, atol=1e-12, err_msg=(step, k))
         for k in ("ChanM3Kin", "ChanM3"):
             np.testing.assert_allclose(getattr(v, k), g["out_" + k][step], rtol=1e-8, atol=1e-9, err_msg=(step, k))
+
+
+def test_total_time_series_and_water_use_sum_on_the_device_sweep(amd, tmp_path):
+    """the two per-step consumers of accuflux the reference has outside routing: the 'total' time-series operation
+    (global_modules/output.py:573: catchmenttotal(x * PixelArea, Ldd) * InvUpArea at the gauges) and WUseSumM3
+    (waterabstraction.py:533: accuflux(Ldd, withdrawal * InvDtSec)), both on LddDevice's sweep, against a host
+    accumulation in downstream order"""
+    from lisflood_amd import ldd as L
+    from lisflood_amd import output as O
+    from lisflood_amd import synthetic as syn
+    H, W = 120, 90
+    mask = np.random.default_rng(2).random((H, W)) > 0.15
+    codes = syn.make_ldd("river", H, W, 5, land_mask=mask)[mask].astype(np.float64)
+    N = codes.size
+    down = L.downstream_index(codes, mask)
+    d = L.LddDevice(codes, mask)
+
+    def host_accuflux(x):          # upstream cells first: process in order of decreasing distance to the outlet
+        from lisflood_amd.kinematic_wave_parallel import Graph
+        po, ss = Graph(codes, mask).orders()
+        out = np.array(x, dtype=np.float64)
+        for k in range(ss.shape[0]):
+            for p in po[ss[k, 0]:ss[k, 1]]:
+                if down[p] >= 0:
+                    out[down[p]] += out[p]
+        return out
+    rng = np.random.default_rng(3)
+    area = rng.uniform(2e7, 3e7, N)
+    inv_up = 1.0 / host_accuflux(area)
+    gauges = rng.choice(N, 12, replace=False)
+    w = O.TssWriter(str(tmp_path / "tot.tss"), list(range(1, 13)), gauges, how="total", router=d, pixel_area=area,
+                    inv_up_area=inv_up, date="D")
+    xs = [rng.uniform(0, 5, N) for _ in range(3)]
+    for x in xs:
+        w.sample(x)
+    w.close()
+    vals = O.read_tss(str(tmp_path / "tot.tss"))[3]
+    for row, x in zip(vals, xs):
+        np.testing.assert_allclose(row, (host_accuflux(x * area) * inv_up)[gauges], rtol=5e-6)   # (%14g keeps 6 digits)
+    withdrawal = rng.uniform(0, 1e4, N)
+    np.testing.assert_allclose(d.water_use_sum(withdrawal, 1 / 86400.0), host_accuflux(withdrawal / 86400.0), rtol=1e-12)
+    d.close()
