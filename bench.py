@@ -197,7 +197,7 @@ def roofline_of(res, kernel_key=None, workload=None):
     prof = res["prof"]
     wide, narrow = prof["wide_level"], prof["narrow_run"]
     dom = wide if wide["ms"] >= narrow["ms"] else narrow
-    name = "k_level" if dom is wide else "k_sweep_cones / k_levels_narrow (runs of narrow levels)"
+    name = "k_level" if dom is wide else "k_sweep_cones_split / k_sweep_cones (blocks of narrow levels, cone by cone)"
     if dom["launches"] == 0 or dom["ms"] == 0:
         return None
     cells_per_launch = dom["cells"] / dom["launches"]
@@ -326,6 +326,19 @@ def soil_bench(N=4_000_000, steps=10):
         out[regime] = dict(value=round(cols / ms / 1e3, 2), unit="Mcolumn-steps/s", ms_per_step=round(ms, 4),
                            achieved_GBs=round(gbs, 1), frac_hbm=round(gbs / HBM_PEAK_GBS, 4),
                            multi_substep_columns_frac=round(nd.value / cols, 4))
+        # committed counter passes of this very command (tools/pmc_soil_r04.sh): HBM bytes per call of the regime's kernels
+        tr = {}
+        for key, sub in (("pass1", "k_soil_columns<true, true>" if regime == "wet" else "k_soil_columns<true, false>"),
+                         ("pass2", "k_soil_columns_deferred")):
+            if key == "pass2" and regime != "wet":
+                continue
+            t3, s3, counters = pmc_traffic_r03("soil_%d" % N, sub)
+            if t3 is not None:
+                tr[key] = dict(kernel=sub, traffic=round(t3, 1), traffic_unit="bytes per launch", traffic_source=s3,
+                               bytes_per_column=round(t3 / cols, 1), pmc_per_wavefront=counters)
+        if tr:
+            out[regime]["traffic"] = tr
+            out[regime]["traffic_bytes_per_column_step"] = round(sum(v["traffic"] for v in tr.values()) / cols, 1)
         for a in dev.dev.values():
             a.free()
     out.update(metric="soil Mcolumn-steps/s", columns=3 * N, alg_bytes_per_column_step=504)
@@ -596,12 +609,19 @@ def main():
                                 roofline=roofline_of(r_, workload=wl))
                 kw2, p2, g2 = build_case(other, H, W)
                 entry.update(leg(kw2, p2, "route_%s_%d" % (other, H)), levels=g2.num_levels, level_sizes=level_sizes(g2))
-                if g2.num_levels > 64:      # deep networks: A/B against one launch per level (same router)
+                if g2.num_levels > 64:      # deep networks: A/B against one launch per level (same router) ...
                     os.environ["LF_ROUTE_CONES"] = "0"
                     try:
                         entry["level_sweep"] = leg(kw2, p2)
                     finally:
                         del os.environ["LF_ROUTE_CONES"]
+                    # ... and against the round-3 cone kernel (one wavefront per cone does everything; same solver)
+                    os.environ["LF_ROUTE_SPLIT"] = "0"
+                    try:
+                        entry["one_wavefront_per_cone"] = leg(kw2, p2)
+                    finally:
+                        del os.environ["LF_ROUTE_SPLIT"]
+                    entry["cone_plan"] = kw2.route_plan_stats()
                 kw2.close()
                 extra[other] = entry
             except Exception as e:  # secondary numbers must never break the headline line

@@ -490,6 +490,8 @@ int64_t lf_dist_graph_round_recv_slot(const lf_dist_graph *g, int round, int sid
 int lf_comm_unique_id(char id[128]);                 /* rank 0; broadcast the 128 bytes to the other ranks */
 int lf_comm_create(const char id[128], int nranks, int rank, int device, lf_comm **out);
 void lf_comm_destroy(lf_comm *c);
+/* the same, returning what the communicator's teardown reports (an asynchronous error of an earlier Send / Recv) */
+int lf_comm_close(lf_comm *c);
 
 /* alpha / dx / alpha_floodplains: per LOCAL pixel (row-major over the rank's own rows) */
 int lf_dist_router_create(const lf_dist_graph *g, const double *alpha, double beta, const double *dx,

@@ -749,6 +749,19 @@ void lf_comm_destroy(lf_comm *c)
     delete c;
 }
 
+// lf_comm_destroy that reports what the communicator's teardown returns: an operation that failed on the device after the
+// last call that could have reported it (RCCL: an asynchronous error) surfaces here instead of being dropped
+int lf_comm_close(lf_comm *c)
+{
+    if (!c) return LF_OK;
+    int e = 0;
+    if (c->comm && g_rccl.CommDestroy) e = g_rccl.CommDestroy(c->comm);
+    delete c;
+    if (e != 0)
+        return lf_set_error(LF_E_COMM, "ncclCommDestroy: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "error");
+    return LF_OK;
+}
+
 } // extern "C"
 
 // ------------------------------------------------------------------------------------------------

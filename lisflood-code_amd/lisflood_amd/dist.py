@@ -524,9 +524,10 @@ class Comm:
         check(lib().lf_comm_create(C.c_char_p(uid), C.c_int(nranks), C.c_int(rank), C.c_int(device), C.byref(self._h)))
 
     def close(self):
+        """tears the communicator down; raises if RCCL reports an error of an earlier (asynchronous) operation"""
         if self._h:
-            lib().lf_comm_destroy(self._h)
-            self._h = C.c_void_p()
+            h, self._h = self._h, C.c_void_p()
+            check(lib().lf_comm_close(h))
 
 
 class DistRouter:

@@ -27,6 +27,13 @@ def main():
     Q = router.new_state(p["Q0"][sel])
     rounds = list(range(g.num_phases - 1))
     assert len(rounds) >= 2, "the test needs a partition with several halo rounds"
+    # the premise of the test: the rounds' message sizes are not the same read backwards (RCCL -- and the stand-in --
+    # match messages of a pair by order and check only their size; a swap of equal-sized rounds moves data into the wrong
+    # ghost slots without either noticing, which is why the product's order must be right by construction)
+    sizes = [tuple(n for _, n in router.pack(Q, j)) for j in rounds]
+    _lib.synchronize(0)
+    asym = T.allgather(sizes != sizes[::-1])
+    assert any(asym), "halo rounds of equal sizes on every rank: pick another raster"
     if os.environ.get("LF_TEST_REVERSED_RANK", "") == str(rank):
         rounds.reverse()
     ok = True

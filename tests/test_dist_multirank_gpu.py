@@ -104,13 +104,18 @@ def test_a_misordered_rank_is_caught(fake_rccl):
     rank 1 in REVERSE round order.  The stand-in's issue log must show the mismatch (and the run itself must not pass: the
     byte counts of the rounds differ, or a receive waits for a send that comes later)"""
     (outs, log_dir, rcs) = run_ranks(fake_rccl, 3, "tests/dist_worker_order.py",
-                                     {"LF_TEST_FAMILY": "saddle", "LF_TEST_REVERSED_RANK": "1", "FAKE_RCCL_TIMEOUT_S": "5"},
+                                     {"LF_TEST_FAMILY": "shallow", "LF_TEST_REVERSED_RANK": "1", "FAKE_RCCL_TIMEOUT_S": "5"},
                                      timeout=300, expect_failure=True)
-    with pytest.raises(AssertionError):
+    diag = "\n".join("--- rank %d rc=%s\n%s\n%s" % (r, rcs[r], o[-800:], e[-1500:]) for r, (o, e) in enumerate(outs))
+    try:      # rank 1's neighbours see its sizes in the wrong order (the middle rank talks to both)
         check_issue_order(log_dir, 3)
-    assert any(rc != 0 for rc in rcs) or not any("ORDER_WORKER_OK" in o for o, _ in outs)
+    except AssertionError:
+        pass
+    else:
+        pytest.fail("the reversed rank went unnoticed\n" + diag)
+    assert any(rc != 0 for rc in rcs) or not all("ORDER_WORKER_OK" in o for o, _ in outs), [o for o, _ in outs]
     # ... and the same worker with every rank in round order is clean
-    outs = run_ranks(fake_rccl, 3, "tests/dist_worker_order.py", {"LF_TEST_FAMILY": "saddle"}, timeout=300)
+    outs = run_ranks(fake_rccl, 3, "tests/dist_worker_order.py", {"LF_TEST_FAMILY": "shallow"}, timeout=300)
     assert all("ORDER_WORKER_OK" in o for o, _ in outs)
 
 

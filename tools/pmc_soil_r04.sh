@@ -1,0 +1,40 @@
+#!/bin/bash
+# Round-4 counter passes of the soil kernels (runs on the GPU box via gpurun): three SEPARATE rocprofv3 --pmc passes
+# (FETCH_SIZE | WRITE_SIZE | SQ + GRBM) of `bench.py --only soil --steps 2` (both regimes: wet -> k_soil_columns<.., true>
+# + k_soil_columns_deferred, single sub-step -> k_soil_columns<.., false>), condensed per kernel into
+# gpurun_out/pmc_r04_soil_4000000.txt in the format of tools/pmc_r03.sh (tools/pmc_digest_r03.py reads it).
+set -u
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+SQ="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE"
+name=soil_4000000
+for pass in FETCH_SIZE WRITE_SIZE SQ; do
+  C=$pass; [ $pass = SQ ] && C=$SQ
+  rm -rf /tmp/pmc_${name}_$pass
+  timeout 600 rocprofv3 --pmc $C --output-format csv -d /tmp/pmc_${name}_$pass -o pmc -- \
+      python $ROOT/bench.py --only soil > /tmp/pmc_${name}_$pass.log 2>&1
+  echo "$name $pass rc=$?"
+done
+python - "$name" > $OUT/pmc_r04_${name}.txt <<'PY'
+import csv, glob, collections, re, sys
+name = sys.argv[1]
+agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
+for p in ("FETCH_SIZE", "WRITE_SIZE", "SQ"):
+    for f in glob.glob("/tmp/pmc_%s_%s/**/*counter_collection.csv" % (name, p), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
+            k = re.sub(r"\(.*", "", k)
+            a = agg[k][r["Counter_Name"]]
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+print("# %s: per-kernel counter totals over `bench.py --only soil` (12 calls per regime; rocprofv3 --pmc, separate passes); FETCH/WRITE in KiB as reported" % name)
+for k, c in sorted(agg.items()):
+    n = max(v[0] for v in c.values())
+    line = ["%-44s launches=%d" % (k, n)]
+    for cn, v in sorted(c.items()):
+        line.append("%s=%.6g" % (cn, v[1]))
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        line.append("hbm_bytes_per_launch(read x2 + write)=%.6g" % ((2 * c["FETCH_SIZE"][1] + c["WRITE_SIZE"][1]) * 1024 / n))
+    print("  ".join(line))
+PY
+cat $OUT/pmc_r04_${name}.txt
