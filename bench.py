@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads / soil kernel")
     ap.add_argument("--cpu-sample", type=int, default=2000, help="CPU baseline raster is sample x sample")
-    ap.add_argument("--only", choices=["soil", "model_step", "hotpath", "structures"], default=None, help="run only the named secondary benchmark")
+    ap.add_argument("--only", choices=["soil", "model_step", "hotpath", "structures", "overland"], default=None, help="run only the named secondary benchmark")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the row-block/RCCL path even with a single rank (smoke test of that path)")
     ap.add_argument("--calibrate", action="store_true",
@@ -487,6 +487,59 @@ def structures_step_bench(size=3000, nsteps=24):
     return out
 
 
+def overland_bench(size=4000, channel_frac=0.04, steps=6):
+    """The three overland routers (surface_routing.py:104-113, 151-153) on a domain where overland flow routes: a `deep`
+    land LDD with `channel_frac` channel pixels, LddToChan cut at the channels -- a graph hundreds of levels deep and
+    millions of cells wide --, the routers swept together in engine order (three routers per cone / per wide level)."""
+    from lisflood_amd import _lib
+    from lisflood_amd import synthetic as syn
+    from lisflood_amd.kinematic_wave_parallel import Graph, kinematicWave
+    H = W = size
+    N = H * W
+    rng = np.random.default_rng(43)
+    codes = syn.make_ldd("deep", H, W, SEEDS["deep"])
+    is_chan = rng.random((H, W)) < channel_frac
+    raster = np.where(is_chan, np.uint8(5), codes)        # ifthenelse(IsChannel, 5, Ldd): channel pixels are pits
+    g = Graph(ldd_raster=raster)
+    p = syn.router_params(N, seed=12)
+    kws = [kinematicWave(None, None, p["alpha"] * f, p["beta"], 5000.0, 86400.0, graph=g) for f in (1.0, 2.5, 0.4)]
+    tmp = _lib.DeviceArray(N)
+    qs, lats = [], []
+    for i, kw in enumerate(kws):
+        for host, dst in ((np.minimum(p["Q0"], 50.0) * rng.uniform(0, 1, N), qs), (syn.lateral_inflow(N, i, hi=2e-5), lats)):
+            d = _lib.DeviceArray.from_host(host)
+            kw.to_engine_order(d, tmp)
+            d.copy_from(tmp)
+            dst.append(d)
+    out = {}
+    for mode in ("together", "one_wavefront_per_cone", "one_by_one"):
+        if mode == "one_wavefront_per_cone":
+            os.environ["LF_ROUTE_SPLIT"] = "0"
+        run = (lambda: kinematicWave.route_together(kws, qs, lats, engine_order=True)) if mode != "one_by_one" else (
+            lambda: [kw.route_ordered(q, x) for kw, q, x in zip(kws, qs, lats)])
+        run()
+        _lib.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            run()
+        _lib.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3 / steps
+        os.environ.pop("LF_ROUTE_SPLIT", None)
+        out[mode] = dict(ms_per_overland_step=round(ms, 3), value=round(3 * N / ms / 1e3, 2), unit="Mcell-steps/s",
+                         launches=kws[0].last_launches()["launches"],
+                         frac_hbm_whole_step=round(3 * B_ALG * N / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+    out["finite"] = bool(all(np.isfinite(q.download()).all() for q in qs))
+    out["config"] = ("%dx%d deep land LDD, %.0f %% channel pixels (pits of LddToChan): NL=%d, K=%d; three routers (other / "
+                     "forest / direct) on one graph, engine order, one call each per overland step"
+                     % (H, W, 100 * channel_frac, g.num_levels, g.max_upstream if hasattr(g, "max_upstream") else -1))
+    out["cone_plan"] = kws[0].route_plan_stats()
+    for d in qs + lats + [tmp]:
+        d.free()
+    for kw in kws:
+        kw.close()
+    return out
+
+
 def hotpath_bench(size=2000, steps=6):
     """The whole device-resident hot path of a model step (canopy -> soil -> per-pixel aggregates -> 3 overland
     routers -> 24 split-routing channel sub-steps), lisflood_amd.hotpath.HotPathDevice; only the five forcing
@@ -531,6 +584,9 @@ def main():
         return
     if a.only == "structures":
         print(json.dumps(structures_step_bench()))
+        return
+    if a.only == "overland":
+        print(json.dumps(overland_bench()), flush=True)
         return
     if a.only == "hotpath":
         print(json.dumps(hotpath_bench(min(a.size, 2000))), flush=True)
@@ -638,6 +694,10 @@ def main():
             extra["model_step_with_structures"] = structures_step_bench()
         except Exception as e:
             extra["structures_error"] = repr(e)
+        try:
+            extra["overland_sparse_channels"] = overland_bench()
+        except Exception as e:
+            extra["overland_sparse_channels_error"] = repr(e)
         try:
             extra["resident_hot_path_step"] = hotpath_bench()
         except Exception as e:

@@ -1214,6 +1214,52 @@ def test_routers_on_one_graph_swept_together(amd, solver, family):
         kw.close()
 
 
+def test_overland_routers_where_they_route_sparse_channels(amd, oracle, solver):
+    """surface_routing.py:104-113,151-153 on a domain where overland flow actually travels: 4 % of the pixels of a `deep`
+    land LDD are channel pixels, LddToChan = lddrepair(ifthenelse(IsChannel, 5, Ldd)) -- a graph hundreds of levels deep
+    instead of LF_ETRS89's all-pits one.  The three overland routers (direct / other / forest: own alpha, own discharge
+    and inflow) are swept TOGETHER (lf_router_route_device_multi, three routers per cone) and compared with the oracle's
+    three separate routers over three calls."""
+    from lisflood_amd import ldd as L
+    from lisflood_amd import synthetic as syn
+    from lisflood_amd._lib import DeviceArray
+    from lisflood_amd.kinematic_wave_parallel import Graph, kinematicWave
+    H, W = 260, 200
+    N = H * W
+    mask = np.ones((H, W), bool)
+    rng = np.random.default_rng(41)
+    codes = syn.make_ldd("deep", H, W, 8)[mask].astype(np.float64)
+    is_chan = rng.random(N) < 0.04
+    ldd_to_chan = L.lddrepair(np.where(is_chan, float(L.PIT), codes), mask)
+    g = Graph(ldd_to_chan, mask)
+    assert g.num_levels > 40                                   # overland paths of dozens of cells, not all-pits
+    p = syn.router_params(N, seed=12)
+    alphas = [p["alpha"] * f for f in (1.0, 2.5, 0.4)]         # other / forest / direct differ in Manning's n only
+    dt = 86400.0
+    kws = [kinematicWave(None, None, a, p["beta"], 5000.0, dt, graph=g) for a in alphas]
+    cpu = [oracle.kinematicWave(ldd_to_chan, mask, a, p["beta"], 5000.0, dt) for a in alphas]
+    Q0 = [np.minimum(p["Q0"], 50.0) * rng.uniform(0.0, 1.0, N) for _ in kws]
+    qd = [DeviceArray.from_host(q) for q in Q0]
+    qc = [q.copy() for q in Q0]
+    for s in range(3):
+        lats = [syn.lateral_inflow(N, s, hi=2e-5) * f for f in (1.0, 2.0, 0.5)]
+        ld = [DeviceArray.from_host(x) for x in lats]
+        kinematicWave.route_together(kws, qd, ld)
+        for c, q, x in zip(cpu, qc, lats):
+            c.kinematicWaveRouting(q, x)
+        for x in ld:
+            x.free()
+    for i in range(3):
+        got = qd[i].download()
+        np.testing.assert_allclose(got, qc[i], rtol=RTOL, atol=ATOL, err_msg="router %d" % i)
+        assert (got[is_chan] >= 0).all()
+    assert kws[0].last_launches()["launches"] < g.num_levels   # blocks of levels, three routers per launch
+    for d in qd:
+        d.free()
+    for kw in kws:
+        kw.close()
+
+
 @pytest.mark.parametrize("family,nparts", [("deep", 3), ("river", 2)])      # (this river raster has two catchments)
 def test_catchment_partition_model_step_fused(amd, family, nparts):
     """configs[4]'s workload shape on a partition: every part runs the FUSED wavefront (24 split-routing sub-steps, level

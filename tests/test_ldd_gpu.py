@@ -159,7 +159,8 @@ def test_catchments_large_deep_raster(amd):
     d.close()
 
 
-def test_channel_initialisation_reproduces_the_reference_on_cold_xml_inputs(amd):
+@pytest.mark.parametrize("engine_order", [True, False])
+def test_channel_initialisation_reproduces_the_reference_on_cold_xml_inputs(amd, engine_order):
     """routing.initial -> lakes.initial -> reservoir.initial -> structures.initial -> routing.initialSecond on the real
     inputs of settings/cold.xml (model domain mask.map, 5 lakes, 31 reservoirs, avgdis of the use case's pre-run),
     against tests/golden/etrs89_initial.npz -- produced by the reference's OWN methods in that order (PCRaster emulated:
@@ -177,7 +178,7 @@ def test_channel_initialisation_reproduces_the_reference_on_cold_xml_inputs(amd)
                   TabMinOutflowQ=tab["rminq"])
     opts = dict(InitLisflood=False, SplitRouting=True, simulateLakes=True, simulateReservoirs=True, repMBTs=True)
     v = types.SimpleNamespace(DtSec=float(g["DtSec"]), DtSecChannel=float(g["DtSecChannel"]))
-    m = amd.routing.routing(v, options=opts)
+    m = amd.routing.routing(v, options=opts, engine_order=engine_order)
     m.initial(maps, mask)
     ST.lakes(v, opts, maps, tables).initial(mask)
     ST.reservoir(v, opts, maps, tables).initial()
@@ -195,9 +196,22 @@ def test_channel_initialisation_reproduces_the_reference_on_cold_xml_inputs(amd)
                                    rtol=1e-14, atol=0, err_msg=k)          # host arithmetic in the same order: to the bit
     for k in ("UpArea", "StorageStepINIT", "DischargeM3StructuresIni", "InvCatchArea"):   # tree totals: summation order
         np.testing.assert_allclose(getattr(v, k), g["out_" + k], rtol=1e-12, err_msg=k)
-    # the router initialSecond built sweeps the cut LDD exactly like the reference's
-    assert np.array_equal(m.river_router.pixels_ordered, g["router_pixels_ordered"])
-    assert np.array_equal(m.river_router.order_start_stop, g["router_order_start_stop"])
+    if not engine_order:
+        # the router initialSecond built sweeps the cut LDD exactly like the reference's
+        assert np.array_equal(m.river_router.pixels_ordered, g["router_pixels_ordered"])
+        assert np.array_equal(m.river_router.order_start_stop, g["router_order_start_stop"])
+    else:
+        # engine order (the default) with structures: the graph also holds the structures' uncut links as zero-length
+        # links, which puts the cells draining into a lake or reservoir on the structure's own level -- the same pixels,
+        # still every cell after all of its upstream cells, but not the reference's level table
+        po, ss = m.river_router.pixels_ordered, m.river_router.order_start_stop
+        assert np.array_equal(np.sort(po), np.sort(g["router_pixels_ordered"]))
+        level_of = np.empty(po.size, np.int64)
+        for k, (a, b) in enumerate(ss):
+            level_of[po[a:b]] = k
+        down = np.asarray(m.river_router.downstream_lookup).astype(np.int64)
+        has = down >= 0
+        assert (level_of[down[has]] > level_of[np.nonzero(has)[0]]).all()
 
 
 def test_initlisflood_prerun_reproduces_the_reference(amd):
