@@ -202,6 +202,7 @@ struct lf_router {
     int kmax = 8;
     bool fused = false; // beta == 3/5: prep fused into the sweep, polynomial closure solve (lf_math.h)
     lf_dbuf<int32_t> perm, ups_ptr;
+
     lf_dbuf<long long> level_start;
     lf_dbuf<double> a1, a2, dx, constant, qord, io_q, io_lat, tmp_ord, fused_qr1, fused_qr2;
     lf_dbuf<unsigned long long> counter;

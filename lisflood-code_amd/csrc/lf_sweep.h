@@ -108,9 +108,8 @@ struct sweep_args {
 //     contiguous positions themselves (row-block partitions: upstream cells may sit in other phases or in the
 //     ghost slots filled by the halo exchange).
 template <bool FUSED, bool ORDERED, bool INDEXED = false>
-__device__ __forceinline__ void sweep_cell(int p, const sweep_args &A)
+__device__ __forceinline__ void sweep_cell_range(int p, int u0, int u1, const sweep_args &A)
 {
-    const int u0 = A.ups_ptr[p], u1 = A.ups_ptr[p + 1];
     const int pix = ORDERED ? p : A.perm[p];
     const double ap = A.a[p];
     double cst;
@@ -145,6 +144,11 @@ __device__ __forceinline__ void sweep_cell(int p, const sweep_args &A)
     }
     A.qord[p] = q;
     if (!ORDERED) A.q_pix[pix] = q;
+}
+template <bool FUSED, bool ORDERED, bool INDEXED = false>
+__device__ __forceinline__ void sweep_cell(int p, const sweep_args &A)
+{
+    sweep_cell_range<FUSED, ORDERED, INDEXED>(p, A.ups_ptr[p], A.ups_ptr[p + 1], A);
 }
 
 // Read of a table that no kernel of this library ever writes (the cone plans of the level blocks) through the
