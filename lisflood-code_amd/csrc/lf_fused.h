@@ -806,7 +806,7 @@ __global__ void __launch_bounds__(CW) __attribute__((amdgpu_waves_per_eu(LF_CONE
 // So, as in k_sweep_cones_split (lf_sweep.h), per cone of at most 64 cells per level:
 //   * the CHAIN wavefront runs the two routers of the cell (main channel, floodplains) from LDS records: gather the level
 //     above, add, solve, put the router outputs back into LDS -- nothing else (cone_chain<true, NR = 2>);
-//   * KC = 4 SUPPLY wavefronts, one per level of a chunk, work two chunks ahead and two chunks behind it:
+//   * KC = 2 SUPPLY wavefronts, one per level of a chunk, work two chunks ahead and two chunks behind it:
 //       phase ph:   request the state of chunk ph + 1                          (pre-loads)
 //                   request what the fix-ups of chunk ph - 1 need again          (post-loads: 7 streams, L2 hits mostly)
 //                   fix-ups and stores of chunk ph - 2 from its router outputs  (routing.py:526-532, 573-603)
@@ -817,12 +817,12 @@ __global__ void __launch_bounds__(CW) __attribute__((amdgpu_waves_per_eu(LF_CONE
 // Arithmetic per cell = fused_cell's, operation by operation (cone_compute's beta = 3/5 forms): bit-identical.
 // For: beta = 3/5 router and fix-ups, no structures, no zero-length links, no inert-pixel test (a compact channel domain
 // has none), the single-domain plan with cones of <= 64 cells; every other case keeps k_fused_cones.
-constexpr int kFusedKC = 4;
+constexpr int kFusedKC = 2; // (chunks of 2 levels: 31 KB of LDS and three wavefronts per cone; 4: 62 KB and five -- slower at every size measured)
 
-template <bool SPLIT>
-__global__ void __launch_bounds__(64 * (1 + kFusedKC)) k_fused_cones_split(fused_args F)
+template <bool SPLIT, int KC = kFusedKC>
+__global__ void __launch_bounds__(64 * (1 + KC)) k_fused_cones_split(fused_args F)
 {
-    constexpr int NR = SPLIT ? 2 : 1, KC = kFusedKC;
+    constexpr int NR = SPLIT ? 2 : 1;
     __shared__ cone_lds<NR, KC> S;
     __shared__ double s1buf[3][KC][64]; // Sideflow1Chan of a cell from its constant terms to its stores (two chunks later)
     int s, blk;

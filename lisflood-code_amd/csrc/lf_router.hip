@@ -602,6 +602,14 @@ int route_device(lf_router *r, double *q_dev, const double *lat_dev, int section
 static int build_level_blocks(lf_router *r, const lf_graph *g, bool for_route)
 {
     int lmax = for_route ? 256 : 16; // LF_ROUTE_LEVELS / LF_FUSED_LEVELS (measured: §4.1c / §4.3b of DESIGN.md)
+    if (!for_route && !g->has_links) {
+        // graphs whose launches all stay chain-bound (the chain / supply cone kernel, k_fused_cones_split, runs them): blocks
+        // of 32 levels halve the pipeline fill of that kernel (deep 2000^2: 8.5 -> 7.7 ms per model step); k_fused_cones,
+        // which takes the launches of wider graphs, is slower on them (44 vs 31 ms at 5000^2) and keeps 16
+        int64_t widest = 0;
+        for (int64_t k = 0; k < g->NL; ++k) widest = std::max(widest, g->level_start[k + 1] - g->level_start[k]);
+        if (widest <= 3000) lmax = 32;
+    }
     if (const char *e = std::getenv(for_route ? "LF_ROUTE_LEVELS" : "LF_FUSED_LEVELS")) lmax = std::atoi(e);
     lmax = lmax < 1 ? 1 : (lmax > (for_route ? 512 : 64) ? (for_route ? 512 : 64) : lmax);
     int64_t wide = 262144;
@@ -1485,12 +1493,12 @@ int fused_impl(lf_router *r, const lf_substep_args *a, int nsteps, int64_t sidef
             LF_CONES_CW(ST, kBlock);                                                                         \
     } while (0)
                 // The chain / supply form (lf_fused.h: k_fused_cones_split) where it applies and where the launch is
-                // chain-bound: up to ~800 cones in flight (24 sub-steps x 2000 cells per level) it is 1.1 - 1.8 x faster,
-                // beyond that the launch is bound by throughput and by LDS space (62 KB per cone: two per CU) and the
+                // chain-bound: up to ~1600 cones in flight (24 sub-steps x 4000 cells per level) it is 1.1 - 1.8 x faster,
+                // beyond that the launch is bound by throughput (three wavefronts and 31 KB of LDS per cone) and the
                 // one-wavefront kernel wins.  LF_FUSED_SPLIT=0 / 1: never / always (A/B switch).
                 static const int64_t split_max = [] {
                     const char *e = std::getenv("LF_FUSED_SPLIT_MAX");
-                    return e ? std::atoll(e) : (long long)800;
+                    return e ? std::atoll(e) : (long long)1600;
                 }();
                 const char *es = std::getenv("LF_FUSED_SPLIT");
                 const bool split_form = !in && all35 && !F.inert && !F.linked && r->fb_cw == 64 && n < ((int64_t)1 << 29) &&
