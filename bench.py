@@ -31,8 +31,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=10000, help="raster is size x size cells")
     ap.add_argument("--family", default="shallow", choices=["shallow", "deep", "river"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -308,7 +308,10 @@ def soil_bench(N=4_000_000, steps=10):
     from lisflood_amd import synthetic as syn
     from lisflood_amd.soilloop import SoilColumnsDevice
     out = {}
+    only = os.environ.get("LF_BENCH_SOIL_REGIME")          # (tools/pmc_soil_r04.sh: one regime per counter pass)
     for regime in ("wet", "single_substep"):
+        if only and regime != only:
+            continue
         d = syn.soil_params(N, seed=3)
         if regime == "single_substep":
             for k in ("KSat1a", "KSat1b", "KSat2"):
@@ -334,7 +337,7 @@ def soil_bench(N=4_000_000, steps=10):
                          ("pass2", "k_soil_columns_deferred")):
             if key == "pass2" and regime != "wet":
                 continue
-            t3, s3, counters = pmc_traffic_r03("soil_%d" % N, sub)
+            t3, s3, counters = pmc_traffic_r03("soil_%s_%d" % (regime, N), sub)
             if t3 is not None:
                 tr[key] = dict(kernel=sub, traffic=round(t3, 1), traffic_unit="bytes per launch", traffic_source=s3,
                                bytes_per_column=round(t3 / cols, 1), pmc_per_wavefront=counters)

@@ -1,17 +1,18 @@
 #!/bin/bash
 # Round-4 counter passes of the soil kernels (runs on the GPU box via gpurun): three SEPARATE rocprofv3 --pmc passes
-# (FETCH_SIZE | WRITE_SIZE | SQ + GRBM) of `bench.py --only soil --steps 2` (both regimes: wet -> k_soil_columns<.., true>
+# (FETCH_SIZE | WRITE_SIZE | SQ + GRBM) of `LF_BENCH_SOIL_REGIME=<regime> bench.py --only soil` (one regime per set of passes: wet -> k_soil_columns<.., true>
 # + k_soil_columns_deferred, single sub-step -> k_soil_columns<.., false>), condensed per kernel into
-# gpurun_out/pmc_r04_soil_4000000.txt in the format of tools/pmc_r03.sh (tools/pmc_digest_r03.py reads it).
+# gpurun_out/pmc_r04_soil_<regime>_4000000.txt in the format of tools/pmc_r03.sh (tools/pmc_digest_r03.py reads it).
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 SQ="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE"
-name=soil_4000000
+for regime in wet single_substep; do
+name=soil_${regime}_4000000
 for pass in FETCH_SIZE WRITE_SIZE SQ; do
   C=$pass; [ $pass = SQ ] && C=$SQ
   rm -rf /tmp/pmc_${name}_$pass
-  timeout 600 rocprofv3 --pmc $C --output-format csv -d /tmp/pmc_${name}_$pass -o pmc -- \
+  LF_BENCH_SOIL_REGIME=$regime timeout 600 rocprofv3 --pmc $C --output-format csv -d /tmp/pmc_${name}_$pass -o pmc -- \
       python $ROOT/bench.py --only soil > /tmp/pmc_${name}_$pass.log 2>&1
   echo "$name $pass rc=$?"
 done
@@ -27,7 +28,7 @@ for p in ("FETCH_SIZE", "WRITE_SIZE", "SQ"):
             a = agg[k][r["Counter_Name"]]
             a[0] += 1
             a[1] += float(r["Counter_Value"])
-print("# %s: per-kernel counter totals over `bench.py --only soil` (12 calls per regime; rocprofv3 --pmc, separate passes); FETCH/WRITE in KiB as reported" % name)
+print("# %s: per-kernel counter totals over `bench.py --only soil` of that regime (12 calls; rocprofv3 --pmc, separate passes); FETCH/WRITE in KiB as reported" % name)
 for k, c in sorted(agg.items()):
     n = max(v[0] for v in c.values())
     line = ["%-44s launches=%d" % (k, n)]
@@ -38,3 +39,4 @@ for k, c in sorted(agg.items()):
     print("  ".join(line))
 PY
 cat $OUT/pmc_r04_${name}.txt
+done
