@@ -469,7 +469,7 @@ __device__ __forceinline__ void cone_chain(cone_lds<NR, KC> &S, int tid, int nl,
                     // path (c beyond 1e30, NaN, a outside the fast range: kinematic_wave_parallel_tools.py:59-82)
                     const bool le = c <= LF_NEWTON_TOL;
                     const bool quintic = c <= LF_FAST_MAX && cur.fl[r].fast_a != 0;
-#ifdef LF_EXP_NOSOLVE
+#ifdef LF_EXP_NOSOLVE /* timing experiments only (tools/build_variant.sh): WRONG results, bounded values */
                     q = c * 1e-3 + 0.5 * cur.ca[r].cst;
 #else
                     q = lf_solve_3_5_pre(c, cur.ca[r].ap, cur.fl[r].af, cur.fl[r].laf); // (lanes not selected: garbage)
@@ -489,7 +489,7 @@ __device__ __forceinline__ void cone_chain(cone_lds<NR, KC> &S, int tid, int nl,
         };
         operands pa, pb; // two sets, swapping roles level by level (no copies)
         request(O, 0, pa); // the chunk's first level; inside the chunk the operands are requested one level ahead
-#ifdef LF_EXP_NOCHAIN
+#ifdef LF_EXP_NOCHAIN /* timing experiments only: the supply side alone, WRONG results */
         for (int jj = 0; jj < L; ++jj) S.xr[(ob * KC + jj) * NR][tid] = 1.0;
         for (int jj = 0; jj < 0; jj += 2) {
 #else
