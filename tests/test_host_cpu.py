@@ -371,3 +371,27 @@ def test_tss_writer_operations_total_and_mapmaximum(tmp_path):
     assert (O.read_tss(str(tmp_path / "m.tss"))[3] == 9.0).all()
     with pytest.raises(ValueError):
         O.TssWriter(str(tmp_path / "e.tss"), [1], [0], how="total")
+
+
+def test_block_plan_statistics_of_a_graph():
+    """lf_graph_block_plan_stats (host only): the plan a router would sweep the graph with -- every cell of a multi-level
+    block is counted once, the cones tile the levels (cone levels x 64 lanes hold them), shorter blocks are fuller"""
+    codes = syn.make_ldd("river", 300, 260, 4)
+    g = Graph(ldd_raster=codes)
+    lib = _lib.lib()
+
+    def stats(lmax, max_cone):
+        o = (C.c_int64 * 6)()
+        _lib.check(lib.lf_graph_block_plan_stats(g._h, lmax, 262144, max_cone, o))
+        return list(o)
+    perm, ups_ptr, level_start = g.layout()
+    a = stats(16, 64)
+    b = stats(256, 64)
+    for blocks, multi, cones, cone_levels, cells, most in (a, b):
+        assert 0 < multi <= blocks and cones >= multi and most <= cones
+        assert cells <= 300 * 260 and cells <= 64 * cone_levels
+    assert a[0] > b[0]                                   # more, shorter blocks
+    assert a[4] / (64.0 * a[3]) > b[4] / (64.0 * b[3])   # ... with fuller wavefronts
+    one = stats(1, 64)                                   # one level per block: nothing is swept cone by cone
+    assert one[1] == 0 and one[0] == level_start.size - 1
+    g.close()
