@@ -588,7 +588,8 @@ def main():
         print(json.dumps(soil_bench()), flush=True)
         return
     if a.only == "structures":
-        print(json.dumps(structures_step_bench()))
+        explicit = any(x.startswith("--size") for x in sys.argv)
+        print(json.dumps(structures_step_bench(a.size if explicit else 3000)))
         return
     if a.only == "overland":
         print(json.dumps(overland_bench()), flush=True)

@@ -31,6 +31,7 @@ struct fused_args {
     const unsigned int *__restrict__ recompute;
     double dt; // the router's time step (a = alpha * dx / dt)
     const uint8_t *__restrict__ linked; // zero-length structure links: their router output is stored as 0
+    const int *__restrict__ level_nlinked; // number of such links parked at the end of every level (k_fused_cones_split)
     const uint8_t *__restrict__ inert;  // cells whose sub-step is the identity while their state is all +0.0
     lf_inloop_args I;                   // STRUCT: lakes / reservoirs / inflow / transmission loss / sideflow assembly
     const int *__restrict__ site_level; // STRUCT: level of every lake, then every reservoir cell
@@ -815,11 +816,12 @@ __global__ void __launch_bounds__(CW) __attribute__((amdgpu_waves_per_eu(LF_CONE
 //     range load cell 0 and store beyond the end of a buffer resource; the outputs only the last sub-step keeps are
 //     stored beyond the end on the others), so the compiler's wait counts stay exact.
 // Arithmetic per cell = fused_cell's, operation by operation (cone_compute's beta = 3/5 forms): bit-identical.
-// For: beta = 3/5 router and fix-ups, no structures, no zero-length links, no inert-pixel test (a compact channel domain
-// has none), the single-domain plan with cones of <= 64 cells; every other case keeps k_fused_cones.
+// For: beta = 3/5 router and fix-ups, no inert-pixel test (a compact channel domain has none), the single-domain plan with
+// cones of <= 64 cells; with structures in the loop (STRUCT: sideflow assembly in the supply wavefronts, sites between the
+// launches as before) or without, not on a graph with links without them; every other case keeps k_fused_cones.
 constexpr int kFusedKC = 2; // (chunks of 2 levels: 31 KB of LDS and three wavefronts per cone; 4: 62 KB and five -- slower at every size measured)
 
-template <bool SPLIT, int KC = kFusedKC>
+template <bool SPLIT, bool STRUCT = false, int KC = kFusedKC>
 __global__ void __launch_bounds__(64 * (1 + KC)) k_fused_cones_split(fused_args F)
 {
     constexpr int NR = SPLIT ? 2 : 1;
@@ -887,12 +889,15 @@ __global__ void __launch_bounds__(64 * (1 + KC)) k_fused_cones_split(fused_args 
     struct pre_t { // what the constant terms of a cell need, as loaded
         int u0, u1, p;
         double len, side_m3, qold, alpha1, m3, m3_2, start, m3limit, q2start, q2old, alpha2, inv_len, ap1, ap2, dxv;
-        unsigned char chan;
+        // STRUCT: the terms of the sideflow assembly (routing.py:462-478), as cone_load reads them
+        double eva, wuse, qin_old, qdelta, qin_added_old, chanq_old, transcum, lakeout, resout, polder;
+        unsigned char chan, uptrans;
         bool act;
     };
     struct post_t { // what its fix-ups need again two chunks later
         int p;
         double len, alpha1, inv_len, inv_alpha1, start, alpha2, inv_alpha2, qlimit, sum_old, pix_area;
+        unsigned char cut; // STRUCT: zero-length structure link -- its router output is stored as 0
         bool act;
     };
     auto body = [&](auto rc_tag) {
@@ -911,7 +916,26 @@ __global__ void __launch_bounds__(64 * (1 + KC)) k_fused_cones_split(fused_args 
             P.u1 = G.ups_ptr[pc + 1];
             P.len = A.ChanLength[pc];
             P.chan = A.IsChannelKinematic[pc];
-            P.side_m3 = A.SideflowChanM3[(long long)s * G.side_stride + pc];
+            P.eva = P.wuse = P.qin_old = P.qdelta = P.qin_added_old = P.chanq_old = P.transcum = P.lakeout = P.resout = P.polder = 0.0;
+            P.uptrans = 0;
+            if (!STRUCT)
+                P.side_m3 = A.SideflowChanM3[(long long)s * G.side_stride + pc];
+            else { // (an option that is off: any valid stream instead of a branch around the load; its value is not used)
+                const lf_inloop_args &I = G.I;
+                const double *any = I.ToChanM3RunoffDt;
+                P.side_m3 = any[pc];
+                P.eva = (I.EvaAddM3Dt ? I.EvaAddM3Dt : any)[pc];
+                P.wuse = (I.WUseAddM3Dt ? I.WUseAddM3Dt : any)[pc];
+                P.qin_old = (I.QInM3Old ? I.QInM3Old : any)[pc];
+                P.qdelta = (I.QInM3Old ? I.QDelta : any)[pc];
+                P.qin_added_old = (I.QInM3Old ? (const double *)I.QinADDEDM3 : any)[pc];
+                P.chanq_old = A.ChanQ[pc];
+                P.uptrans = (I.UpTrans ? I.UpTrans : A.IsChannelKinematic)[pc];
+                P.transcum = (I.UpTrans ? (const double *)I.TransCum : any)[pc];
+                P.lakeout = (I.QLakeOutM3Dt ? (const double *)I.QLakeOutM3Dt : any)[pc];
+                P.resout = (I.QResOutM3Dt ? (const double *)I.QResOutM3Dt : any)[pc];
+                P.polder = (I.ChannelToPolderM3Dt ? I.ChannelToPolderM3Dt : any)[pc];
+            }
             P.qold = A.ChanQKin[pc];
             P.alpha1 = A.ChannelAlpha[pc];
             P.dxv = (G.dx ? G.dx : A.ChanLength)[pc]; // (no per-pixel dx: any valid stream, the scalar is selected)
@@ -939,7 +963,18 @@ __global__ void __launch_bounds__(64 * (1 + KC)) k_fused_cones_split(fused_args 
             const bool block_top = decltype(first_chunk)::value && sw == 0; // the block's first level
             // ---- the reads of the level above ----
             const int above = jj > 0 ? (ob * KC + jj - 1) * NR : ((ob ^ 1) * KC + KC - 1) * NR;
-            const int cnt = P.act ? P.u1 - P.u0 : 0;
+            int cnt = P.act ? P.u1 - P.u0 : 0;
+            if (STRUCT && !block_top) {
+                // the range of a level's LAST cell runs to the end of the level above, over the zero-length structure links
+                // parked there (lf_graph.cpp): their router output counts as 0, so they are left out of the gather (x + 0.0
+                // == x; the chain wavefront keeps their true output in LDS for their own fix-ups)
+                const int lv = ld_table(G.fb_level, b) + j;          // absolute level of this cell
+                const bool in_block = (unsigned)j < (unsigned)nl;
+                typedef const long long __attribute__((address_space(4))) *cll; // (scalar load: the table is never written)
+                const int level_end = in_block ? (int)((cll)(unsigned long long)G.level_start)[lv + 1] : 0;
+                const int parked = (in_block && j > 0) ? ld_table(G.level_nlinked, lv - 1) : 0;
+                if (P.act && P.p + 1 == level_end) cnt -= parked;
+            }
             const int ab = above * kConeRow + (((P.u0 - lbound(c0, j - 1)) & 0xff) << 3);
             cone_rec_ad a0, a1;
 #pragma unroll
@@ -953,7 +988,46 @@ __global__ void __launch_bounds__(64 * (1 + KC)) k_fused_cones_split(fused_args 
             const double dxp = dx_is_len ? P.len : (G.dx ? P.dxv : G.dx_scalar);
             const double inv_len = RC ? 1.0 / P.len : P.inv_len;
             const double ap1 = RC ? P.alpha1 * dxp / G.dt : P.ap1;
-            const double side = (P.chan != 0) ? P.side_m3 * inv_len * A.InvDtRouting : 0.0;
+            double side_m3 = P.side_m3;
+            if (STRUCT) { // inflow.py:142-144, transmission.py:76-87, sideflow assembly routing.py:462-478 -- as cone_compute
+                const lf_inloop_args &I = G.I;
+                double qin = 0.0, qin_added = 0.0, loss = 0.0, trans_cum = 0.0;
+                if (I.EvaAddM3Dt) side_m3 -= P.eva;
+                if (I.WUseAddM3Dt) side_m3 -= P.wuse;
+                if (I.QInM3Old) {
+                    qin = (P.qin_old + (s + 1) * P.qdelta) * I.InvNoRoutSteps;
+                    qin_added = (s < 1 ? 0.0 : P.qin_added_old) + qin;
+                    side_m3 += qin;
+                }
+                if (I.UpTrans) {
+                    const double qc = P.chanq_old;
+                    double tout = qc;
+                    if (P.uptrans) {
+                        const double inner = cold_pow(qc, I.TransPower2) - I.TransSub;
+                        tout = cold_pow(inner, I.TransPower1);
+                    }
+                    loss = (qc - tout) * I.DtRouting;
+                    trans_cum = P.transcum + loss;
+                    side_m3 -= loss;
+                }
+                if (I.QLakeOutM3Dt) side_m3 += P.lakeout;
+                if (I.QResOutM3Dt) side_m3 += P.resout;
+                if (I.ChannelToPolderM3Dt) side_m3 -= P.polder;
+                // what the assembly leaves behind (an option that is off: stored beyond the end of a buffer, dropped)
+                const unsigned off = P.act ? (unsigned)P.p * 8u : 0xffffffffu;
+                auto put = [&](double *base, bool on, double val) {
+                    __builtin_amdgcn_raw_buffer_store_b64(
+                        __builtin_bit_cast(v2i, val),
+                        __builtin_amdgcn_make_buffer_rsrc(on ? base : I.SideflowChanM3, 0, (int)nbytes, 0x00020000),
+                        on ? off : 0xffffffffu, 0, 0);
+                };
+                put(I.QInDt, I.QInM3Old != nullptr, qin);
+                put(I.QinADDEDM3, I.QInM3Old != nullptr, qin_added);
+                put(I.TransLossM3Dt, I.UpTrans != nullptr, loss);
+                put(I.TransCum, I.UpTrans != nullptr, trans_cum);
+                put(I.SideflowChanM3, true, side_m3);
+            }
+            const double side = (P.chan != 0) ? side_m3 * inv_len * A.InvDtRouting : 0.0;
             double s1 = side, s2 = 0.0;
             if (!SPLIT) {
                 if (isnan(side)) s1 = 0.0;
@@ -1011,6 +1085,7 @@ __global__ void __launch_bounds__(64 * (1 + KC)) k_fused_cones_split(fused_args 
             R.inv_len = RC ? 0.0 : A.InvChanLength[pc];
             R.inv_alpha1 = RC ? 0.0 : A.InvChannelAlpha[pc];
             R.pix_area = A.PixelArea[last ? pc : 0]; // (read by the last sub-step only: one line on the others)
+            R.cut = STRUCT ? G.linked[pc] : 0;
             R.start = R.alpha2 = R.inv_alpha2 = R.qlimit = 0.0;
             if (SPLIT) {
                 R.start = A.Chan2M3Start[pc];
@@ -1056,22 +1131,23 @@ __global__ void __launch_bounds__(64 * (1 + KC)) k_fused_cones_split(fused_args 
                 vel *= sinu;
             }
             const unsigned off = R.act ? (unsigned)R.p * 8u : 0xffffffffu; // beyond the buffer: dropped
-            const unsigned off_last = last ? off : 0xffffffffu;           // what only the last sub-step leaves behind
+            const unsigned off_last = last ? off : 0xffffffffu;           // what only the last sub-step leaves behind ...
+            const unsigned off_keep = STRUCT ? off : off_last;            // ... or every sub-step when structures read ChanQ
             const unsigned off_out = (j == nl - 1) ? off : 0xffffffffu;   // the block's last level: read by the next block
             auto put = [&](double *base, unsigned o, double val) {
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, val),
                                                       __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)nbytes, 0x00020000), o, 0, 0);
             };
-            put(G.qr1 + par, off_out, qr);
+            put(G.qr1 + par, off_out, R.cut ? 0.0 : qr);
             put(A.ChanM3Kin, off, v);
             put(A.ChanQKin, off, q);
-            put(A.ChanQ, off_last, chanq);
+            put(A.ChanQ, off_keep, chanq);
             put(A.sumDisDay, off, R.sum_old + chanq);
             if (SPLIT) {
-                put(G.qr2 + par, off_out, q2r);
-                put(A.Sideflow1Chan, off_last, s1);
+                put(G.qr2 + par, off_out, R.cut ? 0.0 : q2r);
+                put(A.Sideflow1Chan, off_keep, s1);
                 put(A.Chan2M3Kin, off, v2);
-                put(A.CrossSection2Area, off_last, (v2 - R.start) * inv_len);
+                put(A.CrossSection2Area, off_keep, (v2 - R.start) * inv_len);
                 put(A.Chan2QKin, off, q2);
             }
             put(A.FlowVelocity, off_last, vel);
@@ -1083,6 +1159,7 @@ __global__ void __launch_bounds__(64 * (1 + KC)) k_fused_cones_split(fused_args 
         post_t RA, RB;
         RB.act = false; // (the first trip runs the fix-ups of a chunk -1: nothing of it is stored)
         RB.p = 0;
+        RB.cut = 0;
         RB.len = RB.alpha1 = RB.inv_len = RB.inv_alpha1 = RB.start = RB.alpha2 = RB.inv_alpha2 = RB.qlimit = RB.sum_old =
             RB.pix_area = 1.0;
         issue_pre(0, PA);

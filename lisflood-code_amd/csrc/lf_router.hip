@@ -207,6 +207,7 @@ struct lf_router {
     lf_dbuf<double> a1, a2, dx, constant, qord, io_q, io_lat, tmp_ord, fused_qr1, fused_qr2;
     lf_dbuf<unsigned long long> counter;
     lf_dbuf<uint8_t> linked; // zero-length structure links (lf_graph_create_ex); null without them
+    lf_dbuf<int> level_nlinked; // ... and how many of them are parked at the end of every level (k_fused_cones_split)
     lf_dbuf<int32_t> parent; // [N] downstream position of every position, -1 = outlet (lf_ldd.hip builds it on demand)
     lf_dbuf<int32_t> root;   // [N] position of the outlet every position drains to (lf_ldd.hip, on demand: catchment totals)
     lf_dbuf<double> totals_scratch; // catchment totals: engine-order copies of the weights and their accuflux
@@ -621,9 +622,9 @@ static int build_level_blocks(lf_router *r, const lf_graph *g, bool for_route)
         cw = 64;
         if (const char *e = std::getenv("LF_ROUTE_CONE_WIDTH")) cw = std::atoi(e) == 64 ? 64 : kBlock;
     } else {
-        // fused wavefront: one wavefront per cone on graphs without structure links (the chain / supply kernel needs it;
-        // k_fused_cones itself measured the same at 64 and 256: DESIGN.md section 8b), 256 with links
-        cw = g->has_links ? kBlock : 64;
+        // fused wavefront: one wavefront per cone (the chain / supply kernel needs it; k_fused_cones itself measured the
+        // same at 64 and 256: DESIGN.md section 8b)
+        cw = 64;
         if (const char *e = std::getenv("LF_FUSED_CONE_WIDTH")) cw = std::atoi(e) == 64 ? 64 : kBlock;
     }
     lf_block_plan plan;
@@ -718,6 +719,12 @@ int lf_router_create(const lf_graph *g, const double *alpha, double beta, const 
     if (rc == LF_OK) rc = r->perm.upload(g_perm.data(), n, ctx->stream);
     if (rc == LF_OK) rc = r->ups_ptr.upload(g_ups_ptr.data(), n + 1, ctx->stream);
     if (rc == LF_OK && g->has_links) rc = r->linked.upload(g->linked.data(), n, ctx->stream);
+    if (rc == LF_OK && g->has_links) {
+        std::vector<int> parked((size_t)g->NL, 0);
+        for (int64_t k = 0; k < g->NL; ++k)
+            for (int64_t p = g->level_start[k]; p < g->level_start[k + 1]; ++p) parked[k] += g->linked[p] ? 1 : 0;
+        rc = r->level_nlinked.upload(parked.data(), parked.size(), ctx->stream);
+    }
     if (rc == LF_OK && n > 0) {
         std::vector<uint8_t> has_up(n, 0), iso(n, 0);
         for (int64_t p = 0; p < n; ++p)
@@ -1336,6 +1343,7 @@ int fused_impl(lf_router *r, const lf_substep_args *a, int nsteps, int64_t sidef
     F.nsteps = nsteps;
     F.solve35 = r->fused ? 1 : 0;
     F.linked = r->linked.p;
+    F.level_nlinked = r->level_nlinked.p;
     F.inert = nullptr;
     F.site_level = nullptr;
     F.fb_level = F.fb_row = F.fb_cone = nullptr;
@@ -1500,10 +1508,22 @@ int fused_impl(lf_router *r, const lf_substep_args *a, int nsteps, int64_t sidef
                     const char *e = std::getenv("LF_FUSED_SPLIT_MAX");
                     return e ? std::atoll(e) : (long long)1600;
                 }();
+                // (with structures in the loop the supply wavefronts also carry the sideflow assembly and, on reaches with
+                // transmission loss, two OCML pow calls per cell: the crossover is lower -- 3000^2 with 256 sites: 5.5 vs 8.2 ms
+                // at 1000^2, 16.1 vs 15.2 at 2000^2)
+                static const int64_t split_max_struct = [] {
+                    const char *e = std::getenv("LF_FUSED_SPLIT_MAX_STRUCT");
+                    return e ? std::atoll(e) : (long long)600;
+                }();
                 const char *es = std::getenv("LF_FUSED_SPLIT");
-                const bool split_form = !in && all35 && !F.inert && !F.linked && r->fb_cw == 64 && n < ((int64_t)1 << 29) &&
-                                        (es ? es[0] != '0' : acc <= split_max);
-                if (split_form && a->split)
+                // (with structures in the loop: on a graph with their links; without them: on a graph without links)
+                const bool split_form = all35 && !F.inert && (in ? F.linked != nullptr : F.linked == nullptr) && r->fb_cw == 64 &&
+                                        n < ((int64_t)1 << 29) && (es ? es[0] != '0' : acc <= (in ? split_max_struct : split_max));
+                if (split_form && in && a->split)
+                    hipLaunchKernelGGL((k_fused_cones_split<true, true>), grid, dim3(64 * (1 + kFusedKC)), 0, s, F);
+                else if (split_form && in)
+                    hipLaunchKernelGGL((k_fused_cones_split<false, true>), grid, dim3(64 * (1 + kFusedKC)), 0, s, F);
+                else if (split_form && a->split)
                     hipLaunchKernelGGL((k_fused_cones_split<true>), grid, dim3(64 * (1 + kFusedKC)), 0, s, F);
                 else if (split_form)
                     hipLaunchKernelGGL((k_fused_cones_split<false>), grid, dim3(64 * (1 + kFusedKC)), 0, s, F);
