@@ -642,7 +642,12 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 template <bool SPLIT, bool ALL35, bool STRUCT, bool DIST = false, int CW = kBlock>
 __global__ void __launch_bounds__(CW) __attribute__((amdgpu_waves_per_eu(LF_CONES_WAVES))) k_fused_cones(fused_args F)
 {
-    __shared__ double x1[2][CW], x2[SPLIT ? 2 : 1][SPLIT ? CW : 1];
+    // (slot CW of every row holds 0.0: what an absent upstream cell reads -- no select behind the LDS read)
+    __shared__ double x1[2][CW + 1], x2[SPLIT ? 2 : 1][SPLIT ? CW + 1 : 1];
+    if (threadIdx.x < 2) {
+        x1[threadIdx.x][CW] = 0.0;
+        if (SPLIT) x2[threadIdx.x][CW] = 0.0;
+    }
     int s, blk;
     if (F.packed) {
         int cnt = 0, start = 0;
@@ -742,18 +747,16 @@ __global__ void __launch_bounds__(CW) __attribute__((amdgpu_waves_per_eu(LF_CONE
             } else if (j == 0) { // from the block before (previous launch) through the parity buffers
                 ups1 = upstream_sum8(F.qr1 + par, cu0, cu1, kmax);
                 if (SPLIT) ups2 = upstream_sum8(F.qr2 + par, cu0, cu1, kmax);
-            } else { // from LDS, branch-free: absent neighbours read slot 0 and add +0.0 (the sum as upstream_sum8)
+            } else { // from LDS, branch-free: absent neighbours read the slot that holds 0.0 (the sum as upstream_sum8)
                 const double *y1 = &x1[(j - 1) & 1][0], *y2 = &x2[SPLIT ? (j - 1) & 1 : 0][0];
                 const int base = cu0 - first_up;
                 double v1[8], v2[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const bool have = k < kmax && cu0 + k < cu1;
-                    const int idx = have ? base + k : 0;
+                    const int idx = have ? base + k : CW;
                     v1[k] = y1[idx];
                     if (SPLIT) v2[k] = y2[idx];
-                    v1[k] = have ? v1[k] : 0.0;
-                    if (SPLIT) v2[k] = have ? v2[k] : 0.0;
                 }
                 ups1 = 0.0;
 #pragma unroll
