@@ -363,7 +363,7 @@ void launch_split_shape(dim3 grid, hipStream_t s, const cone_plan_args &C, const
     }
     static const int few_limit = [] {
         const char *e = std::getenv("LF_ROUTE_SPLIT_FEW");
-        return e ? std::atoi(e) : 384;
+        return e ? std::atoi(e) : 256;
     }();
     const char *shape = std::getenv("LF_ROUTE_SPLIT_SHAPE"); // (read at every call: A/B legs switch it)
     const bool few = shape ? shape[0] == 'f' : (int)grid.x <= few_limit;
