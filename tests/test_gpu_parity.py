@@ -1260,6 +1260,40 @@ def test_overland_routers_where_they_route_sparse_channels(amd, oracle, solver):
         kw.close()
 
 
+@pytest.mark.parametrize("nr", [2, 4])
+def test_two_and_four_routers_per_cone(amd, solver, nr):
+    """the cone kernels are instantiated for 1..4 routers on one graph (chunks of 4 levels, two supply wavefronts for more
+    than one): 2 and 4 routers swept together on a `deep` graph equal their separate sweeps bit for bit, engine order and
+    pixel order, two calls"""
+    from lisflood_amd import synthetic as syn
+    from lisflood_amd._lib import DeviceArray
+    from lisflood_amd.kinematic_wave_parallel import Graph, kinematicWave
+    H, W = 150, 120
+    N = H * W
+    g = Graph(ldd_raster=syn.make_ldd("deep", H, W, 6))
+    p = syn.router_params(N, seed=4)
+    rng = np.random.default_rng(10)
+    factors = (1.0, 0.5, 2.2, 1.4)[:nr]
+    kws = [kinematicWave(None, None, p["alpha"] * f, p["beta"], p["dx"], p["dt"], graph=g) for f in factors]
+    Q0 = [p["Q0"] * rng.uniform(0.5, 1.5, N) for _ in kws]
+    for ordered in (True, False):
+        qa = [DeviceArray.from_host(q) for q in Q0]
+        qb = [DeviceArray.from_host(q) for q in Q0]
+        for s in range(2):
+            lat = [DeviceArray.from_host(syn.lateral_inflow(N, s) * f) for f in factors]
+            for kw, q, x in zip(kws, qa, lat):
+                (kw.route_ordered if ordered else kw.route_device)(q, x)
+            kinematicWave.route_together(kws, qb, lat, engine_order=ordered)
+            for i in range(nr):
+                assert np.array_equal(qa[i].download(), qb[i].download()), (nr, ordered, s, i)
+            for x in lat:
+                x.free()
+        for d in qa + qb:
+            d.free()
+    for kw in kws:
+        kw.close()
+
+
 @pytest.mark.parametrize("family,nparts", [("deep", 3), ("river", 2)])      # (this river raster has two catchments)
 def test_catchment_partition_model_step_fused(amd, family, nparts):
     """configs[4]'s workload shape on a partition: every part runs the FUSED wavefront (24 split-routing sub-steps, level
