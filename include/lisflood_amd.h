@@ -173,6 +173,10 @@ int lf_router_route_plan_stats(const lf_router *r, int64_t out[6]);
 /* the same figures for the plan a router WOULD build on a graph with blocks of up to lmax levels of at most `wide` cells
  * and cones of at most max_cone cells per level (host only: plan shapes can be studied without a device) */
 int lf_graph_block_plan_stats(const lf_graph *g, int lmax, int64_t wide, int max_cone, int64_t out[6]);
+/* the invariants the cone kernels rely on, checked cell by cell on the host: out[0] cells whose upstream range is not
+ * inside the cone's range of the level above (must be 0), out[1] largest LDS slot + 1 a cell reads (<= max_cone),
+ * out[2] largest upstream count (<= 8), out[3] cells checked */
+int lf_graph_block_plan_check(const lf_graph *g, int lmax, int64_t wide, int max_cone, int64_t out[4]);
 /* per-kernel hipEvent profiling: when enabled every sweep launch is bracketed by an event pair.
  * lf_router_profile_read returns accumulated {launches, milliseconds, cells} per kernel class
  * (0 = prep, 1 = wide level, 2 = narrow run) since the last reset. */

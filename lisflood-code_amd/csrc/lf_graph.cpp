@@ -291,6 +291,50 @@ int lf_graph_block_plan_stats(const lf_graph *g, int lmax, int64_t wide, int max
     return LF_OK;
 }
 
+// What the cone kernels take for granted about that plan, checked cell by cell on the host: the upstream range of every
+// cell of a cone lies inside the cone's range of the level above (it is read from the LDS row of that level: slot =
+// position - start of the range, at most max_cone slots), and holds at most 8 cells.
+//   out[0] cells whose range leaves the cone's range above   out[1] largest slot index + 1 any cell reads
+//   out[2] largest upstream count                             out[3] cells checked
+int lf_graph_block_plan_check(const lf_graph *g, int lmax, int64_t wide, int max_cone, int64_t out[4])
+{
+    if (!g || !out || lmax < 1 || max_cone < 1) return lf_set_error(LF_E_INVALID, "bad argument");
+    for (int i = 0; i < 4; ++i) out[i] = 0;
+    if (g->NL < 1) return LF_OK;
+    lf_block_plan plan;
+    try {
+        lf_build_level_blocks(g->level_start, 0, g->NL, lmax, wide, max_cone,
+                              [&](int64_t pos) { return (int64_t)g->ups_ptr[pos]; }, plan);
+    } catch (const std::bad_alloc &) {
+        return lf_set_error(LF_E_INVALID, "out of host memory while building the level blocks");
+    }
+    plan.level.push_back((int)g->NL);
+    const int NB = (int)plan.level.size() - 1;
+    for (int b = 0; b < NB; ++b) {
+        const int k0 = plan.level[b], nl = plan.level[b + 1] - k0;
+        if (nl < 2) continue;
+        const int64_t cones = plan.row[b + 1] - plan.row[b] - 1;
+        const int *rows = plan.cone.data() + plan.off[b];
+        for (int64_t c = 0; c < cones; ++c) {
+            const int *c0 = rows + c * nl, *c1 = c0 + nl;
+            for (int j = 1; j < nl; ++j) {
+                const int64_t above0 = c0[j - 1], above1 = c1[j - 1];
+                if (above1 - above0 > max_cone) ++out[0];
+                for (int64_t p = c0[j]; p < c1[j]; ++p) {
+                    // (a level's last cell: its range runs on over the structure links parked at the end of the level above)
+                    int64_t u0 = g->ups_ptr[p], u1 = g->ups_ptr[p + 1];
+                    if (g->has_links) while (u1 > u0 && g->linked[u1 - 1]) --u1;
+                    ++out[3];
+                    if (u1 > u0 && (u0 < above0 || u1 > above1)) ++out[0];
+                    if (u1 > u0) out[1] = std::max(out[1], u1 - above0);
+                    out[2] = std::max(out[2], u1 - u0);
+                }
+            }
+        }
+    }
+    return LF_OK;
+}
+
 int lf_graph_get_lookups(const lf_graph *g, double *downstream, int64_t *upstream, int64_t *num_upstream)
 {
     if (!g || !downstream || !upstream || !num_upstream) return lf_set_error(LF_E_INVALID, "null argument");

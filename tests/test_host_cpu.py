@@ -395,3 +395,43 @@ def test_block_plan_statistics_of_a_graph():
     one = stats(1, 64)                                   # one level per block: nothing is swept cone by cone
     assert one[1] == 0 and one[0] == level_start.size - 1
     g.close()
+
+
+@pytest.mark.parametrize("family,H,W", [("deep", 220, 180), ("river", 300, 260), ("shallow", 400, 400), ("saddle", 200, 150)])
+def test_cone_plan_invariants_the_kernels_rely_on(family, H, W):
+    """k_sweep_cones_split / k_fused_cones_split read a cell's upstream discharges from the LDS row of the level above at
+    slot (upstream position - start of the cone's range above): every upstream range must lie inside that range, the slot
+    must fit the row (64), the count the eight address slots -- for the router plan (blocks of 256 levels) and the fused
+    plans (16 and 32 levels), also on a masked raster and on a graph with structure links parked at the end of levels"""
+    lib = _lib.lib()
+
+    def check(g, lmax):
+        o = (C.c_int64 * 4)()
+        _lib.check(lib.lf_graph_block_plan_check(g._h, lmax, 262144, 64, o))
+        bad, slots, cnt, cells = list(o)
+        assert bad == 0 and slots <= 64 and cnt <= 8, (family, lmax, list(o))
+        return cells
+    codes = syn.make_ldd(family, H, W, 9)
+    g = Graph(ldd_raster=codes)
+    assert sum(check(g, lmax) for lmax in (256, 32, 16)) > 0 or family == "shallow"
+    g.close()
+    mask = np.random.default_rng(1).random((H, W)) > 0.25
+    gm = Graph(ldd_raster=syn.make_ldd(family, H, W, 9, land_mask=mask), land_mask=mask)
+    for lmax in (256, 16):
+        check(gm, lmax)
+    gm.close()
+    # structure links: cut the LDD at a few cells and hand their inflow cells back as zero-length links
+    from lisflood_amd import ldd as L
+    flat = codes.reshape(-1).astype(np.float64)
+    allm = np.ones((H, W), bool)
+    down = L.downstream_index(flat, allm)
+    rng = np.random.default_rng(2)
+    sites = rng.choice(np.nonzero(down >= 0)[0], 12, replace=False)
+    is_site = np.zeros(flat.size, bool); is_site[sites] = True
+    feeds = (down >= 0) & is_site[np.maximum(down, 0)]
+    cut = flat.copy(); cut[feeds] = L.PIT
+    vd = np.where(feeds, down, -1)
+    gl = Graph(cut, allm, virtual_down=vd)
+    for lmax in (32, 16):
+        check(gl, lmax)
+    gl.close()
