@@ -573,7 +573,18 @@ def hotpath_bench(size=2000, steps=6):
     out = dict(ms_per_model_step=round(ms, 3), model_steps_per_s=round(1e3 / ms, 2), pixels=N,
                Mpixel_steps_per_s=round(N / ms / 1e3, 2), finite=bool(np.isfinite(q).all()),
                config="%dx%d deep LDD, 30 %% channel pixels, V=3 fractions, NoRoutSteps=24 split routing; forcing "
-                      "uploaded from the host every step" % (H, W))
+                      "uploaded from the host every step; the channel wavefront on a second stream beside the next step's "
+                      "canopy / soil / overland kernels" % (H, W))
+    # A/B: everything on one stream (rounds 1-3)
+    hp.overlap_channel = False
+    hp.step(forc[0], steps + 4)
+    _lib.synchronize()
+    t0 = time.perf_counter()
+    for s in range(steps):
+        hp.step(forc[s % 2], steps + 5 + s)
+        hp.prefetch(forc[(s + 1) % 2])
+    _lib.synchronize()
+    out["one_stream_ms_per_model_step"] = round((time.perf_counter() - t0) * 1e3 / steps, 3)
     hp.free()
     return out
 

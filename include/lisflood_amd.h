@@ -79,6 +79,14 @@ int lf_upload_copy(int device, void *dst_dev, const void *src_host, size_t bytes
 int lf_upload_end(int device, int set);
 int lf_compute_acquire(int device, int set);
 int lf_compute_release(int device, int set);
+/* A second compute stream for a part of a step that the first kernels of the NEXT step do not depend on (the channel
+ * wavefront of a model step beside the canopy / soil / overland kernels of the step after it): between _begin and _end every
+ * library call of this device goes to the side stream, behind what the main stream holds so far; after _end the side work
+ * stays in flight beside the main stream.  _join: the main stream waits for the side work issued so far; the copy entry
+ * points (lf_memcpy_*) join by themselves, lf_device_synchronize waits for both streams. */
+int lf_side_stream_begin(int device);
+int lf_side_stream_end(int device);
+int lf_side_stream_join(int device);
 int lf_memcpy_d2h(int device, void *dst_host, const void *src_dev, size_t bytes);
 int lf_memcpy_d2d(int device, void *dst_dev, const void *src_dev, size_t bytes);
 int lf_memset(int device, void *dst_dev, int value, size_t bytes);

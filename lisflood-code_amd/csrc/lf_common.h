@@ -50,6 +50,11 @@ struct lf_device_ctx {
     hipStream_t copy_stream = nullptr;
     hipEvent_t copied[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
     bool consumed_valid[2] = {false, false};
+    // side stream (lf_side_stream_*): a part of a step that the NEXT step's first kernels do not depend on -- the channel
+    // wavefront of a model step beside the canopy / soil / overland kernels of the step after it (hotpath.py)
+    hipStream_t side_stream = nullptr, main_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_side_done = nullptr;
+    bool side_active = false, side_pending = false;
 };
 int lf_ctx(int device, lf_device_ctx **out); // makes `device` current, creates the context on first use
 

@@ -122,10 +122,13 @@ int lf_device_free(int device, void *ptr_dev)
     return LF_OK;
 }
 
+static int side_join(lf_device_ctx *c);
+
 int lf_memcpy_h2d(int device, void *dst_dev, const void *src_host, size_t bytes)
 {
     lf_device_ctx *c;
     LF_TRY(lf_ctx(device, &c));
+    LF_TRY(side_join(c));
     if (bytes) {
         LF_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, c->stream));
         LF_HIP(hipStreamSynchronize(c->stream));
@@ -195,10 +198,65 @@ int lf_compute_release(int device, int set)
     return LF_OK;
 }
 
+// ---- side stream ---------------------------------------------------------------------------------------------------------
+// lf_side_stream_begin: every library call from now on (kernels, memsets, copies -- they all take the context's stream)
+// goes to the side stream, behind everything enqueued on the main stream so far.  lf_side_stream_end: back to the main
+// stream; the side work stays in flight BESIDE what the main stream gets next.  lf_side_stream_join: the main stream waits
+// for the side work issued so far.  The copies of this file join by themselves when they run on the main stream, so a
+// download never sees a vector the side stream is still writing; a caller that enqueues a KERNEL on the main stream which
+// touches such a vector joins first.  One thread per device context, as everywhere in this library.
+static int side_join(lf_device_ctx *c)
+{
+    if (c->side_pending && !c->side_active) {
+        LF_HIP(hipStreamWaitEvent(c->stream, c->ev_side_done, 0));
+        c->side_pending = false;
+    }
+    return LF_OK;
+}
+
+int lf_side_stream_begin(int device)
+{
+    lf_device_ctx *c;
+    LF_TRY(lf_ctx(device, &c));
+    if (c->side_active) return lf_set_error(LF_E_INVALID, "the side stream is already active");
+    if (!c->side_stream) {
+        LF_HIP(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+        LF_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        LF_HIP(hipEventCreateWithFlags(&c->ev_side_done, hipEventDisableTiming));
+    }
+    LF_HIP(hipEventRecord(c->ev_fork, c->stream));
+    LF_HIP(hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
+    c->main_stream = c->stream;
+    c->stream = c->side_stream;
+    c->side_active = true;
+    return LF_OK;
+}
+
+int lf_side_stream_end(int device)
+{
+    lf_device_ctx *c;
+    LF_TRY(lf_ctx(device, &c));
+    if (!c->side_active) return lf_set_error(LF_E_INVALID, "the side stream is not active");
+    LF_HIP(hipEventRecord(c->ev_side_done, c->side_stream));
+    c->stream = c->main_stream;
+    c->side_active = false;
+    c->side_pending = true;
+    return LF_OK;
+}
+
+int lf_side_stream_join(int device)
+{
+    lf_device_ctx *c;
+    LF_TRY(lf_ctx(device, &c));
+    if (c->side_active) return lf_set_error(LF_E_INVALID, "join from inside the side section");
+    return side_join(c);
+}
+
 int lf_memcpy_d2h(int device, void *dst_host, const void *src_dev, size_t bytes)
 {
     lf_device_ctx *c;
     LF_TRY(lf_ctx(device, &c));
+    LF_TRY(side_join(c));
     if (bytes) {
         LF_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
         LF_HIP(hipStreamSynchronize(c->stream));
@@ -210,6 +268,7 @@ int lf_memcpy_d2d(int device, void *dst_dev, const void *src_dev, size_t bytes)
 {
     lf_device_ctx *c;
     LF_TRY(lf_ctx(device, &c));
+    LF_TRY(side_join(c));
     if (bytes) LF_HIP(hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, c->stream));
     return LF_OK;
 }
@@ -228,6 +287,7 @@ int lf_device_synchronize(int device)
     LF_TRY(lf_ctx(device, &c));
     LF_HIP(hipStreamSynchronize(c->stream));
     LF_HIP(hipDeviceSynchronize());
+    if (!c->side_active) c->side_pending = false;
     return LF_OK;
 }
 

@@ -29,7 +29,7 @@ _CHANNEL_NAMES = set(RT._STATIC + RT._STATE + RT._OUT)
 
 class HotPathDevice:
     def __init__(self, values, scalars, land_mask, ldd_to_chan, ldd_kinematic, split=True, device=0, structures=None,
-                 compact=True):
+                 compact=True, overlap_channel=True):
         """values: name -> host array in pixel order ([N], [3,N]) for every vector of the stages (reference
         attribute names); scalars: Beta, DtSec, DtRouting, NoRoutSteps, DtDay, PixelLength, MMtoM3, M3toMM,
         LeafDrainageK, AvWaterThreshold, CourantCrit, DrainedFraction, InvDtDay.  ldd_to_chan / ldd_kinematic:
@@ -40,6 +40,9 @@ class HotPathDevice:
         compact: leave inert pixels out of the channel router's domain (see inert_pixels): on real domains most land
         pixels are not channel pixels, and the channel wavefront then touches only the ones that are."""
         self.device, self.split = device, bool(split)
+        # overlap_channel: the channel wavefront of a step on a second HIP stream, beside the canopy / soil / overland kernels
+        # of the step after it (same kernels, same results; False: one stream, as rounds 1-3)
+        self.overlap_channel = bool(overlap_channel)
         self.rmod = None
         self.sc = dict(scalars)
         land_mask = np.asarray(land_mask, bool)
@@ -229,18 +232,32 @@ class HotPathDevice:
         self.pixel.TimeSinceStart = float(time_since_start if time_since_start else self.steps_done)
         check(L.lf_pixel_aggregates_device(C.c_int(dev), C.byref(self.pixel)))                          # dyn.py:129-149
         check(L.lf_surface_step(self.r_direct._h, self.r_other._h, self.r_forest._h, C.byref(self.surface)))  # :165
-        d["sumDisDay"].zero()                                                                           # dyn.py:177
+        # The channel wavefront reads nothing but its own vectors and the sideflow gathered below, and nothing of the NEXT
+        # step's canopy / soil / aggregate / overland kernels reads a channel vector: it runs on the side stream, beside
+        # them (a latency-bound chain of small launches beside bandwidth-bound streaming kernels).  Before the gather
+        # overwrites the sideflow the main stream waits for the wavefront of the step before; downloads join by themselves.
+        check(L.lf_side_stream_join(C.c_int(dev)))
         if self.rmod is not None:       # lakes / reservoirs / inflow / transmission loss inside the wavefront
             m = self.rmod
             check(L.lf_gather_device(C.c_int(dev), C.c_int64(self.Nk), self._gidx.ptr, d["ToChanM3RunoffDt"].ptr,
                                      m._st["dev"]["ToChanM3RunoffDt"].ptr))
-            check(L.lf_routing_substeps_fused_structures(self.river._h, C.byref(m._args), C.byref(m._inloop),
-                                                         C.c_int(int(self.sc["NoRoutSteps"]))))          # dyn.py:179-180
-            return
-        check(L.lf_gather_device(C.c_int(dev), C.c_int64(self.Nk), self._gidx.ptr, d["ToChanM3RunoffDt"].ptr,
-                                 d["SideflowChanM3"].ptr))
-        check(L.lf_routing_substeps_fused(self.river._h, C.byref(self.rout), C.c_int(int(self.sc["NoRoutSteps"])),
-                                          C.c_int64(0)))                                                # dyn.py:179-180
+        else:
+            check(L.lf_gather_device(C.c_int(dev), C.c_int64(self.Nk), self._gidx.ptr, d["ToChanM3RunoffDt"].ptr,
+                                     d["SideflowChanM3"].ptr))
+        if self.overlap_channel:
+            check(L.lf_side_stream_begin(C.c_int(dev)))
+        try:
+            d["sumDisDay"].zero()                                                                       # dyn.py:177
+            if self.rmod is not None:
+                m = self.rmod
+                check(L.lf_routing_substeps_fused_structures(self.river._h, C.byref(m._args), C.byref(m._inloop),
+                                                             C.c_int(int(self.sc["NoRoutSteps"]))))      # dyn.py:179-180
+            else:
+                check(L.lf_routing_substeps_fused(self.river._h, C.byref(self.rout), C.c_int(int(self.sc["NoRoutSteps"])),
+                                                  C.c_int64(0)))                                        # dyn.py:179-180
+        finally:
+            if self.overlap_channel:
+                check(L.lf_side_stream_end(C.c_int(dev)))
 
     def download(self, name):
         a = self.d[name].download()
