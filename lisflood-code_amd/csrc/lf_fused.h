@@ -187,7 +187,7 @@ __device__ __forceinline__ void fused_cell(const fused_args &F, long long p, int
         }
         if (I.UpTrans) {
             const double qc = A.ChanQ[p];
-            const double tout = I.UpTrans[p] ? pow(pow(qc, I.TransPower2) - I.TransSub, I.TransPower1) : qc;
+            const double tout = I.UpTrans[p] ? lf_pow_scalar_exponent(lf_pow_scalar_exponent(qc, I.TransPower2) - I.TransSub, I.TransPower1) : qc;
             loss = (qc - tout) * I.DtRouting;
             trans_cum = I.TransCum[p] + loss;
             side_m3 -= loss;
@@ -528,8 +528,8 @@ __device__ __forceinline__ void cone_compute(const fused_args &F, const cone_cel
             const double qc = R.chanq_old;
             double tout = qc;
             if (R.uptrans_raw) {
-                const double inner = (ALL35 ? cold_pow(qc, I.TransPower2) : pow(qc, I.TransPower2)) - I.TransSub;
-                tout = ALL35 ? cold_pow(inner, I.TransPower1) : pow(inner, I.TransPower1);
+                const double inner = lf_pow_scalar_exponent(qc, I.TransPower2) - I.TransSub;
+                tout = lf_pow_scalar_exponent(inner, I.TransPower1);
             }
             O.loss = (qc - tout) * I.DtRouting;
             O.trans_cum = R.transcum + O.loss;
@@ -1006,8 +1006,8 @@ __global__ void __launch_bounds__(64 * (1 + KC)) k_fused_cones_split(fused_args 
                     const double qc = P.chanq_old;
                     double tout = qc;
                     if (P.uptrans) {
-                        const double inner = cold_pow(qc, I.TransPower2) - I.TransSub;
-                        tout = cold_pow(inner, I.TransPower1);
+                        const double inner = lf_pow_scalar_exponent(qc, I.TransPower2) - I.TransSub;
+                        tout = lf_pow_scalar_exponent(inner, I.TransPower1);
                     }
                     loss = (qc - tout) * I.DtRouting;
                     trans_cum = P.transcum + loss;

@@ -303,3 +303,14 @@ __device__ __forceinline__ double lf_pow_pos(double x, double y)
     lf_pow_pos_n<1>(xs, ys, r);
     return r[0];
 }
+
+// x^y of the transmission loss (transmission.py:76-87: (Q^p2 - sub)^p1, both exponents scalars of the settings): lf_pow_pos
+// for a finite positive exponent (x < 0 or NaN -> NaN, 0 -> 0, as pow), OCML pow otherwise.  ~75 instead of ~220
+// instructions per call; every kernel that computes the loss goes through here, so they stay bit-identical to one another.
+// Out of line: inlined twice into the cone kernels it cost them 30 VGPRs (spills in k_fused_cones<STRUCT>, one wavefront
+// per SIMD in k_fused_cones_split<STRUCT>).
+static __device__ __attribute__((noinline)) double lf_pow_scalar_exponent(double x, double y)
+{
+    if (y > 0.0 && y < 1e6) return lf_pow_pos(x, y); // (uniform: y is a kernel argument)
+    return pow(x, y);
+}

@@ -267,7 +267,7 @@ __global__ void __launch_bounds__(kBlock) k_inloop_dense(lf_inloop_args A)
     }
     if (A.UpTrans) {
         const double q = A.ChanQ[p];
-        const double tout = A.UpTrans[p] ? pow(pow(q, A.TransPower2) - A.TransSub, A.TransPower1) : q;
+        const double tout = A.UpTrans[p] ? lf_pow_scalar_exponent(lf_pow_scalar_exponent(q, A.TransPower2) - A.TransSub, A.TransPower1) : q;
         const double loss = (q - tout) * A.DtRouting;
         A.TransLossM3Dt[p] = loss;
         A.TransCum[p] += loss;
