@@ -269,6 +269,22 @@ def main(a):
                          "traffic": None},
             "checksum_sumQ": float(chk[0]), "finite": bool(chk[1] == world),
         }
+    printed = [False]
+
+    def emit():             # the ONE JSON line (rank 0), whatever happened after the headline was measured
+        if rank == 0 and out is not None and not printed[0]:
+            printed[0] = True
+            out["peak_host_memory_gb_rank0"] = round(peak_rss_gb(), 2)
+            _flush_c_stdio()
+            print(json.dumps(out), flush=True)
+    if rank == 0:           # an exception nobody caught, SIGTERM from a launcher that lost another rank: the line still goes out
+        import atexit
+        import signal
+        atexit.register(emit)
+        try:
+            signal.signal(signal.SIGTERM, lambda *_: (emit(), os._exit(1)))
+        except (ValueError, OSError):
+            pass
     # configs[4]'s workload shape on the SAME row blocks: a model step of 24 split-routing sub-steps, every sub-step of a
     # phase as one wavefront (level blocks + cones), ONE RCCL halo block per phase and model step
     row_step = None
@@ -301,7 +317,4 @@ def main(a):
         T.close()
     except Exception as e:
         log(rank, "shutdown: %r" % (e,))
-    _flush_c_stdio()
-    if rank == 0:           # the ONE JSON line, last on stdout
-        out["peak_host_memory_gb_rank0"] = round(peak_rss_gb(), 2)
-        print(json.dumps(out), flush=True)
+    emit()                  # the ONE JSON line, last on stdout
