@@ -440,6 +440,7 @@ int lf_dist_graph_finalize(lf_dist_graph *g, int nphases)
         int lmax = 16;
         if (const char *e = std::getenv("LF_FUSED_LEVELS")) lmax = std::atoi(e);
         lmax = lmax < 1 ? 1 : (lmax > 64 ? 64 : lmax);
+        if ((int64_t)n >= ((int64_t)1 << 29)) lmax = 1; // k_fused_cones: 32-bit byte offsets (see build_level_blocks)
         int64_t wide = 262144;
         if (const char *e = std::getenv("LF_FUSED_WIDE")) wide = std::atoll(e);
         g->fplan = lf_block_plan();

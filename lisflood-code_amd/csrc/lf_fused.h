@@ -355,78 +355,119 @@ struct cone_cell { // what a cell's load phase leaves in registers: loaded value
     bool active;
 };
 
+// The loads and stores of a cone level (round 4).  A wavefront of this kernel is bound by its own instruction stream (one
+// instruction at a time: profiles/pmc_r04g_fused_deep_5000.txt counts ~1 300 per level, more scalar than vector), so what
+// a level's ~35 loads and ~10 stores cost in instructions AROUND them is what matters:
+//  * address = array pointer (scalar registers) + 32-bit byte offset of the cell (one vector register for all arrays of
+//    an element size): the `saddr` form of global_load / global_store, no address arithmetic per array (the fused plan is
+//    only built for graphs below 2^29 cells, build_fused_blocks);
+//  * ONE divergent region around all loads (lanes beyond the cone) and no uniform branch per optional vector: an array
+//    that a uniform condition switches off, or whose pointer is null, is read from a stand-in (the channel lengths: any
+//    valid array of the size) and the value ignored -- what must read 0 then is zeroed in cone_fix, behind the wait.  The
+//    pointer loads from the kernel-argument segment then come in batches in front of the loads (a handful of
+//    scalar-memory waits per level instead of ~25).
+struct cone_range { // one level of a cone: cells [first, first + cnt)
+    long long first;
+    int cnt;
+};
+struct cone_at { // this lane's cell of the level: byte offsets into arrays of 8-, 4- and 1-byte elements
+    unsigned o8, o4, o1;
+    const char *standin;
+};
+__device__ __forceinline__ double cone_ld(const double *base, const cone_at &P) { return *(const double *)((const char *)base + P.o8); }
+__device__ __forceinline__ double cone_ld(const double *base, const cone_at &P, bool on)
+{
+    return *(const double *)(((on && base) ? (const char *)base : P.standin) + P.o8);
+}
+__device__ __forceinline__ unsigned char cone_ld(const uint8_t *base, const cone_at &P) { return *((const uint8_t *)base + P.o1); }
+__device__ __forceinline__ unsigned char cone_ld(const uint8_t *base, const cone_at &P, bool on)
+{
+    return *(const uint8_t *)(((on && base) ? (const char *)base : P.standin) + P.o1);
+}
+__device__ __forceinline__ int cone_ld(const int *base, const cone_at &P, unsigned plus = 0)
+{
+    return *(const int *)((const char *)base + P.o4 + plus);
+}
+__device__ __forceinline__ void cone_st(double *base, unsigned o8, double v) { *(double *)((char *)base + o8) = v; }
+
+// loads only: nothing here may look at a loaded value (cone_fix does, after the wait)
 template <bool SPLIT, bool STRUCT, bool DIST = false>
-__device__ __forceinline__ void cone_load(const fused_args &F, long long p, int s, bool active, cone_cell &R, bool rc = false,
+__device__ __forceinline__ void cone_load(const fused_args &F, const cone_range &L, int tid, int s, cone_cell &R, bool rc = false,
                                           bool dx_is_len = false)
 {
     const lf_substep_args &A = F.S;
-    R.active = active;
+    R.active = tid < L.cnt;
+    if (!R.active) return;
+    const unsigned cell = (unsigned)L.first + (unsigned)tid;
+    const cone_at P = {cell * 8u, cell * 4u, cell, (const char *)A.ChanLength};
+    R.u0 = cone_ld(F.ups_ptr, P);
+    R.u1 = cone_ld(F.ups_ptr, P, 4u);
     R.base = R.slot = -1;
-    if (!active) return;
-    R.u0 = F.ups_ptr[p];
-    R.u1 = F.ups_ptr[p + 1];
     if (DIST) {
-        R.base = F.d_ups_base[p];
-        R.slot = F.d_out_slot[p];
+        R.base = cone_ld(F.d_ups_base, P);
+        R.slot = cone_ld(F.d_out_slot, P);
     }
-    R.dxp = (F.dx && !dx_is_len) ? F.dx[p] : F.dx_scalar; // dx_is_len: taken from ChanLength below (same bits)
-    R.inv_len = rc ? 0.0 : A.InvChanLength[p]; // rc: cone_derive fills the five derived values in from len / alpha / dx
-    R.len = A.ChanLength[p];
-    if (dx_is_len) R.dxp = R.len;
-    R.chan_raw = A.IsChannelKinematic[p];
-    R.chanq_old = R.csa_old = R.sf1_old = 0;
-    R.inert_raw = R.uptrans_raw = R.cut_raw = 0;
-    R.eva = R.wuse = R.qin_old = R.qdelta = R.qin_added_old = R.transcum = R.lakeout = R.resout = R.polder = 0;
-    if (!STRUCT)
-        R.side_m3 = A.SideflowChanM3[(long long)s * F.side_stride + p];
-    else {
-        const lf_inloop_args &I = F.I;
-        R.side_m3 = I.ToChanM3RunoffDt[p];
-        if (I.EvaAddM3Dt) R.eva = I.EvaAddM3Dt[p];
-        if (I.WUseAddM3Dt) R.wuse = I.WUseAddM3Dt[p];
-        if (I.QInM3Old) {
-            R.qin_old = I.QInM3Old[p];
-            R.qdelta = I.QDelta[p];
-            R.qin_added_old = I.QinADDEDM3[p];
-        }
-        if (I.UpTrans) {
-            R.chanq_old = A.ChanQ[p];
-            R.uptrans_raw = I.UpTrans[p];
-            R.transcum = I.TransCum[p];
-        }
-        if (I.QLakeOutM3Dt) R.lakeout = I.QLakeOutM3Dt[p];
-        if (I.QResOutM3Dt) R.resout = I.QResOutM3Dt[p];
-        if (I.ChannelToPolderM3Dt) R.polder = I.ChannelToPolderM3Dt[p];
-    }
-    if (F.linked) R.cut_raw = F.linked[p]; // (also without STRUCT: a sub-step at a time on a graph with structure links)
-    R.ap1 = rc ? 0.0 : F.a1[p];
-    R.qold = A.ChanQKin[p];
-    R.alpha1 = A.ChannelAlpha[p];
-    R.inv_alpha1 = rc ? 0.0 : A.InvChannelAlpha[p];
-    R.sum_old = A.sumDisDay[p];
-    R.m3 = R.m3_2 = R.start = R.m3limit = R.q2start = R.ap2 = R.q2old = R.alpha2 = R.inv_alpha2 = R.qlimit = 0;
+    R.dxp = cone_ld(F.dx, P, !dx_is_len); // no per-cell dx / dx_is_len: cone_fix puts the scalar / the length there
+    R.inv_len = cone_ld(A.InvChanLength, P, !rc); // rc: cone_derive fills the five derived values in from len / alpha / dx
+    R.len = cone_ld(A.ChanLength, P);
+    R.chan_raw = cone_ld(A.IsChannelKinematic, P);
     const bool test_inert = !STRUCT && F.inert && s != F.nsteps - 1; // see k_inert_flags / fused_cell (uniform)
-    if (SPLIT || test_inert) R.m3 = A.ChanM3Kin[p];
+    R.eva = R.wuse = R.qin_old = R.qdelta = R.qin_added_old = R.transcum = R.lakeout = R.resout = R.polder = 0;
+    R.uptrans_raw = 0;
+    if (!STRUCT)
+        R.side_m3 = cone_ld(A.SideflowChanM3 + (long long)s * F.side_stride, P);
+    else { // (absent vectors: the stand-in's value, which cone_compute does not look at -- it tests the same pointers)
+        const lf_inloop_args &I = F.I;
+        R.side_m3 = cone_ld(I.ToChanM3RunoffDt, P);
+        R.eva = cone_ld(I.EvaAddM3Dt, P, true);
+        R.wuse = cone_ld(I.WUseAddM3Dt, P, true);
+        R.qin_old = cone_ld(I.QInM3Old, P, true);
+        R.qdelta = cone_ld(I.QDelta, P, I.QInM3Old != nullptr);
+        R.qin_added_old = cone_ld(I.QinADDEDM3, P, I.QInM3Old != nullptr);
+        R.uptrans_raw = cone_ld(I.UpTrans, P, true);
+        R.transcum = cone_ld(I.TransCum, P, I.UpTrans != nullptr);
+        R.lakeout = cone_ld(I.QLakeOutM3Dt, P, true);
+        R.resout = cone_ld(I.QResOutM3Dt, P, true);
+        R.polder = cone_ld(I.ChannelToPolderM3Dt, P, true);
+    }
+    // ChanQ before the sub-step: STRUCT -- transmission loss; else the inert test
+    R.chanq_old = cone_ld(A.ChanQ, P, STRUCT ? F.I.UpTrans != nullptr : test_inert);
+    R.cut_raw = cone_ld(F.linked, P, true); // (also without STRUCT: a sub-step at a time on a graph with structure links)
+    R.ap1 = cone_ld(F.a1, P, !rc);
+    R.qold = cone_ld(A.ChanQKin, P);
+    R.alpha1 = cone_ld(A.ChannelAlpha, P);
+    R.inv_alpha1 = cone_ld(A.InvChannelAlpha, P, !rc);
+    R.sum_old = cone_ld(A.sumDisDay, P);
+    R.m3 = cone_ld(A.ChanM3Kin, P, SPLIT || test_inert);
+    R.m3_2 = R.start = R.m3limit = R.q2start = R.ap2 = R.q2old = R.alpha2 = R.inv_alpha2 = R.qlimit = 0;
+    R.csa_old = R.sf1_old = 0;
     if (SPLIT) {
-        R.m3_2 = A.Chan2M3Kin[p];
-        R.start = A.Chan2M3Start[p];
-        R.m3limit = A.M3Limit[p];
-        R.q2start = A.Chan2QStart[p];
-        R.ap2 = rc ? 0.0 : F.a2[p];
-        R.q2old = A.Chan2QKin[p];
-        R.alpha2 = A.ChannelAlpha2[p];
-        R.inv_alpha2 = rc ? 0.0 : A.InvChannelAlpha2[p];
-        R.qlimit = A.QLimit[p];
+        R.m3_2 = cone_ld(A.Chan2M3Kin, P);
+        R.start = cone_ld(A.Chan2M3Start, P);
+        R.m3limit = cone_ld(A.M3Limit, P);
+        R.q2start = cone_ld(A.Chan2QStart, P);
+        R.ap2 = cone_ld(F.a2, P, !rc);
+        R.q2old = cone_ld(A.Chan2QKin, P);
+        R.alpha2 = cone_ld(A.ChannelAlpha2, P);
+        R.inv_alpha2 = cone_ld(A.InvChannelAlpha2, P, !rc);
+        R.qlimit = cone_ld(A.QLimit, P);
+        R.csa_old = cone_ld(A.CrossSection2Area, P, test_inert);
+        R.sf1_old = cone_ld(A.Sideflow1Chan, P, test_inert);
     }
-    R.pix_area = (s == F.nsteps - 1) ? A.PixelArea[p] : 0.0;
-    if (test_inert) {
-        R.inert_raw = F.inert[p];
-        R.chanq_old = A.ChanQ[p];
-        if (SPLIT) {
-            R.csa_old = A.CrossSection2Area[p];
-            R.sf1_old = A.Sideflow1Chan[p];
-        }
-    }
+    R.pix_area = cone_ld(A.PixelArea, P, s == F.nsteps - 1);
+    R.inert_raw = cone_ld(F.inert, P, test_inert);
+}
+
+// behind the wait for a level's loads: what depends on uniform conditions AND on loaded values
+template <bool STRUCT>
+__device__ __forceinline__ void cone_fix(const fused_args &F, cone_cell &R, int s, bool dx_is_len)
+{
+    if (dx_is_len)
+        R.dxp = R.len; // (same bits as the per-cell dx, see derived_flags)
+    else if (!F.dx)
+        R.dxp = F.dx_scalar;
+    if (!F.linked) R.cut_raw = 0; // the flags whose vectors may be absent or switched off read a stand-in
+    if (STRUCT || !F.inert || s == F.nsteps - 1) R.inert_raw = 0;
 }
 
 // fused_args::recompute: the five derived statics from the three loaded ones (same operations as the host's)
@@ -551,6 +592,27 @@ __device__ __forceinline__ void cone_compute(const fused_args &F, const cone_cel
         if (fabs(side) < 1e-7) s1 = side;
         s2 = (side - s1) + R.q2start * R.inv_len;
     }
+#ifdef LF_EXP_NO_MATH /* timing experiment only (wrong results): the loads, stores and exchanges without the solves and powers */
+    const double cst = R.ap1 * R.qold + s1 * R.dxp;
+    const double c = ups1 + cst;
+    const double qr = c * 0.25;
+    double v = R.len * R.alpha1 * qr;
+    if (v < 0.0) v = 0.0;
+    const double x = v * R.inv_len * R.inv_alpha1;
+    const double q = x;
+    double chanq = q, q2r = 0, v2 = 0, q2 = 0;
+    if (SPLIT) {
+        const double cst2 = R.ap2 * R.q2old + s2 * R.dxp;
+        const double c2 = ups2 + cst2;
+        q2r = c2 * 0.25;
+        v2 = R.len * R.alpha2 * q2r;
+        if ((v2 - R.start) < 0.0) v2 = R.start;
+        const double x2 = v2 * R.inv_len * R.inv_alpha2;
+        q2 = x2;
+        chanq = q + q2 - R.qlimit;
+        if (chanq < 0.0) chanq = 0.0;
+    }
+#else
     const double cst = R.ap1 * cone_pow_3_5<ALL35>(R.qold, F.beta, s35) + s1 * R.dxp;
     const double c = ups1 + cst;
     const double qr = cone_solve<ALL35>(c, R.ap1, s35, F);
@@ -570,6 +632,7 @@ __device__ __forceinline__ void cone_compute(const fused_args &F, const cone_cel
         chanq = q + q2 - R.qlimit;
         if (chanq < 0.0) chanq = 0.0;
     }
+#endif
     qr_out = qr;
     q2r_out = q2r;
     O.valid = true;
@@ -597,39 +660,68 @@ __device__ __forceinline__ void cone_compute(const fused_args &F, const cone_cel
     }
 }
 
+// the state a level leaves behind (cells without a result -- beyond the cone, skipped -- store nothing)
 template <bool SPLIT, bool STRUCT>
 __device__ __forceinline__ void cone_store(const fused_args &F, const cone_out &O, int s)
 {
     if (!O.valid) return;
     const lf_substep_args &A = F.S;
-    const long long p = O.p;
+    const unsigned o8 = (unsigned)O.p * 8u;
     if (STRUCT) {
         const lf_inloop_args &I = F.I;
         if (I.QInM3Old) {
-            I.QInDt[p] = O.qin;
-            I.QinADDEDM3[p] = O.qin_added;
+            cone_st(I.QInDt, o8, O.qin);
+            cone_st(I.QinADDEDM3, o8, O.qin_added);
         }
         if (I.UpTrans) {
-            I.TransLossM3Dt[p] = O.loss;
-            I.TransCum[p] = O.trans_cum;
+            cone_st(I.TransLossM3Dt, o8, O.loss);
+            cone_st(I.TransCum, o8, O.trans_cum);
         }
-        I.SideflowChanM3[p] = O.side_m3;
+        cone_st(I.SideflowChanM3, o8, O.side_m3);
     }
-    const bool keep = STRUCT || s == F.nsteps - 1; // see fused_cell: intermediate values nobody reads are not stored
-    A.ChanM3Kin[p] = O.v;
-    A.ChanQKin[p] = O.q;
-    if (keep) A.ChanQ[p] = O.chanq;
-    A.sumDisDay[p] = O.sum;
+    const bool last = s == F.nsteps - 1;
+    cone_st(A.ChanM3Kin, o8, O.v);
+    cone_st(A.ChanQKin, o8, O.q);
+    cone_st(A.sumDisDay, o8, O.sum);
     if (SPLIT) {
-        if (keep) A.Sideflow1Chan[p] = O.s1;
-        A.Chan2M3Kin[p] = O.v2;
-        if (keep) A.CrossSection2Area[p] = O.csa;
-        A.Chan2QKin[p] = O.q2;
+        cone_st(A.Chan2M3Kin, o8, O.v2);
+        cone_st(A.Chan2QKin, o8, O.q2);
     }
-    if (s == F.nsteps - 1) {
-        A.FlowVelocity[p] = O.vel;
-        A.TravelDistance[p] = O.trav;
+    if (STRUCT || last) { // see fused_cell: intermediate values nobody reads are not stored
+        cone_st(A.ChanQ, o8, O.chanq);
+        if (SPLIT) {
+            cone_st(A.Sideflow1Chan, o8, O.s1);
+            cone_st(A.CrossSection2Area, o8, O.csa);
+        }
     }
+    if (last) {
+        cone_st(A.FlowVelocity, o8, O.vel);
+        cone_st(A.TravelDistance, o8, O.trav);
+    }
+}
+
+// Workgroups go to the eight XCDs round robin by their linear id.  Neighbouring cones of a block share the 128-byte lines
+// their level segments begin and end in (a segment of 64 cells = 4 lines + on average one shared): with the cones of a
+// (block, sub-step) dealt out in launch order the two halves of such a line are fetched into two L2s.  This gives the
+// workgroups of one XCD CONSECUTIVE cones of the range [0, n) instead (i: position in launch order, linear_id: of this
+// workgroup; a bijection of [0, n)).  -DLF_XCD_REMAP=0: launch order (A/B builds).
+#ifndef LF_XCD_REMAP
+#define LF_XCD_REMAP 1
+#endif
+__device__ __forceinline__ int xcd_contiguous(int i, int n, unsigned linear_id)
+{
+    if (!LF_XCD_REMAP || i >= n) return i;
+    const unsigned start = linear_id - (unsigned)i; // linear id of position 0
+    const int cls = (int)(linear_id & 7u);
+    int before = 0, r_mine = 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int r = (int)(((unsigned)c - start) & 7u); // first position of class c
+        const int cnt = r < n ? (n - r + 7) >> 3 : 0;
+        before += c < cls ? cnt : 0;
+        r_mine = c == cls ? r : r_mine;
+    }
+    return before + ((i - r_mine) >> 3);
 }
 
 // LDS barrier: the wavefronts of the workgroup have finished their LDS writes; global stores keep draining
@@ -668,6 +760,7 @@ __global__ void __launch_bounds__(CW) __attribute__((amdgpu_waves_per_eu(LF_CONE
     // the plan is read through the constant address space: scalar loads, no vector-memory wait on the way (ld_table)
     const int row0 = ld_table(F.fb_row, b), ncones = ld_table(F.fb_row, b + 1) - row0 - 1;
     if (blk >= ncones) return;
+    blk = xcd_contiguous(blk, ncones, blockIdx.x + blockIdx.y * gridDim.x);
     const int nl = ld_table(F.fb_level, b + 1) - ld_table(F.fb_level, b);
     const int *c0 = F.fb_cone + (size_t)ld_table(F.fb_off, b) + (size_t)blk * nl, *c1 = c0 + nl; // this cone / the next
     const int kmax = F.kmax;
@@ -677,6 +770,7 @@ __global__ void __launch_bounds__(CW) __attribute__((amdgpu_waves_per_eu(LF_CONE
     const bool rc = (dflags & 1u) != 0u, dx_is_len = (dflags & 2u) != 0u;
     cone_out pend;
     pend.valid = false;
+    pend.p = 0;
     int first_up = 0; // first position of the level above (LDS index 0)
     // One level of the cone: `cur` holds the loaded state of this thread's cell of level j, `nxt` receives that of level
     // j + 1.  The loop below calls it with the two register sets swapping roles (no copies).
@@ -702,11 +796,11 @@ __global__ void __launch_bounds__(CW) __attribute__((amdgpu_waves_per_eu(LF_CONE
         // arithmetic, the stores' acknowledgement would be waited for on every level).
         cone_store<SPLIT, STRUCT>(F, pend, s);
         pend.valid = false;
-        int nfirst = 0;
-        if (j + 1 < nl) { // nothing of the next level's state depends on this launch
-            nfirst = ld_table(c0, j + 1);
-            cone_load<SPLIT, STRUCT, DIST>(F, nfirst + tid, s, nfirst + tid < ld_table(c1, j + 1), nxt, rc, dx_is_len);
-        }
+        // nothing of the next level's state depends on this launch (behind the last level: an empty range, nothing loaded)
+        const int jn = j + 1 < nl ? j + 1 : j;
+        const int nfirst = ld_table(c0, jn);
+        const cone_range nrng = {nfirst, j + 1 < nl ? ld_table(c1, jn) - nfirst : 0};
+        cone_load<SPLIT, STRUCT, DIST>(F, nrng, tid, s, nxt, rc, dx_is_len);
         if (!cone_skip<SPLIT>(cur)) {
             double ups1, ups2 = 0.0;
             // row-block partition: the upstream cells are the consecutive local run [base, base + count) -- a run of ghost
@@ -785,14 +879,19 @@ __global__ void __launch_bounds__(CW) __attribute__((amdgpu_waves_per_eu(LF_CONE
         // the loads of the next level (issued before this level's arithmetic) and the stores of the previous one: done
         // by now.  Stated explicitly so that the compiler does not wait for `nxt` behind the NEXT level's stores.
         __builtin_amdgcn_s_waitcnt(0x0F70);
-        if (rc && j + 1 < nl) cone_derive<SPLIT>(F, nxt); // off the next level's chain: before its barrier
+        cone_fix<STRUCT>(F, nxt, s, dx_is_len);
+        if (rc) cone_derive<SPLIT>(F, nxt); // off the next level's chain: before its barrier
         first_up = first;
         return nfirst;
     };
     cone_cell ra, rb;
     int first = ld_table(c0, 0);
-    cone_load<SPLIT, STRUCT, DIST>(F, first + tid, s, first + tid < ld_table(c1, 0), ra, rc, dx_is_len);
+    {
+        const cone_range rng0 = {first, ld_table(c1, 0) - first};
+        cone_load<SPLIT, STRUCT, DIST>(F, rng0, tid, s, ra, rc, dx_is_len);
+    }
     __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): inside the loop the current level's registers are always complete
+    cone_fix<STRUCT>(F, ra, s, dx_is_len);
     if (rc) cone_derive<SPLIT>(F, ra);
     for (int j = 0; j < nl; j += 2) {
         first = level(j, ra, rb, first);

@@ -616,7 +616,9 @@ static int build_level_blocks(lf_router *r, const lf_graph *g, bool for_route)
     int64_t wide = 262144;
     if (const char *e = std::getenv("LF_FUSED_WIDE")) wide = std::atoll(e);
     const int64_t NL = g->NL;
-    if (lmax <= 1 || NL < 2 || g->N >= ((int64_t)1 << 31)) return LF_OK;
+    // (the fused cone kernels address a cell by a 32-bit byte offset into its arrays: below 2^29 cells; a larger graph keeps
+    // the level-by-level wavefront)
+    if (lmax <= 1 || NL < 2 || g->N >= ((int64_t)1 << (for_route ? 31 : 29))) return LF_OK;
     int cw = kBlock;
     if (for_route) { // one wavefront per cone: no barrier between the levels (deep 10 000^2: 11.3 -> 10.1 ms per call)
         cw = 64;
@@ -1501,12 +1503,13 @@ int fused_impl(lf_router *r, const lf_substep_args *a, int nsteps, int64_t sidef
             LF_CONES_CW(ST, kBlock);                                                                         \
     } while (0)
                 // The chain / supply form (lf_fused.h: k_fused_cones_split) where it applies and where the launch is
-                // chain-bound: up to ~1600 cones in flight (24 sub-steps x 4000 cells per level) it is 1.1 - 1.8 x faster,
+                // chain-bound: up to ~1100 cones in flight (24 sub-steps x 2900 cells per level) it is 1.1 - 1.7 x faster,
                 // beyond that the launch is bound by throughput (three wavefronts and 31 KB of LDS per cone) and the
-                // one-wavefront kernel wins.  LF_FUSED_SPLIT=0 / 1: never / always (A/B switch).
+                // one-wavefront kernel wins (deep 2000^2, ~860 cones: 7.7 vs 8.7 ms per model step,
+                // 3000^2, ~1220: 15.9 vs 14.5).  LF_FUSED_SPLIT=0 / 1: never / always (A/B switch).
                 static const int64_t split_max = [] {
                     const char *e = std::getenv("LF_FUSED_SPLIT_MAX");
-                    return e ? std::atoll(e) : (long long)1600;
+                    return e ? std::atoll(e) : (long long)1100;
                 }();
                 // (with structures in the loop the supply wavefronts also carry the sideflow assembly and, on reaches with
                 // transmission loss, two OCML pow calls per cell: the crossover is lower -- 3000^2 with 256 sites: 5.5 vs 8.2 ms

@@ -45,7 +45,8 @@ for rep in range(2):
         same = "-" if ref is None else ",".join(k for k in names if not np.array_equal(q[k], ref[k], equal_nan=True)) or "all identical"
         if ref is None:
             ref = q
-        print("%s %d^2 %d sub-steps split=%d LF_FUSED_SPLIT=%s: %.2f ms per model step  %.1f Gcell-steps/s  launches=%d  differing: %s" % (
-            fam, size, nsteps, split, mode, ms, (2 if split else 1) * nsteps * N / ms / 1e6, kw.last_launches()["launches"], same),
+        chk = sum(int(q[k].view(np.uint64).sum(dtype=np.uint64)) for k in names) & 0xffffffffffffffff  # across libraries
+        print("%s %d^2 %d sub-steps split=%d LF_FUSED_SPLIT=%s: %.2f ms per model step  %.1f Gcell-steps/s  launches=%d  differing: %s  bits %016x" % (
+            fam, size, nsteps, split, mode, ms, (2 if split else 1) * nsteps * N / ms / 1e6, kw.last_launches()["launches"], same, chk),
             flush=True)
         st.free()
