@@ -537,6 +537,54 @@ __device__ __forceinline__ double cone_solve(double c, double ap, bool is35, con
     return cold_solve(c, ap, F.beta * ap, F.beta, F.inv_beta, F.b_minus_1);
 }
 
+// beta = 3/5, BOTH lines (main channel, floodplain) of a cell stage by stage in straight code: the two independent chains
+// interleave in the instruction stream, and the lanes beyond the fast range (extreme values, NaN: rare) are redone in ONE
+// divergent region per stage instead of a branch around every power and solve (46 branches per level before).  Value by
+// value the operations of cone_pow_3_5 / cone_solve / cone_pow_5_3 <true>.  -DLF_CONE_MATH_TWO=0: the one-by-one forms.
+#ifndef LF_CONE_MATH_TWO
+#define LF_CONE_MATH_TWO 1
+#endif
+template <bool TWO>
+__device__ __forceinline__ void cone_pow_3_5_two(double x1, double x2, double &y1, double &y2)
+{
+    const bool f1 = lf_fast_range(x1), f2 = TWO && lf_fast_range(x2);
+    const double r1 = lf_root5(f1 ? x1 : 1.0), r2 = TWO ? lf_root5(f2 ? x2 : 1.0) : 0.0;
+    y1 = f1 ? r1 * r1 * r1 : 0.0; // (+-0 -> +0 as pow does: dry cells are common and stay on this path)
+    y2 = f2 ? r2 * r2 * r2 : 0.0;
+    const bool c1 = !f1 && x1 != 0.0, c2 = TWO && !f2 && x2 != 0.0;
+    if (c1 || c2) {
+        if (c1) y1 = cold_pow(x1, 0.6);
+        if (c2) y2 = cold_pow(x2, 0.6);
+    }
+}
+template <bool TWO>
+__device__ __forceinline__ void cone_pow_5_3_two(double x1, double x2, double &y1, double &y2)
+{
+    const bool f1 = lf_fast_range(x1), f2 = TWO && lf_fast_range(x2);
+    const double r1 = lf_cbrt(f1 ? x1 : 1.0), r2 = TWO ? lf_cbrt(f2 ? x2 : 1.0) : 0.0;
+    y1 = f1 ? x1 * (r1 * r1) : 0.0;
+    y2 = f2 ? x2 * (r2 * r2) : 0.0;
+    const bool c1 = !f1 && x1 != 0.0, c2 = TWO && !f2 && x2 != 0.0;
+    if (c1 || c2) {
+        if (c1) y1 = cold_pow(x1, 1.0 / 0.6);
+        if (c2) y2 = cold_pow(x2, 1.0 / 0.6);
+    }
+}
+template <bool TWO>
+__device__ __forceinline__ void cone_solve_two(double c1, double a1, double c2, double a2, const fused_args &F, double &q1,
+                                               double &q2)
+{
+    const bool g1 = lf_fast_range(c1) && lf_fast_range(a1), g2 = TWO && lf_fast_range(c2) && lf_fast_range(a2);
+    const double s1 = lf_solve_3_5(g1 ? c1 : 1.0, g1 ? a1 : 1.0);
+    const double s2 = TWO ? lf_solve_3_5(g2 ? c2 : 1.0, g2 ? a2 : 1.0) : 0.0;
+    q1 = (c1 <= LF_NEWTON_TOL) ? 0.0 : s1;
+    q2 = (c2 <= LF_NEWTON_TOL) ? 0.0 : s2;
+    if (!g1 || (TWO && !g2)) {
+        if (!g1) q1 = cold_solve(c1, a1, F.beta * a1, F.beta, F.inv_beta, F.b_minus_1);
+        if (TWO && !g2) q2 = cold_solve(c2, a2, F.beta * a2, F.beta, F.inv_beta, F.b_minus_1);
+    }
+}
+
 // everything after the loads of fused_cell<SPLIT, false>, in its order, up to the stores: the new state stays in
 // registers (cone_out) and is stored one level later, so that the stores have a whole level's arithmetic to drain
 struct cone_out {
@@ -613,24 +661,50 @@ __device__ __forceinline__ void cone_compute(const fused_args &F, const cone_cel
         if (chanq < 0.0) chanq = 0.0;
     }
 #else
-    const double cst = R.ap1 * cone_pow_3_5<ALL35>(R.qold, F.beta, s35) + s1 * R.dxp;
-    const double c = ups1 + cst;
-    const double qr = cone_solve<ALL35>(c, R.ap1, s35, F);
-    double v = R.len * R.alpha1 * cone_pow_3_5<ALL35>(qr, A.Beta, b35);
-    if (v < 0.0) v = 0.0;
-    const double x = v * R.inv_len * R.inv_alpha1;
-    const double q = cone_pow_5_3<ALL35>(x, A.InvBeta, b35);
-    double chanq = q, q2r = 0, v2 = 0, q2 = 0;
-    if (SPLIT) {
-        const double cst2 = R.ap2 * cone_pow_3_5<ALL35>(R.q2old, F.beta, s35) + s2 * R.dxp;
-        const double c2 = ups2 + cst2;
-        q2r = cone_solve<ALL35>(c2, R.ap2, s35, F);
-        v2 = R.len * R.alpha2 * cone_pow_3_5<ALL35>(q2r, A.Beta, b35);
-        if ((v2 - R.start) < 0.0) v2 = R.start;
-        const double x2 = v2 * R.inv_len * R.inv_alpha2;
-        q2 = cone_pow_5_3<ALL35>(x2, A.InvBeta, b35);
-        chanq = q + q2 - R.qlimit;
-        if (chanq < 0.0) chanq = 0.0;
+    double qr, q, v, chanq, q2r = 0, v2 = 0, q2 = 0;
+    if constexpr (ALL35 && LF_CONE_MATH_TWO) {
+        // beta = 3/5: both lines stage by stage in straight code (cone_*_two): the same operations per value as below
+        double pw1, pw2, pr1, pr2;
+        cone_pow_3_5_two<SPLIT>(R.qold, R.q2old, pw1, pw2);
+        const double c = ups1 + (R.ap1 * pw1 + s1 * R.dxp);
+        const double c2 = SPLIT ? ups2 + (R.ap2 * pw2 + s2 * R.dxp) : 0.0;
+        cone_solve_two<SPLIT>(c, R.ap1, c2, R.ap2, F, qr, q2r);
+        cone_pow_3_5_two<SPLIT>(qr, q2r, pr1, pr2);
+        v = R.len * R.alpha1 * pr1;
+        if (v < 0.0) v = 0.0;
+        const double x = v * R.inv_len * R.inv_alpha1;
+        double x2 = 0.0;
+        if (SPLIT) {
+            v2 = R.len * R.alpha2 * pr2;
+            if ((v2 - R.start) < 0.0) v2 = R.start;
+            x2 = v2 * R.inv_len * R.inv_alpha2;
+        }
+        cone_pow_5_3_two<SPLIT>(x, x2, q, q2);
+        chanq = q;
+        if (SPLIT) {
+            chanq = q + q2 - R.qlimit;
+            if (chanq < 0.0) chanq = 0.0;
+        }
+    } else {
+        const double cst = R.ap1 * cone_pow_3_5<ALL35>(R.qold, F.beta, s35) + s1 * R.dxp;
+        const double c = ups1 + cst;
+        qr = cone_solve<ALL35>(c, R.ap1, s35, F);
+        v = R.len * R.alpha1 * cone_pow_3_5<ALL35>(qr, A.Beta, b35);
+        if (v < 0.0) v = 0.0;
+        const double x = v * R.inv_len * R.inv_alpha1;
+        q = cone_pow_5_3<ALL35>(x, A.InvBeta, b35);
+        chanq = q;
+        if (SPLIT) {
+            const double cst2 = R.ap2 * cone_pow_3_5<ALL35>(R.q2old, F.beta, s35) + s2 * R.dxp;
+            const double c2 = ups2 + cst2;
+            q2r = cone_solve<ALL35>(c2, R.ap2, s35, F);
+            v2 = R.len * R.alpha2 * cone_pow_3_5<ALL35>(q2r, A.Beta, b35);
+            if ((v2 - R.start) < 0.0) v2 = R.start;
+            const double x2 = v2 * R.inv_len * R.inv_alpha2;
+            q2 = cone_pow_5_3<ALL35>(x2, A.InvBeta, b35);
+            chanq = q + q2 - R.qlimit;
+            if (chanq < 0.0) chanq = 0.0;
+        }
     }
 #endif
     qr_out = qr;
