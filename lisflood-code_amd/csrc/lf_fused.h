@@ -974,6 +974,10 @@ __global__ void __launch_bounds__(CW) __attribute__((amdgpu_waves_per_eu(LF_CONE
     cone_store<SPLIT, STRUCT>(F, pend, s);
 }
 
+// element of an array at a 32-bit BYTE offset: array pointer in scalar registers + one vector register (see cone_ld)
+template <class T>
+__device__ __forceinline__ T split_ld(const T *base, unsigned byte_offset) { return *(const T *)((const char *)base + byte_offset); }
+
 // ---- the cone kernel of a model step with the work split between a chain wavefront and supply wavefronts (round 4) ----
 // k_fused_cones makes ONE wavefront (or four, with a barrier per level) do everything a (cell, sub-step) needs: ~25 state
 // loads, the sideflow split, two old-discharge terms, two closure solves, the Q -> V -> Q fix-ups, nine stores -- ~650
@@ -1088,45 +1092,47 @@ __global__ void __launch_bounds__(64 * (1 + KC)) k_fused_cones_split(fused_args 
             P.act = p < lbound(c1, j);
             P.p = p;
             const int pc = P.act ? p : 0;
-            P.u0 = G.ups_ptr[pc];
-            P.u1 = G.ups_ptr[pc + 1];
-            P.len = A.ChanLength[pc];
-            P.chan = A.IsChannelKinematic[pc];
+            // (array pointer in scalar registers + this lane's 32-bit byte offset: no address arithmetic per array, as cone_ld)
+            const unsigned o8 = (unsigned)pc * 8u, o4 = (unsigned)pc * 4u, o1 = (unsigned)pc;
+            P.u0 = split_ld(G.ups_ptr, o4);
+            P.u1 = split_ld(G.ups_ptr, o4 + 4u);
+            P.len = split_ld(A.ChanLength, o8);
+            P.chan = split_ld(A.IsChannelKinematic, o1);
             P.eva = P.wuse = P.qin_old = P.qdelta = P.qin_added_old = P.chanq_old = P.transcum = P.lakeout = P.resout = P.polder = 0.0;
             P.uptrans = 0;
             if (!STRUCT)
-                P.side_m3 = A.SideflowChanM3[(long long)s * G.side_stride + pc];
+                P.side_m3 = split_ld(A.SideflowChanM3 + (long long)s * G.side_stride, o8);
             else { // (an option that is off: any valid stream instead of a branch around the load; its value is not used)
                 const lf_inloop_args &I = G.I;
                 const double *any = I.ToChanM3RunoffDt;
-                P.side_m3 = any[pc];
-                P.eva = (I.EvaAddM3Dt ? I.EvaAddM3Dt : any)[pc];
-                P.wuse = (I.WUseAddM3Dt ? I.WUseAddM3Dt : any)[pc];
-                P.qin_old = (I.QInM3Old ? I.QInM3Old : any)[pc];
-                P.qdelta = (I.QInM3Old ? I.QDelta : any)[pc];
-                P.qin_added_old = (I.QInM3Old ? (const double *)I.QinADDEDM3 : any)[pc];
-                P.chanq_old = A.ChanQ[pc];
-                P.uptrans = (I.UpTrans ? I.UpTrans : A.IsChannelKinematic)[pc];
-                P.transcum = (I.UpTrans ? (const double *)I.TransCum : any)[pc];
-                P.lakeout = (I.QLakeOutM3Dt ? (const double *)I.QLakeOutM3Dt : any)[pc];
-                P.resout = (I.QResOutM3Dt ? (const double *)I.QResOutM3Dt : any)[pc];
-                P.polder = (I.ChannelToPolderM3Dt ? I.ChannelToPolderM3Dt : any)[pc];
+                P.side_m3 = split_ld(any, o8);
+                P.eva = split_ld(I.EvaAddM3Dt ? I.EvaAddM3Dt : any, o8);
+                P.wuse = split_ld(I.WUseAddM3Dt ? I.WUseAddM3Dt : any, o8);
+                P.qin_old = split_ld(I.QInM3Old ? I.QInM3Old : any, o8);
+                P.qdelta = split_ld(I.QInM3Old ? I.QDelta : any, o8);
+                P.qin_added_old = split_ld(I.QInM3Old ? (const double *)I.QinADDEDM3 : any, o8);
+                P.chanq_old = split_ld(A.ChanQ, o8);
+                P.uptrans = split_ld(I.UpTrans ? I.UpTrans : A.IsChannelKinematic, o1);
+                P.transcum = split_ld(I.UpTrans ? (const double *)I.TransCum : any, o8);
+                P.lakeout = split_ld(I.QLakeOutM3Dt ? (const double *)I.QLakeOutM3Dt : any, o8);
+                P.resout = split_ld(I.QResOutM3Dt ? (const double *)I.QResOutM3Dt : any, o8);
+                P.polder = split_ld(I.ChannelToPolderM3Dt ? I.ChannelToPolderM3Dt : any, o8);
             }
-            P.qold = A.ChanQKin[pc];
-            P.alpha1 = A.ChannelAlpha[pc];
-            P.dxv = (G.dx ? G.dx : A.ChanLength)[pc]; // (no per-pixel dx: any valid stream, the scalar is selected)
-            P.inv_len = RC ? 0.0 : A.InvChanLength[pc];
-            P.ap1 = RC ? 0.0 : G.a1[pc];
+            P.qold = split_ld(A.ChanQKin, o8);
+            P.alpha1 = split_ld(A.ChannelAlpha, o8);
+            P.dxv = split_ld(G.dx ? G.dx : A.ChanLength, o8); // (no per-pixel dx: any valid stream, the scalar is selected)
+            P.inv_len = RC ? 0.0 : split_ld(A.InvChanLength, o8);
+            P.ap1 = RC ? 0.0 : split_ld(G.a1, o8);
             P.m3 = P.m3_2 = P.start = P.m3limit = P.q2start = P.q2old = P.alpha2 = P.ap2 = 0.0;
             if (SPLIT) {
-                P.m3 = A.ChanM3Kin[pc];
-                P.m3_2 = A.Chan2M3Kin[pc];
-                P.start = A.Chan2M3Start[pc];
-                P.m3limit = A.M3Limit[pc];
-                P.q2start = A.Chan2QStart[pc];
-                P.q2old = A.Chan2QKin[pc];
-                P.alpha2 = A.ChannelAlpha2[pc];
-                P.ap2 = RC ? 0.0 : G.a2[pc];
+                P.m3 = split_ld(A.ChanM3Kin, o8);
+                P.m3_2 = split_ld(A.Chan2M3Kin, o8);
+                P.start = split_ld(A.Chan2M3Start, o8);
+                P.m3limit = split_ld(A.M3Limit, o8);
+                P.q2start = split_ld(A.Chan2QStart, o8);
+                P.q2old = split_ld(A.Chan2QKin, o8);
+                P.alpha2 = split_ld(A.ChannelAlpha2, o8);
+                P.ap2 = RC ? 0.0 : split_ld(G.a2, o8);
             }
         };
         auto finish_pre = [&](int ph, const pre_t &P, auto first_chunk) {
@@ -1255,19 +1261,20 @@ __global__ void __launch_bounds__(64 * (1 + KC)) k_fused_cones_split(fused_args 
             R.act = p < lbound(c1, j);
             R.p = p;
             const int pc = R.act ? p : 0;
-            R.len = A.ChanLength[pc];
-            R.alpha1 = A.ChannelAlpha[pc];
-            R.sum_old = A.sumDisDay[pc];
-            R.inv_len = RC ? 0.0 : A.InvChanLength[pc];
-            R.inv_alpha1 = RC ? 0.0 : A.InvChannelAlpha[pc];
-            R.pix_area = A.PixelArea[last ? pc : 0]; // (read by the last sub-step only: one line on the others)
-            R.cut = STRUCT ? G.linked[pc] : 0;
+            const unsigned o8 = (unsigned)pc * 8u, o1 = (unsigned)pc;
+            R.len = split_ld(A.ChanLength, o8);
+            R.alpha1 = split_ld(A.ChannelAlpha, o8);
+            R.sum_old = split_ld(A.sumDisDay, o8);
+            R.inv_len = RC ? 0.0 : split_ld(A.InvChanLength, o8);
+            R.inv_alpha1 = RC ? 0.0 : split_ld(A.InvChannelAlpha, o8);
+            R.pix_area = split_ld(A.PixelArea, last ? o8 : 0u); // (read by the last sub-step only: one line on the others)
+            R.cut = STRUCT ? split_ld(G.linked, o1) : 0;
             R.start = R.alpha2 = R.inv_alpha2 = R.qlimit = 0.0;
             if (SPLIT) {
-                R.start = A.Chan2M3Start[pc];
-                R.alpha2 = A.ChannelAlpha2[pc];
-                R.qlimit = A.QLimit[pc];
-                R.inv_alpha2 = RC ? 0.0 : A.InvChannelAlpha2[pc];
+                R.start = split_ld(A.Chan2M3Start, o8);
+                R.alpha2 = split_ld(A.ChannelAlpha2, o8);
+                R.qlimit = split_ld(A.QLimit, o8);
+                R.inv_alpha2 = RC ? 0.0 : split_ld(A.InvChannelAlpha2, o8);
             }
         };
         auto finish_post = [&](int ph, const post_t &R) { // fix-ups and stores of chunk ph (routing.py:526-532, 573-603, 693-703)
