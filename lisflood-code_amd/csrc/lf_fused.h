@@ -361,11 +361,12 @@ struct cone_cell { // what a cell's load phase leaves in registers: loaded value
 //  * address = array pointer (scalar registers) + 32-bit byte offset of the cell (one vector register for all arrays of
 //    an element size): the `saddr` form of global_load / global_store, no address arithmetic per array (the fused plan is
 //    only built for graphs below 2^29 cells, build_fused_blocks);
-//  * ONE divergent region around all loads (lanes beyond the cone) and no uniform branch per optional vector: an array
-//    that a uniform condition switches off, or whose pointer is null, is read from a stand-in (the channel lengths: any
-//    valid array of the size) and the value ignored -- what must read 0 then is zeroed in cone_fix, behind the wait.  The
-//    pointer loads from the kernel-argument segment then come in batches in front of the loads (a handful of
-//    scalar-memory waits per level instead of ~25).
+//  * ONE divergent region around all loads (lanes beyond the cone) and no uniform branch per optional vector: vectors that a
+//    uniform condition switches off are skipped in a few GROUPS (the five derived statics when they are recomputed, the
+//    inert test's four, the last sub-step's, the link flags), their fields keep the zeros of the kernel's start-up; the
+//    optional vectors of the structures (each with its own null test) are read from a stand-in instead (the channel
+//    lengths: any valid array of the size) and the value ignored.  The pointer loads from the kernel-argument segment then
+//    come in batches in front of the loads (a handful of scalar-memory waits per level instead of ~25).
 struct cone_range { // one level of a cone: cells [first, first + cnt)
     long long first;
     int cnt;
@@ -407,16 +408,25 @@ __device__ __forceinline__ void cone_load(const fused_args &F, const cone_range 
         R.base = cone_ld(F.d_ups_base, P);
         R.slot = cone_ld(F.d_out_slot, P);
     }
-    R.dxp = cone_ld(F.dx, P, !dx_is_len); // no per-cell dx / dx_is_len: cone_fix puts the scalar / the length there
-    R.inv_len = cone_ld(A.InvChanLength, P, !rc); // rc: cone_derive fills the five derived values in from len / alpha / dx
+    // Vectors that a uniform condition switches off are skipped in GROUPS, one uniform branch each (a handful per level --
+    // not one per vector): their fields keep what the kernel's start-up left there (zeros, `cone_cell x = {}`), which is
+    // what their readers expect (the flags) or is never looked at (values read behind the same condition).
+    if (F.dx && !dx_is_len) R.dxp = cone_ld(F.dx, P); // else cone_fix puts the scalar / the length there
     R.len = cone_ld(A.ChanLength, P);
     R.chan_raw = cone_ld(A.IsChannelKinematic, P);
+    if (!rc) { // rc: cone_derive fills the five derived values in from len / alpha / dx
+        R.inv_len = cone_ld(A.InvChanLength, P);
+        R.ap1 = cone_ld(F.a1, P);
+        R.inv_alpha1 = cone_ld(A.InvChannelAlpha, P);
+        if (SPLIT) {
+            R.ap2 = cone_ld(F.a2, P);
+            R.inv_alpha2 = cone_ld(A.InvChannelAlpha2, P);
+        }
+    }
     const bool test_inert = !STRUCT && F.inert && s != F.nsteps - 1; // see k_inert_flags / fused_cell (uniform)
-    R.eva = R.wuse = R.qin_old = R.qdelta = R.qin_added_old = R.transcum = R.lakeout = R.resout = R.polder = 0;
-    R.uptrans_raw = 0;
     if (!STRUCT)
         R.side_m3 = cone_ld(A.SideflowChanM3 + (long long)s * F.side_stride, P);
-    else { // (absent vectors: the stand-in's value, which cone_compute does not look at -- it tests the same pointers)
+    else { // (absent vectors: a stand-in's value, which cone_compute does not look at -- it tests the same pointers)
         const lf_inloop_args &I = F.I;
         R.side_m3 = cone_ld(I.ToChanM3RunoffDt, P);
         R.eva = cone_ld(I.EvaAddM3Dt, P, true);
@@ -429,45 +439,41 @@ __device__ __forceinline__ void cone_load(const fused_args &F, const cone_range 
         R.lakeout = cone_ld(I.QLakeOutM3Dt, P, true);
         R.resout = cone_ld(I.QResOutM3Dt, P, true);
         R.polder = cone_ld(I.ChannelToPolderM3Dt, P, true);
+        R.chanq_old = cone_ld(A.ChanQ, P, I.UpTrans != nullptr); // ChanQ before the sub-step: transmission loss
     }
-    // ChanQ before the sub-step: STRUCT -- transmission loss; else the inert test
-    R.chanq_old = cone_ld(A.ChanQ, P, STRUCT ? F.I.UpTrans != nullptr : test_inert);
-    R.cut_raw = cone_ld(F.linked, P, true); // (also without STRUCT: a sub-step at a time on a graph with structure links)
-    R.ap1 = cone_ld(F.a1, P, !rc);
+    if (F.linked) R.cut_raw = cone_ld(F.linked, P); // (also without STRUCT: a sub-step at a time on a graph with structure links)
     R.qold = cone_ld(A.ChanQKin, P);
     R.alpha1 = cone_ld(A.ChannelAlpha, P);
-    R.inv_alpha1 = cone_ld(A.InvChannelAlpha, P, !rc);
     R.sum_old = cone_ld(A.sumDisDay, P);
-    R.m3 = cone_ld(A.ChanM3Kin, P, SPLIT || test_inert);
-    R.m3_2 = R.start = R.m3limit = R.q2start = R.ap2 = R.q2old = R.alpha2 = R.inv_alpha2 = R.qlimit = 0;
-    R.csa_old = R.sf1_old = 0;
     if (SPLIT) {
+        R.m3 = cone_ld(A.ChanM3Kin, P);
         R.m3_2 = cone_ld(A.Chan2M3Kin, P);
         R.start = cone_ld(A.Chan2M3Start, P);
         R.m3limit = cone_ld(A.M3Limit, P);
         R.q2start = cone_ld(A.Chan2QStart, P);
-        R.ap2 = cone_ld(F.a2, P, !rc);
         R.q2old = cone_ld(A.Chan2QKin, P);
         R.alpha2 = cone_ld(A.ChannelAlpha2, P);
-        R.inv_alpha2 = cone_ld(A.InvChannelAlpha2, P, !rc);
         R.qlimit = cone_ld(A.QLimit, P);
-        R.csa_old = cone_ld(A.CrossSection2Area, P, test_inert);
-        R.sf1_old = cone_ld(A.Sideflow1Chan, P, test_inert);
     }
-    R.pix_area = cone_ld(A.PixelArea, P, s == F.nsteps - 1);
-    R.inert_raw = cone_ld(F.inert, P, test_inert);
+    if (test_inert) { // the inert test of cone_skip: the flag and the state it compares with +0.0
+        R.inert_raw = cone_ld(F.inert, P);
+        R.chanq_old = cone_ld(A.ChanQ, P);
+        if (!SPLIT) R.m3 = cone_ld(A.ChanM3Kin, P);
+        if (SPLIT) {
+            R.csa_old = cone_ld(A.CrossSection2Area, P);
+            R.sf1_old = cone_ld(A.Sideflow1Chan, P);
+        }
+    }
+    if (s == F.nsteps - 1) R.pix_area = cone_ld(A.PixelArea, P);
 }
 
 // behind the wait for a level's loads: what depends on uniform conditions AND on loaded values
-template <bool STRUCT>
-__device__ __forceinline__ void cone_fix(const fused_args &F, cone_cell &R, int s, bool dx_is_len)
+__device__ __forceinline__ void cone_fix(const fused_args &F, cone_cell &R, bool dx_is_len)
 {
     if (dx_is_len)
         R.dxp = R.len; // (same bits as the per-cell dx, see derived_flags)
     else if (!F.dx)
         R.dxp = F.dx_scalar;
-    if (!F.linked) R.cut_raw = 0; // the flags whose vectors may be absent or switched off read a stand-in
-    if (STRUCT || !F.inert || s == F.nsteps - 1) R.inert_raw = 0;
 }
 
 // fused_args::recompute: the five derived statics from the three loaded ones (same operations as the host's)
@@ -953,19 +959,19 @@ __global__ void __launch_bounds__(CW) __attribute__((amdgpu_waves_per_eu(LF_CONE
         // the loads of the next level (issued before this level's arithmetic) and the stores of the previous one: done
         // by now.  Stated explicitly so that the compiler does not wait for `nxt` behind the NEXT level's stores.
         __builtin_amdgcn_s_waitcnt(0x0F70);
-        cone_fix<STRUCT>(F, nxt, s, dx_is_len);
+        cone_fix(F, nxt, dx_is_len);
         if (rc) cone_derive<SPLIT>(F, nxt); // off the next level's chain: before its barrier
         first_up = first;
         return nfirst;
     };
-    cone_cell ra, rb;
+    cone_cell ra = {}, rb = {}; // (zeros: what cone_load leaves alone stays 0 -- the inert and link flags above all)
     int first = ld_table(c0, 0);
     {
         const cone_range rng0 = {first, ld_table(c1, 0) - first};
         cone_load<SPLIT, STRUCT, DIST>(F, rng0, tid, s, ra, rc, dx_is_len);
     }
     __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): inside the loop the current level's registers are always complete
-    cone_fix<STRUCT>(F, ra, s, dx_is_len);
+    cone_fix(F, ra, dx_is_len);
     if (rc) cone_derive<SPLIT>(F, ra);
     for (int j = 0; j < nl; j += 2) {
         first = level(j, ra, rb, first);
