@@ -360,7 +360,7 @@ struct cone_cell { // what a cell's load phase leaves in registers: loaded value
 // a level's ~35 loads and ~10 stores cost in instructions AROUND them is what matters:
 //  * address = array pointer (scalar registers) + 32-bit byte offset of the cell (one vector register for all arrays of
 //    an element size): the `saddr` form of global_load / global_store, no address arithmetic per array (the fused plan is
-//    only built for graphs below 2^29 cells, build_fused_blocks);
+//    only built for graphs below 2^29 cells: build_level_blocks in lf_router.hip, the phase plans in lf_dist.hip);
 //  * ONE divergent region around all loads (lanes beyond the cone) and no uniform branch per optional vector: vectors that a
 //    uniform condition switches off are skipped in a few GROUPS (the five derived statics when they are recomputed, the
 //    inert test's four, the last sub-step's, the link flags), their fields keep the zeros of the kernel's start-up; the
