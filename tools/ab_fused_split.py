@@ -1,6 +1,7 @@
 """Same-process A/B of a model step (24 split-routing sub-steps, lf_routing_substeps_fused) with the cone kernel in its
 chain / supply form (default) against the one-wavefront-per-cone kernel (LF_FUSED_SPLIT=0); every state vector compared
-bit by bit.  python tools/ab_fused_split.py family size [nsteps] [split 0|1]"""
+bit by bit; `bits` is a hash of the state vectors for comparisons ACROSS libraries (LISFLOOD_AMD_LIBRARY=another build).
+    python tools/ab_fused_split.py family size [nsteps] [split 0|1]"""
 import os
 import sys
 import time
