@@ -185,6 +185,10 @@ int lf_graph_block_plan_stats(const lf_graph *g, int lmax, int64_t wide, int max
  * inside the cone's range of the level above (must be 0), out[1] largest LDS slot + 1 a cell reads (<= max_cone),
  * out[2] largest upstream count (<= 8), out[3] cells checked */
 int lf_graph_block_plan_check(const lf_graph *g, int lmax, int64_t wide, int max_cone, int64_t out[4]);
+/* the order in which the fused cone kernel hands the n cones of one (block, sub-step) to its workgroups: out[i] = cone of
+ * launch position i when position 0 is the workgroup with linear id first_linear_id -- the workgroups of one XCD (linear
+ * id mod 8) get consecutive cones; a permutation of 0..n-1 (host only: the function the kernel calls, for the tests) */
+int lf_xcd_contiguous_order(int n, unsigned int first_linear_id, int32_t *out);
 /* per-kernel hipEvent profiling: when enabled every sweep launch is bracketed by an event pair.
  * lf_router_profile_read returns accumulated {launches, milliseconds, cells} per kernel class
  * (0 = prep, 1 = wide level, 2 = narrow run) since the last reset. */

@@ -1,9 +1,33 @@
 // lf_blocks.h -- host side: level blocks and their cones for the LDS sweeps (k_sweep_cones, k_fused_cones), shared by the
 // single-domain router (lf_router.hip) and the row-block partition (lf_dist.hip).
 #pragma once
+#include <hip/hip_runtime.h>
+
 #include <algorithm>
 #include <cstdint>
 #include <vector>
+
+// Workgroups go to the eight XCDs round robin by their linear id.  Neighbouring cones of a block share the 128-byte lines
+// their level segments begin and end in (a segment of 64 cells = 4 lines + on average one shared): with the cones of a
+// (block, sub-step) dealt out in launch order the two halves of such a line are fetched into two L2s.  This gives the
+// workgroups of one XCD CONSECUTIVE cones of the range [0, n) instead: i = position in launch order, linear_id = of this
+// workgroup (so position 0 has linear id linear_id - i); a bijection of [0, n), positions beyond n map to themselves.
+// Device code (k_fused_cones) and host (lf_xcd_contiguous_order: the tests look at the whole order).
+__host__ __device__ inline int lf_xcd_contiguous(int i, int n, unsigned linear_id)
+{
+    if (i >= n) return i;
+    const unsigned start = linear_id - (unsigned)i; // linear id of position 0
+    const int cls = (int)(linear_id & 7u);
+    int before = 0, r_mine = 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int r = (int)(((unsigned)c - start) & 7u); // first position of class c
+        const int cnt = r < n ? (n - r + 7) >> 3 : 0;
+        before += c < cls ? cnt : 0;
+        r_mine = c == cls ? r : r_mine;
+    }
+    return before + ((i - r_mine) >> 3);
+}
 
 // Runs of consecutive levels [k_lo, k_hi) of at most `wide` cells are cut into blocks of up to lmax levels; a wider level
 // is a block of its own.  A block is cut into CONES: chunks of its last level, as long as possible with no level of the

@@ -2,6 +2,7 @@
 // kinematic_wave_parallel_tools.py:34-92), shared by the single-GPU router (lf_router.hip) and the row-block partition
 // (lf_dist.hip).  See the comment block above lf_routing_substeps_fused in lf_router.hip for the scheme.
 #pragma once
+#include "lf_blocks.h"
 #include "lf_structures.h"
 #include "lf_sweep.h"
 
@@ -780,28 +781,14 @@ __device__ __forceinline__ void cone_store(const fused_args &F, const cone_out &
     }
 }
 
-// Workgroups go to the eight XCDs round robin by their linear id.  Neighbouring cones of a block share the 128-byte lines
-// their level segments begin and end in (a segment of 64 cells = 4 lines + on average one shared): with the cones of a
-// (block, sub-step) dealt out in launch order the two halves of such a line are fetched into two L2s.  This gives the
-// workgroups of one XCD CONSECUTIVE cones of the range [0, n) instead (i: position in launch order, linear_id: of this
-// workgroup; a bijection of [0, n)).  -DLF_XCD_REMAP=0: launch order (A/B builds).
+// The cones of a (block, sub-step) in XCD-contiguous order (lf_blocks.h: lf_xcd_contiguous).  -DLF_XCD_REMAP=0: launch order
+// (A/B builds).
 #ifndef LF_XCD_REMAP
 #define LF_XCD_REMAP 1
 #endif
 __device__ __forceinline__ int xcd_contiguous(int i, int n, unsigned linear_id)
 {
-    if (!LF_XCD_REMAP || i >= n) return i;
-    const unsigned start = linear_id - (unsigned)i; // linear id of position 0
-    const int cls = (int)(linear_id & 7u);
-    int before = 0, r_mine = 0;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const int r = (int)(((unsigned)c - start) & 7u); // first position of class c
-        const int cnt = r < n ? (n - r + 7) >> 3 : 0;
-        before += c < cls ? cnt : 0;
-        r_mine = c == cls ? r : r_mine;
-    }
-    return before + ((i - r_mine) >> 3);
+    return LF_XCD_REMAP ? lf_xcd_contiguous(i, n, linear_id) : i;
 }
 
 // LDS barrier: the wavefronts of the workgroup have finished their LDS writes; global stores keep draining

@@ -435,3 +435,22 @@ def test_cone_plan_invariants_the_kernels_rely_on(family, H, W):
     for lmax in (32, 16):
         check(gl, lmax)
     gl.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 8, 9, 63, 85, 107, 2040])
+def test_cones_of_a_launch_are_dealt_out_xcd_contiguously(n):
+    """lf_xcd_contiguous (lf_blocks.h; the function k_fused_cones calls, here through its host entry): whatever the linear
+    id of a (block, sub-step)'s first workgroup, the launch positions map ONTO the cones 0..n-1, and the positions of one
+    XCD (linear id mod 8) get one run of consecutive cones"""
+    lib = _lib.lib()
+    for first in (0, 1, 5, 13, 4095, 1000003, 0xfffffff9):
+        out = (C.c_int32 * n)()
+        _lib.check(lib.lf_xcd_contiguous_order(C.c_int(n), C.c_uint(first), out))
+        order = np.array(out[:], dtype=np.int64)
+        assert np.array_equal(np.sort(order), np.arange(n)), (n, first)
+        xcd = (first + np.arange(n, dtype=np.uint64)) % 2**32 % 8
+        for c in range(8):
+            mine = np.sort(order[xcd == c])
+            assert mine.size == 0 or np.array_equal(mine, np.arange(mine[0], mine[0] + mine.size)), (n, first, c)
+            # ... in launch order: a workgroup's successor on the same XCD takes the next cone
+            assert np.array_equal(order[xcd == c], mine), (n, first, c)
