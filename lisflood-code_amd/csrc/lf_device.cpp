@@ -277,6 +277,7 @@ int lf_memset(int device, void *dst_dev, int value, size_t bytes)
 {
     lf_device_ctx *c;
     LF_TRY(lf_ctx(device, &c));
+    LF_TRY(side_join(c)); // like the copies: a vector the side stream's wavefront still works on must not be cleared under it
     if (bytes) LF_HIP(hipMemsetAsync(dst_dev, value, bytes, c->stream));
     return LF_OK;
 }

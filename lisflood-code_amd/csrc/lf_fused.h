@@ -1239,7 +1239,7 @@ __global__ void __launch_bounds__(64 * (1 + KC)) k_fused_cones_split(fused_args 
                 fl.af = (float)ca.ap;
                 fl.laf = __builtin_amdgcn_logf(fl.af);
                 fl.fast_a = fast_a;
-                fl.pad = 0;
+                fl.pos = P.act ? P.p : 0;
                 O.ca[jj][r][tid] = ca;
                 O.fl[jj][r][tid] = fl;
             }

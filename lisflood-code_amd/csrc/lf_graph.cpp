@@ -291,11 +291,6 @@ int lf_graph_block_plan_stats(const lf_graph *g, int lmax, int64_t wide, int max
     return LF_OK;
 }
 
-// What the cone kernels take for granted about that plan, checked cell by cell on the host: the upstream range of every
-// cell of a cone lies inside the cone's range of the level above (it is read from the LDS row of that level: slot =
-// position - start of the range, at most max_cone slots), and holds at most 8 cells.
-//   out[0] cells whose range leaves the cone's range above   out[1] largest slot index + 1 any cell reads
-//   out[2] largest upstream count                             out[3] cells checked
 // The order in which the n cones of one (block, sub-step) are handed to the workgroups of a launch whose first workgroup
 // for them has linear id `first_linear_id` (lf_blocks.h: lf_xcd_contiguous, the function the kernel calls): out[i] = cone of
 // launch position i.  Host only.
@@ -306,6 +301,11 @@ int lf_xcd_contiguous_order(int n, unsigned int first_linear_id, int32_t *out)
     return LF_OK;
 }
 
+// What the cone kernels take for granted about that plan, checked cell by cell on the host: the upstream range of every
+// cell of a cone lies inside the cone's range of the level above (it is read from the LDS row of that level: slot =
+// position - start of the range, at most max_cone slots), and holds at most 8 cells.
+//   out[0] cells whose range leaves the cone's range above   out[1] largest slot index + 1 any cell reads
+//   out[2] largest upstream count                             out[3] cells checked
 int lf_graph_block_plan_check(const lf_graph *g, int lmax, int64_t wide, int max_cone, int64_t out[4])
 {
     if (!g || !out || lmax < 1 || max_cone < 1) return lf_set_error(LF_E_INVALID, "bad argument");

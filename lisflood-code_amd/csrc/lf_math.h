@@ -305,12 +305,15 @@ __device__ __forceinline__ double lf_pow_pos(double x, double y)
 }
 
 // x^y of the transmission loss (transmission.py:76-87: (Q^p2 - sub)^p1, both exponents scalars of the settings): lf_pow_pos
-// for a finite positive exponent (x < 0 or NaN -> NaN, 0 -> 0, as pow), OCML pow otherwise.  ~75 instead of ~220
-// instructions per call; every kernel that computes the loss goes through here, so they stay bit-identical to one another.
+// for a finite positive exponent and a base that is not negative (0 -> 0, NaN -> NaN, as pow), OCML pow otherwise -- a
+// NEGATIVE base must keep pow's semantics: with the settings' defaults TransPower1 = 2, TransSub = 0.3 the inner term is
+// negative on every reach below 0.09 m3/s and pow(-0.3, 2.0) = 0.09, not NaN (integer exponents are defined there).  ~75
+// instead of ~220 instructions per call on the common path; every kernel that computes the loss goes through here, so
+// they stay bit-identical to one another.
 // Out of line: inlined twice into the cone kernels it cost them 30 VGPRs (spills in k_fused_cones<STRUCT>, one wavefront
 // per SIMD in k_fused_cones_split<STRUCT>).
 static __device__ __attribute__((noinline)) double lf_pow_scalar_exponent(double x, double y)
 {
-    if (y > 0.0 && y < 1e6) return lf_pow_pos(x, y); // (uniform: y is a kernel argument)
+    if (y > 0.0 && y < 1e6 && !(x < 0.0)) return lf_pow_pos(x, y); // (y is a kernel argument; negative bases are the rare lanes)
     return pow(x, y);
 }

@@ -505,6 +505,280 @@ k_soil_columns_deferred(lf_soil_args A, veg_plan P,
     }
 }
 
+// ---- the one-launch form (round 5) ---------------------------------------------------------------------------
+// Every stream of the call is read once and every output written once, in full lines: a workgroup owns the 256
+// columns of its tile from the first load to the last store.
+//   phase 1  one lane per column: inputs, evaporation, infiltration, the first conductivities and the Courant
+//            number (soilloop.py:123-249).  The four outputs the sub-step loop does not touch are stored here.  A
+//            column that needs one sub-step takes it in its lane; the others put what the loop needs (7 values per
+//            soil layer) in LDS.
+//   phase 2  the tile's multi-sub-step columns, sorted by trip count (heaviest first), THREE lanes per column -- one
+//            per soil layer; the only traffic between the layers of a column is the capacity of the layer below and
+//            the flux from the layer above (two lane shifts per sub-step).  A wavefront carries 21 columns, so the
+//            trip count of a wavefront follows the sorted list closely (one lane per column ran 64 columns to the
+//            slowest), and a layer's lane needs ~60 registers instead of ~170 for the three layers side by side.
+//   phase 3  every lane, back in column order: state update, diagnostics, upper zone (soilloop.py:313-354) and 18
+//            coalesced stores.
+// Arithmetic per column is the reference's, operation by operation (a layer's lane evaluates exactly the terms
+// soil_column evaluates for that layer), so the results are those of the two-pass form bit for bit.
+constexpr int kLoopCap = 128;             // multi-sub-step columns of a tile handled per round (more -> another round)
+constexpr int kLoopFields = 7 * 3 + 1;    // per layer: w, wres, ws, ksat, 1/m, m, k; per column: flags (trip count: s_key)
+constexpr int kColsPerWave = 21;          // 3 lanes per column, lane 63 idles
+
+template <bool FASTPOW>
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(LF_SOIL_P1_WAVES)))
+k_soil_fused(lf_soil_args A, veg_plan P, unsigned short *__restrict__ tile_list, unsigned int *__restrict__ tile_count,
+             int log2_classes)
+{
+    __shared__ unsigned int s_count, s_next;
+    __shared__ double s_rec[kLoopFields * kLoopCap];
+    __shared__ double s_res[3 * kLoopCap];
+    __shared__ unsigned int s_key[kLoopCap];
+    __shared__ unsigned short s_order[kLoopCap];
+    if (threadIdx.x == 0) {
+        s_count = 0;
+        s_next = 0;
+    }
+    __syncthreads();
+    const long long N = A.N;
+    const double DtDay = A.DtDay;
+    const long long pix = (long long)blockIdx.x * kBlock + threadIdx.x;
+    const int veg = blockIdx.y;
+    const unsigned int tile = blockIdx.x + blockIdx.y * gridDim.x;
+    const int mode = P.mode[veg];
+    bool active = pix < N && mode != 0;
+    if (active && mode == 2 && !A.paddy_inactive[(long long)P.paddy_row[veg] * N + pix]) active = false;
+    const long long i = (long long)veg * N + pix, j = (long long)P.landuse[veg] * N + pix;
+
+    // what phase 3 needs of phase 1
+    double w1a = 0, w1b = 0, w2 = 0, inf = 0, pref = 0, uz = 0, uzout = 0, in_gwp = 0, ws1a = 0;
+    double in_sd1a = 1, in_sd1b = 1, in_sd2 = 1, wwp1a = 0, wwp1b = 0, wwp1 = 0, wwp2 = 0;
+    double in_wfc1a = 1, in_wfc1b = 1, in_wfc1 = 1, in_wfc2 = 1;
+    double sa = 0, sb = 0, sg = 0;
+    double k1a = 0, k1b = 0, k2 = 0, nsub_f = 1; // kept for a column whose turn comes in a later round of phase 2
+    int flags = 0;
+    unsigned int rank = 0xffffffffu;
+    if (active) {
+        // every input of the column before any arithmetic: ~50 independent loads in flight per lane
+        const double in_rain = A.Rain[pix], in_snow = A.SnowMelt[pix], in_leaf = A.LeafDrainage[i], in_int = A.Interception[i];
+        const double in_dslr = A.DSLR[i], in_w1a = A.W1a[i], in_w1b = A.W1b[i], in_w1 = A.W1[i], in_w2 = A.W2[i];
+        const double in_uz = A.UZ[i];
+        const double in_esmax = A.ESMax[i], in_wres1 = A.WRes1[j], in_ws1 = A.WS1[j], in_store = A.StoreMaxPervious[j];
+        const double in_bx = A.b_Xinanjiang[pix], in_pinf = A.PowerInfPot[pix], in_ppref = A.PowerPrefFlow[pix];
+        const double in_uzk = A.UpperZoneK[pix];
+        in_gwp = A.GwPercStep[pix];
+        in_sd1a = A.SoilDepth1a[j]; in_sd1b = A.SoilDepth1b[j]; in_sd2 = A.SoilDepth2[j];
+        wwp1a = A.WWP1a[j]; wwp1b = A.WWP1b[j]; wwp1 = A.WWP1[j]; wwp2 = A.WWP2[j];
+        in_wfc1a = A.WFC1a[j]; in_wfc1b = A.WFC1b[j]; in_wfc1 = A.WFC1[j]; in_wfc2 = A.WFC2[j];
+        const double ks1a = A.KSat1a[j], ks1b = A.KSat1b[j], ks2 = A.KSat2[j];
+        const double im1a = A.GenuInvM1a[j], im1b = A.GenuInvM1b[j], im2 = A.GenuInvM2[j];
+        const double m1a = A.GenuM1a[j], m1b = A.GenuM1b[j], m2 = A.GenuM2[j];
+        const double wres1a = A.WRes1a[j], wres1b = A.WRes1b[j], wres2 = A.WRes2[j];
+        ws1a = A.WS1a[j];
+        const double ws1b = A.WS1b[j], ws2 = A.WS2[j];
+        flags = (A.isFrozenSoil[pix] != 0 ? 1 : 0) | (A.PoreSpaceNotZero1a[j] != 0 ? 2 : 0) |
+                (A.PoreSpaceNotZero1b[j] != 0 ? 4 : 0) | (A.PoreSpaceNotZero2[j] != 0 ? 8 : 0);
+        const bool frozen = (flags & 1) != 0, pore1a = (flags & 2) != 0, pore1b = (flags & 4) != 0, pore2 = (flags & 8) != 0;
+        // available water for infiltration, :100,131
+        double awi = dmax((in_rain + in_snow) + in_leaf - in_int, 0.);
+        // days since last rain, :137-140
+        double dslr = in_dslr;
+        if (awi > A.AvWaterThreshold)
+            dslr = 1;
+        else
+            dslr += DtDay;
+        // bare soil evaporation, :148-163
+        double esact;
+        w1a = in_w1a;
+        w1b = in_w1b;
+        if (frozen)
+            esact = 0.;
+        else {
+            esact = in_esmax * (sqrt(dslr) - sqrt(dslr - 1));
+            esact = dmax(dmin(esact, in_w1 - in_wres1), 0.);
+            const double supply1a = w1a - wres1a;
+            const double es1a = dmin(esact, supply1a);
+            const double es1b = dmax(esact - supply1a, 0.);
+            w1a = dmax(w1a - es1a, wres1a);
+            w1b = dmax(w1b - es1b, wres1b);
+        }
+        const double w1_ = w1a + w1b;
+        // Xinanjiang infiltration capacity, :168-179
+        const double relsat1 = pore1a ? dmin(w1_ / in_ws1, 1.0) : 0.0;
+        const double satfrac = 1.0 - powxy<FASTPOW>(1.0 - relsat1, in_bx);
+        const double infpot = frozen ? 0.0 : in_store * powxy<FASTPOW>(1. - satfrac, in_pinf) * DtDay;
+        // preferential flow, :190-194
+        pref = powxy<FASTPOW>(relsat1, in_ppref) * awi;
+        awi -= pref;
+        // infiltration, :201-211
+        inf = dmax(dmin(awi, infpot), 0.);
+        const double test1a = w1a + inf;
+        w1a = dmin(ws1a, test1a);
+        w1b += dmax(test1a - ws1a, 0.);
+        w2 = in_w2;
+        // the outputs the sub-step loop does not touch
+        A.DSLR[i] = dslr;
+        A.ESAct[i] = esact;
+        A.PrefFlow[i] = pref;
+        A.AvailableWaterForInfiltration[i] = awi;
+        // upper-zone outflow before the seepage arrives, :340-341
+        uz = in_uz;
+        uzout = dmin(in_uzk * uz, uz);
+        uz = dmax(uz - uzout, 0.);
+        // Van Genuchten conductivities and Courant numbers, :223-249
+        {
+            const double w_[3] = {w1a, w1b, w2}, wres_[3] = {wres1a, wres1b, wres2}, ws_[3] = {ws1a, ws1b, ws2};
+            const double ks_[3] = {ks1a, ks1b, ks2}, im_[3] = {im1a, im1b, im2}, m_[3] = {m1a, m1b, m2};
+            const bool pore_[3] = {pore1a, pore1b, pore2};
+            double k_[3];
+            unsat_k3<FASTPOW>(w_, pore_, wres_, ws_, ks_, im_, m_, k_);
+            k1a = k_[0], k1b = k_[1], k2 = k_[2];
+        }
+        const double av1a = w1a - wres1a, av1b = w1b - wres1b, av2 = w2 - wres2;
+        const double ca = (av1a == 0) ? 0. : k1a * DtDay / av1a;
+        const double cb = (av1b == 0) ? 0. : k1b * DtDay / av1b;
+        const double cg = (av2 == 0) ? 0. : k2 * DtDay / av2;
+        const double courant = dmax(dmax(ca, cb), cg);
+        // NoSubS = max(1, ceil(Courant / CourantCrit)), :249 (capped: see soil_column)
+        nsub_f = dmin(dmax(1., ceil(courant / A.CourantCrit)), kMaxSoilSubSteps);
+        if (nsub_f > 1.) {
+            rank = atomicAdd(&s_count, 1u); // LDS: position in the tile's list
+            long long c = (long long)nsub_f;
+            c = log2_classes ? 63 - __clzll((unsigned long long)c) : c;
+            c = c < kClasses - 1 ? c : kClasses - 1;
+            tile_list[(size_t)tile * kBlock + rank] = (unsigned short)(threadIdx.x | ((int)c << 8));
+        } else { // the one sub-step of the column, :266-312 with NoSubS = 1
+            sa = dmin(k1a * DtDay, ws1b - w1b);
+            sb = dmin(k1b * DtDay, ws2 - w2);
+            sg = dmin(k2 * DtDay, av2);
+        }
+        // the records of the multi-sub-step columns, kLoopCap per round (nearly always one round)
+        if (rank < (unsigned int)kLoopCap) {
+#define REC(f, v) s_rec[(f) * kLoopCap + rank] = (v)
+            REC(0, w1a); REC(1, wres1a); REC(2, ws1a); REC(3, ks1a); REC(4, im1a); REC(5, m1a); REC(6, k1a);
+            REC(7, w1b); REC(8, wres1b); REC(9, ws1b); REC(10, ks1b); REC(11, im1b); REC(12, m1b); REC(13, k1b);
+            REC(14, w2); REC(15, wres2); REC(16, ws2); REC(17, ks2); REC(18, im2); REC(19, m2); REC(20, k2);
+            REC(21, (double)flags);
+#undef REC
+            s_key[rank] = (unsigned int)nsub_f;
+        }
+    }
+    __syncthreads();
+    const unsigned int count = (unsigned int)__builtin_amdgcn_readfirstlane((int)s_count);
+    if (threadIdx.x == 0) tile_count[tile] = count;
+    for (unsigned int base = 0; base < count; base += kLoopCap) { // (uniform over the workgroup; nearly always one round)
+        if (base > 0) {
+            // a tile with more than kLoopCap multi-sub-step columns: the next kLoopCap of its list.  Their lanes still hold
+            // the water contents and the first conductivities; the layer parameters are read again (cache hits).
+            __syncthreads(); // the results of the round before have been taken
+            if (threadIdx.x == 0) s_next = 0;
+            const unsigned int r = rank - base;
+            if (r < (unsigned int)kLoopCap) {
+#define REC(f, v) s_rec[(f) * kLoopCap + r] = (v)
+                REC(0, w1a); REC(1, A.WRes1a[j]); REC(2, ws1a); REC(3, A.KSat1a[j]); REC(4, A.GenuInvM1a[j]); REC(5, A.GenuM1a[j]); REC(6, k1a);
+                REC(7, w1b); REC(8, A.WRes1b[j]); REC(9, A.WS1b[j]); REC(10, A.KSat1b[j]); REC(11, A.GenuInvM1b[j]); REC(12, A.GenuM1b[j]); REC(13, k1b);
+                REC(14, w2); REC(15, A.WRes2[j]); REC(16, A.WS2[j]); REC(17, A.KSat2[j]); REC(18, A.GenuInvM2[j]); REC(19, A.GenuM2[j]); REC(20, k2);
+                REC(21, (double)flags);
+#undef REC
+                s_key[r] = (unsigned int)nsub_f;
+            }
+            __syncthreads();
+        }
+        const unsigned int n = (count - base) < (unsigned int)kLoopCap ? (count - base) : (unsigned int)kLoopCap;
+        // descending trip count, ties by list position: entry t goes to place #{entries before it in that order}
+        if (threadIdx.x < n) {
+            const unsigned int k = s_key[threadIdx.x];
+            unsigned int pos = 0;
+            for (unsigned int q = 0; q < n; ++q) {
+                const unsigned int kq = s_key[q];
+                pos += (kq > k || (kq == k && q < threadIdx.x)) ? 1u : 0u;
+            }
+            s_order[pos] = (unsigned short)threadIdx.x;
+        }
+        __syncthreads();
+        const unsigned int ntasks = (n + kColsPerWave - 1) / kColsPerWave, lane = threadIdx.x & 63u;
+        const unsigned int col = lane / 3u, layer = lane - 3u * col;
+        for (;;) {
+            unsigned int t = 0;
+            if (lane == 0) t = atomicAdd(&s_next, 1u);
+            t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
+            if (t >= ntasks) break;
+            const unsigned int e = t * kColsPerWave + col;
+            const bool valid = col < (unsigned int)kColsPerWave && e < n;
+            const unsigned int first = s_order[t * kColsPerWave]; // the task's first column is its heaviest
+            const unsigned int slot = valid ? s_order[e] : first;
+            const double *__restrict__ R = s_rec + (7u * layer) * kLoopCap + slot;
+            const double w = R[0], wres = R[kLoopCap], ws = R[2 * kLoopCap], ks = R[3 * kLoopCap], im = R[4 * kLoopCap],
+                         m = R[5 * kLoopCap];
+            double k = R[6 * kLoopCap];
+            const long long nsub = valid ? (long long)s_key[slot] : 0;
+            const int fl = (int)s_rec[21 * kLoopCap + slot];
+            const bool pore = ((fl >> (1 + (int)layer)) & 1) != 0;
+            const long long tmax = (long long)__builtin_amdgcn_readfirstlane((int)s_key[first]);
+            const double dtsub = DtDay / (double)(long long)s_key[slot];
+            double av = w - wres, wt = w, cap = ws - w, sum = 0.;
+            for (long long s = 0; s < tmax; ++s) {
+                if (s > 0) k = unsat_k<FASTPOW>(wt, pore, wres, ws, ks, im, m);
+                const double cap_below = __shfl_down(cap, 1, 64);     // layer + 1 of the same column
+                const double limit = (layer == 2u) ? av : cap_below;  // :280-285
+                const double flux = dmin(k * dtsub, limit);
+                const double flux_above = __shfl_up(flux, 1, 64);     // layer - 1 of the same column
+                const double net = (layer == 0u) ? -flux : flux_above - flux;
+                const bool live = s < nsub;
+                av = live ? av + net : av;                            // :286-288 (av1a -= fa is av1a + (-fa) exactly)
+                wt = av + wres;
+                cap = ws - wt;
+                sum = live ? sum + flux : sum;
+            }
+            if (valid) s_res[layer * kLoopCap + slot] = sum;
+        }
+        __syncthreads();
+        const unsigned int r = rank - base;
+        if (r < (unsigned int)kLoopCap) {
+            sa = s_res[r];
+            sb = s_res[kLoopCap + r];
+            sg = s_res[2 * kLoopCap + r];
+        }
+    }
+    if (!active) return;
+    const bool frozen = (flags & 1) != 0, pore1a = (flags & 2) != 0, pore1b = (flags & 4) != 0, pore2 = (flags & 8) != 0;
+    if (frozen) sa = sb = sg = 0.; // :313-316
+    // state update, :319-325 (W1 is taken BEFORE the 1a overflow correction, as the reference does)
+    w1a -= sa;
+    w1b = w1b + sa - sb;
+    w2 = w2 + sb - sg;
+    const double w1 = w1a + w1b;
+    inf -= dmax(w1a - ws1a, 0.);
+    w1a = dmin(w1a, ws1a);
+    // upper zone, :342-354
+    if (P.drained[veg]) {
+        uzout += A.DrainedFraction * sg;
+        uz += (1 - A.DrainedFraction) * sg + pref;
+    } else
+        uz += sg + pref;
+    const double perc = dmin(in_gwp, uz);
+    uz = dmax(uz - perc, 0.);
+    A.SeepTopToSubA[i] = sa;
+    A.SeepTopToSubB[i] = sb;
+    A.SeepSubToGW[i] = sg;
+    A.Infiltration[i] = inf;
+    A.W1a[i] = w1a;
+    A.W1b[i] = w1b;
+    A.W1[i] = w1;
+    A.W2[i] = w2;
+    // diagnostics, :330-336
+    A.Theta1a[i] = pore1a ? w1a / in_sd1a : 0.;
+    A.Theta1b[i] = pore1b ? w1b / in_sd1b : 0.;
+    A.Theta2[i] = pore2 ? w2 / in_sd2 : 0.;
+    A.Sat1a[i] = (w1a - wwp1a) / (in_wfc1a - wwp1a);
+    A.Sat1b[i] = (w1b - wwp1b) / (in_wfc1b - wwp1b);
+    A.Sat1[i] = (w1 - wwp1) / (in_wfc1 - wwp1);
+    A.Sat2[i] = (w2 - wwp2) / (in_wfc2 - wwp2);
+    A.UZOutflow[i] = uzout;
+    A.GwPercUZLZ[i] = perc;
+    A.UZ[i] = uz;
+}
+
 int make_plan(const lf_soil_args *a, const uint8_t *paddy_any, veg_plan *P)
 {
     if (a->V > kMaxVeg) return lf_set_error(LF_E_INVALID, "V = %lld exceeds the supported maximum %d", (long long)a->V, kMaxVeg);
@@ -606,10 +880,13 @@ int lf_soil_columns_device(int device, const lf_soil_args *a)
     // tile counts | per-tile lane lists
     const unsigned int tiles_per_veg = (unsigned int)blocks_for(a->N);
     const size_t ntiles = (size_t)tiles_per_veg * (size_t)a->V;
+    // LF_SOIL_TWO_PASS=1: the two-launch form of rounds 1-4 (pass 1 + deferred columns from a staging area), kept for A/B
+    const char *tp = std::getenv("LF_SOIL_TWO_PASS");
+    const bool two_pass = tp && tp[0] == '1';
     // staging area of the deferred columns' inputs: 96 slots per tile of 256 columns (LF_SOIL_STAGE_SLOTS=0: off), used
     // when the previous call deferred at least 4 % of its columns (the count comes back asynchronously)
-    unsigned int cap = kStageCap;
-    if (const char *e = std::getenv("LF_SOIL_STAGE_SLOTS")) cap = std::atol(e) > 0 ? kStageCap : 0; // 0 = never stage
+    unsigned int cap = two_pass ? kStageCap : 0;
+    if (const char *e = std::getenv("LF_SOIL_STAGE_SLOTS")) cap = (two_pass && std::atol(e) > 0) ? kStageCap : 0; // 0 = never stage
     const char *force = std::getenv("LF_SOIL_STAGE_ALWAYS"); // A/B switch
     if (!c->soil_deferred_host) {
         LF_HIP(hipHostMalloc((void **)&c->soil_deferred_host, sizeof(unsigned long long), hipHostMallocDefault));
@@ -651,6 +928,15 @@ int lf_soil_columns_device(int device, const lf_soil_args *a)
     const int log2_classes = (l2 && l2[0] == '1') ? 1 : 0;
     const dim3 grid1(tiles_per_veg, (unsigned)a->V), block(kBlock);
     const dim3 grid2((unsigned)((ntiles + kGroup - 1) / kGroup));
+    if (!two_pass) { // one launch: every stream read once, every output written once (k_soil_fused)
+        if (fastpow)
+            hipLaunchKernelGGL(k_soil_fused<true>, grid1, block, 0, c->stream, *a, P, tile_list, tile_count, log2_classes);
+        else
+            hipLaunchKernelGGL(k_soil_fused<false>, grid1, block, 0, c->stream, *a, P, tile_list, tile_count, log2_classes);
+        c->soil_deferred_pending = false;
+        LF_HIP(hipGetLastError());
+        return LF_OK;
+    }
     LF_HIP(hipMemsetAsync(c->soil_deferred_dev, 0, sizeof(unsigned long long), c->stream));
     if (fastpow && stage)
         hipLaunchKernelGGL((k_soil_columns<true, true>), grid1, block, 0, c->stream, *a, P, tile_list, tile_count, S, log2_classes);

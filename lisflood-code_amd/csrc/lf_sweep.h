@@ -404,7 +404,7 @@ struct cone_rec_ca {
 struct cone_rec_fl {
     float af, laf; // (float)a and log2 of it: the part of lf_solve_3_5's seed that does not depend on c
     int fast_a;    // a in the fast range
-    int pad;
+    int pos;       // the position the lane's operands were read from (cell 0 for a lane beyond the cone's range)
 };
 struct cone_rec_ad {
     int ad[4]; // byte offsets (in the result rows) of four reads of the level above: slot first + k, or the 0.0 in slot 64
@@ -477,7 +477,7 @@ __device__ __forceinline__ void cone_chain(cone_lds<NR, KC> &S, int tid, int nl,
                     q = (le || !quintic) ? 0.0 : q;
                     if (!le && !quintic) {
                         const sweep_args &A = M.r[r];
-                        const double at = A.a[ld_table(c0, ch * KC + jj) + tid]; // (a lane beyond the cone's range: any cell)
+                        const double at = A.a[cur.fl[r].pos]; // (a lane beyond the cone's range: cell 0, like its other operands)
                         q = lf_solve_cell_cold(c, at, A.beta * at, A.beta, A.inv_beta, A.b_minus_1);
                     }
                 } else {
@@ -656,7 +656,7 @@ __global__ void __launch_bounds__(64 * (1 + NS)) k_sweep_cones_split(cone_plan_a
                 fl.af = (float)ca.ap;
                 fl.laf = __builtin_amdgcn_logf(fl.af);
                 fl.fast_a = fast_a;
-                fl.pad = 0;
+                fl.pos = P.act[i] ? lbound(c0, j) + tid : 0;
                 O.ca[jj][r][tid] = ca;
                 O.fl[jj][r][tid] = fl;
             }

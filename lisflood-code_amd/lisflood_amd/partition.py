@@ -53,11 +53,16 @@ def catchment_roots_of_raster(ldd_raster, land_mask=None):
         parent[ok] = tgt[ok]
         del sel, ok, tgt
     parent = parent.reshape(-1)
-    while True:                                                   # parent <- parent o parent until nothing moves
+    parent0 = parent.copy()                                       # one hop: a root is a fixed point of it
+    # parent <- parent o parent until nothing moves: a path of length L settles in ceil(log2 L) passes, so more than
+    # log2(n) + 1 passes means a cycle (odd cycles never settle, even ones would split into several false roots)
+    for _ in range(int(np.ceil(np.log2(max(n, 2)))) + 2):
         nxt = parent[parent]
         if np.array_equal(nxt, parent):
             break
         parent = nxt
+    if not np.array_equal(parent[parent], parent) or not np.array_equal(parent0[parent], parent):
+        raise ValueError("the LDD has a cycle (the Graph path reports LF_E_CYCLE for the same raster)")
     landf = land.reshape(-1)
     comp = np.cumsum(landf, dtype=np.int64).astype(np.int32) - 1  # raster index -> compressed pixel id
     return comp[parent[landf]]

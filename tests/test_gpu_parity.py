@@ -614,8 +614,15 @@ def test_structures_wavefront_mid_size_synthetic(amd, family):
     assert np.isfinite(va.ChanQ).all() and va.QLakeOutM3Dt.max() > 0 and va.QResOutM3Dt.max() > 0 and va.TransCum.max() > 0
 
 
-def test_structures_mid_size_vs_oracle(amd, oracle):
-    """The device's structures + routing sub-step loop against the C oracle (itself 0 ulp from the reference's modules
+@pytest.mark.parametrize("trans", ["scenario", "settings_defaults"])
+def test_structures_mid_size_vs_oracle(amd, oracle, trans):
+    """`settings_defaults`: TransPower1 = 2, TransSub = 0.3 (transmission.py:58-59 with the settings' default maps) on
+    reaches some of which carry less than 0.09 m3/s, so (Q^0.5 - 0.3) is NEGATIVE there and its square is what the
+    reference (numpy ** = C pow) computes -- the fast pow of the loss must not turn that into NaN.  ONE sub-step there, by
+    the wavefront and by the sub-step-by-sub-step engine: the loss 0.6 sqrt(Q) - 0.09 has an unbounded derivative at Q = 0,
+    so from the second sub-step on the 1e-11 rounding noise of a reach that has run dry (ChanQ = max(kin + kin2 - QLimit,
+    0)) is a 1e-2 m3 difference of its loss -- in the reference's arithmetic as much as in any other.
+    The device's structures + routing sub-step loop against the C oracle (itself 0 ulp from the reference's modules
     on the LF_ETRS89 fixture) on a 1.2e5-cell synthetic network with 12 lakes, 36 reservoirs, inflow points and
     transmission loss: 24 sub-steps, every state vector within the parity tolerance."""
     from lisflood_amd import synthetic as syn
@@ -625,7 +632,7 @@ def test_structures_mid_size_vs_oracle(amd, oracle):
     codes = syn.make_ldd("deep", H, W, 11).reshape(-1).astype(np.float64)
     p = syn.router_params(N, seed=7)
     rng = np.random.default_rng(37)
-    beta, dt, nsteps = p["beta"], 3600.0, 24
+    beta, dt, nsteps = p["beta"], 3600.0, (24 if trans == "scenario" else 1)
     alpha, length = p["alpha"], p["dx"]
     alpha2 = alpha * rng.uniform(1.2, 2.0, N)
     qlimit = 2.0 * p["Q0"] * rng.uniform(0.3, 1.2, N)
@@ -647,6 +654,13 @@ def test_structures_mid_size_vs_oracle(amd, oracle):
         d, cut = syn.structures_scenario(codes, (H, W), v.ChanQ, dt, n_lakes=12, n_res=36)
         for k, x in d.items():
             setattr(v, k, np.array(x, copy=True) if isinstance(x, np.ndarray) else x)
+        if trans == "settings_defaults":
+            v.TransPower1, v.TransPower2, v.TransSub = 2.0, 0.5, 0.3
+            dry = np.random.default_rng(41).choice(N, 4000, replace=False)
+            v.UpTrans = v.UpTrans.copy(); v.UpTrans[dry] = True
+            for k in ("ChanQ", "ChanQKin"):
+                x = getattr(v, k).copy(); x[dry] = np.linspace(0.0, 0.09, dry.size, endpoint=False); setattr(v, k, x)
+            v.ChanM3Kin = alpha * length * v.ChanQKin ** beta
         return v, cut
 
     vg, cut = var()
@@ -668,6 +682,17 @@ def test_structures_mid_size_vs_oracle(amd, oracle):
         atol = cancel * (nsteps if k == "TransCum" else 1) if k in ("TransLossM3Dt", "TransCum") else 1e-6
         np.testing.assert_allclose(getattr(vg, k), getattr(vc, k), rtol=RTOL, atol=atol, err_msg=k)
     assert vc.QLakeOutM3Dt.max() > 0 and vc.QResOutM3Dt.max() > 0 and vc.TransCum.max() > 0
+    assert np.isfinite(vg.TransCum).all() and np.isfinite(vg.ChanQ).all()
+    if trans == "settings_defaults":
+        assert vc.TransCum.min() < 0          # the negative-base branch was taken (loss below zero on the dry reaches)
+        v2, _ = var()                         # the same sub-step by lf_inloop_structures + lf_routing_substep
+        m2 = amd.routing.routing(v2, options=dict(SplitRouting=True, InitLisflood=False, simulateLakes=True,
+                                                  simulateReservoirs=True, inflow=True, TransLoss=True), engine_order=True)
+        m2.attach_router(cut, mask)
+        m2.attach_structures()
+        m2.dynamic(0)
+        for k in _STRUCT_KEYS:
+            assert np.array_equal(getattr(v2, k), getattr(vg, k), equal_nan=True), k
 
 
 @pytest.mark.parametrize("with_structures", [False, True])
@@ -963,6 +988,38 @@ def test_soil_columns_device_resident_vs_oracle(amd, oracle, solver):
     for k in syn.SOIL_WRITTEN:
         np.testing.assert_allclose(d2[k], r2[k], rtol=1e-9, atol=1e-11, err_msg=k)
     assert (d2["Theta1a"][1] == 0).all()
+
+
+def test_soil_columns_more_multi_substep_columns_than_a_round_holds(amd, oracle, solver):
+    """Nearly saturated soil: most columns of every 256-column tile need several Courant sub-steps, more than the 128 the
+    sub-step phase of k_soil_fused takes per round, so the later rounds (records rebuilt from the lanes' registers) run;
+    frozen pixels and a skipped paddy fraction in the same tiles."""
+    import ctypes as C
+    from lisflood_amd import synthetic as syn
+    N = 20011
+    d = syn.soil_params(N, seed=11)
+    lu = np.asarray(d["index_landuse_all"])
+    rng = np.random.default_rng(12)
+    for name in ("1a", "1b", "2"):                        # nearly saturated + 8 x KSat: ~99 % need several sub-steps, up to ~550
+        d["W" + name] = d["WRes" + name][lu] + rng.uniform(0.985, 1.0, (3, N)) * (d["WS" + name][lu] - d["WRes" + name][lu])
+        d["KSat" + name] = d["KSat" + name] * 8.0
+    d["W1"] = d["W1a"] + d["W1b"]
+    d["is_paddy_irrig"] = np.array([False, False, True])
+    d["is_irrigated"] = np.array([False, True, True])
+    d["paddy_inactive"] = np.random.default_rng(2).random((1, N)) < 0.7
+    ref = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in d.items()}
+    dev = amd.soil.SoilColumnsDevice(d)
+    for s in range(2):
+        dev.step()
+        oracle.soil_columns(ref)
+        if s == 0:
+            nd = C.c_int64(0)
+            amd.lib.check(amd.lib.lib().lf_soil_last_deferred(C.c_int(0), C.byref(nd)))
+            assert nd.value > 0.6 * 2 * N, nd.value      # > 128 of 256 columns per tile on the two full fractions
+    for k in syn.SOIL_WRITTEN:
+        np.testing.assert_allclose(dev.get(k), ref[k], rtol=1e-9, atol=1e-11, err_msg=k)
+    for a in dev.dev.values():
+        a.free()
 
 
 def test_soil_full_size_water_balance_property(amd):
