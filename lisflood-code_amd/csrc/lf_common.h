@@ -39,12 +39,8 @@ struct lf_device_ctx {
     // before the next one
     void *stage_base = nullptr;
     size_t stage_bytes = 0, stage_need = 0;
-    void *soil_ws = nullptr; // work list of deferred soil columns (lf_soil.hip)
+    void *soil_ws = nullptr; // lists and straggler records of the soil call (lf_soil.hip: soil_ws_layout)
     size_t soil_ws_bytes = 0, soil_ntiles = 0;
-    // deferred-column count of the last soil call, copied back asynchronously: decides whether the next call stages
-    unsigned long long *soil_deferred_host = nullptr, *soil_deferred_dev = nullptr, soil_deferred_columns = 0;
-    hipEvent_t soil_deferred_ready = nullptr;
-    bool soil_deferred_pending = false, soil_stage_last = false;
     // upload stream for double-buffered inputs (lf_upload_*): copies of the NEXT step's forcing overlap the kernels of
     // the current one; per buffer set an event "copy finished" and an event "last kernel reading the set finished"
     hipStream_t copy_stream = nullptr;

@@ -1,18 +1,21 @@
 #!/bin/bash
-# Round-5 A/B of the soil kernels on the GPU box: the one-launch form (k_soil_fused, default) against the two-pass form
-# (LF_SOIL_TWO_PASS=1), same box, same process layout: parity tests first, then `bench.py --only soil` of each.
+# Round-5 A/B of the soil kernel on the GPU box.  usage: ab_soil_r05.sh "<ENV=VAL ...>" "<ENV=VAL ...>" ...
+# each argument is one variant (environment of the run, e.g. "LF_SOIL_TILE=64" or "LF_SOIL_TWO_PASS=1"): the soil parity
+# tests under that environment, then `bench.py --only soil` twice.  Same box, back to back.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out; mkdir -p $OUT
 cd $ROOT
-python -m pytest tests -m gpu -x -q -k "soil or canopy or chain or hot_path or structures_mid_size or cone or deep" 2>&1 | tail -5 | tee $OUT/r05_soil_tests.txt
-for tp in 0 1; do
+[ $# -eq 0 ] && set -- ""
+for v in "$@"; do
+  tag=$(echo "$v" | tr ' =' '__'); [ -z "$tag" ] && tag=default
+  echo "== variant: ${v:-default}"
+  env $v python -m pytest tests -m gpu -x -q -k "soil_columns or soilloop or soil_full" 2>&1 | tail -2
   for rep in 1 2; do
-    LF_SOIL_TWO_PASS=$tp python bench.py --only soil > $OUT/r05_soil_bench_tp${tp}_$rep.json 2> $OUT/r05_soil_bench_tp${tp}_$rep.err
-    python - $OUT/r05_soil_bench_tp${tp}_$rep.json $tp <<'PY'
+    env $v python bench.py --only soil > $OUT/r05_soil_${tag}_$rep.json 2> $OUT/r05_soil_${tag}_$rep.err
+    python - $OUT/r05_soil_${tag}_$rep.json <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-s = d.get("soil", d)
-print("two_pass=%s" % sys.argv[2], {k: (v["ms_per_step"], v["frac_hbm"], v["multi_substep_columns_frac"]) for k, v in s.items() if isinstance(v, dict) and "ms_per_step" in v})
+print("   ", {k: (v["ms_per_step"], v["frac_hbm"], v["multi_substep_columns_frac"]) for k, v in d.items() if isinstance(v, dict) and "ms_per_step" in v})
 PY
   done
 done

@@ -17,3 +17,7 @@ for s in range(12):
     c = np.cumsum(h)
     print(s, "deferred", int(h.sum()), "mean sub-steps %.2f" % ((h * k).sum() / max(h.sum(), 1)),
           "median/p90/p99/max", [int(np.searchsorted(c, q * h.sum())) for q in (0.5, 0.9, 0.99)] + [int(np.nonzero(h)[0].max())])
+    if s in (2, 6, 11):     # the tail: share of the deferred columns and of their sub-steps above a threshold
+        tot, work = h.sum(), (h * k).sum()
+        print("   ", ["T=%d: %.3f of deferred, %.3f of their sub-steps" % (T, h[T + 1:].sum() / tot, (h * k)[T + 1:].sum() / work)
+                      for T in (4, 8, 12, 16, 24, 32, 48)])
