@@ -299,10 +299,10 @@ def cpu_baseline(family, sample, steps=2, full=10000, budget_s=45.0):
 
 
 def soil_bench(N=4_000_000, steps=10):
-    """Secondary metric: soil column-steps/s (lf_soil.hip), 504 B algorithmic per (veg,pixel)-step.  Two regimes of
-    the same synthetic soil: `wet` (KSat 5-500 mm/d, 30 mm/d rain: 17-30 % of the columns need several Courant
-    sub-steps, mean 2.6-4.9 sub-steps per column) and `single_substep` (KSat / 50: every column needs one sub-step,
-    the memory-bound regime of the kernel)."""
+    """Secondary metric: soil column-steps/s (lf_soil.hip: k_soil_fused + k_soil_stragglers), 504 B algorithmic per
+    (veg,pixel)-step.  Two regimes of the same synthetic soil: `wet` (KSat 5-500 mm/d, 30 mm/d rain: 17-30 % of the
+    columns need several Courant sub-steps, mean 2.6-4.9 sub-steps per column, up to 92) and `single_substep` (KSat / 50:
+    nearly every column needs one sub-step, the memory-bound regime of the kernel)."""
     import ctypes as C
     from lisflood_amd import _lib
     from lisflood_amd import synthetic as syn
@@ -331,12 +331,9 @@ def soil_bench(N=4_000_000, steps=10):
         out[regime] = dict(value=round(cols / ms / 1e3, 2), unit="Mcolumn-steps/s", ms_per_step=round(ms, 4),
                            achieved_GBs=round(gbs, 1), frac_hbm=round(gbs / HBM_PEAK_GBS, 4),
                            multi_substep_columns_frac=round(nd.value / cols, 4))
-        # committed counter passes of this very command (tools/pmc_soil_r04.sh): HBM bytes per call of the regime's kernels
+        # committed counter passes of this very command (tools/pmc_soil_r05.sh): HBM bytes per call of the regime's kernels
         tr = {}
-        for key, sub in (("pass1", "k_soil_columns<true, true>" if regime == "wet" else "k_soil_columns<true, false>"),
-                         ("pass2", "k_soil_columns_deferred")):
-            if key == "pass2" and regime != "wet":
-                continue
+        for key, sub in (("columns", "k_soil_fused"), ("stragglers", "k_soil_stragglers")):
             t3, s3, counters = pmc_traffic_r03("soil_%s_%d" % (regime, N), sub)
             if t3 is not None:
                 tr[key] = dict(kernel=sub, traffic=round(t3, 1), traffic_unit="bytes per launch", traffic_source=s3,

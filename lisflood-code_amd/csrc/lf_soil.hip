@@ -7,6 +7,7 @@
 // are fetched once.  Every array keeps the reference's [V,N] / [L,N] C-order layout, so lanes of a
 // wavefront read/write consecutive fp64 of one row: all ~95 streams are coalesced.  The kernel is
 // HBM-bound (~500 B per column-step) unless many Courant sub-steps are needed.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 
@@ -256,7 +257,7 @@ struct soil_strag {
 template <bool FASTPOW, int WAVES>
 __global__ void __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(WAVES)))
 k_soil_fused(lf_soil_args A, veg_plan P, unsigned short *__restrict__ all_list, unsigned int *__restrict__ all_count,
-             soil_strag G)
+             soil_strag G, unsigned int tile0, unsigned int tiles_per_veg)
 {
     constexpr int kLoopCap = kTile / 2; // multi-sub-step columns of a tile handled per round (more -> another round)
     __shared__ unsigned int s_count, s_next, s_all, s_strag;
@@ -274,9 +275,9 @@ k_soil_fused(lf_soil_args A, veg_plan P, unsigned short *__restrict__ all_list, 
     __syncthreads();
     const long long N = A.N;
     const double DtDay = A.DtDay;
-    const long long pix = (long long)blockIdx.x * kTile + threadIdx.x;
-    const int veg = blockIdx.y;
-    const unsigned int tile = blockIdx.x + blockIdx.y * gridDim.x;
+    const unsigned int tile = tile0 + blockIdx.x; // tiles of a vegetation row one after the other, row after row
+    const int veg = (int)(tile / tiles_per_veg);
+    const long long pix = (long long)(tile - (unsigned int)veg * tiles_per_veg) * kTile + threadIdx.x;
     const int mode = P.mode[veg];
     bool active = pix < N && mode != 0;
     if (active && mode == 2 && !A.paddy_inactive[(long long)P.paddy_row[veg] * N + pix]) active = false;
@@ -493,15 +494,15 @@ k_soil_fused(lf_soil_args A, veg_plan P, unsigned short *__restrict__ all_list, 
 // The stragglers of kStragGroup consecutive tiles: sorted by trip count in LDS, 20 columns per wavefront (three lanes per
 // column), heaviest first; the lane of layer 0 finishes the column (phase 3 of k_soil_fused) over the placeholders.
 template <bool FASTPOW>
-__global__ void __launch_bounds__(kTile) k_soil_stragglers(lf_soil_args A, veg_plan P, soil_strag G, unsigned int ntiles,
-                                                           unsigned int tiles_per_veg)
+__global__ void __launch_bounds__(kTile) k_soil_stragglers(lf_soil_args A, veg_plan P, soil_strag G, unsigned int group0,
+                                                           unsigned int ntiles, unsigned int tiles_per_veg)
 {
     constexpr int kMaxEntries = kStragGroup * kStragCap;
     static_assert(kClasses <= kTile && kClasses % 64 == 0 && kStragCap < 256 && kStragGroup < 256, "list layout");
     __shared__ unsigned int off[kStragGroup + 1], h[kClasses], base[kClasses], next_task;
     __shared__ unsigned short cls_of[kMaxEntries], rank_of[kMaxEntries], ent_of[kMaxEntries]; // per raw entry
     __shared__ unsigned short entry[kMaxEntries];                                            // (tile in group << 8 | slot), by class
-    const unsigned int t0 = blockIdx.x * kStragGroup;
+    const unsigned int t0 = (group0 + blockIdx.x) * kStragGroup;
     if (threadIdx.x < kClasses) h[threadIdx.x] = 0;
     if (threadIdx.x == 0) {
         unsigned int t = 0;
@@ -732,21 +733,26 @@ int lf_soil_columns_device(int device, const lf_soil_args *a)
     // LF_SOIL_WAVES=4: four wavefronts per SIMD (128 registers: the state a lane holds across the sub-step phase spills)
     int waves = 3;
     if (const char *e = std::getenv("LF_SOIL_WAVES")) waves = std::atol(e) == 4 ? 4 : 3;
-    const dim3 grid(tiles_per_veg, (unsigned)a->V), block(kTile);
+    // (Sending the call out in chunks of tiles with the stragglers of a chunk on a second stream beside the streaming launch
+    // of the next chunk was measured and dropped: 2.28 / 2.29 / 2.35 / 2.50 / 2.90 ms for 1 / 2 / 4 / 8 / 16 chunks on the wet
+    // synthetic soil -- the streaming launch fills every compute unit, the second stream only gets the chunk tails.)
+    const dim3 grid((unsigned)ntiles), block(kTile);
+    size_t dyn = 0; // LF_SOIL_DEBUG_LDS=<bytes>: extra LDS per workgroup, to bound the tiles in flight per compute unit (timing experiments)
+    if (const char *e = std::getenv("LF_SOIL_DEBUG_LDS")) dyn = (size_t)std::atol(e);
     if (fastpow && waves == 3)
-        hipLaunchKernelGGL((k_soil_fused<true, 3>), grid, block, 0, c->stream, *a, P, all_list, all_count, G);
+        hipLaunchKernelGGL((k_soil_fused<true, 3>), grid, block, dyn, c->stream, *a, P, all_list, all_count, G, 0u, tiles_per_veg);
     else if (fastpow)
-        hipLaunchKernelGGL((k_soil_fused<true, 4>), grid, block, 0, c->stream, *a, P, all_list, all_count, G);
+        hipLaunchKernelGGL((k_soil_fused<true, 4>), grid, block, dyn, c->stream, *a, P, all_list, all_count, G, 0u, tiles_per_veg);
     else if (waves == 3)
-        hipLaunchKernelGGL((k_soil_fused<false, 3>), grid, block, 0, c->stream, *a, P, all_list, all_count, G);
+        hipLaunchKernelGGL((k_soil_fused<false, 3>), grid, block, dyn, c->stream, *a, P, all_list, all_count, G, 0u, tiles_per_veg);
     else
-        hipLaunchKernelGGL((k_soil_fused<false, 4>), grid, block, 0, c->stream, *a, P, all_list, all_count, G);
+        hipLaunchKernelGGL((k_soil_fused<false, 4>), grid, block, dyn, c->stream, *a, P, all_list, all_count, G, 0u, tiles_per_veg);
     if (G.trip_cap > 0) {
         const dim3 grid2((unsigned)((ntiles + kStragGroup - 1) / kStragGroup));
         if (fastpow)
-            hipLaunchKernelGGL(k_soil_stragglers<true>, grid2, block, 0, c->stream, *a, P, G, (unsigned int)ntiles, tiles_per_veg);
+            hipLaunchKernelGGL(k_soil_stragglers<true>, grid2, block, 0, c->stream, *a, P, G, 0u, (unsigned int)ntiles, tiles_per_veg);
         else
-            hipLaunchKernelGGL(k_soil_stragglers<false>, grid2, block, 0, c->stream, *a, P, G, (unsigned int)ntiles, tiles_per_veg);
+            hipLaunchKernelGGL(k_soil_stragglers<false>, grid2, block, 0, c->stream, *a, P, G, 0u, (unsigned int)ntiles, tiles_per_veg);
     }
     LF_HIP(hipGetLastError());
     return LF_OK;
