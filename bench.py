@@ -270,7 +270,9 @@ def cpu_baseline(family, sample, steps=2, full=10000, budget_s=45.0):
         rates[threads] = N * steps / (time.perf_counter() - t0) / 1e6
     cores = max(rates, key=rates.get)
     out = dict(value=round(rates[cores], 3), unit="Mcell-steps/s", cores=cores, kind="port", cpu_model=cpu_model(),
-               host_cpus=ncpu, usable_cpus=avail,
+               host_cpus=ncpu, usable_cpus=avail, one_core_value=round(rates[1], 3),
+               all_cores_value=round(rates[max(rates)], 3), all_cores=max(rates),
+               team_rates={str(k): round(x, 3) for k, x in sorted(rates.items())},
                sample="%dx%d %s raster, %d calls per thread count; best of OpenMP teams %s = %d threads "
                       "(1 thread: %.3f Mcell-steps/s); C restatement of the reference algorithm (oracle/lf_oracle.c), "
                       "not numba" % (sample, sample, family, steps, sorted(rates), cores, rates[1]),
@@ -542,21 +544,29 @@ def overland_bench(size=4000, channel_frac=0.04, steps=6):
     return out
 
 
-def hotpath_bench(size=2000, steps=6):
+def hotpath_bench(size=2000, steps=6, family="deep", block=1_000_000):
     """The whole device-resident hot path of a model step (canopy -> soil -> per-pixel aggregates -> 3 overland
     routers -> 24 split-routing channel sub-steps), lisflood_amd.hotpath.HotPathDevice; only the five forcing
-    vectors cross PCIe per step."""
+    vectors cross PCIe per step.  `stages`: every stage timed on its own (one model step, synchronising after each)
+    with its algorithmic bytes (HotPathDevice.stage_bytes) and the fraction of the HBM roofline that makes."""
     from lisflood_amd import _lib
     from lisflood_amd import synthetic as syn
     from lisflood_amd.hotpath import HotPathDevice
     H = W = size
     N = H * W
     t = time.time()
-    values, sc, mask, ldd_to_chan, ldd_kin = syn.hotpath_scenario(H, W)
+    values, sc, mask, ldd_to_chan, ldd_kin = syn.hotpath_scenario(H, W, family=family, block=block)
+    t_scen = time.time() - t
     hp = HotPathDevice(values, sc, mask, ldd_to_chan, ldd_kin, split=True)
-    forc = [syn.hotpath_forcing(N, s) for s in range(2)]
-    log("[bench] hot-path scenario %dx%d built in %.1f s" % (H, W, time.time() - t))
-    for w in range(3):          # steady state: the soil kernel decides on its staging path from the previous calls
+    del values
+    forc = []
+    for s in range(2):      # page-locked forcing buffers, filled in place (what a netCDF reader would do)
+        f = hp.pinned_forcing()
+        for k, a in syn.hotpath_forcing(N, s).items():
+            f[k][:] = a
+        forc.append(f)
+    log("[bench] hot-path scenario %s %dx%d: fields %.1f s, device set-up %.1f s" % (family, H, W, t_scen, time.time() - t - t_scen))
+    for w in range(3):
         hp.step(forc[w % 2], w + 1)
         _lib.synchronize()
     t0 = time.perf_counter()
@@ -567,11 +577,12 @@ def hotpath_bench(size=2000, steps=6):
     _lib.synchronize()
     ms = (time.perf_counter() - t0) * 1e3 / steps
     q = hp.chan_q_avg()
-    out = dict(ms_per_model_step=round(ms, 3), model_steps_per_s=round(1e3 / ms, 2), pixels=N,
+    out = dict(ms_per_model_step=round(ms, 3), model_steps_per_s=round(1e3 / ms, 2), pixels=N, channel_pixels=int(hp.Nk),
                Mpixel_steps_per_s=round(N / ms / 1e3, 2), finite=bool(np.isfinite(q).all()),
-               config="%dx%d deep LDD, 30 %% channel pixels, V=3 fractions, NoRoutSteps=24 split routing; forcing "
+               levels=dict(channel=int(hp.river.graph.num_levels), overland=int(hp.r_other.graph.num_levels)),
+               config="%dx%d %s LDD, 30 %% channel pixels, V=3 fractions, NoRoutSteps=24 split routing; forcing "
                       "uploaded from the host every step; the channel wavefront on a second stream beside the next step's "
-                      "canopy / soil / overland kernels" % (H, W))
+                      "canopy / soil / overland kernels; parameter fields drawn for %d pixels and repeated" % (H, W, family, min(block, N)))
     # A/B: everything on one stream (rounds 1-3)
     hp.overlap_channel = False
     hp.step(forc[0], steps + 4)
@@ -582,6 +593,17 @@ def hotpath_bench(size=2000, steps=6):
         hp.prefetch(forc[(s + 1) % 2])
     _lib.synchronize()
     out["one_stream_ms_per_model_step"] = round((time.perf_counter() - t0) * 1e3 / steps, 3)
+    # stage by stage (two profiled steps, the mean)
+    acc = {}
+    nprof = 2
+    for s in range(nprof):
+        for k, x in hp.step_profile(forc[s % 2], 2 * steps + 6 + s).items():
+            acc[k] = acc.get(k, 0.0) + x / nprof
+    nbytes = hp.stage_bytes()
+    out["stages"] = {k: dict(ms=round(x, 3), alg_GB=round(nbytes[k] / 1e9, 3),
+                             frac_hbm=round(nbytes[k] / (x * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)) for k, x in acc.items()}
+    out["stages_sum_ms"] = round(sum(acc.values()), 3)
+    out["upload_GB_per_step"] = round(5 * 8 * N / 1e9, 3)
     hp.free()
     return out
 
@@ -603,7 +625,8 @@ def main():
         print(json.dumps(overland_bench()), flush=True)
         return
     if a.only == "hotpath":
-        print(json.dumps(hotpath_bench(min(a.size, 2000))), flush=True)
+        explicit = any(x.startswith("--size") or x.startswith("--family") for x in sys.argv)
+        print(json.dumps(hotpath_bench(a.size if explicit else 5000, family=a.family if explicit and a.family != "shallow" else "deep")), flush=True)
         return
     if a.only == "model_step":
         # default: the 5000^2 deep raster; `--family shallow --size 10000` with --only model_step gives the wide-level case
@@ -712,14 +735,93 @@ def main():
             extra["overland_sparse_channels"] = overland_bench()
         except Exception as e:
             extra["overland_sparse_channels_error"] = repr(e)
-        try:
-            extra["resident_hot_path_step"] = hotpath_bench()
-        except Exception as e:
-            extra["resident_hot_path_error"] = repr(e)
+        for fam in ("deep", "river"):    # the whole resident model step at a BASELINE size, stage by stage
+            try:
+                extra["resident_hot_path_step_%s_5000" % fam] = hotpath_bench(5000, family=fam)
+            except Exception as e:
+                extra["resident_hot_path_%s_error" % fam] = repr(e)
         out["other_workloads"] = extra
     if not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.family, a.cpu_sample, full=a.size)
-    print(json.dumps(out), flush=True)
+    # stdout carries ONE compact line (the driver keeps only the tail of it); everything else goes to the sidecar
+    detail_path = os.path.join(ROOT, "bench_detail.json")
+    try:
+        with open(detail_path, "w") as f:
+            json.dump(out, f, indent=1)
+    except OSError as e:
+        detail_path = "not written: %r" % (e,)
+    print(json.dumps(compact_line(out, os.path.relpath(detail_path, ROOT) if os.path.isabs(detail_path) else detail_path)),
+          flush=True)
+
+
+def compact_line(out, detail):
+    """The bench line the driver sees: the contract's keys, `roofline` and `cpu_baseline` in short form, and per
+    secondary leg only ms / value / frac / traffic ratio / launches (<= 4 KB in all; the rest is in `detail`)."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "finite")
+    line = {k: out[k] for k in keep if k in out}
+    c = out["config"]
+    line["config"] = dict(workload=c["workload"], cells=c["cells"], levels=c["levels"], launches_per_step=c["launches_per_step"],
+                          parallelism=c["parallelism"])
+    r = out.get("roofline")
+    if r:
+        line["roofline"] = dict(bound=r["bound"], kernel=r["kernel"].split(" (")[0], achieved=r["achieved"], peak=r["peak"], unit=r["unit"],
+                                frac=r["frac"], traffic=r["traffic"], alg_bytes_per_launch=r["alg_bytes_per_launch"],
+                                mean_launch_us=r["mean_launch_us"], launches_per_step=r["launches_per_step"])
+    cb = out.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = dict(value=cb["value"], unit=cb["unit"], cores=cb["cores"], kind=cb["kind"],
+                                    sample=cb["sample"].split(";")[0].split(" (")[0] + "; C restatement (oracle/lf_oracle.c), OpenMP",
+                                    one_core=cb.get("one_core_value"), all_cores=cb.get("all_cores"),
+                                    all_cores_value=cb.get("all_cores_value"), cpu=cb.get("cpu_model"))
+    legs = {}
+
+    def ratio(rf):
+        if rf and rf.get("traffic") and rf.get("alg_bytes_per_launch"):
+            return round(rf["traffic"] / rf["alg_bytes_per_launch"], 3)
+        return None
+    ow = out.get("other_workloads", {})
+    for fam in ("deep", "river", "shallow"):
+        e = ow.get(fam)
+        if e:
+            rf = e.get("roofline") or {}
+            legs["route_" + fam] = dict(ms=e["ms_per_step"], value=e["value"], frac=rf.get("frac"), traffic_ratio=ratio(rf),
+                                        launches=e["launches_per_step"])
+    po = out.get("pixel_order_call") or {}
+    if "ms_per_step" in po:
+        legs["pixel_order_call"] = dict(ms=po["ms_per_step"], value=po["value"])
+    so = ow.get("soil") or {}
+    for regime in ("wet", "single_substep"):
+        e = so.get(regime)
+        if e:
+            tb = e.get("traffic_bytes_per_column_step")
+            legs["soil_" + regime] = dict(ms=e["ms_per_step"], value=e["value"], frac=e["frac_hbm"],
+                                          traffic_ratio=round(tb / 504.0, 3) if tb else None, launches=2)
+    for key, short in (("model_step_24_substeps_split", "model_step_deep_5000"), ("model_step_with_structures", "model_step_structures_3000")):
+        e = ow.get(key) or {}
+        f = e.get("fused") or {}
+        if f:
+            rf = f.get("roofline") or {}
+            per = rf.get("hbm_bytes_per_cell_substep")
+            cells = {"model_step_deep_5000": 25e6, "model_step_structures_3000": 9e6}[short]
+            legs[short] = dict(ms=f.get("ms_per_model_step"), value=f.get("value"),
+                               frac=rf.get("frac", round(48 * B_ALG * cells / (f["ms_per_model_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)),
+                               traffic_ratio=round(per / (2 * B_ALG), 3) if per else None, launches=f.get("launches_per_model_step"))
+    e = (ow.get("overland_sparse_channels") or {}).get("together")
+    if e:
+        legs["overland_sparse_4000"] = dict(ms=e["ms_per_overland_step"], value=e["value"], frac=e["frac_hbm_whole_step"], launches=e["launches"])
+    for fam in ("deep", "river"):
+        e = ow.get("resident_hot_path_step_%s_5000" % fam)
+        if e:
+            legs["hot_path_%s_5000" % fam] = dict(ms=e["ms_per_model_step"], value=e["Mpixel_steps_per_s"], unit="Mpixel-steps/s",
+                                                   stages={k: [x["ms"], x["frac_hbm"]] for k, x in e["stages"].items()})
+    errs = {k: v for k, v in ow.items() if k.endswith("_error")}
+    if errs:
+        legs["errors"] = {k: str(v)[:80] for k, v in errs.items()}
+    line["legs"] = legs
+    line["legs_keys"] = "ms, value (Mcell-steps/s unless unit is given), frac = algorithmic bytes / time / 8 TB/s, traffic_ratio = counter bytes / algorithmic bytes, launches per step; stages: [ms, frac]"
+    line["detail"] = detail
+    return line
 
 
 if __name__ == "__main__":

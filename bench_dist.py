@@ -28,6 +28,18 @@ def log(rank, *a):
     print("[bench rank %d]" % rank, *a, file=sys.stderr, flush=True)
 
 
+def loaded_rccl():
+    """path of the librccl this process has mapped (the communicator dlopen()s it): the real one lives under /opt/rocm,
+    the tests' stand-in under tests/fake_rccl"""
+    try:
+        for line in open("/proc/self/maps"):
+            if "librccl" in line:
+                return line.split()[-1]
+    except OSError:
+        pass
+    return None
+
+
 def peak_rss_gb():
     import resource
     return resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6
@@ -268,6 +280,7 @@ def main(a):
                          "unit": "GB/s", "frac": round(B_ALG * N / world / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
                          "traffic": None},
             "checksum_sumQ": float(chk[0]), "finite": bool(chk[1] == world),
+            "rccl_library": loaded_rccl(),
         }
     printed = [False]
 

@@ -69,6 +69,13 @@ int lf_device_name(int device, char *buf, size_t buflen); /* gcnArchName, e.g. "
 int lf_device_alloc(int device, size_t bytes, void **ptr_dev);
 int lf_device_free(int device, void *ptr_dev);
 int lf_memcpy_h2d(int device, void *dst_dev, const void *src_host, size_t bytes);
+/* Page-locked host memory for the vectors that cross PCIe every model step (the meteorological forcing, which the
+ * reference reads from netCDF into fresh arrays each step, Lisflood_dynamic.py:84-112): a copy from such a buffer is a
+ * true asynchronous DMA at the link's rate; from pageable memory the runtime stages it and blocks the caller (measured
+ * at 5000^2: 1 GB of forcing per step, 29 GB/s pageable -- longer than the step's kernels).  lf_host_alloc fails
+ * without a HIP device like every other entry point. */
+int lf_host_alloc(int device, size_t bytes, void **ptr_host);
+int lf_host_free(int device, void *ptr_host);
 /* Double-buffered uploads on a second HIP stream, so that the copies of the NEXT step's inputs overlap the kernels of
  * the current step.  For buffer set b in {0, 1}:
  *     lf_upload_begin(b); lf_upload_copy(...) ...; lf_upload_end(b)            -- at any time, e.g. right after a step

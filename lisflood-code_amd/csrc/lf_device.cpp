@@ -124,6 +124,24 @@ int lf_device_free(int device, void *ptr_dev)
 
 static int side_join(lf_device_ctx *c);
 
+int lf_host_alloc(int device, size_t bytes, void **ptr_host)
+{
+    if (!ptr_host) return lf_set_error(LF_E_INVALID, "null argument");
+    *ptr_host = nullptr;
+    lf_device_ctx *c;
+    LF_TRY(lf_ctx(device, &c));
+    LF_HIP(hipHostMalloc(ptr_host, bytes ? bytes : 1, hipHostMallocDefault));
+    return LF_OK;
+}
+
+int lf_host_free(int device, void *ptr_host)
+{
+    lf_device_ctx *c;
+    LF_TRY(lf_ctx(device, &c));
+    if (ptr_host) LF_HIP(hipHostFree(ptr_host));
+    return LF_OK;
+}
+
 int lf_memcpy_h2d(int device, void *dst_dev, const void *src_host, size_t bytes)
 {
     lf_device_ctx *c;

@@ -82,6 +82,32 @@ def device_name(device=0):
     return buf.value.decode()
 
 
+class PinnedArray:
+    """numpy array in page-locked host memory (lf_host_alloc): `.a` is an ordinary ndarray to fill in place; uploads from
+    it are asynchronous DMA.  Keep the object alive as long as `.a` is in use."""
+
+    def __init__(self, shape, dtype=np.float64, device=0):
+        self.device = device
+        shape = tuple(np.atleast_1d(shape).tolist()) if not isinstance(shape, tuple) else shape
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        check(lib().lf_host_alloc(C.c_int(device), C.c_size_t(n), C.byref(p)))
+        self.ptr = C.c_void_p(p.value)
+        self.a = np.frombuffer((C.c_char * max(n, 1)).from_address(p.value), dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def free(self):
+        if getattr(self, "ptr", None) is not None and self.ptr.value:
+            self.a = None
+            lib().lf_host_free(C.c_int(self.device), self.ptr)
+            self.ptr = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class DeviceArray:
     """fp64 / uint8 vector resident in HBM (thin RAII wrapper over lf_device_alloc)."""
 

@@ -172,6 +172,15 @@ class HotPathDevice:
         check(L.lf_upload_end(C.c_int(dev), C.c_int(b)))
         self._keep[b] = host                 # the host vectors stay alive until the set is uploaded again
 
+    def pinned_forcing(self):
+        """A forcing dict (Rain, SnowMelt, EWRef, ETRef, ESRef) of [N] arrays in page-locked host memory, to be filled in
+        place (e.g. by the netCDF reader) and passed to prefetch() / step(): their upload is an asynchronous DMA at the
+        PCIe rate instead of a staged, blocking copy.  The arrays belong to this object (freed by free())."""
+        from ._lib import PinnedArray
+        bufs = {k: PinnedArray(self.N, np.float64, self.device) for k in FORCING}
+        self.__dict__.setdefault("_pinned", []).append(bufs)
+        return {k: b.a for k, b in bufs.items()}
+
     def prefetch(self, forcing):
         """Start uploading the forcing of the NEXT step() call now: the copies run on a second stream while the kernels
         of the step just enqueued are still executing.  Pass the same dict object to the next step()."""
@@ -221,43 +230,98 @@ class HotPathDevice:
         finally:
             check(L.lf_compute_release(C.c_int(dev), C.c_int(b)))
 
-    def _enqueue(self, time_since_start):
+    def _enqueue(self, time_since_start, stage_ms=None):
+        """stage_ms: a dict -> every stage is bracketed by the device stopwatch (which synchronises) and its
+        milliseconds are added under its name; the channel wavefront then runs on the main stream (step_profile)."""
         d, dev = self.d, self.device
         L = lib()
-        check(L.lf_canopy_device(C.c_int(dev), C.byref(self.canopy)))                                   # dyn.py:114
-        check(L.lf_scale_rows_device(C.c_int(dev), d["ESRef"].ptr, d["LAITerm"].ptr, d["ESMax"].ptr,
-                                     C.c_int64(3), C.c_int64(self.N)))                                 # soilloop.py:638
-        check(L.lf_soil_columns_device(C.c_int(dev), C.byref(self.soil)))                               # dyn.py:123
+        from . import _lib as LB
+
+        class stage:                       # `with stage("soil"):` -- a no-op unless stage_ms was passed
+            def __init__(self, name):
+                self.name = name
+
+            def __enter__(self):
+                if stage_ms is not None:
+                    LB.timer_start(dev)
+
+            def __exit__(self, *exc):
+                if stage_ms is not None and exc[0] is None:
+                    stage_ms[self.name] = stage_ms.get(self.name, 0.0) + LB.timer_stop(dev)
+                return False
+        with stage("canopy"):
+            check(L.lf_canopy_device(C.c_int(dev), C.byref(self.canopy)))                               # dyn.py:114
+            check(L.lf_scale_rows_device(C.c_int(dev), d["ESRef"].ptr, d["LAITerm"].ptr, d["ESMax"].ptr,
+                                         C.c_int64(3), C.c_int64(self.N)))                             # soilloop.py:638
+        with stage("soil_columns"):
+            check(L.lf_soil_columns_device(C.c_int(dev), C.byref(self.soil)))                           # dyn.py:123
         self.steps_done += 1
         self.pixel.TimeSinceStart = float(time_since_start if time_since_start else self.steps_done)
-        check(L.lf_pixel_aggregates_device(C.c_int(dev), C.byref(self.pixel)))                          # dyn.py:129-149
-        check(L.lf_surface_step(self.r_direct._h, self.r_other._h, self.r_forest._h, C.byref(self.surface)))  # :165
+        with stage("pixel_aggregates"):
+            check(L.lf_pixel_aggregates_device(C.c_int(dev), C.byref(self.pixel)))                      # dyn.py:129-149
+        with stage("overland"):
+            check(L.lf_surface_step(self.r_direct._h, self.r_other._h, self.r_forest._h, C.byref(self.surface)))  # :165
         # The channel wavefront reads nothing but its own vectors and the sideflow gathered below, and nothing of the NEXT
         # step's canopy / soil / aggregate / overland kernels reads a channel vector: it runs on the side stream, beside
         # them (a latency-bound chain of small launches beside bandwidth-bound streaming kernels).  Before the gather
         # overwrites the sideflow the main stream waits for the wavefront of the step before; downloads join by themselves.
         check(L.lf_side_stream_join(C.c_int(dev)))
-        if self.rmod is not None:       # lakes / reservoirs / inflow / transmission loss inside the wavefront
-            m = self.rmod
-            check(L.lf_gather_device(C.c_int(dev), C.c_int64(self.Nk), self._gidx.ptr, d["ToChanM3RunoffDt"].ptr,
-                                     m._st["dev"]["ToChanM3RunoffDt"].ptr))
-        else:
-            check(L.lf_gather_device(C.c_int(dev), C.c_int64(self.Nk), self._gidx.ptr, d["ToChanM3RunoffDt"].ptr,
-                                     d["SideflowChanM3"].ptr))
-        if self.overlap_channel:
+        with stage("sideflow_gather"):
+            if self.rmod is not None:       # lakes / reservoirs / inflow / transmission loss inside the wavefront
+                m = self.rmod
+                check(L.lf_gather_device(C.c_int(dev), C.c_int64(self.Nk), self._gidx.ptr, d["ToChanM3RunoffDt"].ptr,
+                                         m._st["dev"]["ToChanM3RunoffDt"].ptr))
+            else:
+                check(L.lf_gather_device(C.c_int(dev), C.c_int64(self.Nk), self._gidx.ptr, d["ToChanM3RunoffDt"].ptr,
+                                         d["SideflowChanM3"].ptr))
+        side = self.overlap_channel and stage_ms is None
+        if side:
             check(L.lf_side_stream_begin(C.c_int(dev)))
         try:
-            d["sumDisDay"].zero()                                                                       # dyn.py:177
-            if self.rmod is not None:
-                m = self.rmod
-                check(L.lf_routing_substeps_fused_structures(self.river._h, C.byref(m._args), C.byref(m._inloop),
-                                                             C.c_int(int(self.sc["NoRoutSteps"]))))      # dyn.py:179-180
-            else:
-                check(L.lf_routing_substeps_fused(self.river._h, C.byref(self.rout), C.c_int(int(self.sc["NoRoutSteps"])),
-                                                  C.c_int64(0)))                                        # dyn.py:179-180
+            with stage("channel_wavefront"):
+                d["sumDisDay"].zero()                                                                   # dyn.py:177
+                if self.rmod is not None:
+                    m = self.rmod
+                    check(L.lf_routing_substeps_fused_structures(self.river._h, C.byref(m._args), C.byref(m._inloop),
+                                                                 C.c_int(int(self.sc["NoRoutSteps"]))))  # dyn.py:179-180
+                else:
+                    check(L.lf_routing_substeps_fused(self.river._h, C.byref(self.rout), C.c_int(int(self.sc["NoRoutSteps"])),
+                                                      C.c_int64(0)))                                    # dyn.py:179-180
         finally:
-            if self.overlap_channel:
+            if side:
                 check(L.lf_side_stream_end(C.c_int(dev)))
+
+    def step_profile(self, forcing, time_since_start=None):
+        """step() with every stage timed on its own (synchronising; no overlap between the stages) -> {stage: ms}"""
+        L, dev = lib(), self.device
+        b = self.steps_done % 2
+        if self._prefetched[b] is not forcing:
+            self._upload(b, forcing)
+        self._prefetched[b] = None
+        check(L.lf_compute_acquire(C.c_int(dev), C.c_int(b)))
+        self._use_set(b)
+        ms = {}
+        try:
+            self._enqueue(time_since_start, ms)
+        finally:
+            check(L.lf_compute_release(C.c_int(dev), C.c_int(b)))
+        return ms
+
+    def stage_bytes(self):
+        """algorithmic HBM bytes of one model step, stage by stage: every vector a stage reads or writes counted once
+        (8 B per fp64, 1 B per flag; in/out vectors twice), the routers at 48 B per cell and call"""
+        N, Nk, n_sub = self.N, self.Nk, int(self.sc["NoRoutSteps"])
+        v8 = lambda names: 3 * 8 * len(names)
+        canopy = N * (2 * v8(SL._CANOPY_IO) + v8(SL._CANOPY_V_IN) + v8(SL._CANOPY_L_IN) + 8 * len(SL._CANOPY_N_IN) + 3 * 24)
+        soil = 3 * N * 504
+        io = set(PA._STATE)
+        pixel = N * (v8(PA._V_IN) + 24 + 8 * len(PA._N_IN) + 16 * len(io) + 8 * len([k for k in PA._OUT if k not in io]))
+        sio = set(SR._STATE)
+        overland = N * (v8(SR._V_IN) + 2 * 24 + 8 * len(SR._N_IN) + 16 * len(sio) + 8 * len([k for k in SR._OUT if k not in sio])
+                        + 3 * 48)
+        channel = Nk * n_sub * (96 if self.split else 48)
+        return dict(canopy=canopy, soil_columns=soil, pixel_aggregates=pixel, overland=overland,
+                    sideflow_gather=Nk * 20, channel_wavefront=channel)
 
     def download(self, name):
         a = self.d[name].download()
@@ -486,6 +550,11 @@ class HotPathDevice:
             a.free()
         for r in (self.r_other, self.r_forest, self.r_direct, self.river):
             r.close()
+        _lib_sync = lib().lf_device_synchronize
+        check(_lib_sync(C.c_int(self.device)))       # no upload may still be reading the page-locked buffers
+        for bufs in self.__dict__.pop("_pinned", []):
+            for b in bufs.values():
+                b.free()
 
 
 def inert_pixels(values, ldd_kinematic, land_mask, split, structures=None):

@@ -254,20 +254,26 @@ def interception_params(N, V=3, seed=21):
         LAI=lai, Rain=rain, TaInterceptionMax=rng.uniform(0.0, 3.0, (V, N)), drainageK=0.25)
 
 
-def hotpath_scenario(H, W, seed=101, channel_frac=0.3, nsteps=24, dt_sec=86400.0):
+def hotpath_scenario(H, W, seed=101, channel_frac=0.3, nsteps=24, dt_sec=86400.0, family="deep", block=None):
     """A complete synthetic input set for the device-resident hot path (lisflood_amd.hotpath.HotPathDevice) and
-    for the module classes: -> (values, scalars, land_mask, ldd_to_chan, ldd_kinematic).  All-land H x W `deep`
-    raster, `channel_frac` of the cells are channel pixels (so overland routing between cells is exercised)."""
+    for the module classes: -> (values, scalars, land_mask, ldd_to_chan, ldd_kinematic).  All-land H x W raster of the
+    LDD `family`, `channel_frac` of the cells are channel pixels (so overland routing between cells is exercised).
+    block: draw the per-pixel parameter and state fields for `block` pixels only and repeat them over the raster (the LDD,
+    the channel mask and everything derived from them are always drawn at full size) -- at 5000^2 the ~110 fields are 48 GB
+    and drawing them takes minutes; repeated fields stream through the kernels exactly like fresh ones."""
     from . import ldd as L
     rng = np.random.default_rng(seed)
-    N = H * W
+    N_full = H * W
     mask = np.ones((H, W), bool)
-    codes = make_ldd("deep", H, W, seed)[mask].astype(np.float64)
-    is_chan = rng.random(N) < channel_frac
-    ldd_to_chan = np.where(is_chan, 5.0, codes)
-    kin_codes, _ = L.lddmask(codes, mask, is_chan)
-    ldd_kin = np.zeros(N)
-    ldd_kin[is_chan] = kin_codes
+    codes = make_ldd(family, H, W, seed)[mask].astype(np.float64)
+    is_chan_full = rng.random(N_full) < channel_frac
+    ldd_to_chan = np.where(is_chan_full, 5.0, codes)
+    kin_codes, _ = L.lddmask(codes, mask, is_chan_full)
+    ldd_kin = np.zeros(N_full)
+    ldd_kin[is_chan_full] = kin_codes
+    del codes, kin_codes
+    N = N_full if not block or block >= N_full else int(block)      # the fields below are drawn for N pixels
+    is_chan = is_chan_full[:N]
     beta = 0.6
     dt_routing = dt_sec / nsteps
     v = {}
@@ -303,13 +309,20 @@ def hotpath_scenario(H, W, seed=101, channel_frac=0.3, nsteps=24, dt_sec=86400.0
     v["OFAlpha"] = ((nman / np.sqrt(grad)) ** beta) * ((pixel_length + 2 * 0.001 * 5.0) ** (2.0 / 3.0 * beta))
     for k in ("OFQDirect", "OFQOther", "OFQForest"):
         v[k] = rng.uniform(0, 0.3, N)
+    # ---- from here on at full size: the block's draws repeated over the raster, the channel mask the full-size one ----
+    reps = -(-N_full // N)
+    rep = (lambda a: a) if N == N_full else (lambda a: np.ascontiguousarray(np.tile(a, reps)[..., :N_full]))
+    for k in list(v):
+        v[k] = rep(v[k])
+    p = {k: (rep(a) if isinstance(a, np.ndarray) else a) for k, a in router_params(N, seed=seed + 3).items()}
+    u_alpha2 = rep(rng.uniform(1.2, 2.0, N))
+    Nb, is_chan, N = N, is_chan_full, N_full
     v["IsChannel"] = is_chan
-    p = router_params(N, seed=seed + 3)
     alpha = np.where(is_chan, p["alpha"], 1.0)
     length = p["dx"]
-    alpha2 = alpha * rng.uniform(1.2, 2.0, N)
+    alpha2 = alpha * u_alpha2
     q0 = np.where(is_chan, np.minimum(p["Q0"], 500.0), 0.0)
-    qlimit = 2.0 * q0 * rng.uniform(0.3, 1.2, N)
+    qlimit = 2.0 * q0 * rep(rng.uniform(0.3, 1.2, Nb))
     v.update(ChannelAlpha=alpha, InvChannelAlpha=1 / alpha, ChannelAlpha2=alpha2, InvChannelAlpha2=1 / alpha2,
              ChanLength=length, InvChanLength=1 / length, QLimit=qlimit, M3Limit=alpha * length * qlimit ** beta,
              Chan2M3Start=alpha2 * length * qlimit ** beta, Chan2QStart=0.1 * qlimit, PixelArea=np.full(N, pixel_area),

@@ -57,3 +57,43 @@ def test_committed_force_dist_line_is_one_json_line_with_both_partitions():
     assert d["model_step_24_substeps_split_row_blocks"]["finite"]
     assert d["catchment_partition"]["finite"]
     assert d["row_block_vs_catchment_partition_sumQ_rel_diff"] < 1e-12
+
+
+def test_committed_compact_line_round5():
+    """Since round 5 stdout carries a COMPACT line (the driver keeps only the tail of stdout, and the 8 KB line of round 4
+    lost its first legs there) and everything else goes to the sidecar bench_detail.json: the committed pair of the last
+    full run (profiles/r05_bench_line.json + profiles/r05_bench_detail.json)."""
+    text = open(os.path.join(ROOT, "profiles", "r05_bench_line.json")).read().strip().splitlines()
+    assert len(text) == 1 and len(text[0]) <= 4096
+    d = json.loads(text[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "legs", "detail"):
+        assert k in d, k
+    assert d["dtype"] == "f64" and d["vs_baseline"] is None and "workload" in d["config"]
+    assert abs(d["value"] - d["config"]["cells"] / d["ms_per_step"] / 1e3) < 1e-3 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-6
+    assert abs(r["achieved"] - r["alg_bytes_per_launch"] / (r["mean_launch_us"] * 1e-6) / 1e9) < 1e-3 * r["achieved"]
+    assert r["launches_per_step"] * r["mean_launch_us"] * 1e-3 <= d["ms_per_step"] * 1.02
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["one_core"] and c["all_cores_value"] and c["all_cores"] >= c["cores"]
+    legs = d["legs"]
+    for k in ("route_deep", "route_river", "soil_wet", "soil_single_substep", "model_step_deep_5000", "hot_path_deep_5000",
+              "hot_path_river_5000"):
+        assert k in legs and legs[k]["ms"] > 0, k
+    assert list(legs)[:2] == ["route_deep", "route_river"]                # the latency-bound legs first
+    assert legs["soil_wet"]["frac"] >= 0.31 and legs["soil_wet"]["traffic_ratio"] <= 1.5      # round-4 review, item 1
+    assert legs["soil_single_substep"]["frac"] >= 0.55
+    st = legs["hot_path_deep_5000"]["stages"]
+    assert set(st) >= {"canopy", "soil_columns", "pixel_aggregates", "overland", "channel_wavefront"}
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_detail.json")))
+    assert full["value"] == d["value"] and "other_workloads" in full and "sample" in full["cpu_baseline"]
+
+
+def test_committed_force_dist_line_round5_ran_on_the_real_rccl():
+    text = open(os.path.join(ROOT, "profiles", "r05_force_dist_1rank.json")).read().strip().splitlines()
+    assert len(text) == 1
+    d = json.loads(text[0])
+    assert d["rccl_library"].startswith("/opt/rocm") and d["finite"]
+    assert d["model_step_24_substeps_split_row_blocks"]["finite"] and d["catchment_partition"]["finite"]
+    assert d["row_block_vs_catchment_partition_sumQ_rel_diff"] < 1e-12
