@@ -250,3 +250,76 @@ def _host_memory_gb():
 def test_config4_workload_20000(amd, oracle, tmp_path):
     """configs[4] at the size BASELINE.json names, on one GPU (4e8 cells, ~26 GB of device vectors)"""
     run_config4(amd, oracle, 20000, tmp_path)
+
+
+def test_resident_hot_path_5000_whole_catchments_vs_oracle_chain(amd, oracle):
+    """The whole resident model step (canopy -> soil columns -> per-pixel aggregates -> three overland routers -> 24
+    split-routing channel sub-steps, HotPathDevice) at a BASELINE size: 5000^2 = 2.5e7 pixels, 7.5e7 soil columns, ~48 GB of
+    device vectors.  A few hundred WHOLE catchments of the combined overland + channel LDD (closed under `upstream` in
+    both graphs, so their cells depend on nothing outside) are run through the same chain assembled from the C oracle;
+    two model steps, every state vector within the parity tolerance on those cells, finite everywhere."""
+    import types
+    from lisflood_amd import synthetic as syn
+    from lisflood_amd.hotpath import HotPathDevice
+    from lisflood_amd.partition import catchment_roots_of_raster
+    H = W = 5000
+    N = H * W
+    values, sc, mask, ldd_to_chan, ldd_kin = syn.hotpath_scenario(H, W, block=1_000_000)
+    is_chan = np.asarray(values["IsChannel"], bool)
+    union = np.where(is_chan, ldd_kin, ldd_to_chan).astype(np.uint8).reshape(H, W)     # one downstream pixel per pixel
+    roots = catchment_roots_of_raster(union)
+    ids, sizes = np.unique(roots, return_counts=True)
+    rng = np.random.default_rng(8)
+    order = np.argsort(-sizes)
+    chosen, budget = list(ids[order[:20]]), 60_000 - int(sizes[order[:20]].sum())          # the 20 largest + random ones
+    for i in rng.permutation(ids.size):
+        if budget <= 0 or len(chosen) > 4000:
+            break
+        if sizes[i] <= budget and sizes[i] > 1:
+            chosen.append(ids[i]); budget -= int(sizes[i])
+    pix = np.nonzero(np.isin(roots, np.array(chosen)))[0]
+    del roots, union
+    r, c = pix // W, pix % W
+    sub_mask = np.zeros((r.max() + 1 - r.min(), c.max() + 1 - c.min()), bool)
+    sub_mask[r - r.min(), c - c.min()] = True
+    take = lambda a: (np.ascontiguousarray(a[..., pix], dtype=np.float64 if a.dtype.kind == "f" else a.dtype)
+                      if isinstance(a, np.ndarray) and a.shape[-1:] == (N,) else a)
+    v = types.SimpleNamespace(**{k: take(a) for k, a in values.items()})
+    for k, a in sc.items():
+        setattr(v, k, a)
+    v.InvBeta, v.InvPixelLength, v.InvDtSec = 1 / v.Beta, 1 / v.PixelLength, 1 / v.DtSec
+    v.InvDtRouting, v.InvNoRoutSteps, v.NoRoutSteps = 1 / v.DtRouting, 1 / v.NoRoutSteps, int(v.NoRoutSteps)
+    sub_l2c, sub_kin = np.ascontiguousarray(ldd_to_chan[pix]), np.ascontiguousarray(ldd_kin[pix])
+    hp = HotPathDevice(values, sc, mask, ldd_to_chan, ldd_kin, split=True)
+    del values
+    n = pix.size
+    idx = np.arange(3)
+    surf = oracle.SurfaceRouting(v, sub_l2c, sub_mask)
+    kw = oracle.kinematicWave(sub_kin, sub_mask, v.ChannelAlpha, v.Beta, v.ChanLength, v.DtRouting, alpha_floodplains=v.ChannelAlpha2)
+    sub = oracle.RoutingSubstep(kw, v)
+    keys = ("W1a", "W1b", "W2", "UZ", "Infiltration", "CumInterception", "LZ", "DirectRunoff", "OFQOther", "OFQDirect",
+            "ToChanM3RunoffDt", "ChanQKin", "Chan2QKin", "ChanM3Kin", "ChanQ", "sumDisDay")
+    for step in range(2):
+        f = syn.hotpath_forcing(N, step)
+        hp.step(f, time_since_start=step + 1)
+        for k, a in f.items():
+            setattr(v, k, np.ascontiguousarray(a[pix]))
+        oracle.canopy(v, idx)                                                      # Lisflood_dynamic.py:114
+        d = dict(vars(v))
+        d["ESMax"] = np.ascontiguousarray(v.ESRef * v.LAITerm)
+        d.update(index_landuse_all=idx, is_irrigated=np.array([False, False, True]), is_paddy_irrig=np.zeros(3, bool),
+                 paddy_inactive=np.zeros((1, n), bool))
+        oracle.soil_columns(d)                                                     # :123
+        v.TimeSinceStart = float(step + 1)
+        oracle.pixel_aggregates(v)                                                 # :129-149
+        surf.dynamic()                                                             # :165
+        v.sumDisDay = np.zeros(n)
+        for s in range(v.NoRoutSteps):                                             # :179-180
+            sub.dynamic(split=True, sideflow_m3=v.ToChanM3RunoffDt)
+    for k in keys:
+        got, want = hp.download(k), np.asarray(getattr(v, k))
+        assert np.isfinite(got).all(), k
+        np.testing.assert_allclose(got[..., pix], want, rtol=1e-8, atol=1e-9 * max(1.0, float(np.abs(want).max())),
+                                   err_msg="%s (%d catchments, %d pixels of %d^2)" % (k, len(chosen), n, H))
+    assert v.ChanQ.max() > 0 and is_chan[pix].sum() > 0.1 * n
+    hp.free()
