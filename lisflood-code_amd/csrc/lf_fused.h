@@ -16,6 +16,8 @@ struct fused_args {
     const double *__restrict__ a1, *__restrict__ a2, *__restrict__ dx;
     const long long *__restrict__ level_start;
     double *qr1, *qr2; // [2][N] router outputs by sub-step parity (main channel / floodplains)
+    // time-major form (k_fused_level_steps): [nsteps][N] router outputs of EVERY sub-step, read by the level below
+    double *hist1, *hist2;
     // slabs of router outputs kept for EVERY sub-step (row-block partition: what crosses a phase or a rank boundary, see
     // lf_dist.hip): the value of (slot, sub-step) sits at slot * root_ss + sub-step * root_st
     double *root1, *root2;
@@ -740,6 +742,171 @@ __device__ __forceinline__ void cone_compute(const fused_args &F, const cone_cel
         O.trav = vel * A.DtSec;
     }
 }
+
+// ---- time-major form: ALL sub-steps of one level in one launch, the state in registers ------------------------------
+// (level k, sub-step s) needs (level k - 1, sub-step s) and (level k, sub-step s - 1): the skewed wavefront above runs
+// the pairs with k + s = t together and so streams a cell's ~25 state vectors through HBM once per sub-step (~200 B,
+// 24 times per model step).  The other order of the same loop nest -- level after level, each level through all its
+// sub-steps -- keeps a cell's state in registers from its first sub-step to its last: the state is read once and written
+// once per MODEL step, and what crosses between levels is the router output of every sub-step (hist1 / hist2:
+// [nsteps][N], 16 B written and ~16 B read per cell and sub-step).  ~1 kB per cell and model step instead of ~4.8 kB --
+// and NL launches instead of NL + nsteps - 1 --, at the price of a dependent chain of nsteps solves per launch: the form
+// for graphs of FEW, WIDE levels (the channel network of the hot-path scenario: 27 levels of 280 000 cells; `shallow`
+// rasters), not for the deep ones, whose thousands of narrow levels are what the skew and the cones exist for.
+// Arithmetic of a (cell, sub-step) is fused_cell's, operation by operation: bit-identical results.
+// ALL35: beta == 3/5 for the fix-up round trips and for the router, known on the host -- both lines stage by stage in
+// straight code (cone_*_two), the general solve and OCML pow out of line
+#ifndef LF_TM_WAVES
+#define LF_TM_WAVES 4
+#endif
+#if LF_TM_WAVES > 0
+#define LF_TM_ATTR __attribute__((amdgpu_waves_per_eu(LF_TM_WAVES)))
+#else
+#define LF_TM_ATTR
+#endif
+template <bool SPLIT, bool ALL35>
+__global__ void __launch_bounds__(kBlock) LF_TM_ATTR k_fused_level_steps(fused_args F, int k)
+{
+    const lf_substep_args &A = F.S;
+    const long long first = F.level_start[k];
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= F.level_start[k + 1] - first) return;
+    const long long p = first + i, n = F.n;
+    const int nsteps = F.nsteps;
+    const int u0 = F.ups_ptr[p], u1 = F.ups_ptr[p + 1], kmax = F.kmax;
+    const bool b35 = A.Beta == 0.6, s35 = F.solve35 != 0;
+    const unsigned int dflags = derived_flags(F);
+    const bool rc = (dflags & 1u) != 0u;
+    const double len = A.ChanLength[p];
+    const double dxp = (dflags & 2u) ? len : (F.dx ? F.dx[p] : F.dx_scalar);
+    const double inv_len = rc ? 1.0 / len : A.InvChanLength[p];
+    const bool is_chan = A.IsChannelKinematic[p] != 0;
+    const bool cut = F.linked && F.linked[p];
+    const double alpha1 = A.ChannelAlpha[p];
+    const double inv_alpha1 = rc ? 1.0 / alpha1 : A.InvChannelAlpha[p], ap1 = rc ? alpha1 * dxp / F.dt : F.a1[p];
+    double qold = A.ChanQKin[p], sum = A.sumDisDay[p];
+    double m3 = 0, m3_2 = 0, start = 0, m3limit = 0, q2start = 0, ap2 = 0, q2old = 0, alpha2 = 0, inv_alpha2 = 0, qlimit = 0;
+    if (SPLIT) {
+        m3 = A.ChanM3Kin[p];
+        m3_2 = A.Chan2M3Kin[p];
+        start = A.Chan2M3Start[p];
+        m3limit = A.M3Limit[p];
+        q2start = A.Chan2QStart[p];
+        q2old = A.Chan2QKin[p];
+        alpha2 = A.ChannelAlpha2[p];
+        ap2 = rc ? alpha2 * dxp / F.dt : F.a2[p];
+        inv_alpha2 = rc ? 1.0 / alpha2 : A.InvChannelAlpha2[p];
+        qlimit = A.QLimit[p];
+    }
+    const double pix_area = A.PixelArea[p];
+    int s0 = 0;
+    if (F.inert && F.inert[p]) { // see k_inert_flags: a sub-step leaves such a cell as it is while its state is all +0.0,
+                                 // so only the last one (which also writes the velocities) is run, as fused_cell does
+        bool zero = plus_zero(qold) && plus_zero(A.ChanM3Kin[p]) && plus_zero(A.ChanQ[p]);
+        if (SPLIT && zero)
+            zero = plus_zero(q2old) && plus_zero(m3_2) && plus_zero(A.CrossSection2Area[p]) && plus_zero(A.Sideflow1Chan[p]);
+        if (zero) s0 = nsteps - 1;
+    }
+    double v = 0, q = 0, chanq = 0, s1 = 0, v2 = 0, q2 = 0;
+    double side_m3 = A.SideflowChanM3[(long long)s0 * F.side_stride + p];
+    for (int s = s0; s < nsteps; ++s) {
+        const double ups1 = upstream_sum8(F.hist1 + (long long)s * n, u0, u1, kmax);
+        const double ups2 = SPLIT ? upstream_sum8(F.hist2 + (long long)s * n, u0, u1, kmax) : 0.0;
+        if (F.side_stride != 0 && s > s0) side_m3 = A.SideflowChanM3[(long long)s * F.side_stride + p];
+        // ---- sideflow (routing.py:512, 524 / 549-567) ----
+        const double side = is_chan ? side_m3 * inv_len * A.InvDtRouting : 0.0;
+        double s2 = 0.0;
+        s1 = side;
+        if (!SPLIT) {
+            if (isnan(side)) s1 = 0.0;
+        } else {
+            const double tot = m3 + m3_2;
+            const double ratio = (tot > 0) ? m3 / tot : 0.0;
+            s1 = ((tot - start) > m3limit) ? ratio * side : side;
+            if (fabs(side) < 1e-7) s1 = side;
+            s2 = (side - s1) + q2start * inv_len;
+        }
+        // ---- main channel: router call + fix-up (routing.py:526-532 / 573-578); floodplains (routing.py:583-603) ----
+        double qr, q2r = 0;
+        if constexpr (ALL35) {
+            double pw1, pw2, pr1, pr2;
+            cone_pow_3_5_two<SPLIT>(qold, q2old, pw1, pw2);
+            const double c = ups1 + (ap1 * pw1 + s1 * dxp);
+            const double c2 = SPLIT ? ups2 + (ap2 * pw2 + s2 * dxp) : 0.0;
+            cone_solve_two<SPLIT>(c, ap1, c2, ap2, F, qr, q2r);
+            cone_pow_3_5_two<SPLIT>(qr, q2r, pr1, pr2);
+            v = len * alpha1 * pr1;
+            if (v < 0.0) v = 0.0;
+            const double x = v * inv_len * inv_alpha1;
+            double x2 = 0.0;
+            if (SPLIT) {
+                v2 = len * alpha2 * pr2;
+                if ((v2 - start) < 0.0) v2 = start;
+                x2 = v2 * inv_len * inv_alpha2;
+            }
+            cone_pow_5_3_two<SPLIT>(x, x2, q, q2);
+            chanq = q;
+            if (SPLIT) {
+                chanq = q + q2 - qlimit;
+                if (chanq < 0.0) chanq = 0.0;
+            }
+        } else {
+            const double cst = ap1 * (s35 ? lf_pow_3_5(qold) : pow(qold, F.beta)) + s1 * dxp;
+            const double c = ups1 + cst;
+            qr = solve_any(c, ap1, s35, F);
+            v = len * alpha1 * (b35 ? lf_pow_3_5(qr) : pow(qr, A.Beta));
+            if (v < 0.0) v = 0.0;
+            const double x = v * inv_len * inv_alpha1;
+            q = b35 ? lf_pow_5_3(x) : pow(x, A.InvBeta);
+            chanq = q;
+            if (SPLIT) {
+                const double cst2 = ap2 * (s35 ? lf_pow_3_5(q2old) : pow(q2old, F.beta)) + s2 * dxp;
+                const double c2 = ups2 + cst2;
+                q2r = solve_any(c2, ap2, s35, F);
+                v2 = len * alpha2 * (b35 ? lf_pow_3_5(q2r) : pow(q2r, A.Beta));
+                if ((v2 - start) < 0.0) v2 = start;
+                const double x2 = v2 * inv_len * inv_alpha2;
+                q2 = b35 ? lf_pow_5_3(x2) : pow(x2, A.InvBeta);
+                chanq = q + q2 - qlimit;
+                if (chanq < 0.0) chanq = 0.0;
+            }
+        }
+        F.hist1[(long long)s * n + p] = cut ? 0.0 : qr;
+        if (SPLIT) F.hist2[(long long)s * n + p] = cut ? 0.0 : q2r;
+        // the state of the next sub-step
+        m3 = v;
+        qold = q;
+        sum = sum + chanq;
+        if (SPLIT) {
+            m3_2 = v2;
+            q2old = q2;
+        }
+    }
+    // ---- what the sub-step-by-sub-step sequence leaves behind ----
+    A.ChanM3Kin[p] = v;
+    A.ChanQKin[p] = q;
+    A.ChanQ[p] = chanq;
+    A.sumDisDay[p] = sum;
+    if (SPLIT) {
+        A.Sideflow1Chan[p] = s1;
+        A.Chan2M3Kin[p] = v2;
+        A.CrossSection2Area[p] = (v2 - start) * inv_len;
+        A.Chan2QKin[p] = q2;
+    }
+    { // routing.py:693-703
+        double area = v * inv_len;
+        if (area < 0.01) area = 0.01;
+        const double v1 = q / area, vv2 = 0.36 * pow(q, 0.24);
+        double vel = (vv2 < v1) ? vv2 : v1;
+        if (isnan(vv2)) vel = vv2;
+        double sinu = sqrt(pix_area) * inv_len;
+        if (sinu > 1) sinu = 1;
+        vel *= sinu;
+        A.FlowVelocity[p] = vel;
+        A.TravelDistance[p] = vel * A.DtSec;
+    }
+}
+
 
 // the state a level leaves behind (cells without a result -- beyond the cone, skipped -- store nothing)
 template <bool SPLIT, bool STRUCT>

@@ -205,6 +205,8 @@ struct lf_router {
 
     lf_dbuf<long long> level_start;
     lf_dbuf<double> a1, a2, dx, constant, qord, io_q, io_lat, tmp_ord, fused_qr1, fused_qr2;
+    lf_dbuf<double> fused_hist1, fused_hist2; // [nsteps][N] router outputs of every sub-step (k_fused_level_steps)
+    int64_t fused_hist_steps = 0;
     lf_dbuf<unsigned long long> counter;
     lf_dbuf<uint8_t> linked; // zero-length structure links (lf_graph_create_ex); null without them
     lf_dbuf<int> level_nlinked; // ... and how many of them are parked at the end of every level (k_fused_cones_split)
@@ -1330,6 +1332,7 @@ int fused_impl(lf_router *r, const lf_substep_args *a, int nsteps, int64_t sidef
     F.level_start = r->level_start.p;
     F.qr1 = r->fused_qr1.p;
     F.qr2 = r->fused_qr2.p;
+    F.hist1 = F.hist2 = nullptr;
     F.root1 = F.root2 = nullptr;
     F.nroots = 0;
     F.root_ss = 1;
@@ -1445,6 +1448,57 @@ int fused_impl(lf_router *r, const lf_substep_args *a, int nsteps, int64_t sidef
                                F.dx, r->dx_scalar, r->dt, r->derived_ok.p);
             F.recompute = r->derived_ok.p;
             ++launches;
+        }
+    }
+    // ---- few, wide levels: level after level, every level through all its sub-steps (k_fused_level_steps) ----------------
+    // LF_FUSED_TIME_MAJOR=0 / 1: never / whenever it applies (A/B switch); LF_FUSED_TIME_MAJOR_LEVELS: the level count up to
+    // which it is the default -- each launch carries a dependent chain of nsteps solves (~10 us), so NL launches of that
+    // kind must stay small beside what the saved traffic (~3.8 kB per cell and model step) is worth
+    {
+        static const int tm_levels = [] {
+            const char *e = std::getenv("LF_FUSED_TIME_MAJOR_LEVELS");
+            return e ? std::atoi(e) : 192;
+        }();
+        const char *e = std::getenv("LF_FUSED_TIME_MAJOR");
+        const bool applies = !in && !F.linked && nsteps > 1;
+        const bool want = e ? e[0] != '0' : (NL <= tm_levels && n >= 20000 * (int64_t)NL);
+        if (applies && want) {
+            if (r->fused_hist_steps < nsteps) {
+                r->fused_hist1.release();
+                r->fused_hist2.release();
+                r->fused_hist_steps = 0;
+            }
+            bool ok = true;
+            if (!r->fused_hist1.p) ok = r->fused_hist1.alloc((size_t)nsteps * n) == LF_OK;
+            if (ok && a->split && !r->fused_hist2.p) ok = r->fused_hist2.alloc((size_t)nsteps * n) == LF_OK;
+            if (ok) {
+                r->fused_hist_steps = nsteps;
+                F.hist1 = r->fused_hist1.p;
+                F.hist2 = r->fused_hist2.p;
+                for (int k = 0; k < NL; ++k) {
+                    const int64_t w = r->h_level_start[k + 1] - r->h_level_start[k];
+                    if (w <= 0) continue;
+                    const bool all35 = r->fused && a->Beta == 0.6;
+                    if (a->split && all35)
+                        hipLaunchKernelGGL((k_fused_level_steps<true, true>), dim3(blocks_for(w)), dim3(kBlock), 0, s, F, k);
+                    else if (a->split)
+                        hipLaunchKernelGGL((k_fused_level_steps<true, false>), dim3(blocks_for(w)), dim3(kBlock), 0, s, F, k);
+                    else if (all35)
+                        hipLaunchKernelGGL((k_fused_level_steps<false, true>), dim3(blocks_for(w)), dim3(kBlock), 0, s, F, k);
+                    else
+                        hipLaunchKernelGGL((k_fused_level_steps<false, false>), dim3(blocks_for(w)), dim3(kBlock), 0, s, F, k);
+                    ++launches;
+                }
+                LF_HIP(hipGetLastError());
+                r->last_stats[0] = launches;
+                r->last_stats[1] = launches;
+                r->last_stats[2] = 0;
+                r->last_stats[3] = r->NL;
+                return LF_OK;
+            }
+            (void)hipGetLastError(); // no room for the history: the skewed wavefront below
+            r->fused_hist1.release();
+            r->fused_hist2.release();
         }
     }
     if (r->fb_lmax > 1 && nsteps <= kMaxPackedSteps) { // several levels per launch (k_fused_cones)
