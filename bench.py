@@ -560,20 +560,20 @@ def hotpath_bench(size=2000, steps=6, family="deep", block=1_000_000):
     hp = HotPathDevice(values, sc, mask, ldd_to_chan, ldd_kin, split=True)
     del values
     forc = []
-    for s in range(2):      # page-locked forcing buffers, filled in place (what a netCDF reader would do)
-        f = hp.pinned_forcing()
+    for s in range(2):      # page-locked forcing buffers, filled in place in the engine's own pixel order (what a netCDF
+        f = hp.pinned_forcing()     # reader does when it compresses the raster with the composed index)
         for k, a in syn.hotpath_forcing(N, s).items():
-            f[k][:] = a
+            f[k][:] = a if hp.pixel_of_position is None else a[hp.pixel_of_position]
         forc.append(f)
     log("[bench] hot-path scenario %s %dx%d: fields %.1f s, device set-up %.1f s" % (family, H, W, t_scen, time.time() - t - t_scen))
     for w in range(3):
-        hp.step(forc[w % 2], w + 1)
+        hp.step(forc[w % 2], w + 1, ordered=True)
         _lib.synchronize()
     t0 = time.perf_counter()
-    hp.prefetch(forc[0])
+    hp.prefetch(forc[0], ordered=True)
     for s in range(steps):
-        hp.step(forc[s % 2], s + 4)
-        hp.prefetch(forc[(s + 1) % 2])          # next step's forcing goes up while this step's kernels run
+        hp.step(forc[s % 2], s + 4, ordered=True)
+        hp.prefetch(forc[(s + 1) % 2], ordered=True)          # next step's forcing goes up while this step's kernels run
     _lib.synchronize()
     ms = (time.perf_counter() - t0) * 1e3 / steps
     q = hp.chan_q_avg()
@@ -585,19 +585,19 @@ def hotpath_bench(size=2000, steps=6, family="deep", block=1_000_000):
                       "canopy / soil / overland kernels; parameter fields drawn for %d pixels and repeated" % (H, W, family, min(block, N)))
     # A/B: everything on one stream (rounds 1-3)
     hp.overlap_channel = False
-    hp.step(forc[0], steps + 4)
+    hp.step(forc[0], steps + 4, ordered=True)
     _lib.synchronize()
     t0 = time.perf_counter()
     for s in range(steps):
-        hp.step(forc[s % 2], steps + 5 + s)
-        hp.prefetch(forc[(s + 1) % 2])
+        hp.step(forc[s % 2], steps + 5 + s, ordered=True)
+        hp.prefetch(forc[(s + 1) % 2], ordered=True)
     _lib.synchronize()
     out["one_stream_ms_per_model_step"] = round((time.perf_counter() - t0) * 1e3 / steps, 3)
     # stage by stage (two profiled steps, the mean)
     acc = {}
     nprof = 2
     for s in range(nprof):
-        for k, x in hp.step_profile(forc[s % 2], 2 * steps + 6 + s).items():
+        for k, x in hp.step_profile(forc[s % 2], 2 * steps + 6 + s, ordered=True).items():
             acc[k] = acc.get(k, 0.0) + x / nprof
     nbytes = hp.stage_bytes()
     out["stages"] = {k: dict(ms=round(x, 3), alg_GB=round(nbytes[k] / 1e9, 3),

@@ -1,0 +1,6 @@
+cd $GRAFT_REPO_ROOT
+python -m pytest tests -m gpu -x -q -k "hot_path or resident or chain or soil or warm or state_maps" 2>&1 | tail -3
+python bench.py --only hotpath --size 5000 --family deep 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('hotpath 5000:', d['ms_per_model_step'], d['one_stream_ms_per_model_step'], d['stages_sum_ms'], {k:(v['ms'],v['frac_hbm']) for k,v in d['stages'].items()})"
+python bench.py --only soil 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print({k: (v['ms_per_step'], v['frac_hbm']) for k, v in d.items() if isinstance(v, dict) and 'ms_per_step' in v})"

@@ -389,6 +389,12 @@ typedef struct lf_surface_args {
 } lf_surface_args;
 int lf_surface_step(lf_router *direct_router, lf_router *other_router, lf_router *forest_router,
                     const lf_surface_args *a);
+/* The same with EVERY vector of `a` in the sweep (engine) order of the three routers' shared graph instead of pixel order:
+ * the element-wise parts do not care, and the routers then stream their vectors (lf_router_route_ordered: ~54 B per cell
+ * instead of ~135 through the position -> pixel table).  A caller that keeps a whole model step resident permutes its
+ * per-pixel fields once (lf_graph_layout gives the table) -- lisflood_amd.hotpath.HotPathDevice does. */
+int lf_surface_step_ordered(lf_router *direct_router, lf_router *other_router, lf_router *forest_router,
+                            const lf_surface_args *a);
 
 /* In-loop structures of routing.dynamic (routing.py:441-478): lakes (lakes.py:199-297, Modified Puls), reservoirs
  * (reservoir.py:173-322), inflow hydrographs (inflow.py:129-147), transmission loss (transmission.py:67-89) and

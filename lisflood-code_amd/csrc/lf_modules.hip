@@ -385,7 +385,22 @@ int lf_scale_rows_device(int device, const double *row_dev, const double *m_dev,
     return LF_OK;
 }
 
+static int surface_step(lf_router *direct_router, lf_router *other_router, lf_router *forest_router, const lf_surface_args *a,
+                        int engine_order);
+
 int lf_surface_step(lf_router *direct_router, lf_router *other_router, lf_router *forest_router, const lf_surface_args *a)
+{
+    return surface_step(direct_router, other_router, forest_router, a, 0);
+}
+
+int lf_surface_step_ordered(lf_router *direct_router, lf_router *other_router, lf_router *forest_router,
+                            const lf_surface_args *a)
+{
+    return surface_step(direct_router, other_router, forest_router, a, 1);
+}
+
+static int surface_step(lf_router *direct_router, lf_router *other_router, lf_router *forest_router, const lf_surface_args *a,
+                        int engine_order)
 {
     if (!direct_router || !other_router || !forest_router || !a) return lf_set_error(LF_E_INVALID, "null argument");
     const int device = lf_router_device(direct_router);
@@ -402,7 +417,7 @@ int lf_surface_step(lf_router *direct_router, lf_router *other_router, lf_router
         lf_router *rs[3] = {direct_router, other_router, forest_router};
         double *q[3] = {a->OFQDirect, a->OFQOther, a->OFQForest};
         const double *lat[3] = {a->scratch, a->scratch + N, a->scratch + 2 * N};
-        LF_TRY(lf_router_route_device_multi(3, rs, q, lat, LF_SECTION_MAIN, 0));
+        LF_TRY(lf_router_route_device_multi(3, rs, q, lat, LF_SECTION_MAIN, engine_order));
     }
     hipLaunchKernelGGL(k_surface_post, grid, block, 0, c->stream, *a);
     LF_HIP(hipGetLastError());

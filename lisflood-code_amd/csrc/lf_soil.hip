@@ -380,6 +380,9 @@ k_soil_fused(lf_soil_args A, veg_plan P, unsigned short *__restrict__ all_list, 
 #ifdef LF_SOIL_DEBUG_MAXTRIPS /* timing experiments only (tools/build_variant.sh): WRONG results */
         nsub_f = dmin(nsub_f, (double)LF_SOIL_DEBUG_MAXTRIPS);
 #endif
+        // a frozen column's three seepage sums are set to zero behind the loop (:313-316) and nothing else of the loop is
+        // kept: its sub-steps are not run at all (the reference runs them and throws the result away)
+        if (frozen) nsub_f = 1.;
         if (nsub_f > 1.) {
             long long c = (long long)nsub_f;
             c = c < kClasses - 1 ? c : kClasses - 1;

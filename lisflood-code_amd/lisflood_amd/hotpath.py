@@ -29,7 +29,7 @@ _CHANNEL_NAMES = set(RT._STATIC + RT._STATE + RT._OUT)
 
 class HotPathDevice:
     def __init__(self, values, scalars, land_mask, ldd_to_chan, ldd_kinematic, split=True, device=0, structures=None,
-                 compact=True, overlap_channel=True):
+                 compact=True, overlap_channel=True, surface_order=True):
         """values: name -> host array in pixel order ([N], [3,N]) for every vector of the stages (reference
         attribute names); scalars: Beta, DtSec, DtRouting, NoRoutSteps, DtDay, PixelLength, MMtoM3, M3toMM,
         LeafDrainageK, AvWaterThreshold, CourantCrit, DrainedFraction, InvDtDay.  ldd_to_chan / ldd_kinematic:
@@ -40,6 +40,11 @@ class HotPathDevice:
         compact: leave inert pixels out of the channel router's domain (see inert_pixels): on real domains most land
         pixels are not channel pixels, and the channel wavefront then touches only the ones that are."""
         self.device, self.split = device, bool(split)
+        # surface_order: every per-pixel vector that is not a channel vector lives in the sweep order of the OVERLAND
+        # routers' graph (the canopy / soil / aggregate kernels are element-wise and do not care; the three overland routers
+        # then stream their vectors instead of going through the position -> pixel table: lf_surface_step_ordered).
+        # Vectors come in and go out in pixel order all the same (constructor, step(), download(), state files); a caller
+        # whose forcing is already in that order (`pixel_of_position`) says step(..., ordered=True) and saves the gather.
         # overlap_channel: the channel wavefront of a step on a second HIP stream, beside the canopy / soil / overland kernels
         # of the step after it (same kernels, same results; False: one stream, as rounds 1-3)
         self.overlap_channel = bool(overlap_channel)
@@ -100,7 +105,15 @@ class HotPathDevice:
                 self.d[k] = m._dev[k]
         self.perm = self.river.graph.layout()[0].astype(np.int64)        # engine position -> channel-domain pixel
         self.gpix = self.ids[self.perm]                                   # engine position -> land pixel
-        self._gidx = DeviceArray.from_host(self.gpix.astype(np.int32), device)
+        # position -> pixel of the overland graph's sweep order (None: the non-channel vectors stay in pixel order)
+        self.pixel_of_position = g_surf.layout()[0].astype(np.int64) if surface_order else None
+        if self.pixel_of_position is not None:
+            inv = np.empty(N, np.int64)
+            inv[self.pixel_of_position] = np.arange(N)
+            src = inv[self.gpix]                                          # where a channel cell's land pixel sits in those vectors
+        else:
+            src = self.gpix
+        self._gidx = DeviceArray.from_host(src.astype(np.int32), device)
         # ---- device vectors ------------------------------------------------------------------------
         bool_names = SL._BOOL | {"IsChannel", "IsChannelKinematic"}
         for k, a in values.items():
@@ -109,6 +122,8 @@ class HotPathDevice:
                 if self.rmod is not None:
                     continue
                 a = np.broadcast_to(a, (Nk,))[self.perm]
+            else:
+                a = self._ordered(a)
             self.d[k] = DeviceArray.from_host(u8(a) if k in bool_names else f64(a), device)
 
         def zeros(name, shape):
@@ -161,9 +176,24 @@ class HotPathDevice:
         r.split, r.engine_order = (1 if self.split else 0), 1
         self.steps_done = 0
 
-    def _upload(self, b, forcing):
+    def _ordered(self, a):
+        """a per-pixel array ([N] or [..., N], pixel order) in the order the non-channel device vectors are kept in"""
+        a = np.asarray(a)
+        if self.pixel_of_position is None or a.ndim == 0 or a.shape[-1] != self.N:
+            return a
+        return np.ascontiguousarray(a[..., self.pixel_of_position])
+
+    def _pixel_order(self, a):
+        """inverse of _ordered"""
+        if self.pixel_of_position is None or a.ndim == 0 or a.shape[-1] != self.N:
+            return a
+        out = np.empty_like(a)
+        out[..., self.pixel_of_position] = a
+        return out
+
+    def _upload(self, b, forcing, ordered=False):
         L, dev = lib(), self.device
-        host = [f64(forcing[k]) for k in FORCING]
+        host = [f64(forcing[k]) if ordered else f64(self._ordered(forcing[k])) for k in FORCING]
         check(L.lf_upload_begin(C.c_int(dev), C.c_int(b)))
         for k, a in zip(FORCING, host):
             if a.size != self.N:
@@ -181,11 +211,13 @@ class HotPathDevice:
         self.__dict__.setdefault("_pinned", []).append(bufs)
         return {k: b.a for k, b in bufs.items()}
 
-    def prefetch(self, forcing):
+    def prefetch(self, forcing, ordered=False):
         """Start uploading the forcing of the NEXT step() call now: the copies run on a second stream while the kernels
-        of the step just enqueued are still executing.  Pass the same dict object to the next step()."""
+        of the step just enqueued are still executing.  Pass the same dict object to the next step().
+        ordered: the vectors are already in the order of `pixel_of_position` (e.g. compressed from the netCDF raster
+        with the composed index) -- otherwise they are in pixel order and are permuted on the host first."""
         b = self.steps_done % 2
-        self._upload(b, forcing)
+        self._upload(b, forcing, ordered)
         self._prefetched[b] = forcing
 
     def _use_set(self, b):
@@ -214,14 +246,14 @@ class HotPathDevice:
         dev["QDelta"].upload(f64(m._up(delta)))
         self._qin_old = q
 
-    def step(self, forcing, time_since_start=None, QInM3=None):
+    def step(self, forcing, time_since_start=None, QInM3=None, ordered=False):
         d, dev = self.d, self.device
         L = lib()
         if QInM3 is not None:
             self.set_inflow(QInM3)
         b = self.steps_done % 2
         if self._prefetched[b] is not forcing:
-            self._upload(b, forcing)
+            self._upload(b, forcing, ordered)
         self._prefetched[b] = None
         check(L.lf_compute_acquire(C.c_int(dev), C.c_int(b)))
         self._use_set(b)
@@ -260,7 +292,8 @@ class HotPathDevice:
         with stage("pixel_aggregates"):
             check(L.lf_pixel_aggregates_device(C.c_int(dev), C.byref(self.pixel)))                      # dyn.py:129-149
         with stage("overland"):
-            check(L.lf_surface_step(self.r_direct._h, self.r_other._h, self.r_forest._h, C.byref(self.surface)))  # :165
+            step_fn = L.lf_surface_step_ordered if self.pixel_of_position is not None else L.lf_surface_step
+            check(step_fn(self.r_direct._h, self.r_other._h, self.r_forest._h, C.byref(self.surface)))   # dyn.py:165
         # The channel wavefront reads nothing but its own vectors and the sideflow gathered below, and nothing of the NEXT
         # step's canopy / soil / aggregate / overland kernels reads a channel vector: it runs on the side stream, beside
         # them (a latency-bound chain of small launches beside bandwidth-bound streaming kernels).  Before the gather
@@ -291,12 +324,12 @@ class HotPathDevice:
             if side:
                 check(L.lf_side_stream_end(C.c_int(dev)))
 
-    def step_profile(self, forcing, time_since_start=None):
+    def step_profile(self, forcing, time_since_start=None, ordered=False):
         """step() with every stage timed on its own (synchronising; no overlap between the stages) -> {stage: ms}"""
         L, dev = lib(), self.device
         b = self.steps_done % 2
         if self._prefetched[b] is not forcing:
-            self._upload(b, forcing)
+            self._upload(b, forcing, ordered)
         self._prefetched[b] = None
         check(L.lf_compute_acquire(C.c_int(dev), C.c_int(b)))
         self._use_set(b)
@@ -329,7 +362,7 @@ class HotPathDevice:
             out = np.zeros(self.N, a.dtype)          # pixels outside the channel domain: their state is identically 0
             out[self.gpix] = a[:self.Nk]
             return out
-        return a
+        return self._pixel_order(a)
 
     def download_site(self, name):
         """lake / reservoir site vectors (LakeStorageM3CC, ReservoirStorageM3CC, ...) and the dense in-loop outputs"""
@@ -371,6 +404,8 @@ class HotPathDevice:
                         raise ValueError("state file holds water in %s on pixels this object left out of the channel "
                                          "domain; build it with compact=False" % k)
                 a = a[self.gpix]
+            else:
+                a = self._ordered(a)
             self.d[k].upload(f64(a))
         if self.rmod is not None:
             for k in RT._LAKE_STATE + RT._RES_STATE + ["TransCum"]:
@@ -438,7 +473,7 @@ class HotPathDevice:
         routing.initial + initialSecond do (routing.py:203-218, 391-397); like the reference's, such a warm start
         continues to rounding, not to the bit (use save_state / load_state for that)."""
         g = lambda name: (None if name not in maps else np.asarray(maps[name], np.float64))
-        up = lambda attr, a: self.d[attr].upload(f64(a[self.gpix] if attr in _CHANNEL_NAMES else a))
+        up = lambda attr, a: self.d[attr].upload(f64(a[self.gpix] if attr in _CHANNEL_NAMES else self._ordered(a)))
         cur = lambda attr: self.download(attr)
         beta = self.sc["Beta"]
         # channel (routing.py:203-218, 243-248, 391-397)
@@ -468,7 +503,7 @@ class HotPathDevice:
         if side is not None and self.split:
             up("Sideflow1Chan", np.where(side == -9999, 0.0, side))
         # overland flow (surface_routing.py:49-63, 93-95)
-        ofa = self.d["OFAlpha"].download()
+        ofa = self.download("OFAlpha")
         for name, row in (("Other", 0), ("Forest", 1), ("Direct", 2)):
             m3 = g("OF%sState" % name)
             if m3 is None:

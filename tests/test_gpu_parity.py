@@ -911,6 +911,33 @@ def test_resident_hot_path_vs_oracle_chain(amd, oracle):
     hp.free()
 
 
+def test_hot_path_in_surface_order_equals_pixel_order(amd):
+    """HotPathDevice(surface_order=True) keeps the non-channel vectors in the sweep order of the overland routers' graph (the
+    routers then stream them); every downloaded vector and the state file equal the pixel-order object's bit for bit, with
+    forcing passed in pixel order and, already permuted, with ordered=True."""
+    from lisflood_amd import synthetic as syn
+    from lisflood_amd.hotpath import HotPathDevice
+    H, W = 44, 52
+    N = H * W
+    values, sc, mask, ldd_to_chan, ldd_kin = syn.hotpath_scenario(H, W)
+    cp = lambda d: {k: (np.array(a, copy=True) if isinstance(a, np.ndarray) else a) for k, a in d.items()}
+    a = HotPathDevice(cp(values), sc, mask, ldd_to_chan, ldd_kin, split=True, surface_order=False)
+    b = HotPathDevice(cp(values), sc, mask, ldd_to_chan, ldd_kin, split=True, surface_order=True)
+    c = HotPathDevice(cp(values), sc, mask, ldd_to_chan, ldd_kin, split=True, surface_order=True)
+    assert a.pixel_of_position is None and sorted(b.pixel_of_position.tolist()) == list(range(N))
+    for s in range(3):
+        f = syn.hotpath_forcing(N, s)
+        a.step(f, s + 1)
+        b.step(f, s + 1)
+        c.step({k: np.ascontiguousarray(x[c.pixel_of_position]) for k, x in f.items()}, s + 1, ordered=True)
+    for k in a.state_names() + ["sumDisDay", "Infiltration", "ToChanM3RunoffDt", "Theta1a", "OFM3Other", "TotalRunoff"]:
+        want = a.download(k)
+        assert np.array_equal(want, b.download(k), equal_nan=True), k
+        assert np.array_equal(want, c.download(k), equal_nan=True), k
+    assert np.abs(a.download("OFQOther")).max() > 0
+    a.free(); b.free(); c.free()
+
+
 def test_hot_path_forcing_from_page_locked_buffers(amd):
     """HotPathDevice.pinned_forcing(): forcing vectors filled in place in page-locked host memory and prefetched (an
     asynchronous DMA) give the bits of the same vectors passed as ordinary arrays."""
