@@ -401,6 +401,27 @@ def model_step_bench(size=5000, nsteps=24, family="deep"):
                          launches_per_model_step=(kw1 if mode == "fused_level_by_level" else kw).last_launches()["launches"] *
                          {"fused": 1, "fused_level_by_level": 1, "sequential": 2 * nsteps, "sequential_single_sweep": nsteps}[mode])
         st.free()
+    # several model steps in flight: the skew runs on across the model-step boundaries (lf_routing_model_steps_fused), so
+    # the pipeline fill of NB launches is paid once per call instead of once per model step
+    try:
+        M = 5
+        st = RoutingStepDevice(kw, vals, True, beta, 1.0 / dt, dt * nsteps)
+        sums = _lib.DeviceArray((M, N)).zero()
+        st.run_model_steps_resident(nsteps, M, sums)
+        _lib.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            st.run_model_steps_resident(nsteps, M, sums)
+        _lib.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3 / 2 / M
+        out["fused_5_model_steps_in_flight"] = dict(ms_per_model_step=round(ms, 3), value=round(2 * nsteps * N / ms / 1e3, 2),
+                                                    unit="Mcell-steps/s", model_steps_per_call=M,
+                                                    launches_per_model_step=round(kw.last_launches()["launches"] / M, 1),
+                                                    frac_hbm=round(2 * B_ALG * N * nsteps / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+        sums.free()
+        st.free()
+    except Exception as e:
+        out["fused_5_model_steps_in_flight"] = {"error": repr(e)}
     out["config"] = "%dx%d %s LDD (NL=%d), NoRoutSteps=%d, split routing: %d cell-steps per cell per model step" % (
         H, W, family, g.num_levels, nsteps, 2 * nsteps)
     t3, s3, counters = pmc_traffic_r03("fused_%s_%d" % (family, size), "k_fused_cones")
@@ -804,6 +825,10 @@ def compact_line(out, detail):
             rf = f.get("roofline") or {}
             per = rf.get("hbm_bytes_per_cell_substep")
             cells = {"model_step_deep_5000": 25e6, "model_step_structures_3000": 9e6}[short]
+            if short == "model_step_deep_5000" and "ms_per_model_step" in (e.get("fused_5_model_steps_in_flight") or {}):
+                x = e["fused_5_model_steps_in_flight"]
+                legs["model_step_deep_5000_5_in_flight"] = dict(ms=x["ms_per_model_step"], value=x["value"], frac=x["frac_hbm"],
+                                                                launches=x["launches_per_model_step"])
             legs[short] = dict(ms=f.get("ms_per_model_step"), value=f.get("value"),
                                frac=rf.get("frac", round(48 * B_ALG * cells / (f["ms_per_model_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)),
                                traffic_ratio=round(per / (2 * B_ALG), 3) if per else None, launches=f.get("launches_per_model_step"))

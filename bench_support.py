@@ -55,6 +55,35 @@ class RoutingStepDevice:
     def run_fused(self, nsteps):
         check(lib().lf_routing_substeps_fused(self.router._h, C.byref(self.args), C.c_int(nsteps), C.c_int64(0)))
 
+    def run_model_steps_resident(self, nsteps, nmodel, sums):
+        """timing form of run_model_steps: the resident sideflow vector for every model step, the sums into the
+        caller's [nmodel, N] device array (not zeroed, not downloaded)"""
+        a = _SubstepArgs.from_buffer_copy(self.args)
+        a.sumDisDay = sums.ptr.value
+        check(lib().lf_routing_model_steps_fused(self.router._h, C.byref(a), C.c_int(nsteps), C.c_int(nmodel), C.c_int64(0)))
+
+    def run_model_steps(self, nsteps, sideflows=None, nmodel=None):
+        """`nmodel` model steps of nsteps sub-steps as ONE wavefront (lf_routing_model_steps_fused).  sideflows: list of
+        pixel-order sideflow vectors, one per model step (None: the resident vector for `nmodel` steps).  Returns the
+        [nmodel, N] discharge sums (pixel order); the state vectors hold what the last model step leaves."""
+        M = len(sideflows) if sideflows is not None else int(nmodel)
+        N = self.N
+        sums = DeviceArray((M, N), np.float64, self.device).zero()
+        a = _SubstepArgs.from_buffer_copy(self.args)
+        a.sumDisDay = sums.ptr.value
+        side, stride = None, 0
+        if sideflows is not None:
+            side = DeviceArray.from_host(f64(np.stack([np.broadcast_to(x, (N,))[self.perm] for x in sideflows])), self.device)
+            a.SideflowChanM3 = side.ptr.value
+            stride = N
+        check(lib().lf_routing_model_steps_fused(self.router._h, C.byref(a), C.c_int(nsteps), C.c_int(M), C.c_int64(stride)))
+        out = np.empty((M, N))
+        out[:, self.perm] = sums.download()
+        sums.free()
+        if side is not None:
+            side.free()
+        return out
+
     def download(self, name):
         out = np.empty(self.N)
         out[self.perm] = self.dev[name].download()

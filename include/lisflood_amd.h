@@ -234,6 +234,15 @@ int lf_substep_stage(int device, int stage, int64_t n, const lf_substep_args *a)
  * sub-step: sideflow_stride = 0 (one vector used by all sub-steps) or N (nsteps vectors back to back).
  * Bit-identical to nsteps calls of lf_routing_substep. */
 int lf_routing_substeps_fused(lf_router *r, const lf_substep_args *a, int nsteps, int64_t sideflow_stride);
+/* n_model_steps MODEL steps of steps_per_model_step sub-steps each (the loop of Lisflood_dynamic.py:179-180, model step
+ * after model step) as ONE wavefront: a->SideflowChanM3 holds one sideflow vector per model step, sideflow_model_stride
+ * elements apart (0: the same vector for all), a->sumDisDay is [n_model_steps][N] and zeroed by the caller (the reference
+ * zeroes it at the start of every model step, Lisflood_dynamic.py:177); every other vector of `a` is the state after the
+ * last model step, exactly as after n_model_steps calls of lf_routing_substeps_fused.  For callers whose channel routing
+ * does not feed back into the sideflow of later steps (no structures in the loop): the land-surface part of several steps
+ * first, then their channel routing in one call.  Bit-identical to the step-by-step calls. */
+int lf_routing_model_steps_fused(lf_router *r, const lf_substep_args *a, int steps_per_model_step, int n_model_steps,
+                                 int64_t sideflow_model_stride);
 
 /* ---------------------------------------------------------------------------------------------
  * LDD one-hop upstream reduction == np.bincount(downstruct, weights)[:N] (routing.py:159-164,

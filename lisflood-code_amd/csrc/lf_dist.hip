@@ -1499,6 +1499,8 @@ int dist_fused_phase(lf_dist_router *r, const lf_substep_args *a, int nsteps, in
     F.root_st = 1;
     F.n = r->N;
     F.side_stride = sideflow_stride;
+    F.msteps = nsteps;
+    F.side_mstride = 0;
     F.dx_scalar = r->dx_scalar;
     F.beta = r->beta;
     F.inv_beta = r->inv_beta;

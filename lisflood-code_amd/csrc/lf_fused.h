@@ -24,6 +24,12 @@ struct fused_args {
     long long nroots;
     long long root_ss, root_st; // slab index of (slot, sub-step) = slot * root_ss + sub-step * root_st
     long long n, side_stride;
+    // several MODEL steps in one wavefront (lf_routing_model_steps_fused): sub-step s belongs to model step s / msteps; it
+    // reads the sideflow at SideflowChanM3 + s * side_stride + (s / msteps) * side_mstride and adds to the discharge sum at
+    // sumDisDay + (s / msteps) * n; the last sub-step of EVERY model step leaves what fused_cell's `last` leaves.  One model
+    // step: msteps = nsteps, side_mstride = 0.
+    int msteps;
+    long long side_mstride;
     double dx_scalar, beta, inv_beta, b_minus_1;
     int kmax, nlevels, nsteps, t;
     int solve35; // router runs the beta = 3/5 quintic solve (false: general path, e.g. LF_GENERAL_POW=1)
@@ -57,6 +63,14 @@ struct fused_args {
     int use_lvl;
     int lvl[kMaxPackedSteps];
 };
+
+// sub-step s inside its model step (fused_args::msteps); s is uniform, so these are scalar operations
+__device__ __forceinline__ bool fused_last(const fused_args &F, int s) { return (s + 1) % F.msteps == 0; }
+__device__ __forceinline__ const double *fused_side(const fused_args &F, int s)
+{
+    return F.S.SideflowChanM3 + (long long)s * F.side_stride + (long long)(s / F.msteps) * F.side_mstride;
+}
+__device__ __forceinline__ double *fused_sum(const fused_args &F, int s) { return F.S.sumDisDay + (long long)(s / F.msteps) * F.n; }
 
 __device__ __forceinline__ bool plus_zero(double x) { return __double_as_longlong(x) == 0; }
 __device__ __forceinline__ bool same_bits(double a, double b) { return __double_as_longlong(a) == __double_as_longlong(b); }
@@ -156,7 +170,7 @@ __device__ __forceinline__ void fused_cell(const fused_args &F, long long p, int
                                            long long root_slot = -1)
 {
     const lf_substep_args &A = F.S;
-    if (!STRUCT && F.inert && F.inert[p] && s != F.nsteps - 1) { // see k_inert_flags; the last sub-step also writes
+    if (!STRUCT && F.inert && F.inert[p] && !fused_last(F, s)) { // see k_inert_flags; the last sub-step also writes
         bool zero = plus_zero(A.ChanQKin[p]) && plus_zero(A.ChanM3Kin[p]) && plus_zero(A.ChanQ[p]); // velocities
         if (SPLIT && zero)
             zero = plus_zero(A.Chan2QKin[p]) && plus_zero(A.Chan2M3Kin[p]) && plus_zero(A.CrossSection2Area[p]) &&
@@ -177,7 +191,7 @@ __device__ __forceinline__ void fused_cell(const fused_args &F, long long p, int
     const bool cut = F.linked && F.linked[p];
     double side_m3, qin = 0, qin_added = 0, loss = 0, trans_cum = 0;
     if (!STRUCT)
-        side_m3 = A.SideflowChanM3[(long long)s * F.side_stride + p];
+        side_m3 = fused_side(F, s)[p];
     else { // inflow.py:142-144, transmission.py:76-87, sideflow assembly routing.py:462-478 -- as k_inloop_dense
         const lf_inloop_args &I = F.I;
         side_m3 = I.ToChanM3RunoffDt[p];
@@ -201,7 +215,8 @@ __device__ __forceinline__ void fused_cell(const fused_args &F, long long p, int
     }
     const double qold = A.ChanQKin[p], alpha1 = A.ChannelAlpha[p];
     const double inv_alpha1 = rc ? 1.0 / alpha1 : A.InvChannelAlpha[p], ap1 = rc ? alpha1 * dxp / F.dt : F.a1[p];
-    const double sum_old = A.sumDisDay[p];
+    double *const sum_dst = fused_sum(F, s);
+    const double sum_old = sum_dst[p];
     const double ups1 = ups_of(F.qr1 + par, 0);
     double m3 = 0, m3_2 = 0, start = 0, m3limit = 0, q2start = 0, ap2 = 0, q2old = 0, alpha2 = 0, inv_alpha2 = 0, qlimit = 0,
            ups2 = 0;
@@ -218,7 +233,7 @@ __device__ __forceinline__ void fused_cell(const fused_args &F, long long p, int
         qlimit = A.QLimit[p];
         ups2 = ups_of(F.qr2 + par, 1);
     }
-    const bool last = s == F.nsteps - 1;
+    const bool last = fused_last(F, s);
     double pix_area = 0;
     if (last) pix_area = A.PixelArea[p];
     // ---- sideflow (routing.py:512, 524 / 549-567) ----
@@ -275,7 +290,7 @@ __device__ __forceinline__ void fused_cell(const fused_args &F, long long p, int
     A.ChanM3Kin[p] = v;
     A.ChanQKin[p] = q;
     if (keep) A.ChanQ[p] = chanq;
-    A.sumDisDay[p] = sum_old + chanq;
+    sum_dst[p] = sum_old + chanq;
     if (SPLIT) {
         if (keep) A.Sideflow1Chan[p] = s1;
         F.qr2[par + p] = cut ? 0.0 : q2r;
@@ -426,9 +441,9 @@ __device__ __forceinline__ void cone_load(const fused_args &F, const cone_range 
             R.inv_alpha2 = cone_ld(A.InvChannelAlpha2, P);
         }
     }
-    const bool test_inert = !STRUCT && F.inert && s != F.nsteps - 1; // see k_inert_flags / fused_cell (uniform)
+    const bool test_inert = !STRUCT && F.inert && !fused_last(F, s); // see k_inert_flags / fused_cell (uniform)
     if (!STRUCT)
-        R.side_m3 = cone_ld(A.SideflowChanM3 + (long long)s * F.side_stride, P);
+        R.side_m3 = cone_ld(fused_side(F, s), P);
     else { // (absent vectors: a stand-in's value, which cone_compute does not look at -- it tests the same pointers)
         const lf_inloop_args &I = F.I;
         R.side_m3 = cone_ld(I.ToChanM3RunoffDt, P);
@@ -447,7 +462,7 @@ __device__ __forceinline__ void cone_load(const fused_args &F, const cone_range 
     if (F.linked) R.cut_raw = cone_ld(F.linked, P); // (also without STRUCT: a sub-step at a time on a graph with structure links)
     R.qold = cone_ld(A.ChanQKin, P);
     R.alpha1 = cone_ld(A.ChannelAlpha, P);
-    R.sum_old = cone_ld(A.sumDisDay, P);
+    R.sum_old = cone_ld(fused_sum(F, s), P);
     if (SPLIT) {
         R.m3 = cone_ld(A.ChanM3Kin, P);
         R.m3_2 = cone_ld(A.Chan2M3Kin, P);
@@ -467,7 +482,7 @@ __device__ __forceinline__ void cone_load(const fused_args &F, const cone_range 
             R.sf1_old = cone_ld(A.Sideflow1Chan, P);
         }
     }
-    if (s == F.nsteps - 1) R.pix_area = cone_ld(A.PixelArea, P);
+    if (fused_last(F, s)) R.pix_area = cone_ld(A.PixelArea, P);
 }
 
 // behind the wait for a level's loads: what depends on uniform conditions AND on loaded values
@@ -610,7 +625,7 @@ __device__ __forceinline__ void cone_compute(const fused_args &F, const cone_cel
     const lf_substep_args &A = F.S;
     const bool b35 = A.Beta == 0.6;
     const bool s35 = F.solve35 != 0;
-    const bool last = s == F.nsteps - 1;
+    const bool last = fused_last(F, s);
     double side_m3 = R.side_m3;
     O.qin = O.qin_added = O.loss = O.trans_cum = 0.0;
     if (STRUCT) { // inflow.py:142-144, transmission.py:76-87, sideflow assembly routing.py:462-478 -- as fused_cell
@@ -784,7 +799,7 @@ __global__ void __launch_bounds__(kBlock) LF_TM_ATTR k_fused_level_steps(fused_a
     const bool cut = F.linked && F.linked[p];
     const double alpha1 = A.ChannelAlpha[p];
     const double inv_alpha1 = rc ? 1.0 / alpha1 : A.InvChannelAlpha[p], ap1 = rc ? alpha1 * dxp / F.dt : F.a1[p];
-    double qold = A.ChanQKin[p], sum = A.sumDisDay[p];
+    double qold = A.ChanQKin[p], sum = 0.0;
     double m3 = 0, m3_2 = 0, start = 0, m3limit = 0, q2start = 0, ap2 = 0, q2old = 0, alpha2 = 0, inv_alpha2 = 0, qlimit = 0;
     if (SPLIT) {
         m3 = A.ChanM3Kin[p];
@@ -805,14 +820,17 @@ __global__ void __launch_bounds__(kBlock) LF_TM_ATTR k_fused_level_steps(fused_a
         bool zero = plus_zero(qold) && plus_zero(A.ChanM3Kin[p]) && plus_zero(A.ChanQ[p]);
         if (SPLIT && zero)
             zero = plus_zero(q2old) && plus_zero(m3_2) && plus_zero(A.CrossSection2Area[p]) && plus_zero(A.Sideflow1Chan[p]);
-        if (zero) s0 = nsteps - 1;
+        if (zero) s0 = nsteps - 1; // (several model steps: the last sub-step of the last one -- the sums of the others stay 0)
     }
     double v = 0, q = 0, chanq = 0, s1 = 0, v2 = 0, q2 = 0;
-    double side_m3 = A.SideflowChanM3[(long long)s0 * F.side_stride + p];
+    double side_m3 = fused_side(F, s0)[p];
+    sum = fused_sum(F, s0)[p];
     for (int s = s0; s < nsteps; ++s) {
         const double ups1 = upstream_sum8(F.hist1 + (long long)s * n, u0, u1, kmax);
         const double ups2 = SPLIT ? upstream_sum8(F.hist2 + (long long)s * n, u0, u1, kmax) : 0.0;
-        if (F.side_stride != 0 && s > s0) side_m3 = A.SideflowChanM3[(long long)s * F.side_stride + p];
+        const bool first_of_step = s % F.msteps == 0;
+        if ((F.side_stride != 0 || first_of_step) && s > s0) side_m3 = fused_side(F, s)[p];
+        if (first_of_step && s > s0) sum = fused_sum(F, s)[p]; // the next model step's sum (zeroed by the caller)
         // ---- sideflow (routing.py:512, 524 / 549-567) ----
         const double side = is_chan ? side_m3 * inv_len * A.InvDtRouting : 0.0;
         double s2 = 0.0;
@@ -877,6 +895,7 @@ __global__ void __launch_bounds__(kBlock) LF_TM_ATTR k_fused_level_steps(fused_a
         m3 = v;
         qold = q;
         sum = sum + chanq;
+        if (fused_last(F, s) && s != nsteps - 1) fused_sum(F, s)[p] = sum; // a model step inside the call is complete
         if (SPLIT) {
             m3_2 = v2;
             q2old = q2;
@@ -886,7 +905,7 @@ __global__ void __launch_bounds__(kBlock) LF_TM_ATTR k_fused_level_steps(fused_a
     A.ChanM3Kin[p] = v;
     A.ChanQKin[p] = q;
     A.ChanQ[p] = chanq;
-    A.sumDisDay[p] = sum;
+    fused_sum(F, nsteps - 1)[p] = sum;
     if (SPLIT) {
         A.Sideflow1Chan[p] = s1;
         A.Chan2M3Kin[p] = v2;
@@ -927,10 +946,10 @@ __device__ __forceinline__ void cone_store(const fused_args &F, const cone_out &
         }
         cone_st(I.SideflowChanM3, o8, O.side_m3);
     }
-    const bool last = s == F.nsteps - 1;
+    const bool last = fused_last(F, s);
     cone_st(A.ChanM3Kin, o8, O.v);
     cone_st(A.ChanQKin, o8, O.q);
-    cone_st(A.sumDisDay, o8, O.sum);
+    cone_st(fused_sum(F, s), o8, O.sum);
     if (SPLIT) {
         cone_st(A.Chan2M3Kin, o8, O.v2);
         cone_st(A.Chan2QKin, o8, O.q2);
@@ -1215,7 +1234,7 @@ __global__ void __launch_bounds__(64 * (1 + KC)) k_fused_cones_split(fused_args 
     const int sw = wave - 1;
     const unsigned int dflags = derived_flags(F);
     const bool dx_is_len = (dflags & 2u) != 0u;
-    const bool last = s == F.nsteps - 1;
+    const bool last = fused_last(F, s);
     const long long par = (long long)(s & 1) * F.n;
     const unsigned nbytes = (unsigned)F.n * 8u;
     typedef int v2i __attribute__((ext_vector_type(2)));
@@ -1261,7 +1280,7 @@ __global__ void __launch_bounds__(64 * (1 + KC)) k_fused_cones_split(fused_args 
             P.eva = P.wuse = P.qin_old = P.qdelta = P.qin_added_old = P.chanq_old = P.transcum = P.lakeout = P.resout = P.polder = 0.0;
             P.uptrans = 0;
             if (!STRUCT)
-                P.side_m3 = split_ld(A.SideflowChanM3 + (long long)s * G.side_stride, o8);
+                P.side_m3 = split_ld(fused_side(G, s), o8);
             else { // (an option that is off: any valid stream instead of a branch around the load; its value is not used)
                 const lf_inloop_args &I = G.I;
                 const double *any = I.ToChanM3RunoffDt;
@@ -1424,7 +1443,7 @@ __global__ void __launch_bounds__(64 * (1 + KC)) k_fused_cones_split(fused_args 
             const unsigned o8 = (unsigned)pc * 8u, o1 = (unsigned)pc;
             R.len = split_ld(A.ChanLength, o8);
             R.alpha1 = split_ld(A.ChannelAlpha, o8);
-            R.sum_old = split_ld(A.sumDisDay, o8);
+            R.sum_old = split_ld(fused_sum(G, s), o8);
             R.inv_len = RC ? 0.0 : split_ld(A.InvChanLength, o8);
             R.inv_alpha1 = RC ? 0.0 : split_ld(A.InvChannelAlpha, o8);
             R.pix_area = split_ld(A.PixelArea, last ? o8 : 0u); // (read by the last sub-step only: one line on the others)
@@ -1485,7 +1504,7 @@ __global__ void __launch_bounds__(64 * (1 + KC)) k_fused_cones_split(fused_args 
             put(A.ChanM3Kin, off, v);
             put(A.ChanQKin, off, q);
             put(A.ChanQ, off_keep, chanq);
-            put(A.sumDisDay, off, R.sum_old + chanq);
+            put(fused_sum(G, s), off, R.sum_old + chanq);
             if (SPLIT) {
                 put(G.qr2 + par, off_out, R.cut ? 0.0 : q2r);
                 put(A.Sideflow1Chan, off_keep, s1);

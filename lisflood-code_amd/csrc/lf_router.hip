@@ -1311,13 +1311,19 @@ extern "C" int lf_routing_substep(lf_router *r, const lf_substep_args *a)
 
 namespace {
 
-int fused_impl(lf_router *r, const lf_substep_args *a, int nsteps, int64_t sideflow_stride, const lf_inloop_args *in)
+int fused_impl(lf_router *r, const lf_substep_args *a, int nsteps, int64_t sideflow_stride, const lf_inloop_args *in,
+               int msteps = 0, int64_t side_mstride = 0)
 {
     if (!r || !a || nsteps < 1) return lf_set_error(LF_E_INVALID, "bad argument");
     if (!a->engine_order) return lf_set_error(LF_E_INVALID, "the fused sub-step wavefront needs engine-order vectors");
     if (a->split && !r->has_floodplains)
         return lf_set_error(LF_E_SECTION, "split routing requested but the router has no floodplain alpha");
     if (sideflow_stride != 0 && sideflow_stride != r->N) return lf_set_error(LF_E_INVALID, "sideflow_stride must be 0 or N");
+    if (msteps <= 0) msteps = nsteps; // one model step
+    if (nsteps % msteps != 0) return lf_set_error(LF_E_INVALID, "the sub-step count must be a multiple of the sub-steps per model step");
+    if (msteps != nsteps && (in || sideflow_stride != 0 || (side_mstride != 0 && side_mstride < r->N)))
+        return lf_set_error(LF_E_INVALID, "several model steps per call: no structures, one sideflow vector per model step "
+                                          "(stride 0 or >= N)");
     LF_HIP(hipSetDevice(r->device));
     const int64_t n = r->N;
     if (n == 0) return LF_OK;
@@ -1339,6 +1345,8 @@ int fused_impl(lf_router *r, const lf_substep_args *a, int nsteps, int64_t sidef
     F.root_st = 0;
     F.n = n;
     F.side_stride = sideflow_stride;
+    F.msteps = msteps;
+    F.side_mstride = side_mstride;
     F.dx_scalar = r->dx_scalar;
     F.beta = r->beta;
     F.inv_beta = r->inv_beta;
@@ -1687,6 +1695,16 @@ int fused_impl(lf_router *r, const lf_substep_args *a, int nsteps, int64_t sidef
 extern "C" int lf_routing_substeps_fused(lf_router *r, const lf_substep_args *a, int nsteps, int64_t sideflow_stride)
 {
     return fused_impl(r, a, nsteps, sideflow_stride, nullptr);
+}
+
+// Several MODEL steps as one wavefront: the skew runs on across the model-step boundary, so the pipeline fill (one launch per
+// level block) is paid once per call instead of once per model step -- what a deep network needs (deep 5000^2: 313 blocks +
+// 23 launches per model step on its own, 24 per model step in steady state).
+extern "C" int lf_routing_model_steps_fused(lf_router *r, const lf_substep_args *a, int steps_per_model_step, int n_model_steps,
+                                            int64_t sideflow_model_stride)
+{
+    if (steps_per_model_step < 1 || n_model_steps < 1) return lf_set_error(LF_E_INVALID, "bad argument");
+    return fused_impl(r, a, steps_per_model_step * n_model_steps, 0, nullptr, steps_per_model_step, sideflow_model_stride);
 }
 
 extern "C" int lf_routing_substeps_fused_structures(lf_router *r, const lf_substep_args *a, const lf_inloop_args *in,

@@ -563,6 +563,44 @@ def test_structures_inside_the_fused_wavefront(amd, solver):
         mb.river_router.kinematicWaveRouting(np.zeros(mb.river_router.num_pixels), np.zeros(mb.river_router.num_pixels))
 
 
+@pytest.mark.parametrize("family,time_major", [("deep", "0"), ("shallow", "0"), ("shallow", "1")])
+def test_several_model_steps_in_one_wavefront(amd, monkeypatch, family, time_major):
+    """lf_routing_model_steps_fused: four model steps of 24 split-routing sub-steps, each with its own sideflow vector, as
+    ONE wavefront (the skew runs on across the model-step boundaries) against four calls of the one-model-step wavefront
+    with the discharge sum zeroed in between -- every state vector and every model step's sum bit for bit; on the cones
+    (deep), the level kernel (shallow) and the time-major form."""
+    from lisflood_amd import synthetic as syn
+    from lisflood_amd.kinematic_wave_parallel import kinematicWave
+    from lisflood_amd.routing import _STATE, _OUT
+    from bench_support import RoutingStepDevice
+    monkeypatch.setenv("LF_FUSED_TIME_MAJOR", time_major)
+    H, W = (260, 300) if family == "deep" else (600, 700)
+    N = H * W
+    nsteps, M = 24, 4
+    codes = syn.make_ldd(family, H, W, 3)
+    mask = np.ones((H, W), bool)
+    p = syn.router_params(N, seed=21)
+    vals, dt = syn.model_step_values(N, p)
+    kw = kinematicWave(codes[mask].astype(np.float64), mask, p["alpha"], p["beta"], p["dx"], dt,
+                       alpha_floodplains=vals["ChannelAlpha2"])
+    sides = [syn.lateral_inflow(N, 40 + m) * p["dx"] * dt for m in range(M)]
+    a = RoutingStepDevice(kw, dict(vals, SideflowChanM3=sides[0]), True, p["beta"], 1.0 / dt, dt * nsteps)
+    b = RoutingStepDevice(kw, dict(vals, SideflowChanM3=sides[0]), True, p["beta"], 1.0 / dt, dt * nsteps)
+    want = []
+    for m in range(M):                                        # model step by model step
+        a.dev["SideflowChanM3"].upload(np.ascontiguousarray(sides[m][a.perm]))
+        a.dev["sumDisDay"].zero()
+        a.run_fused(nsteps)
+        want.append(a.download("sumDisDay"))
+    got = b.run_model_steps(nsteps, sides)                    # the four of them in one wavefront
+    for m in range(M):
+        assert np.array_equal(got[m], want[m]), (family, m)
+    for k in [x for x in _STATE + _OUT if x != "sumDisDay"]:
+        assert np.array_equal(a.download(k), b.download(k), equal_nan=True), (family, k)
+    assert np.isfinite(got).all() and got.max() > 0
+    a.free(); b.free(); kw.close()
+
+
 @pytest.mark.parametrize("family", ["deep", "shallow"])
 def test_structures_wavefront_mid_size_synthetic(amd, family):
     """2e5 cells, 16 lakes + 48 reservoirs + 32 inflow points + transmission loss, 24 split-routing sub-steps, two model
