@@ -1079,6 +1079,29 @@ def test_soil_columns_device_resident_vs_oracle(amd, oracle, solver):
     assert (d2["Theta1a"][1] == 0).all()
 
 
+@pytest.mark.parametrize("trip_cap", ["0", "3", "16", "200"])
+def test_soil_columns_same_bits_whatever_the_trip_cap(amd, monkeypatch, trip_cap):
+    """Which columns leave their tile for k_soil_stragglers (LF_SOIL_TRIP_CAP: none, nearly all multi-sub-step ones --
+    more than a tile's 24 record slots hold, so the rest stay in the tile --, the default, hardly any) must not change a
+    single bit of any output: in-lane, in-tile and straggler columns run the same arithmetic."""
+    from lisflood_amd import synthetic as syn
+    N = 30011
+    d = syn.soil_params(N, seed=21)
+    d["is_irrigated"] = np.array([False, True, True])
+    outs = {}
+    for cap in ("16", trip_cap):
+        monkeypatch.setenv("LF_SOIL_TRIP_CAP", cap)
+        dev = amd.soil.SoilColumnsDevice({k: (v.copy() if hasattr(v, "copy") else v) for k, v in d.items()})
+        for s in range(3):
+            dev.set("Rain", np.random.default_rng(50 + s).uniform(0, 30, N))
+            dev.step()
+        outs[cap] = {k: dev.get(k) for k in syn.SOIL_WRITTEN}
+        for a in dev.dev.values():
+            a.free()
+    for k in syn.SOIL_WRITTEN:
+        assert np.array_equal(outs["16"][k], outs[trip_cap][k], equal_nan=True), k
+
+
 def test_soil_columns_more_multi_substep_columns_than_a_round_holds(amd, oracle, solver):
     """Nearly saturated soil: most columns of every 256-column tile need several Courant sub-steps, more than the 128 the
     sub-step phase of k_soil_fused takes per round, so the later rounds (records rebuilt from the lanes' registers) run;
