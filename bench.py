@@ -332,7 +332,7 @@ def soil_bench(N=4_000_000, steps=10):
         _lib.check(_lib.lib().lf_soil_last_deferred(C.c_int(0), C.byref(nd)))
         out[regime] = dict(value=round(cols / ms / 1e3, 2), unit="Mcolumn-steps/s", ms_per_step=round(ms, 4),
                            achieved_GBs=round(gbs, 1), frac_hbm=round(gbs / HBM_PEAK_GBS, 4),
-                           multi_substep_columns_frac=round(nd.value / cols, 4))
+                           multi_substep_columns_frac=round(nd.value / cols, 4), derived_parameters_recomputed=bool(dev.derived))
         # committed counter passes of this very command (tools/pmc_soil_r05.sh): HBM bytes per call of the regime's kernels
         tr = {}
         for key, sub in (("columns", "k_soil_fused"), ("stragglers", "k_soil_stragglers")):

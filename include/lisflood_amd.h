@@ -487,6 +487,10 @@ int lf_soil_columns_host(int device, const lf_soil_args *a);
 /* device-resident forms: every array pointer is device memory (except the small per-vegetation ones) */
 int lf_interception_device(int device, const lf_interception_args *a);
 int lf_soil_columns_device(int device, const lf_soil_args *a);
+/* The same for a caller that vouches for the relations soil.py:180-228 establishes between its parameter arrays (GenuInvM =
+ * 1 / GenuM; WS1 = WS1a + WS1b, and so WRes1, WFC1, WWP1; PoreSpaceNotZero = SoilDepth != 0 and WS != 0): those ten arrays
+ * are recomputed (one IEEE operation each: the same bits) instead of read and may be NULL -- 59 bytes less per column. */
+int lf_soil_columns_device_derived(int device, const lf_soil_args *a);
 /* instrumentation: columns of the last lf_soil_columns_device call that needed > 1 Courant sub-step */
 int lf_soil_last_deferred(int device, int64_t *count);
 /* ... and their histogram by trip count (hist[k] = columns with k sub-steps, last bin = nbins-1 or more; the engine

@@ -254,8 +254,12 @@ struct soil_strag {
 
 // all_list / all_count: every multi-sub-step column of the tile (lane | class << 8), for lf_soil_last_deferred and
 // lf_soil_substep_histogram (2 bytes per such column)
-template <bool FASTPOW, int WAVES>
-__global__ void __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(WAVES)))
+// DERIVED: ten of the parameter streams are not read but recomputed from the ones they were made of (soil.py:180-228:
+// GenuInvM = 1 / GenuM, WS1 = WS1a + WS1b and the same for WRes1 / WFC1 / WWP1, PoreSpaceNotZero = depth != 0 and WS != 0;
+// one IEEE operation each, so the same bits) -- 59 of the 526 bytes a column reads and writes.  The caller vouches for the
+// relations (lf_soil_columns_device_derived); the ten pointers are not touched.
+template <bool FASTPOW, bool DERIVED>
+__global__ void __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(3)))
 k_soil_fused(lf_soil_args A, veg_plan P, unsigned short *__restrict__ all_list, unsigned int *__restrict__ all_count,
              soil_strag G, unsigned int tile0, unsigned int tiles_per_veg)
 {
@@ -298,21 +302,34 @@ k_soil_fused(lf_soil_args A, veg_plan P, unsigned short *__restrict__ all_list, 
         const double in_rain = A.Rain[pix], in_snow = A.SnowMelt[pix], in_leaf = A.LeafDrainage[i], in_int = A.Interception[i];
         const double in_dslr = A.DSLR[i], in_w1a = A.W1a[i], in_w1b = A.W1b[i], in_w1 = A.W1[i], in_w2 = A.W2[i];
         const double in_uz = A.UZ[i];
-        const double in_esmax = A.ESMax[i], in_wres1 = A.WRes1[j], in_ws1 = A.WS1[j], in_store = A.StoreMaxPervious[j];
+        const double in_esmax = A.ESMax[i], in_store = A.StoreMaxPervious[j];
         const double in_bx = A.b_Xinanjiang[pix], in_pinf = A.PowerInfPot[pix], in_ppref = A.PowerPrefFlow[pix];
         const double in_uzk = A.UpperZoneK[pix];
         T.gwp = A.GwPercStep[pix];
         T.sd1a = A.SoilDepth1a[j]; T.sd1b = A.SoilDepth1b[j]; T.sd2 = A.SoilDepth2[j];
-        T.wwp1a = A.WWP1a[j]; T.wwp1b = A.WWP1b[j]; T.wwp1 = A.WWP1[j]; T.wwp2 = A.WWP2[j];
-        T.wfc1a = A.WFC1a[j]; T.wfc1b = A.WFC1b[j]; T.wfc1 = A.WFC1[j]; T.wfc2 = A.WFC2[j];
+        T.wwp1a = A.WWP1a[j]; T.wwp1b = A.WWP1b[j]; T.wwp2 = A.WWP2[j];
+        T.wfc1a = A.WFC1a[j]; T.wfc1b = A.WFC1b[j]; T.wfc2 = A.WFC2[j];
         const double ks1a = A.KSat1a[j], ks1b = A.KSat1b[j], ks2 = A.KSat2[j];
-        const double im1a = A.GenuInvM1a[j], im1b = A.GenuInvM1b[j], im2 = A.GenuInvM2[j];
         const double m1a = A.GenuM1a[j], m1b = A.GenuM1b[j], m2 = A.GenuM2[j];
         const double wres1a = A.WRes1a[j], wres1b = A.WRes1b[j], wres2 = A.WRes2[j];
         const double ws1a = A.WS1a[j], ws1b = A.WS1b[j], ws2 = A.WS2[j];
         T.ws1a = ws1a;
-        const int flags = (A.isFrozenSoil[pix] != 0 ? 1 : 0) | (A.PoreSpaceNotZero1a[j] != 0 ? 2 : 0) |
-                          (A.PoreSpaceNotZero1b[j] != 0 ? 4 : 0) | (A.PoreSpaceNotZero2[j] != 0 ? 8 : 0);
+        const bool is_frozen = A.isFrozenSoil[pix] != 0;
+        double im1a, im1b, im2, in_wres1, in_ws1;
+        int flags;
+        if (DERIVED) {
+            im1a = 1 / m1a; im1b = 1 / m1b; im2 = 1 / m2;                      // soil.py:180-182
+            in_ws1 = ws1a + ws1b; in_wres1 = wres1a + wres1b;                  // :196, 201
+            T.wfc1 = T.wfc1a + T.wfc1b; T.wwp1 = T.wwp1a + T.wwp1b;            // :215, 224
+            flags = (is_frozen ? 1 : 0) | ((T.sd1a != 0 && ws1a != 0) ? 2 : 0) | ((T.sd1b != 0 && ws1b != 0) ? 4 : 0) |
+                    ((T.sd2 != 0 && ws2 != 0) ? 8 : 0);                        // :226-228
+        } else {
+            im1a = A.GenuInvM1a[j]; im1b = A.GenuInvM1b[j]; im2 = A.GenuInvM2[j];
+            in_ws1 = A.WS1[j]; in_wres1 = A.WRes1[j];
+            T.wfc1 = A.WFC1[j]; T.wwp1 = A.WWP1[j];
+            flags = (is_frozen ? 1 : 0) | (A.PoreSpaceNotZero1a[j] != 0 ? 2 : 0) | (A.PoreSpaceNotZero1b[j] != 0 ? 4 : 0) |
+                    (A.PoreSpaceNotZero2[j] != 0 ? 8 : 0);
+        }
         T.flags = flags;
         const bool frozen = (flags & 1) != 0, pore1a = (flags & 2) != 0, pore1b = (flags & 4) != 0, pore2 = (flags & 8) != 0;
         // available water for infiltration, :100,131
@@ -439,9 +456,9 @@ k_soil_fused(lf_soil_args A, veg_plan P, unsigned short *__restrict__ all_list, 
             const unsigned int r = rank - base;
             if (r < (unsigned int)kLoopCap) {
 #define REC(f, v) s_rec[(f) * kLoopCap + r] = (v)
-                REC(0, T.w1a); REC(1, A.WRes1a[j]); REC(2, T.ws1a); REC(3, A.KSat1a[j]); REC(4, A.GenuInvM1a[j]); REC(5, A.GenuM1a[j]); REC(6, k1a);
-                REC(7, T.w1b); REC(8, A.WRes1b[j]); REC(9, A.WS1b[j]); REC(10, A.KSat1b[j]); REC(11, A.GenuInvM1b[j]); REC(12, A.GenuM1b[j]); REC(13, k1b);
-                REC(14, T.w2); REC(15, A.WRes2[j]); REC(16, A.WS2[j]); REC(17, A.KSat2[j]); REC(18, A.GenuInvM2[j]); REC(19, A.GenuM2[j]); REC(20, k2);
+                REC(0, T.w1a); REC(1, A.WRes1a[j]); REC(2, T.ws1a); REC(3, A.KSat1a[j]); REC(4, DERIVED ? 1 / A.GenuM1a[j] : A.GenuInvM1a[j]); REC(5, A.GenuM1a[j]); REC(6, k1a);
+                REC(7, T.w1b); REC(8, A.WRes1b[j]); REC(9, A.WS1b[j]); REC(10, A.KSat1b[j]); REC(11, DERIVED ? 1 / A.GenuM1b[j] : A.GenuInvM1b[j]); REC(12, A.GenuM1b[j]); REC(13, k1b);
+                REC(14, T.w2); REC(15, A.WRes2[j]); REC(16, A.WS2[j]); REC(17, A.KSat2[j]); REC(18, DERIVED ? 1 / A.GenuM2[j] : A.GenuInvM2[j]); REC(19, A.GenuM2[j]); REC(20, k2);
                 REC(21, (double)T.flags);
 #undef REC
                 s_key[r] = (unsigned int)nsub_f;
@@ -696,7 +713,15 @@ int lf_soil_substep_histogram(int device, int64_t *hist, int nbins)
     return LF_OK;
 }
 
-int lf_soil_columns_device(int device, const lf_soil_args *a)
+static int soil_columns_device(int device, const lf_soil_args *a, bool derived);
+
+int lf_soil_columns_device(int device, const lf_soil_args *a) { return soil_columns_device(device, a, false); }
+
+// The same for a caller that vouches for the relations of k_soil_fused<.., DERIVED> between its parameter arrays: the ten
+// derived ones (GenuInvM1a/1b/2, WS1, WRes1, WFC1, WWP1, PoreSpaceNotZero1a/1b/2) are not read and may be NULL.
+int lf_soil_columns_device_derived(int device, const lf_soil_args *a) { return soil_columns_device(device, a, true); }
+
+static int soil_columns_device(int device, const lf_soil_args *a, bool derived)
 {
     if (!a || !a->index_landuse_all) return lf_set_error(LF_E_INVALID, "null argument");
     lf_device_ctx *c;
@@ -733,23 +758,22 @@ int lf_soil_columns_device(int device, const lf_soil_args *a)
     // LF_GENERAL_POW=1: OCML pow instead of lf_pow_pos (A/B parity and timing)
     const char *force_general = std::getenv("LF_GENERAL_POW");
     const bool fastpow = !(force_general && force_general[0] == '1');
-    // LF_SOIL_WAVES=4: four wavefronts per SIMD (128 registers: the state a lane holds across the sub-step phase spills)
-    int waves = 3;
-    if (const char *e = std::getenv("LF_SOIL_WAVES")) waves = std::atol(e) == 4 ? 4 : 3;
     // (Sending the call out in chunks of tiles with the stragglers of a chunk on a second stream beside the streaming launch
     // of the next chunk was measured and dropped: 2.28 / 2.29 / 2.35 / 2.50 / 2.90 ms for 1 / 2 / 4 / 8 / 16 chunks on the wet
-    // synthetic soil -- the streaming launch fills every compute unit, the second stream only gets the chunk tails.)
+    // synthetic soil -- the streaming launch fills every compute unit, the second stream only gets the chunk tails.  So was
+    // a build at four wavefronts per SIMD: the state a lane holds across the sub-step phase spills, 1.72 vs 1.26 ms.)
     const dim3 grid((unsigned)ntiles), block(kTile);
     size_t dyn = 0; // LF_SOIL_DEBUG_LDS=<bytes>: extra LDS per workgroup, to bound the tiles in flight per compute unit (timing experiments)
     if (const char *e = std::getenv("LF_SOIL_DEBUG_LDS")) dyn = (size_t)std::atol(e);
-    if (fastpow && waves == 3)
-        hipLaunchKernelGGL((k_soil_fused<true, 3>), grid, block, dyn, c->stream, *a, P, all_list, all_count, G, 0u, tiles_per_veg);
+    if (const char *e = std::getenv("LF_SOIL_NO_DERIVED")) derived = derived && e[0] != '1'; // A/B switch
+    if (fastpow && derived)
+        hipLaunchKernelGGL((k_soil_fused<true, true>), grid, block, dyn, c->stream, *a, P, all_list, all_count, G, 0u, tiles_per_veg);
     else if (fastpow)
-        hipLaunchKernelGGL((k_soil_fused<true, 4>), grid, block, dyn, c->stream, *a, P, all_list, all_count, G, 0u, tiles_per_veg);
-    else if (waves == 3)
-        hipLaunchKernelGGL((k_soil_fused<false, 3>), grid, block, dyn, c->stream, *a, P, all_list, all_count, G, 0u, tiles_per_veg);
+        hipLaunchKernelGGL((k_soil_fused<true, false>), grid, block, dyn, c->stream, *a, P, all_list, all_count, G, 0u, tiles_per_veg);
+    else if (derived)
+        hipLaunchKernelGGL((k_soil_fused<false, true>), grid, block, dyn, c->stream, *a, P, all_list, all_count, G, 0u, tiles_per_veg);
     else
-        hipLaunchKernelGGL((k_soil_fused<false, 4>), grid, block, dyn, c->stream, *a, P, all_list, all_count, G, 0u, tiles_per_veg);
+        hipLaunchKernelGGL((k_soil_fused<false, false>), grid, block, dyn, c->stream, *a, P, all_list, all_count, G, 0u, tiles_per_veg);
     if (G.trip_cap > 0) {
         const dim3 grid2((unsigned)((ntiles + kStragGroup - 1) / kStragGroup));
         if (fastpow)

@@ -49,6 +49,8 @@ class HotPathDevice:
         # of the step after it (same kernels, same results; False: one stream, as rounds 1-3)
         self.overlap_channel = bool(overlap_channel)
         self.rmod = None
+        # the ten derived soil parameter arrays recomputed instead of read where they are what soil.py:180-228 makes them
+        self.soil_derived = SL.derived_parameters_hold(values)
         self.sc = dict(scalars)
         land_mask = np.asarray(land_mask, bool)
         self.N = N = int(land_mask.sum())
@@ -286,7 +288,8 @@ class HotPathDevice:
             check(L.lf_scale_rows_device(C.c_int(dev), d["ESRef"].ptr, d["LAITerm"].ptr, d["ESMax"].ptr,
                                          C.c_int64(3), C.c_int64(self.N)))                             # soilloop.py:638
         with stage("soil_columns"):
-            check(L.lf_soil_columns_device(C.c_int(dev), C.byref(self.soil)))                           # dyn.py:123
+            soil_fn = L.lf_soil_columns_device_derived if self.soil_derived else L.lf_soil_columns_device
+            check(soil_fn(C.c_int(dev), C.byref(self.soil)))                                            # dyn.py:123
         self.steps_done += 1
         self.pixel.TimeSinceStart = float(time_since_start if time_since_start else self.steps_done)
         with stage("pixel_aggregates"):

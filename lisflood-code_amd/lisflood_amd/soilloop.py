@@ -108,6 +108,25 @@ def soilColumnsWaterBalance(*args, device=0):
     check(lib().lf_soil_columns_host(C.c_int(device), C.byref(a)))
 
 
+def derived_parameters_hold(d):
+    """True when the ten derived parameter arrays of soilColumnsWaterBalance are, bit for bit, what soil.py:180-228 makes
+    them from the others (GenuInvM = 1 / GenuM; WS1 = WS1a + WS1b, likewise WRes1, WFC1, WWP1; PoreSpaceNotZero = SoilDepth
+    != 0 and WS != 0) -- then lf_soil_columns_device_derived recomputes them instead of reading them (59 B per column).
+    One pass over host arrays at set-up time; any array that is missing or different -> False (the streamed form)."""
+    try:
+        same = lambda a, b: np.array_equal(np.asarray(a, np.float64), np.asarray(b, np.float64))
+        with np.errstate(all="ignore"):
+            ok = all(same(d["GenuInvM" + l], 1 / np.asarray(d["GenuM" + l], np.float64)) for l in ("1a", "1b", "2"))
+            ok = ok and all(same(d[k + "1"], np.asarray(d[k + "1a"], np.float64) + np.asarray(d[k + "1b"], np.float64))
+                            for k in ("WS", "WRes", "WFC", "WWP"))
+            ok = ok and all(np.array_equal(np.asarray(d["PoreSpaceNotZero" + l]) != 0,
+                                           (np.asarray(d["SoilDepth" + l]) != 0) & (np.asarray(d["WS" + l]) != 0))
+                            for l in ("1a", "1b", "2"))
+        return bool(ok)
+    except KeyError:
+        return False
+
+
 class SoilColumnsDevice:
     """Device-resident soil columns: every array of the reference call lives in HBM; `step()` is one
     soilColumnsWaterBalance pass, `interception()` one interception_water_balance pass."""
@@ -116,6 +135,7 @@ class SoilColumnsDevice:
         self.device = device
         self.V, self.N = d["Interception"].shape
         self.L = np.asarray(d["WS1a"]).shape[0]
+        self.derived = derived_parameters_hold(d)      # checked once: the parameter arrays are static (set() refuses them)
         self.dev = {}
         for k in _L_FIELDS + _N_FIELDS + _V_IN + _V_IO:
             self.dev[k] = DeviceArray.from_host(u8(d[k]) if k in _BOOL else f64(d[k]), device)
@@ -137,7 +157,8 @@ class SoilColumnsDevice:
         a.V, a.L, a.N = self.V, self.L, self.N
 
     def step(self):
-        check(lib().lf_soil_columns_device(C.c_int(self.device), C.byref(self.args)))
+        fn = lib().lf_soil_columns_device_derived if self.derived else lib().lf_soil_columns_device
+        check(fn(C.c_int(self.device), C.byref(self.args)))
 
     def substep_histogram(self, nbins=128):
         """hist[k] = columns of the last step that needed k Courant sub-steps, k >= 2 (columns with one sub-step are not
@@ -151,6 +172,8 @@ class SoilColumnsDevice:
         return out
 
     def set(self, name, value):
+        if name in _L_FIELDS:
+            self.derived = False        # a parameter array changed: back to the streamed form (nothing re-checks it)
         self.dev[name].upload(u8(value) if name in _BOOL else f64(value))
 
 

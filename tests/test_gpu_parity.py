@@ -1079,6 +1079,36 @@ def test_soil_columns_device_resident_vs_oracle(amd, oracle, solver):
     assert (d2["Theta1a"][1] == 0).all()
 
 
+def test_soil_derived_parameters_recomputed_give_the_same_bits(amd, monkeypatch):
+    """lf_soil_columns_device_derived (GenuInvM, WS1, WRes1, WFC1, WWP1 and the pore-space flags recomputed from the arrays
+    soil.py:180-228 makes them of) against the streamed form on the same inputs, bit for bit; an array that does not
+    follow the relation switches the object back to the streamed form."""
+    from lisflood_amd import synthetic as syn
+    from lisflood_amd.soilloop import derived_parameters_hold
+    N = 20003
+    d = syn.soil_params(N, seed=31)
+    assert derived_parameters_hold(d)
+    outs = []
+    for no_derived in ("0", "1"):
+        monkeypatch.setenv("LF_SOIL_NO_DERIVED", no_derived)
+        dev = amd.soil.SoilColumnsDevice({k: (v.copy() if hasattr(v, "copy") else v) for k, v in d.items()})
+        assert dev.derived
+        for s in range(2):
+            dev.step()
+        outs.append({k: dev.get(k) for k in syn.SOIL_WRITTEN})
+        for a in dev.dev.values():
+            a.free()
+    for k in syn.SOIL_WRITTEN:
+        assert np.array_equal(outs[0][k], outs[1][k], equal_nan=True), k
+    d2 = dict(d)
+    d2["WS1"] = d["WS1"] * (1 + 1e-15)
+    assert not derived_parameters_hold(d2)
+    dev = amd.soil.SoilColumnsDevice(d2)
+    assert not dev.derived
+    for a in dev.dev.values():
+        a.free()
+
+
 @pytest.mark.parametrize("trip_cap", ["0", "3", "16", "200"])
 def test_soil_columns_same_bits_whatever_the_trip_cap(amd, monkeypatch, trip_cap):
     """Which columns leave their tile for k_soil_stragglers (LF_SOIL_TRIP_CAP: none, nearly all multi-sub-step ones --
