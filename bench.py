@@ -590,28 +590,58 @@ def hotpath_bench(size=2000, steps=6, family="deep", block=1_000_000):
     for w in range(3):
         hp.step(forc[w % 2], w + 1, ordered=True)
         _lib.synchronize()
+    # (a) forcing resident in HBM when the timed region starts (the two buffer sets hold the two forcing sets)
+    t0 = time.perf_counter()
+    for s in range(steps):
+        hp.step(None, s + 4)
+    _lib.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / steps
+    # (b) PCIe-inclusive: every step's five forcing vectors come up from page-locked host memory while the step before runs
     t0 = time.perf_counter()
     hp.prefetch(forc[0], ordered=True)
     for s in range(steps):
-        hp.step(forc[s % 2], s + 4, ordered=True)
+        hp.step(forc[s % 2], s + 4 + steps, ordered=True)
         hp.prefetch(forc[(s + 1) % 2], ordered=True)          # next step's forcing goes up while this step's kernels run
     _lib.synchronize()
-    ms = (time.perf_counter() - t0) * 1e3 / steps
+    ms_up = (time.perf_counter() - t0) * 1e3 / steps
+    # (c) the same with the forcing held as float32 (as the reference's meteo files store it) and widened on the device
+    forc32 = []
+    for f in forc:
+        g = hp.pinned_forcing(np.float32)
+        for k in f:
+            g[k][:] = f[k]
+        forc32.append(g)
+    hp.step(forc32[0], 3 * steps + 4, ordered=True)
+    _lib.synchronize()
+    t0 = time.perf_counter()
+    hp.prefetch(forc32[1], ordered=True)
+    for s in range(steps):
+        hp.step(forc32[(s + 1) % 2], 3 * steps + 5 + s, ordered=True)
+        hp.prefetch(forc32[s % 2], ordered=True)
+    _lib.synchronize()
+    ms_up32 = (time.perf_counter() - t0) * 1e3 / steps
+    for b_ in range(2):         # the fp64 sets back into the buffers (the legs below step on resident forcing)
+        hp.step(forc[b_], 4 * steps + 6 + b_, ordered=True)
+    _lib.synchronize()
     q = hp.chan_q_avg()
     out = dict(ms_per_model_step=round(ms, 3), model_steps_per_s=round(1e3 / ms, 2), pixels=N, channel_pixels=int(hp.Nk),
                Mpixel_steps_per_s=round(N / ms / 1e3, 2), finite=bool(np.isfinite(q).all()),
+               ms_per_model_step_with_forcing_upload=round(ms_up, 3),
+               ms_per_model_step_with_float32_forcing_upload=round(ms_up32, 3),
+               forcing_upload_GBs=round(5 * 8 * N / 1e9 / (ms_up * 1e-3), 1),
                levels=dict(channel=int(hp.river.graph.num_levels), overland=int(hp.r_other.graph.num_levels)),
-               config="%dx%d %s LDD, 30 %% channel pixels, V=3 fractions, NoRoutSteps=24 split routing; forcing "
-                      "uploaded from the host every step; the channel wavefront on a second stream beside the next step's "
-                      "canopy / soil / overland kernels; parameter fields drawn for %d pixels and repeated" % (H, W, family, min(block, N)))
+               config="%dx%d %s LDD, 30 %% channel pixels, V=3 fractions, NoRoutSteps=24 split routing; ms_per_model_step: the "
+                      "forcing of the step resident in HBM; ..._with_forcing_upload: its five vectors (40 B per pixel) uploaded "
+                      "from page-locked host memory every step, overlapped with the step before; the channel wavefront on a "
+                      "second stream beside the next step's canopy / soil / overland kernels; parameter fields drawn for %d "
+                      "pixels and repeated" % (H, W, family, min(block, N)))
     # A/B: everything on one stream (rounds 1-3)
     hp.overlap_channel = False
-    hp.step(forc[0], steps + 4, ordered=True)
+    hp.step(None, 2 * steps + 4)
     _lib.synchronize()
     t0 = time.perf_counter()
     for s in range(steps):
-        hp.step(forc[s % 2], steps + 5 + s, ordered=True)
-        hp.prefetch(forc[(s + 1) % 2], ordered=True)
+        hp.step(None, 2 * steps + 5 + s)
     _lib.synchronize()
     out["one_stream_ms_per_model_step"] = round((time.perf_counter() - t0) * 1e3 / steps, 3)
     # stage by stage (two profiled steps, the mean)
@@ -839,6 +869,7 @@ def compact_line(out, detail):
         e = ow.get("resident_hot_path_step_%s_5000" % fam)
         if e:
             legs["hot_path_%s_5000" % fam] = dict(ms=e["ms_per_model_step"], value=e["Mpixel_steps_per_s"], unit="Mpixel-steps/s",
+                                                   ms_with_forcing_upload=e.get("ms_per_model_step_with_forcing_upload"),
                                                    stages={k: [x["ms"], x["frac_hbm"]] for k, x in e["stages"].items()})
     errs = {k: v for k, v in ow.items() if k.endswith("_error")}
     if errs:

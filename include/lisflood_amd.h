@@ -83,6 +83,9 @@ int lf_host_free(int device, void *ptr_host);
  * The copies wait for the kernels that last read set b, those kernels wait for the copies; the other set is free. */
 int lf_upload_begin(int device, int set);
 int lf_upload_copy(int device, void *dst_dev, const void *src_host, size_t bytes);
+/* the same for a vector the caller holds as float32 (the reference's meteo files are float32; readnetcdf widens them on the
+ * host): half the bytes over PCIe, widened to fp64 on the device behind the copy -- the same exact conversion */
+int lf_upload_copy_f32(int device, double *dst_dev, const float *src_host, size_t count);
 int lf_upload_end(int device, int set);
 int lf_compute_acquire(int device, int set);
 int lf_compute_release(int device, int set);

@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <map>
 #include <vector>
 
 #include "../../include/lisflood_amd.h"
@@ -44,6 +45,7 @@ struct lf_device_ctx {
     // upload stream for double-buffered inputs (lf_upload_*): copies of the NEXT step's forcing overlap the kernels of
     // the current one; per buffer set an event "copy finished" and an event "last kernel reading the set finished"
     hipStream_t copy_stream = nullptr;
+    std::map<void *, std::pair<void *, size_t>> f32_stage; // lf_upload_copy_f32: fp32 staging buffer per destination vector
     hipEvent_t copied[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
     bool consumed_valid[2] = {false, false};
     // side stream (lf_side_stream_*): a part of a step that the NEXT step's first kernels do not depend on -- the channel

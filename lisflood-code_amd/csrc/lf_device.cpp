@@ -191,6 +191,37 @@ int lf_upload_copy(int device, void *dst_dev, const void *src_host, size_t bytes
     return LF_OK;
 }
 
+// fp32 forcing: the reference's meteo files hold float32 (tests/data/LF_ETRS89_UseCase/meteo_1950: "float32 as stored") and
+// widens them on the host; widening on the device is the same exact conversion and halves what crosses PCIe.  The fp32
+// image goes to a staging buffer kept per destination vector, the widening kernel runs on the copy stream behind it.
+__global__ void k_widen_f32(long long n, const float *__restrict__ src, double *__restrict__ dst)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (double)src[i];
+}
+
+int lf_upload_copy_f32(int device, double *dst_dev, const float *src_host, size_t count)
+{
+    if (!dst_dev || (!src_host && count)) return lf_set_error(LF_E_INVALID, "null argument");
+    lf_device_ctx *c;
+    LF_TRY(upload_ctx(device, 0, &c));
+    if (!count) return LF_OK;
+    auto &st = c->f32_stage[(void *)dst_dev];
+    if (st.second < count * sizeof(float)) {
+        LF_HIP(hipStreamSynchronize(c->copy_stream)); // (a copy into the old buffer may still be in flight)
+        if (st.first) (void)hipFree(st.first);
+        st.first = nullptr;
+        st.second = 0;
+        LF_HIP(hipMalloc(&st.first, count * sizeof(float)));
+        st.second = count * sizeof(float);
+    }
+    LF_HIP(hipMemcpyAsync(st.first, src_host, count * sizeof(float), hipMemcpyHostToDevice, c->copy_stream));
+    hipLaunchKernelGGL(k_widen_f32, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->copy_stream, (long long)count,
+                       (const float *)st.first, dst_dev);
+    LF_HIP(hipGetLastError());
+    return LF_OK;
+}
+
 int lf_upload_end(int device, int set)
 {
     lf_device_ctx *c;

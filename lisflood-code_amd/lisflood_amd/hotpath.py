@@ -124,9 +124,15 @@ class HotPathDevice:
                 if self.rmod is not None:
                     continue
                 a = np.broadcast_to(a, (Nk,))[self.perm]
+            elif self.pixel_of_position is not None and a.ndim >= 1 and a.shape[-1] == N and k not in bool_names:
+                self.d[k] = self._upload_ordered(f64(a))      # permuted on the device (a host gather of ~100 fields is slow)
+                continue
             else:
                 a = self._ordered(a)
             self.d[k] = DeviceArray.from_host(u8(a) if k in bool_names else f64(a), device)
+        if getattr(self, "_perm_tmp", None) is not None:
+            self._perm_tmp.free(); self._perm_idx.free()
+            self._perm_tmp = self._perm_idx = None
 
         def zeros(name, shape):
             if name not in self.d:
@@ -178,6 +184,21 @@ class HotPathDevice:
         r.split, r.engine_order = (1 if self.split else 0), 1
         self.steps_done = 0
 
+    def _upload_ordered(self, a):
+        """fp64 [N] or [R, N] host array in pixel order -> device array in the order of pixel_of_position: every row is
+        uploaded as it is and gathered on the device (lf_gather_device)"""
+        L, dev, N = lib(), self.device, self.N
+        if getattr(self, "_perm_tmp", None) is None:
+            self._perm_tmp = DeviceArray(N, np.float64, dev)
+            self._perm_idx = DeviceArray.from_host(self.pixel_of_position.astype(np.int32), dev)
+        dst = DeviceArray(a.shape, np.float64, dev)
+        rows = a.reshape(-1, N)
+        for r in range(rows.shape[0]):
+            self._perm_tmp.upload(np.ascontiguousarray(rows[r]))
+            check(L.lf_gather_device(C.c_int(dev), C.c_int64(N), self._perm_idx.ptr, self._perm_tmp.ptr,
+                                     C.c_void_p(dst.ptr.value + r * N * 8)))
+        return dst
+
     def _ordered(self, a):
         """a per-pixel array ([N] or [..., N], pixel order) in the order the non-channel device vectors are kept in"""
         a = np.asarray(a)
@@ -194,22 +215,28 @@ class HotPathDevice:
         return out
 
     def _upload(self, b, forcing, ordered=False):
+        """float32 vectors (meteo as the netCDF files store it) go up as float32 and are widened on the device -- exactly
+        what widening them on the host first would give, at half the PCIe traffic"""
         L, dev = lib(), self.device
-        host = [f64(forcing[k]) if ordered else f64(self._ordered(forcing[k])) for k in FORCING]
+        as_is = lambda a: np.ascontiguousarray(a) if np.asarray(a).dtype == np.float32 else f64(a)
+        host = [as_is(forcing[k]) if ordered else as_is(self._ordered(forcing[k])) for k in FORCING]
         check(L.lf_upload_begin(C.c_int(dev), C.c_int(b)))
         for k, a in zip(FORCING, host):
             if a.size != self.N:
                 raise ValueError("forcing vector %s must have %d entries" % (k, self.N))
+            if a.dtype == np.float32:
+                check(L.lf_upload_copy_f32(C.c_int(dev), self.force[b][k].ptr, a.ctypes.data_as(C.c_void_p), C.c_size_t(a.size)))
+                continue
             check(L.lf_upload_copy(C.c_int(dev), self.force[b][k].ptr, a.ctypes.data_as(C.c_void_p), C.c_size_t(a.nbytes)))
         check(L.lf_upload_end(C.c_int(dev), C.c_int(b)))
         self._keep[b] = host                 # the host vectors stay alive until the set is uploaded again
 
-    def pinned_forcing(self):
+    def pinned_forcing(self, dtype=np.float64):
         """A forcing dict (Rain, SnowMelt, EWRef, ETRef, ESRef) of [N] arrays in page-locked host memory, to be filled in
         place (e.g. by the netCDF reader) and passed to prefetch() / step(): their upload is an asynchronous DMA at the
         PCIe rate instead of a staged, blocking copy.  The arrays belong to this object (freed by free())."""
         from ._lib import PinnedArray
-        bufs = {k: PinnedArray(self.N, np.float64, self.device) for k in FORCING}
+        bufs = {k: PinnedArray(self.N, dtype, self.device) for k in FORCING}
         self.__dict__.setdefault("_pinned", []).append(bufs)
         return {k: b.a for k, b in bufs.items()}
 
@@ -254,7 +281,10 @@ class HotPathDevice:
         if QInM3 is not None:
             self.set_inflow(QInM3)
         b = self.steps_done % 2
-        if self._prefetched[b] is not forcing:
+        if forcing is None:          # the vectors this buffer set already holds (uploaded for an earlier step): no PCIe traffic
+            if self._keep[b] is None:
+                raise ValueError("step(None): buffer set %d has never been uploaded" % b)
+        elif self._prefetched[b] is not forcing:
             self._upload(b, forcing, ordered)
         self._prefetched[b] = None
         check(L.lf_compute_acquire(C.c_int(dev), C.c_int(b)))

@@ -1000,6 +1000,30 @@ def test_hot_path_forcing_from_page_locked_buffers(amd):
     a.free(); b.free()
 
 
+def test_hot_path_float32_forcing_is_widened_on_the_device(amd):
+    """Forcing vectors held as float32 (the reference's meteo files are float32) go over PCIe as float32 and are widened on
+    the device: the bits of the same values widened on the host first."""
+    from lisflood_amd import synthetic as syn
+    from lisflood_amd.hotpath import HotPathDevice
+    H, W = 40, 50
+    N = H * W
+    values, sc, mask, ldd_to_chan, ldd_kin = syn.hotpath_scenario(H, W)
+    cp = lambda d: {k: (np.array(a, copy=True) if isinstance(a, np.ndarray) else a) for k, a in d.items()}
+    a = HotPathDevice(cp(values), sc, mask, ldd_to_chan, ldd_kin, split=True)
+    b = HotPathDevice(cp(values), sc, mask, ldd_to_chan, ldd_kin, split=True)
+    bufs = [b.pinned_forcing(np.float32) for _ in range(2)]
+    for s in range(3):
+        f32 = {k: x.astype(np.float32) for k, x in syn.hotpath_forcing(N, s).items()}
+        a.step({k: x.astype(np.float64) for k, x in f32.items()}, s + 1)
+        for k, x in f32.items():
+            bufs[s % 2][k][:] = x
+        b.prefetch(bufs[s % 2])
+        b.step(bufs[s % 2], s + 1)
+    for k in a.state_names() + ["sumDisDay", "Infiltration", "ToChanM3RunoffDt"]:
+        assert np.array_equal(a.download(k), b.download(k), equal_nan=True), k
+    a.free(); b.free()
+
+
 def test_hot_path_warm_start(amd, tmp_path):
     """save_state after step 1 -> a fresh HotPathDevice + load_state must continue exactly like the original run
     (with lakes / reservoirs in the loop, so the site vectors travel too)."""
