@@ -127,6 +127,19 @@ def test_compute_fails_loudly_without_gpu():
     d = syn.soil_params(8)
     with pytest.raises(_lib.LisfloodAmdError):
         soilColumnsWaterBalance(*[d[k] for k in syn.SOIL_ARG_ORDER])
+    # the entry points added in round 5 fail the same way (page-locked host memory needs a HIP device too)
+    import ctypes as C
+    L = _lib.lib()
+    p = C.c_void_p()
+    assert L.lf_host_alloc(C.c_int(0), C.c_size_t(64), C.byref(p)) == _lib.LF_E_NO_DEVICE and not p.value
+    from lisflood_amd.soilloop import _SoilArgs
+    a = _SoilArgs()
+    idx = np.zeros(3, np.int64)
+    a.index_landuse_all = idx.ctypes.data
+    a.V, a.L, a.N = 3, 3, 8
+    assert L.lf_soil_columns_device_derived(C.c_int(0), C.byref(a)) == _lib.LF_E_NO_DEVICE
+    buf = np.zeros(4, np.float32)
+    assert L.lf_upload_copy_f32(C.c_int(0), C.c_void_p(8), buf.ctypes.data_as(C.c_void_p), C.c_size_t(4)) == _lib.LF_E_NO_DEVICE
 
 
 def test_graph_with_structure_links():
