@@ -1133,6 +1133,26 @@ def test_soil_derived_parameters_recomputed_give_the_same_bits(amd, monkeypatch)
         a.free()
 
 
+@pytest.mark.parametrize("N,V,L", [(1, 3, 3), (63, 1, 1), (255, 5, 2), (257, 4, 3), (777, 5, 2)])
+def test_soil_columns_small_and_ragged_shapes(amd, oracle, N, V, L):
+    """Tiles that are mostly empty, one column, vegetation fractions that share land-use rows (index_landuse_all with
+    repeats), V != L: against the oracle, two steps (device-resident and through the 73-argument drop-in call)."""
+    from lisflood_amd import synthetic as syn
+    d = syn.soil_params(N, V=V, L=L, seed=41)
+    ref = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in d.items()}
+    host = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in d.items()}
+    dev = amd.soil.SoilColumnsDevice(d)
+    for s in range(2):
+        dev.step()
+        oracle.soil_columns(ref)
+        amd.soil.soilColumnsWaterBalance(*[host[k] for k in syn.SOIL_ARG_ORDER])
+    for k in syn.SOIL_WRITTEN:
+        np.testing.assert_allclose(dev.get(k), ref[k], rtol=1e-9, atol=1e-11, err_msg=k)
+        assert np.array_equal(dev.get(k), host[k], equal_nan=True), k          # derived / streamed parameters, device / host form
+    for a in dev.dev.values():
+        a.free()
+
+
 @pytest.mark.parametrize("trip_cap", ["0", "3", "16", "200"])
 def test_soil_columns_same_bits_whatever_the_trip_cap(amd, monkeypatch, trip_cap):
     """Which columns leave their tile for k_soil_stragglers (LF_SOIL_TRIP_CAP: none, nearly all multi-sub-step ones --
