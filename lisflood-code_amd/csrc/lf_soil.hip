@@ -2,11 +2,11 @@
 // Replaces the numba kernels interception_water_balance (soilloop.py:27-70) and
 // soilColumnsWaterBalance (soilloop.py:78-355, helpers 360-396).
 //
-// Columns (vegetation fraction x pixel) are independent: one lane per pixel, the lane walks the V
-// vegetation fractions so that the per-pixel inputs (Rain, SnowMelt, isFrozenSoil, b_Xinanjiang, ...)
-// are fetched once.  Every array keeps the reference's [V,N] / [L,N] C-order layout, so lanes of a
-// wavefront read/write consecutive fp64 of one row: all ~95 streams are coalesced.  The kernel is
-// HBM-bound (~500 B per column-step) unless many Courant sub-steps are needed.
+// Columns (vegetation fraction x pixel) are independent: one lane per column, a workgroup per tile of 256 columns of
+// one vegetation fraction.  Every array keeps the reference's [V,N] / [L,N] C-order layout, so lanes of a wavefront
+// read / write consecutive fp64 of one row: all ~70 streams are coalesced.  The kernel is HBM-bound (504 B per
+// column-step) where columns need one Courant sub-step; the columns that need more are worked three
+// lanes per column in LDS (k_soil_fused, phase 2) and, above a trip count, in k_soil_stragglers.
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -16,8 +16,7 @@
 
 namespace {
 
-constexpr double kMaxSoilSubSteps = 1048576.0; // cap of the per-column Courant sub-step count (see soil_column)
-
+constexpr double kMaxSoilSubSteps = 1048576.0; // cap of the per-column Courant sub-step count (see k_soil_fused, :249)
 
 constexpr int kBlock = 256;
 constexpr int kMaxVeg = 16;
