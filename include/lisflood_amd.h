@@ -575,6 +575,16 @@ int lf_dist_routing_substeps_fused(lf_dist_router *r, lf_comm *comm, const lf_su
 /* its pieces (other transports, in-process loopback): allocate for nsteps; one phase; where a round's halo sits in the
  * slab of a section -- out = {send offset, send count, recv offset, recv count} in doubles; the RCCL exchange */
 int lf_dist_fused_prepare(lf_dist_router *r, const lf_substep_args *a, int nsteps);
+/* Several MODEL steps per call on the partition (= lf_routing_model_steps_fused on the whole raster, bit for bit): every phase
+ * runs the sub-steps of all n_model_steps model steps as one wavefront and hands over the slabs of all of them in ONE halo
+ * block, so the pipeline fill of a phase and the exchange round are paid once per call instead of once per model step.
+ * a->SideflowChanM3: one vector per model step, sideflow_model_stride elements apart (0: one for all); a->sumDisDay:
+ * [n_model_steps][N], zeroed by the caller.  _phase_model_steps: one phase of it (after lf_dist_fused_prepare for
+ * steps_per_model_step * n_model_steps sub-steps), for callers that move the halo themselves. */
+int lf_dist_routing_model_steps_fused(lf_dist_router *r, lf_comm *comm, const lf_substep_args *a, int steps_per_model_step,
+                                      int n_model_steps, int64_t sideflow_model_stride, int rank_top, int rank_bottom);
+int lf_dist_fused_phase_model_steps(lf_dist_router *r, const lf_substep_args *a, int steps_per_model_step, int n_model_steps,
+                                    int64_t sideflow_model_stride, int phase);
 int lf_dist_fused_phase(lf_dist_router *r, const lf_substep_args *a, int nsteps, int64_t sideflow_stride, int phase);
 int lf_dist_fused_halo_block(const lf_dist_router *r, int round, int side, int64_t out[4]);
 int lf_dist_fused_slab(const lf_dist_router *r, int section, void **slab_dev);

@@ -825,6 +825,7 @@ struct lf_dist_router {
     lf_dbuf<int32_t> ups_idx_f, out_slot;
     lf_dbuf<double> fused_qr1, fused_qr2, slab1, slab2;
     int64_t n_slots = 0, slab_steps = 0, slot_export[2] = {0, 0}, slot_ghost[2] = {0, 0};
+    lf_dbuf<double> fused_hist1, fused_hist2; // [nsteps][N] router outputs of every sub-step (k_fused_level_steps<DIST>)
     std::vector<int32_t> phase_level; // [nphases + 1] first launch unit of every phase
     // level blocks + cones of every phase (empty: one launch per unit)
     std::vector<int> fb_level, fb_row, fb_off;
@@ -1475,7 +1476,8 @@ int dist_fused_prepare(lf_dist_router *r, const lf_substep_args *a, int nsteps)
 }
 
 // every sub-step of one phase as a wavefront over (unit, sub-step): nunits + nsteps - 1 launches
-int dist_fused_phase(lf_dist_router *r, const lf_substep_args *a, int nsteps, int64_t sideflow_stride, int phase)
+int dist_fused_phase(lf_dist_router *r, const lf_substep_args *a, int nsteps, int64_t sideflow_stride, int phase, int msteps = 0,
+                     int64_t side_mstride = 0)
 {
     if (phase < 0 || phase >= r->nphases) return lf_set_error(LF_E_INVALID, "phase %d out of range", phase);
     if (sideflow_stride != 0 && sideflow_stride != r->N) return lf_set_error(LF_E_INVALID, "sideflow_stride must be 0 or N");
@@ -1499,8 +1501,8 @@ int dist_fused_phase(lf_dist_router *r, const lf_substep_args *a, int nsteps, in
     F.root_st = 1;
     F.n = r->N;
     F.side_stride = sideflow_stride;
-    F.msteps = nsteps;
-    F.side_mstride = 0;
+    F.msteps = msteps > 0 ? msteps : nsteps; // several model steps per call: lf_dist_routing_model_steps_fused
+    F.side_mstride = side_mstride;
     F.dx_scalar = r->dx_scalar;
     F.beta = r->beta;
     F.inv_beta = r->inv_beta;
@@ -1521,6 +1523,47 @@ int dist_fused_phase(lf_dist_router *r, const lf_substep_args *a, int nsteps, in
     F.d_ups_base = D.ups_base;
     F.d_ups_idx = D.ups_idx;
     F.d_out_slot = D.out_slot;
+    // ---- a phase of few, wide levels: level after level, every level through all its sub-steps (k_fused_level_steps<DIST>,
+    // lf_fused.h; the single domain's rule and switches: LF_FUSED_TIME_MAJOR, LF_FUSED_TIME_MAJOR_LEVELS) -------------------
+    {
+        static const int tm_levels = [] {
+            const char *e = std::getenv("LF_FUSED_TIME_MAJOR_LEVELS");
+            return e ? std::atoi(e) : 192;
+        }();
+        const char *e = std::getenv("LF_FUSED_TIME_MAJOR");
+        const int64_t cells = r->h_level_start[unit0 + nunits] - r->h_level_start[unit0];
+        const bool want = e ? e[0] != '0' : (nunits <= tm_levels && cells >= 20000 * (int64_t)nunits);
+        if (want && nsteps > 1) {
+            const size_t need = (size_t)nsteps * (size_t)r->N;
+            bool ok = true;
+            if (r->fused_hist1.n < need) ok = r->fused_hist1.alloc(need) == LF_OK;
+            if (ok && a->split && r->fused_hist2.n < need) ok = r->fused_hist2.alloc(need) == LF_OK;
+            if (ok) {
+                F.hist1 = r->fused_hist1.p;
+                F.hist2 = r->fused_hist2.p;
+                const bool all35 = r->fused && a->Beta == 0.6;
+                for (int k = 0; k < nunits; ++k) {
+                    const int64_t w = r->h_level_start[unit0 + k + 1] - r->h_level_start[unit0 + k];
+                    if (w <= 0) continue;
+                    const dim3 grid(blocks_for(w)), block(kBlock);
+                    if (a->split && all35)
+                        hipLaunchKernelGGL((k_fused_level_steps<true, true, true>), grid, block, 0, s, F, unit0 + k);
+                    else if (a->split)
+                        hipLaunchKernelGGL((k_fused_level_steps<true, false, true>), grid, block, 0, s, F, unit0 + k);
+                    else if (all35)
+                        hipLaunchKernelGGL((k_fused_level_steps<false, true, true>), grid, block, 0, s, F, unit0 + k);
+                    else
+                        hipLaunchKernelGGL((k_fused_level_steps<false, false, true>), grid, block, 0, s, F, unit0 + k);
+                    r->last_launches++;
+                }
+                LF_HIP(hipGetLastError());
+                return LF_OK;
+            }
+            (void)hipGetLastError(); // no room for the history: the skewed wavefront below
+            r->fused_hist1.release();
+            r->fused_hist2.release();
+        }
+    }
     if (!r->fb_phase_block.empty() && nsteps <= kMaxPackedSteps) { // blocks of levels, cone by cone (k_fused_cones<DIST>)
         const int b0 = r->fb_phase_block[phase], NB = r->fb_phase_block[phase + 1] - b0;
         F.fb_level = r->fb_level_dev.p;
@@ -1686,6 +1729,43 @@ int lf_dist_fused_exchange(lf_dist_router *r, lf_comm *comm, int round, int spli
         }
     }
     LF_NCCL(g_rccl.GroupEnd());
+    return LF_OK;
+}
+
+// Several MODEL steps per call on the partition (lf_routing_model_steps_fused on the whole raster, bit for bit): every phase
+// runs the sub-steps of ALL n_model_steps model steps as one wavefront and hands over the slabs of all of them in ONE halo
+// block -- the pipeline fill of a phase and the exchange round are paid once per call instead of once per model step, which
+// is what the partition of a deep network needs (successive calls in flight).  a->SideflowChanM3: one
+// vector per model step, sideflow_model_stride elements apart (0: one for all); a->sumDisDay: [n_model_steps][N], zeroed by
+// the caller.
+static int check_model_steps(const lf_dist_router *r, int steps_per_model_step, int n_model_steps, int64_t stride)
+{
+    if (!r || steps_per_model_step < 1 || n_model_steps < 1) return lf_set_error(LF_E_INVALID, "bad argument");
+    if (stride != 0 && stride < r->N) return lf_set_error(LF_E_INVALID, "sideflow_model_stride must be 0 or >= N");
+    return LF_OK;
+}
+
+int lf_dist_fused_phase_model_steps(lf_dist_router *r, const lf_substep_args *a, int steps_per_model_step, int n_model_steps,
+                                    int64_t sideflow_model_stride, int phase)
+{
+    if (!a) return lf_set_error(LF_E_INVALID, "null argument");
+    LF_TRY(check_model_steps(r, steps_per_model_step, n_model_steps, sideflow_model_stride));
+    LF_HIP(hipSetDevice(r->device));
+    return dist_fused_phase(r, a, steps_per_model_step * n_model_steps, 0, phase, steps_per_model_step, sideflow_model_stride);
+}
+
+int lf_dist_routing_model_steps_fused(lf_dist_router *r, lf_comm *comm, const lf_substep_args *a, int steps_per_model_step,
+                                      int n_model_steps, int64_t sideflow_model_stride, int rank_top, int rank_bottom)
+{
+    if (!a) return lf_set_error(LF_E_INVALID, "null argument");
+    LF_TRY(check_model_steps(r, steps_per_model_step, n_model_steps, sideflow_model_stride));
+    const int nsteps = steps_per_model_step * n_model_steps;
+    LF_TRY(dist_fused_prepare(r, a, nsteps));
+    r->last_launches = 0;
+    for (int j = 0; j < r->nphases; ++j) {
+        LF_TRY(dist_fused_phase(r, a, nsteps, 0, j, steps_per_model_step, sideflow_model_stride));
+        if (j + 1 < r->nphases) LF_TRY(lf_dist_fused_exchange(r, comm, j, a->split, rank_top, rank_bottom));
+    }
     return LF_OK;
 }
 

@@ -779,7 +779,10 @@ __device__ __forceinline__ void cone_compute(const fused_args &F, const cone_cel
 #else
 #define LF_TM_ATTR
 #endif
-template <bool SPLIT, bool ALL35>
+// DIST (row-block partition, a phase's levels): upstream cells are a consecutive local run (hist), or come from the list --
+// same-phase positions (hist) and slab slots (earlier phases, other ranks: the slabs hold every sub-step) --, and a cell
+// whose router outputs cross a phase or rank boundary also writes them to its slab slot, as k_fused_substeps_dist does.
+template <bool SPLIT, bool ALL35, bool DIST = false>
 __global__ void __launch_bounds__(kBlock) LF_TM_ATTR k_fused_level_steps(fused_args F, int k)
 {
     const lf_substep_args &A = F.S;
@@ -789,6 +792,31 @@ __global__ void __launch_bounds__(kBlock) LF_TM_ATTR k_fused_level_steps(fused_a
     const long long p = first + i, n = F.n;
     const int nsteps = F.nsteps;
     const int u0 = F.ups_ptr[p], u1 = F.ups_ptr[p + 1], kmax = F.kmax;
+    int base = u0;
+    long long slot = -1;
+    if (DIST) {
+        const int base_raw = F.d_ups_base[p]; // (a run of ghost slots is not a local run: see k_fused_substeps_dist)
+        base = (base_raw >= 0 && (long long)base_raw + (u1 - u0) <= n) ? base_raw : -1;
+        slot = F.d_out_slot[p];
+    }
+    auto ups_of = [&](const double *hist, const double *slab, int s) {
+        if (!DIST) return upstream_sum8(hist + (long long)s * n, u0, u1, kmax);
+        if (base >= 0) return upstream_sum8(hist + (long long)s * n, base, base + (u1 - u0), kmax);
+        double v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            double x = 0.0;
+            if (j < kmax && u0 + j < u1) {
+                const int e = F.d_ups_idx[u0 + j];
+                x = e >= 0 ? hist[(long long)s * n + e] : slab[(long long)(-(e + 1)) * F.root_ss + (long long)s * F.root_st];
+            }
+            v[j] = x;
+        }
+        double ups = 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ups += v[j];
+        return ups;
+    };
     const bool b35 = A.Beta == 0.6, s35 = F.solve35 != 0;
     const unsigned int dflags = derived_flags(F);
     const bool rc = (dflags & 1u) != 0u;
@@ -826,8 +854,8 @@ __global__ void __launch_bounds__(kBlock) LF_TM_ATTR k_fused_level_steps(fused_a
     double side_m3 = fused_side(F, s0)[p];
     sum = fused_sum(F, s0)[p];
     for (int s = s0; s < nsteps; ++s) {
-        const double ups1 = upstream_sum8(F.hist1 + (long long)s * n, u0, u1, kmax);
-        const double ups2 = SPLIT ? upstream_sum8(F.hist2 + (long long)s * n, u0, u1, kmax) : 0.0;
+        const double ups1 = ups_of(F.hist1, F.root1, s);
+        const double ups2 = SPLIT ? ups_of(F.hist2, F.root2, s) : 0.0;
         const bool first_of_step = s % F.msteps == 0;
         if ((F.side_stride != 0 || first_of_step) && s > s0) side_m3 = fused_side(F, s)[p];
         if (first_of_step && s > s0) sum = fused_sum(F, s)[p]; // the next model step's sum (zeroed by the caller)
@@ -891,6 +919,10 @@ __global__ void __launch_bounds__(kBlock) LF_TM_ATTR k_fused_level_steps(fused_a
         }
         F.hist1[(long long)s * n + p] = cut ? 0.0 : qr;
         if (SPLIT) F.hist2[(long long)s * n + p] = cut ? 0.0 : q2r;
+        if (DIST && slot >= 0) { // kept for the next phase / rank, as fused_cell does
+            F.root1[slot * F.root_ss + (long long)s * F.root_st] = qr;
+            if (SPLIT) F.root2[slot * F.root_ss + (long long)s * F.root_st] = q2r;
+        }
         // the state of the next sub-step
         m3 = v;
         qold = q;

@@ -689,6 +689,32 @@ class DistRoutingStep:
     def fused_phase(self, nsteps, phase):
         check(lib().lf_dist_fused_phase(self.router._h, C.byref(self.args), C.c_int(nsteps), C.c_int64(0), C.c_int(phase)))
 
+    # --- several model steps per call: the sub-steps of all of them as one wavefront per phase, one halo block per phase ----
+    def _model_step_args(self, sums, sideflows):
+        from .routing import _SubstepArgs
+        a = _SubstepArgs.from_buffer_copy(self.args)
+        a.sumDisDay = sums.ptr.value
+        stride = 0
+        if sideflows is not None:
+            a.SideflowChanM3 = sideflows.ptr.value
+            stride = self.N
+        return a, stride
+
+    def model_steps_fused(self, nsteps, nmodel, sums, sideflows=None):
+        """nmodel model steps of nsteps sub-steps in one call (lf_dist_routing_model_steps_fused).  sums: device array
+        [nmodel, N] (zeroed by the caller) that receives every model step's discharge sum; sideflows: device array
+        [nmodel, N] in the rank's engine order, or None for the resident vector in every model step."""
+        r = self.router
+        ch = r.comm._h if r.comm is not None else None
+        a, stride = self._model_step_args(sums, sideflows)
+        check(lib().lf_dist_routing_model_steps_fused(r._h, ch, C.byref(a), C.c_int(nsteps), C.c_int(nmodel), C.c_int64(stride),
+                                                      C.c_int(r.rank_top), C.c_int(r.rank_bottom)))
+
+    def fused_phase_model_steps(self, nsteps, nmodel, phase, sums, sideflows=None):
+        a, stride = self._model_step_args(sums, sideflows)
+        check(lib().lf_dist_fused_phase_model_steps(self.router._h, C.byref(a), C.c_int(nsteps), C.c_int(nmodel),
+                                                    C.c_int64(stride), C.c_int(phase)))
+
     def fused_halo_block(self, rnd, side):
         """(send offset, send count, recv offset, recv count) in doubles inside the slab of a section"""
         o = (C.c_int64 * 4)()
@@ -758,6 +784,38 @@ def loopback_substeps_fused(steps, nsteps):
                     assert sc == rc, (k, j, side, sc, rc)
                     check(lib().lf_memcpy_d2d(C.c_int(dev), C.c_void_p(slabs[k] + 8 * ro),
                                               C.c_void_p(slabs[src_rank] + 8 * so), C.c_size_t(8 * rc)))
+
+
+def _loopback_halo(steps, j):
+    """the slab blocks of halo round j between blocks that live on one GPU, as device-to-device copies"""
+    R = len(steps)
+    dev = steps[0].device
+    for section in range(2 if steps[0].split else 1):
+        blocks = [[s.fused_halo_block(j, side) for side in (0, 1)] for s in steps]
+        slabs = [s.fused_slab(section) for s in steps]
+        for k in range(R):
+            for side, src_rank, src_side in ((0, k - 1, 1), (1, k + 1, 0)):
+                _so, _sc, ro, rc = blocks[k][side]
+                if rc == 0:
+                    continue
+                so, sc, _ro, _rc = blocks[src_rank][src_side]
+                assert sc == rc, (k, j, side, sc, rc)
+                check(lib().lf_memcpy_d2d(C.c_int(dev), C.c_void_p(slabs[k] + 8 * ro),
+                                          C.c_void_p(slabs[src_rank] + 8 * so), C.c_size_t(8 * rc)))
+
+
+def loopback_model_steps_fused(steps, nsteps, nmodel, sums, sideflows=None):
+    """`nmodel` model steps of nsteps sub-steps over blocks that all live on one GPU, all of them in ONE pass over the
+    phases (lf_dist_fused_phase_model_steps per block and phase; the halo of a phase carries the slabs of every model
+    step).  sums[k] / sideflows[k]: block k's [nmodel, N_k] device arrays (sideflows None: the resident vector)."""
+    nph = steps[0].router.graph.num_phases
+    for s in steps:
+        s.fused_prepare(nsteps * nmodel)
+    for j in range(nph):
+        for k, s in enumerate(steps):
+            s.fused_phase_model_steps(nsteps, nmodel, j, sums[k], None if sideflows is None else sideflows[k])
+        if j + 1 < nph:
+            _loopback_halo(steps, j)
 
 
 def loopback_route_many(routers, q_states, lat_lists, late_halo=False, section="main_channel"):

@@ -176,3 +176,56 @@ def test_pipelined_router_calls_on_alternating_state_vectors(amd, family, seed, 
     for l in lats:
         for d in l:
             d.free()
+
+
+@pytest.mark.parametrize("family,seed,nblocks", [("deep", 2, 3), ("saddle", 6, 4), ("shallow", 1, 2)])
+def test_several_model_steps_per_call_on_row_blocks(amd, family, seed, nblocks):
+    """lf_dist_fused_phase_model_steps / lf_dist_routing_model_steps_fused: three model steps of 8 split-routing sub-steps,
+    each with its own sideflow vector, in ONE pass over the phases (every phase runs the sub-steps of all three as one
+    wavefront, its halo block carries the slabs of all three) against lf_routing_model_steps_fused on the whole raster --
+    which the single-domain tests hold bit-identical to model step after model step: every state vector and every model
+    step's discharge sum bit for bit."""
+    from lisflood_amd import dist as D
+    from lisflood_amd import synthetic as syn
+    from lisflood_amd._lib import DeviceArray
+    nsteps, M = 8, 3
+    H, W = 150, 130
+    N = H * W
+    codes, p, vals, dt = _case(family, H, W, seed)
+    kw, ref = _whole(codes, p, vals, dt, True, nsteps)
+    steps, nph = _blocks(codes, p, vals, dt, True, nsteps, nblocks)
+    sides = [syn.lateral_inflow(N, 60 + m) * p["dx"] * dt for m in range(M)]
+    want = ref.run_model_steps(nsteps, sides)
+    blocks = D.row_blocks(H, nblocks)
+    sums, sfl = [], []
+    for st, (r0, r1) in zip(steps, blocks):
+        sl = slice(r0 * W, r1 * W)
+        sums.append(DeviceArray((M, st.N)).zero())
+        sfl.append(DeviceArray.from_host(np.ascontiguousarray(np.stack([s[sl][st.perm] for s in sides]))))
+    D.loopback_model_steps_fused(steps, nsteps, M, sums, sfl)
+    from lisflood_amd.routing import _OUT, _STATE
+    for k in [x for x in _STATE + _OUT if x != "sumDisDay"]:
+        got = np.concatenate([st.download(k) for st in steps])
+        assert np.array_equal(got, ref.download(k), equal_nan=True), (family, k)
+    for m in range(M):
+        got = []
+        for st, sm in zip(steps, sums):
+            row = np.empty(st.N)
+            row[st.perm] = sm.download()[m]
+            got.append(row)
+        assert np.array_equal(np.concatenate(got), want[m]), (family, m)
+    # one block holding everything: the composite entry point (no communicator needed)
+    one, _ = _blocks(codes, p, vals, dt, True, nsteps, 1)
+    kw2, ref2 = _whole(codes, p, vals, dt, True, nsteps)
+    want2 = ref2.run_model_steps(nsteps, sides)
+    s1 = DeviceArray((M, N)).zero()
+    f1 = DeviceArray.from_host(np.ascontiguousarray(np.stack([s[one[0].perm] for s in sides])))
+    one[0].model_steps_fused(nsteps, M, s1, f1)
+    got = np.empty((M, N))
+    got[:, one[0].perm] = s1.download()
+    assert np.array_equal(got, want2)
+    for a in sums + sfl + [s1, f1]:
+        a.free()
+    for st in steps + one:
+        st.free()
+    ref.free(); ref2.free(); kw.close(); kw2.close()
