@@ -183,11 +183,39 @@ def row_block_model_step(a, T, rank, world, device, graph, comm, N, i0, i1, nste
     q = st.download("ChanQ")
     chk = T.allreduce(np.array([float(q.sum()), float(np.isfinite(q).all() and (q >= 0).all())]), "sum")
     launches = int(T.allreduce(int(router.last_launches()), "max"))
+    # several model steps per call: every phase runs the sub-steps of all of them as one wavefront, ONE halo block per phase
+    many = None
+    M = 4
+    sums = None
+    try:
+        sums = _lib.DeviceArray((M, max(st.N, 1)), device=device).zero()
+        st.fused_prepare(nsteps * M)                          # grows the slabs: the allocation that can fail
+    except Exception as e:
+        many = {"error": repr(e)}
+    if int(T.allreduce(0 if many else 1, "min")) == 0:      # all ranks take the same branch (RCCL calls must pair up)
+        many = many or {"error": "set-up failed on another rank"}
+    else:
+        st.model_steps_fused(nsteps, M, sums)                 # warm-up
+        _lib.synchronize(device)
+        T.barrier()
+        t0 = time.perf_counter()
+        st.model_steps_fused(nsteps, M, sums)
+        _lib.synchronize(device)
+        dt_m = time.perf_counter() - t0
+        T.barrier()
+        ms_m = float(T.allreduce(dt_m, "max")) * 1e3 / M
+        many = {"model_steps_per_call": M, "ms_per_model_step": round(ms_m, 3),
+                "value": round(2 * nsteps * N / ms_m / 1e3, 2), "unit": "Mcell-steps/s",
+                "max_launches_per_model_step": round(int(T.allreduce(int(router.last_launches()), "max")) / M, 1),
+                "halo_exchanges_per_model_step": round((graph.num_phases - 1) / M, 2)}
+    if sums is not None:
+        sums.free()
     st.free()
     router.close()
     return {"ms_per_model_step": round(ms, 3), "value": round(2 * nsteps * N / ms / 1e3, 2), "unit": "Mcell-steps/s",
             "max_launches_per_model_step": launches, "halo_exchanges_per_model_step": graph.num_phases - 1,
             "checksum_sumChanQ": float(chk[0]), "finite": bool(chk[1] == world),
+            "several_model_steps_per_call": many,
             "note": "lf_dist_routing_substeps_fused: per phase one wavefront over (level block, sub-step), slabs "
                     "[slot][sub-step] for what crosses a phase or rank boundary, one RCCL Send/Recv block per phase, "
                     "neighbour and section"}
