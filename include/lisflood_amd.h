@@ -97,6 +97,13 @@ int lf_compute_release(int device, int set);
 int lf_side_stream_begin(int device);
 int lf_side_stream_end(int device);
 int lf_side_stream_join(int device);
+/* Lanes: several streams of one device for work items that do not depend on one another -- the blocks of a row-block
+ * partition that live on ONE GPU are independent inside a phase (on real hardware each has its own GPU):
+ *     lf_lane_fork(); for k: { lf_lane_select(k + 1); <block k's calls> }  lf_lane_select(0); lf_lane_join();
+ * a lane first waits for what the main stream held at the fork; the join makes the main stream wait for every lane used. */
+int lf_lane_fork(int device);
+int lf_lane_select(int device, int lane);
+int lf_lane_join(int device);
 int lf_memcpy_d2h(int device, void *dst_host, const void *src_dev, size_t bytes);
 int lf_memcpy_d2d(int device, void *dst_dev, const void *src_dev, size_t bytes);
 int lf_memset(int device, void *dst_dev, int value, size_t bytes);

@@ -53,6 +53,14 @@ struct lf_device_ctx {
     hipStream_t side_stream = nullptr, main_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_side_done = nullptr;
     bool side_active = false, side_pending = false;
+    // lanes (lf_lane_*): streams for independent work items of one device (loopback blocks of the partition)
+    std::vector<hipStream_t> lanes;
+    std::vector<hipEvent_t> lane_done;
+    std::vector<bool> lane_used;
+    hipEvent_t lane_fork = nullptr;
+    hipStream_t lane_main = nullptr;
+    int lane_current = 0;
+    bool lane_forked = false;
 };
 int lf_ctx(int device, lf_device_ctx **out); // makes `device` current, creates the context on first use
 

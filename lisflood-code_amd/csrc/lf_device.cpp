@@ -1,4 +1,5 @@
 // lf_device.cpp -- error reporting, per-device context (stream + stopwatch), memory plumbing.
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -244,6 +245,69 @@ int lf_compute_release(int device, int set)
     LF_TRY(upload_ctx(device, set, &c));
     LF_HIP(hipEventRecord(c->consumed[set], c->stream));
     c->consumed_valid[set] = true;
+    return LF_OK;
+}
+
+// ---- lanes: several streams of one device, for work items that do not depend on one another ------------------------------
+// The blocks of a row-block partition that live on ONE GPU (the loopback form of the multi-GPU path) are independent inside a
+// phase -- on real hardware every block has its own GPU.  lf_lane_select(i > 0) sends the library calls that follow to lane
+// stream i (created on first use), which first waits for everything the main stream held at the last lf_lane_fork();
+// lf_lane_select(0) returns to the main stream; lf_lane_join() makes the main stream wait for all lanes used since the fork.
+//     lf_lane_fork(); for k: lf_lane_select(k + 1); <block k's kernels>;   lf_lane_select(0); lf_lane_join();
+int lf_lane_fork(int device)
+{
+    lf_device_ctx *c;
+    LF_TRY(lf_ctx(device, &c));
+    if (c->side_active || c->lane_current != 0) return lf_set_error(LF_E_INVALID, "lf_lane_fork inside a side section or a lane");
+    if (!c->lane_fork) LF_HIP(hipEventCreateWithFlags(&c->lane_fork, hipEventDisableTiming));
+    LF_HIP(hipEventRecord(c->lane_fork, c->stream));
+    c->lane_main = c->stream;
+    std::fill(c->lane_used.begin(), c->lane_used.end(), false);
+    c->lane_forked = true;
+    return LF_OK;
+}
+
+int lf_lane_select(int device, int lane)
+{
+    lf_device_ctx *c;
+    LF_TRY(lf_ctx(device, &c));
+    if (lane < 0 || lane > 64) return lf_set_error(LF_E_INVALID, "lane out of range");
+    if (!c->lane_forked) return lf_set_error(LF_E_INVALID, "lf_lane_fork first");
+    if (lane == 0) {
+        c->stream = c->lane_main;
+        c->lane_current = 0;
+        return LF_OK;
+    }
+    if ((int)c->lanes.size() < lane) {
+        c->lanes.resize(lane, nullptr);
+        c->lane_done.resize(lane, nullptr);
+        c->lane_used.resize(lane, false);
+    }
+    if (!c->lanes[lane - 1]) {
+        LF_HIP(hipStreamCreateWithFlags(&c->lanes[lane - 1], hipStreamNonBlocking));
+        LF_HIP(hipEventCreateWithFlags(&c->lane_done[lane - 1], hipEventDisableTiming));
+    }
+    if (!c->lane_used[lane - 1]) { // first use since the fork: behind everything the main stream held at the fork
+        LF_HIP(hipStreamWaitEvent(c->lanes[lane - 1], c->lane_fork, 0));
+        c->lane_used[lane - 1] = true;
+    }
+    c->stream = c->lanes[lane - 1];
+    c->lane_current = lane;
+    return LF_OK;
+}
+
+int lf_lane_join(int device)
+{
+    lf_device_ctx *c;
+    LF_TRY(lf_ctx(device, &c));
+    if (!c->lane_forked || c->lane_current != 0) return lf_set_error(LF_E_INVALID, "lf_lane_join: select lane 0 first");
+    for (size_t i = 0; i < c->lanes.size(); ++i)
+        if (c->lane_used[i]) {
+            LF_HIP(hipEventRecord(c->lane_done[i], c->lanes[i]));
+            LF_HIP(hipStreamWaitEvent(c->stream, c->lane_done[i], 0));
+            c->lane_used[i] = false;
+        }
+    c->lane_forked = false;
     return LF_OK;
 }
 

@@ -757,33 +757,30 @@ def loopback_substep(steps):
             s.stage(2)
 
 
-def loopback_substeps_fused(steps, nsteps):
+def loopback_substeps_fused(steps, nsteps, lanes=False):
     """A whole model step (nsteps sub-steps) over blocks that all live on one GPU: lf_dist_fused_phase per block and phase,
     the per-phase halo of the slabs as device-to-device copies -- the kernels and the plan of
-    lf_dist_routing_substeps_fused, only the transport differs."""
-    R = len(steps)
+    lf_dist_routing_substeps_fused, only the transport differs.  lanes: the blocks of a phase on separate streams (see
+    loopback_model_steps_fused)."""
     dev = steps[0].device
     nph = steps[0].router.graph.num_phases
+    L = lib()
     for s in steps:
         s.fused_prepare(nsteps)
     for j in range(nph):
-        for s in steps:
-            s.fused_phase(nsteps, j)
-        if j + 1 == nph:
-            break
-        for section in range(2 if steps[0].split else 1):
-            blocks = [[s.fused_halo_block(j, side) for side in (0, 1)] for s in steps]
-            slabs = [s.fused_slab(section) for s in steps]
-            for k in range(R):
-                # side 0: from the rank above (its bottom exports); side 1: from the rank below (its top exports)
-                for side, src_rank, src_side in ((0, k - 1, 1), (1, k + 1, 0)):
-                    _so, _sc, ro, rc = blocks[k][side]
-                    if rc == 0:
-                        continue
-                    so, sc, _ro, _rc = blocks[src_rank][src_side]
-                    assert sc == rc, (k, j, side, sc, rc)
-                    check(lib().lf_memcpy_d2d(C.c_int(dev), C.c_void_p(slabs[k] + 8 * ro),
-                                              C.c_void_p(slabs[src_rank] + 8 * so), C.c_size_t(8 * rc)))
+        if lanes:
+            check(L.lf_lane_fork(C.c_int(dev)))
+        try:
+            for k, s in enumerate(steps):
+                if lanes:
+                    check(L.lf_lane_select(C.c_int(dev), C.c_int(k + 1)))
+                s.fused_phase(nsteps, j)
+        finally:
+            if lanes:
+                check(L.lf_lane_select(C.c_int(dev), C.c_int(0)))
+                check(L.lf_lane_join(C.c_int(dev)))
+        if j + 1 < nph:
+            _loopback_halo(steps, j)
 
 
 def _loopback_halo(steps, j):
@@ -804,16 +801,29 @@ def _loopback_halo(steps, j):
                                           C.c_void_p(slabs[src_rank] + 8 * so), C.c_size_t(8 * rc)))
 
 
-def loopback_model_steps_fused(steps, nsteps, nmodel, sums, sideflows=None):
+def loopback_model_steps_fused(steps, nsteps, nmodel, sums, sideflows=None, lanes=True):
     """`nmodel` model steps of nsteps sub-steps over blocks that all live on one GPU, all of them in ONE pass over the
     phases (lf_dist_fused_phase_model_steps per block and phase; the halo of a phase carries the slabs of every model
-    step).  sums[k] / sideflows[k]: block k's [nmodel, N_k] device arrays (sideflows None: the resident vector)."""
+    step).  sums[k] / sideflows[k]: block k's [nmodel, N_k] device arrays (sideflows None: the resident vector).
+    lanes: the blocks of a phase on separate streams (lf_lane_*): inside a phase they are independent -- each has its own GPU
+    on real hardware --, so their launch chains overlap instead of queueing behind one another."""
     nph = steps[0].router.graph.num_phases
+    dev = steps[0].device
+    L = lib()
     for s in steps:
         s.fused_prepare(nsteps * nmodel)
     for j in range(nph):
-        for k, s in enumerate(steps):
-            s.fused_phase_model_steps(nsteps, nmodel, j, sums[k], None if sideflows is None else sideflows[k])
+        if lanes:
+            check(L.lf_lane_fork(C.c_int(dev)))
+        try:
+            for k, s in enumerate(steps):
+                if lanes:
+                    check(L.lf_lane_select(C.c_int(dev), C.c_int(k + 1)))
+                s.fused_phase_model_steps(nsteps, nmodel, j, sums[k], None if sideflows is None else sideflows[k])
+        finally:
+            if lanes:
+                check(L.lf_lane_select(C.c_int(dev), C.c_int(0)))
+                check(L.lf_lane_join(C.c_int(dev)))
         if j + 1 < nph:
             _loopback_halo(steps, j)
 

@@ -72,7 +72,7 @@ def test_fused_model_step_on_row_blocks_small(amd, family, seed, nblocks, split)
     steps, nph = _blocks(codes, p, vals, dt, split, nsteps, nblocks)
     for rep in range(2):
         ref.run_fused(nsteps)
-        D.loopback_substeps_fused(steps, nsteps)
+        D.loopback_substeps_fused(steps, nsteps, lanes=(rep == 1))      # (second model step: the blocks of a phase on lanes)
         _same(steps, ref, split, (family, rep))
     assert nph >= 2
     # one block holding everything: the composite entry point, no communicator needed

@@ -33,8 +33,14 @@ for family, seed in (("deep", 2), ("shallow", 1)):
         D.loopback_substeps_fused(steps, nsteps)
     _lib.synchronize()
     one = (time.perf_counter() - t0) * 1e3 / 2
+    D.loopback_substeps_fused(steps, nsteps, lanes=True); _lib.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(2):
+        D.loopback_substeps_fused(steps, nsteps, lanes=True)
+    _lib.synchronize()
+    one_l = (time.perf_counter() - t0) * 1e3 / 2
     out = {"family": family, "size": size, "blocks": nblocks, "phases": nph, "single_domain_ms": round(single, 2),
-           "partition_step_by_step_ms": round(one, 2)}
+           "partition_step_by_step_ms": round(one, 2), "partition_step_by_step_blocks_on_lanes_ms": round(one_l, 2)}
     for M in (2, 4, 5):
         sums = [DeviceArray((M, st.N)).zero() for st in steps]
         D.loopback_model_steps_fused(steps, nsteps, M, sums); _lib.synchronize()
@@ -42,6 +48,12 @@ for family, seed in (("deep", 2), ("shallow", 1)):
         D.loopback_model_steps_fused(steps, nsteps, M, sums)
         _lib.synchronize()
         out["partition_%d_model_steps_per_call_ms_per_step" % M] = round((time.perf_counter() - t0) * 1e3 / M, 2)
+        D.loopback_model_steps_fused(steps, nsteps, M, sums, lanes=False); _lib.synchronize()
+        t0 = time.perf_counter()
+        D.loopback_model_steps_fused(steps, nsteps, M, sums, lanes=False)
+        _lib.synchronize()
+        out["the_same_on_one_stream"] = out.get("the_same_on_one_stream", {})
+        out["the_same_on_one_stream"][M] = round((time.perf_counter() - t0) * 1e3 / M, 2)
         for a in sums:
             a.free()
     print(out, flush=True)
