@@ -1,7 +1,7 @@
 """Worker of tests/test_dist_multirank_gpu.py: one process per rank, a model step of NoRoutSteps split-routing sub-steps on
 the rank's row block (lf_dist_routing_substeps_fused: one halo block per phase, neighbour and section through the
-communicator), twice; rank 0 runs the same model steps on the whole raster (lf_routing_substeps_fused) and compares
-bit for bit."""
+communicator), twice, then three more model steps in ONE call (lf_dist_routing_model_steps_fused); rank 0 runs the same
+model steps on the whole raster (lf_routing_substeps_fused, lf_routing_model_steps_fused) and compares bit for bit."""
 import os
 import sys
 
@@ -46,6 +46,16 @@ def main():
         st.substeps_fused(nsteps)
         _lib.synchronize(device)
         outs.append([st.download(k) for k in names])          # (the transport carries lists, not dicts)
+    # several model steps per call (lf_dist_routing_model_steps_fused): the halo block of a phase carries the slabs of all of
+    # them; the resident sideflow vector in every model step, the per-model-step discharge sums in [M, N]
+    M = int(os.environ.get("LF_TEST_MODEL_STEPS", "3"))
+    sums = _lib.DeviceArray((M, max(st.N, 1)), device=device).zero()
+    st.model_steps_fused(nsteps, M, sums)
+    _lib.synchronize(device)
+    per_step = np.empty((M, st.N))
+    per_step[:, st.perm] = sums.download()[:, :st.N]
+    outs.append([st.download(k) for k in names] + [per_step])
+    sums.free()
     gathered = T.allgather(outs)
     if rank == 0:
         from lisflood_amd.kinematic_wave_parallel import Graph, kinematicWave
@@ -58,6 +68,14 @@ def main():
             for i, k in enumerate(names):
                 got = np.concatenate([gathered[r][rep][i] for r in range(world)])
                 assert np.array_equal(got, ref.download(k), equal_nan=True), (family, rep, k)
+        want = ref.run_model_steps(nsteps, nmodel=M)
+        for i, k in enumerate(names):
+            if k == "sumDisDay":
+                continue
+            got = np.concatenate([gathered[r][2][i] for r in range(world)])
+            assert np.array_equal(got, ref.download(k), equal_nan=True), (family, "model steps", k)
+        got = np.concatenate([gathered[r][2][len(names)] for r in range(world)], axis=1)
+        assert np.array_equal(got, want), (family, "model step sums")
         ref.free()
         kw.close()
         print("DIST_FUSED_OK phases=%d ranks=%d" % (g.num_phases, world))
