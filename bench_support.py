@@ -55,6 +55,17 @@ class RoutingStepDevice:
     def run_fused(self, nsteps):
         check(lib().lf_routing_substeps_fused(self.router._h, C.byref(self.args), C.c_int(nsteps), C.c_int64(0)))
 
+    def run_fused_sideflow_per_substep(self, sideflows):
+        """one model step whose sub-steps each have their own sideflow vector (sideflow_stride = N): sideflows = list of
+        pixel-order vectors, one per sub-step"""
+        N = self.N
+        side = DeviceArray.from_host(f64(np.stack([np.broadcast_to(x, (N,))[self.perm] for x in sideflows])), self.device)
+        a = _SubstepArgs.from_buffer_copy(self.args)
+        a.SideflowChanM3 = side.ptr.value
+        check(lib().lf_routing_substeps_fused(self.router._h, C.byref(a), C.c_int(len(sideflows)), C.c_int64(N)))
+        check(lib().lf_device_synchronize(C.c_int(self.device)))
+        side.free()
+
     def run_model_steps_resident(self, nsteps, nmodel, sums):
         """timing form of run_model_steps: the resident sideflow vector for every model step, the sums into the
         caller's [nmodel, N] device array (not zeroed, not downloaded)"""

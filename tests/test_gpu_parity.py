@@ -564,6 +564,37 @@ def test_structures_inside_the_fused_wavefront(amd, solver):
 
 
 @pytest.mark.parametrize("family,time_major", [("deep", "0"), ("shallow", "0"), ("shallow", "1")])
+def test_fused_wavefront_with_a_sideflow_vector_per_substep(amd, monkeypatch, family, time_major):
+    """lf_routing_substeps_fused(sideflow_stride = N): every sub-step of the model step reads its own sideflow vector,
+    against the sub-steps one by one with that vector uploaded before each -- bit for bit (cones, level kernel, time-major)."""
+    from lisflood_amd import synthetic as syn
+    from lisflood_amd.kinematic_wave_parallel import kinematicWave
+    from lisflood_amd.routing import _STATE, _OUT
+    from bench_support import RoutingStepDevice
+    monkeypatch.setenv("LF_FUSED_TIME_MAJOR", time_major)
+    H, W = (200, 240) if family == "deep" else (500, 600)
+    N = H * W
+    nsteps = 9
+    codes = syn.make_ldd(family, H, W, 4)
+    mask = np.ones((H, W), bool)
+    p = syn.router_params(N, seed=22)
+    vals, dt = syn.model_step_values(N, p)
+    kw = kinematicWave(codes[mask].astype(np.float64), mask, p["alpha"], p["beta"], p["dx"], dt,
+                       alpha_floodplains=vals["ChannelAlpha2"])
+    sides = [syn.lateral_inflow(N, 70 + s) * p["dx"] * dt for s in range(nsteps)]
+    a = RoutingStepDevice(kw, dict(vals, SideflowChanM3=sides[0]), True, p["beta"], 1.0 / dt, dt * nsteps)
+    b = RoutingStepDevice(kw, dict(vals, SideflowChanM3=sides[0]), True, p["beta"], 1.0 / dt, dt * nsteps)
+    for s in range(nsteps):
+        a.dev["SideflowChanM3"].upload(np.ascontiguousarray(sides[s][a.perm]))
+        a.run_sequential(1)
+    b.run_fused_sideflow_per_substep(sides)
+    # (the fused call keeps ChanQ / Sideflow1Chan / CrossSection2Area of the last sub-step only -- what the sequence leaves)
+    for k in _STATE + [x for x in _OUT if x not in ("scratch0", "scratch1")]:
+        assert np.array_equal(a.download(k), b.download(k), equal_nan=True), (family, k)
+    a.free(); b.free(); kw.close()
+
+
+@pytest.mark.parametrize("family,time_major", [("deep", "0"), ("shallow", "0"), ("shallow", "1")])
 def test_several_model_steps_in_one_wavefront(amd, monkeypatch, family, time_major):
     """lf_routing_model_steps_fused: four model steps of 24 split-routing sub-steps, each with its own sideflow vector, as
     ONE wavefront (the skew runs on across the model-step boundaries) against four calls of the one-model-step wavefront
