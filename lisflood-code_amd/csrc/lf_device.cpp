@@ -108,8 +108,17 @@ int lf_device_alloc(int device, size_t bytes, void **ptr_dev)
 
 int lf_device_free(int device, void *ptr_dev)
 {
-    LF_TRY(lf_ctx(device, nullptr));
+    lf_device_ctx *c = nullptr;
+    LF_TRY(lf_ctx(device, &c));
     if (!ptr_dev) return LF_OK;
+    if (c) { // the fp32 staging buffer of lf_upload_copy_f32 for this vector goes with it
+        auto st = c->f32_stage.find(ptr_dev);
+        if (st != c->f32_stage.end()) {
+            if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+            if (st->second.first) (void)hipFree(st->second.first);
+            c->f32_stage.erase(st);
+        }
+    }
     void *base = ptr_dev;
     {
         std::lock_guard<std::mutex> lock(g_ctx_mutex);
