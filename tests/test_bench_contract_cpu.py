@@ -97,3 +97,15 @@ def test_committed_force_dist_line_round5_ran_on_the_real_rccl():
     assert d["rccl_library"].startswith("/opt/rocm") and d["finite"]
     assert d["model_step_24_substeps_split_row_blocks"]["finite"] and d["catchment_partition"]["finite"]
     assert d["row_block_vs_catchment_partition_sumQ_rel_diff"] < 1e-12
+
+
+def test_compact_line_is_a_function_of_the_sidecar():
+    """bench.compact_line(detail) reproduces the committed stdout line from the committed sidecar: nothing in the line that
+    is not in the detail file, nothing hand-edited"""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_detail.json")))
+    line = json.loads(open(os.path.join(ROOT, "profiles", "r05_bench_line.json")).read().strip())
+    again = bench.compact_line(full, line["detail"])
+    assert json.loads(json.dumps(again)) == line

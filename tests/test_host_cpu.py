@@ -467,3 +467,38 @@ def test_cones_of_a_launch_are_dealt_out_xcd_contiguously(n):
             assert mine.size == 0 or np.array_equal(mine, np.arange(mine[0], mine[0] + mine.size)), (n, first, c)
             # ... in launch order: a workgroup's successor on the same XCD takes the next cone
             assert np.array_equal(order[xcd == c], mine), (n, first, c)
+
+
+def test_derived_soil_parameters_check_is_exact():
+    """soilloop.derived_parameters_hold: True exactly when the ten derived parameter arrays are what soil.py:180-228 makes of
+    the others, bit for bit (then the device recomputes them instead of reading them)"""
+    from lisflood_amd.soilloop import derived_parameters_hold
+    d = syn.soil_params(257, seed=5)
+    assert derived_parameters_hold(d)
+    for name, bump in (("WS1", lambda a: a * (1 + 2e-16)), ("GenuInvM2", lambda a: np.nextafter(a, np.inf)),
+                       ("WWP1", lambda a: a + 1e-13), ("PoreSpaceNotZero1b", lambda a: ~a)):
+        e = dict(d)
+        e[name] = bump(np.array(d[name], copy=True))
+        assert not derived_parameters_hold(e), name
+    e = dict(d)
+    del e["WFC1"]
+    assert not derived_parameters_hold(e)
+
+
+def test_hotpath_scenario_drawn_for_a_block_and_repeated():
+    """synthetic.hotpath_scenario(block=...): per-pixel fields drawn for `block` pixels and repeated, the LDD and the channel
+    mask at full size; without `block` nothing changes (the fixtures and GPU tests rely on that)"""
+    H, W = 30, 40
+    N = H * W
+    full, sc, mask, l2c, lk = syn.hotpath_scenario(H, W)
+    tiled, sc2, mask2, l2c2, lk2 = syn.hotpath_scenario(H, W, block=500)
+    assert sc == sc2 and np.array_equal(l2c, l2c2) and np.array_equal(lk, lk2) and np.array_equal(mask, mask2)
+    assert np.array_equal(full["IsChannel"], tiled["IsChannel"])
+    for k, a in tiled.items():
+        assert a.shape[-1] == N and a.flags.c_contiguous, k
+    assert np.array_equal(tiled["KSat1a"][:, :500], tiled["KSat1a"][:, 500:1000])          # repeated block
+    chan = tiled["IsChannel"]
+    assert (tiled["ChanQKin"][~chan] == 0).all() and (tiled["ChannelAlpha"][~chan] == 1).all()
+    assert np.allclose(tiled["InvChannelAlpha2"], 1 / tiled["ChannelAlpha2"])
+    river = syn.hotpath_scenario(H, W, family="river", block=500)[3]
+    assert river.shape == (N,) and not np.array_equal(river, l2c)
