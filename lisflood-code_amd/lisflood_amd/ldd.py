@@ -156,9 +156,9 @@ def downstruct(codes, land_mask):
     return out
 
 
-def catchment(codes, land_mask, points):
-    """PCRaster catchment(ldd, points): every cell gets the id of the first non-zero point met going downstream
-    (a point cell belongs to its own catchment); 0 if none (routing.py:168-171)."""
+def subcatchment(codes, land_mask, points):
+    """PCRaster subcatchment(ldd, points): every cell gets the id of the FIRST non-zero point met going downstream
+    (a point cell belongs to its own sub-catchment); 0 if none."""
     g = Graph(np.asarray(codes, np.float64), land_mask)
     down = g.lookups()[0].astype(np.int64)
     po, ss = g.orders()
@@ -172,13 +172,31 @@ def catchment(codes, land_mask, points):
     return lab
 
 
+def _enclosing_points(points, first_hit, down):
+    """the points that have no other point strictly downstream of them: the only ones PCRaster's catchment() labels with
+    (`first_hit` = subcatchment labels of `points`)"""
+    pts = np.asarray(points).astype(np.int64)
+    below = np.where(down >= 0, first_hit[np.maximum(down, 0)], 0)
+    return np.where(below == 0, pts, 0)
+
+
+def catchment(codes, land_mask, points):
+    """PCRaster catchment(ldd, points): every cell upstream of a non-zero point (the point included) gets the point's
+    id, 0 if no point lies downstream; sub-catchments are NOT identified -- where one point lies in the catchment of
+    another, the enclosing (most downstream) point wins (routing.py:168-171, whose outflow points are never nested:
+    each sits next to a pit).  = subcatchment() over the points that have no point downstream of them."""
+    down = downstream_index(codes, land_mask)
+    first = subcatchment(codes, land_mask, points)
+    return subcatchment(codes, land_mask, _enclosing_points(points, first, down))
+
+
 def cut_at_structures(codes, land_mask, is_structure):
     """structures.initial (structures.py:44-61): the cells just upstream of a lake / reservoir become pits of the
     kinematic LDD (their outflow reaches the structure through its own inflow term instead).  Returns
     (cut codes, IsUpsOfStructureKinematicC)."""
     down = downstream_index(codes, land_mask)
     st = np.asarray(is_structure, bool)
-    ups = (down >= 0) & st[np.maximum(down, 0)]          # downstream(LddKinematic, IsStructureKinematic)
+    ups = np.where(down >= 0, st[np.maximum(down, 0)], st)   # downstream(LddKinematic, IsStructureKinematic): a pit reads itself
     out = np.asarray(codes).copy()
     out[ups] = PIT
     return lddrepair(out, land_mask), ups
@@ -263,13 +281,25 @@ class LddDevice:
             check(lib().lf_downstream_host(self.kw._h, ptr(x), ptr(out)))
         return out
 
-    def catchment(self, points):
+    def subcatchment(self, points):
+        """PCRaster subcatchment: the first non-zero point met going downstream (pointer jumping, lf_catchments)"""
         from ._lib import check, lib, ptr
         pts = np.ascontiguousarray(np.broadcast_to(points, (self.N,)), dtype=np.int64)
         out = np.empty(self.N, np.int64)
         if self.N:
             check(lib().lf_catchments(self.kw._h, ptr(pts), ptr(out)))
         return out
+
+    def catchment(self, points):
+        """PCRaster catchment: the most downstream point wins (see catchment() above) -- two labelling passes and one
+        downstream() on the device"""
+        pts = np.ascontiguousarray(np.broadcast_to(points, (self.N,)), dtype=np.int64)
+        first = self.subcatchment(pts)
+        if self.N == 0:
+            return first
+        at_pit = self.kw.graph.lookups()[0] < 0
+        below = np.where(at_pit, 0, self.downstream(first.astype(np.float64)).astype(np.int64))
+        return self.subcatchment(np.where(below == 0, pts, 0))
 
     def catchment_totals(self, w):
         """np.take(np.bincount(Catchments, weights=w), Catchments) for Catchments = catchment(ldd, pit(ldd))"""

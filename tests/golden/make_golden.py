@@ -16,6 +16,7 @@ Fixtures:
   soil_columns.npz      a16    soilColumnsWaterBalance, 3 consecutive steps (soilloop.py:78-355)
   canopy_soil_step.npz  a17/18 soilloop.dynamic_canopy + dynamic_soil  (soilloop.py:519-704)
   upstream_sum.npz      a20    np.bincount one-hop upstream sum        (lakes.py:215, routing.py:159-164)
+  ldd_ops.npz           a21    PCRaster LDD operations, naive stand-in (routing.py:90-171, structures.py:51-59)
 """
 import os
 import sys
@@ -36,6 +37,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 sys.path.insert(0, os.path.join(ROOT, "lisflood-code_amd"))
+sys.path.insert(0, HERE)
 
 import ref_bootstrap as rb  # noqa: E402
 from lisflood_amd import synthetic as syn  # noqa: E402
@@ -1004,18 +1006,20 @@ def gen_soil_pf():
 # initialisation of the channel part on the REAL inputs of cold.xml: routing.initial -> lakes.initial ->
 # reservoir.initial -> structures.initial -> routing.initialSecond (Lisflood_initial.py:184-226 order), every one the
 # reference's own method.  PCRaster is not installed: its operations are emulated on compressed vectors (class PcrEmu
-# below -- lddmask / lddrepair / downstream / catchment / accuflux through the host graph helpers of lisflood_amd.ldd,
-# lookupscalar by reading the use case's tables); what this fixture pins is therefore everything BUT those LDD
-# operations: the order of the steps, -9999 cold-start handling, channel geometry and alpha, the split-routing start
-# values, lake / reservoir parameter derivation, the cut LDD, the mass-balance start values.
+# below -- lddmask / lddrepair / downstream / upstream / catchment / accuflux / pit / uniqueid by the naive cell-by-cell
+# walks of tests/golden/pcr_naive.py, which restate the PCRaster manual and import numpy only; lookupscalar by reading
+# the use case's tables).  The fixture pins the order of the steps, -9999 cold-start handling, channel geometry and
+# alpha, the split-routing start values, lake / reservoir parameter derivation, the cut LDD, the mass-balance start
+# values -- and, because the stand-in shares no code with the product, the product's LDD operations too.
 # ------------------------------------------------------------------------------------------------
 class PcrEmu:
     """PCRaster operations on compressed vectors over a fixed land mask (missing value: 0 for ldd / nominal / boolean maps,
-    NaN for scalar maps)."""
+    NaN for scalar maps).  The LDD operations are tests/golden/pcr_naive.py: cell-by-cell walks restated from the PCRaster
+    manual, numpy only -- nothing of the product (lisflood_amd) or of oracle/ is involved in making these fixtures."""
 
     def __init__(self, mask, maps, tables):
-        from lisflood_amd import ldd as L
-        self.L, self.mask, self.N = L, mask, int(mask.sum())
+        from pcr_naive import NaivePcr
+        self.P, self.mask, self.N = NaivePcr(mask), mask, int(mask.sum())
         self.maps, self.tables = maps, tables
 
     def loadmap(self, name, pcr=False, lddflag=False, **kw):
@@ -1023,75 +1027,28 @@ class PcrEmu:
         return v.copy() if isinstance(v, np.ndarray) else v
 
     def lddmask(self, ldd, keep):
-        keep = np.asarray(keep).astype(bool)
-        codes, _ = self.L.lddmask(np.asarray(ldd, float), self.mask, keep)
-        out = np.zeros(self.N)
-        out[keep] = codes
-        return out
+        return self.P.lddmask(ldd, keep)
 
     def lddrepair(self, ldd):
-        ldd = np.asarray(ldd, float)
-        defined = (ldd >= 1) & (ldd <= 9)
-        sub = np.zeros(self.mask.shape, bool); sub[self.mask] = defined
-        out = np.zeros(self.N)
-        out[defined] = self.L.lddrepair(ldd[defined], sub)
-        return out
-
-    def _down(self, ldd):
-        ldd = np.asarray(ldd, float)
-        defined = (ldd >= 1) & (ldd <= 9)
-        sub = np.zeros(self.mask.shape, bool); sub[self.mask] = defined
-        d = self.L.downstream_index(ldd[defined], sub)
-        ids = np.nonzero(defined)[0]
-        down = np.full(self.N, -1, np.int64)
-        down[defined] = np.where(d >= 0, ids[np.maximum(d, 0)], -1)
-        return down, defined
+        return self.P.lddrepair(ldd)
 
     def downstream(self, ldd, x):
-        down, _ = self._down(ldd)
-        x = np.asarray(x)
-        return np.where(down >= 0, x[np.maximum(down, 0)], x)
+        return self.P.downstream(ldd, x)
 
     def upstream(self, ldd, x):
-        down, _ = self._down(ldd)
-        return np.bincount(np.where(down >= 0, down, self.N), weights=np.asarray(x, float), minlength=self.N + 1)[:self.N]
+        return self.P.upstream(ldd, x)
 
     def accuflux(self, ldd, x):
-        down, defined = self._down(ldd)
-        acc = np.array(np.broadcast_to(np.asarray(x, float), (self.N,)))
-        order = self._topo(down)
-        for p in order:
-            if down[p] >= 0:
-                acc[down[p]] += acc[p]
-        return acc
-
-    def _topo(self, down):
-        nups = np.bincount(down[down >= 0], minlength=self.N)
-        stack = list(np.nonzero(nups == 0)[0])
-        out = []
-        while stack:
-            p = stack.pop()
-            out.append(p)
-            d = down[p]
-            if d >= 0:
-                nups[d] -= 1
-                if nups[d] == 0:
-                    stack.append(d)
-        return out
+        return self.P.accuflux(ldd, x)
 
     def catchment(self, ldd, points):
-        down, defined = self._down(ldd)
-        pts = np.asarray(points).astype(np.int64)
-        lab = np.zeros(self.N, np.int64)
-        for p in reversed(self._topo(down)):          # outlets first
-            lab[p] = pts[p] if pts[p] != 0 else (lab[down[p]] if down[p] >= 0 else 0)
-        return lab
+        return self.P.catchment(ldd, points)
 
     def pit(self, ldd):
-        return self.L.pit(np.asarray(ldd))
+        return self.P.pit(ldd)
 
     def uniqueid(self, b):
-        return self.L.uniqueid(np.asarray(b).astype(bool))
+        return self.P.uniqueid(b)
 
     def lookupscalar(self, table, ids):
         t = self.tables[os.path.splitext(os.path.basename(str(table)))[0]]
@@ -1270,11 +1227,77 @@ def gen_prerun():
     S.options.clear()
 
 
+def gen_ldd_ops():
+    """a21: inputs and results of every PCRaster LDD operation the reference's initialisation calls (routing.py:90-171,
+    387; structures.py:51-59; lakes.py:90), computed by the naive stand-in of pcr_naive.py (numpy only; shares no code
+    with the product).  Two rasters: LF_ETRS89's real LDD on its land cells with the real channel map, and a seeded
+    48 x 56 raster with a ragged mask, MV holes, non-keypad codes (0, 77, 2.5, NaN) and cells that point off the grid or
+    into the holes.  Per raster, in the order routing.initial / structures.initial use them:
+        lddmask(ldd, domain)  lddmask(Ldd, IsChannel)  lddrepair(ifthenelse(IsChannel, 5, Ldd))  pit(Ldd)
+        downstream(Ldd, AtOutflow)  uniqueid(AtLastPoint)  catchment(Ldd, OutflowPoints)  catchment(Ldd, pit(Ldd))
+        downstream(LddKinematic, pixel ids)  upstream(LddKinematic, w)  accuflux(Ldd, w)
+        downstream(LddKinematic, IsStructure)  lddrepair(ifthenelse(IsUpsOfStructure, 5, LddKinematic))"""
+    from pcr_naive import NaivePcr
+    z, ldd_e, land_e = etrs89()
+    cases = {}
+    # (the use case's channel map is 1 on every land cell: a channel network of the cells draining >= 1e8 m2 instead)
+    cases["etrs89"] = (ldd_e[land_e].astype(np.float64), land_e, z["mask_map"][land_e], z["uparea"][land_e] >= 1.0e8,
+                       (z["res"][land_e] > 0) | (z["lakes"][land_e] > 0))
+    codes, mask = syn_case("syn48_masked")
+    rng = np.random.default_rng(2106)
+    c = codes[mask].astype(np.float64)
+    n = c.size
+    bad = rng.choice(n, 24, replace=False)
+    c[bad[:6]] = 0.0
+    c[bad[6:12]] = 77.0
+    c[bad[12:18]] = 2.5
+    c[bad[18:]] = np.nan
+    cases["syn48_holes"] = (c, mask, rng.random(n) < 0.7, rng.random(n) < 0.35, rng.random(n) < 0.02)
+    out = {}
+    for name, (c, land, domain, chan, struct) in cases.items():
+        P = NaivePcr(land)
+        N = P.N
+        w = np.random.default_rng(5).uniform(0.0, 3.0, N)
+        r = dict(codes=c, land_mask=land, domain=domain, is_channel=chan, is_structure=struct, w=w)
+        r["lddmask_domain"] = P.lddmask(c, domain)                                  # routing.py:90
+        Ldd = P.lddrepair(c)                                                        # a sound Ldd over the whole land mask
+        r["Ldd"] = Ldd
+        defined = Ldd != 0
+        r["LddChan"] = P.lddmask(Ldd, chan)                                         # routing.py:118
+        r["LddToChan"] = P.lddrepair(np.where(chan, 5, Ldd))                        # routing.py:125
+        r["pit"] = P.pit(Ldd)                                                       # routing.py:127
+        at_out = r["pit"] != 0
+        r["downstream_AtOutflow"] = P.downstream(Ldd, at_out.astype(np.float64))    # routing.py:141
+        last = (r["downstream_AtOutflow"] == 1) & ~at_out & chan & defined
+        r["AtLastPoint"] = last
+        r["OutflowPoints"] = P.uniqueid(last)                                       # routing.py:168
+        r["Catchments"] = P.catchment(Ldd, r["OutflowPoints"])                      # routing.py:170
+        r["catchment_of_pits"] = P.catchment(Ldd, r["pit"])
+        nested = np.where(np.random.default_rng(11).random(N) < 0.03, np.arange(1, N + 1), 0) * defined   # points inside points' catchments
+        r["points_nested"] = nested
+        r["catchment_nested"] = P.catchment(Ldd, nested)
+        r["subcatchment_nested"] = P.subcatchment(Ldd, nested)
+        assert (r["catchment_nested"] != r["subcatchment_nested"]).any()
+        kin = r["LddChan"]
+        r["downstruct_ids"] = P.downstream(kin, np.arange(N, dtype=np.float64))     # routing.py:159-162
+        r["upstream_w"] = P.upstream(kin, w)                                        # routing.py:387
+        r["upstream_w_Ldd"] = P.upstream(Ldd, w)
+        r["accuflux_w"] = P.accuflux(Ldd, w)                                        # routing.py:98
+        ups = (P.downstream(kin, struct.astype(np.float64)) == 1) & (kin != 0)      # structures.py:51-53 (a pit reads itself)
+        r["IsUpsOfStructure"] = ups
+        r["LddKinematic_cut"] = P.lddrepair(np.where(ups, 5, kin))                  # structures.py:59
+        for k, a in r.items():
+            out[name + "__" + k] = np.asarray(a)
+        print("  %-12s N=%d pits=%d last points=%d channel cells=%d MV cells=%d" % (
+            name, N, int(at_out.sum()), int(last.sum()), int((kin != 0).sum()), int((~defined).sum())))
+    save("ldd_ops", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["graphs", "routes", "edge", "substeps", "upsum", "interception", "soil", "surface",
-                             "canopy", "canopy_options", "inloop", "pixel", "chain", "pf", "initial", "prerun"]
+                             "canopy", "canopy_options", "inloop", "pixel", "chain", "pf", "initial", "prerun", "ldd_ops"]
     fns = dict(graphs=gen_graphs, routes=gen_routes, edge=gen_route_edge, substeps=gen_substeps,
                upsum=gen_upstream_sum, interception=gen_interception, soil=gen_soil_columns,
-               surface=gen_surface_step, canopy=gen_canopy_soil_step, canopy_options=gen_canopy_options, inloop=gen_inloop, pixel=gen_pixel_aggregates, chain=gen_chain, pf=gen_soil_pf, initial=gen_initial, prerun=gen_prerun)
+               surface=gen_surface_step, canopy=gen_canopy_soil_step, canopy_options=gen_canopy_options, inloop=gen_inloop, pixel=gen_pixel_aggregates, chain=gen_chain, pf=gen_soil_pf, initial=gen_initial, prerun=gen_prerun, ldd_ops=gen_ldd_ops)
     for w in which:
         fns[w]()

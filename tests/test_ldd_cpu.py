@@ -41,12 +41,16 @@ def test_catchment_labels_by_walking():
     assert (lab > 0).all()
     for p in range(0, codes.size, 7):
         assert lab[p] == outlets[walk_down(down, p)[-1]]
-    # interior points override what lies downstream of them
+    # subcatchment: interior points override what lies downstream of them; catchment: the enclosing point wins
     pts = np.zeros(codes.size, np.int64); pts[[50, 300, 400]] = [7, 8, 9]
-    lab2 = L.catchment(codes, mask, pts)
+    pts[walk_down(down, 50)[3]] = 11                                  # a point downstream of point 7
+    lab2 = L.subcatchment(codes, mask, pts)
+    lab3 = L.catchment(codes, mask, pts)
     for p in range(codes.size):
         hit = [pts[q] for q in walk_down(down, p) if pts[q]]
         assert lab2[p] == (hit[0] if hit else 0)
+        assert lab3[p] == (hit[-1] if hit else 0)
+    assert lab2[50] == 7 and lab3[50] == 11
 
 
 def test_lddmask_and_repair_make_pits_at_the_cut():
@@ -142,3 +146,61 @@ def test_cyclic_ldd_is_an_error_by_default_and_can_be_broken_explicitly():
     assert roots_of[15] == pits[19] and roots_of[2] == pits[6]
     g.close()
     assert L.break_cycles(fixed, mask)[1] == 0                                        # sound now: nothing to break
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the independent pin of a21: tests/golden/ldd_ops.npz is made by tests/golden/pcr_naive.py -- cell-by-cell walks
+# restated from the PCRaster manual, numpy only, no code shared with lisflood_amd -- on LF_ETRS89's real LDD and on a
+# seeded raster with MV holes, non-keypad codes (0, 77, 2.5, NaN) and cells pointing off the grid / into holes.
+# ---------------------------------------------------------------------------------------------------------------------
+def ldd_ops_case(name):
+    from conftest import golden
+    z = golden("ldd_ops")
+    return {k[len(name) + 2:]: z[k] for k in z.files if k.startswith(name + "__")}
+
+
+def known_only(a):
+    """MV (0) where PCRaster has a missing value; the product's compressed forms put a pit there (documented in
+    ldd.lddrepair: a compressed vector has no missing values)"""
+    return np.where(np.isin(a, range(1, 10)), a, 0)
+
+
+@pytest.mark.parametrize("name", ["etrs89", "syn48_holes"])
+def test_host_ldd_operations_equal_the_independent_fixture(name):
+    g = ldd_ops_case(name)
+    c, land = g["codes"], g["land_mask"]
+    N = c.size
+    mv = g["Ldd"] == 0                                            # land pixels whose code is a missing value
+    # lddmask(ldd, domain): routing.py:90
+    sub, sub_mask = L.lddmask(c, land, g["domain"])
+    want = g["lddmask_domain"]
+    assert np.array_equal(known_only(sub), want[g["domain"]]) and sub_mask.sum() == g["domain"].sum()
+    # lddrepair over the whole land mask: MV pixels become pits in the compressed form, every other cell is PCRaster's
+    Ldd = L.lddrepair(c, land)
+    assert np.array_equal(Ldd[~mv], g["Ldd"][~mv]) and (Ldd[mv] == L.PIT).all()
+    # from here on the sound Ldd of the fixture restricted to its defined cells is the input (as routing.initial sees it)
+    d = ~mv
+    dm = land.copy(); dm[land] = d
+    ldd = g["Ldd"][d]
+    chan = g["is_channel"][d]
+    kin, kin_mask = L.lddmask(ldd, dm, chan)                                                         # routing.py:118
+    assert np.array_equal(kin, g["LddChan"][d][chan])
+    assert np.array_equal(L.lddrepair(np.where(chan, L.PIT, ldd), dm), g["LddToChan"][d])             # routing.py:125
+    assert np.array_equal(L.pit(ldd), g["pit"][d])                                                    # routing.py:127
+    at_out = (L.pit(ldd) != 0).astype(np.float64)
+    assert np.array_equal(L.downstream(ldd, dm, at_out), g["downstream_AtOutflow"][d])                # routing.py:141
+    assert np.array_equal(L.uniqueid(g["AtLastPoint"][d]), g["OutflowPoints"][d])                     # routing.py:168
+    assert np.array_equal(L.catchment(ldd, dm, g["OutflowPoints"][d]), g["Catchments"][d])            # routing.py:170
+    assert np.array_equal(L.catchment(ldd, dm, g["pit"][d]), g["catchment_of_pits"][d])
+    assert np.array_equal(L.catchment(ldd, dm, g["points_nested"][d]), g["catchment_nested"][d])
+    assert np.array_equal(L.subcatchment(ldd, dm, g["points_nested"][d]), g["subcatchment_nested"][d])
+    # the kinematic (channel) LDD on the channel pixels: downstruct, one-hop upstream sum, structures cut
+    ids = np.arange(N, dtype=np.float64)[d][chan]
+    assert np.array_equal(L.downstream(kin, kin_mask, ids), g["downstruct_ids"][d][chan])             # routing.py:159-162
+    w = g["w"][d]
+    down_kin = L.downstream_index(kin, kin_mask)
+    ups = np.bincount(np.where(down_kin >= 0, down_kin, kin.size), weights=w[chan], minlength=kin.size + 1)[:kin.size]
+    assert np.array_equal(ups, g["upstream_w"][d][chan])                                              # routing.py:387
+    cut, is_ups = L.cut_at_structures(kin, kin_mask, g["is_structure"][d][chan])                      # structures.py:51-59
+    assert np.array_equal(is_ups, g["IsUpsOfStructure"][d][chan])
+    assert np.array_equal(cut, g["LddKinematic_cut"][d][chan])

@@ -45,8 +45,9 @@ def test_downstream_catchment_totals_vs_walks(amd):
     root = np.array([walk_down(down, p) for p in range(N)])
     assert np.array_equal(lab, outlets[root]) and (lab > 0).all()
     pts = np.zeros(N, np.int64); pts[[50, 300, 400, 1700]] = [7, 8, 9, 7]          # interior points stop the walk
-    lab2 = d.catchment(pts)
-    assert np.array_equal(lab2, L.catchment(codes, mask, pts))
+    lab2 = d.subcatchment(pts)
+    assert np.array_equal(lab2, L.subcatchment(codes, mask, pts))
+    assert np.array_equal(d.catchment(pts), L.catchment(codes, mask, pts))      # PCRaster catchment: the enclosing point wins
     for p in range(0, N, 11):
         q, hit = p, 0
         while True:
@@ -291,3 +292,57 @@ def test_total_time_series_and_water_use_sum_on_the_device_sweep(amd, tmp_path):
     withdrawal = rng.uniform(0, 1e4, N)
     np.testing.assert_allclose(d.water_use_sum(withdrawal, 1 / 86400.0), host_accuflux(withdrawal / 86400.0), rtol=1e-12)
     d.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# a21, independent pin: the device forms against tests/golden/ldd_ops.npz, which tests/golden/pcr_naive.py makes by
+# cell-by-cell walks restated from the PCRaster manual (numpy only; no code shared with lisflood_amd or oracle/).
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["etrs89", "syn48_holes"])
+def test_device_ldd_operations_equal_the_independent_fixture(amd, name):
+    """lddmask / lddrepair / pit / downstream / uniqueid / catchment / subcatchment / upstream / accuflux and the structures
+    cut, in the order routing.initial (routing.py:90-171, 387) and structures.initial (structures.py:51-59) call them, on
+    LF_ETRS89's LDD and on a raster with MV holes, non-keypad codes (0, 77, 2.5, NaN) and off-grid pointers"""
+    from lisflood_amd import ldd as L
+    z = golden("ldd_ops")
+    g = {k[len(name) + 2:]: z[k] for k in z.files if k.startswith(name + "__")}
+    c, land = g["codes"], g["land_mask"]
+    N = c.size
+    known = lambda a: np.where(np.isin(a, range(1, 10)), a, 0)
+    mv = g["Ldd"] == 0
+    sub, sub_mask = L.lddmask_device(c, land, g["domain"])                                            # routing.py:90
+    assert np.array_equal(known(sub), g["lddmask_domain"][g["domain"]]) and sub_mask.sum() == g["domain"].sum()
+    Ldd = L.lddrepair_device(c, land)                   # MV pixels become pits in the compressed form (ldd.lddrepair)
+    assert np.array_equal(Ldd[~mv], g["Ldd"][~mv]) and (Ldd[mv] == L.PIT).all()
+    d = ~mv
+    dm = land.copy(); dm[land] = d
+    ldd, chan = g["Ldd"][d], g["is_channel"][d]
+    kin, kin_mask = L.lddmask_device(ldd, dm, chan)                                                   # routing.py:118
+    assert np.array_equal(kin, g["LddChan"][d][chan])
+    assert np.array_equal(L.lddrepair_device(np.where(chan, L.PIT, ldd), dm), g["LddToChan"][d])      # routing.py:125
+    pits = L.pit(ldd)
+    assert np.array_equal(pits, g["pit"][d])                                                          # routing.py:127
+    dev = L.LddDevice(ldd, dm)
+    assert np.array_equal(dev.downstream((pits != 0).astype(np.float64)), g["downstream_AtOutflow"][d])   # routing.py:141
+    assert np.array_equal(dev.catchment(L.uniqueid(g["AtLastPoint"][d])), g["Catchments"][d])         # routing.py:168-170
+    assert np.array_equal(dev.catchment(pits), g["catchment_of_pits"][d])
+    assert np.array_equal(dev.catchment(g["points_nested"][d]), g["catchment_nested"][d])
+    assert np.array_equal(dev.subcatchment(g["points_nested"][d]), g["subcatchment_nested"][d])
+    w = g["w"][d]
+    assert np.array_equal(dev.upstream(w), g["upstream_w_Ldd"][d])             # ascending source index: bit-exact
+    np.testing.assert_allclose(dev.accuflux(w), g["accuflux_w"][d], rtol=1e-12)                       # routing.py:98
+    dev.close()
+    kdev = L.LddDevice(kin, kin_mask)
+    ids = np.arange(N, dtype=np.float64)[d][chan]
+    assert np.array_equal(kdev.downstream(ids), g["downstruct_ids"][d][chan])                         # routing.py:159-162
+    assert np.array_equal(kdev.upstream(w[chan]), g["upstream_w"][d][chan])                           # routing.py:387
+    st = g["is_structure"][d][chan]
+    ups = kdev.downstream(st.astype(np.float64)) > 0                                                  # structures.py:51-53
+    assert np.array_equal(ups, g["IsUpsOfStructure"][d][chan])
+    cut = L.lddrepair_device(np.where(ups, L.PIT, kin), kin_mask)                                     # structures.py:59
+    assert np.array_equal(cut, g["LddKinematic_cut"][d][chan])
+    kdev.close()
+    # the whole-raster one-hop reduction (LDS-staged 3 x 3 neighbourhoods) on the same LDD
+    ras = np.zeros(land.shape, np.uint8); ras[dm] = ldd.astype(np.uint8)
+    wr = np.zeros(land.shape); wr[dm] = w
+    assert np.array_equal(L.upstream_raster(ras, wr)[dm], g["upstream_w_Ldd"][d])
