@@ -87,6 +87,10 @@ int lf_upload_copy(int device, void *dst_dev, const void *src_host, size_t bytes
  * host): half the bytes over PCIe, widened to fp64 on the device behind the copy -- the same exact conversion */
 int lf_upload_copy_f32(int device, double *dst_dev, const float *src_host, size_t count);
 int lf_upload_end(int device, int set);
+/* host side of the protocol: blocks until the copies of the last lf_upload_begin(set) .. lf_upload_end(set) have finished.
+ * Call it before refilling, in place, a page-locked source buffer that was handed to lf_upload_copy for `set` (the copy is
+ * a true asynchronous DMA out of that buffer); returns at once if the set was never uploaded. */
+int lf_upload_wait(int device, int set);
 int lf_compute_acquire(int device, int set);
 int lf_compute_release(int device, int set);
 /* A second compute stream for a part of a step that the first kernels of the NEXT step do not depend on (the channel
@@ -104,6 +108,9 @@ int lf_side_stream_join(int device);
 int lf_lane_fork(int device);
 int lf_lane_select(int device, int lane);
 int lf_lane_join(int device);
+/* releases what the context keeps for reuse (lane streams, fp32 staging buffers, the staging arena of the *_host forms);
+ * waits for the device first, refuses between lf_lane_fork and lf_lane_join or inside a side section */
+int lf_device_trim(int device);
 int lf_memcpy_d2h(int device, void *dst_host, const void *src_dev, size_t bytes);
 int lf_memcpy_d2d(int device, void *dst_dev, const void *src_dev, size_t bytes);
 int lf_memset(int device, void *dst_dev, int value, size_t bytes);

@@ -2,7 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdint>
 #include <cstdio>
 #include <string>
@@ -47,7 +49,7 @@ struct lf_device_ctx {
     hipStream_t copy_stream = nullptr;
     std::map<void *, std::pair<void *, size_t>> f32_stage; // lf_upload_copy_f32: fp32 staging buffer per destination vector
     hipEvent_t copied[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
-    bool consumed_valid[2] = {false, false};
+    bool consumed_valid[2] = {false, false}, copied_valid[2] = {false, false};
     // side stream (lf_side_stream_*): a part of a step that the NEXT step's first kernels do not depend on -- the channel
     // wavefront of a model step beside the canopy / soil / overland kernels of the step after it (hotpath.py)
     hipStream_t side_stream = nullptr, main_stream = nullptr;
@@ -127,3 +129,47 @@ struct lf_dbuf { // owning device buffer
     lf_dbuf(const lf_dbuf &) = delete;
     lf_dbuf &operator=(const lf_dbuf &) = delete;
 };
+
+// The [nsteps][N] history of the time-major fused form (k_fused_level_steps) is OPTIONAL working storage: without it the
+// skewed wavefront runs.  It can be tens of GB (10000^2, 24 split sub-steps: 2 x 19 GB), so it is taken only inside a
+// budget -- LF_FUSED_TIME_MAJOR_MAX_BYTES if set, otherwise half of what hipMemGetInfo reports free (counting what the
+// two buffers already hold) -- and a refused size is remembered, so a router that does not fit never pays a multi-GB
+// hipMalloc / failed hipMalloc / synchronising hipFree per call.  -> true: both buffers hold `count` doubles (h2 only
+// if `two`).
+inline bool lf_history_ensure(lf_dbuf<double> &h1, lf_dbuf<double> &h2, size_t &refused_bytes, size_t count, bool two)
+{
+    const bool ok1 = h1.p && h1.n >= count, ok2 = !two || (h2.p && h2.n >= count);
+    if (ok1 && ok2) return true;
+    const size_t total = count * sizeof(double) * (two ? 2 : 1);
+    if (total >= refused_bytes) return false;
+    size_t budget = 0;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+            (void)hipGetLastError();
+            refused_bytes = total;
+            return false;
+        }
+        const size_t held = (h1.p ? h1.n : 0) * sizeof(double) + (h2.p ? h2.n : 0) * sizeof(double);
+        budget = (free_b + held) / 2;
+        static const long long cap = [] {
+            const char *e = std::getenv("LF_FUSED_TIME_MAJOR_MAX_BYTES");
+            return e ? std::atoll(e) : -1ll;
+        }();
+        if (cap >= 0) budget = std::min((size_t)cap, free_b + held);
+    }
+    if (total > budget) {
+        refused_bytes = total;
+        return false;
+    }
+    bool ok = true;
+    if (!ok1) ok = h1.alloc(count) == LF_OK;
+    if (ok && !ok2) ok = h2.alloc(count) == LF_OK;
+    if (!ok) {
+        (void)hipGetLastError();
+        h1.release();
+        h2.release();
+        refused_bytes = total;
+    }
+    return ok;
+}

@@ -237,6 +237,19 @@ int lf_upload_end(int device, int set)
     lf_device_ctx *c;
     LF_TRY(upload_ctx(device, set, &c));
     LF_HIP(hipEventRecord(c->copied[set], c->copy_stream));
+    c->copied_valid[set] = true;
+    return LF_OK;
+}
+
+// The host side of the protocol: a caller that refills a page-locked source buffer in place (the netCDF reader writing the
+// next step's forcing into the arrays of pinned_forcing()) must not do so while the DMA that reads it is in flight.
+// Blocks until every copy enqueued between the last lf_upload_begin(set) / lf_upload_end(set) pair has finished; returns at
+// once if the set was never uploaded.
+int lf_upload_wait(int device, int set)
+{
+    lf_device_ctx *c;
+    LF_TRY(upload_ctx(device, set, &c));
+    if (c->copied_valid[set]) LF_HIP(hipEventSynchronize(c->copied[set]));
     return LF_OK;
 }
 
@@ -268,6 +281,7 @@ int lf_lane_fork(int device)
     lf_device_ctx *c;
     LF_TRY(lf_ctx(device, &c));
     if (c->side_active || c->lane_current != 0) return lf_set_error(LF_E_INVALID, "lf_lane_fork inside a side section or a lane");
+    if (c->lane_forked) return lf_set_error(LF_E_INVALID, "lf_lane_fork: the previous fork has not been joined (lf_lane_join)");
     if (!c->lane_fork) LF_HIP(hipEventCreateWithFlags(&c->lane_fork, hipEventDisableTiming));
     LF_HIP(hipEventRecord(c->lane_fork, c->stream));
     c->lane_main = c->stream;
@@ -341,6 +355,8 @@ int lf_side_stream_begin(int device)
     lf_device_ctx *c;
     LF_TRY(lf_ctx(device, &c));
     if (c->side_active) return lf_set_error(LF_E_INVALID, "the side stream is already active");
+    if (c->lane_current != 0 || c->lane_forked)
+        return lf_set_error(LF_E_INVALID, "lf_side_stream_begin between lf_lane_fork and lf_lane_join");
     if (!c->side_stream) {
         LF_HIP(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
         LF_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -372,6 +388,32 @@ int lf_side_stream_join(int device)
     LF_TRY(lf_ctx(device, &c));
     if (c->side_active) return lf_set_error(LF_E_INVALID, "join from inside the side section");
     return side_join(c);
+}
+
+// Releases what the context created on demand and keeps for reuse: the lane streams and their events, the fp32 staging
+// buffers of lf_upload_copy_f32, the staging arena of the *_host entry points.  Waits for the device first; refuses inside
+// a lane or side section.  Everything is created again on next use.
+int lf_device_trim(int device)
+{
+    lf_device_ctx *c;
+    LF_TRY(lf_ctx(device, &c));
+    if (c->side_active || c->lane_current != 0 || c->lane_forked)
+        return lf_set_error(LF_E_INVALID, "lf_device_trim inside a lane or side section");
+    LF_TRY(lf_device_synchronize(device));
+    for (hipStream_t st : c->lanes)
+        if (st) (void)hipStreamDestroy(st);
+    for (hipEvent_t ev : c->lane_done)
+        if (ev) (void)hipEventDestroy(ev);
+    c->lanes.clear();
+    c->lane_done.clear();
+    c->lane_used.clear();
+    for (auto &kv : c->f32_stage)
+        if (kv.second.first) (void)hipFree(kv.second.first);
+    c->f32_stage.clear();
+    if (c->stage_base) (void)hipFree(c->stage_base);
+    c->stage_base = nullptr;
+    c->stage_bytes = 0;
+    return LF_OK;
 }
 
 int lf_memcpy_d2h(int device, void *dst_host, const void *src_dev, size_t bytes)

@@ -826,6 +826,7 @@ struct lf_dist_router {
     lf_dbuf<double> fused_qr1, fused_qr2, slab1, slab2;
     int64_t n_slots = 0, slab_steps = 0, slot_export[2] = {0, 0}, slot_ghost[2] = {0, 0};
     lf_dbuf<double> fused_hist1, fused_hist2; // [nsteps][N] router outputs of every sub-step (k_fused_level_steps<DIST>)
+    size_t fused_hist_refused = SIZE_MAX;     // smallest history size that did not fit its budget (lf_history_ensure)
     std::vector<int32_t> phase_level; // [nphases + 1] first launch unit of every phase
     // level blocks + cones of every phase (empty: one launch per unit)
     std::vector<int> fb_level, fb_row, fb_off;
@@ -1534,10 +1535,8 @@ int dist_fused_phase(lf_dist_router *r, const lf_substep_args *a, int nsteps, in
         const int64_t cells = r->h_level_start[unit0 + nunits] - r->h_level_start[unit0];
         const bool want = e ? e[0] != '0' : (nunits <= tm_levels && cells >= 20000 * (int64_t)nunits);
         if (want && nsteps > 1) {
-            const size_t need = (size_t)nsteps * (size_t)r->N;
-            bool ok = true;
-            if (r->fused_hist1.n < need) ok = r->fused_hist1.alloc(need) == LF_OK;
-            if (ok && a->split && r->fused_hist2.n < need) ok = r->fused_hist2.alloc(need) == LF_OK;
+            const bool ok = lf_history_ensure(r->fused_hist1, r->fused_hist2, r->fused_hist_refused,
+                                              (size_t)nsteps * (size_t)r->N, a->split);
             if (ok) {
                 F.hist1 = r->fused_hist1.p;
                 F.hist2 = r->fused_hist2.p;
@@ -1559,9 +1558,7 @@ int dist_fused_phase(lf_dist_router *r, const lf_substep_args *a, int nsteps, in
                 LF_HIP(hipGetLastError());
                 return LF_OK;
             }
-            (void)hipGetLastError(); // no room for the history: the skewed wavefront below
-            r->fused_hist1.release();
-            r->fused_hist2.release();
+            // no room for the history inside its budget (remembered in fused_hist_refused): the skewed wavefront below
         }
     }
     if (!r->fb_phase_block.empty() && nsteps <= kMaxPackedSteps) { // blocks of levels, cone by cone (k_fused_cones<DIST>)

@@ -848,7 +848,13 @@ __global__ void __launch_bounds__(kBlock) LF_TM_ATTR k_fused_level_steps(fused_a
         bool zero = plus_zero(qold) && plus_zero(A.ChanM3Kin[p]) && plus_zero(A.ChanQ[p]);
         if (SPLIT && zero)
             zero = plus_zero(q2old) && plus_zero(m3_2) && plus_zero(A.CrossSection2Area[p]) && plus_zero(A.Sideflow1Chan[p]);
-        if (zero) s0 = nsteps - 1; // (several model steps: the last sub-step of the last one -- the sums of the others stay 0)
+        if (zero) {
+            s0 = nsteps - 1;
+            // several model steps in the call: fused_cell runs the last sub-step of EVERY model step on such a cell and
+            // stores sum + ChanQ with ChanQ = +0.0 -- the same store here, so that a -0.0 the caller left in the sums of
+            // the earlier model steps ends up as +0.0 in both forms (any other value is unchanged by the addition)
+            for (int m = F.msteps - 1; m < nsteps - 1; m += F.msteps) fused_sum(F, m)[p] = fused_sum(F, m)[p] + 0.0;
+        }
     }
     double v = 0, q = 0, chanq = 0, s1 = 0, v2 = 0, q2 = 0;
     double side_m3 = fused_side(F, s0)[p];

@@ -206,7 +206,7 @@ struct lf_router {
     lf_dbuf<long long> level_start;
     lf_dbuf<double> a1, a2, dx, constant, qord, io_q, io_lat, tmp_ord, fused_qr1, fused_qr2;
     lf_dbuf<double> fused_hist1, fused_hist2; // [nsteps][N] router outputs of every sub-step (k_fused_level_steps)
-    int64_t fused_hist_steps = 0;
+    size_t fused_hist_refused = SIZE_MAX;     // smallest history size that did not fit its budget (lf_history_ensure)
     lf_dbuf<unsigned long long> counter;
     lf_dbuf<uint8_t> linked; // zero-length structure links (lf_graph_create_ex); null without them
     lf_dbuf<int> level_nlinked; // ... and how many of them are parked at the end of every level (k_fused_cones_split)
@@ -1471,16 +1471,8 @@ int fused_impl(lf_router *r, const lf_substep_args *a, int nsteps, int64_t sidef
         const bool applies = !in && !F.linked && nsteps > 1;
         const bool want = e ? e[0] != '0' : (NL <= tm_levels && n >= 20000 * (int64_t)NL);
         if (applies && want) {
-            if (r->fused_hist_steps < nsteps) {
-                r->fused_hist1.release();
-                r->fused_hist2.release();
-                r->fused_hist_steps = 0;
-            }
-            bool ok = true;
-            if (!r->fused_hist1.p) ok = r->fused_hist1.alloc((size_t)nsteps * n) == LF_OK;
-            if (ok && a->split && !r->fused_hist2.p) ok = r->fused_hist2.alloc((size_t)nsteps * n) == LF_OK;
+            const bool ok = lf_history_ensure(r->fused_hist1, r->fused_hist2, r->fused_hist_refused, (size_t)nsteps * n, a->split);
             if (ok) {
-                r->fused_hist_steps = nsteps;
                 F.hist1 = r->fused_hist1.p;
                 F.hist2 = r->fused_hist2.p;
                 for (int k = 0; k < NL; ++k) {
@@ -1504,9 +1496,7 @@ int fused_impl(lf_router *r, const lf_substep_args *a, int nsteps, int64_t sidef
                 r->last_stats[3] = r->NL;
                 return LF_OK;
             }
-            (void)hipGetLastError(); // no room for the history: the skewed wavefront below
-            r->fused_hist1.release();
-            r->fused_hist2.release();
+            // no room for the history inside its budget (remembered in fused_hist_refused): the skewed wavefront below
         }
     }
     if (r->fb_lmax > 1 && nsteps <= kMaxPackedSteps) { // several levels per launch (k_fused_cones)

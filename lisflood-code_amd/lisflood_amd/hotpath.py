@@ -234,11 +234,19 @@ class HotPathDevice:
     def pinned_forcing(self, dtype=np.float64):
         """A forcing dict (Rain, SnowMelt, EWRef, ETRef, ESRef) of [N] arrays in page-locked host memory, to be filled in
         place (e.g. by the netCDF reader) and passed to prefetch() / step(): their upload is an asynchronous DMA at the
-        PCIe rate instead of a staged, blocking copy.  The arrays belong to this object (freed by free())."""
+        PCIe rate instead of a staged, blocking copy.  The arrays belong to this object (freed by free()).
+        The DMA reads the arrays AFTER prefetch() / step() has returned: call upload_wait() before writing the next
+        time step into a set that was handed over (or alternate between two pinned sets and wait before reuse)."""
         from ._lib import PinnedArray
         bufs = {k: PinnedArray(self.N, dtype, self.device) for k in FORCING}
         self.__dict__.setdefault("_pinned", []).append(bufs)
         return {k: b.a for k, b in bufs.items()}
+
+    def upload_wait(self, buffer_set=None):
+        """Block until the forcing uploads started by prefetch() / step() have left the host arrays (lf_upload_wait):
+        after it the arrays of pinned_forcing() may be refilled in place.  buffer_set: 0 / 1, default both."""
+        for b in ((0, 1) if buffer_set is None else (int(buffer_set),)):
+            check(lib().lf_upload_wait(C.c_int(self.device), C.c_int(b)))
 
     def prefetch(self, forcing, ordered=False):
         """Start uploading the forcing of the NEXT step() call now: the copies run on a second stream while the kernels

@@ -1028,6 +1028,19 @@ def test_hot_path_forcing_from_page_locked_buffers(amd):
         b.step(bufs[s % 2], s + 1)
     for k in a.state_names() + ["sumDisDay", "Infiltration", "ToChanM3RunoffDt"]:
         assert np.array_equal(a.download(k), b.download(k), equal_nan=True), k
+    # ONE page-locked set refilled in place for every step: upload_wait() (lf_upload_wait) is what makes the refill safe --
+    # the DMA out of the arrays runs after prefetch() has returned
+    one = bufs[0]
+    for s in range(3, 7):
+        f = syn.hotpath_forcing(N, s)
+        a.step(f, s + 1)
+        b.upload_wait()
+        for k, x in f.items():
+            one[k][:] = x
+        b.prefetch(one)
+        b.step(one, s + 1)
+    for k in a.state_names() + ["sumDisDay", "Infiltration", "ToChanM3RunoffDt"]:
+        assert np.array_equal(a.download(k), b.download(k), equal_nan=True), k
     a.free(); b.free()
 
 
