@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads / soil kernel")
     ap.add_argument("--cpu-sample", type=int, default=2000, help="CPU baseline raster is sample x sample")
-    ap.add_argument("--only", choices=["soil", "model_step", "hotpath", "structures", "overland"], default=None, help="run only the named secondary benchmark")
+    ap.add_argument("--only", choices=["soil", "model_step", "hotpath", "structures", "overland", "etrs89"], default=None, help="run only the named secondary benchmark")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the row-block/RCCL path even with a single rank (smoke test of that path)")
     ap.add_argument("--calibrate", action="store_true",
@@ -222,81 +222,27 @@ def roofline_of(res, kernel_key=None, workload=None):
                 prep_ms_per_step=round(prof["prep"]["ms"] / max(prof["prep"]["launches"], 1), 4))
 
 
-def cpu_model():
+def cpu_baseline(family, sample, steps=2, full=10000, budget_s=25.0):
+    """The CPU baseline lives in bench_cpu.py and runs as a separate process: the OpenMP runtime must START with thread
+    binding (OMP_PROC_BIND=close OMP_PLACES=cores).  It times the oracle (C restatement of the reference algorithm,
+    OpenMP where numba uses prange; parallel first touch of every vector) on bounded samples of the GPU legs' workloads:
+    routing (team-size sweep {1, 16, 32, 64, physical cores, all threads}, then the best team on the largest raster up to
+    the bench's size that fits the budget), soil columns, the whole model step and the LF_ETRS89 chain.  Returns the
+    routing figure in the contract's shape with the other three as sub-objects."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "bench_cpu.py"), "--family", family, "--sample", str(sample), "--full", str(full),
+           "--steps", str(steps), "--budget", str(budget_s)]
     try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                return line.split(":", 1)[1].strip()
-    except OSError:
-        pass
-    import platform
-    return platform.processor() or "unknown"
-
-
-def cpu_baseline(family, sample, steps=2, full=10000, budget_s=45.0):
-    """The oracle (C restatement of the reference algorithm, OpenMP level-parallel like numba prange) timed on this
-    host: first on a sample x sample raster over several team sizes, then -- with the best team -- on the largest raster
-    up to the bench's own size whose graph build + 3 calls fit `budget_s` (estimated from the sample; the oracle's
-    graph build is single-threaded host code and dominates).  `value` is the larger leg's rate."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import oracle
-    from lisflood_amd import synthetic as syn
-    oracle.build()
-    ncpu = os.cpu_count() or 1
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = ncpu
-
-    def case(size):
-        H = W = size
-        t0 = time.perf_counter()
-        codes = syn.make_ldd(family, H, W, SEEDS[family])
-        mask = np.ones((H, W), bool)
-        N = H * W
-        p = syn.router_params(N)
-        kw = oracle.kinematicWave(codes.reshape(-1).astype(np.float64), mask, p["alpha"], p["beta"], p["dx"], p["dt"])
-        return kw, p["Q0"].copy(), syn.lateral_inflow(N, 0), N, time.perf_counter() - t0
-    kw, Q, q, N, t_build = case(sample)
-    kw.kinematicWaveRouting(Q, q)    # warm
-    rates = {}
-    for threads in sorted({1, 8, 32, avail}):
-        if threads > avail:
-            continue
-        oracle.set_threads(threads)
-        t0 = time.perf_counter()
-        for s in range(steps):
-            kw.kinematicWaveRouting(Q, q)
-        rates[threads] = N * steps / (time.perf_counter() - t0) / 1e6
-    cores = max(rates, key=rates.get)
-    out = dict(value=round(rates[cores], 3), unit="Mcell-steps/s", cores=cores, kind="port", cpu_model=cpu_model(),
-               host_cpus=ncpu, usable_cpus=avail, one_core_value=round(rates[1], 3),
-               all_cores_value=round(rates[max(rates)], 3), all_cores=max(rates),
-               team_rates={str(k): round(x, 3) for k, x in sorted(rates.items())},
-               sample="%dx%d %s raster, %d calls per thread count; best of OpenMP teams %s = %d threads "
-                      "(1 thread: %.3f Mcell-steps/s); C restatement of the reference algorithm (oracle/lf_oracle.c), "
-                      "not numba" % (sample, sample, family, steps, sorted(rates), cores, rates[1]),
-               newton_iters_mean=round(kw.last_iters[0] / N, 3), newton_iters_max=kw.last_iters[1])
-    # the bench's own size, or the largest that fits the budget
-    per_cell = (t_build + 3.0 * N / rates[cores] / 1e6) / N
-    size = int(min(full, (budget_s / per_cell) ** 0.5))
-    size -= size % 100
-    if size > sample * 1.2:
-        del kw, Q, q
-        kw, Q, q, N2, t_b2 = case(size)
-        oracle.set_threads(cores)
-        kw.kinematicWaveRouting(Q, q)
-        t0 = time.perf_counter()
-        for s in range(steps):
-            kw.kinematicWaveRouting(Q, q)
-        rate = N2 * steps / (time.perf_counter() - t0) / 1e6
-        out["sample_leg"] = dict(value=out["value"], size=sample)
-        out["value"] = round(rate, 3)
-        out["sample"] = ("%dx%d %s raster (largest up to the bench's %d^2 whose oracle set-up + calls fit %.0f s: set-up "
-                         "took %.1f s), %d calls with %d OpenMP threads; team size chosen on a %dx%d sample among %s "
-                         "(1 thread there: %.3f Mcell-steps/s); C restatement of the reference algorithm "
-                         "(oracle/lf_oracle.c), not numba"
-                         % (size, size, family, full, budget_s, t_b2, steps, cores, sample, sample, sorted(rates), rates[1]))
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, text=True)
+        res = json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:
+        return dict(value=None, unit="Mcell-steps/s", cores=0, kind="port", sample="bench_cpu.py failed: %r" % (e,))
+    out = dict(res.get("routing") or dict(value=None, unit="Mcell-steps/s", cores=0, kind="port", sample="routing leg missing"))
+    out.update(cpu_model=res.get("cpu_model"), host_cpus=res.get("host_cpus"), usable_cpus=res.get("usable_cpus"),
+               physical_cores=res.get("physical_cores"), wall_s=res.get("wall_s"))
+    for k in ("soil", "model_step", "etrs89", "soil_error", "model_step_error", "etrs89_error"):
+        if k in res:
+            out[k] = res[k]
     return out
 
 
@@ -659,6 +605,46 @@ def hotpath_bench(size=2000, steps=6, family="deep", block=1_000_000):
     return out
 
 
+def etrs89_bench(passes=3):
+    """The one real-data configuration (BASELINE.json configs[1]): the LF_ETRS89 domain of tests/golden/etrs89_chain.npz
+    (2 847 pixels, 113 levels cut at 5 lakes + 31 reservoirs, 24 split-routing sub-steps, real meteo fields) through
+    HotPathDevice -- the fixed cost of a model step (Python, ctypes, ~100+ launches) on a domain far too small to fill the
+    GPU, which is the size the reference's users test on.  ms per model step with the forcing uploaded every step (40 kB),
+    the launches of the channel wavefront, and `dis` checked against the reference-driven fixture on the first pass."""
+    from lisflood_amd import _lib
+    from lisflood_amd.hotpath import HotPathDevice
+    g = np.load(os.path.join(ROOT, "tests", "golden", "etrs89_chain.npz"))
+    cp = lambda d: {k: (np.array(a, copy=True) if isinstance(a, np.ndarray) else a) for k, a in d.items()}
+    values = {k[4:]: g[k] for k in g.files if k.startswith("val_")}
+    sc = {k[3:]: float(g[k]) for k in g.files if k.startswith("sc_")}
+    st = {k[3:]: (g[k] if g[k].ndim else float(g[k])) for k in g.files if k.startswith("st_")}
+    forcing = [{k[5:]: np.ascontiguousarray(g[k][s]) for k in g.files if k.startswith("forc_")} for s in range(g["QInM3"].shape[0])]
+    t0 = time.perf_counter()
+    hp = HotPathDevice(cp(values), sc, g["mask"], g["ldd_to_chan"], g["ldd_cut"], split=True, structures=cp(st))
+    setup_s = time.perf_counter() - t0
+    worst = 0.0
+    for step, f in enumerate(forcing):                     # first pass: parity with the reference's dis, and the warm-up
+        hp.step(f, time_since_start=step + 1, QInM3=g["QInM3"][step])
+        want = g["out_ChanQAvg"][step]
+        worst = max(worst, float(np.max(np.abs(hp.chan_q_avg() - want) / np.maximum(np.abs(want), 1e-3))))
+    launches = hp.river.last_launches()["launches"]
+    _lib.synchronize()
+    n = 0
+    t0 = time.perf_counter()
+    for p in range(passes):
+        for step, f in enumerate(forcing):
+            hp.step(f, time_since_start=step + 1, QInM3=g["QInM3"][step])
+            n += 1
+    _lib.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / n
+    N, Nk = hp.N, hp.Nk
+    hp.free()
+    return dict(ms_per_model_step=round(ms, 3), model_steps_per_s=round(1e3 / ms, 1), pixels=int(N), channel_pixels=int(Nk),
+                channel_wavefront_launches=int(launches), setup_s=round(setup_s, 2), dis_max_rel_dev_first_pass=float("%.3e" % worst),
+                bound="launch-latency", note="%d model steps timed (wall clock, forcing and inflow uploaded every step); a domain of "
+                "%d pixels cannot fill 256 CUs: the step is the sum of its launches and host calls, not of its bytes" % (n, N))
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -671,6 +657,9 @@ def main():
     if a.only == "structures":
         explicit = any(x.startswith("--size") for x in sys.argv)
         print(json.dumps(structures_step_bench(a.size if explicit else 3000)))
+        return
+    if a.only == "etrs89":
+        print(json.dumps(etrs89_bench()), flush=True)
         return
     if a.only == "overland":
         print(json.dumps(overland_bench()), flush=True)
@@ -786,6 +775,10 @@ def main():
             extra["overland_sparse_channels"] = overland_bench()
         except Exception as e:
             extra["overland_sparse_channels_error"] = repr(e)
+        try:
+            extra["etrs89_chain"] = etrs89_bench()
+        except Exception as e:
+            extra["etrs89_chain_error"] = repr(e)
         for fam in ("deep", "river"):    # the whole resident model step at a BASELINE size, stage by stage
             try:
                 extra["resident_hot_path_step_%s_5000" % fam] = hotpath_bench(5000, family=fam)
@@ -822,9 +815,12 @@ def compact_line(out, detail):
     cb = out.get("cpu_baseline")
     if cb:
         line["cpu_baseline"] = dict(value=cb["value"], unit=cb["unit"], cores=cb["cores"], kind=cb["kind"],
-                                    sample=cb["sample"].split(";")[0].split(" (")[0] + "; C restatement (oracle/lf_oracle.c), OpenMP",
-                                    one_core=cb.get("one_core_value"), all_cores=cb.get("all_cores"),
-                                    all_cores_value=cb.get("all_cores_value"), cpu=cb.get("cpu_model"))
+                                    sample=cb["sample"].split(";")[0].split(" (")[0] + "; C restatement (oracle/lf_oracle.c), "
+                                           "OpenMP bound to cores, parallel first touch",
+                                    physical_cores=cb.get("physical_cores"), team_rates=cb.get("team_rates"), cpu=cb.get("cpu_model"))
+        for k in ("soil", "model_step", "etrs89"):          # the other CPU figures of SURVEY 8(d), next to their GPU legs below
+            if isinstance(cb.get(k), dict):
+                line["cpu_baseline"][k] = {x: cb[k][x] for x in ("value", "unit", "ms_per_model_step", "cores") if x in cb[k]}
     legs = {}
 
     def ratio(rf):
@@ -871,11 +867,60 @@ def compact_line(out, detail):
             legs["hot_path_%s_5000" % fam] = dict(ms=e["ms_per_model_step"], value=e["Mpixel_steps_per_s"], unit="Mpixel-steps/s",
                                                    ms_with_forcing_upload=e.get("ms_per_model_step_with_forcing_upload"),
                                                    stages={k: [x["ms"], x["frac_hbm"]] for k, x in e["stages"].items()})
+    e = ow.get("etrs89_chain")
+    if e:
+        legs["etrs89_chain"] = dict(ms=e["ms_per_model_step"], pixels=e["pixels"], launches=e["channel_wavefront_launches"],
+                                    dis_dev=e["dis_max_rel_dev_first_pass"])
+        cpu = (cb or {}).get("etrs89") or {}
+        if "ms_per_model_step" in cpu:
+            legs["etrs89_chain"]["cpu_ms"] = cpu["ms_per_model_step"]
+    # what bounds each leg, with the live number that says so (the analysis behind the labels: DESIGN.md section 5):
+    #   hbm            bytes actually moved (frac x traffic_ratio) are at the rate this memory system gives many streams
+    #   level-latency  a chain of dependent levels: ms / levels is the per-level latency, bytes per level are tiny
+    #   launch-latency ms / launches is a kernel launch + drain, not a transfer time
+    #   valu           fp64 issue (pow chains of the soil sub-steps, or 64-lane wavefronts a fraction full)
+    def bound(leg, kind, **why):
+        if leg in legs:
+            legs[leg]["bound"] = kind
+            legs[leg].update({k: x for k, x in why.items() if x is not None})
+    for fam in ("deep", "river", "shallow"):
+        leg = legs.get("route_" + fam)
+        if leg:
+            lv = (ow.get(fam) or {}).get("levels")
+            moved = round(leg["frac"] * (leg.get("traffic_ratio") or 1.0), 3) if leg.get("frac") else None
+            if lv and lv >= 1000:
+                bound("route_" + fam, "level-latency", us_per_level=round(leg["ms"] * 1e3 / lv, 3), levels=lv)
+            else:
+                bound("route_" + fam, "hbm", moved_frac=moved, levels=lv)
+    bound("soil_wet", "valu")
+    bound("soil_single_substep", "hbm")
+    for k in ("model_step_deep_5000", "model_step_deep_5000_5_in_flight"):
+        if k in legs:
+            tr = legs["model_step_deep_5000"].get("traffic_ratio")
+            bound(k, "hbm", moved_frac=round(legs[k]["frac"] * tr, 3) if tr and legs[k].get("frac") else None)
+    if "model_step_structures_3000" in legs:
+        x = legs["model_step_structures_3000"]
+        bound("model_step_structures_3000", "launch-latency", us_per_launch=round(x["ms"] * 1e3 / x["launches"], 1) if x.get("launches") else None)
+    bound("overland_sparse_4000", "valu")
+    bound("etrs89_chain", "launch-latency")
+    for fam in ("deep", "river"):
+        if "hot_path_%s_5000" % fam in legs:
+            legs["hot_path_%s_5000" % fam]["stage_bound"] = dict(canopy="hbm", soil_columns="valu", pixel_aggregates="hbm",
+                                                                 overland="hbm", channel_wavefront="hbm", land_surface="valu")
+    if isinstance((cb or {}).get("soil"), dict) and "soil_wet" in legs:
+        legs["soil_wet"]["cpu_value"] = cb["soil"]["value"]
+    if isinstance((cb or {}).get("model_step"), dict):
+        for fam in ("deep", "river"):
+            if "hot_path_%s_5000" % fam in legs:
+                legs["hot_path_%s_5000" % fam]["cpu_value"] = cb["model_step"]["value"]
     errs = {k: v for k, v in ow.items() if k.endswith("_error")}
     if errs:
         legs["errors"] = {k: str(v)[:80] for k, v in errs.items()}
     line["legs"] = legs
-    line["legs_keys"] = "ms, value (Mcell-steps/s unless unit is given), frac = algorithmic bytes / time / 8 TB/s, traffic_ratio = counter bytes / algorithmic bytes, launches per step; stages: [ms, frac]"
+    line["legs_keys"] = ("ms, value (Mcell-steps/s unless unit is given), frac = algorithmic bytes / time / 8 TB/s, traffic_ratio = "
+                         "counter bytes / algorithmic bytes, launches per step, bound = hbm | level-latency | launch-latency | valu with "
+                         "its live number (moved_frac = frac x traffic_ratio, us_per_level, us_per_launch), cpu_value / cpu_ms = the "
+                         "oracle on the host cores in the leg's unit; stages: [ms, frac]")
     line["detail"] = detail
     return line
 

@@ -1,0 +1,221 @@
+#!/usr/bin/env python
+"""bench_cpu.py -- the CPU baseline of bench.py, run as a SEPARATE PROCESS so that the OpenMP runtime starts with
+thread binding (OMP_PROC_BIND=close OMP_PLACES=cores must be in the environment before libgomp initialises).
+
+What is timed is the C restatement of the reference's algorithm (oracle/lf_oracle.c, OpenMP loops where the reference's
+numba kernels use prange) -- test / bench infrastructure, `kind: "port"`: the reference itself is numba-jitted Python and
+numba is not in this image.  Three figures, each on a bounded sample of the GPU legs' workloads:
+
+  routing     kinematicWaveRouting calls on the bench's synthetic raster: team-size sweep {1, 16, 32, 64, physical cores,
+              all hardware threads} on a sample raster with parallel first touch of every vector, then the best team on
+              the largest raster up to the bench's own size whose set-up fits the budget           [Mcell-steps/s]
+  soil        soilColumnsWaterBalance on the bench's `wet` soil (same generator and seed as the GPU leg) [Mcolumn-steps/s]
+  model_step  the whole chain of a model step (oracle_chain.OracleChain) on the hot-path scenario   [Mpixel-steps/s]
+  etrs89      the same chain on the LF_ETRS89 fixture (tests/golden/etrs89_chain.npz)               [ms per model step]
+
+Prints one JSON object on stdout.  `python bench_cpu.py --help` for the knobs; bench.py calls it with its defaults."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+BIND = {"OMP_PROC_BIND": "close", "OMP_PLACES": "cores"}
+
+
+def reexec_bound():
+    """restart once with the binding variables set (they are read when libgomp loads)"""
+    if all(os.environ.get(k) == v for k, v in BIND.items()) or os.environ.get("LF_BENCH_CPU_NO_BIND"):
+        return
+    env = dict(os.environ, **BIND)
+    env.pop("OMP_NUM_THREADS", None)
+    os.execve(sys.executable, [sys.executable] + sys.argv, env)
+
+
+def topology():
+    """(hardware threads usable by this process, physical cores among them, model name)"""
+    try:
+        usable = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = list(range(os.cpu_count() or 1))
+    cores, model = set(), "unknown"
+    try:
+        cur = {}
+        for line in open("/proc/cpuinfo"):
+            if ":" in line:
+                k, x = [t.strip() for t in line.split(":", 1)]
+                cur[k] = x
+                if k == "model name":
+                    model = x
+            elif cur:
+                if int(cur.get("processor", -1)) in usable:
+                    cores.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+                cur = {}
+        if cur and int(cur.get("processor", -1)) in usable:
+            cores.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+    except OSError:
+        pass
+    return len(usable), (len(cores) or len(usable)), model
+
+
+def teams(usable, physical):
+    return sorted({t for t in (1, 16, 32, 64, physical, usable) if 1 <= t <= usable})
+
+
+def routing(family, sample, full, steps, budget_s, usable, physical):
+    import numpy as np
+    import oracle
+    from lisflood_amd import synthetic as syn
+    seeds = {"shallow": 1, "deep": 2, "river": 7}
+
+    def case(size, threads):
+        H = W = size
+        t0 = time.perf_counter()
+        codes = syn.make_ldd(family, H, W, seeds[family])
+        mask = np.ones((H, W), bool)
+        N = H * W
+        p = syn.router_params(N)
+        kw = oracle.kinematicWave(codes.reshape(-1).astype(np.float64), mask, p["alpha"], p["beta"], p["dx"], p["dt"])
+        t_build = time.perf_counter() - t0
+        return kw, p["Q0"].copy(), syn.lateral_inflow(N, 0), N, t_build
+
+    def timed(kw, Q0, q0, threads, n):
+        oracle.set_threads(threads)
+        kw.first_touch()                                   # pages of every vector placed by THIS team
+        Q, q = oracle.first_touch(Q0), oracle.first_touch(q0)
+        kw.kinematicWaveRouting(Q, q)                      # warm
+        t0 = time.perf_counter()
+        for _ in range(n):
+            kw.kinematicWaveRouting(Q, q)
+        return (time.perf_counter() - t0) / n
+
+    kw, Q0, q0, N, t_build = case(sample, 1)
+    rates = {}
+    for t in teams(usable, physical):
+        rates[t] = N / timed(kw, Q0, q0, t, steps) / 1e6
+    best = max(rates, key=rates.get)
+    out = dict(value=round(rates[best], 3), unit="Mcell-steps/s", cores=best, kind="port",
+               team_rates={str(k): round(x, 3) for k, x in sorted(rates.items())}, one_core_value=round(rates[1], 3),
+               physical_cores=physical, usable_cpus=usable, binding="OMP_PROC_BIND=close OMP_PLACES=cores, parallel first touch",
+               newton_iters_mean=round(kw.last_iters[0] / N, 3), newton_iters_max=kw.last_iters[1],
+               sample="%dx%d %s raster, %d calls per team size; best of OpenMP teams %s = %d threads; C restatement of the "
+                      "reference algorithm (oracle/lf_oracle.c), not numba" % (sample, sample, family, steps, sorted(rates), best))
+    if physical in rates and 32 in rates and physical > 32:
+        out["physical_vs_32"] = round(rates[physical] / rates[32], 3)
+    # the bench's own size, or the largest whose single-threaded graph build + calls fit the budget
+    per_cell = (t_build + (steps + 1.0) * N / rates[best] / 1e6) / N
+    size = int(min(full, (budget_s / per_cell) ** 0.5))
+    size -= size % 100
+    if size > sample * 1.2:
+        del kw
+        kw, Q0, q0, N2, t_b2 = case(size, best)
+        rate = N2 / timed(kw, Q0, q0, best, steps) / 1e6
+        out["sample_leg"] = dict(value=out["value"], size=sample)
+        out["value"] = round(rate, 3)
+        out["sample"] = ("%dx%d %s raster (largest up to the bench's %d^2 whose oracle set-up + calls fit %.0f s: set-up took "
+                         "%.1f s), %d calls with %d OpenMP threads; team size chosen on a %dx%d sample among %s; C restatement "
+                         "of the reference algorithm (oracle/lf_oracle.c), not numba"
+                         % (size, size, family, full, budget_s, t_b2, steps, best, sample, sample, sorted(rates)))
+    return out, best
+
+
+def soil(threads, n_pixels, steps):
+    import numpy as np
+    import oracle
+    from lisflood_amd import synthetic as syn
+    oracle.set_threads(threads)
+    d = syn.soil_params(n_pixels, seed=3)                  # the GPU leg's `wet` soil (bench.py soil_bench)
+    for k, a in list(d.items()):
+        if isinstance(a, np.ndarray) and a.dtype == np.float64 and a.size >= n_pixels:
+            d[k] = oracle.first_touch(a)
+    oracle.soil_columns(d)                                 # warm (and one step into the run, like the GPU leg's warm-up)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        oracle.soil_columns(d)
+    dt = (time.perf_counter() - t0) / steps
+    cols = 3 * n_pixels
+    return dict(value=round(cols / dt / 1e6, 3), unit="Mcolumn-steps/s", cores=threads, kind="port", ms_per_step=round(dt * 1e3, 2),
+                sample="%d pixels x 3 fractions of the bench's `wet` soil (syn.soil_params seed 3), %d calls" % (n_pixels, steps))
+
+
+def model_step(threads, size, steps):
+    import numpy as np
+    import oracle
+    from oracle_chain import OracleChain
+    from lisflood_amd import synthetic as syn
+    oracle.set_threads(threads)
+    H = W = size
+    N = H * W
+    values, sc, mask, ldd_to_chan, ldd_kin = syn.hotpath_scenario(H, W)
+    t0 = time.perf_counter()
+    ch = OracleChain(values, sc, mask, ldd_to_chan, ldd_kin, split=True)
+    t_setup = time.perf_counter() - t0
+    ch.step(syn.hotpath_forcing(N, 0))                     # warm
+    t0 = time.perf_counter()
+    for s in range(steps):
+        ch.step(syn.hotpath_forcing(N, (s + 1) % 2))
+    dt = (time.perf_counter() - t0) / steps
+    return dict(value=round(N / dt / 1e6, 3), unit="Mpixel-steps/s", cores=threads, kind="port", ms_per_model_step=round(dt * 1e3, 1),
+                setup_s=round(t_setup, 1),
+                sample="%dx%d hot-path scenario (syn.hotpath_scenario: canopy, soil, aggregates, overland, %d split-routing "
+                       "sub-steps), %d model steps; the forcing generator is inside the timed loop"
+                       % (size, size, int(sc["NoRoutSteps"]), steps))
+
+
+def etrs89(threads, steps):
+    import numpy as np
+    import oracle
+    from oracle_chain import OracleChain
+    oracle.set_threads(threads)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "etrs89_chain.npz"))
+    values = {k[4:]: g[k] for k in g.files if k.startswith("val_")}
+    sc = {k[3:]: float(g[k]) for k in g.files if k.startswith("sc_")}
+    st = {k[3:]: (g[k] if g[k].ndim else float(g[k])) for k in g.files if k.startswith("st_")}
+    forcing = [{k[5:]: np.ascontiguousarray(g[k][s]) for k in g.files if k.startswith("forc_")} for s in range(g["QInM3"].shape[0])]
+    ch = OracleChain(values, sc, g["mask"], g["ldd_to_chan"], g["ldd_cut"], structures=st, split=True)
+    n = min(steps, len(forcing))
+    t0 = time.perf_counter()
+    for s in range(n):
+        ch.step(forcing[s], g["QInM3"][s])
+    dt = (time.perf_counter() - t0) / n
+    return dict(ms_per_model_step=round(dt * 1e3, 2), cores=threads, kind="port", pixels=int(g["mask"].sum()),
+                sample="LF_ETRS89 chain fixture (2 847 pixels, lakes + reservoirs, 24 split-routing sub-steps), %d model steps" % n)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--family", default="shallow")
+    ap.add_argument("--sample", type=int, default=2000)
+    ap.add_argument("--full", type=int, default=10000)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--budget", type=float, default=25.0, help="seconds for the full-size routing leg")
+    ap.add_argument("--soil-pixels", type=int, default=4_000_000)
+    ap.add_argument("--model-size", type=int, default=1000)
+    ap.add_argument("--only", default="routing,soil,model_step,etrs89")
+    a = ap.parse_args()
+    reexec_bound()
+    for p in (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "lisflood-code_amd")):
+        sys.path.insert(0, p)
+    import oracle
+    oracle.build()
+    usable, physical, model = topology()
+    want = a.only.split(",")
+    out = dict(cpu_model=model, usable_cpus=usable, physical_cores=physical, host_cpus=os.cpu_count())
+    best = min(physical, usable)
+    t00 = time.perf_counter()
+    if "routing" in want:
+        out["routing"], best = routing(a.family, a.sample, a.full, a.steps, a.budget, usable, physical)
+    for name, fn in (("soil", lambda: soil(best, a.soil_pixels, 2)), ("model_step", lambda: model_step(best, a.model_size, 2)),
+                     ("etrs89", lambda: etrs89(min(best, 8), 6))):
+        if name in want:
+            try:
+                out[name] = fn()
+            except Exception as e:                        # a secondary figure must not cost the primary one
+                out[name + "_error"] = repr(e)
+    out["wall_s"] = round(time.perf_counter() - t00, 1)
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

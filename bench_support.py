@@ -73,13 +73,15 @@ class RoutingStepDevice:
         a.sumDisDay = sums.ptr.value
         check(lib().lf_routing_model_steps_fused(self.router._h, C.byref(a), C.c_int(nsteps), C.c_int(nmodel), C.c_int64(0)))
 
-    def run_model_steps(self, nsteps, sideflows=None, nmodel=None):
+    def run_model_steps(self, nsteps, sideflows=None, nmodel=None, sums0=None):
         """`nmodel` model steps of nsteps sub-steps as ONE wavefront (lf_routing_model_steps_fused).  sideflows: list of
         pixel-order sideflow vectors, one per model step (None: the resident vector for `nmodel` steps).  Returns the
         [nmodel, N] discharge sums (pixel order); the state vectors hold what the last model step leaves."""
         M = len(sideflows) if sideflows is not None else int(nmodel)
         N = self.N
         sums = DeviceArray((M, N), np.float64, self.device).zero()
+        if sums0 is not None:                  # [M, N] pixel order: what the sums hold when the call starts (default +0.0)
+            sums.upload(f64(np.asarray(sums0)[:, self.perm]))
         a = _SubstepArgs.from_buffer_copy(self.args)
         a.sumDisDay = sums.ptr.value
         side, stride = None, 0

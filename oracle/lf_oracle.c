@@ -239,6 +239,7 @@ void lfo_route(double *discharge, const double *q_lat, const double *dx, double 
 void lfo_sideflow(const double *SideflowChanM3, const uint8_t *IsChannelKinematic, const double *InvChanLength,
                   double InvDtRouting, int nan_to_zero, int64_t n, double *SideflowChan)
 {
+#pragma omp parallel for schedule(static)
     for (int64_t p = 0; p < n; ++p) {
         double s = IsChannelKinematic[p] ? SideflowChanM3[p] * InvChanLength[p] * InvDtRouting : 0.0;
         if (nan_to_zero && isnan(s)) s = 0;
@@ -251,6 +252,7 @@ void lfo_split_sideflow(const double *SideflowChan, const double *ChanM3Kin, con
                         const double *Chan2M3Start, const double *M3Limit, const double *Chan2QStart,
                         const double *InvChanLength, int64_t n, double *Sideflow1Chan, double *Sideflow2Chan)
 {
+#pragma omp parallel for schedule(static)
     for (int64_t p = 0; p < n; ++p) {
         double tot = ChanM3Kin[p] + Chan2M3Kin[p];
         double ratio = (tot > 0) ? ChanM3Kin[p] / tot : 0.0;                                       /* :549 */
@@ -266,6 +268,7 @@ void lfo_main_fixup(double *ChanQKin, double *ChanM3Kin, const double *ChanLengt
                     const double *InvChanLength, const double *InvChannelAlpha, double Beta, double InvBeta,
                     int64_t n)
 {
+#pragma omp parallel for schedule(static)
     for (int64_t p = 0; p < n; ++p) {
         double v = ChanLength[p] * ChannelAlpha[p] * pow(ChanQKin[p], Beta);
         if (v < 0.0) v = 0.0; /* np.maximum(v, 0.0); NaN propagates */
@@ -280,6 +283,7 @@ void lfo_floodplain_fixup(double *Chan2QKin, double *Chan2M3Kin, double *CrossSe
                           const double *InvChanLength, const double *InvChannelAlpha2, const double *Chan2M3Start,
                           const double *QLimit, double Beta, double InvBeta, int64_t n)
 {
+#pragma omp parallel for schedule(static)
     for (int64_t p = 0; p < n; ++p) {
         double v = ChanLength[p] * ChannelAlpha2[p] * pow(Chan2QKin[p], Beta);
         double diff = v - Chan2M3Start[p];
@@ -297,6 +301,7 @@ void lfo_floodplain_fixup(double *Chan2QKin, double *Chan2M3Kin, double *CrossSe
 void lfo_velocity(const double *ChanM3Kin, const double *ChanQKin, const double *InvChanLength,
                   const double *PixelArea, double DtSec, int64_t n, double *FlowVelocity, double *TravelDistance)
 {
+#pragma omp parallel for schedule(static)
     for (int64_t p = 0; p < n; ++p) {
         double area = ChanM3Kin[p] * InvChanLength[p];
         if (area < 0.01) area = 0.01; /* np.maximum(area, 0.01); NaN propagates */
@@ -315,6 +320,14 @@ void lfo_velocity(const double *ChanM3Kin, const double *ChanQKin, const double 
  * a20: one-hop LDD upstream reduction == np.bincount(downstruct, weights)[:N]
  * (routing.py:159-164, lakes.py:215): sum in ascending source index.
  * ---------------------------------------------------------------------------------------------- */
+/* parallel first touch: dst (fresh, untouched pages) <- src with the static schedule of every loop above, so that on a
+ * multi-socket host each thread's share of a state vector lies in its own NUMA node (bench.py cpu_baseline) */
+void lfo_parallel_copy(double *dst, const double *src, int64_t n)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t p = 0; p < n; ++p) dst[p] = src[p];
+}
+
 void lfo_upstream_sum(const int32_t *downstruct, const double *w, int64_t n, double *out)
 {
     for (int64_t p = 0; p < n; ++p) out[p] = 0.0;
@@ -707,6 +720,7 @@ void lfo_inloop_structures(const lfo_inloop_args *A)
         A->QResOutM3Dt[A->res_cell[r]] = vol_out;
     }
     /* inflow hydrographs, transmission loss, sideflow assembly */
+#pragma omp parallel for schedule(static)
     for (int64_t p = 0; p < A->N; ++p) {
         double side = A->ToChanM3RunoffDt[p];
         if (A->EvaAddM3Dt) side -= A->EvaAddM3Dt[p];
@@ -763,6 +777,7 @@ void lfo_pixel_aggregates(const lfo_pixel_args *A)
 {
     const int64_t N = A->N;
     const double *f = A->SoilFraction;
+#pragma omp parallel for schedule(static)
     for (int64_t p = 0; p < N; ++p) {
         /* direct runoff from sealed area and open water, opensealed.py:45-70 */
         const double ewref = A->EWRef[p], sealed = A->DirectRunoffFraction[p], water = A->WaterFraction[p];
@@ -839,6 +854,7 @@ void lfo_surface_pre(const double *soil_fraction, const double *avail, const dou
                      double inv_pixel_length, double inv_dt_sec, int64_t N, double *surface_run_soil,
                      double *surface_runoff, double *total_runoff, double *side)
 {
+#pragma omp parallel for schedule(static)
     for (int64_t p = 0; p < N; ++p) {
         double part[3];
         for (int l = 0; l < 3; ++l) {
@@ -861,6 +877,7 @@ void lfo_surface_post(const double *q_direct, const double *q_other, const doubl
                       int64_t N, double *m3_direct, double *m3_other, double *m3_forest, double *to_chan_m3,
                       double *water_depth, double *to_chan_runoff, double *to_chan_runoff_dt)
 {
+#pragma omp parallel for schedule(static)
     for (int64_t p = 0; p < N; ++p) {
         const double vd = pixel_length * of_alpha[2 * N + p] * pow(q_direct[p], beta);
         const double vo = pixel_length * of_alpha[p] * pow(q_other[p], beta);
@@ -892,6 +909,7 @@ void lfo_canopy(double *Interception, double *TaInterception, double *LeafDraina
                 const uint8_t *isFrozenSoil, const int64_t *landuse, double LeafDrainageK, double InvDtDay, int64_t V,
                 int64_t N)
 {
+#pragma omp parallel for schedule(static)
     for (int64_t pix = 0; pix < N; ++pix) {
         const double rain = Rain[pix], ewref = EWRef[pix], etref = ETRef[pix];
         for (int64_t veg = 0; veg < V; ++veg) {
@@ -977,6 +995,7 @@ void lfo_soil_pf(double *pF0, double *pF1, double *pF2, const double *W1a, const
                  int64_t N)
 {
     for (int64_t veg = 0; veg < V; ++veg)
+#pragma omp parallel for schedule(static)
         for (int64_t pix = 0; pix < N; ++pix) {
             const int64_t i = veg * N + pix, j = landuse[veg] * N + pix;
             pF0[i] = lfo_pf_layer(W1a[i], P1a[j], WRes1a[j], WS1a[j], IA1a[j], IM1a[j], IN1a[j], HeadMax);

@@ -47,6 +47,17 @@ def set_threads(n):
     C.CDLL(ctypes.util.find_library("gomp") or "libgomp.so.1").omp_set_num_threads(int(n))
 
 
+def first_touch(a):
+    """A copy of `a` (any 8-byte dtype, C-contiguous) whose pages are first written by the OpenMP team with the static
+    schedule of the oracle's loops (lfo_parallel_copy): on a multi-socket host every thread's share of the vector then
+    lies in its own NUMA node.  numpy's own allocation is touched by the calling thread alone.  bench baseline only."""
+    a = np.ascontiguousarray(a)
+    assert a.dtype.itemsize == 8
+    out = np.empty(a.shape, a.dtype)                      # large allocation: mmap'ed, pages untouched until written
+    lib().lfo_parallel_copy(_ptr(out.view(np.float64)), _ptr(a.view(np.float64)), C.c_int64(a.size))
+    return out
+
+
 def _f(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 
@@ -106,6 +117,15 @@ class kinematicWave:
         self.pixels_ordered, self.order_start_stop = orders(self.downstream_lookup, ups8, self.num_upstream_pixels)
         self._scratch = np.empty(self.num_upstream_pixels.size)
         self.last_iters = (0, 0)
+
+    def first_touch(self):
+        """re-home the router's own vectors (see first_touch above); call after set_threads()"""
+        for k in ("a_dx_div_dt_channel", "b_a_dx_div_dt_channel", "a_dx_div_dt_floodplains", "b_a_dx_div_dt_floodplains",
+                  "upstream_lookup", "num_upstream_pixels", "pixels_ordered", "_scratch"):
+            if hasattr(self, k):
+                setattr(self, k, first_touch(getattr(self, k)))
+        if np.ndim(self.space_delta) != 0:
+            self.space_delta = first_touch(_f(self.space_delta))
 
     def kinematicWaveRouting(self, discharge, specific_lateral_inflow, section="main_channel"):
         if section == "main_channel":

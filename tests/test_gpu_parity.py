@@ -632,6 +632,56 @@ def test_several_model_steps_in_one_wavefront(amd, monkeypatch, family, time_maj
     a.free(); b.free(); kw.close()
 
 
+def test_inert_pixels_leave_the_same_sums_in_both_fused_forms(amd, monkeypatch):
+    """Several model steps in one call on a domain with inert pixels (isolated non-channel pixels whose state is all
+    +0.0): the time-major form (k_fused_level_steps) jumps such a pixel to the last sub-step of the call, the skewed form
+    (fused_cell) runs the last sub-step of EVERY model step on it -- both must leave `sum + 0.0` in the sums of every
+    model step, also when the caller did not zero them: -0.0 becomes +0.0, any other value stays (bit for bit, signs of
+    zero included)."""
+    from lisflood_amd import synthetic as syn
+    from lisflood_amd import ldd as L
+    from lisflood_amd.kinematic_wave_parallel import kinematicWave
+    from bench_support import RoutingStepDevice
+    H, W = 600, 700
+    N = H * W
+    mask = np.ones((H, W), bool)
+    codes = syn.make_ldd("shallow", H, W, 5).reshape(-1).astype(np.float64)
+    rng = np.random.default_rng(23)
+    is_chan = rng.random(N) < 0.8
+    kin, _ = L.lddmask(codes, mask, is_chan)
+    ldd_kin = np.zeros(N); ldd_kin[is_chan] = kin
+    p = syn.router_params(N, seed=12)
+    beta, dt, nsteps, M = p["beta"], 3600.0, 6, 3
+    alpha, length = p["alpha"], p["dx"]
+    alpha2 = alpha * rng.uniform(1.2, 2.0, N)
+    q0 = np.where(is_chan, p["Q0"], 0.0)
+    qlimit = 2.0 * q0 * rng.uniform(0.3, 1.2, N)
+    vals = dict(ChanLength=length, InvChanLength=1 / length, ChannelAlpha=alpha, InvChannelAlpha=1 / alpha,
+                ChannelAlpha2=alpha2, InvChannelAlpha2=1 / alpha2, QLimit=qlimit, M3Limit=alpha * length * qlimit ** beta,
+                Chan2M3Start=alpha2 * length * qlimit ** beta, Chan2QStart=qlimit * 0.1, PixelArea=np.full(N, 2.5e7),
+                IsChannelKinematic=is_chan, SideflowChanM3=syn.lateral_inflow(N, 0) * length * dt)
+    vals["Chan2M3Kin"] = vals["Chan2M3Start"].copy()
+    vals["ChanM3Kin"] = alpha * length * q0 ** beta
+    vals["ChanQKin"] = q0.copy()
+    vals["Chan2QKin"] = (vals["Chan2M3Kin"] / length / alpha2) ** (1 / beta)
+    kw = kinematicWave(ldd_kin, mask, alpha, beta, length, dt, alpha_floodplains=alpha2)
+    sums0 = np.zeros((M, N))
+    sums0[:, ::3] = -0.0
+    sums0[:, 1::3] = rng.uniform(1.0, 9.0, (M, sums0[:, 1::3].shape[1]))
+    got = {}
+    for tm in ("0", "1"):
+        monkeypatch.setenv("LF_FUSED_TIME_MAJOR", tm)
+        r = RoutingStepDevice(kw, vals, True, beta, 1 / dt, dt * nsteps)
+        got[tm] = r.run_model_steps(nsteps, nmodel=M, sums0=sums0)
+        r.free()
+    same = got["0"].view(np.int64) == got["1"].view(np.int64)                  # bits: +0.0 and -0.0 differ
+    assert same.all(), np.argwhere(~same)[:5]
+    inert = ~is_chan                                                           # isolated, zero state, no sideflow
+    assert inert.sum() > N // 10
+    assert (got["1"][:, inert] == sums0[:, inert]).all() and not np.signbit(got["1"][:, inert]).any()
+    kw.close()
+
+
 @pytest.mark.parametrize("family", ["deep", "shallow"])
 def test_structures_wavefront_mid_size_synthetic(amd, family):
     """2e5 cells, 16 lakes + 48 reservoirs + 32 inflow points + transmission loss, 24 split-routing sub-steps, two model
