@@ -239,7 +239,8 @@ def cpu_baseline(family, sample, steps=2, full=10000, budget_s=25.0):
         return dict(value=None, unit="Mcell-steps/s", cores=0, kind="port", sample="bench_cpu.py failed: %r" % (e,))
     out = dict(res.get("routing") or dict(value=None, unit="Mcell-steps/s", cores=0, kind="port", sample="routing leg missing"))
     out.update(cpu_model=res.get("cpu_model"), host_cpus=res.get("host_cpus"), usable_cpus=res.get("usable_cpus"),
-               physical_cores=res.get("physical_cores"), wall_s=res.get("wall_s"))
+               physical_cores=res.get("physical_cores"), wall_s=res.get("wall_s"), cgroup_cpu_quota=res.get("cgroup_cpu_quota"),
+               loadavg=res.get("loadavg"))
     for k in ("soil", "model_step", "etrs89", "soil_error", "model_step_error", "etrs89_error"):
         if k in res:
             out[k] = res[k]

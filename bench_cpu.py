@@ -59,6 +59,22 @@ def topology():
     return len(usable), (len(cores) or len(usable)), model
 
 
+def cgroup_cpu_quota():
+    """CPUs' worth of run time the container may use per period (cgroup v2 cpu.max / v1 cfs quota), None = unlimited.
+    A team larger than this is throttled by the kernel, whatever the affinity mask says."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else round(float(q) / float(per), 2)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else round(q / per, 2)
+    except (OSError, ValueError):
+        return None
+
+
 def teams(usable, physical):
     return sorted({t for t in (1, 16, 32, 64, physical, usable) if 1 <= t <= usable})
 
@@ -201,7 +217,8 @@ def main():
     oracle.build()
     usable, physical, model = topology()
     want = a.only.split(",")
-    out = dict(cpu_model=model, usable_cpus=usable, physical_cores=physical, host_cpus=os.cpu_count())
+    out = dict(cpu_model=model, usable_cpus=usable, physical_cores=physical, host_cpus=os.cpu_count(),
+               cgroup_cpu_quota=cgroup_cpu_quota(), loadavg=[round(x, 1) for x in os.getloadavg()])
     best = min(physical, usable)
     t00 = time.perf_counter()
     if "routing" in want:

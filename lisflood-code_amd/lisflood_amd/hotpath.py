@@ -264,6 +264,17 @@ class HotPathDevice:
                 if hasattr(type(st), k):
                     setattr(st, k, self.force[b][k].ptr.value)
 
+    def set_lai(self, LAI, LAITerm):
+        """The prescribed leaf area index of the coming steps: what leafarea.dynamic sets once per ten-day interval
+        (leafarea.py:80-91: LAI of the interval, LAITerm = exp(-kgb * LAI)), [3, N] each, pixel order.  Waits for the
+        step in flight (its canopy kernel reads the vectors)."""
+        check(lib().lf_device_synchronize(C.c_int(self.device)))
+        for k, a in (("LAI", LAI), ("LAITerm", LAITerm)):
+            a = np.asarray(a, np.float64)
+            if a.shape != (3, self.N):
+                raise ValueError("%s must be [3, %d]" % (k, self.N))
+            self.d[k].upload(f64(self._ordered(a)))
+
     def set_inflow(self, QInM3):
         """inflow.dynamic + dynamic_init (inflow.py:108-125) for the coming step: QInM3 [N] is the hydrograph volume of
         the model step [m3]; QDelta = (QInM3 - QInM3Old) * InvNoRoutSteps goes to the device next to QInM3Old, and

@@ -950,6 +950,251 @@ def gen_chain():
     opts.clear()
 
 
+# ------------------------------------------------------------------------------------------------
+# Row N1, long form: LONG_STEPS model steps on LF_ETRS89 with the land surface initialised by the reference's OWN
+# initial() methods from what cold.xml binds (etrs89_bindings.npz, made by extract_etrs89_bindings.py from the use case's
+# maps): landusechange.initial -> the groundwater lines of miscInitial -> soil.initial -> groundwater.initial ->
+# surface_routing.initial, then leafarea.dynamic's two lines per step (LAI stack of the use case).  Nothing of the soil
+# column, canopy, groundwater or overland parameters is seeded any more; still stand-ins (documented in the fixture):
+# snow melt and frozen soil (snow.py / frost.py are not on the path), the inflow hydrographs, the transmission-loss
+# reaches, precipitation scaled x4 plus two seeded storms so that reservoirs move between their storage regimes.
+# ------------------------------------------------------------------------------------------------
+LONG_STEPS = 72
+LAI_DAYS = [1, 11, 21, 32, 42, 52, 60, 70, 80, 91, 101, 111, 121, 131, 141, 152, 162, 172, 182,
+            192, 202, 213, 223, 233, 244, 254, 264, 274, 284, 294, 305, 315, 325, 335, 345, 355, 370]    # leafarea.py:50-51
+
+
+def real_land_surface(mask, sc):
+    """-> (v, LAIX[36, 3, N], kgb): the reference's initialisation of every land-surface vector on mask.map"""
+    import importlib
+    from collections import OrderedDict
+    B = np.load(os.path.join(HERE, "etrs89_bindings.npz"))
+    N = int(mask.sum())
+
+    def loadmap(name, *a, **kw):                         # add1.py:318-565 for a netCDF map / a number in the settings file
+        x = B[name]
+        if x.ndim == 0:
+            return float(x)
+        out = x[mask].astype(float)                      # compressArray(...).astype(float), add1.py:268-282
+        assert np.isfinite(out).all(), name
+        return out
+    S = REF["LisSettings"]
+    S.options.clear()
+    S.options.update(InitLisflood=False, cropsEPIC=False, drainedIrrigation=False, simulatePF=False,
+                     TransientLandUseChange=False, readNetcdfStack=False)
+    S.landuse_inputmap = OrderedDict(zip(SOIL_USES, ["OtherFraction", "ForestFraction", "IrrigationFraction"]))   # settings.py:343
+    S.vegetation_landuse = dict(zip(PRESCRIBED, SOIL_USES))
+    M = REF["MaskInfo"]
+    M.n = N
+    M.info = types.SimpleNamespace(mask=~mask, mapC=(N,))
+    v = model_var(N)
+    v.coord_vegetation = OrderedDict([v.dim_vegetation, v.dim_pixel])
+    v.coord_prescribed_vegetation = OrderedDict([v.dim_vegetation, v.dim_pixel])
+    v.coord_landuse = OrderedDict([v.dim_landuse, v.dim_pixel])
+    v.allocateVariableAllVegetation = lambda dtype=float: v.allocateDataArray(v.coord_vegetation, dtype)   # Lisflood_initial.py:333
+
+    def backup(name, values=None):                       # add1.py:91-99
+        if name is None:
+            return values
+        return loadmap(name) if isinstance(name, str) else name
+
+    def defsoil(n1, n2=None, n3=None, coords=None):      # Lisflood_initial.py:371-391
+        data = v.allocateDataArray(v.coord_landuse if coords is None else coords)
+        first = backup(n1)
+        data.values[0][:] = first
+        data.values[1][:] = backup(n2, first)
+        data.values[2][:] = backup(n3, first)
+        return data
+    v.defsoil = defsoil
+    for k in ("DtSec", "DtDay", "InvDtDay", "PixelLength", "Beta"):
+        setattr(v, k, sc[k])
+    v.InvPixelLength, v.InvBeta, v.AlpPow, v.MMtoM = 1 / v.PixelLength, 1 / v.Beta, 2.0 / 3.0 * v.Beta, 0.001   # miscInitial.py:75-108
+    mods = {k: REF[k] for k in ("soil", "groundwater", "surface")}
+    mods["landuse"] = importlib.import_module("lisflood.hydrological_modules.landusechange")
+    for m in mods.values():
+        for n, f in (("loadmap", loadmap), ("loadmap_base", loadmap), ("makenumpy", lambda x: x if isinstance(x, np.ndarray) else np.full(N, float(x))),
+                     ("NumpyModified", lambda a, dims=None: VA(np.array(a, dtype=float), dims))):
+            if n in vars(m):
+                setattr(m, n, f)
+    with np.errstate(all="ignore"):
+        mods["landuse"].landusechange(v).initial()                               # Lisflood_initial.py: landusechange first
+        v.GwLoss = loadmap("GwLoss")                                             # miscInitial.py:117-133
+        v.GwPerc = np.maximum(loadmap("GwPercValue"), v.GwLoss)
+        v.GwPercStep, v.GwLossStep = v.GwPerc * v.DtDay, v.GwLoss * v.DtDay
+        mods["soil"].soil(v).initial()
+        mods["groundwater"].groundwater(v).initial()
+        mods["surface"].surface_routing(v).initial()
+    kgb = 0.75 * loadmap("kdf")                                                  # leafarea.py:48
+    LAIX = np.stack([np.stack([B[n][i][mask].astype(float) for n in ("LAIOtherMaps", "LAIForestMaps", "LAIIrrigationMaps")])
+                     for i in range(36)])                                        # leafarea.py:59-64
+    S.options.clear()
+    return v, LAIX, kgb
+
+
+def gen_long():
+    values, sc, st, mask, ldd_to_chan, cut, _, _ = chain_inputs()
+    N = int(mask.sum())
+    rng = np.random.default_rng(6060)
+    v0, LAIX, kgb = real_land_surface(mask, sc)
+    # every land-surface vector of the chain from the reference's initialisation (names as the module methods read them)
+    real = {}
+    for k in list(values):
+        if hasattr(v0, k) and k not in ("IsChannel", "IsChannelKinematic", "PixelArea"):
+            a = np.array(getattr(v0, k))
+            if a.shape == np.shape(values[k]) or (a.ndim == 0 and np.ndim(values[k]) == 1):
+                real[k] = np.broadcast_to(a, np.shape(values[k])).astype(np.asarray(values[k]).dtype).copy()
+    seeded_left = [k for k in values if k not in real and np.ndim(values[k]) >= 1 and not k.startswith(("Chan", "Inv", "QLimit", "M3Limit"))]
+    values.update(real)
+    sc = dict(sc, LeafDrainageK=float(v0.LeafDrainageK), AvWaterThreshold=float(v0.AvWaterThreshold),
+              CourantCrit=float(v0.CourantCrit), DrainedFraction=float(v0.DrainedFraction))
+    values["PowerInfPot"] = np.array(v0.PowerInfPot)
+    values["SMaxSealed"] = np.full(N, float(v0.SMaxSealed))
+    # transient outputs start from zero, as the reference allocates them
+    for k in ("AvailableWaterForInfiltration", "ESAct", "PrefFlow", "Infiltration", "Theta1a", "Theta1b", "Theta2", "Sat1a", "Sat1b",
+              "Sat1", "Sat2", "SeepTopToSubA", "SeepTopToSubB", "SeepSubToGW", "UZOutflow", "GwPercUZLZ", "TaInterception",
+              "potential_transpiration", "RWS", "Ta", "LeafDrainage", "Interception", "ESMax"):
+        values[k] = np.zeros((3, N))
+    for k in ("LZInflowCUM", "TaInterceptionCUM", "TaCUM", "ESActCUM", "GwLossCUM"):
+        values[k] = np.zeros(N)
+    met = np.load(os.path.join(HERE, "etrs89_meteo_long.npz"))
+    f32 = lambda a: np.asarray(a, np.float32).astype(np.float64)          # every forcing value is a float32 (as the files store it)
+    # stand-in for frost.py: soil frozen where the first ten days are colder than -3 degC on average
+    values["isFrozenSoil"] = met["ta"][:40].mean(0) < -3.0
+    forcing, lai_idx = [], []
+    for s in range(LONG_STEPS):
+        rain = 4.0 * met["pr"][s].astype(np.float64)
+        if s in (3, 4, 5, 40, 41, 42, 43):
+            rain = rain + rng.uniform(0.0, 45.0 if s < 10 else 70.0, N) * (rng.random(N) < 0.35)
+        ta = met["ta"][s].astype(np.float64)
+        f = dict(Rain=f32(rain), EWRef=f32(met["e0"][s]), ETRef=f32(met["et"][s]), ESRef=f32(met["es"][s]),
+                 SnowMelt=f32(np.where((ta > 0) & (ta < 3), 0.8 * ta, 0.0)))
+        forcing.append(f)
+        day = 1 + s                                                        # daily steps from 1 January
+        lai_idx.append(max(i for i in range(36) if day >= LAI_DAYS[i]))    # leafarea.py:66-72 (L1)
+    # transmission loss only on reaches that keep a discharge (transmission.py:76-87 takes a power of ChanQ**p - TransSub:
+    # NaN in the reference itself once a small channel falls dry): cells draining at least 40 pixels
+    uparea = np.load(os.path.join(HERE, "etrs89_initial.npz"))["out_UpArea"]
+    st["UpTrans"] = (rng.random(N) < 0.5) & (uparea >= 40 * 2.5e7)
+    pts = np.flatnonzero(st["QInM3Old"] == 0)[rng.choice(N, 6, replace=False)]
+    qin = np.zeros((LONG_STEPS, N))
+    base = rng.uniform(2e5, 4e6, 6)
+    for s in range(LONG_STEPS):
+        qin[s, pts] = base * (1.0 + 0.5 * np.sin(0.7 * s + np.arange(6))) * (3.0 if 38 <= s < 46 else 1.0)
+    # ---- the reference's module methods on one shared var, as gen_chain ----
+    opts = REF["LisSettings"].options
+    opts.clear()
+    opts.update(InitLisflood=False, SplitRouting=True, simulateLakes=True, simulateReservoirs=True, TransLoss=True,
+                inflow=True, repMBTs=True)
+    REF["MaskInfo"].n = N
+    REF["LisSettings"].soil_uses = SOIL_USES[:]
+    REF["LisSettings"].vegetation_landuse = dict(zip(PRESCRIBED, SOIL_USES))
+    v = model_var(N)
+    vn, ln = ["vegetation", "pixel"], ["landuse", "pixel"]
+    V_NAMES = set(syn.SOIL_WRITTEN) | {"LeafDrainage", "Interception", "LAI", "LAITerm", "CumInterception", "TaInterception",
+                                      "potential_transpiration", "RWS", "Ta", "SoilFraction"}
+    for k, a in values.items():
+        a = np.array(a, copy=True)
+        if a.ndim == 2:
+            a = VA(a, vn if k in V_NAMES else (["runoff", "pixel"] if k == "OFAlpha" else ln))
+        setattr(v, k, a)
+    for k, a in sc.items():
+        setattr(v, k, a)
+    for k, a in st.items():
+        setattr(v, k, np.array(a, copy=True) if isinstance(a, np.ndarray) else a)
+    v.NoRoutSteps = int(v.NoRoutSteps)
+    v.InvBeta, v.InvPixelLength, v.InvDtSec = 1 / v.Beta, 1 / v.PixelLength, 1 / v.DtSec
+    v.InvDtRouting, v.InvNoRoutSteps = 1 / v.DtRouting, 1 / v.NoRoutSteps
+    v.LakeSitesC2 = np.zeros(N); v.LakeSitesC2[v.LakeIndex] = 1.0
+    v.ReservoirSitesC = np.zeros(N); v.ReservoirSitesC[v.ReservoirIndex] = 1.0
+    v.WPF3a, v.WPF3b = VA(np.array(v0.WPF3a), ln), VA(np.array(v0.WPF3b), ln)
+    v.SoilMoistureStressDays = VA(np.zeros((3, N)), vn)
+    v.Theta = VA(np.zeros((3, N)), vn)
+    v.deffraction = lambda variable: (np.asarray(v.SoilFraction) * np.asarray(variable)).sum(0)
+    v.SMaxSealed = float(v0.SMaxSealed)
+    v.sumDis = np.zeros(N)
+    m_loop = REF["soilloop"].soilloop(v); m_loop.initial()
+    m_open, m_soil, m_gw = REF["opensealed"].opensealed(v), REF["soil"].soil(v), REF["groundwater"].groundwater(v)
+    m_surf = REF["surface"].surface_routing(v)
+    mk = lambda i: kwp.kinematicWave(ldd_to_chan.copy(), mask.copy(), v.OFAlpha.values[i], v.Beta, v.PixelLength, v.DtSec)
+    m_surf.other_surface_router, m_surf.forest_surface_router, m_surf.direct_surface_router = mk(0), mk(1), mk(2)
+    m_rout = REF["routing"].routing(v)
+    m_rout.river_router = kwp.kinematicWave(cut.copy(), mask.copy(), v.ChannelAlpha, v.Beta, v.ChanLength, v.DtRouting,
+                                            alpha_floodplains=v.ChannelAlpha2)
+    m_rout.lakes_module = REF["lakes"].lakes(v)
+    m_rout.reservoir_module = REF["reservoir"].reservoir(v)
+    m_inflow = m_rout.inflow_module = REF["inflow"].inflow(v)
+    m_rout.transmission_module = REF["transmission"].transmission(v)
+    m_rout.polder_module = types.SimpleNamespace(dynamic_inloop=lambda *a, **k: None)
+    gauges = np.flatnonzero(np.load(os.path.join(HERE, "etrs89_static.npz"))["outlets"][mask] > 0)
+    site_keys = ("LakeStorageM3CC", "LakeOutflowCC", "LakeLevelCC", "ReservoirStorageM3CC", "ReservoirFillCC")
+    snap_n = ("LZ", "ChanQKin", "Chan2QKin", "ChanM3", "sumDis", "OFQOther", "TransCum", "CumInterSealed", "UZOutflowPixel")
+    snap_v = ("W1a", "W1b", "W2", "UZ", "DSLR", "CumInterception")
+    every10 = [s for s in range(LONG_STEPS) if s % 10 == 9] + [LONG_STEPS - 1]
+    thirds = [0, LONG_STEPS // 2, LONG_STEPS - 1]
+    dis, sites = [], {k: [] for k in site_keys}
+    snapn, snapv = {k: [] for k in snap_n}, {k: [] for k in snap_v}
+    nsub_multi = 0
+    with np.errstate(all="ignore"):
+        for s in range(LONG_STEPS):
+            for k, a in forcing[s].items():
+                setattr(v, k, a.copy())
+            v.TimeSinceStart = float(s + 1)
+            lai = LAIX[lai_idx[s]]
+            v.LAI = VA(lai.copy(), vn)                                    # leafarea.py:80-91
+            v.LAITerm = VA(np.exp(-kgb * lai), vn)
+            def finite(stage):
+                bad = [k for k, a in vars(v).items() if isinstance(a, np.ndarray) and a.dtype.kind == "f" and not np.isfinite(a).all()]
+                assert not bad, (s, stage, bad)
+            m_loop.dynamic_canopy(); finite("canopy")
+            m_loop.dynamic_soil(); finite("soil")
+            m_open.dynamic()
+            m_soil.dynamic_perpixel()
+            m_gw.dynamic(); finite("per-pixel")
+            m_surf.dynamic(); finite("overland")
+            v.QInM3 = qin[s].copy()
+            m_inflow.dynamic_init()
+            v.sumDisDay = np.zeros(N)
+            for sub in range(v.NoRoutSteps):
+                m_rout.dynamic(sub)
+            finite("channel")
+            v.QInM3Old = v.QInM3
+            v.ChanM3 = v.ChanM3Kin + v.Chan2M3Kin - v.Chan2M3Start
+            v.TotalCrossSectionArea = v.ChanM3 * v.InvChanLength
+            v.sumDis += v.sumDisDay
+            v.ChanQAvg = v.sumDisDay / v.NoRoutSteps
+            dis.append(np.array(v.ChanQAvg, dtype=np.float64))
+            for k in site_keys:
+                sites[k].append(np.array(getattr(v, k), dtype=np.float64).copy())
+            if s in every10:
+                for k in snap_n:
+                    snapn[k].append(np.array(getattr(v, k), dtype=np.float64).copy())
+            if s in thirds:
+                for k in snap_v:
+                    snapv[k].append(np.array(getattr(v, k), dtype=np.float64).copy())
+    dis = np.array(dis)
+    fill = np.array(sites["ReservoirFillCC"])                              # [steps, reservoirs]
+    lims = [np.asarray(st[k], float) / np.asarray(st["TotalReservoirStorageM3CC"], float) if k.endswith("M3CC") else np.asarray(st[k], float)
+            for k in ("ConservativeStorageLimitCC", "NormalStorageLimitCC", "FloodStorageLimitCC")]
+    regime = sum((fill > l[None, :]).astype(int) for l in lims)            # 0..3: which storage regime a reservoir is in
+    crossed = int((regime.max(0) != regime.min(0)).sum())
+    print("  steps=%d N=%d gauges=%d dis max=%.1f  reservoirs changing storage regime: %d of %d (regimes seen: %s)  frozen pixels: %d"
+          % (LONG_STEPS, N, gauges.size, dis.max(), crossed, fill.shape[1], sorted(set(regime.ravel().tolist())), int(values["isFrozenSoil"].sum())))
+    print("  still seeded (not from the reference's initialisation):", seeded_left)
+    assert np.isfinite(dis).all() and dis.max() > 10 and crossed >= 1
+    out = {"val_" + k: np.asarray(a) for k, a in values.items() if k not in ("LAI", "LAITerm")}
+    out.update({"sc_" + k: np.float64(a) for k, a in sc.items()})
+    out.update({"st_" + k: np.asarray(a) for k, a in st.items()})
+    for name in forcing[0]:
+        out["forc_" + name] = np.array([f[name] for f in forcing], dtype=np.float32)
+    used = sorted(set(lai_idx))
+    save("etrs89_long", mask=mask, ldd_to_chan=ldd_to_chan, ldd_cut=cut, QInM3_points=pts, QInM3_values=qin[:, pts],
+         lai_interval_of_step=np.array([used.index(i) for i in lai_idx]), LAI=np.array([LAIX[i] for i in used]), kgb=np.float64(kgb),
+         gauges=gauges, out_dis=dis, snap_steps=np.array(every10), snapv_steps=np.array(thirds),
+         **out, **{"site_" + k: np.array(a) for k, a in sites.items()},
+         **{"snap_" + k: np.array(a) for k, a in snapn.items()}, **{"snapv_" + k: np.array(a) for k, a in snapv.items()})
+    opts.clear()
+
+
 def gen_soil_pf():
     """soilloop.dynamic_soil with option simulatePF (soilloop.py:630-704): the pF values of the three layers after one
     soil step, computed by the reference's own (un-jitted) suctionUnsaturatedSoilPF / pressureHead."""
@@ -1295,9 +1540,9 @@ def gen_ldd_ops():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["graphs", "routes", "edge", "substeps", "upsum", "interception", "soil", "surface",
-                             "canopy", "canopy_options", "inloop", "pixel", "chain", "pf", "initial", "prerun", "ldd_ops"]
+                             "canopy", "canopy_options", "inloop", "pixel", "chain", "pf", "initial", "prerun", "ldd_ops", "long"]
     fns = dict(graphs=gen_graphs, routes=gen_routes, edge=gen_route_edge, substeps=gen_substeps,
                upsum=gen_upstream_sum, interception=gen_interception, soil=gen_soil_columns,
-               surface=gen_surface_step, canopy=gen_canopy_soil_step, canopy_options=gen_canopy_options, inloop=gen_inloop, pixel=gen_pixel_aggregates, chain=gen_chain, pf=gen_soil_pf, initial=gen_initial, prerun=gen_prerun, ldd_ops=gen_ldd_ops)
+               surface=gen_surface_step, canopy=gen_canopy_soil_step, canopy_options=gen_canopy_options, inloop=gen_inloop, pixel=gen_pixel_aggregates, chain=gen_chain, pf=gen_soil_pf, initial=gen_initial, prerun=gen_prerun, ldd_ops=gen_ldd_ops, long=gen_long)
     for w in which:
         fns[w]()

@@ -316,3 +316,84 @@ def test_warm_start_from_reference_named_state_maps(amd, tmp_path):
         close(c.download(k), want, 1e-12, ("cold", k))
     assert (c.download("OFQOther") == 0).all()
     a.free(); b.free(); c.free()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Row N1, long form (tests/golden/etrs89_long.npz, make_golden.py `long`): 72 model steps, the land surface initialised
+# by the reference's OWN soil / groundwater / landusechange / surface_routing initial() from what cold.xml binds (no
+# seeded soil parameter left), LAI from the use case's ten-day stack, two storms: 10 of the 31 reservoirs move between
+# storage regimes inside the window.  `dis` of every step, the lake / reservoir series of every step, state snapshots
+# every tenth step.
+# ---------------------------------------------------------------------------------------------------------------------
+def long_fixture():
+    g = golden("etrs89_long")
+    values = {k[4:]: g[k] for k in g.files if k.startswith("val_")}
+    sc = {k[3:]: float(g[k]) for k in g.files if k.startswith("sc_")}
+    st = {k[3:]: (g[k] if g[k].ndim else float(g[k])) for k in g.files if k.startswith("st_")}
+    nsteps, N = g["out_dis"].shape
+    forcing = [{k[5:]: g[k][s] for k in g.files if k.startswith("forc_")} for s in range(nsteps)]    # float32, as stored
+    qin = np.zeros((nsteps, N))
+    qin[:, g["QInM3_points"]] = g["QInM3_values"]
+    lai = [g["LAI"][i] for i in g["lai_interval_of_step"]]
+    laiterm = [np.exp(-float(g["kgb"]) * x) for x in lai]                        # leafarea.py:91
+    values["LAI"], values["LAITerm"] = lai[0].copy(), laiterm[0].copy()
+    return g, values, sc, st, forcing, qin, lai, laiterm
+
+
+def test_oracle_chain_reproduces_the_long_reference_chain():
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    from oracle_chain import OracleChain
+    g, values, sc, st, forcing, qin, lai, laiterm = long_fixture()
+    ch = OracleChain(values, sc, g["mask"], g["ldd_to_chan"], g["ldd_cut"], structures=st, split=True)
+    snap = list(g["snap_steps"])
+    worst = 0.0
+    for step, f in enumerate(forcing):
+        ch.v.LAI, ch.v.LAITerm = lai[step].copy(), laiterm[step].copy()
+        dis = ch.step({k: a.astype(np.float64) for k, a in f.items()}, qin[step])
+        want = g["out_dis"][step]
+        worst = max(worst, float(np.max(np.abs(dis - want) / np.maximum(np.abs(want), 1e-3))))
+        close(dis, want, 1e-9, (step, "dis"))
+        for k in ("LakeStorageM3CC", "ReservoirStorageM3CC", "ReservoirFillCC"):
+            close(getattr(ch.v, k), g["site_" + k][step], 1e-9, (step, k))
+        if step in snap:
+            for k in ("LZ", "ChanQKin", "Chan2QKin", "ChanM3", "sumDis", "OFQOther", "TransCum", "CumInterSealed"):
+                close(getattr(ch.v, k), g["snap_" + k][snap.index(step)], 1e-8, (step, k))
+    print("oracle chain, %d steps: max relative deviation of dis %.3e" % (len(forcing), worst))
+    assert worst < 1e-8
+    fill = g["site_ReservoirFillCC"]
+    assert ((fill.max(0) - fill.min(0)) > 0.02).sum() >= 5          # the reservoirs do move in the window
+
+
+@pytest.mark.gpu
+def test_hot_path_reproduces_the_long_reference_dis(amd):
+    """72 model steps of HotPathDevice on the reference-initialised LF_ETRS89 land surface: `dis` within 1e-6 relative
+    (north_star's bar; asserted at 1e-8) on every step, the lake / reservoir series on every step, the state snapshots."""
+    from lisflood_amd.hotpath import HotPathDevice
+    g, values, sc, st, forcing, qin, lai, laiterm = long_fixture()
+    hp = HotPathDevice(cp(values), sc, g["mask"], g["ldd_to_chan"], g["ldd_cut"], split=True, structures=cp(st))
+    snap, snapv = list(g["snap_steps"]), list(g["snapv_steps"])
+    idx = g["lai_interval_of_step"]
+    worst = 0.0
+    for step, f in enumerate(forcing):
+        if step == 0 or idx[step] != idx[step - 1]:
+            hp.set_lai(lai[step], laiterm[step])                                 # leafarea.dynamic, once per interval
+        hp.step(f, time_since_start=step + 1, QInM3=qin[step])                  # float32 forcing: widened on the device
+        dis = hp.chan_q_avg()
+        want = g["out_dis"][step]
+        worst = max(worst, float(np.max(np.abs(dis - want) / np.maximum(np.abs(want), 1e-3))))
+        close(dis, want, 1e-8, (step, "dis"))
+        close(dis[g["gauges"]], want[g["gauges"]], 1e-8, (step, "dis at the gauges"))
+        for k in ("LakeStorageM3CC", "LakeOutflowCC", "LakeLevelCC", "ReservoirStorageM3CC", "ReservoirFillCC"):
+            close(hp.download_site(k), g["site_" + k][step], 1e-8, (step, k))
+        if step in snap:
+            i = snap.index(step)
+            for k in ("LZ", "ChanQKin", "Chan2QKin", "OFQOther", "CumInterSealed", "UZOutflowPixel"):
+                close(hp.download(k), g["snap_" + k][i], SNAP_RTOL, (step, k))
+            close(hp.download_site("TransCum"), g["snap_TransCum"][i], SNAP_RTOL, (step, "TransCum"))
+        if step in snapv:
+            i = snapv.index(step)
+            for k in ("W1a", "W1b", "W2", "UZ", "DSLR", "CumInterception"):
+                close(hp.download(k), g["snapv_" + k][i], SNAP_RTOL, (step, k))
+    print("max relative deviation of dis over %d steps: %.3e" % (len(forcing), worst))
+    assert worst < 1e-6
+    hp.free()
