@@ -377,6 +377,16 @@ typedef struct lf_canopy_args {
     int64_t irrigated_veg;
 } lf_canopy_args;
 int lf_canopy_device(int device, const lf_canopy_args *a);
+/* The land surface of a model step in ONE pass over the columns: dynamic_canopy (soilloop.py:519-627), ESMax = ESRef *
+ * LAITerm (:638) and soilColumnsWaterBalance (:78-355) -- the lane that runs a column's canopy carries LeafDrainage,
+ * Interception, W1a / W1b / W1 and ESMax into the column's soil water balance in registers (Lisflood_dynamic.py:114-123
+ * calls the two methods back to back; nothing reads the vectors in between).  Bit-identical to lf_canopy_device +
+ * lf_scale_rows_device + lf_soil_columns_device (derived != 0: _derived).  `canopy` and `soil` must describe the same
+ * columns: V = L, same N, index_landuse[v] == v in both, no paddy fraction, and the vectors both structs name (W1a, W1b,
+ * W1, Interception, LeafDrainage, Rain, isFrozenSoil, WWP1a/b, WFC1a/b) must be the same device vectors -- LF_E_INVALID
+ * otherwise (use the separate entry points then).  soil->ESMax is not read; ESRef_dev is the [N] vector. */
+int lf_land_columns_device(int device, const lf_canopy_args *canopy, const lf_soil_args *soil, const double *ESRef_dev,
+                           int derived);
 
 /* suctionUnsaturatedSoilPF + pressureHead (soilloop.py:427-432, 673-695; option simulatePF): pF = log10 of the capillary
  * head of the three soil layers, -1 where the head is not positive.  [V,N] by vegetation row, [L,N] by land-use row. */

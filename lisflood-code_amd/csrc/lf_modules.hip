@@ -6,6 +6,7 @@
 #include <cmath>
 
 #include "lf_common.h"
+#include "lf_canopy.h"
 #include "lf_math.h"
 #include "lf_structures.h"
 
@@ -31,87 +32,13 @@ __global__ void __launch_bounds__(kBlock) k_canopy(lf_canopy_args A, veg_map M)
     if (pix >= N) return;
     const double rain = A.Rain[pix], ewref = A.EWRef[pix], etref = A.ETRef[pix];
     const bool frozen = A.isFrozenSoil[pix] != 0;
-    for (int veg = 0; veg < (int)A.V; ++veg) {
+    for (int veg = 0; veg < (int)A.V; ++veg) { // the body of a column: lf_canopy.h (shared with the land-surface form of the soil kernel)
         const long long i = (long long)veg * N + pix;
         const long long j = (long long)M.landuse[veg] * N + pix;
-        // --- interception (soilloop.py:531-544, kernel 27-70) ---
-        const double one_minus_lt = 1. - A.LAITerm[i];       // :531
-        const double ta_max = ewref * one_minus_lt;           // :532
-        const double lai = A.LAI[i];
-        double smax;
-        if (lai <= .1)
-            smax = 0.;
-        else if (lai <= 43.3)
-            smax = 0.935 + 0.498 * lai - 0.00575 * (lai * lai);
-        else
-            smax = 11.718;
-        double cum = A.CumInterception[i], inter;
-        if (smax > 0) {
-            double v = smax - cum;
-            v = dmin(v, smax * (1. - exp(-0.046 * lai * rain / smax)));
-            v = dmin(v, rain);
-            inter = v;
-            cum += inter;
-        } else
-            inter = 0.;
-        double ta_int, drain;
-        if (cum > 0.) {
-            ta_int = dmax(dmin(cum, ta_max), 0.);
-            cum = dmax(cum - ta_int, 0.);
-            drain = A.LeafDrainageK * cum;
-            cum = dmax(cum - drain, 0.);
-        } else {
-            ta_int = 0.;
-            drain = 0.;
-        }
-        A.Interception[i] = inter;
-        A.TaInterception[i] = ta_int;
-        A.LeafDrainage[i] = drain;
-        A.CumInterception[i] = cum;
-        // --- potential transpiration (:549-556) ---
-        const double transpir_max = A.CropCoef[j] * etref * one_minus_lt;
-        const double pot = npmax(transpir_max - ta_int, 0.);
-        A.potential_transpiration[i] = pot;
-        // --- water stress and abstraction (:564-627) ---
-        const double cgn = A.CropGroupNumber[j];
-        const double e = npmin(0.1 * etref * A.InvDtDay, 1.0);
-        double swdf = 1 / (0.76 + 1.5 * e) - 0.10 * (5 - cgn);
-        if (cgn <= 2.5) swdf = swdf + (e - 0.6) / (cgn * (cgn + 3));
-        swdf = npmax(npmin(swdf, 1.0), 0.);
-        const double wwp1 = A.WWP1[j], wwp1a = A.WWP1a[j], wwp1b = A.WWP1b[j];
-        const double wcrit1 = ((1 - swdf) * (A.WFC1[j] - wwp1)) + wwp1;
-        const double wcrit1a = ((1 - swdf) * (A.WFC1a[j] - wwp1a)) + wwp1a;
-        const double wcrit1b = ((1 - swdf) * (A.WFC1b[j] - wwp1b)) + wwp1b;
-        const double w1 = A.W1[j]; // the reference indexes W1 by the land-use row here (:592)
-        double rws = ((wcrit1 - wwp1) > 0) ? (w1 - wwp1) / (wcrit1 - wwp1) : 1.;
-        rws = npmax(npmin(rws, 1.), 0.);
-        A.RWS[i] = rws;
-        if (A.SoilMoistureStressDays) A.SoilMoistureStressDays[i] = (rws < 1) ? A.DtDay : 0.; // :597-598 (repStressDays)
-        if (A.WFilla && veg == (int)A.irrigated_veg) {                                          // :582-587 (wateruse)
-            A.WFilla[pix] = npmin(wcrit1a, A.WPF3a[j]);
-            A.WFillb[pix] = npmin(wcrit1b, A.WPF3b[j]);
-        }
-        const double transpirable = npmax(w1 - wwp1, 0.);
-        double ta = npmin(rws * pot, transpirable);
-        if (frozen) ta = 0.;
-        A.Ta[i] = ta;
-        double w1a = A.W1a[j], w1b = A.W1b[j];
-        const double wc1a = npmax(w1a - wcrit1a, 0.), wc1b = npmax(w1b - wcrit1b, 0.);
-        double ta1a = npmin(ta, wc1a);
-        double rest = npmax(ta - ta1a, 0.);
-        double ta1b = npmin(rest, wc1b);
-        rest = npmax(rest - ta1b, 0.);
-        const double sa = npmax(w1a - ta1a - wwp1a, 0.), sb = npmax(w1b - ta1b - wwp1b, 0.);
-        const double st = sa + sb;
-        const bool avail = st > 0;
-        const double fa = avail ? sa / st : 0., fb = avail ? sb / st : 0.;
-        ta1a += fa * rest;
-        ta1b += fb * rest;
-        w1a -= ta1a;
-        w1b -= ta1b;
-        A.W1a[j] = w1a;
-        A.W1b[j] = w1b;
-        A.W1[i] = w1a + w1b; // row of the vegetation fraction (:627)
+        const lf_canopy::column_out o = lf_canopy::column(A, veg, pix, i, j, rain, ewref, etref, frozen);
+        A.W1a[j] = o.w1a;
+        A.W1b[j] = o.w1b;
+        A.W1[i] = o.w1;
     }
 }
 

@@ -12,6 +12,7 @@
 #include <cstdlib>
 
 #include "lf_common.h"
+#include "lf_canopy.h"
 #include "lf_math.h"
 
 namespace {
@@ -257,10 +258,16 @@ struct soil_strag {
 // GenuInvM = 1 / GenuM, WS1 = WS1a + WS1b and the same for WRes1 / WFC1 / WWP1, PoreSpaceNotZero = depth != 0 and WS != 0;
 // one IEEE operation each, so the same bits) -- 59 of the 526 bytes a column reads and writes.  The caller vouches for the
 // relations (lf_soil_columns_device_derived); the ten pointers are not touched.
-template <bool FASTPOW, bool DERIVED>
+// CANOPY (the land-surface form, lf_land_columns_device): the lane first runs soilloop.dynamic_canopy for its column
+// (lf_canopy.h -- interception, potential transpiration, water stress, abstraction of transpiration from layers 1a / 1b)
+// and carries what the soil water balance reads of it -- LeafDrainage, Interception, W1a, W1b, W1 and ESMax = ESRef *
+// LAITerm (soilloop.py:638) -- in registers instead of through HBM: the canopy's 24 streams per column shrink to the 12 the
+// soil part does not read anyway, inside a kernel whose sub-step arithmetic leaves the memory system idle part of the time.
+// Requires index_landuse[veg] == veg (a column's canopy and soil rows coincide) and every fraction active (mode 1).
+template <bool FASTPOW, bool DERIVED, bool CANOPY>
 __global__ void __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(3)))
 k_soil_fused(lf_soil_args A, veg_plan P, unsigned short *__restrict__ all_list, unsigned int *__restrict__ all_count,
-             soil_strag G, unsigned int tile0, unsigned int tiles_per_veg)
+             soil_strag G, unsigned int tile0, unsigned int tiles_per_veg, lf_canopy_args C, const double *__restrict__ ESRef)
 {
     constexpr int kLoopCap = kTile / 2; // multi-sub-step columns of a tile handled per round (more -> another round)
     __shared__ unsigned int s_count, s_next, s_all, s_strag;
@@ -298,10 +305,22 @@ k_soil_fused(lf_soil_args A, veg_plan P, unsigned short *__restrict__ all_list, 
     if (active) {
         // every input of the column before any arithmetic: ~50 independent loads in flight per lane (the kernel is a
         // stream of ~70 vectors; memory-level parallelism, not ALU, sets the speed of this phase)
-        const double in_rain = A.Rain[pix], in_snow = A.SnowMelt[pix], in_leaf = A.LeafDrainage[i], in_int = A.Interception[i];
-        const double in_dslr = A.DSLR[i], in_w1a = A.W1a[i], in_w1b = A.W1b[i], in_w1 = A.W1[i], in_w2 = A.W2[i];
+        const double in_rain = A.Rain[pix], in_snow = A.SnowMelt[pix];
+        double in_leaf, in_int, in_w1a, in_w1b, in_w1, in_esmax;
+        if (CANOPY) {
+            const lf_canopy::column_out o = lf_canopy::column(C, veg, pix, i, j, in_rain, C.EWRef[pix], C.ETRef[pix],
+                                                              A.isFrozenSoil[pix] != 0);
+            in_leaf = o.leaf_drainage; in_int = o.interception;
+            in_w1a = o.w1a; in_w1b = o.w1b; in_w1 = o.w1;
+            in_esmax = ESRef[pix] * C.LAITerm[i];                              // soilloop.py:638
+        } else {
+            in_leaf = A.LeafDrainage[i]; in_int = A.Interception[i];
+            in_w1a = A.W1a[i]; in_w1b = A.W1b[i]; in_w1 = A.W1[i];
+            in_esmax = A.ESMax[i];
+        }
+        const double in_dslr = A.DSLR[i], in_w2 = A.W2[i];
         const double in_uz = A.UZ[i];
-        const double in_esmax = A.ESMax[i], in_store = A.StoreMaxPervious[j];
+        const double in_store = A.StoreMaxPervious[j];
         const double in_bx = A.b_Xinanjiang[pix], in_pinf = A.PowerInfPot[pix], in_ppref = A.PowerPrefFlow[pix];
         const double in_uzk = A.UpperZoneK[pix];
         T.gwp = A.GwPercStep[pix];
@@ -712,7 +731,8 @@ int lf_soil_substep_histogram(int device, int64_t *hist, int nbins)
     return LF_OK;
 }
 
-static int soil_columns_device(int device, const lf_soil_args *a, bool derived);
+static int soil_columns_device(int device, const lf_soil_args *a, bool derived, const lf_canopy_args *canopy = nullptr,
+                               const double *esref = nullptr);
 
 int lf_soil_columns_device(int device, const lf_soil_args *a) { return soil_columns_device(device, a, false); }
 
@@ -720,7 +740,33 @@ int lf_soil_columns_device(int device, const lf_soil_args *a) { return soil_colu
 // derived ones (GenuInvM1a/1b/2, WS1, WRes1, WFC1, WWP1, PoreSpaceNotZero1a/1b/2) are not read and may be NULL.
 int lf_soil_columns_device_derived(int device, const lf_soil_args *a) { return soil_columns_device(device, a, true); }
 
-static int soil_columns_device(int device, const lf_soil_args *a, bool derived)
+// The land surface of a model step in one pass: soilloop.dynamic_canopy (soilloop.py:519-627), ESMax = ESRef * LAITerm
+// (:638) and soilColumnsWaterBalance (:78-355) -- k_soil_fused<.., CANOPY> + k_soil_stragglers.  `canopy` and `soil` must
+// describe the same columns: same V = L, N, identity land-use rows, no paddy fraction, and the vectors both name (W1a, W1b,
+// W1, Interception, LeafDrainage, Rain, isFrozenSoil, the WWP / WFC parameters) must be the SAME device vectors; soil->ESMax
+// is not read.  Same results, bit for bit, as lf_canopy_device + lf_scale_rows_device + lf_soil_columns_device[_derived].
+int lf_land_columns_device(int device, const lf_canopy_args *canopy, const lf_soil_args *soil, const double *ESRef_dev, int derived)
+{
+    if (!canopy || !soil || !ESRef_dev || !canopy->index_landuse || !soil->index_landuse_all)
+        return lf_set_error(LF_E_INVALID, "null argument");
+    if (canopy->V != soil->V || canopy->N != soil->N || canopy->L != soil->L || soil->V != soil->L)
+        return lf_set_error(LF_E_INVALID, "land columns: canopy and soil must have the same V = L and N");
+    for (int v = 0; v < (int)soil->V; ++v)
+        if (canopy->index_landuse[v] != v || soil->index_landuse_all[v] != v || (soil->is_paddy_irrig && soil->is_paddy_irrig[v]))
+            return lf_set_error(LF_E_INVALID, "land columns: needs index_landuse[v] == v and no paddy fraction (use the "
+                                "separate entry points otherwise)");
+    if ((canopy->WFilla || canopy->WFillb) && (!canopy->WFilla || !canopy->WFillb || !canopy->WPF3a || !canopy->WPF3b))
+        return lf_set_error(LF_E_INVALID, "wateruse: WFilla, WFillb, WPF3a and WPF3b are needed together");
+    const bool same = canopy->W1a == soil->W1a && canopy->W1b == soil->W1b && canopy->W1 == soil->W1 &&
+                      canopy->Interception == soil->Interception && canopy->LeafDrainage == soil->LeafDrainage &&
+                      canopy->Rain == soil->Rain && canopy->isFrozenSoil == soil->isFrozenSoil &&
+                      canopy->WWP1a == soil->WWP1a && canopy->WWP1b == soil->WWP1b && canopy->WFC1a == soil->WFC1a &&
+                      canopy->WFC1b == soil->WFC1b;
+    if (!same) return lf_set_error(LF_E_INVALID, "land columns: canopy and soil arguments name different vectors");
+    return soil_columns_device(device, soil, derived != 0, canopy, ESRef_dev);
+}
+
+static int soil_columns_device(int device, const lf_soil_args *a, bool derived, const lf_canopy_args *canopy, const double *esref)
 {
     if (!a || !a->index_landuse_all) return lf_set_error(LF_E_INVALID, "null argument");
     lf_device_ctx *c;
@@ -765,14 +811,23 @@ static int soil_columns_device(int device, const lf_soil_args *a, bool derived)
     size_t dyn = 0; // LF_SOIL_DEBUG_LDS=<bytes>: extra LDS per workgroup, to bound the tiles in flight per compute unit (timing experiments)
     if (const char *e = std::getenv("LF_SOIL_DEBUG_LDS")) dyn = (size_t)std::atol(e);
     if (const char *e = std::getenv("LF_SOIL_NO_DERIVED")) derived = derived && e[0] != '1'; // A/B switch
-    if (fastpow && derived)
-        hipLaunchKernelGGL((k_soil_fused<true, true>), grid, block, dyn, c->stream, *a, P, all_list, all_count, G, 0u, tiles_per_veg);
-    else if (fastpow)
-        hipLaunchKernelGGL((k_soil_fused<true, false>), grid, block, dyn, c->stream, *a, P, all_list, all_count, G, 0u, tiles_per_veg);
-    else if (derived)
-        hipLaunchKernelGGL((k_soil_fused<false, true>), grid, block, dyn, c->stream, *a, P, all_list, all_count, G, 0u, tiles_per_veg);
-    else
-        hipLaunchKernelGGL((k_soil_fused<false, false>), grid, block, dyn, c->stream, *a, P, all_list, all_count, G, 0u, tiles_per_veg);
+    lf_canopy_args C{};
+    if (canopy) C = *canopy;
+#define LF_SOIL_LAUNCH(FP, DR, CN)                                                                                        \
+    hipLaunchKernelGGL((k_soil_fused<FP, DR, CN>), grid, block, dyn, c->stream, *a, P, all_list, all_count, G, 0u,       \
+                       tiles_per_veg, C, esref)
+    if (canopy) {
+        if (fastpow && derived) LF_SOIL_LAUNCH(true, true, true);
+        else if (fastpow) LF_SOIL_LAUNCH(true, false, true);
+        else if (derived) LF_SOIL_LAUNCH(false, true, true);
+        else LF_SOIL_LAUNCH(false, false, true);
+    } else {
+        if (fastpow && derived) LF_SOIL_LAUNCH(true, true, false);
+        else if (fastpow) LF_SOIL_LAUNCH(true, false, false);
+        else if (derived) LF_SOIL_LAUNCH(false, true, false);
+        else LF_SOIL_LAUNCH(false, false, false);
+    }
+#undef LF_SOIL_LAUNCH
     if (G.trip_cap > 0) {
         const dim3 grid2((unsigned)((ntiles + kStragGroup - 1) / kStragGroup));
         if (fastpow)

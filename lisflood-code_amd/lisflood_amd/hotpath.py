@@ -29,7 +29,7 @@ _CHANNEL_NAMES = set(RT._STATIC + RT._STATE + RT._OUT)
 
 class HotPathDevice:
     def __init__(self, values, scalars, land_mask, ldd_to_chan, ldd_kinematic, split=True, device=0, structures=None,
-                 compact=True, overlap_channel=True, surface_order=True):
+                 compact=True, overlap_channel=True, surface_order=True, land_fused=None):
         """values: name -> host array in pixel order ([N], [3,N]) for every vector of the stages (reference
         attribute names); scalars: Beta, DtSec, DtRouting, NoRoutSteps, DtDay, PixelLength, MMtoM3, M3toMM,
         LeafDrainageK, AvWaterThreshold, CourantCrit, DrainedFraction, InvDtDay.  ldd_to_chan / ldd_kinematic:
@@ -51,6 +51,11 @@ class HotPathDevice:
         self.rmod = None
         # the ten derived soil parameter arrays recomputed instead of read where they are what soil.py:180-228 makes them
         self.soil_derived = SL.derived_parameters_hold(values)
+        # land_fused: canopy + ESMax + soil columns as ONE pass over the columns (lf_land_columns_device; the three prescribed
+        # fractions map to their own land-use rows, which is what it needs).  None: on, unless LF_LAND_FUSED=0 (A/B switch);
+        # False: the three separate launches of rounds 1-5 -- same bits either way
+        import os
+        self.land_fused = (os.environ.get("LF_LAND_FUSED", "1") != "0") if land_fused is None else bool(land_fused)
         self.sc = dict(scalars)
         land_mask = np.asarray(land_mask, bool)
         self.N = N = int(land_mask.sum())
@@ -332,13 +337,20 @@ class HotPathDevice:
                 if stage_ms is not None and exc[0] is None:
                     stage_ms[self.name] = stage_ms.get(self.name, 0.0) + LB.timer_stop(dev)
                 return False
-        with stage("canopy"):
-            check(L.lf_canopy_device(C.c_int(dev), C.byref(self.canopy)))                               # dyn.py:114
-            check(L.lf_scale_rows_device(C.c_int(dev), d["ESRef"].ptr, d["LAITerm"].ptr, d["ESMax"].ptr,
-                                         C.c_int64(3), C.c_int64(self.N)))                             # soilloop.py:638
-        with stage("soil_columns"):
-            soil_fn = L.lf_soil_columns_device_derived if self.soil_derived else L.lf_soil_columns_device
-            check(soil_fn(C.c_int(dev), C.byref(self.soil)))                                            # dyn.py:123
+        if self.land_fused:
+            # canopy, ESMax and the soil columns in ONE pass (k_soil_fused<.., CANOPY>): the lane that runs a column's canopy
+            # carries LeafDrainage / Interception / W1a / W1b / W1 / ESMax into its soil water balance in registers
+            with stage("land_surface"):
+                check(L.lf_land_columns_device(C.c_int(dev), C.byref(self.canopy), C.byref(self.soil), d["ESRef"].ptr,
+                                               C.c_int(1 if self.soil_derived else 0)))                 # dyn.py:114-123
+        else:
+            with stage("canopy"):
+                check(L.lf_canopy_device(C.c_int(dev), C.byref(self.canopy)))                           # dyn.py:114
+                check(L.lf_scale_rows_device(C.c_int(dev), d["ESRef"].ptr, d["LAITerm"].ptr, d["ESMax"].ptr,
+                                             C.c_int64(3), C.c_int64(self.N)))                         # soilloop.py:638
+            with stage("soil_columns"):
+                soil_fn = L.lf_soil_columns_device_derived if self.soil_derived else L.lf_soil_columns_device
+                check(soil_fn(C.c_int(dev), C.byref(self.soil)))                                        # dyn.py:123
         self.steps_done += 1
         self.pixel.TimeSinceStart = float(time_since_start if time_since_start else self.steps_done)
         with stage("pixel_aggregates"):
@@ -405,8 +417,17 @@ class HotPathDevice:
         overland = N * (v8(SR._V_IN) + 2 * 24 + 8 * len(SR._N_IN) + 16 * len(sio) + 8 * len([k for k in SR._OUT if k not in sio])
                         + 3 * 48)
         channel = Nk * n_sub * (96 if self.split else 48)
-        return dict(canopy=canopy, soil_columns=soil, pixel_aggregates=pixel, overland=overland,
-                    sideflow_gather=Nk * 20, channel_wavefront=channel)
+        # the fused land surface: the soil's 504 B per column without the three streams that now stay in registers
+        # (LeafDrainage, Interception, ESMax), the canopy's own streams -- 5 read (LAI, LAITerm, CumInterception, CropCoef,
+        # CropGroupNumber; its WWP / WFC / W1 reads are the soil's), 7 written -- and the three [N] vectors EWRef, ETRef, ESRef
+        land = 3 * N * (504 - 24 + 8 * (5 + 7)) + 24 * N
+        out = dict(canopy=canopy, soil_columns=soil, land_surface=land, pixel_aggregates=pixel, overland=overland,
+                   sideflow_gather=Nk * 20, channel_wavefront=channel)
+        if self.land_fused:
+            out.pop("canopy"); out.pop("soil_columns")
+        else:
+            out.pop("land_surface")
+        return out
 
     def download(self, name):
         a = self.d[name].download()

@@ -1057,6 +1057,41 @@ def test_hot_path_in_surface_order_equals_pixel_order(amd):
     a.free(); b.free(); c.free()
 
 
+def test_land_surface_in_one_pass_equals_the_three_launches(amd, solver):
+    """lf_land_columns_device (canopy, ESMax = ESRef * LAITerm and the soil columns in ONE pass: the lane that runs a
+    column's canopy carries LeafDrainage, Interception, W1a / W1b / W1 and ESMax into the column's soil water balance in
+    registers) against lf_canopy_device + lf_scale_rows_device + lf_soil_columns_device, the launches of rounds 1-5: four
+    model steps of the resident chain, every state vector and every canopy / soil output bit for bit -- both `pow` paths
+    (the `solver` fixture), trip caps that send columns to the straggler kernel and keep them in the tile."""
+    from lisflood_amd import synthetic as syn
+    from lisflood_amd.hotpath import HotPathDevice
+    from lisflood_amd import soilloop as SL
+    H, W = 70, 90
+    N = H * W
+    values, sc, mask, ldd_to_chan, ldd_kin = syn.hotpath_scenario(H, W)
+    cp = lambda d: {k: (np.array(a, copy=True) if isinstance(a, np.ndarray) else a) for k, a in d.items()}
+    a = HotPathDevice(cp(values), sc, mask, ldd_to_chan, ldd_kin, split=True, land_fused=False)
+    b = HotPathDevice(cp(values), sc, mask, ldd_to_chan, ldd_kin, split=True, land_fused=True)
+    assert b.land_fused and not a.land_fused and "land_surface" in b.stage_bytes() and "canopy" in a.stage_bytes()
+    assert b.stage_bytes()["land_surface"] < a.stage_bytes()["canopy"] + a.stage_bytes()["soil_columns"]
+    names = list(dict.fromkeys(a.state_names() + SL._CANOPY_IO + list(SL._V_IO) + ["sumDisDay", "Infiltration", "ToChanM3RunoffDt"]))
+    for s in range(4):
+        f = syn.hotpath_forcing(N, s)
+        a.step(f, s + 1)
+        if s == 2:
+            ms = b.step_profile(f, s + 1)                     # the timed form takes the same path
+            assert "land_surface" in ms and "canopy" not in ms
+        else:
+            b.step(f, s + 1)
+        for k in names:
+            assert np.array_equal(a.download(k), b.download(k), equal_nan=True), (s, k)
+    import ctypes as C
+    multi = C.c_int64(0)
+    amd.lib.check(amd.lib.lib().lf_soil_last_deferred(C.c_int(0), C.byref(multi)))
+    assert multi.value > 0                                    # some columns did take several Courant sub-steps
+    a.free(); b.free()
+
+
 def test_hot_path_forcing_from_page_locked_buffers(amd):
     """HotPathDevice.pinned_forcing(): forcing vectors filled in place in page-locked host memory and prefetched (an
     asynchronous DMA) give the bits of the same vectors passed as ordinary arrays."""

@@ -140,6 +140,22 @@ def test_compute_fails_loudly_without_gpu():
     assert L.lf_soil_columns_device_derived(C.c_int(0), C.byref(a)) == _lib.LF_E_NO_DEVICE
     buf = np.zeros(4, np.float32)
     assert L.lf_upload_copy_f32(C.c_int(0), C.c_void_p(8), buf.ctypes.data_as(C.c_void_p), C.c_size_t(4)) == _lib.LF_E_NO_DEVICE
+    # round 6: the land surface in one pass checks its two argument blocks against each other BEFORE it needs a device
+    from lisflood_amd.soilloop import _CanopyArgs
+    cn = _CanopyArgs()
+    cn.index_landuse = idx.ctypes.data
+    cn.V, cn.L, cn.N = 3, 3, 8
+    es = C.c_void_p(8)
+    assert L.lf_land_columns_device(C.c_int(0), C.byref(cn), C.byref(a), es, C.c_int(1)) == _lib.LF_E_INVALID   # rows 0,0,0
+    assert b"index_landuse" in L.lf_last_error()
+    idx[:] = [0, 1, 2]
+    cn.W1a = 64                                                     # canopy and soil name different W1a vectors
+    assert L.lf_land_columns_device(C.c_int(0), C.byref(cn), C.byref(a), es, C.c_int(1)) == _lib.LF_E_INVALID
+    assert b"different vectors" in L.lf_last_error()
+    cn.W1a = None
+    assert L.lf_land_columns_device(C.c_int(0), C.byref(cn), C.byref(a), es, C.c_int(1)) == _lib.LF_E_NO_DEVICE
+    assert L.lf_upload_wait(C.c_int(0), C.c_int(0)) == _lib.LF_E_NO_DEVICE
+    assert L.lf_device_trim(C.c_int(0)) == _lib.LF_E_NO_DEVICE
 
 
 def test_graph_with_structure_links():
