@@ -512,7 +512,7 @@ def overland_bench(size=4000, channel_frac=0.04, steps=6):
     return out
 
 
-def hotpath_bench(size=2000, steps=6, family="deep", block=1_000_000):
+def hotpath_bench(size=2000, steps=6, family="deep", block=1_000_000, lean_too=False):
     """The whole device-resident hot path of a model step (canopy -> soil -> per-pixel aggregates -> 3 overland
     routers -> 24 split-routing channel sub-steps), lisflood_amd.hotpath.HotPathDevice; only the five forcing
     vectors cross PCIe per step.  `stages`: every stage timed on its own (one model step, synchronising after each)
@@ -603,6 +603,31 @@ def hotpath_bench(size=2000, steps=6, family="deep", block=1_000_000):
     out["stages_sum_ms"] = round(sum(acc.values()), 3)
     out["upload_GB_per_step"] = round(5 * 8 * N / 1e9, 3)
     hp.free()
+    if lean_too or os.environ.get("LF_BENCH_LEAN") == "1":
+        # the same step with the OPTIONAL maps left out (HotPathDevice(report=())): the soil diagnostics, the per-pixel
+        # diagnostics and the cumulative sums of the mass-balance report are not computed and their inputs not streamed --
+        # a run that reports `dis` and writes state maps needs none of them.  Never the leg's headline figure.
+        values, sc, mask, ldd_to_chan, ldd_kin = syn.hotpath_scenario(H, W, family=family, block=block)
+        hp = HotPathDevice(values, sc, mask, ldd_to_chan, ldd_kin, split=True, report=())
+        del values
+        for s in range(2):
+            f = {k: (a if hp.pixel_of_position is None else a[hp.pixel_of_position]) for k, a in syn.hotpath_forcing(N, s).items()}
+            hp.step(f, s + 1, ordered=True)
+        _lib.synchronize()
+        t0 = time.perf_counter()
+        for s in range(steps):
+            hp.step(None, s + 3)
+        _lib.synchronize()
+        lean_ms = (time.perf_counter() - t0) * 1e3 / steps
+        acc = hp.step_profile(f, steps + 3, ordered=True)
+        nb = hp.stage_bytes()
+        out["unreported_maps_left_out"] = dict(
+            ms_per_model_step=round(lean_ms, 3), finite=bool(np.isfinite(hp.chan_q_avg()).all()),
+            stages={k: dict(ms=round(x, 3), alg_GB=round(nb[k] / 1e9, 3), frac_hbm=round(nb[k] / (x * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+                    for k, x in acc.items()},
+            note="HotPathDevice(report=()): no optional map computed; dis and every state vector identical to the full step "
+                 "(tests/test_gpu_parity.py::test_hot_path_with_unreported_maps_left_out)")
+        hp.free()
     return out
 
 
@@ -782,7 +807,7 @@ def main():
             extra["etrs89_chain_error"] = repr(e)
         for fam in ("deep", "river"):    # the whole resident model step at a BASELINE size, stage by stage
             try:
-                extra["resident_hot_path_step_%s_5000" % fam] = hotpath_bench(5000, family=fam)
+                extra["resident_hot_path_step_%s_5000" % fam] = hotpath_bench(5000, family=fam, lean_too=(fam == "deep"))
             except Exception as e:
                 extra["resident_hot_path_%s_error" % fam] = repr(e)
         out["other_workloads"] = extra
@@ -868,6 +893,8 @@ def compact_line(out, detail):
             legs["hot_path_%s_5000" % fam] = dict(ms=e["ms_per_model_step"], value=e["Mpixel_steps_per_s"], unit="Mpixel-steps/s",
                                                    ms_with_forcing_upload=e.get("ms_per_model_step_with_forcing_upload"),
                                                    stages={k: [x["ms"], x["frac_hbm"]] for k, x in e["stages"].items()})
+            if "unreported_maps_left_out" in e:
+                legs["hot_path_%s_5000" % fam]["ms_unreported_maps_left_out"] = e["unreported_maps_left_out"]["ms_per_model_step"]
     e = ow.get("etrs89_chain")
     if e:
         legs["etrs89_chain"] = dict(ms=e["ms_per_model_step"], pixels=e["pixels"], launches=e["channel_wavefront_launches"],

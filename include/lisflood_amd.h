@@ -321,6 +321,8 @@ typedef struct lf_interception_args {
     int64_t V, N;
 } lf_interception_args;
 
+/* The seven diagnostics Theta1a, Theta1b, Theta2, Sat1a, Sat1b, Sat1, Sat2 (soilloop.py:330-336) are OPTIONAL in the
+ * device forms: a NULL pointer = not reported, not computed (nothing else in the column's water balance reads them). */
 typedef struct lf_soil_args {
     /* [L,N] statics */
     const uint8_t *PoreSpaceNotZero1a, *PoreSpaceNotZero1b, *PoreSpaceNotZero2;
@@ -488,6 +490,9 @@ int lf_router_reset_site_cache(lf_router *r);
  * opensealed.dynamic (opensealed.py:40-71), soil.dynamic_perpixel (soil.py:471-514; deffraction =
  * sum over the fractions of SoilFraction * X, Lisflood_initial.py:69-71,393-396) and groundwater.dynamic
  * (groundwater.py:134-180).  Prescribed fractions (V = L = 3, fraction v uses land-use row v). */
+/* Every output but DirectRunoff, UZOutflowPixel, LZOutflowToChannelPixel and the states CumInterSealed / LZ is OPTIONAL:
+ * a NULL pointer means the map is not reported -- it is not computed, and a [3,N] input only it reads may be NULL too
+ * (the reference computes all of them every step and writes the ones its rep* options name). */
 typedef struct lf_pixel_args {
     /* [3,N] in */
     const double *SoilFraction, *TaInterception, *Ta, *ESAct, *PrefFlow, *Infiltration, *SeepTopToSubA, *SeepTopToSubB,

@@ -97,11 +97,18 @@ __global__ void __launch_bounds__(kBlock) k_surface_post(lf_surface_args A)
     A.ToChanM3RunoffDt[p] = run * A.InvNoRoutSteps;
 }
 // opensealed.dynamic + soil.dynamic_perpixel + groundwater.dynamic, one lane per pixel
+// Every diagnostic output is optional: a NULL pointer means the map is not reported, it is then not computed and the
+// [3,N] vectors only it needs are not read (uniform branches on kernel arguments).  What the rest of the model step needs
+// -- DirectRunoff, UZOutflowPixel, LZOutflowToChannelPixel, the states CumInterSealed and LZ -- is always computed.
 __global__ void __launch_bounds__(kBlock) k_pixel_aggregates(lf_pixel_args A)
 {
     const long long p = (long long)blockIdx.x * kBlock + threadIdx.x;
     const long long N = A.N;
     if (p >= N) return;
+#define LF_ST(X, v)                                                                                                      \
+    do {                                                                                                                 \
+        if (A.X) A.X[p] = (v);                                                                                           \
+    } while (0)
     // ---- opensealed.py:45-70 ----
     const double ewref = A.EWRef[p], drf = A.DirectRunoffFraction[p], wf = A.WaterFraction[p];
     const double rsm = npmax(A.Rain[p] + A.SnowMelt[p], 0.0);
@@ -113,63 +120,74 @@ __global__ void __launch_bounds__(kBlock) k_pixel_aggregates(lf_pixel_args A)
     cis += inter;
     const double tas = npmax(npmin(cis, ewref), 0.0);
     cis = npmax(cis - tas, 0.0);
-    A.RainSnowmelt[p] = rsm;
-    A.EWaterAct[p] = ewact;
-    A.InterSealed[p] = inter;
-    A.TASealed[p] = tas;
+    LF_ST(RainSnowmelt, rsm);
+    LF_ST(EWaterAct, ewact);
+    LF_ST(InterSealed, inter);
+    LF_ST(TASealed, tas);
     A.CumInterSealed[p] = cis;
     A.DirectRunoff[p] = drf * (rsm - inter) + wf * (rsm - ewact);
     // ---- soil.py:475-513 : deffraction(X) = (SoilFraction * X).sum(vegetation) = ((f0 x0 + f1 x1) + f2 x2) ----
     const double f0 = A.SoilFraction[p], f1 = A.SoilFraction[N + p], f2 = A.SoilFraction[2 * N + p];
 #define LF_DEF(X) ((f0 * A.X[p] + f1 * A.X[N + p]) + f2 * A.X[2 * N + p])
-    const double ta_int_all = LF_DEF(TaInterception) + drf * tas;
-    A.TaInterceptionAll[p] = ta_int_all;
-    A.TaInterceptionCUM[p] += ta_int_all;
-    const double ta_pix = LF_DEF(Ta);
-    A.TaPixel[p] = ta_pix;
-    A.TaCUM[p] += ta_pix;
-    const double es_pix = LF_DEF(ESAct) + wf * ewact;
-    A.ESActPixel[p] = es_pix;
-    A.ESActCUM[p] += es_pix;
-    A.PrefFlowPixel[p] = LF_DEF(PrefFlow);
-    A.InfiltrationPixel[p] = LF_DEF(Infiltration);
-    double th[3];
-#pragma unroll
-    for (int v = 0; v < 3; ++v) {
-        const long long i = v * N + p;
-        const double tot_sm = A.W1a[i] + A.W1b[i] + A.W2[i];
-        th[v] = A.SoilFraction[i] * tot_sm / A.SoilDepthTotal[i];
-        A.Theta[i] = th[v];
+    if (A.TaInterceptionAll || A.TaInterceptionCUM) {
+        const double ta_int_all = LF_DEF(TaInterception) + drf * tas;
+        LF_ST(TaInterceptionAll, ta_int_all);
+        if (A.TaInterceptionCUM) A.TaInterceptionCUM[p] += ta_int_all;
     }
-    const double fsum = (f0 + f1) + f2;
-    A.ThetaAll[p] = (fsum > 0) ? ((th[0] + th[1]) + th[2]) / fsum : 0.0;
-    A.SeepTopToSubPixelA[p] = LF_DEF(SeepTopToSubA);
-    A.SeepTopToSubPixelB[p] = LF_DEF(SeepTopToSubB);
-    A.SeepSubToGWPixel[p] = LF_DEF(SeepSubToGW);
-    A.Theta1aPixel[p] = LF_DEF(Theta1a);
-    A.Theta1bPixel[p] = LF_DEF(Theta1b);
-    A.Theta2Pixel[p] = LF_DEF(Theta2);
+    if (A.TaPixel || A.TaCUM) {
+        const double ta_pix = LF_DEF(Ta);
+        LF_ST(TaPixel, ta_pix);
+        if (A.TaCUM) A.TaCUM[p] += ta_pix;
+    }
+    if (A.ESActPixel || A.ESActCUM) {
+        const double es_pix = LF_DEF(ESAct) + wf * ewact;
+        LF_ST(ESActPixel, es_pix);
+        if (A.ESActCUM) A.ESActCUM[p] += es_pix;
+    }
+    if (A.PrefFlowPixel) A.PrefFlowPixel[p] = LF_DEF(PrefFlow);
+    if (A.InfiltrationPixel) A.InfiltrationPixel[p] = LF_DEF(Infiltration);
+    if (A.Theta || A.ThetaAll) {
+        double th[3];
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            const long long i = v * N + p;
+            const double tot_sm = A.W1a[i] + A.W1b[i] + A.W2[i];
+            th[v] = A.SoilFraction[i] * tot_sm / A.SoilDepthTotal[i];
+            if (A.Theta) A.Theta[i] = th[v];
+        }
+        const double fsum = (f0 + f1) + f2;
+        LF_ST(ThetaAll, (fsum > 0) ? ((th[0] + th[1]) + th[2]) / fsum : 0.0);
+    }
+    if (A.SeepTopToSubPixelA) A.SeepTopToSubPixelA[p] = LF_DEF(SeepTopToSubA);
+    if (A.SeepTopToSubPixelB) A.SeepTopToSubPixelB[p] = LF_DEF(SeepTopToSubB);
+    if (A.SeepSubToGWPixel) A.SeepSubToGWPixel[p] = LF_DEF(SeepSubToGW);
+    if (A.Theta1aPixel) A.Theta1aPixel[p] = LF_DEF(Theta1a);
+    if (A.Theta1bPixel) A.Theta1bPixel[p] = LF_DEF(Theta1b);
+    if (A.Theta2Pixel) A.Theta2Pixel[p] = LF_DEF(Theta2);
     // ---- groundwater.py:137-180 ----
     double lz = A.LZ[p];
     double lzout = npmin(A.LowerZoneK[p] * lz, lz - A.LZThreshold[p]);
     lzout = npmax(lzout, 0.0);
-    A.LZOutflow[p] = lzout;
+    LF_ST(LZOutflow, lzout);
     lz -= lzout;
     A.UZOutflowPixel[p] = LF_DEF(UZOutflow);
     const double perc = LF_DEF(GwPercUZLZ);
-    A.GwPercUZLZPixel[p] = perc;
+    LF_ST(GwPercUZLZPixel, perc);
     lz += perc;
     const double loss = npmax(npmin(A.GwLossStep[p], lz), 0.0);
     lz = lz - loss;
-    A.GwLossLZ[p] = loss;
+    LF_ST(GwLossLZ, loss);
     A.LZ[p] = lz;
-    double cum = A.LZInflowCUM[p] + (perc - loss);
-    cum = npmax(cum, 0.0);
-    A.LZInflowCUM[p] = cum;
-    A.GwLossCUM[p] += loss;
-    A.LZAvInflow[p] = (cum * A.InvDtDay) / A.TimeSinceStart;
+    if (A.LZInflowCUM) {
+        double cum = A.LZInflowCUM[p] + (perc - loss);
+        cum = npmax(cum, 0.0);
+        A.LZInflowCUM[p] = cum;
+        LF_ST(LZAvInflow, (cum * A.InvDtDay) / A.TimeSinceStart);
+    }
+    if (A.GwLossCUM) A.GwLossCUM[p] += loss;
     A.LZOutflowToChannelPixel[p] = lzout;
 #undef LF_DEF
+#undef LF_ST
 }
 
 // lakes.dynamic_inloop (lakes.py:215-258) and reservoir.dynamic_inloop (reservoir.py:190-296): one lane per site
@@ -254,6 +272,20 @@ int lf_soil_pf_device(int device, const lf_soil_pf_args *a)
 int lf_pixel_aggregates_device(int device, const lf_pixel_args *a)
 {
     if (!a) return lf_set_error(LF_E_INVALID, "null argument");
+    // always needed: what the rest of the model step reads, and the inputs behind it
+    if (!a->SoilFraction || !a->UZOutflow || !a->GwPercUZLZ || !a->Rain || !a->SnowMelt || !a->EWRef || !a->SMaxSealed ||
+        !a->DirectRunoffFraction || !a->WaterFraction || !a->LowerZoneK || !a->LZThreshold || !a->GwLossStep ||
+        !a->CumInterSealed || !a->LZ || !a->DirectRunoff || !a->UZOutflowPixel || !a->LZOutflowToChannelPixel)
+        return lf_set_error(LF_E_INVALID, "pixel aggregates: a required vector is NULL");
+    // optional outputs (NULL = the map is not reported): the [3,N] input each one reads must be there
+    if (((a->TaInterceptionAll || a->TaInterceptionCUM) && !a->TaInterception) || ((a->TaPixel || a->TaCUM) && !a->Ta) ||
+        ((a->ESActPixel || a->ESActCUM) && !a->ESAct) || (a->PrefFlowPixel && !a->PrefFlow) ||
+        (a->InfiltrationPixel && !a->Infiltration) ||
+        ((a->Theta || a->ThetaAll) && (!a->W1a || !a->W1b || !a->W2 || !a->SoilDepthTotal)) ||
+        (a->SeepTopToSubPixelA && !a->SeepTopToSubA) || (a->SeepTopToSubPixelB && !a->SeepTopToSubB) ||
+        (a->SeepSubToGWPixel && !a->SeepSubToGW) || (a->Theta1aPixel && !a->Theta1a) || (a->Theta1bPixel && !a->Theta1b) ||
+        (a->Theta2Pixel && !a->Theta2) || (a->LZAvInflow && !a->LZInflowCUM))
+        return lf_set_error(LF_E_INVALID, "pixel aggregates: an output is requested whose input vector is NULL");
     lf_device_ctx *c;
     LF_TRY(lf_ctx(device, &c));
     if (a->N > 0) hipLaunchKernelGGL(k_pixel_aggregates, dim3(blocks_for(a->N)), dim3(kBlock), 0, c->stream, *a);

@@ -230,14 +230,15 @@ __device__ __forceinline__ void soil_finish(const lf_soil_args &A, long long i, 
     A.W1b[i] = w1b;
     A.W1[i] = w1;
     A.W2[i] = w2;
-    // diagnostics, :330-336
-    A.Theta1a[i] = pore1a ? w1a / T.sd1a : 0.;
-    A.Theta1b[i] = pore1b ? w1b / T.sd1b : 0.;
-    A.Theta2[i] = pore2 ? w2 / T.sd2 : 0.;
-    A.Sat1a[i] = (w1a - T.wwp1a) / (T.wfc1a - T.wwp1a);
-    A.Sat1b[i] = (w1b - T.wwp1b) / (T.wfc1b - T.wwp1b);
-    A.Sat1[i] = (w1 - T.wwp1) / (T.wfc1 - T.wwp1);
-    A.Sat2[i] = (w2 - T.wwp2) / (T.wfc2 - T.wwp2);
+    // diagnostics, :330-336.  Nothing on the hot path reads them (the per-pixel Theta averages apart): each is computed
+    // and stored only if the caller passed a vector for it (a NULL pointer = the map is not reported; uniform branches)
+    if (A.Theta1a) A.Theta1a[i] = pore1a ? w1a / T.sd1a : 0.;
+    if (A.Theta1b) A.Theta1b[i] = pore1b ? w1b / T.sd1b : 0.;
+    if (A.Theta2) A.Theta2[i] = pore2 ? w2 / T.sd2 : 0.;
+    if (A.Sat1a) A.Sat1a[i] = (w1a - T.wwp1a) / (T.wfc1a - T.wwp1a);
+    if (A.Sat1b) A.Sat1b[i] = (w1b - T.wwp1b) / (T.wfc1b - T.wwp1b);
+    if (A.Sat1) A.Sat1[i] = (w1 - T.wwp1) / (T.wfc1 - T.wwp1);
+    if (A.Sat2) A.Sat2[i] = (w2 - T.wwp2) / (T.wfc2 - T.wwp2);
     A.UZOutflow[i] = uzout;
     A.GwPercUZLZ[i] = perc;
     A.UZ[i] = uz;

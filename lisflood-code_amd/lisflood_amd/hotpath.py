@@ -27,9 +27,24 @@ FORCING = ("Rain", "SnowMelt", "EWRef", "ETRef", "ESRef")
 _CHANNEL_NAMES = set(RT._STATIC + RT._STATE + RT._OUT)
 
 
+# Maps of the land-surface stages that nothing else on the hot path reads (HotPathDevice(report=...)): the soil kernel's
+# diagnostics (soilloop.py:330-336), the per-pixel diagnostics of opensealed / soil.dynamic_perpixel / groundwater and the
+# cumulative sums of the mass-balance report.  Everything else -- states, `dis`, what a later stage reads -- always exists.
+OPTIONAL_MAPS = ("Theta1a Theta1b Theta2 Sat1a Sat1b Sat1 Sat2 "
+                 "RainSnowmelt EWaterAct InterSealed TASealed TaInterceptionAll TaPixel ESActPixel PrefFlowPixel InfiltrationPixel "
+                 "Theta ThetaAll SeepTopToSubPixelA SeepTopToSubPixelB SeepSubToGWPixel Theta1aPixel Theta1bPixel Theta2Pixel "
+                 "LZOutflow GwPercUZLZPixel GwLossLZ LZAvInflow LZInflowCUM TaInterceptionCUM TaCUM ESActCUM GwLossCUM").split()
+# [3,N] inputs of the per-pixel aggregates -> the optional outputs that read them (none reported: the input is not streamed)
+PA_READERS = dict(TaInterception=("TaInterceptionAll", "TaInterceptionCUM"), Ta=("TaPixel", "TaCUM"), ESAct=("ESActPixel", "ESActCUM"),
+                  PrefFlow=("PrefFlowPixel",), Infiltration=("InfiltrationPixel",), SeepTopToSubA=("SeepTopToSubPixelA",),
+                  SeepTopToSubB=("SeepTopToSubPixelB",), SeepSubToGW=("SeepSubToGWPixel",), Theta1a=("Theta1aPixel",),
+                  Theta1b=("Theta1bPixel",), Theta2=("Theta2Pixel",), W1a=("Theta", "ThetaAll"), W1b=("Theta", "ThetaAll"),
+                  W2=("Theta", "ThetaAll"), SoilDepthTotal=("Theta", "ThetaAll"))
+
+
 class HotPathDevice:
     def __init__(self, values, scalars, land_mask, ldd_to_chan, ldd_kinematic, split=True, device=0, structures=None,
-                 compact=True, overlap_channel=True, surface_order=True, land_fused=None):
+                 compact=True, overlap_channel=True, surface_order=True, land_fused=None, report=None):
         """values: name -> host array in pixel order ([N], [3,N]) for every vector of the stages (reference
         attribute names); scalars: Beta, DtSec, DtRouting, NoRoutSteps, DtDay, PixelLength, MMtoM3, M3toMM,
         LeafDrainageK, AvWaterThreshold, CourantCrit, DrainedFraction, InvDtDay.  ldd_to_chan / ldd_kinematic:
@@ -56,6 +71,14 @@ class HotPathDevice:
         # False: the three separate launches of rounds 1-5 -- same bits either way
         import os
         self.land_fused = (os.environ.get("LF_LAND_FUSED", "1") != "0") if land_fused is None else bool(land_fused)
+        # report: which of the OPTIONAL maps (OPTIONAL_MAPS below: diagnostics and cumulative sums nothing else on the hot
+        # path reads) are wanted.  None: all of them, as the reference computes them every step; an iterable of names: only
+        # those -- the others get no device vector, are not computed, and the [3,N] vectors only they read are not streamed
+        # (the reference writes the maps its rep* options name; what is not reported need not exist).  `dis`, the state
+        # maps and everything another stage reads are always there.
+        self.report = None if report is None else set(report)
+        if self.report is not None and not self.report <= set(OPTIONAL_MAPS):
+            raise ValueError("report: not optional maps: %s" % sorted(self.report - set(OPTIONAL_MAPS)))
         self.sc = dict(scalars)
         land_mask = np.asarray(land_mask, bool)
         self.N = N = int(land_mask.sum())
@@ -125,6 +148,8 @@ class HotPathDevice:
         bool_names = SL._BOOL | {"IsChannel", "IsChannelKinematic"}
         for k, a in values.items():
             a = np.asarray(a)
+            if self.report is not None and k in OPTIONAL_MAPS and k not in self._kept():
+                continue                              # an optional map nobody asked for: no device vector at all
             if k in chan_names:                       # channel vectors: engine order of the river router
                 if self.rmod is not None:
                     continue
@@ -164,7 +189,8 @@ class HotPathDevice:
         a.V, a.L, a.N = 3, 3, N
         zeros("LAITerm", (3, N)); zeros("ESMax", (3, N))
         s = self.soil = SL._SoilArgs()
-        fill(s, SL._L_FIELDS + SL._V_IN + SL._V_IO, vn)
+        wanted = lambda names: [k for k in names if self.report is None or k not in OPTIONAL_MAPS or k in self._kept()]
+        fill(s, wanted(SL._L_FIELDS + SL._V_IN + SL._V_IO), vn)
         fill(s, SL._N_FIELDS, n1)
         self._irr = np.array([0, 0, 1], np.uint8)
         self._pad = np.zeros(3, np.uint8)
@@ -174,8 +200,12 @@ class HotPathDevice:
                                                                          sc["CourantCrit"], sc["DrainedFraction"])
         s.V, s.L, s.N = 3, 3, N
         p = self.pixel = PA._PixelArgs()
-        fill(p, PA._V_IN + ["Theta"], vn)
-        fill(p, PA._N_IN + PA._STATE + PA._OUT, n1)
+        fill(p, wanted(PA._V_IN + ["Theta"]), vn)
+        fill(p, wanted(PA._N_IN + PA._STATE + PA._OUT), n1)
+        if self.report is not None:        # a [3,N] input that only unreported maps read is not handed to the kernel
+            for src, outs in PA_READERS.items():
+                if not any(o in self._kept() for o in outs):
+                    setattr(p, src, None)
         p.InvDtDay, p.N = sc["InvDtDay"], N
         f = self.surface = SR._SurfaceArgs()
         fill(f, SR._V_IN + ["SurfaceRunSoil", "scratch"], vn)
@@ -188,6 +218,18 @@ class HotPathDevice:
         r.Beta, r.InvBeta, r.InvDtRouting, r.DtSec = sc["Beta"], 1 / sc["Beta"], 1 / sc["DtRouting"], sc["DtSec"]
         r.split, r.engine_order = (1 if self.split else 0), 1
         self.steps_done = 0
+
+    def _kept(self):
+        """the optional maps that exist in this object: the reported ones plus what they are made of (the per-pixel Theta
+        averages read the soil kernel's Theta1a / Theta1b / Theta2)"""
+        if self.report is None:
+            return set(OPTIONAL_MAPS)
+        keep = set(self.report)
+        for pix, col in (("Theta1aPixel", "Theta1a"), ("Theta1bPixel", "Theta1b"), ("Theta2Pixel", "Theta2"),
+                         ("LZAvInflow", "LZInflowCUM")):
+            if pix in keep:
+                keep.add(col)
+        return keep
 
     def _upload_ordered(self, a):
         """fp64 [N] or [R, N] host array in pixel order -> device array in the order of pixel_of_position: every row is
@@ -411,8 +453,13 @@ class HotPathDevice:
         v8 = lambda names: 3 * 8 * len(names)
         canopy = N * (2 * v8(SL._CANOPY_IO) + v8(SL._CANOPY_V_IN) + v8(SL._CANOPY_L_IN) + 8 * len(SL._CANOPY_N_IN) + 3 * 24)
         soil = 3 * N * 504
-        io = set(PA._STATE)
-        pixel = N * (v8(PA._V_IN) + 24 + 8 * len(PA._N_IN) + 16 * len(io) + 8 * len([k for k in PA._OUT if k not in io]))
+        kept = self._kept()
+        have = lambda names: [k for k in names if k not in OPTIONAL_MAPS or k in kept]
+        v_in = [k for k in PA._V_IN if k not in PA_READERS or any(o in kept for o in PA_READERS[k])]
+        io = set(have(PA._STATE))
+        pixel = N * (v8(v_in) + (24 if "Theta" in kept else 0) + 8 * len(PA._N_IN) + 16 * len(io) +
+                     8 * len([k for k in have(PA._OUT) if k not in io]))
+        soil -= 3 * N * 8 * len([k for k in ("Theta1a", "Theta1b", "Theta2", "Sat1a", "Sat1b", "Sat1", "Sat2") if k not in kept])
         sio = set(SR._STATE)
         overland = N * (v8(SR._V_IN) + 2 * 24 + 8 * len(SR._N_IN) + 16 * len(sio) + 8 * len([k for k in SR._OUT if k not in sio])
                         + 3 * 48)
@@ -420,7 +467,7 @@ class HotPathDevice:
         # the fused land surface: the soil's 504 B per column without the three streams that now stay in registers
         # (LeafDrainage, Interception, ESMax), the canopy's own streams -- 5 read (LAI, LAITerm, CumInterception, CropCoef,
         # CropGroupNumber; its WWP / WFC / W1 reads are the soil's), 7 written -- and the three [N] vectors EWRef, ETRef, ESRef
-        land = 3 * N * (504 - 24 + 8 * (5 + 7)) + 24 * N
+        land = soil + 3 * N * (-24 + 8 * (5 + 7)) + 24 * N
         out = dict(canopy=canopy, soil_columns=soil, land_surface=land, pixel_aggregates=pixel, overland=overland,
                    sideflow_gather=Nk * 20, channel_wavefront=channel)
         if self.land_fused:

@@ -1092,6 +1092,45 @@ def test_land_surface_in_one_pass_equals_the_three_launches(amd, solver):
     a.free(); b.free()
 
 
+def test_hot_path_with_unreported_maps_left_out(amd):
+    """HotPathDevice(report=[...]): the optional maps (soil diagnostics, per-pixel diagnostics, cumulative sums of the
+    mass-balance report) that are not asked for get no device vector, are not computed and their inputs are not streamed
+    -- NULL pointers in lf_soil_args / lf_pixel_args.  Everything that exists must be the bits of the object that computes
+    all of them: `dis`, every state vector, the reported maps; an unreported map cannot be downloaded."""
+    from lisflood_amd import synthetic as syn
+    from lisflood_amd.hotpath import HotPathDevice, OPTIONAL_MAPS
+    H, W = 60, 70
+    N = H * W
+    values, sc, mask, ldd_to_chan, ldd_kin = syn.hotpath_scenario(H, W)
+    cp = lambda d: {k: (np.array(a, copy=True) if isinstance(a, np.ndarray) else a) for k, a in d.items()}
+    full = HotPathDevice(cp(values), sc, mask, ldd_to_chan, ldd_kin, split=True)
+    lean = HotPathDevice(cp(values), sc, mask, ldd_to_chan, ldd_kin, split=True, report=())
+    some = HotPathDevice(cp(values), sc, mask, ldd_to_chan, ldd_kin, split=True, report=("Theta1aPixel", "ThetaAll", "TaCUM", "LZAvInflow"))
+    with pytest.raises(ValueError):
+        HotPathDevice(cp(values), sc, mask, ldd_to_chan, ldd_kin, split=True, report=("ChanQ",))
+    bytes_full, bytes_lean = full.stage_bytes(), lean.stage_bytes()
+    assert bytes_lean["pixel_aggregates"] < 0.5 * bytes_full["pixel_aggregates"]
+    assert bytes_lean["land_surface"] < bytes_full["land_surface"]
+    for s in range(3):
+        f = syn.hotpath_forcing(N, s)
+        for hp in (full, lean, some):
+            hp.step(f, s + 1)
+        assert np.array_equal(full.chan_q_avg(), lean.chan_q_avg()) and np.array_equal(full.chan_q_avg(), some.chan_q_avg())
+        for hp in (lean, some):
+            for k in hp.state_names() + ["sumDisDay", "Infiltration", "ToChanM3RunoffDt", "DirectRunoff", "UZOutflowPixel",
+                                         "LZOutflowToChannelPixel", "TaInterception", "Ta"]:
+                assert np.array_equal(full.download(k), hp.download(k), equal_nan=True), (s, k)
+        for k in ("Theta1aPixel", "ThetaAll", "TaCUM", "LZAvInflow", "Theta1a", "LZInflowCUM"):
+            assert np.array_equal(full.download(k), some.download(k), equal_nan=True), (s, k)
+    gone = [k for k in OPTIONAL_MAPS if k not in lean.d]
+    assert set(gone) == set(OPTIONAL_MAPS)
+    assert "Sat1a" not in some.d and "Theta1b" not in some.d and "Theta1a" in some.d
+    with pytest.raises(KeyError):
+        lean.download("Sat1a")
+    for hp in (full, lean, some):
+        hp.free()
+
+
 def test_hot_path_forcing_from_page_locked_buffers(amd):
     """HotPathDevice.pinned_forcing(): forcing vectors filled in place in page-locked host memory and prefetched (an
     asynchronous DMA) give the bits of the same vectors passed as ordinary arrays."""
