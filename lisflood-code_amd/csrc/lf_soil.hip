@@ -251,120 +251,7 @@ struct soil_strag {
     unsigned short *key; // [tile][kStragCap]
     unsigned int *count; // [tile]
     int trip_cap;        // columns above this many sub-steps leave their tile (0: none do)
-    unsigned int *done;  // [group] tiles of the group that have finished (nullptr: the pools run as a launch of their own)
-    unsigned int ntiles; // tiles of the call
 };
-
-// LDS of the straggler pool (a group of kStragGroup consecutive tiles)
-struct strag_smem {
-    unsigned int off[kStragGroup + 1], h[kClasses], base[kClasses], next_task;
-    unsigned short cls_of[kStragGroup * kStragCap], rank_of[kStragGroup * kStragCap], ent_of[kStragGroup * kStragCap]; // per raw entry
-    unsigned short entry[kStragGroup * kStragCap]; // (tile in group << 8 | slot), by class
-};
-
-// The stragglers of the kStragGroup consecutive tiles from t0 on: sorted by trip count in LDS, 20 columns per wavefront (three
-// lanes per column), heaviest first; the lane of layer 0 finishes the column (phase 3 of k_soil_fused) over the placeholders.
-// Called by every thread of a workgroup of kTile threads (barriers inside).
-template <bool FASTPOW>
-__device__ __forceinline__ void straggler_group(const lf_soil_args &A, const veg_plan &P, const soil_strag &G, unsigned int t0,
-                                                unsigned int ntiles, unsigned int tiles_per_veg, strag_smem &S)
-{
-    constexpr int kMaxEntries = kStragGroup * kStragCap;
-    static_assert(kClasses <= kTile && kClasses % 64 == 0 && kStragCap < 256 && kStragGroup < 256 && kMaxEntries > 0, "list layout");
-    if (threadIdx.x < kClasses) S.h[threadIdx.x] = 0;
-    if (threadIdx.x == 0) {
-        unsigned int t = 0;
-        for (int g = 0; g < kStragGroup; ++g) {
-            S.off[g] = t;
-            t += (t0 + g < ntiles) ? G.count[t0 + g] : 0;
-        }
-        S.off[kStragGroup] = t;
-        S.next_task = 0;
-    }
-    __syncthreads();
-    const unsigned int total = S.off[kStragGroup];
-    if (total == 0) return;
-    // class histogram, exclusive scan, scatter (all in LDS)
-    for (unsigned int q = threadIdx.x; q < total; q += kTile) {
-        unsigned int g = 0;
-        while (S.off[g + 1] <= q) ++g;
-        const unsigned int sl = q - S.off[g];
-        const unsigned int cls = G.key[(size_t)(t0 + g) * kStragCap + sl] >> 8;
-        S.cls_of[q] = (unsigned short)cls;
-        S.ent_of[q] = (unsigned short)((g << 8) | sl);
-        S.rank_of[q] = (unsigned short)atomicAdd(&S.h[cls], 1u);
-    }
-    __syncthreads();
-    if (threadIdx.x < 64) { // exclusive scan of the histogram by one wavefront: lane l owns kClasses / 64 consecutive bins
-        constexpr int per = kClasses / 64;
-        unsigned int mine_sum = 0;
-#pragma unroll
-        for (int q = 0; q < per; ++q) mine_sum += S.h[threadIdx.x * per + q];
-        unsigned int incl = mine_sum;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const unsigned int up = __shfl_up(incl, d, 64);
-            if ((int)threadIdx.x >= d) incl += up;
-        }
-        unsigned int acc = incl - mine_sum;
-#pragma unroll
-        for (int q = 0; q < per; ++q) {
-            S.base[threadIdx.x * per + q] = acc;
-            acc += S.h[threadIdx.x * per + q];
-        }
-    }
-    __syncthreads();
-    for (unsigned int q = threadIdx.x; q < total; q += kTile) S.entry[S.base[S.cls_of[q]] + S.rank_of[q]] = S.ent_of[q];
-    __syncthreads();
-    const unsigned int ntasks = (total + kColsPerWave - 1) / kColsPerWave, lane = threadIdx.x & 63u;
-    const unsigned int in_row = lane & 15u, col_in_row = in_row / 3u, layer = in_row - 3u * col_in_row;
-    const unsigned int col = (lane >> 4) * 5u + col_in_row;
-    for (;;) {
-        unsigned int t = 0;
-        if (lane == 0) t = atomicAdd(&S.next_task, 1u);
-        t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
-        if (t >= ntasks) break;
-        const unsigned int e = t * kColsPerWave + col;
-        const bool valid = col_in_row < 5u && e < total;
-        const unsigned int ent = S.entry[total - 1u - (valid ? e : t * kColsPerWave)]; // heaviest first
-        const unsigned int tile = t0 + (ent >> 8);
-        const double *__restrict__ R = G.rec + ((size_t)tile * kStragCap + (ent & 0xffu)) * kStragFields;
-        const double *__restrict__ L = R + 7u * layer;
-        const double w = L[0], wres = L[1], ws = L[2], ks = L[3], im = L[4], m = L[5], k0 = L[6];
-        const int fl = (int)R[21];
-        const bool pore = ((fl >> (1 + (int)layer)) & 1) != 0;
-        const int nsub = valid ? (int)R[22] : 0;
-        int trips = nsub; // the wavefront's heaviest column (the classes are clamped, so not simply its first)
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            const int o = __shfl_xor(trips, d, 64);
-            trips = o > trips ? o : trips;
-        }
-        const double sum = layer_loop<FASTPOW>(layer, w, wres, ws, ks, im, m, k0, pore, nsub, trips, A.DtDay);
-        const double sb = row_next(sum);
-        const double sg = row_next(sb);
-        if (valid && layer == 0u) {
-            soil_tail T;
-            T.w1a = R[0]; T.w1b = R[7]; T.w2 = R[14]; T.ws1a = R[2]; T.flags = fl;
-            T.inf = R[24]; T.pref = R[25]; T.uz = R[26]; T.uzout = R[27]; T.gwp = R[28];
-            T.sd1a = R[29]; T.sd1b = R[30]; T.sd2 = R[31];
-            T.wwp1a = R[32]; T.wwp1b = R[33]; T.wwp1 = R[34]; T.wwp2 = R[35];
-            T.wfc1a = R[36]; T.wfc1b = R[37]; T.wfc1 = R[38]; T.wfc2 = R[39];
-            const int veg = (int)(tile / tiles_per_veg);
-            const long long pix = (long long)(tile - (unsigned int)veg * tiles_per_veg) * kTile + (long long)R[23];
-            soil_finish(A, (long long)veg * A.N + pix, P.drained[veg] != 0, T, sum, sb, sg);
-        }
-    }
-}
-
-// the straggler pools as a launch of their own (LF_SOIL_STRAG_INLINE=0): one workgroup per group of tiles
-template <bool FASTPOW>
-__global__ void __launch_bounds__(kTile) k_soil_stragglers(lf_soil_args A, veg_plan P, soil_strag G, unsigned int group0,
-                                                           unsigned int ntiles, unsigned int tiles_per_veg)
-{
-    __shared__ strag_smem S;
-    straggler_group<FASTPOW>(A, P, G, (group0 + blockIdx.x) * kStragGroup, ntiles, tiles_per_veg, S);
-}
 
 // all_list / all_count: every multi-sub-step column of the tile (lane | class << 8), for lf_soil_last_deferred and
 // lf_soil_substep_histogram (2 bytes per such column)
@@ -639,28 +526,106 @@ k_soil_fused(lf_soil_args A, veg_plan P, unsigned short *__restrict__ all_list, 
             sg = s_res[2 * kLoopCap + r];
         }
     }
-    if (active) soil_finish(A, i, P.drained[veg] != 0, T, sa, sb, sg);
-    // ---- the stragglers of this tile's group, by whichever of the group's tiles finishes last --------------------------
-    // Every tile of the group has then written its straggler records and stored its placeholders (release: the fence
-    // before the counter), so the pool can run at once -- in a workgroup of THIS launch, beside the streaming phases of
-    // the tiles around it, instead of as a VALU-bound launch of its own after the last tile (2.4 of 11.8 ms at 5000^2).
-    // No workgroup waits for another one: the counter decides who does the work, nothing spins.
-    if (G.done == nullptr || G.trip_cap <= 0) return;
-    __shared__ unsigned int s_last;
-    __shared__ strag_smem S;
-    const unsigned int group = tile / kStragGroup, g0 = group * kStragGroup;
-    const unsigned int in_group = (G.ntiles - g0) < (unsigned int)kStragGroup ? (G.ntiles - g0) : (unsigned int)kStragGroup;
-    __threadfence();   // this thread's stores (records, placeholders) before the count, device scope
-    __syncthreads();   // ... of every thread of the tile
+    if (!active) return;
+    soil_finish(A, i, P.drained[veg] != 0, T, sa, sb, sg);
+}
+
+// The stragglers of kStragGroup consecutive tiles: sorted by trip count in LDS, 20 columns per wavefront (three lanes per
+// column), heaviest first; the lane of layer 0 finishes the column (phase 3 of k_soil_fused) over the placeholders.
+template <bool FASTPOW>
+__global__ void __launch_bounds__(kTile) k_soil_stragglers(lf_soil_args A, veg_plan P, soil_strag G, unsigned int group0,
+                                                           unsigned int ntiles, unsigned int tiles_per_veg)
+{
+    constexpr int kMaxEntries = kStragGroup * kStragCap;
+    static_assert(kClasses <= kTile && kClasses % 64 == 0 && kStragCap < 256 && kStragGroup < 256, "list layout");
+    __shared__ unsigned int off[kStragGroup + 1], h[kClasses], base[kClasses], next_task;
+    __shared__ unsigned short cls_of[kMaxEntries], rank_of[kMaxEntries], ent_of[kMaxEntries]; // per raw entry
+    __shared__ unsigned short entry[kMaxEntries];                                            // (tile in group << 8 | slot), by class
+    const unsigned int t0 = (group0 + blockIdx.x) * kStragGroup;
+    if (threadIdx.x < kClasses) h[threadIdx.x] = 0;
     if (threadIdx.x == 0) {
-        const unsigned int prev = atomicAdd(&G.done[group], 1u);
-        s_last = (prev + 1u == in_group) ? 1u : 0u;
-        if (s_last) G.done[group] = 0u; // ready for the next call (the stream orders the calls)
+        unsigned int t = 0;
+        for (int g = 0; g < kStragGroup; ++g) {
+            off[g] = t;
+            t += (t0 + g < ntiles) ? G.count[t0 + g] : 0;
+        }
+        off[kStragGroup] = t;
+        next_task = 0;
     }
     __syncthreads();
-    if (!s_last) return;
-    __threadfence();   // acquire: the other tiles' records and placeholders
-    straggler_group<FASTPOW>(A, P, G, g0, G.ntiles, tiles_per_veg, S);
+    const unsigned int total = off[kStragGroup];
+    if (total == 0) return;
+    // class histogram, exclusive scan, scatter (all in LDS)
+    for (unsigned int q = threadIdx.x; q < total; q += kTile) {
+        unsigned int g = 0;
+        while (off[g + 1] <= q) ++g;
+        const unsigned int sl = q - off[g];
+        const unsigned int cls = G.key[(size_t)(t0 + g) * kStragCap + sl] >> 8;
+        cls_of[q] = (unsigned short)cls;
+        ent_of[q] = (unsigned short)((g << 8) | sl);
+        rank_of[q] = (unsigned short)atomicAdd(&h[cls], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) { // exclusive scan of the histogram by one wavefront: lane l owns kClasses / 64 consecutive bins
+        constexpr int per = kClasses / 64;
+        unsigned int mine_sum = 0;
+#pragma unroll
+        for (int q = 0; q < per; ++q) mine_sum += h[threadIdx.x * per + q];
+        unsigned int incl = mine_sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned int up = __shfl_up(incl, d, 64);
+            if ((int)threadIdx.x >= d) incl += up;
+        }
+        unsigned int acc = incl - mine_sum;
+#pragma unroll
+        for (int q = 0; q < per; ++q) {
+            base[threadIdx.x * per + q] = acc;
+            acc += h[threadIdx.x * per + q];
+        }
+    }
+    __syncthreads();
+    for (unsigned int q = threadIdx.x; q < total; q += kTile) entry[base[cls_of[q]] + rank_of[q]] = ent_of[q];
+    __syncthreads();
+    const unsigned int ntasks = (total + kColsPerWave - 1) / kColsPerWave, lane = threadIdx.x & 63u;
+    const unsigned int in_row = lane & 15u, col_in_row = in_row / 3u, layer = in_row - 3u * col_in_row;
+    const unsigned int col = (lane >> 4) * 5u + col_in_row;
+    for (;;) {
+        unsigned int t = 0;
+        if (lane == 0) t = atomicAdd(&next_task, 1u);
+        t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
+        if (t >= ntasks) break;
+        const unsigned int e = t * kColsPerWave + col;
+        const bool valid = col_in_row < 5u && e < total;
+        const unsigned int ent = entry[total - 1u - (valid ? e : t * kColsPerWave)]; // heaviest first
+        const unsigned int tile = t0 + (ent >> 8);
+        const double *__restrict__ R = G.rec + ((size_t)tile * kStragCap + (ent & 0xffu)) * kStragFields;
+        const double *__restrict__ L = R + 7u * layer;
+        const double w = L[0], wres = L[1], ws = L[2], ks = L[3], im = L[4], m = L[5], k0 = L[6];
+        const int fl = (int)R[21];
+        const bool pore = ((fl >> (1 + (int)layer)) & 1) != 0;
+        const int nsub = valid ? (int)R[22] : 0;
+        int trips = nsub; // the wavefront's heaviest column (the classes are clamped, so not simply its first)
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const int o = __shfl_xor(trips, d, 64);
+            trips = o > trips ? o : trips;
+        }
+        const double sum = layer_loop<FASTPOW>(layer, w, wres, ws, ks, im, m, k0, pore, nsub, trips, A.DtDay);
+        const double sb = row_next(sum);
+        const double sg = row_next(sb);
+        if (valid && layer == 0u) {
+            soil_tail T;
+            T.w1a = R[0]; T.w1b = R[7]; T.w2 = R[14]; T.ws1a = R[2]; T.flags = fl;
+            T.inf = R[24]; T.pref = R[25]; T.uz = R[26]; T.uzout = R[27]; T.gwp = R[28];
+            T.sd1a = R[29]; T.sd1b = R[30]; T.sd2 = R[31];
+            T.wwp1a = R[32]; T.wwp1b = R[33]; T.wwp1 = R[34]; T.wwp2 = R[35];
+            T.wfc1a = R[36]; T.wfc1b = R[37]; T.wfc1 = R[38]; T.wfc2 = R[39];
+            const int veg = (int)(tile / tiles_per_veg);
+            const long long pix = (long long)(tile - (unsigned int)veg * tiles_per_veg) * kTile + (long long)R[23];
+            soil_finish(A, (long long)veg * A.N + pix, P.drained[veg] != 0, T, sum, sb, sg);
+        }
+    }
 }
 
 int make_plan(const lf_soil_args *a, const uint8_t *paddy_any, veg_plan *P)
@@ -710,7 +675,7 @@ int lf_interception_device(int device, const lf_interception_args *a)
 // Per-device workspace of the soil call (grow-only): | all_count[ntiles + 4] | all_list[ntiles * 256] | straggler
 // count[ntiles + 4] | straggler key[ntiles * kStragCap] | straggler records[ntiles * kStragCap * kStragFields] |
 struct soil_ws_layout {
-    size_t all_count, all_list, s_count, s_key, s_rec, done, bytes;
+    size_t all_count, all_list, s_count, s_key, s_rec, bytes;
 };
 static soil_ws_layout soil_layout(size_t ntiles)
 {
@@ -721,8 +686,7 @@ static soil_ws_layout soil_layout(size_t ntiles)
     L.s_count = L.all_list + up(sizeof(unsigned short) * ntiles * kTile);
     L.s_key = L.s_count + up(sizeof(unsigned int) * (ntiles + 4));
     L.s_rec = L.s_key + up(sizeof(unsigned short) * ntiles * kStragCap);
-    L.done = L.s_rec + up(sizeof(double) * ntiles * kStragCap * kStragFields);
-    L.bytes = L.done + up(sizeof(unsigned int) * (ntiles / kStragGroup + 4));
+    L.bytes = L.s_rec + sizeof(double) * ntiles * kStragCap * kStragFields;
     return L;
 }
 
@@ -825,10 +789,7 @@ static int soil_columns_device(int device, const lf_soil_args *a, bool derived, 
         c->soil_ws_bytes = 0;
         LF_HIP(hipMalloc(&c->soil_ws, L.bytes));
         c->soil_ws_bytes = L.bytes;
-        c->soil_ntiles = 0;
     }
-    if (c->soil_ntiles != ntiles) // (new workspace or another tiling: the group counters start from zero; they reset themselves)
-        LF_HIP(hipMemsetAsync((char *)c->soil_ws + L.done, 0, sizeof(unsigned int) * (ntiles / kStragGroup + 4), c->stream));
     c->soil_ntiles = ntiles;
     char *ws = (char *)c->soil_ws;
     unsigned int *all_count = (unsigned int *)(ws + L.all_count);
@@ -840,12 +801,6 @@ static int soil_columns_device(int device, const lf_soil_args *a, bool derived, 
     // columns above this many Courant sub-steps leave their tile for k_soil_stragglers; LF_SOIL_TRIP_CAP=0: none do
     G.trip_cap = kSoilTripCap;
     if (const char *e = std::getenv("LF_SOIL_TRIP_CAP")) G.trip_cap = (int)std::atol(e) > 0 ? (int)std::atol(e) : 0;
-    // the straggler pools inside the streaming launch (the last tile of a group to finish runs the group's pool) or, with
-    // LF_SOIL_STRAG_INLINE=0, as a second launch behind it (rounds 5's form; A/B switch)
-    G.ntiles = (unsigned int)ntiles;
-    G.done = (unsigned int *)(ws + L.done);
-    if (const char *e = std::getenv("LF_SOIL_STRAG_INLINE"))
-        if (e[0] == '0') G.done = nullptr;
     // LF_GENERAL_POW=1: OCML pow instead of lf_pow_pos (A/B parity and timing)
     const char *force_general = std::getenv("LF_GENERAL_POW");
     const bool fastpow = !(force_general && force_general[0] == '1');
@@ -874,7 +829,7 @@ static int soil_columns_device(int device, const lf_soil_args *a, bool derived, 
         else LF_SOIL_LAUNCH(false, false, false);
     }
 #undef LF_SOIL_LAUNCH
-    if (G.trip_cap > 0 && G.done == nullptr) {
+    if (G.trip_cap > 0) {
         const dim3 grid2((unsigned)((ntiles + kStragGroup - 1) / kStragGroup));
         if (fastpow)
             hipLaunchKernelGGL(k_soil_stragglers<true>, grid2, block, 0, c->stream, *a, P, G, 0u, (unsigned int)ntiles, tiles_per_veg);

@@ -1321,31 +1321,27 @@ def test_soil_columns_small_and_ragged_shapes(amd, oracle, N, V, L):
         a.free()
 
 
-@pytest.mark.parametrize("inline", ["1", "0"])
 @pytest.mark.parametrize("trip_cap", ["0", "3", "16", "200"])
-def test_soil_columns_same_bits_whatever_the_trip_cap(amd, monkeypatch, trip_cap, inline):
-    """Which columns leave their tile for the straggler pools (LF_SOIL_TRIP_CAP: none, nearly all multi-sub-step ones --
+def test_soil_columns_same_bits_whatever_the_trip_cap(amd, monkeypatch, trip_cap):
+    """Which columns leave their tile for k_soil_stragglers (LF_SOIL_TRIP_CAP: none, nearly all multi-sub-step ones --
     more than a tile's 24 record slots hold, so the rest stay in the tile --, the default, hardly any) must not change a
-    single bit of any output: in-lane, in-tile and straggler columns run the same arithmetic.  Nor must WHERE the pools
-    run: inside the streaming launch, by the last tile of a group of 16 to finish (LF_SOIL_STRAG_INLINE=1, the default),
-    or as a launch of their own behind it (=0) -- the reference run below is the round-5 form (cap 16, own launch)."""
+    single bit of any output: in-lane, in-tile and straggler columns run the same arithmetic."""
     from lisflood_amd import synthetic as syn
     N = 30011
     d = syn.soil_params(N, seed=21)
     d["is_irrigated"] = np.array([False, True, True])
-    outs = []
-    for cap, where in (("16", "0"), (trip_cap, inline)):
+    outs = {}
+    for cap in ("16", trip_cap):
         monkeypatch.setenv("LF_SOIL_TRIP_CAP", cap)
-        monkeypatch.setenv("LF_SOIL_STRAG_INLINE", where)
         dev = amd.soil.SoilColumnsDevice({k: (v.copy() if hasattr(v, "copy") else v) for k, v in d.items()})
         for s in range(3):
             dev.set("Rain", np.random.default_rng(50 + s).uniform(0, 30, N))
             dev.step()
-        outs.append({k: dev.get(k) for k in syn.SOIL_WRITTEN})
+        outs[cap] = {k: dev.get(k) for k in syn.SOIL_WRITTEN}
         for a in dev.dev.values():
             a.free()
     for k in syn.SOIL_WRITTEN:
-        assert np.array_equal(outs[0][k], outs[1][k], equal_nan=True), k
+        assert np.array_equal(outs["16"][k], outs[trip_cap][k], equal_nan=True), k
 
 
 def test_soil_columns_more_multi_substep_columns_than_a_round_holds(amd, oracle, solver):
