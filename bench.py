@@ -916,9 +916,9 @@ def compact_line(out, detail):
         if leg:
             lv = (ow.get(fam) or {}).get("levels")
             moved = round(leg["frac"] * (leg.get("traffic_ratio") or 1.0), 3) if leg.get("frac") else None
-            if lv and lv >= 1000:
+            if lv and lv >= 1000 and (moved or 0.0) < 0.5:
                 bound("route_" + fam, "level-latency", us_per_level=round(leg["ms"] * 1e3 / lv, 3), levels=lv)
-            else:
+            else:     # the bytes actually moved are at half the peak or more: the memory system, not the chain, sets the pace
                 bound("route_" + fam, "hbm", moved_frac=moved, levels=lv)
     bound("soil_wet", "valu")
     bound("soil_single_substep", "hbm")
@@ -931,10 +931,8 @@ def compact_line(out, detail):
         bound("model_step_structures_3000", "launch-latency", us_per_launch=round(x["ms"] * 1e3 / x["launches"], 1) if x.get("launches") else None)
     bound("overland_sparse_4000", "valu")
     bound("etrs89_chain", "launch-latency")
-    for fam in ("deep", "river"):
-        if "hot_path_%s_5000" % fam in legs:
-            legs["hot_path_%s_5000" % fam]["stage_bound"] = dict(canopy="hbm", soil_columns="valu", pixel_aggregates="hbm",
-                                                                 overland="hbm", channel_wavefront="hbm", land_surface="valu")
+    if any(k.startswith("hot_path_") for k in legs):
+        line["stage_bound"] = dict(land_surface="valu", pixel_aggregates="hbm", overland="hbm", channel_wavefront="hbm")
     if isinstance((cb or {}).get("soil"), dict) and "soil_wet" in legs:
         legs["soil_wet"]["cpu_value"] = cb["soil"]["value"]
     if isinstance((cb or {}).get("model_step"), dict):
@@ -945,10 +943,9 @@ def compact_line(out, detail):
     if errs:
         legs["errors"] = {k: str(v)[:80] for k, v in errs.items()}
     line["legs"] = legs
-    line["legs_keys"] = ("ms, value (Mcell-steps/s unless unit is given), frac = algorithmic bytes / time / 8 TB/s, traffic_ratio = "
-                         "counter bytes / algorithmic bytes, launches per step, bound = hbm | level-latency | launch-latency | valu with "
-                         "its live number (moved_frac = frac x traffic_ratio, us_per_level, us_per_launch), cpu_value / cpu_ms = the "
-                         "oracle on the host cores in the leg's unit; stages: [ms, frac]")
+    line["legs_keys"] = ("ms; value (Mcell-steps/s unless unit given); frac = algorithmic bytes / time / 8 TB/s; traffic_ratio = counter / "
+                         "algorithmic bytes; launches per step; bound with its live number (moved_frac = frac x traffic_ratio); "
+                         "cpu_value / cpu_ms = oracle on the host; stages: [ms, frac]")
     line["detail"] = detail
     return line
 
