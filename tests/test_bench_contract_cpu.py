@@ -116,6 +116,8 @@ def test_compact_line_is_a_function_of_the_sidecar():
         again = json.loads(json.dumps(bench.compact_line(full, line["detail"])))
         if not whole:
             again.pop("cpu_baseline"); line.pop("cpu_baseline")
+            for k in set(again) - set(line):                          # top-level keys added since (stage_bound)
+                again.pop(k)
             for k in set(again["legs"]) - set(line["legs"]):          # legs added since
                 again["legs"].pop(k)
             for leg in again["legs"]:                                  # keys added to old legs since
@@ -123,3 +125,30 @@ def test_compact_line_is_a_function_of_the_sidecar():
                     again["legs"][leg] = {k: x for k, x in again["legs"][leg].items() if k in line["legs"][leg]}
             again["legs_keys"] = line["legs_keys"]
         assert again == line, tag
+
+
+def test_committed_compact_line_round6():
+    """Round 6: the CPU baseline is a bound, first-touch team sweep with soil / model-step / LF_ETRS89 figures beside it,
+    every leg names what bounds it, the land surface is one stage, the real catchment has a leg."""
+    text = open(os.path.join(ROOT, "profiles", "r06_bench_line.json")).read().strip().splitlines()
+    assert len(text) == 1 and len(text[0]) <= 4096
+    d = json.loads(text[0])
+    assert d["dtype"] == "f64" and d["vs_baseline"] is None and d["n_gpus"] == 1 and "workload" in d["config"]
+    assert abs(d["value"] - d["config"]["cells"] / d["ms_per_step"] / 1e3) < 1e-3 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-6 and r["traffic"] >= r["alg_bytes_per_launch"]
+    assert r["launches_per_step"] * r["mean_launch_us"] * 1e-3 <= d["ms_per_step"] * 1.02
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == d["unit"] and c["physical_cores"] >= c["cores"] >= 1
+    teams = {int(k): x for k, x in c["team_rates"].items()}
+    assert 1 in teams and c["physical_cores"] in teams and max(teams.values()) >= c["value"] * 0.5
+    assert c["soil"]["unit"] == "Mcolumn-steps/s" and c["model_step"]["unit"] == "Mpixel-steps/s" and c["etrs89"]["ms_per_model_step"] > 0
+    legs = d["legs"]
+    for k, x in legs.items():
+        if k not in ("pixel_order_call", "errors") and not k.startswith("hot_path"):
+            assert x.get("bound") in ("hbm", "level-latency", "launch-latency", "valu"), k
+    assert legs["route_deep"]["bound"] == "level-latency" and legs["route_deep"]["us_per_level"] < 0.5
+    assert legs["etrs89_chain"]["dis_dev"] < 1e-6 and legs["etrs89_chain"]["cpu_ms"] > legs["etrs89_chain"]["ms"]
+    st = legs["hot_path_deep_5000"]["stages"]
+    assert "land_surface" in st and "canopy" not in st and st["land_surface"][0] < 14.8     # canopy 2.9 + soil 11.9 in round 5
+    assert legs["hot_path_deep_5000"]["ms"] < 23.6 and legs["hot_path_deep_5000"]["ms_unreported_maps_left_out"] < 20.0
