@@ -20,15 +20,19 @@ for f in glob.glob(prefix + "*/**/*counter_collection.csv", recursive=True):
         a = agg[k][r["Counter_Name"]]
         a[0] += 1
         a[1] += float(r["Counter_Value"])
-print("# %s: per-kernel counter totals over the run (rocprofv3 --pmc, one pass per counter); HBM bytes = FETCH_SIZE x 64 x 2"
-      " (gfx950: the counter reads half) + WRITE_SIZE x 64" % label)
+print("# %s: per-kernel counter totals over the run (rocprofv3 --pmc, one pass per counter); HBM bytes = FETCH_SIZE [KiB] x 2"
+      " (gfx950: the counter reads half, calibrated with a stream copy in round 1) + WRITE_SIZE [KiB]" % label)
 for k, c in sorted(agg.items()):
     n = max(v[0] for v in c.values())
-    rd = c.get("FETCH_SIZE", [0, 0.0])[1] * 64 * 2
-    wr = c.get("WRITE_SIZE", [0, 0.0])[1] * 64
+    rd = c.get("FETCH_SIZE", [0, 0.0])[1] * 1024 * 2      # KiB; x2: the gfx950 calibration of the read counter
+    wr = c.get("WRITE_SIZE", [0, 0.0])[1] * 1024
     print("%-60s launches=%-6d read_GB=%-10.4f write_GB=%-10.4f total_GB=%.4f" % (k, n, rd / 1e9, wr / 1e9, (rd + wr) / 1e9))
 PY
 }
+echo "== 0. kernel trace of the headline alone (the default size, 100 calls, no other leg: the k_level launches of this run are the headline's)"
+rm -rf $OUT/prof_r06head_only
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_r06head_only -o kt -- python $ROOT/bench.py --no-extra --no-cpu-baseline > $OUT/prof_r06head_only_bench.json 2> /dev/null; echo rc=$?
+find $OUT/prof_r06head_only -type f ! -name "*kernel_stats.csv" -delete 2>/dev/null
 echo "== 1. kernel trace of the default bench command"
 rm -rf $OUT/prof_r06head_kt
 timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_r06head_kt -o kt -- python $ROOT/bench.py --no-cpu-baseline > $OUT/prof_r06head_bench.json 2> $OUT/prof_r06head_bench.err; echo rc=$?
@@ -48,6 +52,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 tail -c 600 /tmp/ps_FETCH_SIZE.log > $OUT/pmc_r06_structures.txt; echo >> $OUT/pmc_r06_structures.txt
 agg /tmp/ps_ "bench.py --only structures (3000^2 deep, 64 lakes + 192 reservoirs)" | grep -v rocclr >> $OUT/pmc_r06_structures.txt
+find $OUT/prof_r06head_kt -type f ! -name "*kernel_stats.csv" -delete 2>/dev/null   # (the raw trace is ~70 MB: over the merge cap)
 find $OUT -name "*.db" -delete 2>/dev/null
 find $OUT -name "*_agent_info.csv" -delete 2>/dev/null
 du -sh $OUT/prof_r06head_kt $OUT/pmc_r06_* | tail
