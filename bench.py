@@ -441,6 +441,22 @@ def structures_step_bench(size=3000, nsteps=24):
     ms = (time.perf_counter() - t0) * 1e3 / 3
     out["fused"] = dict(ms_per_model_step=round(ms, 3), value=round(2 * nsteps * N / ms / 1e3, 2), unit="Mcell-steps/s",
                         launches_per_model_step=r.last_launches()["launches"])
+    try:    # committed counter passes of this workload (tools/pmc_r06.sh, profiles/r06_pmc_digest.json)
+        import glob
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_digest.json")), reverse=True):
+            w = json.load(open(f)).get("workloads", {}).get("fused_structures_deep_%d" % size)
+            if w and "hbm_bytes_per_cell_substep" in w:
+                per = w["hbm_bytes_per_cell_substep"]
+                out["fused"]["roofline"] = dict(bound="launch-latency", kernel="k_fused_cones (structures in the wavefront)",
+                                                hbm_bytes_per_cell_substep=per, traffic_source=w["source"],
+                                                frac=round(2 * B_ALG * N * nsteps / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                                moved_GBs=round(per * N * nsteps / (ms * 1e-3) / 1e9, 1),
+                                                note="counter bytes per (cell, sub-step) against 2 x 48 B algorithmic: the cone "
+                                                     "kernel also streams the in-loop vectors (runoff, inflow, transmission loss, "
+                                                     "sideflow) and re-reads the statics at each of a cell's 24 visits")
+                break
+    except Exception:
+        pass
     _lib.synchronize()
     t0 = time.perf_counter()
     for s in range(nsteps):
