@@ -941,7 +941,9 @@ def compact_line(out, detail):
     for k in ("model_step_deep_5000", "model_step_deep_5000_5_in_flight"):
         if k in legs:
             tr = legs["model_step_deep_5000"].get("traffic_ratio")
-            bound(k, "hbm", moved_frac=round(legs[k]["frac"] * tr, 3) if tr and legs[k].get("frac") else None)
+            # (instruction issue of the cone kernel -- ~730 instructions per level of a cone, DESIGN_NOTEBOOK 4.3b -- with the
+            # moved bytes at about half the peak)
+            bound(k, "valu", moved_frac=round(legs[k]["frac"] * tr, 3) if tr and legs[k].get("frac") else None)
     if "model_step_structures_3000" in legs:
         x = legs["model_step_structures_3000"]
         bound("model_step_structures_3000", "launch-latency", us_per_launch=round(x["ms"] * 1e3 / x["launches"], 1) if x.get("launches") else None)
