@@ -516,6 +516,8 @@ class HotPathDevice:
         z = np.load(path)
         chan = set(RT._STATIC + RT._STATE + RT._OUT)
         for k in self.state_names():
+            if k not in z.files and k in OPTIONAL_MAPS:
+                continue                              # a state file written by an object that did not report this map
             a = z[k]
             if k in chan:
                 if self.Nk < self.N:
