@@ -602,7 +602,7 @@ int route_device(lf_router *r, double *q_dev, const double *lat_dev, int section
 // block is cut into cones: chunks of its last level, as long as possible with no level of the cone wider than kBlock
 // cells; a block whose thinnest possible cone (one cell of the last level) is still too wide somewhere loses levels
 // until it fits (one level always does).  Nothing is built when no block holds more than one level.
-static int build_level_blocks(lf_router *r, const lf_graph *g, bool for_route)
+static int build_level_blocks(lf_router *r, const lf_graph *g, bool for_route, int lmax_override = 0)
 {
     int lmax = for_route ? 256 : 16; // LF_ROUTE_LEVELS / LF_FUSED_LEVELS (measured: §4.1c / §4.3b of DESIGN.md)
     if (!for_route && !g->has_links) {
@@ -614,6 +614,7 @@ static int build_level_blocks(lf_router *r, const lf_graph *g, bool for_route)
         if (widest <= 3000) lmax = 32;
     }
     if (const char *e = std::getenv(for_route ? "LF_ROUTE_LEVELS" : "LF_FUSED_LEVELS")) lmax = std::atoi(e);
+    if (lmax_override > 0) lmax = lmax_override;
     lmax = lmax < 1 ? 1 : (lmax > (for_route ? 512 : 64) ? (for_route ? 512 : 64) : lmax);
     int64_t wide = 262144;
     if (const char *e = std::getenv("LF_FUSED_WIDE")) wide = std::atoll(e);
@@ -668,6 +669,72 @@ static int build_level_blocks(lf_router *r, const lf_graph *g, bool for_route)
     r->fb_lmax = lmax;
     r->fb_cw = cw;
     return LF_OK;
+}
+
+// ---- levels per block of plain router calls, chosen per graph ------------------------------------------------------------
+// Blocks of 256 levels are right for graphs whose cone launches are CHAIN-bound (deep 10 000^2: 157 cones per launch, every
+// launch costs its fill + 256 level times whatever the block length, so fewer launches win).  A graph of many short trees --
+// the overland graph of a domain with few channel pixels: 4 223 cones of ~100 levels whose ranges are 64 cells wide at one
+// level and ~10 on average -- is THROUGHPUT-bound on lanes that idle: a cone must fit its widest level, so the longer the
+// block, the thinner the rest of the cone.  Shorter blocks re-cut the cones where the graph narrows (overland 4000^2, 4 %
+// channel pixels: 1.43 ms with 256 levels per block, 1.08 / 0.90 / 0.86 / 0.90 / 1.06 with 128 / 64 / 32 / 16 / 8).  Which
+// length is best depends on the width profile, so it is MEASURED: when the default plan fills less than 40 % of its lanes
+// and has more cones in a launch than the chip holds at once, the candidates are built and timed on scratch vectors (three
+// router calls each, hipEvents) and the fastest stays.  Routers of one graph share the result (they must: swept together
+// they use one plan).  The plan does not change a single bit of the results (every routing test runs on whatever it picks).
+// LF_ROUTE_LEVELS=n fixes the length, LF_ROUTE_TUNE=0 keeps the default.
+__global__ void __launch_bounds__(kBlock) k_fill_f64(long long n, double *x, double v)
+{
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) x[i] = v;
+}
+
+static int tune_route_blocks(lf_router *r, const lf_graph *g)
+{
+    static std::map<uint64_t, int> tuned; // graph serial -> levels per block (one thread per device context drives this)
+    if (std::getenv("LF_ROUTE_LEVELS")) return LF_OK;
+    if (const char *e = std::getenv("LF_ROUTE_TUNE"))
+        if (e[0] == '0') return LF_OK;
+    if (r->rb_lmax <= 1 || r->N < 1000000) return LF_OK;
+    int64_t st[6];
+    LF_TRY(lf_router_route_plan_stats(r, st));
+    const double lane_use = st[3] > 0 ? (double)st[4] / ((double)r->rb_cw * (double)st[3]) : 1.0;
+    if (lane_use >= 0.4 || st[5] <= 1024) return LF_OK; // lanes busy, or few enough cones per launch to be chain-bound
+    auto it = tuned.find(g->serial);
+    if (g->serial != 0 && it != tuned.end()) return it->second == r->rb_lmax ? LF_OK : build_level_blocks(r, g, true, it->second);
+    lf_dbuf<double> Q, q;
+    LF_TRY(Q.alloc((size_t)r->N));
+    LF_TRY(q.alloc((size_t)r->N));
+    hipStream_t s = r->ctx->stream;
+    hipEvent_t e0, e1;
+    LF_HIP(hipEventCreate(&e0));
+    LF_HIP(hipEventCreate(&e1));
+    int best = r->rb_lmax, rc = LF_OK;
+    float best_ms = 1e30f;
+    for (int lmax : {256, 128, 64, 32, 16}) {
+        if (lmax != r->rb_lmax) rc = build_level_blocks(r, g, true, lmax);
+        if (rc != LF_OK || r->rb_lmax != lmax) break; // (no multi-level block at this length: nothing shorter will have one)
+        hipLaunchKernelGGL(k_fill_f64, dim3(blocks_for(r->N)), dim3(kBlock), 0, s, (long long)r->N, Q.p, 1.0);
+        hipLaunchKernelGGL(k_fill_f64, dim3(blocks_for(r->N)), dim3(kBlock), 0, s, (long long)r->N, q.p, 1.0e-4);
+        rc = route_device(r, Q.p, q.p, 0, true); // warm
+        if (rc != LF_OK) break;
+        (void)hipEventRecord(e0, s);
+        for (int k = 0; k < 3 && rc == LF_OK; ++k) rc = route_device(r, Q.p, q.p, 0, true);
+        (void)hipEventRecord(e1, s);
+        if (rc != LF_OK || hipEventSynchronize(e1) != hipSuccess) break;
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best_ms) {
+            best_ms = ms;
+            best = lmax;
+        } else if (ms > 1.15f * best_ms)
+            break; // past the minimum
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc == LF_OK && r->rb_lmax != best) rc = build_level_blocks(r, g, true, best);
+    if (rc == LF_OK && g->serial != 0) tuned[g->serial] = best;
+    return rc;
 }
 
 extern "C" {
@@ -772,6 +839,7 @@ int lf_router_create(const lf_graph *g, const double *alpha, double beta, const 
     // range of the LAST cell of the next level -- which adds their 0.0 -- and so inside the last cone of a block)
     rc = build_level_blocks(r, g, false);
     if (rc == LF_OK && !g->has_links) rc = build_level_blocks(r, g, true);
+    if (rc == LF_OK && !g->has_links) rc = tune_route_blocks(r, g);
     if (rc != LF_OK) {
         delete r;
         return rc;

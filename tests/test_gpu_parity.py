@@ -1057,6 +1057,60 @@ def test_hot_path_in_surface_order_equals_pixel_order(amd):
     a.free(); b.free(); c.free()
 
 
+def test_block_length_chosen_per_graph_leaves_the_bits_alone(amd, monkeypatch):
+    """lf_router_create times shorter level blocks for a graph whose default cone plan (blocks of 256 levels) fills less than
+    40 % of its lanes -- the overland graph of a domain with few channel pixels: many short trees -- and keeps the fastest
+    (tune_route_blocks, csrc/lf_router.hip).  The plan is a schedule, not arithmetic: the three overland routers swept
+    together on the tuned plan, on the default plan (LF_ROUTE_TUNE=0) and one launch per level (LF_ROUTE_CONES=0) give the
+    same bits; routers of one graph share the tuned length (they are swept together on one plan)."""
+    from lisflood_amd import _lib
+    from lisflood_amd import synthetic as syn
+    from lisflood_amd.kinematic_wave_parallel import Graph, kinematicWave
+    H = W = 1300
+    N = H * W
+    rng = np.random.default_rng(43)
+    codes = syn.make_ldd("deep", H, W, 2)
+    raster = np.where(rng.random((H, W)) < 0.04, np.uint8(5), codes)     # ifthenelse(IsChannel, 5, Ldd)
+    p = syn.router_params(N, seed=12)
+    q0 = [np.minimum(p["Q0"], 50.0) * rng.uniform(0, 1, N) for _ in range(3)]
+    lat = [syn.lateral_inflow(N, i, hi=2e-5) for i in range(3)]
+
+    def run(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        g = Graph(ldd_raster=raster)
+        kws = [kinematicWave(None, None, p["alpha"] * f, p["beta"], 5000.0, 86400.0, graph=g) for f in (1.0, 2.5, 0.4)]
+        plans = [kw.route_plan_stats() for kw in kws]
+        tmp = _lib.DeviceArray(N)
+        qs, ls = [], []
+        for kw, a, b in zip(kws, q0, lat):
+            for host, dst in ((a, qs), (b, ls)):
+                d = _lib.DeviceArray.from_host(host)
+                kw.to_engine_order(d, tmp)
+                d.copy_from(tmp)
+                dst.append(d)
+        for _ in range(2):
+            kinematicWave.route_together(kws, qs, ls, engine_order=True)
+        out = [d.download() for d in qs]
+        launches = kws[0].last_launches()["launches"]
+        for d in qs + ls + [tmp]:
+            d.free()
+        for kw in kws:
+            kw.close()
+        for k in env:
+            monkeypatch.delenv(k)
+        return out, plans, launches
+    tuned, plans_t, launches_t = run({})
+    default, plans_d, launches_d = run({"LF_ROUTE_TUNE": "0"})
+    levels, _, launches_l = run({"LF_ROUTE_CONES": "0"})
+    for a, b, c in zip(tuned, default, levels):
+        assert np.array_equal(a, b) and np.array_equal(a, c) and np.isfinite(a).all()
+    assert plans_d[0]["lane_use"] < 0.4                                    # the case the tuning is for
+    assert plans_t[0]["blocks"] > plans_d[0]["blocks"] and plans_t[0]["lane_use"] > plans_d[0]["lane_use"]
+    assert plans_t[0] == plans_t[1] == plans_t[2]                          # one graph, one plan
+    assert launches_d <= launches_t < launches_l
+
+
 def test_land_surface_in_one_pass_equals_the_three_launches(amd, solver):
     """lf_land_columns_device (canopy, ESMax = ESRef * LAITerm and the soil columns in ONE pass: the lane that runs a
     column's canopy carries LeafDrainage, Interception, W1a / W1b / W1 and ESMax into the column's soil water balance in
