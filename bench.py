@@ -423,6 +423,8 @@ def structures_step_bench(size=3000, nsteps=24):
     v.ChanQ = v.ChanQKin.copy()
     v.CrossSection2Area, v.Sideflow1Chan, v.sumDisDay = np.zeros(N), np.zeros(N), np.zeros(N)
     d, cut = syn.structures_scenario(codes, (H, W), v.ChanQ, dt)
+    if os.environ.get("LF_BENCH_NO_TRANS") == "1":        # A/B: no transmission-loss reach (the scenario flags 30 % of the cells)
+        d["UpTrans"] = np.zeros(N, bool)
     for k, x in d.items():
         setattr(v, k, x)
     m = routing(v, options=dict(SplitRouting=True, InitLisflood=False, simulateLakes=True, simulateReservoirs=True,
@@ -946,7 +948,9 @@ def compact_line(out, detail):
             bound(k, "valu", moved_frac=round(legs[k]["frac"] * tr, 3) if tr and legs[k].get("frac") else None)
     if "model_step_structures_3000" in legs:
         x = legs["model_step_structures_3000"]
-        bound("model_step_structures_3000", "launch-latency", us_per_launch=round(x["ms"] * 1e3 / x["launches"], 1) if x.get("launches") else None)
+        # (not the launches: 422 / 235 / 141 launches with 16 / 32 / 64 levels per block all take 21.3-22.4 ms -- the ~6 us a lone
+        # wavefront needs per level of a cone, times the levels, over the ~1100 cones a launch has in flight)
+        bound("model_step_structures_3000", "level-latency", us_per_launch=round(x["ms"] * 1e3 / x["launches"], 1) if x.get("launches") else None)
     bound("overland_sparse_4000", "valu")
     bound("etrs89_chain", "launch-latency")
     if any(k.startswith("hot_path_") for k in legs):
