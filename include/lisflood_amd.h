@@ -69,6 +69,10 @@ int lf_device_name(int device, char *buf, size_t buflen); /* gcnArchName, e.g. "
 int lf_device_alloc(int device, size_t bytes, void **ptr_dev);
 int lf_device_free(int device, void *ptr_dev);
 int lf_memcpy_h2d(int device, void *dst_dev, const void *src_host, size_t bytes);
+/* the same without waiting: the bytes are copied to a page-locked staging slot owned by the library (the source is free
+ * again on return) and go up by DMA on the stream the library calls currently go to, in order with the kernels around it.
+ * For small per-step vectors (inflow hydrographs, LAI): lf_memcpy_h2d's wait for the stream would stall the host. */
+int lf_memcpy_h2d_staged(int device, void *dst_dev, const void *src_host, size_t bytes);
 /* Page-locked host memory for the vectors that cross PCIe every model step (the meteorological forcing, which the
  * reference reads from netCDF into fresh arrays each step, Lisflood_dynamic.py:84-112): a copy from such a buffer is a
  * true asynchronous DMA at the link's rate; from pageable memory the runtime stages it and blocks the caller (measured

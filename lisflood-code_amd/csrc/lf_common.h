@@ -50,6 +50,15 @@ struct lf_device_ctx {
     std::map<void *, std::pair<void *, size_t>> f32_stage; // lf_upload_copy_f32: fp32 staging buffer per destination vector
     hipEvent_t copied[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
     bool consumed_valid[2] = {false, false}, copied_valid[2] = {false, false};
+    // page-locked staging ring of lf_memcpy_h2d_staged: small per-step uploads that must not stall the host
+    struct staged_slot {
+        void *host = nullptr;
+        size_t cap = 0;
+        hipEvent_t done = nullptr;
+        bool in_flight = false;
+    };
+    staged_slot staged[8];
+    int staged_next = 0;
     // side stream (lf_side_stream_*): a part of a step that the NEXT step's first kernels do not depend on -- the channel
     // wavefront of a model step beside the canopy / soil / overland kernels of the step after it (hotpath.py)
     hipStream_t side_stream = nullptr, main_stream = nullptr;

@@ -164,6 +164,36 @@ int lf_memcpy_h2d(int device, void *dst_dev, const void *src_host, size_t bytes)
     return LF_OK;
 }
 
+// A small upload that does not stall the host: the bytes go to a page-locked slot of a ring owned by the context (host
+// memcpy, the source is free again on return) and from there by DMA on the stream the library calls currently go to -- main,
+// side or lane -- in order with the kernels around it.  lf_memcpy_h2d waits for the stream (its source may be pageable and
+// the caller may reuse it at once): for the per-step vectors of a small domain that wait IS the step (LF_ETRS89: two 23 kB
+// inflow vectors cost 0.7 of 1.85 ms).  A slot is reused only after its copy has finished (event per slot).
+int lf_memcpy_h2d_staged(int device, void *dst_dev, const void *src_host, size_t bytes)
+{
+    if (!dst_dev || (!src_host && bytes)) return lf_set_error(LF_E_INVALID, "null argument");
+    lf_device_ctx *c;
+    LF_TRY(lf_ctx(device, &c));
+    if (!bytes) return LF_OK;
+    lf_device_ctx::staged_slot &sl = c->staged[c->staged_next];
+    c->staged_next = (c->staged_next + 1) % 8;
+    if (sl.in_flight) LF_HIP(hipEventSynchronize(sl.done));
+    sl.in_flight = false;
+    if (sl.cap < bytes) {
+        if (sl.host) (void)hipHostFree(sl.host);
+        sl.host = nullptr;
+        sl.cap = 0;
+        LF_HIP(hipHostMalloc(&sl.host, bytes, hipHostMallocDefault));
+        sl.cap = bytes;
+    }
+    if (!sl.done) LF_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    std::memcpy(sl.host, src_host, bytes);
+    LF_HIP(hipMemcpyAsync(dst_dev, sl.host, bytes, hipMemcpyHostToDevice, c->stream));
+    LF_HIP(hipEventRecord(sl.done, c->stream));
+    sl.in_flight = true;
+    return LF_OK;
+}
+
 // ---- double-buffered uploads on a second stream ------------------------------------------------------------------
 // Protocol for buffer set b in {0, 1}:   lf_upload_begin(b); lf_upload_copy(...) x n; lf_upload_end(b)   [any time]
 //                                        lf_compute_acquire(b); <kernels reading set b>; lf_compute_release(b)

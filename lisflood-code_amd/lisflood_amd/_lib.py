@@ -137,6 +137,16 @@ class DeviceArray:
         check(lib().lf_memcpy_h2d(C.c_int(self.device), self.ptr, ptr(a), C.c_size_t(self.nbytes)))
         return self
 
+    def upload_staged(self, a):
+        """upload() that does not wait for the device (lf_memcpy_h2d_staged): `a` is copied to a page-locked staging slot
+        of the library before the call returns; the DMA runs in order on the stream the library calls currently go to"""
+        a = np.ascontiguousarray(a)
+        if a.dtype == np.bool_:
+            a = a.view(np.uint8)
+        assert a.nbytes == self.nbytes and a.dtype == self.dtype, (a.shape, a.dtype, self.shape, self.dtype)
+        check(lib().lf_memcpy_h2d_staged(C.c_int(self.device), self.ptr, ptr(a), C.c_size_t(self.nbytes)))
+        return self
+
     def download(self, out=None):
         if out is None:
             out = np.empty(self.shape, self.dtype)

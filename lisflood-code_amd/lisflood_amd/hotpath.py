@@ -337,8 +337,19 @@ class HotPathDevice:
         q = np.ascontiguousarray(q[self.ids])
         m, dev = self.rmod, self.rmod._st["dev"]
         delta = (q - self._qin_old) * m.var.InvNoRoutSteps
-        dev["QInM3Old"].upload(f64(m._up(self._qin_old)))
-        dev["QDelta"].upload(f64(m._up(delta)))
+        # Only the channel wavefront reads the two vectors: they go up on ITS stream (the side stream when the wavefront
+        # runs there), behind the wavefront of the step before and ahead of the next one, without a host wait and without
+        # making the main stream wait for the side stream (lf_memcpy_h2d would do both)
+        L, d = lib(), C.c_int(self.device)
+        side = self.overlap_channel
+        if side:
+            check(L.lf_side_stream_begin(d))
+        try:
+            dev["QInM3Old"].upload_staged(f64(m._up(self._qin_old)))
+            dev["QDelta"].upload_staged(f64(m._up(delta)))
+        finally:
+            if side:
+                check(L.lf_side_stream_end(d))
         self._qin_old = q
 
     def step(self, forcing, time_since_start=None, QInM3=None, ordered=False):
