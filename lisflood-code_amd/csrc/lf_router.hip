@@ -613,6 +613,10 @@ static int build_level_blocks(lf_router *r, const lf_graph *g, bool for_route, i
         for (int64_t k = 0; k < g->NL; ++k) widest = std::max(widest, g->level_start[k + 1] - g->level_start[k]);
         if (widest <= 3000) lmax = 32;
     }
+    // a catchment of a few thousand cells (LF_ETRS89: 2 847 cells, 113 levels): every launch is its own latency, a cone's chain
+    // of levels is what it costs, and 8 levels per block balance chain against launch count (model step with structures, ms:
+    // 2.29 / 1.96 / 1.96 / 2.20 / 2.96 for 2 / 4 / 8 / 16 / 32 levels per block)
+    if (!for_route && g->N <= 65536) lmax = 8;
     if (const char *e = std::getenv(for_route ? "LF_ROUTE_LEVELS" : "LF_FUSED_LEVELS")) lmax = std::atoi(e);
     if (lmax_override > 0) lmax = lmax_override;
     lmax = lmax < 1 ? 1 : (lmax > (for_route ? 512 : 64) ? (for_route ? 512 : 64) : lmax);
