@@ -45,9 +45,10 @@ def peak_rss_gb():
     return resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6
 
 
-def catchment_leg(a, T, rank, world, device):
+def catchment_leg(a, T, rank, world, device, model_step=True):
     """Same raster, same calls, ranks own whole catchments (lisflood_amd.partition): no halo, no collective on the data
-    path.  Every rank derives the partition from the full LDD itself (set-up, untimed)."""
+    path.  Every rank derives the partition from the full LDD itself (set-up, untimed).  model_step=False: the router
+    calls only (what main() measures FIRST, as the line's fallback should the RCCL path fail)."""
     from lisflood_amd import _lib
     from lisflood_amd import partition as P
     from lisflood_amd import synthetic as syn
@@ -112,8 +113,20 @@ def catchment_leg(a, T, rank, world, device):
            "largest_catchment": int(sizes.max()), "finite": bool(ok[0] == world and int(ok[1]) == N),
            "checksum_sumQ": float(ok[2]),
            "note": "ranks own whole catchments (no exchange on the data path); engine-order vectors as in the N = 1 run"}
-    # configs[4]'s workload shape on the same partition: a model step of 24 split-routing sub-steps as ONE fused wavefront
-    # per rank (level blocks + cones), no exchange
+    ctx = {"codes": codes, "mask": mask, "ids": ids, "H": H, "W": W, "N": N}
+    if not model_step:
+        out["_ctx"] = ctx      # (popped by main(): what catchment_model_step needs later)
+        return out
+    return catchment_model_step(a, T, rank, world, device, ctx, out)
+
+
+def catchment_model_step(a, T, rank, world, device, ctx, out):
+    """configs[4]'s workload shape on the catchment partition: a model step of 24 split-routing sub-steps as ONE fused
+    wavefront per rank (level blocks + cones), no exchange.  Adds its object to `out`."""
+    from lisflood_amd import _lib
+    from lisflood_amd import synthetic as syn
+    from lisflood_amd.kinematic_wave_parallel import kinematicWave
+    codes, mask, ids, H, W, N = ctx["codes"], ctx["mask"], ctx["ids"], ctx["H"], ctx["W"], ctx["N"]
     err = None
     nsteps = 24
     try:
@@ -221,6 +234,49 @@ def row_block_model_step(a, T, rank, world, device, graph, comm, N, i0, i1, nste
                     "neighbour and section"}
 
 
+def headline_line(a, world, N, ms, workload, extra_config, roof_kernel):
+    """the contract's keys for the N > 1 line (value = the whole raster's cells per second over all ranks)"""
+    value = N / ms / 1e3
+    cfg = {"workload": workload, "cells": N}
+    cfg.update(extra_config)
+    return {
+        "metric": "Mcell-steps/s kinematic routing", "value": round(value, 2), "unit": "Mcell-steps/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": cfg,
+        "hbm_frac_whole_step": round(B_ALG * N / (ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), 6),
+        # per-GPU algorithmic bandwidth over the WHOLE step (sweeps + packs + RCCL halo rounds), not a
+        # per-kernel hipEvent figure: the per-kernel roofline is reported by the N = 1 run
+        "roofline": {"bound": "hbm", "kernel": roof_kernel,
+                     "achieved": round(B_ALG * N / world / (ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(B_ALG * N / world / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                     "traffic": None},
+    }
+
+
+class Watchdog:
+    """Bounds a section that may hang where nothing can be cancelled (a collective whose peer never arrives): after
+    `seconds` it runs `on_expiry` (rank 0: print the fallback line) and ends THIS process with os._exit -- every rank
+    arms its own, so the launcher sees all of them end.  disarm() before the section's normal end."""
+
+    def __init__(self, seconds, on_expiry, what):
+        import threading
+        self._t = threading.Timer(seconds, self._fire)
+        self._t.daemon = True
+        self._on_expiry, self._what, self._seconds = on_expiry, what, seconds
+        self._t.start()
+
+    def _fire(self):
+        try:
+            print("[bench] watchdog: %s did not finish within %.0f s" % (self._what, self._seconds), file=sys.stderr, flush=True)
+            self._on_expiry("%s did not finish within %.0f s" % (self._what, self._seconds))
+        finally:
+            os._exit(0)     # (every rank: the launcher must not turn the line that went out into a failed run)
+
+    def disarm(self):
+        self._t.cancel()
+
+
 def main(a):
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on these hosts (before HIP starts)
     from lisflood_amd import _lib
@@ -233,99 +289,153 @@ def main(a):
     T = D.SocketTransport.from_env(timeout=300.0)     # a rank that dies must not leave the others waiting for ever
     ndev = _lib.device_count()
     device = local_rank % max(ndev, 1)
-    t_setup = time.time()
     H = W = a.size
-    seed = {"shallow": 1, "deep": 2, "river": 7}[a.family]
-    r0, r1 = D.row_blocks(H, world)[rank]
-    g0, g1 = max(0, r0 - 1), min(H, r1 + 1)
-    codes = syn.make_ldd(a.family, H, W, seed, r0=g0, r1=g1)
-    top = codes[0] if r0 > 0 else None
-    bot = codes[-1] if r1 < H else None
-    local = codes[(r0 - g0):(r0 - g0) + (r1 - r0)]
-    graph = D.DistGraph(local, None, top, None, bot, None)
-    D.settle_phases(graph, T)
-    uid = T.broadcast(D.Comm.unique_id() if rank == 0 else None, src=0)
-    # RCCL announces its version / library path on stdout (C stdio) while the communicator is built: send that to stderr
-    # so that stdout carries the ONE JSON line and nothing else
-    sys.stdout.flush()
-    saved = os.dup(1)
-    os.dup2(2, 1)
-    try:
-        comm = D.Comm(uid, world, rank, device)
-        _flush_c_stdio()
-    finally:
-        os.dup2(saved, 1)
-        os.close(saved)
     N = H * W
-    i0, i1 = r0 * W, r1 * W
-    p = syn.router_params_slice(N, i0, i1)
-    router = D.DistRouter(graph, p["alpha"], p["beta"], p["dx"], p["dt"], device=device, comm=comm,
-                          rank_top=rank - 1 if rank > 0 else -1, rank_bottom=rank + 1 if rank + 1 < world else -1)
-    Q = router.new_state(p["Q0"])
-    nq = 3
-    qs = [router.new_state(syn.lateral_inflow_slice(N, s, i0, i1)) for s in range(nq)]
-    _lib.synchronize(device)
-    log(rank, "rows [%d,%d) cells=%d phases=%d launch_units=%d ghosts=%s exports=%s non-contiguous inflow: %d cells; "
-        "setup %.1f s, peak host memory %.1f GB" % (r0, r1, graph.num_pixels, graph.num_phases, graph.num_launch_units,
-                                                     graph.n_ghost, graph.n_export, graph.num_noncontiguous,
-                                                     time.time() - t_setup, peak_rss_gb()))
-    # the K calls as ONE pipelined sequence (lf_dist_router_route_many: phase 0 of call s + 1 beside the later halo rounds
-    # of call s, alternating state vectors); LF_DIST_OVERLAP=0 or a single phase: call by call
-    if a.warmup:
-        router.route_many(Q, [qs[s % nq] for s in range(a.warmup)])
-    _lib.synchronize(device)
-    T.barrier()
-    t0 = time.perf_counter()
-    router.route_many(Q, [qs[s % nq] for s in range(a.steps)])
-    _lib.synchronize(device)
-    dt_local = time.perf_counter() - t0
-    T.barrier()
-    dt_max = float(T.allreduce(dt_local, "max"))
-    Qh = router.download_pix(Q)
-    chk = T.allreduce(np.array([float(Qh.sum()), float(np.isfinite(Qh).all() and (Qh >= 0).all())]), "sum")
-    launches = int(T.allreduce(int(router.last_launches()), "max"))
+    seed = {"shallow": 1, "deep": 2, "river": 7}[a.family]
+    family_name = {"shallow": "random ('shallow')", "deep": "sheet-flow ('deep')", "river": "dendritic ('river')"}[a.family]
+    workload = "%dx%d fp64 raster, %s LDD (seed %d), all land, beta=0.6, 1 router call per step" % (H, W, family_name, seed)
+
+    # (1) FIRST the partition that needs no exchange: the same raster, the same calls, ranks own whole catchments and run
+    # the single-GPU engine.  It is the line's secondary object when the row-block path below works -- and the line's
+    # headline should that path fail or hang on the first real links it meets (nothing before the driver's N > 1 run has
+    # ever put RCCL on more than one device: DESIGN.md section 6), so that a scaling point exists either way.
+    catch, catch_ctx = None, None
+    if os.environ.get("LF_BENCH_CATCHMENT_FIRST", "1") == "1":
+        try:
+            catch = catchment_leg(a, T, rank, world, device, model_step=False)
+            catch_ctx = catch.pop("_ctx", None)
+        except Exception as e:  # must never cost the headline line
+            catch = {"error": repr(e)}
+
     out = None
-    if rank == 0:           # the headline first: nothing a secondary leg does below can cost it
-        ms = dt_max * 1e3 / a.steps
-        value = N / ms / 1e3
-        out = {
-            "metric": "Mcell-steps/s kinematic routing", "value": round(value, 2), "unit": "Mcell-steps/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 4),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%dx%d fp64 raster, %s LDD (seed %d), all land, beta=0.6, 1 router call per step"
-                                   % (H, W, {"shallow": "random ('shallow')", "deep": "sheet-flow ('deep')",
-                                             "river": "dendritic ('river')"}[a.family], seed),
-                       "cells": N, "phases": graph.num_phases, "max_launches_per_step": launches,
-                       "layout": "engine sweep order per rank, ghost slots appended",
-                       "parallelism": "row-block x%d, RCCL Send/Recv halo per phase on a second stream, calls pipelined "
-                                      "on alternating state vectors; rendezvous over TCP sockets (no PyTorch in the "
-                                      "ranks)" % world},
-            "hbm_frac_whole_step": round(B_ALG * N / (ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), 6),
-            # per-GPU algorithmic bandwidth over the WHOLE step (sweeps + packs + RCCL halo rounds), not a
-            # per-kernel hipEvent figure: the per-kernel roofline is reported by the N = 1 run
-            "roofline": {"bound": "hbm", "kernel": "k_level[fused+ordered+indexed] (whole step, per GPU)",
-                         "achieved": round(B_ALG * N / world / (ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(B_ALG * N / world / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
-                         "traffic": None},
-            "checksum_sumQ": float(chk[0]), "finite": bool(chk[1] == world),
-            "rccl_library": loaded_rccl(),
-        }
     printed = [False]
 
-    def emit():             # the ONE JSON line (rank 0), whatever happened after the headline was measured
-        if rank == 0 and out is not None and not printed[0]:
+    def fallback_line(why):
+        """the catchment partition as the headline (rank 0; None if that leg has no number either)"""
+        if rank != 0 or not catch or "value" not in catch:
+            return None
+        ms = catch["ms_per_step"]
+        line = headline_line(a, world, N, ms, workload,
+                             {"cells_per_rank": catch["cells_per_rank"], "catchments": catch["catchments"],
+                              "layout": "engine sweep order per rank",
+                              "parallelism": "catchment partition x%d: ranks own whole catchments, no exchange on the data "
+                                             "path (fallback headline: the row-block RCCL path did not complete)" % world},
+                             "k_level[fused+ordered] (whole step, per GPU)")
+        line["checksum_sumQ"] = catch["checksum_sumQ"]
+        line["finite"] = catch["finite"]
+        line["row_block_error"] = why
+        line["rccl_library"] = loaded_rccl()
+        return line
+
+    def emit(line=None):    # the ONE JSON line (rank 0), whatever happened after the headline was measured
+        line = line if line is not None else out
+        if rank == 0 and line is not None and not printed[0]:
             printed[0] = True
-            out["peak_host_memory_gb_rank0"] = round(peak_rss_gb(), 2)
+            line["peak_host_memory_gb_rank0"] = round(peak_rss_gb(), 2)
             _flush_c_stdio()
-            print(json.dumps(out), flush=True)
+            print(json.dumps(line), flush=True)
+
+    def on_hang(why):       # (watchdog thread) the row-block path hangs: what has been measured goes out, the process ends
+        emit(out if out is not None else fallback_line(why))
+
     if rank == 0:           # an exception nobody caught, SIGTERM from a launcher that lost another rank: the line still goes out
         import atexit
         import signal
-        atexit.register(emit)
+        atexit.register(lambda: emit(out if out is not None else fallback_line("the row-block path raised before its headline")))
         try:
-            signal.signal(signal.SIGTERM, lambda *_: (emit(), os._exit(1)))
+            signal.signal(signal.SIGTERM, lambda *_: (emit(out if out is not None else fallback_line("SIGTERM before the row-block headline")), os._exit(1)))
         except (ValueError, OSError):
             pass
+
+    # (2) the row-block partition: set-up, RCCL communicator, K pipelined router calls.  Every step that can fail is inside
+    # the try; the ranks agree on the outcome over the sockets afterwards (a rank that is stuck in a collective is ended by
+    # its watchdog, which makes the others' socket calls fail: they end up in the same branch).
+    limit = float(os.environ.get("LF_BENCH_RCCL_TIMEOUT_S", "300"))
+    dog = Watchdog(limit, on_hang, "the row-block RCCL path (set-up + %d + %d router calls)" % (a.warmup, a.steps))
+    err, comm, router, graph = None, None, None, None
+    chk, launches, dt_max = None, 0, None
+    try:
+        if os.environ.get("LF_BENCH_FAIL_ROW_BLOCKS") == "1":     # (tests: the fallback line)
+            raise RuntimeError("LF_BENCH_FAIL_ROW_BLOCKS=1")
+        if os.environ.get("LF_BENCH_HANG_ROW_BLOCKS") == "1":     # (tests: the watchdog)
+            time.sleep(1e6)
+        t_setup = time.time()
+        r0, r1 = D.row_blocks(H, world)[rank]
+        g0, g1 = max(0, r0 - 1), min(H, r1 + 1)
+        codes = syn.make_ldd(a.family, H, W, seed, r0=g0, r1=g1)
+        top = codes[0] if r0 > 0 else None
+        bot = codes[-1] if r1 < H else None
+        local = codes[(r0 - g0):(r0 - g0) + (r1 - r0)]
+        graph = D.DistGraph(local, None, top, None, bot, None)
+        D.settle_phases(graph, T)
+        uid = T.broadcast(D.Comm.unique_id() if rank == 0 else None, src=0)
+        # RCCL announces its version / library path on stdout (C stdio) while the communicator is built: send that to
+        # stderr so that stdout carries the ONE JSON line and nothing else
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            comm = D.Comm(uid, world, rank, device)
+            _flush_c_stdio()
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
+        i0, i1 = r0 * W, r1 * W
+        p = syn.router_params_slice(N, i0, i1)
+        router = D.DistRouter(graph, p["alpha"], p["beta"], p["dx"], p["dt"], device=device, comm=comm,
+                              rank_top=rank - 1 if rank > 0 else -1, rank_bottom=rank + 1 if rank + 1 < world else -1)
+        Q = router.new_state(p["Q0"])
+        nq = 3
+        qs = [router.new_state(syn.lateral_inflow_slice(N, s, i0, i1)) for s in range(nq)]
+        _lib.synchronize(device)
+        log(rank, "rows [%d,%d) cells=%d phases=%d launch_units=%d ghosts=%s exports=%s non-contiguous inflow: %d cells; "
+            "setup %.1f s, peak host memory %.1f GB" % (r0, r1, graph.num_pixels, graph.num_phases, graph.num_launch_units,
+                                                         graph.n_ghost, graph.n_export, graph.num_noncontiguous,
+                                                         time.time() - t_setup, peak_rss_gb()))
+        # the K calls as ONE pipelined sequence (lf_dist_router_route_many: phase 0 of call s + 1 beside the later halo
+        # rounds of call s, alternating state vectors); LF_DIST_OVERLAP=0 or a single phase: call by call
+        if a.warmup:
+            router.route_many(Q, [qs[s % nq] for s in range(a.warmup)])
+        _lib.synchronize(device)
+        T.barrier()
+        t0 = time.perf_counter()
+        router.route_many(Q, [qs[s % nq] for s in range(a.steps)])
+        _lib.synchronize(device)
+        dt_local = time.perf_counter() - t0
+        T.barrier()
+        dt_max = float(T.allreduce(dt_local, "max"))
+        Qh = router.download_pix(Q)
+        chk = T.allreduce(np.array([float(Qh.sum()), float(np.isfinite(Qh).all() and (Qh >= 0).all())]), "sum")
+        launches = int(T.allreduce(int(router.last_launches()), "max"))
+    except Exception as e:
+        err = repr(e)
+        log(rank, "row-block path failed: %s" % err)
+    try:                    # the ranks agree (a peer that is gone makes this raise: same branch)
+        all_ok = int(T.allreduce(0 if err else 1, "min")) == 1
+    except Exception as e:
+        all_ok, err = False, err or ("a peer left the row-block path: %r" % (e,))
+    dog.disarm()
+    if not all_ok:
+        emit(fallback_line(err or "the row-block path failed on another rank"))
+        try:
+            T.close()
+        except Exception:
+            pass
+        return
+    if rank == 0:           # the headline first: nothing a secondary leg does below can cost it
+        ms = dt_max * 1e3 / a.steps
+        out = headline_line(a, world, N, ms, workload,
+                            {"phases": graph.num_phases, "max_launches_per_step": launches,
+                             "layout": "engine sweep order per rank, ghost slots appended",
+                             "parallelism": "row-block x%d, RCCL Send/Recv halo per phase on a second stream, calls pipelined "
+                                            "on alternating state vectors; rendezvous over TCP sockets (no PyTorch in the "
+                                            "ranks)" % world},
+                            "k_level[fused+ordered+indexed] (whole step, per GPU)")
+        out["checksum_sumQ"] = float(chk[0])
+        out["finite"] = bool(chk[1] == world)
+        out["rccl_library"] = loaded_rccl()
+    # from here on a hang costs the secondary objects only: the watchdog prints the line as it stands
+    dog = Watchdog(float(os.environ.get("LF_BENCH_EXTRA_TIMEOUT_S", "600")), on_hang, "a secondary leg of the N > 1 bench")
     # configs[4]'s workload shape on the SAME row blocks: a model step of 24 split-routing sub-steps, every sub-step of a
     # phase as one wavefront (level blocks + cones), ONE RCCL halo block per phase and model step
     row_step = None
@@ -334,13 +444,12 @@ def main(a):
             row_step = row_block_model_step(a, T, rank, world, device, graph, comm, N, i0, i1)
         except Exception as e:
             row_step = {"error": repr(e)}
-    # secondary: the same raster partitioned by whole catchments -- no exchange, every rank runs the single-GPU engine
-    catch = None
-    if not getattr(a, "no_extra", False):
+    # secondary: the model step on the catchment partition (its router calls were measured first, above)
+    if catch is not None and catch_ctx is not None and "value" in catch and not getattr(a, "no_extra", False):
         try:
-            catch = catchment_leg(a, T, rank, world, device)
+            catchment_model_step(a, T, rank, world, device, catch_ctx, catch)
         except Exception as e:  # must never cost the headline line
-            catch = {"error": repr(e)}
+            catch["model_step_24_substeps_split"] = {"error": repr(e)}
     if rank == 0:
         if row_step is not None:
             out["model_step_24_substeps_split_row_blocks"] = row_step
@@ -358,4 +467,5 @@ def main(a):
         T.close()
     except Exception as e:
         log(rank, "shutdown: %r" % (e,))
+    dog.disarm()
     emit()                  # the ONE JSON line, last on stdout

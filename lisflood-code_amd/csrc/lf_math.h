@@ -312,8 +312,13 @@ __device__ __forceinline__ double lf_pow_pos(double x, double y)
 // they stay bit-identical to one another.
 // Out of line: inlined twice into the cone kernels it cost them 30 VGPRs (spills in k_fused_cones<STRUCT>, one wavefront
 // per SIMD in k_fused_cones_split<STRUCT>).
+// The settings' defaults are TransPower1 = 2 and TransPower2 = 1 / TransPower1 = 0.5 (cold.xml:1329, transmission.py:57):
+// numpy itself evaluates `arr ** 2.0` as np.square and `arr ** 0.5` as np.sqrt (its scalar-exponent fast paths), so x * x
+// and the IEEE square root are what the reference computes there -- one and ~15 instructions (y is wavefront-uniform).
 static __device__ __attribute__((noinline)) double lf_pow_scalar_exponent(double x, double y)
 {
+    if (y == 2.0) return x * x;
+    if (y == 0.5) return sqrt(x);
     if (y > 0.0 && y < 1e6 && !(x < 0.0)) return lf_pow_pos(x, y); // (y is a kernel argument; negative bases are the rare lanes)
     return pow(x, y);
 }

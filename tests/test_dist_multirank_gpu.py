@@ -153,3 +153,19 @@ def test_bench_line_of_a_multi_rank_job(fake_rccl, world):
     assert step.get("finite") is True, step
     for rank in range(1, world):
         assert outs[rank][0].strip() == ""
+
+
+@pytest.mark.parametrize("how", ["raises", "hangs"])
+def test_bench_line_when_the_row_block_path_fails(fake_rccl, how):
+    """the N > 1 line must exist even if the row-block RCCL path fails or hangs on the first real links it meets: the
+    catchment partition (measured first, no exchange on the data path) becomes the headline and the line says why"""
+    import json
+    env = {"LF_BENCH_FAIL_ROW_BLOCKS": "1"} if how == "raises" else {"LF_BENCH_HANG_ROW_BLOCKS": "1", "LF_BENCH_RCCL_TIMEOUT_S": "15"}
+    outs = run_ranks(fake_rccl, 2, "bench.py", env,
+                     args=["--gpus", "2", "--size", "1200", "--steps", "4", "--warmup", "1"], timeout=600)
+    lines = [l for l in outs[0][0].splitlines() if l.strip()]
+    assert len(lines) == 1, outs[0][0][-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["finite"] and d["value"] > 0 and d["metric"].startswith("Mcell-steps/s")
+    assert "row_block_error" in d and "catchment partition" in d["config"]["parallelism"]
+    assert outs[1][0].strip() == ""
