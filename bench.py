@@ -474,6 +474,25 @@ def structures_step_bench(size=3000, nsteps=24):
                      % (H, W, d["LakeIndex"].size, d["ReservoirIndex"].size, r.graph.num_levels, nsteps))
     finite = bool(np.isfinite(m._dev["ChanQ"].download()).all())
     out["finite"] = finite
+    # (last: reaches that run dry under the default powers would be NaN under the scenario's own, whose inner term must stay
+    # positive -- nothing above may see that state)
+    # the same step with the transmission-loss powers of the reference's settings (TransPower1 = 2, TransPower2 = 1 / 2,
+    # TransSub = 0.3: cold.xml:1323-1329, transmission.py:57-59) instead of the scenario's 1 / 0.95 and 0.95: numpy evaluates
+    # those two as a square and a square root and so does the engine (lf_pow_scalar_exponent) -- one and ~15 instructions
+    # instead of two ~75-instruction powers per flagged cell and sub-step
+    saved = (m._inloop.TransPower1, m._inloop.TransPower2, m._inloop.TransSub)
+    m._inloop.TransPower1, m._inloop.TransPower2, m._inloop.TransSub = 2.0, 0.5, 0.3
+    _lib.check(L.lf_routing_substeps_fused_structures(r._h, C.byref(m._args), C.byref(m._inloop), C.c_int(nsteps)))
+    _lib.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        _lib.check(L.lf_routing_substeps_fused_structures(r._h, C.byref(m._args), C.byref(m._inloop), C.c_int(nsteps)))
+    _lib.synchronize()
+    ms_d = (time.perf_counter() - t0) * 1e3 / 3
+    out["fused_with_the_settings_default_transmission_powers"] = dict(
+        ms_per_model_step=round(ms_d, 3), value=round(2 * nsteps * N / ms_d / 1e3, 2), unit="Mcell-steps/s",
+        finite=bool(np.isfinite(m._dev["ChanQ"].download()).all()))
+    m._inloop.TransPower1, m._inloop.TransPower2, m._inloop.TransSub = saved
     return out
 
 
