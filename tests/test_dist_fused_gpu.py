@@ -2,6 +2,8 @@
 as lf_dist_routing_substeps_fused runs it -- phase by phase, every sub-step of a phase as one wavefront, one halo block
 per phase -- against lf_routing_substeps_fused on the whole raster: bit-identical.  The blocks live on ONE GPU and the
 halo travels by device copy (the test boxes have one GPU); kernels and plan are those of the RCCL path."""
+import os
+
 import numpy as np
 import pytest
 
@@ -155,6 +157,9 @@ def test_pipelined_router_calls_on_alternating_state_vectors(amd, family, seed, 
     (no communicator: call by call) agrees too."""
     from lisflood_amd import dist as D
     from lisflood_amd import synthetic as syn
+    if os.environ.get("LF_GENERAL_POW") == "1":
+        pytest.skip("the pipelined form reads the old discharge from a second vector: the beta = 3/5 path only "
+                    "(lf_dist_router_route_many routes call by call otherwise)")
     H, W = 300, 260
     N = H * W
     codes = syn.make_ldd(family, H, W, seed)

@@ -1164,7 +1164,8 @@ def test_hot_path_with_unreported_maps_left_out(amd):
         HotPathDevice(cp(values), sc, mask, ldd_to_chan, ldd_kin, split=True, report=("ChanQ",))
     bytes_full, bytes_lean = full.stage_bytes(), lean.stage_bytes()
     assert bytes_lean["pixel_aggregates"] < 0.5 * bytes_full["pixel_aggregates"]
-    assert bytes_lean["land_surface"] < bytes_full["land_surface"]
+    land = lambda b: b["land_surface"] if "land_surface" in b else b["canopy"] + b["soil_columns"]     # (LF_LAND_FUSED=0)
+    assert land(bytes_lean) < land(bytes_full)
     for s in range(3):
         f = syn.hotpath_forcing(N, s)
         for hp in (full, lean, some):
