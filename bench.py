@@ -184,7 +184,7 @@ def committed_rocprof_mean(cells_per_launch):
                     key=lambda f: os.path.basename(f).split("head")[0], reverse=True):
         try:
             for r in csv.DictReader(open(f)):
-                if "k_level<true, true, false>" in r["Name"]:
+                if "k_level<true, true, false" in r["Name"]:       # (round 6: k_level<true, true, false, 2>, the static-record form)
                     us = float(r["AverageNs"]) / 1e3
                     return dict(file=os.path.relpath(f, ROOT), mean_launch_us=round(us, 3), calls=int(r["Calls"]),
                                 frac=round(B_ALG * cells_per_launch / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 6))
@@ -208,7 +208,7 @@ def roofline_of(res, kernel_key=None, workload=None):
     traffic, src = pmc_traffic(kernel_key, cells_per_launch) if kernel_key else (None, None)
     counters = None
     if workload:        # round-3 digests: per workload, the dominant kernel by name
-        t3, s3, counters = pmc_traffic_r03(workload, "k_level<true, true, false>" if dom is wide else "k_sweep_cones")
+        t3, s3, counters = pmc_traffic_r03(workload, "k_level<true, true, false" if dom is wide else "k_sweep_cones")
         if t3 is not None:
             traffic, src = t3, s3
     check = committed_rocprof_mean(cells_per_launch) if (kernel_key and dom is wide) else None

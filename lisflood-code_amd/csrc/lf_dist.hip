@@ -809,6 +809,8 @@ struct lf_dist_router {
     lf_dbuf<int32_t> perm, ups_ptr, ups_idx, ups_base, export_pos[2];
     lf_dbuf<long long> level_start;
     lf_dbuf<double> a1, a2, dx, constant, sendbuf[2];
+    lf_dbuf<lf_rec24> rec24_1, rec24_2; // the level kernel's static values as one record per cell and section (dist_level_statics)
+    bool statics_refused = false;
     std::vector<int64_t> h_level_start;
     std::vector<std::vector<dsegment>> schedule; // per stage (2 * phase + part, see lf_dist_graph::crit)
     // halo exchange beside the bulk part of a phase: second stream + events (lf_dist_router_route)
@@ -840,6 +842,28 @@ struct lf_dist_router {
 
 namespace {
 
+// The static values a cell of the level kernel reads (a, dx, its upstream list range, ups_base) as ONE 24-byte record per
+// section instead of four streams (k_level<.., STATICS = 3>, lf_sweep.h), built on the first call; nullptr: scalar dx,
+// LF_LEVEL_STATICS=0, a graph of 2^28 cells or more, or no memory for them.
+const lf_rec24 *dist_level_statics(lf_dist_router *r, const sweep_args &A)
+{
+    if (!r->fused || !r->dx_per_pixel || r->statics_refused || r->N <= 0 || r->N >= ((int64_t)1 << 28)) return nullptr;
+    const char *e = std::getenv("LF_LEVEL_STATICS");
+    if (e && e[0] == '0') return nullptr;
+    lf_dbuf<lf_rec24> &buf = (A.a == r->a1.p) ? r->rec24_1 : r->rec24_2;
+    if (!buf.p) {
+        if (r->ups_idx.n >= ((size_t)1 << 28) || buf.alloc((size_t)r->N) != LF_OK) {
+            r->statics_refused = true;
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        hipLaunchKernelGGL(k_static_records_indexed, dim3((unsigned)((r->N + kLevelBlock - 1) / kLevelBlock)), dim3(kLevelBlock), 0,
+                           r->ctx->stream, (long long)r->N, A.a, (const double *)r->dx.p, (const int *)r->ups_ptr.p,
+                           (const int *)r->ups_base.p, buf.p);
+    }
+    return buf.p;
+}
+
 // part: 0 = the boundary-critical cells of the phase, 1 = the rest, -1 = both
 int dist_compute_phase(lf_dist_router *r, double *q, const double *lat, int section, int phase, int part = -1,
                        const double *q_in = nullptr)
@@ -866,6 +890,9 @@ int dist_compute_phase(lf_dist_router *r, double *q, const double *lat, int sect
     A.kmax = r->kmax;
     A.qord = q;
     A.q_pix = nullptr;
+    A.adx = nullptr;
+    A.rec = nullptr;
+    A.rec24 = dist_level_statics(r, A);
     A.qold_src = q_in; // pipelined calls: old discharge from the other state vector (beta = 3/5 path only)
     if (q_in && !r->fused) return lf_set_error(LF_E_INVALID, "separate input discharge needs the beta = 3/5 path");
     if (!r->fused && phase == 0 && part != 1 && r->N > 0) { // general beta: constant for ALL local cells from the old discharge
@@ -895,7 +922,9 @@ int dist_compute_phase(lf_dist_router *r, double *q, const double *lat, int sect
                     const int count = (int)(r->h_level_start[k0 + 1] - r->h_level_start[k0]);
                     if (count <= 0) continue;
                     const dim3 grid(level_blocks_for(count)), block(kLevelBlock);
-                    if (r->fused)
+                    if (r->fused && A.rec24)
+                        hipLaunchKernelGGL((k_level<true, true, true, 3>), grid, block, 0, s, first, count, A);
+                    else if (r->fused)
                         hipLaunchKernelGGL((k_level<true, true, true>), grid, block, 0, s, first, count, A);
                     else
                         hipLaunchKernelGGL((k_level<false, true, true>), grid, block, 0, s, first, count, A);
@@ -909,7 +938,9 @@ int dist_compute_phase(lf_dist_router *r, double *q, const double *lat, int sect
             const int first = (int)r->h_level_start[g.k0];
             const int count = (int)(r->h_level_start[g.k1] - r->h_level_start[g.k0]);
             const dim3 grid(level_blocks_for(count)), block(kLevelBlock);
-            if (r->fused)
+            if (r->fused && A.rec24)
+                hipLaunchKernelGGL((k_level<true, true, true, 3>), grid, block, 0, s, first, count, A);
+            else if (r->fused)
                 hipLaunchKernelGGL((k_level<true, true, true>), grid, block, 0, s, first, count, A);
             else
                 hipLaunchKernelGGL((k_level<false, true, true>), grid, block, 0, s, first, count, A);

@@ -235,6 +235,11 @@ struct lf_router {
     // the same plan with longer blocks for plain router calls (k_sweep_cones: no sub-step dimension to fill the machine
     // with, so fewer, longer launches pay): host tables + the cone starts on the device
     std::vector<int> rb_level, rb_row, rb_off;
+    // the static vectors of a cell as one record per section, for the wide levels of ordered beta = 3/5 calls (k_level<.., STATICS>):
+    // built on the first such call; statics_refused: the allocation failed once, the separate streams stay
+    lf_dbuf<double2> adx1, adx2;
+    lf_dbuf<lf_rec20> rec1, rec2;
+    bool statics_refused = false;
     lf_dbuf<int> rb_cone;
     int rb_lmax = 0, rb_cw = kBlock; // levels per block, cells per level of a cone (LF_ROUTE_CONE_WIDTH: 64 or 256)
     int64_t last_stats[4] = {0, 0, 0, 0};
@@ -317,7 +322,63 @@ sweep_args make_sweep_args(lf_router *r, double *q_dev, const double *lat_dev, i
     A.qord = ordered ? q_dev : r->qord.p;
     A.q_pix = ordered ? nullptr : q_dev;
     A.qold_src = nullptr;
+    A.adx = nullptr;
+    A.rec = nullptr;
+    A.rec24 = nullptr;
     return A;
+}
+
+// The static records of A's section for the wide levels of an ordered beta = 3/5 call -> 2 (A.rec set), 1 (A.adx set) or 0:
+// dx is a scalar (the sweep then has one static stream anyway), LF_LEVEL_STATICS=0 (A/B switch, read at every call; 1
+// forces the 16-byte form) or no memory for them.  20 bytes per cell and section (16 from 2^28 cells on).
+int level_statics(lf_router *r, sweep_args &A)
+{
+    if (!r->fused || !r->dx_per_pixel || r->statics_refused || r->N <= 0 || r->linked.p) return 0;
+    const char *e = std::getenv("LF_LEVEL_STATICS");
+    int want = (r->N < ((int64_t)1 << 28) && r->kmax <= 8) ? 2 : 1;
+    if (e && e[0] == '0') return 0;
+    if (e && e[0] == '1') want = 1;
+    const bool main_section = A.a == r->a1.p;
+    const unsigned blocks = (unsigned)((r->N + kLevelBlock - 1) / kLevelBlock);
+    if (want == 2) {
+        lf_dbuf<lf_rec20> &buf = main_section ? r->rec1 : r->rec2;
+        if (!buf.p) {
+            if (buf.alloc((size_t)r->N) != LF_OK) {
+                r->statics_refused = true;
+                (void)hipGetLastError();
+                return 0;
+            }
+            hipLaunchKernelGGL(k_static_records, dim3(blocks), dim3(kLevelBlock), 0, r->ctx->stream, (long long)r->N, A.a,
+                               (const double *)r->dx.p, (const int *)r->ups_ptr.p, (double2 *)nullptr, buf.p);
+        }
+        A.rec = buf.p;
+        return 2;
+    }
+    lf_dbuf<double2> &buf = main_section ? r->adx1 : r->adx2;
+    if (!buf.p) {
+        if (buf.alloc((size_t)r->N) != LF_OK) {
+            r->statics_refused = true;
+            (void)hipGetLastError();
+            return 0;
+        }
+        hipLaunchKernelGGL(k_static_records, dim3(blocks), dim3(kLevelBlock), 0, r->ctx->stream, (long long)r->N, A.a,
+                           (const double *)r->dx.p, (const int *)r->ups_ptr.p, buf.p, (lf_rec20 *)nullptr);
+    }
+    A.adx = buf.p;
+    return 1;
+}
+
+// one wide level of an ORDERED beta = 3/5 call
+void launch_level_ordered_fused(lf_router *r, hipStream_t s, int first, int cells, sweep_args A)
+{
+    const dim3 grid(level_blocks_for(cells)), block(kLevelBlock);
+    const int statics = level_statics(r, A);
+    if (statics == 2)
+        hipLaunchKernelGGL((k_level<true, true, false, 2>), grid, block, 0, s, first, cells, A);
+    else if (statics == 1)
+        hipLaunchKernelGGL((k_level<true, true, false, 1>), grid, block, 0, s, first, cells, A);
+    else
+        hipLaunchKernelGGL((k_level<true, true>), grid, block, 0, s, first, cells, A);
 }
 
 // A router call block by block (build_level_blocks): blocks of several levels cone by cone (k_sweep_cones), single wide
@@ -426,7 +487,7 @@ int enqueue_blocks(int count, lf_router **rs, const sweep_args_multi &M, bool or
             LF_TRY(r->prof_begin(1, cells));
             if (count == 1) {
                 if (r->fused && ordered)
-                    hipLaunchKernelGGL((k_level<true, true>), grid1, block1, 0, s, first, cells, M.r[0]);
+                    launch_level_ordered_fused(r, s, first, cells, M.r[0]);
                 else if (r->fused)
                     hipLaunchKernelGGL((k_level<true, false>), grid1, block1, 0, s, first, cells, M.r[0]);
                 else if (ordered)
@@ -545,7 +606,7 @@ int enqueue_route(lf_router *r, double *q_dev, const double *lat_dev, int sectio
             LF_TRY(r->prof_begin(1, count));
             const dim3 grid(level_blocks_for(count)), block(kLevelBlock);
             if (r->fused && ordered)
-                hipLaunchKernelGGL((k_level<true, true>), grid, block, 0, s, first, count, A);
+                launch_level_ordered_fused(r, s, first, count, A);
             else if (r->fused)
                 hipLaunchKernelGGL((k_level<true, false>), grid, block, 0, s, first, count, A);
             else if (ordered)

@@ -95,6 +95,24 @@ struct sweep_args {
     // null -- successive calls ping-pong between two state vectors so that a call may start before the one before it has
     // finished its later phases (lf_dist_router_route_many)
     const double *qold_src;
+    // STATICS kernels only (wide levels of an ordered beta = 3/5 call): what a cell reads of the router's static vectors as
+    // ONE record instead of three streams -- fewer streams open at a time serve this memory system better at the same
+    // bytes (198 -> 191 -> 189 us per 20 M-cell level).  STATICS = 1: (a, dx), 16 bytes, ups_ptr
+    // read as before; STATICS = 2: (a, dx, first upstream position | count << 28), 20 bytes, graphs below 2^28 cells.
+    const double2 *__restrict__ adx;
+    const struct lf_rec20 *__restrict__ rec;
+    // STATICS = 3 (INDEXED: the row-block partition's level kernel, which reads four static streams -- a, dx, ups_ptr,
+    // ups_base): (a, dx, first list entry | count << 28, ups_base), 24 bytes
+    const struct lf_rec24 *__restrict__ rec24;
+};
+struct lf_rec24 {
+    double a, dx;
+    unsigned int up; // first entry of the cell's upstream list (28 bits) | number of upstream cells << 28
+    int base;        // ups_base: first upstream position if they are consecutive, else -1
+};
+struct __attribute__((packed, aligned(4))) lf_rec20 {
+    double a, dx;
+    unsigned int up; // first upstream position (28 bits) | number of upstream cells << 28 (a D8 cell: at most 8)
 };
 
 // One cell of the implicit sweep.
@@ -107,14 +125,37 @@ struct sweep_args {
 //   INDEXED: upstream positions come from the index list ups_idx[ups_ptr[p] .. ups_ptr[p+1]) instead of being the
 //     contiguous positions themselves (row-block partitions: upstream cells may sit in other phases or in the
 //     ghost slots filled by the halo exchange).
-template <bool FUSED, bool ORDERED, bool INDEXED = false>
+template <bool FUSED, bool ORDERED, bool INDEXED = false, int STATICS = 0>
 __device__ __forceinline__ void sweep_cell_range(int p, int u0, int u1, const sweep_args &A)
 {
+    static_assert(STATICS == 0 || (FUSED && ORDERED && INDEXED == (STATICS == 3)), "the records are the ordered beta = 3/5 router's");
     const int pix = ORDERED ? p : A.perm[p];
-    const double ap = A.a[p];
+    double ap, dxp;
+    int rec_base = 0;
+    if (STATICS == 3) {
+        const lf_rec24 R = A.rec24[p];
+        ap = R.a;
+        dxp = R.dx;
+        u0 = (int)(R.up & 0x0fffffffu);
+        u1 = u0 + (int)(R.up >> 28);
+        rec_base = R.base;
+    } else if (STATICS == 2) {
+        const lf_rec20 R = A.rec[p];
+        ap = R.a;
+        dxp = R.dx;
+        u0 = (int)(R.up & 0x0fffffffu);
+        u1 = u0 + (int)(R.up >> 28);
+    } else if (STATICS == 1) {
+        const double2 sd = A.adx[p];
+        ap = sd.x;
+        dxp = sd.y;
+    } else {
+        ap = A.a[p];
+        dxp = (FUSED && A.dx) ? A.dx[p] : A.dx_scalar;
+    }
     double cst;
     if (FUSED) {
-        const double lateral = A.lat[pix] * (A.dx ? A.dx[p] : A.dx_scalar);
+        const double lateral = A.lat[pix] * dxp;
         const double qold = ORDERED ? ((INDEXED && A.qold_src) ? A.qold_src[p] : A.qord[p]) : A.q_pix[pix];
         cst = ap * lf_pow_3_5(qold) + lateral;
     } else {
@@ -124,7 +165,7 @@ __device__ __forceinline__ void sweep_cell_range(int p, int u0, int u1, const sw
     // at most 8 upstream neighbours: all candidate loads are issued at once (predicated) instead of a
     // dependent load per loop trip; missing ones contribute +0.0, which leaves the sum bit-identical.
     double v[8];
-    const int base = INDEXED ? A.ups_base[p] : u0;
+    const int base = INDEXED ? (STATICS == 3 ? rec_base : A.ups_base[p]) : u0;
     if (!INDEXED || base >= 0) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = (k < A.kmax && u0 + k < u1) ? A.qord[base + k] : 0.0;
@@ -145,10 +186,13 @@ __device__ __forceinline__ void sweep_cell_range(int p, int u0, int u1, const sw
     A.qord[p] = q;
     if (!ORDERED) A.q_pix[pix] = q;
 }
-template <bool FUSED, bool ORDERED, bool INDEXED = false>
+template <bool FUSED, bool ORDERED, bool INDEXED = false, int STATICS = 0>
 __device__ __forceinline__ void sweep_cell(int p, const sweep_args &A)
 {
-    sweep_cell_range<FUSED, ORDERED, INDEXED>(p, A.ups_ptr[p], A.ups_ptr[p + 1], A);
+    if (STATICS >= 2)
+        sweep_cell_range<FUSED, ORDERED, INDEXED, STATICS>(p, 0, 0, A); // (the upstream range comes with the record)
+    else
+        sweep_cell_range<FUSED, ORDERED, INDEXED, STATICS>(p, A.ups_ptr[p], A.ups_ptr[p + 1], A);
 }
 
 // Read of a table that no kernel of this library ever writes (the cone plans of the level blocks) through the
@@ -174,12 +218,44 @@ inline int level_blocks_for(int64_t n) { return (int)((n + kLevelBlock - 1) / kL
 #else
 #define LF_LEVEL_ATTR
 #endif
-template <bool FUSED, bool ORDERED, bool INDEXED = false>
+template <bool FUSED, bool ORDERED, bool INDEXED = false, int STATICS = 0>
 __global__ void __launch_bounds__(kLevelBlock) LF_LEVEL_ATTR k_level(int first, int count, sweep_args A)
 {
     const int i = blockIdx.x * kLevelBlock + threadIdx.x;
     if (i >= count) return;
-    sweep_cell<FUSED, ORDERED, INDEXED>(first + i, A);
+    sweep_cell<FUSED, ORDERED, INDEXED, STATICS>(first + i, A);
+}
+
+__global__ void __launch_bounds__(kLevelBlock) k_static_records_indexed(long long n, const double *__restrict__ a,
+                                                                        const double *__restrict__ dx, const int *__restrict__ ups_ptr,
+                                                                        const int *__restrict__ ups_base, lf_rec24 *__restrict__ rec)
+{
+    const long long i = (long long)blockIdx.x * kLevelBlock + threadIdx.x;
+    if (i >= n) return;
+    lf_rec24 r;
+    r.a = a[i];
+    r.dx = dx[i];
+    r.up = (unsigned)ups_ptr[i] | ((unsigned)(ups_ptr[i + 1] - ups_ptr[i]) << 28);
+    r.base = ups_base[i];
+    rec[i] = r;
+}
+
+// the records of k_level<.., STATICS> from the router's static vectors (once per router and section)
+__global__ void __launch_bounds__(kLevelBlock) k_static_records(long long n, const double *__restrict__ a, const double *__restrict__ dx,
+                                                                const int *__restrict__ ups_ptr, double2 *__restrict__ adx,
+                                                                lf_rec20 *__restrict__ rec)
+{
+    const long long i = (long long)blockIdx.x * kLevelBlock + threadIdx.x;
+    if (i >= n) return;
+    if (rec) {
+        lf_rec20 r;
+        r.a = a[i];
+        r.dx = dx[i];
+        r.up = (unsigned)ups_ptr[i] | ((unsigned)(ups_ptr[i + 1] - ups_ptr[i]) << 28);
+        rec[i] = r;
+    } else {
+        adx[i] = make_double2(a[i], dx[i]);
+    }
 }
 
 // Several routers on ONE graph (surface_routing.py:151-153: the direct / other / forest overland routers differ only in

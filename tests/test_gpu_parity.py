@@ -1057,6 +1057,60 @@ def test_hot_path_in_surface_order_equals_pixel_order(amd):
     a.free(); b.free(); c.free()
 
 
+@pytest.mark.parametrize("family,env", [("shallow", {"LF_FUSED_WIDE": "2000"}), ("river", {"LF_ROUTE_CONES": "0"})])
+def test_static_records_of_the_wide_levels_leave_the_bits_alone(amd, oracle, monkeypatch, family, env):
+    """The wide levels of an ordered beta = 3/5 call read a cell's static values as one record -- (a, dx, upstream range),
+    20 bytes, or (a, dx), 16 bytes -- instead of three streams (k_level<.., STATICS>, csrc/lf_sweep.h): a layout of the
+    router's own copies, not arithmetic.  Both sections of a router with floodplains, per-pixel channel lengths, four calls:
+    the three forms (LF_LEVEL_STATICS=2 / 1 / 0) bit for bit, and the oracle."""
+    from lisflood_amd import _lib
+    from lisflood_amd import synthetic as syn
+    from lisflood_amd.kinematic_wave_parallel import Graph, kinematicWave
+    H, W = 420, 380
+    N = H * W
+    codes = syn.make_ldd(family, H, W, 5)
+    p = syn.router_params(N, seed=8)
+    rng = np.random.default_rng(3)
+    alpha2 = p["alpha"] * rng.uniform(1.2, 2.0, N)
+    lat = [syn.lateral_inflow(N, i) for i in range(4)]
+    for k, v in env.items():     # what makes levels of this small raster wide levels (k_level): above 2000 cells among the
+        monkeypatch.setenv(k, v)  # level blocks, or above 1024 with one launch per level
+
+    def run(statics):
+        monkeypatch.setenv("LF_LEVEL_STATICS", statics)
+        g = Graph(ldd_raster=codes)
+        kw = kinematicWave(None, None, p["alpha"], p["beta"], p["dx"], p["dt"], alpha_floodplains=alpha2, graph=g)
+        tmp = _lib.DeviceArray(N)
+        out, wide = [], 0
+        for section in ("main_channel", "floodplains"):
+            Q = _lib.DeviceArray.from_host(p["Q0"])
+            kw.to_engine_order(Q, tmp); Q.copy_from(tmp)
+            for i in range(4):
+                q = _lib.DeviceArray.from_host(lat[i])
+                kw.to_engine_order(q, tmp); q.copy_from(tmp)
+                kw.route_ordered(Q, q, section)
+                q.free()
+            wide = kw.last_launches()["wide"]
+            kw.from_engine_order(Q, tmp)
+            out.append(tmp.download().copy())
+            Q.free()
+        tmp.free(); kw.close()
+        return out, wide
+    (m2, f2), wide = run("2")
+    assert wide >= 1, wide                                # the case is about the wide levels
+    (m1, f1), _ = run("1")
+    (m0, f0), _ = run("0")
+    assert np.array_equal(m2, m0) and np.array_equal(m1, m0) and np.array_equal(f2, f0) and np.array_equal(f1, f0)
+    mask = np.ones((H, W), bool)
+    cpu = oracle.kinematicWave(codes.reshape(-1).astype(np.float64), mask, p["alpha"], p["beta"], p["dx"], p["dt"],
+                               alpha_floodplains=alpha2)
+    for got, section in ((m0, "main_channel"), (f0, "floodplains")):
+        Q = p["Q0"].copy()
+        for i in range(4):
+            cpu.kinematicWaveRouting(Q, lat[i], section)
+        close(got, Q, (family, section))
+
+
 def test_block_length_chosen_per_graph_leaves_the_bits_alone(amd, monkeypatch):
     """lf_router_create times shorter level blocks for a graph whose default cone plan (blocks of 256 levels) fills less than
     40 % of its lanes -- the overland graph of a domain with few channel pixels: many short trees -- and keeps the fastest
