@@ -891,7 +891,6 @@ int dist_compute_phase(lf_dist_router *r, double *q, const double *lat, int sect
     A.qord = q;
     A.q_pix = nullptr;
     A.adx = nullptr;
-    A.rec = nullptr;
     A.rec24 = dist_level_statics(r, A);
     A.qold_src = q_in; // pipelined calls: old discharge from the other state vector (beta = 3/5 path only)
     if (q_in && !r->fused) return lf_set_error(LF_E_INVALID, "separate input discharge needs the beta = 3/5 path");

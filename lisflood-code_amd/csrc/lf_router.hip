@@ -238,7 +238,6 @@ struct lf_router {
     // the static vectors of a cell as one record per section, for the wide levels of ordered beta = 3/5 calls (k_level<.., STATICS>):
     // built on the first such call; statics_refused: the allocation failed once, the separate streams stay
     lf_dbuf<double2> adx1, adx2;
-    lf_dbuf<lf_rec20> rec1, rec2;
     bool statics_refused = false;
     lf_dbuf<int> rb_cone;
     int rb_lmax = 0, rb_cw = kBlock; // levels per block, cells per level of a cone (LF_ROUTE_CONE_WIDTH: 64 or 256)
@@ -323,59 +322,37 @@ sweep_args make_sweep_args(lf_router *r, double *q_dev, const double *lat_dev, i
     A.q_pix = ordered ? nullptr : q_dev;
     A.qold_src = nullptr;
     A.adx = nullptr;
-    A.rec = nullptr;
     A.rec24 = nullptr;
     return A;
 }
 
-// The static records of A's section for the wide levels of an ordered beta = 3/5 call -> 2 (A.rec set), 1 (A.adx set) or 0:
-// dx is a scalar (the sweep then has one static stream anyway), LF_LEVEL_STATICS=0 (A/B switch, read at every call; 1
-// forces the 16-byte form) or no memory for them.  20 bytes per cell and section (16 from 2^28 cells on).
-int level_statics(lf_router *r, sweep_args &A)
+// The (a, dx) records of A's section for the wide levels of an ordered beta = 3/5 call, or nullptr: dx is a scalar (the
+// sweep then has one static load anyway), LF_LEVEL_STATICS=0 (A/B switch, read at every call) or no memory for them
+// (16 bytes per cell and section).
+const double2 *level_statics(lf_router *r, const sweep_args &A)
 {
-    if (!r->fused || !r->dx_per_pixel || r->statics_refused || r->N <= 0 || r->linked.p) return 0;
+    if (!r->fused || !r->dx_per_pixel || r->statics_refused || r->N <= 0) return nullptr;
     const char *e = std::getenv("LF_LEVEL_STATICS");
-    int want = (r->N < ((int64_t)1 << 28) && r->kmax <= 8) ? 2 : 1;
-    if (e && e[0] == '0') return 0;
-    if (e && e[0] == '1') want = 1;
-    const bool main_section = A.a == r->a1.p;
-    const unsigned blocks = (unsigned)((r->N + kLevelBlock - 1) / kLevelBlock);
-    if (want == 2) {
-        lf_dbuf<lf_rec20> &buf = main_section ? r->rec1 : r->rec2;
-        if (!buf.p) {
-            if (buf.alloc((size_t)r->N) != LF_OK) {
-                r->statics_refused = true;
-                (void)hipGetLastError();
-                return 0;
-            }
-            hipLaunchKernelGGL(k_static_records, dim3(blocks), dim3(kLevelBlock), 0, r->ctx->stream, (long long)r->N, A.a,
-                               (const double *)r->dx.p, (const int *)r->ups_ptr.p, (double2 *)nullptr, buf.p);
-        }
-        A.rec = buf.p;
-        return 2;
-    }
-    lf_dbuf<double2> &buf = main_section ? r->adx1 : r->adx2;
+    if (e && e[0] == '0') return nullptr;
+    lf_dbuf<double2> &buf = (A.a == r->a1.p) ? r->adx1 : r->adx2;
     if (!buf.p) {
         if (buf.alloc((size_t)r->N) != LF_OK) {
             r->statics_refused = true;
             (void)hipGetLastError();
-            return 0;
+            return nullptr;
         }
-        hipLaunchKernelGGL(k_static_records, dim3(blocks), dim3(kLevelBlock), 0, r->ctx->stream, (long long)r->N, A.a,
-                           (const double *)r->dx.p, (const int *)r->ups_ptr.p, buf.p, (lf_rec20 *)nullptr);
+        hipLaunchKernelGGL(k_static_records, dim3((unsigned)((r->N + kLevelBlock - 1) / kLevelBlock)), dim3(kLevelBlock), 0, r->ctx->stream,
+                           (long long)r->N, A.a, (const double *)r->dx.p, buf.p);
     }
-    A.adx = buf.p;
-    return 1;
+    return buf.p;
 }
 
 // one wide level of an ORDERED beta = 3/5 call
 void launch_level_ordered_fused(lf_router *r, hipStream_t s, int first, int cells, sweep_args A)
 {
     const dim3 grid(level_blocks_for(cells)), block(kLevelBlock);
-    const int statics = level_statics(r, A);
-    if (statics == 2)
-        hipLaunchKernelGGL((k_level<true, true, false, 2>), grid, block, 0, s, first, cells, A);
-    else if (statics == 1)
+    A.adx = level_statics(r, A);
+    if (A.adx)
         hipLaunchKernelGGL((k_level<true, true, false, 1>), grid, block, 0, s, first, cells, A);
     else
         hipLaunchKernelGGL((k_level<true, true>), grid, block, 0, s, first, cells, A);

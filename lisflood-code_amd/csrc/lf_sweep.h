@@ -96,11 +96,9 @@ struct sweep_args {
     // finished its later phases (lf_dist_router_route_many)
     const double *qold_src;
     // STATICS kernels only (wide levels of an ordered beta = 3/5 call): what a cell reads of the router's static vectors as
-    // ONE record instead of three streams -- fewer streams open at a time serve this memory system better at the same
-    // bytes (198 -> 191 -> 189 us per 20 M-cell level).  STATICS = 1: (a, dx), 16 bytes, ups_ptr
-    // read as before; STATICS = 2: (a, dx, first upstream position | count << 28), 20 bytes, graphs below 2^28 cells.
+    // ONE record instead of separate loads -- the level sweep is sensitive to the number of its memory instructions at the
+    // same bytes.  STATICS = 1: (a, dx), 16 bytes, ups_ptr read as before.
     const double2 *__restrict__ adx;
-    const struct lf_rec20 *__restrict__ rec;
     // STATICS = 3 (INDEXED: the row-block partition's level kernel, which reads four static streams -- a, dx, ups_ptr,
     // ups_base): (a, dx, first list entry | count << 28, ups_base), 24 bytes
     const struct lf_rec24 *__restrict__ rec24;
@@ -109,10 +107,6 @@ struct lf_rec24 {
     double a, dx;
     unsigned int up; // first entry of the cell's upstream list (28 bits) | number of upstream cells << 28
     int base;        // ups_base: first upstream position if they are consecutive, else -1
-};
-struct __attribute__((packed, aligned(4))) lf_rec20 {
-    double a, dx;
-    unsigned int up; // first upstream position (28 bits) | number of upstream cells << 28 (a D8 cell: at most 8)
 };
 
 // One cell of the implicit sweep.
@@ -139,12 +133,6 @@ __device__ __forceinline__ void sweep_cell_range(int p, int u0, int u1, const sw
         u0 = (int)(R.up & 0x0fffffffu);
         u1 = u0 + (int)(R.up >> 28);
         rec_base = R.base;
-    } else if (STATICS == 2) {
-        const lf_rec20 R = A.rec[p];
-        ap = R.a;
-        dxp = R.dx;
-        u0 = (int)(R.up & 0x0fffffffu);
-        u1 = u0 + (int)(R.up >> 28);
     } else if (STATICS == 1) {
         const double2 sd = A.adx[p];
         ap = sd.x;
@@ -166,7 +154,19 @@ __device__ __forceinline__ void sweep_cell_range(int p, int u0, int u1, const sw
     // dependent load per loop trip; missing ones contribute +0.0, which leaves the sum bit-identical.
     double v[8];
     const int base = INDEXED ? (STATICS == 3 ? rec_base : A.ups_base[p]) : u0;
-    if (!INDEXED || base >= 0) {
+    if (!INDEXED) {
+        // the contiguous upstream run two values per load: four 16-byte loads instead of eight 8-byte ones (189.8 -> 186.5 us
+        // per 20 M-cell level; the sweep is sensitive to the number of its memory instructions).  The second value of a pair
+        // may lie one position behind the run -- still inside the vector (a cell's upstream positions all precede its own) --
+        // and is then discarded.
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double2 t = make_double2(0.0, 0.0);
+            if (2 * j < A.kmax && u0 + 2 * j < u1) t = *(const double2 *)(A.qord + u0 + 2 * j); // (8-byte aligned)
+            v[2 * j] = t.x;
+            v[2 * j + 1] = (u0 + 2 * j + 1 < u1) ? t.y : 0.0;
+        }
+    } else if (base >= 0) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = (k < A.kmax && u0 + k < u1) ? A.qord[base + k] : 0.0;
     } else { // ghost or cross-phase inflow: positions from the list (a second, dependent load)
@@ -189,7 +189,7 @@ __device__ __forceinline__ void sweep_cell_range(int p, int u0, int u1, const sw
 template <bool FUSED, bool ORDERED, bool INDEXED = false, int STATICS = 0>
 __device__ __forceinline__ void sweep_cell(int p, const sweep_args &A)
 {
-    if (STATICS >= 2)
+    if (STATICS == 3)
         sweep_cell_range<FUSED, ORDERED, INDEXED, STATICS>(p, 0, 0, A); // (the upstream range comes with the record)
     else
         sweep_cell_range<FUSED, ORDERED, INDEXED, STATICS>(p, A.ups_ptr[p], A.ups_ptr[p + 1], A);
@@ -226,6 +226,7 @@ __global__ void __launch_bounds__(kLevelBlock) LF_LEVEL_ATTR k_level(int first, 
     sweep_cell<FUSED, ORDERED, INDEXED, STATICS>(first + i, A);
 }
 
+// the 24-byte records of k_level<.., INDEXED, STATICS = 3> (row-block partition; once per router and section)
 __global__ void __launch_bounds__(kLevelBlock) k_static_records_indexed(long long n, const double *__restrict__ a,
                                                                         const double *__restrict__ dx, const int *__restrict__ ups_ptr,
                                                                         const int *__restrict__ ups_base, lf_rec24 *__restrict__ rec)
@@ -240,22 +241,12 @@ __global__ void __launch_bounds__(kLevelBlock) k_static_records_indexed(long lon
     rec[i] = r;
 }
 
-// the records of k_level<.., STATICS> from the router's static vectors (once per router and section)
+// the (a, dx) records of k_level<.., STATICS = 1> from the router's static vectors (once per router and section)
 __global__ void __launch_bounds__(kLevelBlock) k_static_records(long long n, const double *__restrict__ a, const double *__restrict__ dx,
-                                                                const int *__restrict__ ups_ptr, double2 *__restrict__ adx,
-                                                                lf_rec20 *__restrict__ rec)
+                                                                double2 *__restrict__ adx)
 {
     const long long i = (long long)blockIdx.x * kLevelBlock + threadIdx.x;
-    if (i >= n) return;
-    if (rec) {
-        lf_rec20 r;
-        r.a = a[i];
-        r.dx = dx[i];
-        r.up = (unsigned)ups_ptr[i] | ((unsigned)(ups_ptr[i + 1] - ups_ptr[i]) << 28);
-        rec[i] = r;
-    } else {
-        adx[i] = make_double2(a[i], dx[i]);
-    }
+    if (i < n) adx[i] = make_double2(a[i], dx[i]);
 }
 
 // Several routers on ONE graph (surface_routing.py:151-153: the direct / other / forest overland routers differ only in

@@ -1,5 +1,5 @@
 """Same-process A/B of the wide-level kernel's static streams: python tools/level_adx_ab.py [size] [steps] [family]
-LF_LEVEL_STATICS=0: ups_ptr, a and dx as three streams (rounds 1-5); 1: (a, dx) records; 2 / unset: (a, dx, upstream range) records"""
+LF_LEVEL_STATICS=0: a and dx as two loads (rounds 1-5); 1 / unset: one (a, dx) record"""
 import os
 import sys
 
@@ -12,7 +12,7 @@ size = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 family = sys.argv[3] if len(sys.argv) > 3 else "shallow"
 kw, p, g = bench.build_case(family, size, size)
-for x in ("0", "1", "2", "0", "1", "2"):
+for x in (sys.argv[4].split(",") if len(sys.argv) > 4 else ("0", "1", "0", "1", "0", "1")):
     os.environ["LF_LEVEL_STATICS"] = x
     out = []
     for rep in range(2):
