@@ -151,6 +151,34 @@ __device__ __forceinline__ double solve_any(double c, double ap, bool b35, const
     return lf_solve_cell(c, ap, F.beta * ap, F.beta, F.inv_beta, F.b_minus_1);
 }
 
+#ifndef LF_FUSED_PAIRS
+#define LF_FUSED_PAIRS 1 /* 0: the contiguous upstream run one value per load everywhere (A/B builds) */
+#endif
+// The same sum with the run read two values per load (four 16-byte loads instead of eight 8-byte ones, as the level
+// sweep of lf_sweep.h does): for runs inside a vector whose positions all precede their reader -- the second value of the
+// last pair may lie one position behind the run and is discarded.  NOT for the row-block partition's ghost runs, which may
+// end where their buffer ends.
+__device__ __forceinline__ double upstream_sum8_pairs(const double *q, int u0, int u1, int kmax)
+{
+    double v[8];
+#if LF_FUSED_PAIRS
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        double2 t = make_double2(0.0, 0.0);
+        if (2 * j < kmax && u0 + 2 * j < u1) t = *(const double2 *)(q + u0 + 2 * j); // (8-byte aligned)
+        v[2 * j] = t.x;
+        v[2 * j + 1] = (u0 + 2 * j + 1 < u1) ? t.y : 0.0;
+    }
+#else
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = (k < kmax && u0 + k < u1) ? q[u0 + k] : 0.0;
+#endif
+    double ups = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ups += v[k];
+    return ups;
+}
+
 __device__ __forceinline__ double upstream_sum8(const double *q, int u0, int u1, int kmax)
 {
     double v[8];
@@ -339,7 +367,7 @@ __global__ void __launch_bounds__(kBlock) k_fused_substeps(fused_args F)
     const long long p = first + i;
     const int u0 = F.ups_ptr[p], u1 = F.ups_ptr[p + 1];
     const int kmax = F.kmax;
-    fused_cell<SPLIT, STRUCT>(F, p, s, [u0, u1, kmax](const double *q, int) { return upstream_sum8(q, u0, u1, kmax); });
+    fused_cell<SPLIT, STRUCT>(F, p, s, [u0, u1, kmax](const double *q, int) { return upstream_sum8_pairs(q, u0, u1, kmax); });
 }
 
 // ---- several levels per launch: the wavefront over LEVEL BLOCKS, one workgroup per upstream cone --------------------
@@ -800,7 +828,7 @@ __global__ void __launch_bounds__(kBlock) LF_TM_ATTR k_fused_level_steps(fused_a
         slot = F.d_out_slot[p];
     }
     auto ups_of = [&](const double *hist, const double *slab, int s) {
-        if (!DIST) return upstream_sum8(hist + (long long)s * n, u0, u1, kmax);
+        if (!DIST) return upstream_sum8_pairs(hist + (long long)s * n, u0, u1, kmax);
         if (base >= 0) return upstream_sum8(hist + (long long)s * n, base, base + (u1 - u0), kmax);
         double v[8];
 #pragma unroll
@@ -1130,8 +1158,8 @@ __global__ void __launch_bounds__(CW) __attribute__((amdgpu_waves_per_eu(LF_CONE
                     for (int k = 0; k < 8; ++k) ups2 += v2[k];
                 }
             } else if (j == 0) { // from the block before (previous launch) through the parity buffers
-                ups1 = upstream_sum8(F.qr1 + par, cu0, cu1, kmax);
-                if (SPLIT) ups2 = upstream_sum8(F.qr2 + par, cu0, cu1, kmax);
+                ups1 = DIST ? upstream_sum8(F.qr1 + par, cu0, cu1, kmax) : upstream_sum8_pairs(F.qr1 + par, cu0, cu1, kmax);
+                if (SPLIT) ups2 = DIST ? upstream_sum8(F.qr2 + par, cu0, cu1, kmax) : upstream_sum8_pairs(F.qr2 + par, cu0, cu1, kmax);
             } else { // from LDS, branch-free: absent neighbours read the slot that holds 0.0 (the sum as upstream_sum8)
                 const double *y1 = &x1[(j - 1) & 1][0], *y2 = &x2[SPLIT ? (j - 1) & 1 : 0][0];
                 const int base = cu0 - first_up;
