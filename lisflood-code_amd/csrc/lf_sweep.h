@@ -141,30 +141,35 @@ __device__ __forceinline__ void sweep_cell_range(int p, int u0, int u1, const sw
         ap = A.a[p];
         dxp = (FUSED && A.dx) ? A.dx[p] : A.dx_scalar;
     }
-    double cst;
+    // the cell's own two values first: requested with the statics above, before anything waits for the upstream range
+    double lat_q = 0.0, qold = 0.0;
     if (FUSED) {
-        const double lateral = A.lat[pix] * dxp;
-        const double qold = ORDERED ? ((INDEXED && A.qold_src) ? A.qold_src[p] : A.qord[p]) : A.q_pix[pix];
-        cst = ap * lf_pow_3_5(qold) + lateral;
-    } else {
-        cst = A.constant[p];
+        lat_q = A.lat[pix];
+        qold = ORDERED ? ((INDEXED && A.qold_src) ? A.qold_src[p] : A.qord[p]) : A.q_pix[pix];
     }
     // Upstream inflow, summed in ascending pixel id (kinematic_wave_parallel_tools.py:57-58).  A D8 cell has
     // at most 8 upstream neighbours: all candidate loads are issued at once (predicated) instead of a
     // dependent load per loop trip; missing ones contribute +0.0, which leaves the sum bit-identical.
+    // The requests go out as soon as the upstream range is known, BEFORE the old-discharge term is worked out (its power
+    // runs while they travel), and nothing may use a value before all of them are out: the empty asm behind the power is
+    // where they are first needed (without it the compiler sinks `0.0 + v[0]` into the first load's branch and waits for
+    // that load before it requests the others).
     double v[8];
     const int base = INDEXED ? (STATICS == 3 ? rec_base : A.ups_base[p]) : u0;
+    // (the upstream loads sit behind branches -- a wavefront none of whose lanes has a fourth pair skips that request -- so
+    // the compiler cannot count them and waits for ALL loads wherever it needs one: the cell's own values are therefore
+    // taken in here, before the upstream requests go out, and the power below then runs with only those in flight)
+    if (FUSED) asm volatile("" : "+v"(qold), "+v"(lat_q));
     if (!INDEXED) {
-        // the contiguous upstream run two values per load: four 16-byte loads instead of eight 8-byte ones (189.8 -> 186.5 us
-        // per 20 M-cell level; the sweep is sensitive to the number of its memory instructions).  The second value of a pair
-        // may lie one position behind the run -- still inside the vector (a cell's upstream positions all precede its own) --
-        // and is then discarded.
+        // the contiguous upstream run two values per load: four 16-byte loads instead of eight 8-byte ones (the sweep is
+        // sensitive to the number of its memory instructions).  The second value of a pair may lie one position behind the
+        // run -- still inside the vector (a cell's upstream positions all precede its own) -- and is then discarded.
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             double2 t = make_double2(0.0, 0.0);
             if (2 * j < A.kmax && u0 + 2 * j < u1) t = *(const double2 *)(A.qord + u0 + 2 * j); // (8-byte aligned)
             v[2 * j] = t.x;
-            v[2 * j + 1] = (u0 + 2 * j + 1 < u1) ? t.y : 0.0;
+            v[2 * j + 1] = t.y;
         }
     } else if (base >= 0) {
 #pragma unroll
@@ -172,6 +177,19 @@ __device__ __forceinline__ void sweep_cell_range(int p, int u0, int u1, const sw
     } else { // ghost or cross-phase inflow: positions from the list (a second, dependent load)
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = (k < A.kmax && u0 + k < u1) ? A.qord[A.ups_idx[u0 + k]] : 0.0;
+    }
+    double cst;
+    if (FUSED) {
+        const double lateral = lat_q * dxp;
+        cst = ap * lf_pow_3_5(qold) + lateral;
+    } else {
+        cst = A.constant[p];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(v[k]));
+    if (!INDEXED) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[2 * j + 1] = (u0 + 2 * j + 1 < u1) ? v[2 * j + 1] : 0.0;
     }
     double ups = 0.0;
 #pragma unroll
