@@ -4,6 +4,7 @@
 //   surface_routing.dynamic  (surface_routing.py:115-212) -> k_surface_pre / k_surface_post + 3 router calls
 // The reference spends ~40 numpy passes per vegetation fraction here; each method is one pass on the GPU.
 #include <cmath>
+#include <cstdlib>
 
 #include "lf_common.h"
 #include "lf_canopy.h"
@@ -100,6 +101,13 @@ __global__ void __launch_bounds__(kBlock) k_surface_post(lf_surface_args A)
 // Every diagnostic output is optional: a NULL pointer means the map is not reported, it is then not computed and the
 // [3,N] vectors only it needs are not read (uniform branches on kernel arguments).  What the rest of the model step needs
 // -- DirectRunoff, UZOutflowPixel, LZOutflowToChannelPixel, the states CumInterSealed and LZ -- is always computed.
+// ALL: every optional map is reported (what HotPathDevice does by default, as the reference computes them every step).
+// The kernel is then straight code and -- the point -- requests EVERY input of the pixel before any arithmetic: written
+// block by block (inputs of a map, its arithmetic, its store, the next map) each wavefront walks ~20 dependent round
+// trips, because the struct's pointers may alias and no load may pass the store before it; 8 wavefronts x 3 loads in
+// flight per SIMD.  With ~70 loads in flight per lane (3 wavefronts per SIMD) the same bytes move at the rate of
+// independent streams (tools/micro/stream_count.hip).  Same operations per map, same bits.
+template <bool ALL>
 __global__ void __launch_bounds__(kBlock) k_pixel_aggregates(lf_pixel_args A)
 {
     const long long p = (long long)blockIdx.x * kBlock + threadIdx.x;
@@ -107,15 +115,33 @@ __global__ void __launch_bounds__(kBlock) k_pixel_aggregates(lf_pixel_args A)
     if (p >= N) return;
 #define LF_ST(X, v)                                                                                                      \
     do {                                                                                                                 \
-        if (A.X) A.X[p] = (v);                                                                                           \
+        if (ALL || A.X) A.X[p] = (v);                                                                                    \
     } while (0)
+    struct tri {
+        double a, b, c;
+    };
+    auto ld3 = [&](const double *X) { return tri{X[p], X[N + p], X[2 * N + p]}; };
+    tri t_taint = {}, t_ta = {}, t_es = {}, t_pref = {}, t_inf = {}, t_w1a = {}, t_w1b = {}, t_w2 = {}, t_sdt = {}, t_sa = {},
+        t_sb = {}, t_sg = {}, t_th1a = {}, t_th1b = {}, t_th2 = {}, t_uzo = {}, t_gwp = {};
+    double c_taint = 0, c_ta = 0, c_es = 0, c_lzin = 0, c_gwloss = 0;
+    if (ALL) {
+        t_taint = ld3(A.TaInterception); t_ta = ld3(A.Ta); t_es = ld3(A.ESAct); t_pref = ld3(A.PrefFlow);
+        t_inf = ld3(A.Infiltration); t_w1a = ld3(A.W1a); t_w1b = ld3(A.W1b); t_w2 = ld3(A.W2); t_sdt = ld3(A.SoilDepthTotal);
+        t_sa = ld3(A.SeepTopToSubA); t_sb = ld3(A.SeepTopToSubB); t_sg = ld3(A.SeepSubToGW); t_th1a = ld3(A.Theta1a);
+        t_th1b = ld3(A.Theta1b); t_th2 = ld3(A.Theta2); t_uzo = ld3(A.UZOutflow); t_gwp = ld3(A.GwPercUZLZ);
+        c_taint = A.TaInterceptionCUM[p]; c_ta = A.TaCUM[p]; c_es = A.ESActCUM[p]; c_lzin = A.LZInflowCUM[p];
+        c_gwloss = A.GwLossCUM[p];
+    }
     // ---- opensealed.py:45-70 ----
     const double ewref = A.EWRef[p], drf = A.DirectRunoffFraction[p], wf = A.WaterFraction[p];
-    const double rsm = npmax(A.Rain[p] + A.SnowMelt[p], 0.0);
+    const double in_rain = A.Rain[p], in_snow = A.SnowMelt[p], in_cis = A.CumInterSealed[p], in_smax = A.SMaxSealed[p];
+    const double f0 = A.SoilFraction[p], f1 = A.SoilFraction[N + p], f2 = A.SoilFraction[2 * N + p];
+    const double in_lz = A.LZ[p], in_lzk = A.LowerZoneK[p], in_lzthr = A.LZThreshold[p], in_gwloss = A.GwLossStep[p];
+    const double rsm = npmax(in_rain + in_snow, 0.0);
     double ewact = npmin(ewref, rsm);
     ewact = npmax(ewact * 1.0, 0.0);
-    double cis = A.CumInterSealed[p];
-    double inter = npmax(A.SMaxSealed[p] - cis, 0.0);
+    double cis = in_cis;
+    double inter = npmax(in_smax - cis, 0.0);
     inter = npmin(inter, rsm);
     cis += inter;
     const double tas = npmax(npmin(cis, ewref), 0.0);
@@ -127,64 +153,70 @@ __global__ void __launch_bounds__(kBlock) k_pixel_aggregates(lf_pixel_args A)
     A.CumInterSealed[p] = cis;
     A.DirectRunoff[p] = drf * (rsm - inter) + wf * (rsm - ewact);
     // ---- soil.py:475-513 : deffraction(X) = (SoilFraction * X).sum(vegetation) = ((f0 x0 + f1 x1) + f2 x2) ----
-    const double f0 = A.SoilFraction[p], f1 = A.SoilFraction[N + p], f2 = A.SoilFraction[2 * N + p];
-#define LF_DEF(X) ((f0 * A.X[p] + f1 * A.X[N + p]) + f2 * A.X[2 * N + p])
-    if (A.TaInterceptionAll || A.TaInterceptionCUM) {
-        const double ta_int_all = LF_DEF(TaInterception) + drf * tas;
+#define LF_DEF(X, T) (ALL ? ((f0 * T.a + f1 * T.b) + f2 * T.c) : ((f0 * A.X[p] + f1 * A.X[N + p]) + f2 * A.X[2 * N + p]))
+    if (ALL || A.TaInterceptionAll || A.TaInterceptionCUM) {
+        const double ta_int_all = LF_DEF(TaInterception, t_taint) + drf * tas;
         LF_ST(TaInterceptionAll, ta_int_all);
-        if (A.TaInterceptionCUM) A.TaInterceptionCUM[p] += ta_int_all;
+        if (ALL) A.TaInterceptionCUM[p] = c_taint + ta_int_all;
+        else if (A.TaInterceptionCUM) A.TaInterceptionCUM[p] += ta_int_all;
     }
-    if (A.TaPixel || A.TaCUM) {
-        const double ta_pix = LF_DEF(Ta);
+    if (ALL || A.TaPixel || A.TaCUM) {
+        const double ta_pix = LF_DEF(Ta, t_ta);
         LF_ST(TaPixel, ta_pix);
-        if (A.TaCUM) A.TaCUM[p] += ta_pix;
+        if (ALL) A.TaCUM[p] = c_ta + ta_pix;
+        else if (A.TaCUM) A.TaCUM[p] += ta_pix;
     }
-    if (A.ESActPixel || A.ESActCUM) {
-        const double es_pix = LF_DEF(ESAct) + wf * ewact;
+    if (ALL || A.ESActPixel || A.ESActCUM) {
+        const double es_pix = LF_DEF(ESAct, t_es) + wf * ewact;
         LF_ST(ESActPixel, es_pix);
-        if (A.ESActCUM) A.ESActCUM[p] += es_pix;
+        if (ALL) A.ESActCUM[p] = c_es + es_pix;
+        else if (A.ESActCUM) A.ESActCUM[p] += es_pix;
     }
-    if (A.PrefFlowPixel) A.PrefFlowPixel[p] = LF_DEF(PrefFlow);
-    if (A.InfiltrationPixel) A.InfiltrationPixel[p] = LF_DEF(Infiltration);
-    if (A.Theta || A.ThetaAll) {
+    if (ALL || A.PrefFlowPixel) A.PrefFlowPixel[p] = LF_DEF(PrefFlow, t_pref);
+    if (ALL || A.InfiltrationPixel) A.InfiltrationPixel[p] = LF_DEF(Infiltration, t_inf);
+    if (ALL || A.Theta || A.ThetaAll) {
         double th[3];
+        const double fv[3] = {f0, f1, f2};
+        const double w1a[3] = {t_w1a.a, t_w1a.b, t_w1a.c}, w1b[3] = {t_w1b.a, t_w1b.b, t_w1b.c}, w2[3] = {t_w2.a, t_w2.b, t_w2.c},
+                     sdt[3] = {t_sdt.a, t_sdt.b, t_sdt.c};
 #pragma unroll
         for (int v = 0; v < 3; ++v) {
             const long long i = v * N + p;
-            const double tot_sm = A.W1a[i] + A.W1b[i] + A.W2[i];
-            th[v] = A.SoilFraction[i] * tot_sm / A.SoilDepthTotal[i];
-            if (A.Theta) A.Theta[i] = th[v];
+            const double tot_sm = ALL ? w1a[v] + w1b[v] + w2[v] : A.W1a[i] + A.W1b[i] + A.W2[i];
+            th[v] = (ALL ? fv[v] : A.SoilFraction[i]) * tot_sm / (ALL ? sdt[v] : A.SoilDepthTotal[i]);
+            if (ALL || A.Theta) A.Theta[i] = th[v];
         }
         const double fsum = (f0 + f1) + f2;
         LF_ST(ThetaAll, (fsum > 0) ? ((th[0] + th[1]) + th[2]) / fsum : 0.0);
     }
-    if (A.SeepTopToSubPixelA) A.SeepTopToSubPixelA[p] = LF_DEF(SeepTopToSubA);
-    if (A.SeepTopToSubPixelB) A.SeepTopToSubPixelB[p] = LF_DEF(SeepTopToSubB);
-    if (A.SeepSubToGWPixel) A.SeepSubToGWPixel[p] = LF_DEF(SeepSubToGW);
-    if (A.Theta1aPixel) A.Theta1aPixel[p] = LF_DEF(Theta1a);
-    if (A.Theta1bPixel) A.Theta1bPixel[p] = LF_DEF(Theta1b);
-    if (A.Theta2Pixel) A.Theta2Pixel[p] = LF_DEF(Theta2);
+    if (ALL || A.SeepTopToSubPixelA) A.SeepTopToSubPixelA[p] = LF_DEF(SeepTopToSubA, t_sa);
+    if (ALL || A.SeepTopToSubPixelB) A.SeepTopToSubPixelB[p] = LF_DEF(SeepTopToSubB, t_sb);
+    if (ALL || A.SeepSubToGWPixel) A.SeepSubToGWPixel[p] = LF_DEF(SeepSubToGW, t_sg);
+    if (ALL || A.Theta1aPixel) A.Theta1aPixel[p] = LF_DEF(Theta1a, t_th1a);
+    if (ALL || A.Theta1bPixel) A.Theta1bPixel[p] = LF_DEF(Theta1b, t_th1b);
+    if (ALL || A.Theta2Pixel) A.Theta2Pixel[p] = LF_DEF(Theta2, t_th2);
     // ---- groundwater.py:137-180 ----
-    double lz = A.LZ[p];
-    double lzout = npmin(A.LowerZoneK[p] * lz, lz - A.LZThreshold[p]);
+    double lz = in_lz;
+    double lzout = npmin(in_lzk * lz, lz - in_lzthr);
     lzout = npmax(lzout, 0.0);
     LF_ST(LZOutflow, lzout);
     lz -= lzout;
-    A.UZOutflowPixel[p] = LF_DEF(UZOutflow);
-    const double perc = LF_DEF(GwPercUZLZ);
+    A.UZOutflowPixel[p] = LF_DEF(UZOutflow, t_uzo);
+    const double perc = LF_DEF(GwPercUZLZ, t_gwp);
     LF_ST(GwPercUZLZPixel, perc);
     lz += perc;
-    const double loss = npmax(npmin(A.GwLossStep[p], lz), 0.0);
+    const double loss = npmax(npmin(in_gwloss, lz), 0.0);
     lz = lz - loss;
     LF_ST(GwLossLZ, loss);
     A.LZ[p] = lz;
-    if (A.LZInflowCUM) {
-        double cum = A.LZInflowCUM[p] + (perc - loss);
+    if (ALL || A.LZInflowCUM) {
+        double cum = (ALL ? c_lzin : A.LZInflowCUM[p]) + (perc - loss);
         cum = npmax(cum, 0.0);
         A.LZInflowCUM[p] = cum;
         LF_ST(LZAvInflow, (cum * A.InvDtDay) / A.TimeSinceStart);
     }
-    if (A.GwLossCUM) A.GwLossCUM[p] += loss;
+    if (ALL) A.GwLossCUM[p] = c_gwloss + loss;
+    else if (A.GwLossCUM) A.GwLossCUM[p] += loss;
     A.LZOutflowToChannelPixel[p] = lzout;
 #undef LF_DEF
 #undef LF_ST
@@ -288,7 +320,19 @@ int lf_pixel_aggregates_device(int device, const lf_pixel_args *a)
         return lf_set_error(LF_E_INVALID, "pixel aggregates: an output is requested whose input vector is NULL");
     lf_device_ctx *c;
     LF_TRY(lf_ctx(device, &c));
-    if (a->N > 0) hipLaunchKernelGGL(k_pixel_aggregates, dim3(blocks_for(a->N)), dim3(kBlock), 0, c->stream, *a);
+    // every optional map reported: the straight-line form with all loads up front (LF_AGG_ALL=0: the block-by-block form)
+    const bool all = a->RainSnowmelt && a->EWaterAct && a->InterSealed && a->TASealed && a->TaInterceptionAll && a->TaInterceptionCUM &&
+                     a->TaPixel && a->TaCUM && a->ESActPixel && a->ESActCUM && a->PrefFlowPixel && a->InfiltrationPixel && a->Theta &&
+                     a->ThetaAll && a->SeepTopToSubPixelA && a->SeepTopToSubPixelB && a->SeepSubToGWPixel && a->Theta1aPixel &&
+                     a->Theta1bPixel && a->Theta2Pixel && a->LZOutflow && a->GwPercUZLZPixel && a->GwLossLZ && a->LZInflowCUM &&
+                     a->LZAvInflow && a->GwLossCUM;
+    const char *e = std::getenv("LF_AGG_ALL");
+    if (a->N > 0) {
+        if (all && !(e && e[0] == '0'))
+            hipLaunchKernelGGL(k_pixel_aggregates<true>, dim3(blocks_for(a->N)), dim3(kBlock), 0, c->stream, *a);
+        else
+            hipLaunchKernelGGL(k_pixel_aggregates<false>, dim3(blocks_for(a->N)), dim3(kBlock), 0, c->stream, *a);
+    }
     LF_HIP(hipGetLastError());
     return LF_OK;
 }
