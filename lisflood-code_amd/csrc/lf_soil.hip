@@ -308,12 +308,18 @@ k_soil_fused(lf_soil_args A, veg_plan P, unsigned short *__restrict__ all_list, 
         // stream of ~70 vectors; memory-level parallelism, not ALU, sets the speed of this phase)
         const double in_rain = A.Rain[pix], in_snow = A.SnowMelt[pix];
         double in_leaf, in_int, in_w1a, in_w1b, in_w1, in_esmax;
+        // CANOPY: what the canopy of the column reads goes out FIRST and in one go (lf_canopy::load), the soil's own ~45
+        // inputs right behind it; the canopy's arithmetic and its stores run while those travel.  (Input by input between
+        // its stores, the canopy used to be a chain of eight dependent round trips in front of the soil's requests.)
+        lf_canopy::column_in cin = {};
+        double c_ewref = 0., c_etref = 0., c_esref = 0.;
+        unsigned char c_frozen = 0;
         if (CANOPY) {
-            const lf_canopy::column_out o = lf_canopy::column(C, veg, pix, i, j, in_rain, C.EWRef[pix], C.ETRef[pix],
-                                                              A.isFrozenSoil[pix] != 0);
-            in_leaf = o.leaf_drainage; in_int = o.interception;
-            in_w1a = o.w1a; in_w1b = o.w1b; in_w1 = o.w1;
-            in_esmax = ESRef[pix] * C.LAITerm[i];                              // soilloop.py:638
+            cin = lf_canopy::load(C, veg, i, j);
+            c_ewref = C.EWRef[pix];
+            c_etref = C.ETRef[pix];
+            c_esref = ESRef[pix];
+            c_frozen = A.isFrozenSoil[pix];
         } else {
             in_leaf = A.LeafDrainage[i]; in_int = A.Interception[i];
             in_w1a = A.W1a[i]; in_w1b = A.W1b[i]; in_w1 = A.W1[i];
@@ -333,6 +339,12 @@ k_soil_fused(lf_soil_args A, veg_plan P, unsigned short *__restrict__ all_list, 
         const double wres1a = A.WRes1a[j], wres1b = A.WRes1b[j], wres2 = A.WRes2[j];
         const double ws1a = A.WS1a[j], ws1b = A.WS1b[j], ws2 = A.WS2[j];
         T.ws1a = ws1a;
+        if (CANOPY) {
+            const lf_canopy::column_out o = lf_canopy::compute(C, veg, pix, i, j, cin, in_rain, c_ewref, c_etref, c_frozen != 0);
+            in_leaf = o.leaf_drainage; in_int = o.interception;
+            in_w1a = o.w1a; in_w1b = o.w1b; in_w1 = o.w1;
+            in_esmax = c_esref * cin.lai_term;                                   // soilloop.py:638
+        }
         const bool is_frozen = A.isFrozenSoil[pix] != 0;
         double im1a, im1b, im2, in_wres1, in_ws1;
         int flags;
