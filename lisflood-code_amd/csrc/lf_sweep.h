@@ -159,7 +159,9 @@ __device__ __forceinline__ void sweep_cell_range(int p, int u0, int u1, const sw
     // (the upstream loads sit behind branches -- a wavefront none of whose lanes has a fourth pair skips that request -- so
     // the compiler cannot count them and waits for ALL loads wherever it needs one: the cell's own values are therefore
     // taken in here, before the upstream requests go out, and the power below then runs with only those in flight)
-    if (FUSED) asm volatile("" : "+v"(qold), "+v"(lat_q));
+    // (pixel-order vectors: the cell's own values are themselves a second trip, behind perm -- the upstream requests go out
+    // with them and one wait takes all of it in)
+    if (FUSED && ORDERED) asm volatile("" : "+v"(qold), "+v"(lat_q));
     if (!INDEXED) {
         // the contiguous upstream run two values per load: four 16-byte loads instead of eight 8-byte ones (the sweep is
         // sensitive to the number of its memory instructions).  The second value of a pair may lie one position behind the
