@@ -149,7 +149,10 @@ constexpr int kClasses = 128;             // trip-count classes of the lists (th
 constexpr int kLoopFields = 7 * 3 + 1;    // per layer: w, wres, ws, ksat, 1/m, m, k; per column: flags (trip count: s_key)
 constexpr int kColsPerWave = 20;          // 3 lanes per column, 5 columns per row of 16 lanes (lane 15 of a row idles)
 constexpr int kTile = 256;                // columns per tile
-constexpr int kStragCap = 24;             // straggler records per tile (more stragglers than that stay in the tile)
+#ifndef LF_STRAG_CAP
+#define LF_STRAG_CAP 48 /* (24 until round 6: see kSoilTripCap) */
+#endif
+constexpr int kStragCap = LF_STRAG_CAP;   // straggler records per tile (more stragglers than that stay in the tile)
 constexpr int kStragFields = 40;          // loop record (22) + trip count + lane + 16 values of phase 3
 constexpr int kStragGroup = 16;           // tiles pooled by one workgroup of k_soil_stragglers
 
@@ -667,7 +670,14 @@ int make_plan(const lf_soil_args *a, const uint8_t *paddy_any, veg_plan *P)
 }
 
 inline int blocks_for(int64_t n) { return (int)((n + kBlock - 1) / kBlock); }
-constexpr int kSoilTripCap = 16; // default of soil_strag::trip_cap
+// default of soil_strag::trip_cap.  Round 6: 6 with 48 straggler records per tile, from 16 with 24.  A tile waits for its
+// heaviest in-tile column while three of its four wavefronts idle, so the cap wants to be low -- but with 24 records a tile of
+// the wet regime (~35 columns above 8 sub-steps) overflowed, the overflow stayed in the tile at up to 92 sub-steps, and a low
+// cap lost there what it won elsewhere (rounds 4-5: "the two regimes want different caps").  With room for 48 the low cap
+// wins in both: soil wet 2.25 -> 2.10 ms per 12 M columns, resident step 5000^2 22.2 -> 21.1 ms (early, wet steps) and
+// 20.0 -> 18.8 ms (later steps), land-surface stage 13.2 -> 11.8 ms; caps 4 / 5 / 6 / 8 within noise of one another, 64
+// records no better than 48.
+constexpr int kSoilTripCap = 6;
 
 } // namespace
 
