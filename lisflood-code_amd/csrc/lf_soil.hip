@@ -154,7 +154,10 @@ constexpr int kTile = 256;                // columns per tile
 #endif
 constexpr int kStragCap = LF_STRAG_CAP;   // straggler records per tile (more stragglers than that stay in the tile)
 constexpr int kStragFields = 40;          // loop record (22) + trip count + lane + 16 values of phase 3
-constexpr int kStragGroup = 16;           // tiles pooled by one workgroup of k_soil_stragglers
+#ifndef LF_STRAG_GROUP
+#define LF_STRAG_GROUP 16
+#endif
+constexpr int kStragGroup = LF_STRAG_GROUP; // tiles pooled by one workgroup of k_soil_stragglers
 
 // value of the lane before / after this one in its row of 16 lanes (DPP row_shr:1 / row_shl:1: a VALU move, no LDS
 // round trip -- the exchange sits on the sub-step loop's dependent chain); first / last lane of a row: 0 (bound_ctrl)
