@@ -196,6 +196,8 @@ int lf_router_route_device_multi(int count, lf_router **routers, double **discha
 int lf_gather_device(int device, int64_t n, const int32_t *index_dev, const double *src_dev, double *dst_dev);
 int lf_router_to_engine_order(lf_router *r, const double *src_pix_dev, double *dst_ord_dev);
 int lf_router_from_engine_order(lf_router *r, const double *src_ord_dev, double *dst_pix_dev);
+/* (The first such call of a router with per-pixel channel lengths builds, per section, a 16-byte (alpha*dx/dt, dx) record per
+ * cell on the device for its wide levels -- 16 N bytes that stay with the router; LF_LEVEL_STATICS=0 keeps the two vectors.) */
 int lf_router_route_ordered(lf_router *r, double *discharge_ord_dev, const double *lateral_ord_dev, int section);
 /* nancheck (kinematic_wave_parallel.py:180-184): number of non-finite entries of a device vector. */
 int lf_count_nonfinite(int device, const double *x_dev, int64_t n, int64_t *count);
@@ -520,7 +522,9 @@ int lf_pixel_aggregates_device(int device, const lf_pixel_args *a);
 /* host-buffer forms (drop-in for the numba kernels; PCIe-inclusive) */
 int lf_interception_host(int device, const lf_interception_args *a);
 int lf_soil_columns_host(int device, const lf_soil_args *a);
-/* device-resident forms: every array pointer is device memory (except the small per-vegetation ones) */
+/* device-resident forms: every array pointer is device memory (except the small per-vegetation ones).  The soil call keeps a
+ * per-device workspace for the columns that leave their tile (above LF_SOIL_TRIP_CAP = 6 Courant sub-steps, up to 48 per
+ * tile of 256 columns): ~15.4 KB per tile = ~60 bytes per column, grow-only, released by lf_device_trim. */
 int lf_interception_device(int device, const lf_interception_args *a);
 int lf_soil_columns_device(int device, const lf_soil_args *a);
 /* The same for a caller that vouches for the relations soil.py:180-228 establishes between its parameter arrays (GenuInvM =
