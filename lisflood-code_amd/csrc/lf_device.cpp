@@ -443,6 +443,10 @@ int lf_device_trim(int device)
     if (c->stage_base) (void)hipFree(c->stage_base);
     c->stage_base = nullptr;
     c->stage_bytes = 0;
+    if (c->soil_ws) (void)hipFree(c->soil_ws); // lists and straggler records of the soil call: rebuilt by the next one
+    c->soil_ws = nullptr;
+    c->soil_ws_bytes = 0;
+    c->soil_ntiles = 0;
     return LF_OK;
 }
 
