@@ -1443,11 +1443,12 @@ def test_soil_columns_small_and_ragged_shapes(amd, oracle, N, V, L):
         a.free()
 
 
-@pytest.mark.parametrize("trip_cap", ["0", "3", "16", "200"])
+@pytest.mark.parametrize("trip_cap", ["0", "1", "3", "6", "200"])
 def test_soil_columns_same_bits_whatever_the_trip_cap(amd, monkeypatch, trip_cap):
-    """Which columns leave their tile for k_soil_stragglers (LF_SOIL_TRIP_CAP: none, nearly all multi-sub-step ones --
-    more than a tile's 24 record slots hold, so the rest stay in the tile --, the default, hardly any) must not change a
-    single bit of any output: in-lane, in-tile and straggler columns run the same arithmetic."""
+    """Which columns leave their tile for k_soil_stragglers (LF_SOIL_TRIP_CAP: none, every multi-sub-step one -- more than
+    a tile's 48 record slots hold, so the rest stay in the tile --, the default 6, the round-5 default 16, hardly any) must not
+    change a single bit of any output: in-lane, in-tile and straggler columns run the same arithmetic.  The device context's
+    workspace (lists, straggler records) is released in between (lf_device_trim) and rebuilt by the next call."""
     from lisflood_amd import synthetic as syn
     N = 30011
     d = syn.soil_params(N, seed=21)
@@ -1462,6 +1463,8 @@ def test_soil_columns_same_bits_whatever_the_trip_cap(amd, monkeypatch, trip_cap
         outs[cap] = {k: dev.get(k) for k in syn.SOIL_WRITTEN}
         for a in dev.dev.values():
             a.free()
+        import ctypes as C
+        amd.lib.check(amd.lib.lib().lf_device_trim(C.c_int(0)))
     for k in syn.SOIL_WRITTEN:
         assert np.array_equal(outs["16"][k], outs[trip_cap][k], equal_nan=True), k
 
