@@ -179,6 +179,50 @@ __device__ __forceinline__ double upstream_sum8_pairs(const double *q, int u0, i
     return ups;
 }
 
+// The run of BOTH router-output vectors of a cell (main channel, floodplain) requested together: eight 16-byte loads go out
+// before any of them is used.  (One sum after the other, the compiler sinks `0.0 + v[0]` into the first load's branch and
+// waits there -- for every load in flight, since loads behind branches cannot be counted -- before it requests the rest:
+// two to four dependent round trips per sub-step of the time-major kernel instead of one.)
+__device__ __forceinline__ void upstream_sum8_pairs2(const double *q1, const double *q2, bool two, int u0, int u1, int kmax,
+                                                     double &s1, double &s2)
+{
+#if LF_FUSED_PAIRS
+    double v1[8], v2[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        double2 t = make_double2(0.0, 0.0);
+        if (2 * j < kmax && u0 + 2 * j < u1) t = *(const double2 *)(q1 + u0 + 2 * j);
+        v1[2 * j] = t.x;
+        v1[2 * j + 1] = t.y;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        double2 t = make_double2(0.0, 0.0);
+        if (two && 2 * j < kmax && u0 + 2 * j < u1) t = *(const double2 *)(q2 + u0 + 2 * j);
+        v2[2 * j] = t.x;
+        v2[2 * j + 1] = t.y;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(v1[k]), "+v"(v2[k]));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bool have = u0 + 2 * j + 1 < u1;
+        v1[2 * j + 1] = have ? v1[2 * j + 1] : 0.0;
+        v2[2 * j + 1] = have ? v2[2 * j + 1] : 0.0;
+    }
+    double a = 0.0, b = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a += v1[k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) b += v2[k];
+    s1 = a;
+    s2 = two ? b : 0.0;
+#else
+    s1 = upstream_sum8_pairs(q1, u0, u1, kmax);
+    s2 = two ? upstream_sum8_pairs(q2, u0, u1, kmax) : 0.0;
+#endif
+}
+
 __device__ __forceinline__ double upstream_sum8(const double *q, int u0, int u1, int kmax)
 {
     double v[8];
@@ -888,8 +932,13 @@ __global__ void __launch_bounds__(kBlock) LF_TM_ATTR k_fused_level_steps(fused_a
     double side_m3 = fused_side(F, s0)[p];
     sum = fused_sum(F, s0)[p];
     for (int s = s0; s < nsteps; ++s) {
-        const double ups1 = ups_of(F.hist1, F.root1, s);
-        const double ups2 = SPLIT ? ups_of(F.hist2, F.root2, s) : 0.0;
+        double ups1, ups2;
+        if (!DIST) {
+            upstream_sum8_pairs2(F.hist1 + (long long)s * n, F.hist2 + (long long)s * n, SPLIT, u0, u1, kmax, ups1, ups2);
+        } else {
+            ups1 = ups_of(F.hist1, F.root1, s);
+            ups2 = SPLIT ? ups_of(F.hist2, F.root2, s) : 0.0;
+        }
         const bool first_of_step = s % F.msteps == 0;
         if ((F.side_stride != 0 || first_of_step) && s > s0) side_m3 = fused_side(F, s)[p];
         if (first_of_step && s > s0) sum = fused_sum(F, s)[p]; // the next model step's sum (zeroed by the caller)
@@ -1158,8 +1207,12 @@ __global__ void __launch_bounds__(CW) __attribute__((amdgpu_waves_per_eu(LF_CONE
                     for (int k = 0; k < 8; ++k) ups2 += v2[k];
                 }
             } else if (j == 0) { // from the block before (previous launch) through the parity buffers
-                ups1 = DIST ? upstream_sum8(F.qr1 + par, cu0, cu1, kmax) : upstream_sum8_pairs(F.qr1 + par, cu0, cu1, kmax);
-                if (SPLIT) ups2 = DIST ? upstream_sum8(F.qr2 + par, cu0, cu1, kmax) : upstream_sum8_pairs(F.qr2 + par, cu0, cu1, kmax);
+                if (DIST) {
+                    ups1 = upstream_sum8(F.qr1 + par, cu0, cu1, kmax);
+                    if (SPLIT) ups2 = upstream_sum8(F.qr2 + par, cu0, cu1, kmax);
+                } else {
+                    upstream_sum8_pairs2(F.qr1 + par, F.qr2 + par, SPLIT, cu0, cu1, kmax, ups1, ups2);
+                }
             } else { // from LDS, branch-free: absent neighbours read the slot that holds 0.0 (the sum as upstream_sum8)
                 const double *y1 = &x1[(j - 1) & 1][0], *y2 = &x2[SPLIT ? (j - 1) & 1 : 0][0];
                 const int base = cu0 - first_up;
