@@ -177,8 +177,15 @@ __device__ __forceinline__ void sweep_cell_range(int p, int u0, int u1, const sw
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = (k < A.kmax && u0 + k < u1) ? A.qord[base + k] : 0.0;
     } else { // ghost or cross-phase inflow: positions from the list (a second, dependent load)
+        // (all list entries first, then all discharges: entry by entry the compiler waits for every load in flight before each
+        // dependent one -- sixteen round trips in a row for a wavefront with one such lane)
+        int e[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = (k < A.kmax && u0 + k < u1) ? A.qord[A.ups_idx[u0 + k]] : 0.0;
+        for (int k = 0; k < 8; ++k) e[k] = (k < A.kmax && u0 + k < u1) ? A.ups_idx[u0 + k] : 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(e[k]));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (k < A.kmax && u0 + k < u1) ? A.qord[e[k]] : 0.0;
     }
     double cst;
     if (FUSED) {
