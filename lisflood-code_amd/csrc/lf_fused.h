@@ -931,6 +931,9 @@ __global__ void __launch_bounds__(kBlock) LF_TM_ATTR k_fused_level_steps(fused_a
     double v = 0, q = 0, chanq = 0, s1 = 0, v2 = 0, q2 = 0;
     double side_m3 = fused_side(F, s0)[p];
     sum = fused_sum(F, s0)[p];
+    // position of the sub-step inside its model step, counted along (s starts per lane -- inert cells run only the last
+    // sub-step -- so `s % msteps` would be a vector-register division, ~25 instructions, twice per sub-step)
+    int sm = s0 % F.msteps;
     for (int s = s0; s < nsteps; ++s) {
         double ups1, ups2;
         if (!DIST) {
@@ -939,7 +942,7 @@ __global__ void __launch_bounds__(kBlock) LF_TM_ATTR k_fused_level_steps(fused_a
             ups1 = ups_of(F.hist1, F.root1, s);
             ups2 = SPLIT ? ups_of(F.hist2, F.root2, s) : 0.0;
         }
-        const bool first_of_step = s % F.msteps == 0;
+        const bool first_of_step = sm == 0;
         if ((F.side_stride != 0 || first_of_step) && s > s0) side_m3 = fused_side(F, s)[p];
         if (first_of_step && s > s0) sum = fused_sum(F, s)[p]; // the next model step's sum (zeroed by the caller)
         // ---- sideflow (routing.py:512, 524 / 549-567) ----
@@ -1010,7 +1013,9 @@ __global__ void __launch_bounds__(kBlock) LF_TM_ATTR k_fused_level_steps(fused_a
         m3 = v;
         qold = q;
         sum = sum + chanq;
-        if (fused_last(F, s) && s != nsteps - 1) fused_sum(F, s)[p] = sum; // a model step inside the call is complete
+        const bool last_of_step = sm + 1 == F.msteps; // fused_last(F, s)
+        if (last_of_step && s != nsteps - 1) fused_sum(F, s)[p] = sum; // a model step inside the call is complete
+        sm = last_of_step ? 0 : sm + 1;
         if (SPLIT) {
             m3_2 = v2;
             q2old = q2;
